@@ -1,0 +1,279 @@
+"""CPU oracle model for the Qwen3-TTS speech-LM decode path, composed from oracle/voxref.c primitives.
+
+TEST INFRASTRUCTURE ONLY (see oracle/voxref.c header).  Follows, step by step:
+  Qwen3TTSModel.forward            /root/reference/vox_serve/model/qwen3_tts.py:1805-1861
+  Qwen3TTSDecoderLayer / Attention / MLP                           qwen3_tts.py:573-704
+  Qwen3TTSModel.sampling           qwen3_tts.py:1863-1962   (greedy / seeded sampler contract)
+  run_lm_depth + depth_forward + depth_sampling   worker/base.py:546-614, qwen3_tts.py:923-944,1964-2004
+  ModelWorker.prepare_lm_inputs page/position bookkeeping          worker/base.py:210-360 (incl. quirk Q1)
+Weights use the reference's state_dict names so the same dict loads into the reference nn.Module.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import voxref as vr
+
+
+@dataclass
+class StackCfg:
+    hidden: int
+    layers: int
+    heads: int
+    kv_heads: int
+    head_dim: int
+    ffn: int
+    eps: float = 1e-6
+    rope_theta: float = 1e6
+    rope_scale: float = 1.0
+    rope_dim: Optional[int] = None
+    rope_interleave: bool = False
+    rope_llama31: Optional[tuple] = None      # (low, high, old_ctx)
+    qk_norm: bool = True
+    qkv_bias: bool = False
+
+
+@dataclass
+class Qwen3Cfg:
+    talker: StackCfg = field(default_factory=lambda: StackCfg(2048, 28, 16, 8, 128, 6144))
+    depth: StackCfg = field(default_factory=lambda: StackCfg(1024, 5, 16, 8, 128, 3072))
+    vocab: int = 3072
+    text_vocab: int = 151936
+    text_hidden: int = 2048
+    depth_vocab: int = 2048
+    n_groups: int = 16
+    eos_id: int = 2150
+    tts_pad_id: int = 151671
+    max_pos: int = 4096
+
+    @property
+    def suppress_ids(self):
+        return [i for i in range(self.vocab - 1024, self.vocab) if i != self.eos_id]
+
+
+def tiny_cfg() -> Qwen3Cfg:
+    """Small config with the same structure (all dims multiples of 8) for fast parity tests."""
+    return Qwen3Cfg(talker=StackCfg(256, 2, 4, 2, 64, 512), depth=StackCfg(128, 2, 4, 2, 64, 256),
+                    vocab=1280, text_vocab=512, text_hidden=256, depth_vocab=256, n_groups=4, eos_id=300,
+                    tts_pad_id=7, max_pos=512)
+
+
+def random_weights(cfg: Qwen3Cfg, seed: int = 0, std: float = 0.02) -> Dict[str, np.ndarray]:
+    """N(0, std^2) bf16 weights, norm weights 1 (SURVEY §8d synthetic recipe); reference state_dict names."""
+    rng = np.random.default_rng(seed)
+
+    def w(*shape, s=std):
+        return vr.f2bf((rng.standard_normal(shape, dtype=np.float32) * np.float32(s)))
+
+    def ones(n):
+        return vr.f2bf(np.ones(n, np.float32))
+
+    W: Dict[str, np.ndarray] = {}
+
+    def stack(prefix, c: StackCfg):
+        for i in range(c.layers):
+            p = f"{prefix}.layers.{i}."
+            W[p + "self_attn.q_proj.weight"] = w(c.heads * c.head_dim, c.hidden)
+            W[p + "self_attn.k_proj.weight"] = w(c.kv_heads * c.head_dim, c.hidden)
+            W[p + "self_attn.v_proj.weight"] = w(c.kv_heads * c.head_dim, c.hidden)
+            W[p + "self_attn.o_proj.weight"] = w(c.hidden, c.heads * c.head_dim)
+            W[p + "self_attn.q_norm.weight"] = ones(c.head_dim)
+            W[p + "self_attn.k_norm.weight"] = ones(c.head_dim)
+            W[p + "mlp.gate_proj.weight"] = w(c.ffn, c.hidden)
+            W[p + "mlp.up_proj.weight"] = w(c.ffn, c.hidden)
+            W[p + "mlp.down_proj.weight"] = w(c.hidden, c.ffn)
+            W[p + "input_layernorm.weight"] = ones(c.hidden)
+            W[p + "post_attention_layernorm.weight"] = ones(c.hidden)
+        W[prefix + ".norm.weight"] = ones(c.hidden)
+
+    H = cfg.talker.hidden
+    stack("talker.model", cfg.talker)
+    W["talker.model.codec_embedding.weight"] = w(cfg.vocab, H)
+    W["talker.model.text_embedding.weight"] = w(cfg.text_vocab, cfg.text_hidden)
+    W["talker.text_projection.linear_fc1.weight"] = w(cfg.text_hidden, cfg.text_hidden)
+    W["talker.text_projection.linear_fc1.bias"] = w(cfg.text_hidden)
+    W["talker.text_projection.linear_fc2.weight"] = w(H, cfg.text_hidden)
+    W["talker.text_projection.linear_fc2.bias"] = w(H)
+    W["talker.codec_head.weight"] = w(cfg.vocab, H)
+    stack("talker.code_predictor.model", cfg.depth)
+    for j in range(cfg.n_groups - 1):
+        W[f"talker.code_predictor.model.codec_embedding.{j}.weight"] = w(cfg.depth_vocab, H)
+        W[f"talker.code_predictor.lm_head.{j}.weight"] = w(cfg.depth_vocab, cfg.depth.hidden)
+    W["talker.code_predictor.small_to_mtp_projection.weight"] = w(cfg.depth.hidden, H)
+    W["talker.code_predictor.small_to_mtp_projection.bias"] = w(cfg.depth.hidden)
+    return W
+
+
+class RefStack:
+    """Decoder stack (qwen3_tts.py:611-739) over a paged KV cache [L][P,2,page,Hkv,D]."""
+
+    def __init__(self, c: StackCfg, W, prefix, max_pos):
+        self.c, self.W, self.p = c, W, prefix
+        self.cs = vr.rope_table(max_pos, c.rope_dim or c.head_dim, c.rope_theta, c.rope_scale, c.rope_llama31)
+
+    def forward(self, x, pos, kv, q_req, q_kvlen, indptr, indices, page, slot, final_norm=True):
+        c, W = self.c, self.W
+        N = x.shape[0]
+        for i in range(c.layers):
+            p = f"{self.p}.layers.{i}."
+            h = vr.rmsnorm(x, W[p + "input_layernorm.weight"], c.eps)
+            q = vr.linear(W[p + "self_attn.q_proj.weight"], h, W.get(p + "self_attn.q_proj.bias"))
+            k = vr.linear(W[p + "self_attn.k_proj.weight"], h, W.get(p + "self_attn.k_proj.bias"))
+            v = vr.linear(W[p + "self_attn.v_proj.weight"], h, W.get(p + "self_attn.v_proj.bias"))
+            if c.qk_norm:
+                q = vr.rmsnorm(q.reshape(-1, c.head_dim), W[p + "self_attn.q_norm.weight"], c.eps)
+                k = vr.rmsnorm(k.reshape(-1, c.head_dim), W[p + "self_attn.k_norm.weight"], c.eps)
+            q = vr.rope(q.reshape(N, c.heads, c.head_dim), pos, self.cs, c.rope_dim, c.rope_interleave)
+            k = vr.rope(k.reshape(N, c.kv_heads, c.head_dim), pos, self.cs, c.rope_dim, c.rope_interleave)
+            vr.kv_append(kv[i], k, v.reshape(N, c.kv_heads, c.head_dim), page, slot)
+            a = vr.paged_attention(q, kv[i], q_req, q_kvlen, indptr, indices)
+            x = vr.linear(W[p + "self_attn.o_proj.weight"], a.reshape(N, -1), residual=x)
+            h = vr.rmsnorm(x, W[p + "post_attention_layernorm.weight"], c.eps)
+            g = vr.linear_silu_mul(W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"], h)
+            x = vr.linear(W[p + "mlp.down_proj.weight"], g, residual=x)
+        return vr.rmsnorm(x, W[self.p + ".norm.weight"], c.eps) if final_norm else x
+
+
+@dataclass
+class RefRequest:
+    """Mirror of the KV / position bookkeeping fields of vox_serve.requests.Request (requests.py:12-77)."""
+    kv_pages: List[int] = field(default_factory=list)
+    kv_token_len: int = 0
+    kv_last_page_len: int = 0
+    next_position_id: int = 0
+    input_ids: np.ndarray = None       # [1, n_groups+1] int32
+    input_mask: bool = True
+    input_features: np.ndarray = None  # [1,H] bf16 bits
+    frames: List[np.ndarray] = field(default_factory=list)
+
+
+class Qwen3Ref:
+    def __init__(self, cfg: Qwen3Cfg, W, page_size=128, max_pages=64, max_batch=8):
+        self.cfg, self.W, self.page_size = cfg, W, page_size
+        t, d = cfg.talker, cfg.depth
+        self.talker = RefStack(t, W, "talker.model", cfg.max_pos)
+        self.depth = RefStack(d, W, "talker.code_predictor.model", 64)
+        self.kv = [np.zeros((max_pages, 2, page_size, t.kv_heads, t.head_dim), np.uint16) for _ in range(t.layers)]
+        # depth KV: one page of n_groups slots per batch row (worker/base.py:196-205)
+        self.dkv = [np.zeros((max_batch, 2, cfg.n_groups, d.kv_heads, d.head_dim), np.uint16)
+                    for _ in range(d.layers)]
+        self.free_pages = list(range(max_pages))
+
+    # ---- embedding mix (qwen3_tts.py:1836-1852) ----
+    def embed(self, input_ids, masks, feats):
+        W = self.W
+        te = vr.gather(W["talker.model.text_embedding.weight"], input_ids[:, -1])
+        h = vr.linear(W["talker.text_projection.linear_fc1.weight"], te, W["talker.text_projection.linear_fc1.bias"])
+        h = vr.silu(h)
+        text = vr.linear(W["talker.text_projection.linear_fc2.weight"], h, W["talker.text_projection.linear_fc2.bias"])
+        codec = vr.gather(W["talker.model.codec_embedding.weight"], input_ids[:, 0])
+        return vr.qwen3_mix(text, codec, masks, feats)
+
+    # ---- prefill of one request (worker/base.py:253-300) ----
+    def prefill(self, req: RefRequest, input_ids, masks, feats):
+        n = input_ids.shape[0]
+        ps = self.page_size
+        npg = (n + ps - 1) // ps
+        req.kv_pages = [self.free_pages.pop(0) for _ in range(npg)]
+        req.kv_token_len = n
+        req.kv_last_page_len = n % ps or ps
+        req.next_position_id = n + 1                       # quirk Q1 (worker/base.py:299)
+        pos = np.arange(n, dtype=np.int32)
+        x = self.embed(input_ids, masks, feats)
+        indptr, indices = np.array([0, npg], np.int32), np.array(req.kv_pages, np.int32)
+        page = np.array([req.kv_pages[t // ps] for t in range(n)], np.int32)
+        slot = np.array([t % ps for t in range(n)], np.int32)
+        hid = self.talker.forward(x, pos, self.kv, np.zeros(n, np.int32), np.arange(1, n + 1, dtype=np.int32),
+                                  indptr, indices, page, slot)
+        logits = vr.linear(self.W["talker.codec_head.weight"], hid[-1:])
+        return logits, hid[-1:]
+
+    # ---- one decode step for a batch (worker/base.py:302-325 + qwen3_tts.py:1805-1861) ----
+    def decode(self, reqs: List[RefRequest]):
+        ps = self.page_size
+        B = len(reqs)
+        indptr, indices, page, slot, pos, kvlen = [0], [], [], [], [], []
+        for r in reqs:
+            r.kv_token_len += 1
+            r.kv_last_page_len += 1
+            if r.kv_last_page_len > ps:
+                r.kv_pages.append(self.free_pages.pop(0))
+                r.kv_last_page_len = 1
+            indptr.append(indptr[-1] + len(r.kv_pages))
+            indices.extend(r.kv_pages)
+            page.append(r.kv_pages[-1])
+            slot.append(r.kv_last_page_len - 1)
+            pos.append(r.next_position_id)
+            kvlen.append(r.kv_token_len)
+            r.next_position_id += 1
+        ids = np.concatenate([r.input_ids for r in reqs], 0)
+        masks = np.array([r.input_mask for r in reqs], np.uint8)
+        feats = np.concatenate([r.input_features for r in reqs], 0)
+        x = self.embed(ids, masks, feats)
+        hid = self.talker.forward(x, np.array(pos, np.int32), self.kv, np.arange(B, dtype=np.int32),
+                                  np.array(kvlen, np.int32), np.array(indptr, np.int32),
+                                  np.array(indices, np.int32), np.array(page, np.int32), np.array(slot, np.int32))
+        logits = vr.linear(self.W["talker.codec_head.weight"], hid)
+        return logits, hid
+
+    # ---- sampling of codebook 0 (qwen3_tts.py:1863-1925) ----
+    def sample0(self, logits, sampler=None):
+        logits = vr.suppress(logits, self.cfg.suppress_ids)
+        # repetition penalty is an identity for Qwen3 (quirk Q3: cache never persisted) -> op kept, mask empty
+        return (vr.argmax(logits) if sampler is None else sampler(logits, 0)), logits
+
+    # ---- depth loop (worker/base.py:546-614; qwen3_tts.py:923-944, 1981-2004) ----
+    def depth_loop(self, hid, c0, sampler=None):
+        cfg, W = self.cfg, self.W
+        B = hid.shape[0]
+        for l in self.dkv:
+            l[:] = 0
+        out = np.zeros((B, cfg.n_groups + 1), np.int32)
+        out[:, 0] = c0
+        out[:, -1] = cfg.tts_pad_id
+        c0e = vr.gather(W["talker.model.codec_embedding.weight"], c0)
+        feats = np.zeros((B, cfg.talker.hidden), np.uint16)          # req.input_features = zeros (qwen3_tts.py:1944)
+        indptr = np.arange(B + 1, dtype=np.int32)
+        indices = np.arange(B, dtype=np.int32)
+        all_logits = []
+        for i in range(1, cfg.n_groups):
+            if i == 1:
+                x = np.stack([hid, c0e], 1).reshape(2 * B, -1)
+                pos = np.tile(np.array([0, 1], np.int32), B)
+                q_req = np.repeat(np.arange(B, dtype=np.int32), 2)
+                q_kvlen = np.tile(np.array([1, 2], np.int32), B)
+                slot = pos.copy()
+            else:
+                pos = np.full(B, i, np.int32)
+                q_req = np.arange(B, dtype=np.int32)
+                q_kvlen = np.full(B, i + 1, np.int32)
+                slot = pos.copy()
+            x = vr.linear(W["talker.code_predictor.small_to_mtp_projection.weight"], x,
+                          W["talker.code_predictor.small_to_mtp_projection.bias"])
+            h = self.depth.forward(x, pos, self.dkv, q_req, q_kvlen, indptr, indices, q_req.copy(), slot)
+            if i == 1:
+                h = h[1::2]
+            logits = vr.linear(W[f"talker.code_predictor.lm_head.{i - 1}.weight"], h)
+            all_logits.append(logits)
+            ids = vr.argmax(logits) if sampler is None else sampler(logits, i)
+            out[:, i] = ids
+            x = vr.gather(W[f"talker.code_predictor.model.codec_embedding.{i - 1}.weight"], ids)
+            feats = vr.add(feats, x)                                  # req.input_features[:] += ci_embed
+        return out, feats, all_logits
+
+    # ---- one full frame for a batch of already-prefilled requests ----
+    def frame(self, reqs: List[RefRequest], first_logits=None, first_hidden=None, sampler=None):
+        if first_logits is None:
+            logits, hid = self.decode(reqs)
+        else:
+            logits, hid = first_logits, first_hidden
+        c0, masked = self.sample0(logits, sampler)
+        out, feats, dl = self.depth_loop(hid, c0, sampler)
+        for b, r in enumerate(reqs):
+            ids = np.zeros((1, self.cfg.n_groups + 1), np.int32)
+            ids[0, 0] = c0[b]
+            ids[0, -1] = self.cfg.tts_pad_id
+            r.input_ids, r.input_mask, r.input_features = ids, True, feats[b:b + 1].copy()
+            r.frames.append(out[b].copy())
+        return out, masked, hid, dl

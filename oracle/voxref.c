@@ -1,0 +1,447 @@
+/*
+ * oracle/voxref.c — CPU restatement of the vox-serve speech-LM hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under vox_serve_amd/ links, imports or calls this file; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it (as the checker / the
+ * timed CPU baseline), never as the product path.
+ *
+ * What it restates (reference file:line under /root/reference):
+ *   vr_rmsnorm        flashinfer.norm.rmsnorm via rms_norm            vox_serve/flashinfer_utils.py:251-267
+ *   vr_rope*          flashinfer.rope.apply_[llama31_]rope_pos_ids    vox_serve/flashinfer_utils.py:270-324
+ *   vr_kv_append      Flashinfer{Decode,Prefill}Wrapper.set_kv_cache  vox_serve/flashinfer_utils.py:134-145,232-244
+ *   vr_paged_attention Batch{Decode,Prefill}WithPagedKVCacheWrapper.run vox_serve/flashinfer_utils.py:127-132,228-230
+ *   vr_linear / vr_linear_silu_mul / vr_add   nn.Linear + SiLU gate + residual
+ *                                             vox_serve/model/qwen3_tts.py:562-575,590-601,678-704
+ *   vr_suppress / vr_rep_penalty / vr_rep_update / vr_argmax / vr_sample
+ *                                             vox_serve/sampling.py:21-178, model/qwen3_tts.py:1894-1895
+ *
+ * flashinfer-python 0.2.11.post1 (pyproject.toml:36) is a third-party CUDA wheel whose source is not
+ * in the reference tree; its arithmetic is restated from the published contracts.
+ * Pinning: tests/test_oracle_goldens.py checks every function here against fixtures captured from the
+ * reference's own Python (tests/golden/make_goldens.py) to bf16 tolerance.  The stochastic samplers'
+ * RNG stream is flashinfer-internal => "parity unpinned" for the draws themselves (support set and
+ * probabilities are pinned).
+ *
+ * NUMERIC CONTRACT ("canonical order").  Storage bf16, arithmetic fp32, one RNE rounding to bf16 per
+ * reference tensor op.  Every reduction has a FIXED order, chosen so that a wave64 GPU kernel can
+ * reproduce it bit-for-bit independent of grid shape and batch size:
+ *   DOT(w,x,K):  K/8 chunks of 8 elements; chunk c belongs to lane c%64; a lane accumulates its chunks
+ *                in increasing c, 8 sequential fmaf per chunk; then an xor-butterfly over 64 lanes
+ *                (offsets 32,16,8,4,2,1; s = s + s_partner).
+ *   EXP2(x):     n=rint(x), f=x-n, degree-7 Horner (fmaf) of 2^f, exponent add; x<=-125 -> 0.
+ *   attention:   KV split in chunks of 32 tokens; per chunk scores=DOT*scale, local max, p=EXP2,
+ *                l and o accumulated sequentially in token order; chunks merged sequentially in chunk
+ *                order against the global max.
+ * No -ffast-math, no contraction: build with -ffp-contract=off (see Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint16_t bf16;
+
+#define VR_TC 32 /* attention chunk (tokens) */
+#define VR_LOG2E 1.44269504088896340736f
+
+static inline float bf2f(bf16 h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline bf16 f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16)((u >> 16) | 0x40); /* quiet NaN */
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16)(u >> 16);
+}
+
+float vr_exp2(float x) {
+    if (!(x > -125.0f)) return 0.0f;
+    if (x >= 128.0f) return INFINITY;
+    float n = rintf(x);
+    float f = x - n;
+    float p = 1.52527338e-5f;          /* ln2^7/7! */
+    p = fmaf(p, f, 1.54035304e-4f);    /* ln2^6/6! */
+    p = fmaf(p, f, 1.33335581e-3f);    /* ln2^5/5! */
+    p = fmaf(p, f, 9.61812911e-3f);    /* ln2^4/4! */
+    p = fmaf(p, f, 5.55041087e-2f);    /* ln2^3/3! */
+    p = fmaf(p, f, 2.40226507e-1f);    /* ln2^2/2! */
+    p = fmaf(p, f, 6.93147181e-1f);    /* ln2 */
+    p = fmaf(p, f, 1.0f);
+    int32_t u;
+    memcpy(&u, &p, 4);
+    u += ((int32_t)n) << 23;
+    memcpy(&p, &u, 4);
+    return p;
+}
+
+static inline void butterfly64(float* s) {
+    float t[64];
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; ++l) t[l] = s[l] + s[l ^ off];
+        memcpy(s, t, sizeof(t));
+    }
+}
+
+/* canonical dot of two bf16 vectors, K % 8 == 0 */
+static float dot_bb(const bf16* w, const bf16* x, int K) {
+    float s[64];
+    for (int l = 0; l < 64; ++l) s[l] = 0.0f;
+    int nch = K >> 3;
+    for (int c = 0; c < nch; ++c) {
+        float a = s[c & 63];
+        const bf16* wp = w + 8 * c;
+        const bf16* xp = x + 8 * c;
+        for (int i = 0; i < 8; ++i) a = fmaf(bf2f(wp[i]), bf2f(xp[i]), a);
+        s[c & 63] = a;
+    }
+    butterfly64(s);
+    return s[0];
+}
+
+/* canonical sum of squares (same lane partition) */
+static float sumsq_b(const bf16* x, int K) {
+    float s[64];
+    for (int l = 0; l < 64; ++l) s[l] = 0.0f;
+    int nch = K >> 3;
+    for (int c = 0; c < nch; ++c) {
+        float a = s[c & 63];
+        for (int i = 0; i < 8; ++i) {
+            float v = bf2f(x[8 * c + i]);
+            a = fmaf(v, v, a);
+        }
+        s[c & 63] = a;
+    }
+    butterfly64(s);
+    return s[0];
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* y[b,n] = bf16( DOT(W[n,:], x[b,:]) + bias[n] ); optional residual: y = bf16(res + y)               */
+void vr_linear(const bf16* W, const bf16* bias, const bf16* x, const bf16* residual, bf16* y, int B, int N,
+               int K) {
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        for (int b = 0; b < B; ++b) {
+            float a = dot_bb(W + (size_t)n * K, x + (size_t)b * K, K);
+            if (bias) a = a + bf2f(bias[n]);
+            bf16 r = f2bf(a);
+            if (residual) r = f2bf(bf2f(residual[(size_t)b * N + n]) + bf2f(r));
+            y[(size_t)b * N + n] = r;
+        }
+    }
+}
+
+static inline float silu_c(float g) {
+    float e = vr_exp2((-g) * VR_LOG2E);
+    return g / (1.0f + e);
+}
+
+/* h[b,n] = bf16( bf16(silu(bf16(gate))) * bf16(up) )   (qwen3_tts.py:573-575) */
+void vr_linear_silu_mul(const bf16* Wg, const bf16* Wu, const bf16* x, bf16* h, int B, int N, int K) {
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        for (int b = 0; b < B; ++b) {
+            bf16 g = f2bf(dot_bb(Wg + (size_t)n * K, x + (size_t)b * K, K));
+            bf16 u = f2bf(dot_bb(Wu + (size_t)n * K, x + (size_t)b * K, K));
+            bf16 a = f2bf(silu_c(bf2f(g)));
+            h[(size_t)b * N + n] = f2bf(bf2f(a) * bf2f(u));
+        }
+    }
+}
+
+/* y = bf16(silu(x)) elementwise (text_projection act, qwen3_tts.py:666-675) */
+void vr_silu(const bf16* x, bf16* y, long n) {
+    for (long i = 0; i < n; ++i) y[i] = f2bf(silu_c(bf2f(x[i])));
+}
+
+void vr_add(const bf16* a, const bf16* b, bf16* y, long n) {
+    for (long i = 0; i < n; ++i) y[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+
+/* flashinfer rmsnorm: y = bf16( x * rsqrt(mean(x^2)+eps) * w ) */
+void vr_rmsnorm(const bf16* x, const bf16* w, bf16* y, int R, int H, float eps) {
+    for (int r = 0; r < R; ++r) {
+        const bf16* xr = x + (size_t)r * H;
+        float ss = sumsq_b(xr, H);
+        float rinv = 1.0f / sqrtf(ss / (float)H + eps);
+        for (int i = 0; i < H; ++i) y[(size_t)r * H + i] = f2bf((bf2f(xr[i]) * rinv) * bf2f(w[i]));
+    }
+}
+
+/* cos/sin table: cs[pos][i] = {cos, sin}(pos * f_i), i < rot/2.  llama31: HF "llama3" scaling. */
+void vr_rope_table(float* cs, int max_pos, int rot, double theta, double scale, int llama31, double lo,
+                   double hi, int old_ctx) {
+    int half = rot / 2;
+    for (int i = 0; i < half; ++i) {
+        double f = 1.0 / pow(theta, (double)(2 * i) / (double)rot);
+        if (llama31) {
+            double smooth = (f * old_ctx / (2.0 * M_PI) - lo) / (hi - lo);
+            if (smooth < 0) smooth = 0;
+            if (smooth > 1) smooth = 1;
+            f = (1.0 - smooth) * (f / scale) + smooth * f;
+        } else {
+            f = f / scale;
+        }
+        float ff = (float)f;
+        for (int p = 0; p < max_pos; ++p) {
+            float ang = (float)p * ff;
+            cs[((size_t)p * half + i) * 2 + 0] = (float)cos((double)ang);
+            cs[((size_t)p * half + i) * 2 + 1] = (float)sin((double)ang);
+        }
+    }
+}
+
+/* in-place rotary on x[N,H,D]; pairs (i, i+rot/2) (NeoX) or (2i,2i+1) (interleave) */
+void vr_rope(bf16* x, const int* pos, int N, int H, int D, int rot, int interleave, const float* cs) {
+    int half = rot / 2;
+    for (int n = 0; n < N; ++n) {
+        const float* t = cs + (size_t)pos[n] * half * 2;
+        for (int h = 0; h < H; ++h) {
+            bf16* v = x + ((size_t)n * H + h) * D;
+            for (int i = 0; i < half; ++i) {
+                int ia = interleave ? 2 * i : i, ib = interleave ? 2 * i + 1 : i + half;
+                float a = bf2f(v[ia]), b = bf2f(v[ib]), c = t[2 * i], s = t[2 * i + 1];
+                float ra = fmaf(-b, s, a * c);
+                float rb = fmaf(a, s, b * c);
+                v[ia] = f2bf(ra);
+                v[ib] = f2bf(rb);
+            }
+        }
+    }
+}
+
+/* kv[page,0/1,slot,h,:] = k/v[n,h,:]   (kv layout [P,2,page_size,Hkv,D]); page<0 rows are skipped */
+void vr_kv_append(bf16* kv, const bf16* k, const bf16* v, const int* page, const int* slot, int N, int page_size,
+                  int Hkv, int D) {
+    size_t ps = (size_t)2 * page_size * Hkv * D;
+    for (int n = 0; n < N; ++n) {
+        if (page[n] < 0) continue;
+        bf16* base = kv + (size_t)page[n] * ps;
+        memcpy(base + ((size_t)slot[n]) * Hkv * D, k + (size_t)n * Hkv * D, sizeof(bf16) * Hkv * D);
+        memcpy(base + ((size_t)page_size + slot[n]) * Hkv * D, v + (size_t)n * Hkv * D, sizeof(bf16) * Hkv * D);
+    }
+}
+
+/*
+ * Paged GQA attention for a list of query rows.  Row i belongs to request q_req[i] and sees the first
+ * q_kvlen[i] tokens of that request's KV (decode: kvlen = full length; causal prefill: n-m+i+1).
+ * Token t of request r lives at (indices[indptr[r] + t/page], t%page).
+ */
+void vr_paged_attention(const bf16* q, const bf16* kv, const int* q_req, const int* q_kvlen, const int* indptr,
+                        const int* indices, int Nq, int Hq, int Hkv, int D, int page_size, float scale, bf16* out) {
+    size_t ps = (size_t)2 * page_size * Hkv * D;
+    int G = Hq / Hkv;
+#pragma omp parallel for schedule(dynamic) collapse(2)
+    for (int i = 0; i < Nq; ++i) {
+        for (int h = 0; h < Hq; ++h) {
+            int r = q_req[i], L = q_kvlen[i], hk = h / G;
+            const bf16* qh = q + ((size_t)i * Hq + h) * D;
+            int nchunk = (L + VR_TC - 1) / VR_TC;
+            float* mc = (float*)malloc(sizeof(float) * (size_t)nchunk * (D + 2));
+            float* lc = mc + nchunk;
+            float* oc = lc + nchunk;
+            for (int c = 0; c < nchunk; ++c) {
+                int t0 = c * VR_TC, t1 = t0 + VR_TC < L ? t0 + VR_TC : L;
+                float s[VR_TC], m = -INFINITY;
+                for (int t = t0; t < t1; ++t) {
+                    const bf16* kp = kv + (size_t)indices[indptr[r] + t / page_size] * ps +
+                                     ((size_t)(t % page_size) * Hkv + hk) * D;
+                    s[t - t0] = dot_bb(qh, kp, D) * scale;
+                    if (s[t - t0] > m) m = s[t - t0];
+                }
+                float l = 0.0f;
+                float* o = oc + (size_t)c * D;
+                for (int d = 0; d < D; ++d) o[d] = 0.0f;
+                for (int t = t0; t < t1; ++t) {
+                    float p = vr_exp2((s[t - t0] - m) * VR_LOG2E);
+                    l = l + p;
+                    const bf16* vp = kv + (size_t)indices[indptr[r] + t / page_size] * ps +
+                                     ((size_t)(page_size + t % page_size) * Hkv + hk) * D;
+                    for (int d = 0; d < D; ++d) o[d] = fmaf(p, bf2f(vp[d]), o[d]);
+                }
+                mc[c] = m;
+                lc[c] = l;
+            }
+            float M = -INFINITY;
+            for (int c = 0; c < nchunk; ++c)
+                if (mc[c] > M) M = mc[c];
+            float Lsum = 0.0f;
+            float O[512];
+            for (int d = 0; d < D; ++d) O[d] = 0.0f;
+            for (int c = 0; c < nchunk; ++c) {
+                float w = vr_exp2((mc[c] - M) * VR_LOG2E);
+                Lsum = fmaf(lc[c], w, Lsum);
+                for (int d = 0; d < D; ++d) O[d] = fmaf(oc[(size_t)c * D + d], w, O[d]);
+            }
+            bf16* op = out + ((size_t)i * Hq + h) * D;
+            for (int d = 0; d < D; ++d) op[d] = f2bf(O[d] / Lsum);
+            free(mc);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Sampler (sampling.py).  logits are bf16 [B,V].                                                     */
+
+/* logits[b, ids[j]] = finfo(bf16).min   (qwen3_tts.py:1894-1895) */
+void vr_suppress(bf16* logits, int B, int V, const int* ids, int n) {
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < n; ++j) logits[(size_t)b * V + ids[j]] = 0xFF7F;
+}
+
+/* apply_repetition_penalty (sampling.py:122-146): mask[b,v] = any_w cache[b,w,0,v] (codebook 0 row when
+ * logits cover one codebook); l>0 ? bf16(l/p) : bf16(l*p) where mask. cache is uint8 [B,W,C,V]. */
+void vr_rep_penalty(bf16* logits, const uint8_t* cache, int B, int W, int C, int V, float penalty) {
+    for (int b = 0; b < B; ++b)
+        for (int v = 0; v < V; ++v) {
+            int m = 0;
+            for (int w = 0; w < W; ++w) m |= cache[(((size_t)b * W + w) * C + 0) * V + v];
+            if (!m) continue;
+            float l = bf2f(logits[(size_t)b * V + v]);
+            logits[(size_t)b * V + v] = f2bf(l > 0.0f ? l / penalty : l * penalty);
+        }
+}
+
+/* update_repetition_penalty_cache (sampling.py:150-178), codebook-0-only form used by Qwen3/CSM:
+ * reproduces the cross-request leak: EVERY row receives EVERY request's token. */
+void vr_rep_update(uint8_t* cache, const int* ids, int B, int W, int C, int V, int window) {
+    if (window > 1) {
+        for (int b = 0; b < B; ++b) {
+            uint8_t* cb = cache + (size_t)b * W * C * V;
+            memmove(cb, cb + (size_t)C * V, (size_t)(W - 1) * C * V);
+            memset(cb + (size_t)(W - 1) * C * V, 0, (size_t)C * V);
+            for (int j = 0; j < B; ++j) cb[((size_t)(W - 1) * C + 0) * V + ids[j]] = 1;
+        }
+    } else {
+        for (int b = 0; b < B; ++b)
+            for (int w = 0; w < W; ++w)
+                for (int j = 0; j < B; ++j) cache[(((size_t)b * W + w) * C + 0) * V + ids[j]] = 1;
+    }
+}
+
+/* greedy (sampling.py:21-27): first maximal index */
+void vr_argmax(const bf16* logits, int B, int V, int* out) {
+    for (int b = 0; b < B; ++b) {
+        int best = 0;
+        float bv = bf2f(logits[(size_t)b * V]);
+        for (int v = 1; v < V; ++v) {
+            float x = bf2f(logits[(size_t)b * V + v]);
+            if (x > bv) {
+                bv = x;
+                best = v;
+            }
+        }
+        out[b] = best;
+    }
+}
+
+/* Philox4x32-10, key = (seed_lo, seed_hi), counter = (offset_lo, offset_hi, row, 0); returns word 0 */
+static uint32_t philox_u32(uint64_t seed, uint64_t offset, uint32_t row) {
+    uint32_t c0 = (uint32_t)offset, c1 = (uint32_t)(offset >> 32), c2 = row, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+/*
+ * Stochastic sampling contract (our own; the reference's draw is flashinfer-internal):
+ *   x = bf16(l / T) per element (sampling.py:31,44,57,71 operate in the logits dtype);
+ *   eligible set: top_k>0 -> the k largest by (value desc, index asc); then softmax over the eligible
+ *   set (fp32, EXP2, sequential sum in that sorted order); top_p<1 -> shortest sorted prefix whose
+ *   cumulative probability >= top_p; min_p>0 -> p >= min_p*pmax;
+ *   draw u = (philox>>8)*2^-24 in [0,1); pick the first sorted entry whose running cumulative sum
+ *   (sequential, fp32) exceeds u * total.
+ * mode: 0 greedy.  Returns ids; if support != NULL writes the eligible ids (sorted order, -1 padded, V max
+ * kmax entries) for support-set parity checks.
+ */
+typedef struct {
+    float v;
+    int i;
+} vr_pair;
+static int cmp_pair(const void* a, const void* b) {
+    const vr_pair* x = (const vr_pair*)a;
+    const vr_pair* y = (const vr_pair*)b;
+    if (x->v > y->v) return -1;
+    if (x->v < y->v) return 1;
+    return x->i - y->i;
+}
+void vr_sample(const bf16* logits, int B, int V, int top_k, float top_p, float min_p, float temperature,
+               uint64_t seed, uint64_t offset, int* out, int* support, int kmax) {
+    vr_pair* pr = (vr_pair*)malloc(sizeof(vr_pair) * V);
+    float* pe = (float*)malloc(sizeof(float) * V);
+    for (int b = 0; b < B; ++b) {
+        for (int v = 0; v < V; ++v) {
+            pr[v].v = bf2f(f2bf(bf2f(logits[(size_t)b * V + v]) / temperature));
+            pr[v].i = v;
+        }
+        qsort(pr, V, sizeof(vr_pair), cmp_pair);
+        int n = (top_k > 0 && top_k < V) ? top_k : V;
+        float m = pr[0].v, tot = 0.0f;
+        for (int j = 0; j < n; ++j) {
+            pe[j] = vr_exp2((pr[j].v - m) * VR_LOG2E);
+            tot = tot + pe[j];
+        }
+        if (min_p > 0.0f) {
+            int k = 0;
+            while (k < n && pe[k] >= min_p * pe[0]) ++k;
+            n = k;
+            tot = 0.0f;
+            for (int j = 0; j < n; ++j) tot = tot + pe[j];
+        }
+        if (top_p < 1.0f) {
+            float c = 0.0f, thr = top_p * tot;
+            int k = 0;
+            while (k < n) {
+                c = c + pe[k];
+                ++k;
+                if (c >= thr) break;
+            }
+            n = k;
+            tot = c;
+        }
+        if (support)
+            for (int j = 0; j < kmax; ++j) support[(size_t)b * kmax + j] = j < n ? pr[j].i : -1;
+        float u = (float)(philox_u32(seed, offset, (uint32_t)b) >> 8) * (1.0f / 16777216.0f);
+        float thr = u * tot, c = 0.0f;
+        int pick = n - 1;
+        for (int j = 0; j < n; ++j) {
+            c = c + pe[j];
+            if (c > thr) {
+                pick = j;
+                break;
+            }
+        }
+        out[b] = pr[pick].i;
+    }
+    free(pr);
+    free(pe);
+}
+
+/* embedding gather: y[b,:] = table[ids[b],:] */
+void vr_gather(const bf16* table, const int* ids, bf16* y, int B, int H) {
+    for (int b = 0; b < B; ++b) memcpy(y + (size_t)b * H, table + (size_t)ids[b] * H, sizeof(bf16) * H);
+}
+
+/* Qwen3 input mix (qwen3_tts.py:1836-1852): e = mask ? bf16(text+codec) : text; y = bf16(e + feat) */
+void vr_qwen3_mix(const bf16* text, const bf16* codec, const uint8_t* mask, const bf16* feat, bf16* y, int B,
+                  int H) {
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < H; ++i) {
+            size_t j = (size_t)b * H + i;
+            bf16 e = mask[b] ? f2bf(bf2f(text[j]) + bf2f(codec[j])) : text[j];
+            y[j] = f2bf(bf2f(e) + bf2f(feat[j]));
+        }
+}
+
+int vr_abi_version(void) { return 1; }

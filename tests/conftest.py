@@ -1,0 +1,35 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+        return cache[name]
+    return load
+
+
+def bf16_close(a_bits, b_bits, ulps=2, atol=0.0):
+    """|a-b| <= ulps * bf16-ulp(max(|a|,|b|)) + atol, elementwise, on bf16 bit patterns."""
+    from oracle import voxref as vr
+    a, b = vr.bf2f(a_bits).astype(np.float64), vr.bf2f(b_bits).astype(np.float64)
+    mag = np.maximum(np.abs(a), np.abs(b))
+    ulp = np.where(mag > 0, 2.0 ** (np.floor(np.log2(np.maximum(mag, 1e-38))) - 7), 0.0)
+    return np.abs(a - b) <= ulps * ulp + atol

@@ -1,0 +1,267 @@
+"""Generate the committed golden fixtures by RUNNING THE REFERENCE (vox-serve) on CPU.
+
+Runs only in the build container (needs /root/reference).  Output: tests/golden/*.npz — data only
+(inputs + the reference's outputs).  See _ref_harness.py for how the reference is imported.
+
+  python tests/golden/make_goldens.py [g1 g2 g3 g4 ...]
+"""
+import os
+import queue
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import _ref_harness as H  # noqa: E402
+
+from oracle import voxref as vr  # noqa: E402  (bf16<->numpy helpers + weight recipe only)
+from oracle import qwen3_ref as QR  # noqa: E402
+
+
+def bits(t):
+    return vr.from_torch(t.to(torch.bfloat16))
+
+
+# --------------------------------------------------------------------------------------------------
+def g1_sampler(ns):
+    """Sampler: greedy ids, suppress mask, repetition penalty incl. quirks Q2/Q3 (sampling.py:21-178)."""
+    S = ns.sampling
+    out = {}
+    g = torch.Generator().manual_seed(42)
+    for name, (B, V) in {"a": (1, 3072), "b": (8, 3072), "c": (32, 3072), "d": (8, 2048), "e": (4, 168960)}.items():
+        logits = torch.randn(B, V, generator=g).to(torch.bfloat16)
+        out[f"greedy_{name}_logits"] = bits(logits)
+        out[f"greedy_{name}_ids"] = S.Sampler.run_sampling(logits, S.SamplingConfig(greedy=True)).numpy().astype(np.int32)
+    # ties: argmax must return the FIRST maximal index
+    t = torch.zeros(3, 64, dtype=torch.bfloat16)
+    t[0, [5, 9]] = 1.0
+    t[1, [63, 0]] = 2.0
+    t[2, :] = -1.0
+    out["greedy_tie_logits"], out["greedy_tie_ids"] = bits(t), S.greedy_sampling(t).numpy().astype(np.int32)
+
+    # repetition penalty: logits [B,1,V], cache [B,W,C,V]
+    B, W, C, V = 3, 2, 5, 256
+    logits = torch.randn(B, 1, V, generator=g).to(torch.bfloat16)
+    cache = torch.rand(B, W, C, V, generator=g) < 0.1
+    pen = S.Sampler.apply_repetition_penalty(logits.clone(), cache, 1.3)
+    out["pen_logits"], out["pen_cache"], out["pen_out"] = bits(logits), cache.numpy().astype(np.uint8), bits(pen)
+    # cache update, global window (Qwen3: W=1) and sliding window; codebook-0-only form => leak Q2
+    for tag, (Wn, window) in {"glob": (1, -1), "win": (3, 3)}.items():
+        c = torch.rand(B, Wn, C, V, generator=g) < 0.02
+        ids = torch.tensor([[5], [7], [9]])
+        c2 = c.clone()
+        S.Sampler.update_repetition_penalty_cache(c2, ids, window)
+        out[f"upd_{tag}_in"], out[f"upd_{tag}_ids"], out[f"upd_{tag}_out"] = (
+            c.numpy().astype(np.uint8), ids.numpy().astype(np.int32)[:, 0], c2.numpy().astype(np.uint8))
+    # temperature scaling happens in the logits dtype (sampling.py:31): bf16(l/T)
+    l = torch.randn(4, 512, generator=g).to(torch.bfloat16)
+    out["temp_logits"], out["temp_out"] = bits(l), bits(l / 0.9)
+    np.savez_compressed(os.path.join(HERE, "g1_sampler.npz"), **out)
+    print("g1 ok", len(out))
+
+
+# --------------------------------------------------------------------------------------------------
+def g2_wrappers(ns):
+    """plan() page/slot arithmetic and set_kv_cache layout (flashinfer_utils.py:60-145,189-244)."""
+    FU = ns.flashinfer_utils
+    out = {}
+    rng = np.random.default_rng(7)
+    page, Hq, Hkv, D, P = 4, 4, 2, 16, 24
+    cpu = torch.device("cpu")
+    # prefill: 3 requests, ragged; one of them a 1-token "decode piggy-back" with existing context
+    q_lens = [6, 1, 9]
+    kv_lens = [6, 11, 9]
+    pages, indptr, last = [], [0], []
+    free = list(rng.permutation(P))
+    for n in kv_lens:
+        k = (n + page - 1) // page
+        pages += [int(free.pop()) for _ in range(k)]
+        indptr.append(indptr[-1] + k)
+        last.append(n % page or page)
+    qo = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    w = FU.FlashInferPrefillWrapper(torch.empty(1), Hq, Hkv, Hq * D, page, device=cpu)
+    w.plan(torch.tensor(qo), torch.tensor(indptr, dtype=torch.int32), torch.tensor(pages, dtype=torch.int32),
+           torch.tensor(last, dtype=torch.int32), torch.bfloat16)
+    T = int(qo[-1])
+    g = torch.Generator().manual_seed(3)
+    kv = (torch.randn(P, 2, page, Hkv, D, generator=g)).to(torch.bfloat16)
+    k = torch.randn(T, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(T, Hkv, D, generator=g).to(torch.bfloat16)
+    q = torch.randn(T, Hq, D, generator=g).to(torch.bfloat16)
+    kv_in = kv.clone()
+    w.set_kv_cache(kv, k, v)
+    o = w.run(q, kv)
+    out.update(pf_qo=qo, pf_indptr=np.array(indptr, np.int32), pf_indices=np.array(pages, np.int32),
+               pf_last=np.array(last, np.int32), pf_token_to_page=w.token_to_page.numpy().astype(np.int32),
+               pf_token_to_cache=w.token_to_cache.numpy().astype(np.int32), pf_kv_in=bits(kv_in), pf_k=bits(k),
+               pf_v=bits(v), pf_q=bits(q), pf_kv_out=bits(kv), pf_out=bits(o), page=np.int32(page))
+    # decode
+    d = FU.FlashInferDecodeWrapper(torch.empty(1), Hq, Hkv, Hq * D, page, device=cpu)
+    d.plan(torch.tensor(indptr, dtype=torch.int32), torch.tensor(pages, dtype=torch.int32),
+           torch.tensor(last, dtype=torch.int32), torch.bfloat16)
+    B = len(kv_lens)
+    k1 = torch.randn(B, Hkv, D, generator=g).to(torch.bfloat16)
+    v1 = torch.randn(B, Hkv, D, generator=g).to(torch.bfloat16)
+    q1 = torch.randn(B, Hq, D, generator=g).to(torch.bfloat16)
+    kv2 = kv.clone()
+    d.set_kv_cache(kv2, k1, v1)
+    o1 = d.run(q1, kv2)
+    out.update(dc_loc=d.kv_cache_locations.numpy().astype(np.int32), dc_k=bits(k1), dc_v=bits(v1), dc_q=bits(q1),
+               dc_kv_out=bits(kv2), dc_out=bits(o1))
+    # rms_norm / rope (three variants used by the model families)
+    x = torch.randn(5, 256, generator=g).to(torch.bfloat16)
+    wn = (1 + 0.1 * torch.randn(256, generator=g)).to(torch.bfloat16)
+    out.update(rms_x=bits(x), rms_w=bits(wn), rms_y=bits(FU.rms_norm(x, wn, 1e-6)))
+    qq = torch.randn(7, 4, 64, generator=g).to(torch.bfloat16)
+    kk = torch.randn(7, 2, 64, generator=g).to(torch.bfloat16)
+    pos = torch.tensor([0, 1, 2, 17, 100, 1000, 2047], dtype=torch.int32)
+    out.update(rope_q=bits(qq), rope_k=bits(kk), rope_pos=pos.numpy())
+    a, b = FU.apply_rope_pos_ids(qq, kk, pos, rope_theta=1e6, interleave=False)
+    out.update(rope_neox_q=bits(a), rope_neox_k=bits(b))
+    a, b = FU.apply_rope_pos_ids(qq, kk, pos, rope_theta=1e4, interleave=True, rotary_dim=32)
+    out.update(rope_glm_q=bits(a), rope_glm_k=bits(b))
+    a, b = FU.apply_rope_pos_ids(qq, kk, pos, rope_scale=32.0, rope_theta=5e5, interleave=False,
+                                 low_freq_factor=1.0, high_freq_factor=4.0, old_context_len=8192)
+    out.update(rope_l31_q=bits(a), rope_l31_k=bits(b))
+    np.savez_compressed(os.path.join(HERE, "g2_wrappers.npz"), **out)
+    print("g2 ok")
+
+
+# --------------------------------------------------------------------------------------------------
+def _ref_qwen3(ns, cfg: QR.Qwen3Cfg, W):
+    """Build the reference Qwen3TTSForCausalLM + Qwen3TTSModel plugin (constructors bypassed) on CPU."""
+    Q = ns.qwen3_tts
+    t, d = cfg.talker, cfg.depth
+    cp = Q.Qwen3TTSCodePredictorConfig(hidden_size=d.hidden, intermediate_size=d.ffn, num_hidden_layers=d.layers,
+                                       num_attention_heads=d.heads, num_key_value_heads=d.kv_heads,
+                                       head_dim=d.head_dim, vocab_size=cfg.depth_vocab, num_code_groups=cfg.n_groups,
+                                       rope_theta=int(d.rope_theta))
+    tc = Q.Qwen3TTSTalkerConfig(hidden_size=t.hidden, intermediate_size=t.ffn, num_hidden_layers=t.layers,
+                                num_attention_heads=t.heads, num_key_value_heads=t.kv_heads, head_dim=t.head_dim,
+                                vocab_size=cfg.vocab, text_vocab_size=cfg.text_vocab, text_hidden_size=cfg.text_hidden,
+                                num_code_groups=cfg.n_groups, codec_eos_token_id=cfg.eos_id,
+                                rope_theta=int(t.rope_theta), code_predictor_config=cp)
+    rc = Q.Qwen3TTSConfig(tts_model_type="custom_voice", talker_config=tc, tts_pad_token_id=cfg.tts_pad_id)
+    net = Q.Qwen3TTSForCausalLM(rc).to(torch.bfloat16)
+    sd = {k: vr.to_torch(v) for k, v in W.items()}
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("lm_head_weight" in m or "inv_freq" in m for m in missing), missing
+    net.talker.code_predictor.lm_head_weight.copy_(
+        torch.stack([h.weight for h in net.talker.code_predictor.lm_head], dim=0))
+    m = Q.Qwen3TTSModel.__new__(Q.Qwen3TTSModel)
+    m.model, m.config, m.device, m.dtype = net, rc, "cpu", torch.bfloat16
+    m.model_name = "tiny"
+    m._detokenize_interval = 10
+    m._num_attention_heads, m._num_key_value_heads = t.heads, t.kv_heads
+    m._num_hidden_layers, m._hidden_size = t.layers, t.hidden
+    m._depth_num_attention_heads, m._depth_num_key_value_heads = d.heads, d.kv_heads
+    m._depth_num_hidden_layers, m._depth_hidden_size = d.layers, d.hidden
+    m._vocab_size, m.stop_token_id = cfg.vocab, cfg.eos_id
+    m.suppress_tokens = cfg.suppress_ids
+    m.tts_model_type = "custom_voice"
+    m.default_sampling_config = ns.sampling.SamplingConfig(greedy=True, repetition_penalty=1.05, repetition_window=-1)
+    return m
+
+
+def g3_qwen3_lm(ns):
+    """Tiny Qwen3-TTS talker+depth through the reference's own worker: prefill + 3 decode frames, B=2."""
+    torch.cuda.synchronize = lambda *a, **k: None          # worker/base.py calls it unconditionally
+    FU, MW = ns.flashinfer_utils, ns.ModelWorker
+    from vox_serve.model.base import PreprocessOutput
+    cfg = QR.tiny_cfg()
+    W = QR.random_weights(cfg, seed=0, std=0.08)
+    m = _ref_qwen3(ns, cfg, W)
+    t, d = cfg.talker, cfg.depth
+    page, P = 16, 32
+    cpu = torch.device("cpu")
+    w = MW.__new__(MW)
+    w.model, w.device, w.page_size, w.max_batch_size = m, "cpu", page, 4
+    w.empty_pages = queue.Queue()
+    for i in range(P):
+        w.empty_pages.put(i)
+    w.prefill_wrapper = FU.FlashInferPrefillWrapper(torch.empty(1), t.heads, t.kv_heads, t.heads * t.head_dim, page, device=cpu)
+    w.decode_wrapper = FU.FlashInferDecodeWrapper(torch.empty(1), t.heads, t.kv_heads, t.heads * t.head_dim, page, device=cpu)
+    w.kv_cache = torch.zeros(t.layers, P, 2, page, t.kv_heads, t.head_dim, dtype=torch.bfloat16)
+    w.has_depth_transformer = True
+    w.depth_attn_wrapper = FU.FlashInferPrefillWrapper(torch.empty(1), d.heads, d.kv_heads, d.heads * d.head_dim, page, device=cpu)
+    w.depth_kv_cache = torch.zeros(d.layers, P, 2, cfg.n_groups, d.kv_heads, d.head_dim, dtype=torch.bfloat16)
+    import logging
+    w.logger = logging.getLogger("golden")
+    w.nvtx_enabled = False
+
+    rec = {"logits": [], "hidden": [], "dlogits": []}
+    f0, df0 = m.forward, m.depth_forward
+
+    def fwd(**kw):
+        lg, hs = f0(**kw)
+        rec["logits"].append(lg.clone()); rec["hidden"].append(hs.clone())
+        return lg, hs
+
+    def dfwd(**kw):
+        lg = df0(**kw)
+        rec["dlogits"].append(lg.clone())
+        return lg
+    m.forward, m.depth_forward = fwd, dfwd
+
+    g = torch.Generator().manual_seed(11)
+    out = {"page": np.int32(page), "P": np.int32(P)}
+    reqs = []
+    R = ns.requests.Request
+    for r, n in enumerate([20, 13]):
+        ids = torch.zeros(n, cfg.n_groups + 1, dtype=torch.long)
+        ids[:, -1] = torch.randint(0, cfg.text_vocab, (n,), generator=g)
+        ids[:, 0] = torch.randint(0, cfg.vocab - 1024, (n,), generator=g)
+        masks = torch.zeros(n, cfg.n_groups + 1, dtype=torch.bool)
+        masks[n // 2:, -1] = True
+        feats = (0.05 * torch.randn(n, t.hidden, generator=g)).to(torch.bfloat16)
+        feats[: n // 3] = 0
+        out[f"r{r}_ids"], out[f"r{r}_masks"], out[f"r{r}_feats"] = (
+            ids.numpy().astype(np.int32), masks[:, -1].numpy().astype(np.uint8), bits(feats))
+        req = R(request_id=str(r), prompt="x")
+        m.preprocess = (lambda ids=ids, masks=masks, feats=feats: (lambda prompt=None, audio_path=None, **kw:
+                        PreprocessOutput(input_tokens=ids, input_masks=masks, input_features=feats,
+                                         repetition_cache=torch.zeros(1, cfg.n_groups + 1, cfg.vocab,
+                                                                      dtype=torch.bool))))()  # qwen3_tts.py:1786
+        # one prefill per step, as the scheduler does (scheduler/base.py:264-298)
+        li = w.prepare_lm_inputs([req], [])
+        n_before = len(rec["logits"])
+        w.run_lm_prefill([req], li)
+        out[f"r{r}_prefill_logits"] = bits(rec["logits"][n_before][-1:, 0])
+        out[f"r{r}_prefill_hidden"] = bits(rec["hidden"][n_before][-1:])
+        out[f"r{r}_kv_pages"] = np.array(req.kv_pages, np.int32)
+        out[f"r{r}_frame0"] = req.lm_output_tokens[-1].numpy().astype(np.int32)[0]
+        out[f"r{r}_next_pos"] = np.int32(req.next_position_id)
+        reqs.append(req)
+    out["prefill_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 else x) for x in rec["dlogits"]])
+    rec["dlogits"].clear()
+    for f in range(3):
+        li = w.prepare_lm_inputs(reqs, [])
+        out[f"f{f}_pos"] = li["position_ids"].numpy().astype(np.int32)
+        out[f"f{f}_indptr"] = np.array(li["paged_kv_indptr"], np.int32)
+        out[f"f{f}_indices"] = np.array(li["paged_kv_indices"], np.int32)
+        out[f"f{f}_last"] = np.array(li["paged_kv_last_page_len"], np.int32)
+        out[f"f{f}_in_ids"] = li["input_ids"].numpy().astype(np.int32)
+        out[f"f{f}_in_feats"] = bits(li["input_features"])
+        w.run_lm_decode(reqs, li)
+        out[f"f{f}_logits"] = bits(rec["logits"][-1][:, 0])
+        out[f"f{f}_hidden"] = bits(rec["hidden"][-1])
+        out[f"f{f}_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 * len(reqs) else x) for x in rec["dlogits"]])
+        rec["dlogits"].clear()
+        out[f"f{f}_tokens"] = np.stack([r.lm_output_tokens[-1].numpy().astype(np.int32)[0] for r in reqs])
+    out["kv_final"] = bits(w.kv_cache)
+    np.savez_compressed(os.path.join(HERE, "g3_qwen3_lm.npz"), **out)
+    print("g3 ok; frame tokens", out["f2_tokens"][:, :6])
+
+
+ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm}
+
+if __name__ == "__main__":
+    ns = H.boot()
+    torch.manual_seed(0)
+    for k in (sys.argv[1:] or list(ALL)):
+        with torch.no_grad():
+            ALL[k](ns)

@@ -1,0 +1,167 @@
+"""Pin the CPU oracle (oracle/voxref.c + oracle/qwen3_ref.py) against fixtures captured from the
+reference's own Python (tests/golden/make_goldens.py).  CPU-only.
+
+Integer / index / mask work must match bit-exactly.  Floating point matches to bf16 rounding: the
+oracle fixes its own summation order (see oracle/voxref.c header) which differs from torch-CPU's, so a
+tensor op may land on the neighbouring bf16 value (tolerance stated per test).
+"""
+import numpy as np
+import pytest
+
+from oracle import voxref as vr
+from oracle import qwen3_ref as QR
+from tests.conftest import bf16_close
+
+
+# ---------------------------------------------------------------- g1: sampler ---------------------
+@pytest.mark.parametrize("name", ["a", "b", "c", "d", "e", "tie"])
+def test_greedy_first_max(golden, name):
+    g = golden("g1_sampler")
+    assert np.array_equal(vr.argmax(g[f"greedy_{name}_logits"]), g[f"greedy_{name}_ids"])
+
+
+def test_repetition_penalty_bit_exact(golden):
+    g = golden("g1_sampler")
+    got = vr.rep_penalty(g["pen_logits"][:, 0], g["pen_cache"], 1.3)
+    assert np.array_equal(got, g["pen_out"][:, 0])
+
+
+@pytest.mark.parametrize("tag,window", [("glob", -1), ("win", 3)])
+def test_repetition_cache_update_reproduces_leak(golden, tag, window):
+    g = golden("g1_sampler")
+    c = g[f"upd_{tag}_in"].copy()
+    vr.rep_update(c, g[f"upd_{tag}_ids"], window)
+    assert np.array_equal(c, g[f"upd_{tag}_out"])
+    # quirk Q2: every row got every request's token on codebook 0
+    for b in range(c.shape[0]):
+        assert all(c[b, -1, 0, t] for t in g[f"upd_{tag}_ids"])
+
+
+def test_temperature_in_bf16(golden):
+    g = golden("g1_sampler")
+    l = vr.bf2f(g["temp_logits"])
+    assert np.array_equal(vr.f2bf(l / np.float32(0.9)), g["temp_out"])
+
+
+def test_sampler_support_and_determinism():
+    rng = np.random.default_rng(0)
+    logits = vr.f2bf(rng.standard_normal((4, 3072)).astype(np.float32) * 3)
+    ids, sup = vr.sample(logits, top_k=50, top_p=1.0, temperature=0.9, seed=123, offset=5, kmax=64)
+    ids2 = vr.sample(logits, top_k=50, top_p=1.0, temperature=0.9, seed=123, offset=5)
+    assert np.array_equal(ids, ids2)
+    x = vr.bf2f(vr.f2bf(vr.bf2f(logits) / np.float32(0.9)))
+    for b in range(4):
+        want = np.lexsort((np.arange(3072), -x[b]))[:50]
+        assert np.array_equal(sup[b, :50], want) and (sup[b, 50:] == -1).all()
+        assert ids[b] in want
+    # distribution: chi-square of 20000 draws against softmax over the top-k
+    k = 8
+    l1 = logits[:1]
+    draws = np.array([vr.sample(l1, top_k=k, temperature=1.0, seed=9, offset=o)[0] for o in range(20000)])
+    xs = vr.bf2f(l1)[0]
+    top = np.lexsort((np.arange(3072), -xs))[:k]
+    p = np.exp(xs[top] - xs[top].max())
+    p /= p.sum()
+    cnt = np.array([(draws == t).sum() for t in top])
+    assert cnt.sum() == 20000
+    chi2 = ((cnt - 20000 * p) ** 2 / (20000 * p)).sum()
+    assert chi2 < 30.0, chi2     # 7 dof, p~1e-4 tail
+
+
+# ---------------------------------------------------------------- g2: wrappers / ops --------------
+def _plan_prefill(qo, indptr, indices, last, page):
+    """token -> (page, slot) exactly as FlashInferPrefillWrapper.plan (flashinfer_utils.py:86-124)."""
+    tp, tc, q_req, q_kvlen = [], [], [], []
+    for r in range(len(last)):
+        m = qo[r + 1] - qo[r]
+        n = (indptr[r + 1] - indptr[r] - 1) * page + last[r]
+        for i in range(m):
+            t = n - m + i
+            tp.append(indices[indptr[r] + t // page]); tc.append(t % page)
+            q_req.append(r); q_kvlen.append(t + 1)
+    return map(lambda a: np.array(a, np.int32), (tp, tc, q_req, q_kvlen))
+
+
+def test_prefill_plan_append_attention(golden):
+    g = golden("g2_wrappers")
+    page = int(g["page"])
+    tp, tc, q_req, q_kvlen = _plan_prefill(g["pf_qo"], g["pf_indptr"], g["pf_indices"], g["pf_last"], page)
+    assert np.array_equal(tp, g["pf_token_to_page"]) and np.array_equal(tc, g["pf_token_to_cache"])
+    kv = g["pf_kv_in"].copy()
+    vr.kv_append(kv, g["pf_k"], g["pf_v"], tp, tc)
+    assert np.array_equal(kv, g["pf_kv_out"])
+    out = vr.paged_attention(g["pf_q"], kv, q_req, q_kvlen, g["pf_indptr"], g["pf_indices"])
+    assert bf16_close(out, g["pf_out"], ulps=1).all()
+
+
+def test_decode_plan_append_attention(golden):
+    g = golden("g2_wrappers")
+    page = int(g["page"])
+    indptr, indices, last = g["pf_indptr"], g["pf_indices"], g["pf_last"]
+    pg = indices[indptr[1:] - 1]
+    sl = last - 1
+    assert np.array_equal(np.stack([pg, sl], 1), g["dc_loc"])
+    kv = g["pf_kv_out"].copy()
+    vr.kv_append(kv, g["dc_k"], g["dc_v"], pg, sl)
+    assert np.array_equal(kv, g["dc_kv_out"])
+    kvlen = (indptr[1:] - indptr[:-1] - 1) * page + last
+    out = vr.paged_attention(g["dc_q"], kv, np.arange(len(last)), kvlen, indptr, indices)
+    assert bf16_close(out, g["dc_out"], ulps=1).all()
+
+
+def test_rmsnorm(golden):
+    g = golden("g2_wrappers")
+    assert bf16_close(vr.rmsnorm(g["rms_x"], g["rms_w"], 1e-6), g["rms_y"], ulps=1).all()
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("neox", dict(theta=1e6)),
+    ("glm", dict(theta=1e4, rot=32, interleave=True)),
+    ("l31", dict(theta=5e5, scale=32.0, llama31=(1.0, 4.0, 8192))),
+])
+def test_rope_variants(golden, tag, kw):
+    g = golden("g2_wrappers")
+    rot = kw.get("rot", 64)
+    cs = vr.rope_table(2048, rot, kw["theta"], kw.get("scale", 1.0), kw.get("llama31"))
+    q = vr.rope(g["rope_q"], g["rope_pos"], cs, rot, kw.get("interleave", False))
+    k = vr.rope(g["rope_k"], g["rope_pos"], cs, rot, kw.get("interleave", False))
+    # fp32 trig of a large angle (pos 2047 * f) differs in the last bits between libm and torch
+    assert bf16_close(q, g[f"rope_{tag}_q"], ulps=1, atol=1e-3).all()
+    assert bf16_close(k, g[f"rope_{tag}_k"], ulps=1, atol=1e-3).all()
+    assert (q == g[f"rope_{tag}_q"]).mean() > 0.98
+
+
+# ---------------------------------------------------------------- g3: Qwen3 talker + depth --------
+def test_qwen3_lm_against_reference_worker(golden):
+    """Prefill + 3 frames, B=2, greedy, through the oracle vs the reference's ModelWorker."""
+    g = golden("g3_qwen3_lm")
+    cfg = QR.tiny_cfg()
+    W = QR.random_weights(cfg, seed=0, std=0.08)
+    m = QR.Qwen3Ref(cfg, W, page_size=int(g["page"]), max_pages=int(g["P"]), max_batch=4)
+    reqs = []
+    tok_mismatch = 0
+    for r in range(2):
+        req = QR.RefRequest()
+        logits, hid = m.prefill(req, g[f"r{r}_ids"], g[f"r{r}_masks"], g[f"r{r}_feats"])
+        assert np.array_equal(np.array(req.kv_pages, np.int32), g[f"r{r}_kv_pages"])      # FIFO page order
+        assert req.next_position_id == int(g[f"r{r}_next_pos"])                            # quirk Q1
+        assert bf16_close(hid, g[f"r{r}_prefill_hidden"], ulps=4, atol=2e-2).all()
+        assert bf16_close(logits, g[f"r{r}_prefill_logits"], ulps=4, atol=3e-2).all()
+        out, _, _, _ = m.frame([req], logits, hid)
+        tok_mismatch += int((out[0] != g[f"r{r}_frame0"]).sum())
+        # teacher-force the reference's frame so the following steps see identical inputs
+        req.frames[-1] = g[f"r{r}_frame0"].copy()
+        reqs.append(req)
+    for f in range(3):
+        # inputs the reference fed (teacher forcing): ids + accumulated features
+        for b, req in enumerate(reqs):
+            req.input_ids = g[f"f{f}_in_ids"][b:b + 1].copy()
+            req.input_features = g[f"f{f}_in_feats"][b:b + 1].copy()
+        logits, hid = m.decode(reqs)
+        assert np.array_equal(np.array([r.next_position_id - 1 for r in reqs]), g[f"f{f}_pos"])
+        assert bf16_close(hid, g[f"f{f}_hidden"], ulps=4, atol=2e-2).all()
+        assert bf16_close(logits, g[f"f{f}_logits"], ulps=4, atol=3e-2).all()
+        out, _, _, dl = m.frame(reqs, logits, hid)
+        tok_mismatch += int((out != g[f"f{f}_tokens"]).sum())
+    # greedy ids agree except where bf16 near-ties flip (different fp32 summation order)
+    assert tok_mismatch <= 6, tok_mismatch
