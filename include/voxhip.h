@@ -1,0 +1,203 @@
+/*
+ * voxhip.h — C ABI of libvoxhip.so, the MI355X (gfx950) native hot path of the vox-serve speech-LM
+ * serving loop.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * The reference (vox-serve, 100 % Python) has no FFI of its own: the seam it crosses into native code
+ * is the `flashinfer` wheel, reached through vox_serve/flashinfer_utils.py and vox_serve/sampling.py.
+ * Each entry point below names the reference interface it replaces (file:line under /root/reference).
+ * INTEGRATION.md shows the ctypes stubs that bind them from the reference's modules.
+ *
+ * Conventions
+ *   - every `const void*` / `void*` tensor argument is a DEVICE pointer unless the name ends in _host;
+ *   - bf16 tensors are contiguous row-major; "stream" is a hipStream_t passed as void*;
+ *   - all calls only ENQUEUE work on the given stream (safe inside hipGraph capture), allocate nothing
+ *     after the context / engine was created, and return VOX_OK or an error code (vox_last_error()).
+ *   - numerics follow the fixed-order contract written in DESIGN.md §"Numeric contract" (the same one
+ *     oracle/voxref.c restates on the CPU): results do not depend on grid shape or batch size.
+ */
+#ifndef VOXHIP_H
+#define VOXHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOX_ABI_VERSION 1
+#define VOX_ATTN_CHUNK 32 /* KV tokens per attention partial (part of the numeric contract) */
+
+typedef enum {
+    VOX_OK = 0,
+    VOX_ERR_INVALID = 1, /* bad argument / unsupported shape */
+    VOX_ERR_HIP = 2,     /* a HIP runtime call failed */
+    VOX_ERR_NOMEM = 3,
+    VOX_ERR_STATE = 4
+} vox_status;
+
+typedef struct vox_ctx vox_ctx;
+typedef struct vox_stack vox_stack;
+typedef struct vox_qwen3 vox_qwen3;
+typedef struct vox_graph vox_graph;
+
+int vox_abi_version(void);
+const char* vox_last_error(void);
+
+/* One context per process/GPU (the reference: one scheduler process per GPU, launch.py:183-279). */
+int vox_ctx_create(int device, vox_ctx** out);
+void vox_ctx_destroy(vox_ctx* ctx);
+/* device properties the host side sizes things with: [0]=CU count, [1]=LDS bytes/CU, [2]=HBM bytes */
+int vox_ctx_props(vox_ctx* ctx, int64_t out[3]);
+
+/* ---- hipGraph capture (replaces torch.cuda.graph in worker/cuda_graph_worker.py:189-805) ---------- */
+int vox_graph_begin(vox_ctx* ctx, void* stream);
+int vox_graph_end(vox_ctx* ctx, void* stream, vox_graph** out);
+int vox_graph_launch(vox_graph* g, void* stream);
+void vox_graph_destroy(vox_graph* g);
+
+/* ---- ops: drop-in for vox_serve/flashinfer_utils.py ------------------------------------------------ */
+
+/* rms_norm (flashinfer_utils.py:251-267): y = bf16(x * rsqrt(mean(x^2)+eps) * w); x,y [rows,cols] bf16 */
+int vox_rmsnorm(vox_ctx* ctx, void* stream, const void* x, const void* w, void* y, int rows, int cols, float eps);
+
+/* cos/sin table for apply_rope_pos_ids / apply_llama31_rope_pos_ids (flashinfer_utils.py:270-324).
+ * Writes max_pos*(rot/2)*2 floats to a HOST buffer; upload it once and pass the device copy below. */
+int vox_rope_table_host(float* cs_host, int max_pos, int rot, double theta, double scale, int llama31,
+                        double low_freq_factor, double high_freq_factor, int old_context_len);
+
+/* apply_rope_pos_ids: out-of-place rotary on q [N,Hq,D] and k [N,Hkv,D]; pos int32 [N] */
+int vox_rope(vox_ctx* ctx, void* stream, const void* q, const void* k, void* q_out, void* k_out, const int32_t* pos,
+             int N, int Hq, int Hkv, int D, int rot, int interleave, const float* cs_table, int table_max_pos);
+
+/* Flashinfer{Prefill,Decode}Wrapper.set_kv_cache (flashinfer_utils.py:134-145, 232-244):
+ * kv_layer [P,2,page_size,Hkv,D]; k,v [N,Hkv,D]; page/slot int32 [N] (page<0: skip = graph padding) */
+int vox_kv_append(vox_ctx* ctx, void* stream, void* kv_layer, const void* k, const void* v, const int32_t* page,
+                  const int32_t* slot, int N, int page_size, int Hkv, int D);
+
+/* Batch{Decode,Prefill}WithPagedKVCacheWrapper.run (flashinfer_utils.py:127-132, 228-230).
+ * Query row i belongs to request q_req[i] and attends to the first q_kvlen[i] tokens of its KV
+ * (decode: whole length; causal prefill row j of m with kv length n: n-m+j+1).  max_kvlen bounds the
+ * launch grid (rows may be shorter).  workspace: vox_attn_workspace_bytes() bytes. */
+int64_t vox_attn_workspace_bytes(int Nq, int Hq, int D, int max_kvlen);
+int vox_paged_attention(vox_ctx* ctx, void* stream, const void* q, const void* kv_layer, const int32_t* q_req,
+                        const int32_t* q_kvlen, const int32_t* kv_indptr, const int32_t* kv_indices, void* out,
+                        void* workspace, int Nq, int Hq, int Hkv, int D, int page_size, int max_kvlen, float scale);
+
+/* nn.Linear on bf16 (qwen3_tts.py:562-601): y[b,n] = bf16(dot(W[n,:],x[b,:]) + bias[n]);
+ * residual != NULL: y = bf16(residual + y).  act: 0 none, 1 SiLU applied to the rounded output. */
+int vox_linear(vox_ctx* ctx, void* stream, const void* W, const void* bias, const void* x, const void* residual,
+               void* y, int B, int N, int K, int act);
+/* h = act(gate_proj(x)) * up_proj(x)  (Qwen3TTSMLP.forward, qwen3_tts.py:573-575) */
+int vox_linear_silu_mul(vox_ctx* ctx, void* stream, const void* Wg, const void* Wu, const void* x, void* h, int B,
+                        int N, int K);
+
+/* ---- sampler: drop-in for vox_serve/sampling.py ----------------------------------------------------- */
+typedef struct {
+    int32_t greedy;      /* SamplingConfig.greedy or temperature == 0 (sampling.py:99-104) */
+    int32_t top_k;       /* 0 = unset */
+    float top_p;         /* 1.0 = unset */
+    float min_p;         /* 0.0 = unset */
+    float temperature;   /* 1.0 default */
+    float repetition_penalty; /* 1.0 = off */
+} vox_sampling_config;
+
+/* logits[b, ids[j]] = finfo(bf16).min (qwen3_tts.py:1894-1895) */
+int vox_suppress(vox_ctx* ctx, void* stream, void* logits, int B, int V, const int32_t* ids, int n);
+/* Sampler.apply_repetition_penalty (sampling.py:122-146); cache uint8/bool [B,W,C,V], codebook row 0 */
+int vox_rep_penalty(vox_ctx* ctx, void* stream, void* logits, const uint8_t* cache, int B, int W, int C, int V,
+                    float penalty);
+/* Sampler.update_repetition_penalty_cache, codebook-0 form incl. the cross-request leak (sampling.py:150-178) */
+int vox_rep_update(vox_ctx* ctx, void* stream, uint8_t* cache, const int32_t* ids, int B, int W, int C, int V,
+                   int window);
+/* Sampler.run_sampling (sampling.py:85-118): out_ids int32 [B].  Stochastic modes draw from a Philox4x32-10
+ * stream keyed by (seed, offset, row) — the contract oracle/voxref.c::vr_sample restates. */
+int vox_sample(vox_ctx* ctx, void* stream, const void* logits, int B, int V, const vox_sampling_config* cfg,
+               uint64_t seed, uint64_t offset, int32_t* out_ids);
+
+/* ---- decoder stack engine: replaces vox_serve/model/<family>.py decoder layers --------------------- */
+typedef struct {
+    int32_t hidden, layers, heads, kv_heads, head_dim, ffn;
+    float eps;
+    int32_t qk_norm;        /* per-head RMSNorm on q,k (qwen3_tts.py:620-625) */
+    int32_t qkv_bias;       /* GLM / CosyVoice2 */
+    int32_t rope_dim;       /* rotary dims (<= head_dim) */
+    int32_t rope_interleave;
+    int32_t page_size;
+    int32_t max_rows;       /* max query rows per forward (batch for decode, tokens for prefill) */
+    int32_t max_kvlen;      /* bounds attention partial workspace */
+} vox_stack_config;
+
+typedef struct { /* per-layer device pointers, bf16; wqkv = rows [q;k;v] concatenated */
+    const void *wqkv, *bqkv, *wo, *wgate, *wup, *wdown, *ln1, *ln2, *qnorm, *knorm;
+} vox_layer_weights;
+
+int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_weights* layers,
+                     const void* final_norm, const float* rope_table, int rope_table_max_pos, vox_stack** out);
+void vox_stack_destroy(vox_stack* s);
+
+typedef struct { /* device int32 arrays describing one ragged forward (FlashInfer*Wrapper.plan outputs) */
+    const int32_t *pos, *q_req, *q_kvlen, *page, *slot, *kv_indptr, *kv_indices;
+    int32_t n_rows;
+    int32_t max_kvlen; /* grid bound for this call (<= cfg.max_kvlen) */
+} vox_rows;
+
+/* x [n_rows,hidden] bf16 is updated in place layer by layer; y (may alias x) = final RMSNorm(x).
+ * kv: [layers][P,2,page,Hkv,D], layer stride kv_layer_stride elements. */
+int vox_stack_forward(vox_stack* s, void* stream, void* x, void* y, void* kv, int64_t kv_layer_stride,
+                      const vox_rows* rows);
+
+/* ---- Qwen3-TTS frame engine: talker decode + on-device sampling + 15-step depth loop ----------------
+ * replaces CudaGraphWorker.run_lm_decode/run_lm_depth (worker/cuda_graph_worker.py:946-1160) and
+ * Qwen3TTSModel.forward/sampling/depth_forward/depth_sampling (model/qwen3_tts.py:1805-2004).      */
+typedef struct {
+    vox_stack_config talker, depth;
+    int32_t vocab, text_vocab, text_hidden, depth_vocab, n_groups, eos_id, tts_pad_id;
+    int32_t max_batch;
+} vox_qwen3_config;
+
+typedef struct {
+    const vox_layer_weights *talker_layers, *depth_layers;
+    const void *talker_norm, *depth_norm;
+    const void *codec_embedding, *text_embedding;         /* [vocab,H], [text_vocab,text_hidden] */
+    const void *tp_fc1_w, *tp_fc1_b, *tp_fc2_w, *tp_fc2_b; /* text_projection */
+    const void* codec_head;                                /* [vocab,H] */
+    const void* const* depth_codec_embedding;              /* n_groups-1 x [depth_vocab,H] */
+    const void* depth_lm_head;                             /* [n_groups-1, depth_vocab, depth_hidden] */
+    const void *mtp_w, *mtp_b;                             /* small_to_mtp_projection */
+    const float *talker_rope, *depth_rope;
+    int32_t talker_rope_max_pos, depth_rope_max_pos;
+} vox_qwen3_weights;
+
+typedef struct { /* device buffers owned by the caller (graph-stable addresses) */
+    int32_t* input_ids;      /* [max_batch, n_groups+1]; col 0 codec id, col -1 text id */
+    uint8_t* input_masks;    /* [max_batch] (mask of the last column, qwen3_tts.py:1848) */
+    void* input_features;    /* [max_batch, H] bf16 */
+    int32_t *pos, *kvlen, *page, *slot, *kv_indptr, *kv_indices; /* plan() outputs */
+    void* kv;                /* talker KV [layers][P,2,page,Hkv,D] */
+    int64_t kv_layer_stride;
+    int32_t* out_ids;        /* [max_batch, n_groups+1] sampled frame */
+    void* out_logits;        /* [max_batch, vocab] bf16 codebook-0 logits after suppress/penalty */
+    void* out_hidden;        /* [max_batch, H] bf16 backbone hidden (post-norm) */
+    void* out_depth_logits;  /* optional [n_groups-1, max_batch, depth_vocab] bf16, may be NULL */
+    void* next_features;     /* [max_batch, H] bf16: sum of depth code embeddings (next input_features) */
+    uint64_t* rng_offset;    /* device counter, advanced once per frame */
+} vox_qwen3_io;
+
+int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_weights* w, vox_qwen3** out);
+void vox_qwen3_destroy(vox_qwen3* m);
+/* Enqueue one whole frame for `batch` rows.  With feedback != 0 the engine also writes the next step's
+ * input_ids / input_masks / input_features in place (qwen3_tts.py:1931-1944), so frames can be replayed
+ * back-to-back from one captured graph while the host only advances the plan arrays. */
+int vox_qwen3_frame(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int batch, int max_kvlen,
+                    const vox_sampling_config* sampling, uint64_t seed, int feedback);
+/* Ragged prefill of n_rows tokens (one or more requests); logits/hidden of row `last_rows[r]` go to
+ * out_logits/out_hidden row r, then sampling + depth loop run for n_req rows as in vox_qwen3_frame. */
+int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const int32_t* row_ids /*[n_rows,n_groups+1]*/,
+                      const uint8_t* row_masks, const void* row_features, const int32_t* q_req, int n_rows,
+                      const int32_t* last_rows, int n_req, int max_kvlen, const vox_sampling_config* sampling,
+                      uint64_t seed, int feedback);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXHIP_H */

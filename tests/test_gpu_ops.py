@@ -1,0 +1,211 @@
+"""GPU parity of every libvoxhip op (called through the C ABI via the drop-in Python wrappers) against the
+CPU oracle.  Bar: BIT-EXACT bf16 outputs and integer ids — the HIP kernels and oracle/voxref.c follow the
+same fixed-order numeric contract.  Also replays the reference-captured goldens on the GPU path.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import voxref as vr
+from tests.conftest import bf16_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vox_serve_amd import _native as N
+    N.ctx()
+    return torch.device("cuda")
+
+
+def T(bits, dev):
+    return vr.to_torch(bits).to(dev)
+
+
+def Bits(t):
+    return vr.from_torch(t)
+
+
+def rnd(rng, *shape, s=1.0):
+    return vr.f2bf(rng.standard_normal(shape).astype(np.float32) * np.float32(s))
+
+
+@pytest.mark.parametrize("B,N_,K", [(1, 64, 256), (1, 2048, 2048), (2, 1030, 1024), (3, 512, 6144), (4, 4096, 2048),
+                                    (5, 96, 512), (8, 3072, 1024), (9, 128, 2048), (19, 256, 768), (1, 7, 64)])
+def test_linear_bit_exact(dev, B, N_, K):
+    from vox_serve_amd import _native as N
+    rng = np.random.default_rng(B * 1000 + N_ + K)
+    W, x, bias, res = rnd(rng, N_, K, s=0.05), rnd(rng, B, K), rnd(rng, N_, s=0.1), rnd(rng, B, N_)
+    for use_bias, use_res, act in [(False, False, 0), (True, False, 0), (True, True, 0), (True, False, 1)]:
+        y = torch.empty(B, N_, dtype=torch.bfloat16, device=dev)
+        Wt, xt, bt, rt = T(W, dev), T(x, dev), T(bias, dev), T(res, dev)
+        N.check(N.lib().vox_linear(N.ctx(), N.stream(), N.ptr(Wt), N.ptr(bt) if use_bias else None, N.ptr(xt),
+                                   N.ptr(rt) if use_res else None, N.ptr(y), B, N_, K, act))
+        ref = vr.linear(W, x, bias if use_bias else None, None)
+        if act:
+            ref = vr.silu(ref)
+        if use_res:
+            ref = vr.add(res, ref)
+        assert np.array_equal(Bits(y), ref), (use_bias, use_res, act)
+
+
+@pytest.mark.parametrize("B,N_,K", [(1, 6144, 2048), (2, 768, 256), (4, 3072, 1024), (8, 520, 512), (11, 64, 128)])
+def test_linear_silu_mul_bit_exact(dev, B, N_, K):
+    from vox_serve_amd import _native as N
+    rng = np.random.default_rng(N_ + K + B)
+    Wg, Wu, x = rnd(rng, N_, K, s=0.05), rnd(rng, N_, K, s=0.05), rnd(rng, B, K)
+    h = torch.empty(B, N_, dtype=torch.bfloat16, device=dev)
+    N.check(N.lib().vox_linear_silu_mul(N.ctx(), N.stream(), N.ptr(T(Wg, dev)), N.ptr(T(Wu, dev)), N.ptr(T(x, dev)),
+                                        N.ptr(h), B, N_, K))
+    assert np.array_equal(Bits(h), vr.linear_silu_mul(Wg, Wu, x))
+
+
+@pytest.mark.parametrize("rows,H", [(1, 2048), (5, 128), (33, 1024), (64, 64), (3, 4096)])
+def test_rmsnorm_bit_exact(dev, rows, H):
+    from vox_serve_amd.flashinfer_utils import rms_norm
+    rng = np.random.default_rng(rows + H)
+    x, w = rnd(rng, rows, H, s=2.0), vr.f2bf(1 + 0.1 * rng.standard_normal(H).astype(np.float32))
+    assert np.array_equal(Bits(rms_norm(T(x, dev), T(w, dev), 1e-6)), vr.rmsnorm(x, w, 1e-6))
+
+
+def test_rmsnorm_reference_golden(dev, golden):
+    from vox_serve_amd.flashinfer_utils import rms_norm
+    g = golden("g2_wrappers")
+    assert bf16_close(Bits(rms_norm(T(g["rms_x"], dev), T(g["rms_w"], dev), 1e-6)), g["rms_y"], ulps=1).all()
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("neox", dict(rope_theta=1e6)),
+    ("glm", dict(rope_theta=1e4, rotary_dim=32, interleave=True)),
+    ("l31", dict(rope_theta=5e5, rope_scale=32.0, low_freq_factor=1.0, high_freq_factor=4.0, old_context_len=8192)),
+])
+def test_rope_bit_exact_and_golden(dev, golden, tag, kw):
+    from vox_serve_amd.flashinfer_utils import apply_rope_pos_ids
+    g = golden("g2_wrappers")
+    q, k = apply_rope_pos_ids(T(g["rope_q"], dev), T(g["rope_k"], dev), torch.from_numpy(g["rope_pos"]).to(dev), **kw)
+    rot = kw.get("rotary_dim", 64)
+    l31 = (1.0, 4.0, 8192) if "low_freq_factor" in kw else None
+    cs = vr.rope_table(8192, rot, kw["rope_theta"], kw.get("rope_scale", 1.0), l31)
+    qo = vr.rope(g["rope_q"], g["rope_pos"], cs, rot, kw.get("interleave", False))
+    ko = vr.rope(g["rope_k"], g["rope_pos"], cs, rot, kw.get("interleave", False))
+    assert np.array_equal(Bits(q), qo) and np.array_equal(Bits(k), ko)          # vs oracle: bit-exact
+    assert bf16_close(Bits(q), g[f"rope_{tag}_q"], ulps=1, atol=1e-3).all()      # vs reference capture
+
+
+def test_reference_wrappers_golden_on_gpu(dev, golden):
+    """The reference's own plan()/set_kv_cache()/run() sequence, replayed through the drop-in wrappers."""
+    from vox_serve_amd.flashinfer_utils import FlashInferDecodeWrapper, FlashInferPrefillWrapper
+    g = golden("g2_wrappers")
+    page, Hq, Hkv, D = int(g["page"]), 4, 2, 16
+    w = FlashInferPrefillWrapper(None, Hq, Hkv, Hq * D, page, device=dev)
+    i32 = lambda a: torch.from_numpy(a.astype(np.int32))
+    w.plan(i32(g["pf_qo"]), i32(g["pf_indptr"]), i32(g["pf_indices"]), i32(g["pf_last"]), torch.bfloat16)
+    assert np.array_equal(w.token_to_page.cpu().numpy(), g["pf_token_to_page"])
+    assert np.array_equal(w.token_to_cache.cpu().numpy(), g["pf_token_to_cache"])
+    kv = T(g["pf_kv_in"], dev)
+    w.set_kv_cache(kv, T(g["pf_k"], dev), T(g["pf_v"], dev))
+    assert np.array_equal(Bits(kv), g["pf_kv_out"])
+    out = w.run(T(g["pf_q"], dev), kv)
+    assert bf16_close(Bits(out), g["pf_out"], ulps=1).all()
+    d = FlashInferDecodeWrapper(None, Hq, Hkv, Hq * D, page, device=dev)
+    d.plan(i32(g["pf_indptr"]), i32(g["pf_indices"]), i32(g["pf_last"]), torch.bfloat16)
+    assert np.array_equal(d.kv_cache_locations.cpu().numpy(), g["dc_loc"])
+    d.set_kv_cache(kv, T(g["dc_k"], dev), T(g["dc_v"], dev))
+    assert np.array_equal(Bits(kv), g["dc_kv_out"])
+    out = d.run(T(g["dc_q"], dev), kv)
+    assert bf16_close(Bits(out), g["dc_out"], ulps=1).all()
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,page,lens", [
+    (16, 8, 128, 128, [1, 31, 32, 33, 200, 517]),
+    (32, 8, 64, 16, [5, 64, 100]),
+    (32, 2, 128, 128, [77, 300]),
+    (14, 2, 64, 8, [9, 130]),
+    (4, 2, 16, 4, [3, 40]),
+])
+def test_paged_decode_attention_bit_exact(dev, Hq, Hkv, D, page, lens):
+    from vox_serve_amd.flashinfer_utils import FlashInferDecodeWrapper
+    rng = np.random.default_rng(Hq * D + page)
+    B = len(lens)
+    npages = [(n + page - 1) // page for n in lens]
+    P = sum(npages) + 3
+    perm = rng.permutation(P)
+    indptr = np.concatenate([[0], np.cumsum(npages)]).astype(np.int32)
+    indices = perm[: indptr[-1]].astype(np.int32)
+    last = np.array([n % page or page for n in lens], np.int32)
+    kv = rnd(rng, P, 2, page, Hkv, D)
+    q = rnd(rng, B, Hq, D)
+    w = FlashInferDecodeWrapper(None, Hq, Hkv, Hq * D, page, device=dev)
+    w.plan(torch.from_numpy(indptr), torch.from_numpy(indices), torch.from_numpy(last), torch.bfloat16)
+    out = w.run(T(q, dev), T(kv, dev))
+    ref = vr.paged_attention(q, kv, np.arange(B), np.array(lens), indptr, indices)
+    assert np.array_equal(Bits(out), ref)
+
+
+def test_paged_prefill_attention_bit_exact(dev):
+    from vox_serve_amd.flashinfer_utils import FlashInferPrefillWrapper
+    rng = np.random.default_rng(5)
+    Hq, Hkv, D, page = 16, 8, 128, 16
+    q_lens, kv_lens = [40, 1, 75], [40, 90, 75]
+    npages = [(n + page - 1) // page for n in kv_lens]
+    P = sum(npages) + 2
+    indptr = np.concatenate([[0], np.cumsum(npages)]).astype(np.int32)
+    indices = rng.permutation(P)[: indptr[-1]].astype(np.int32)
+    last = np.array([n % page or page for n in kv_lens], np.int32)
+    qo = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    kv = rnd(rng, P, 2, page, Hkv, D)
+    Tn = int(qo[-1])
+    q, k, v = rnd(rng, Tn, Hq, D), rnd(rng, Tn, Hkv, D), rnd(rng, Tn, Hkv, D)
+    w = FlashInferPrefillWrapper(None, Hq, Hkv, Hq * D, page, device=dev)
+    w.plan(torch.from_numpy(qo), torch.from_numpy(indptr), torch.from_numpy(indices), torch.from_numpy(last), torch.bfloat16)
+    kvt = T(kv, dev)
+    w.set_kv_cache(kvt, T(k, dev), T(v, dev))
+    out = w.run(T(q, dev), kvt)
+    tp, tc = w.token_to_page.cpu().numpy().astype(np.int32), w.token_to_cache.cpu().numpy().astype(np.int32)
+    kv_ref = kv.copy()
+    vr.kv_append(kv_ref, k, v, tp, tc)
+    assert np.array_equal(Bits(kvt), kv_ref)
+    q_req = np.repeat(np.arange(3), q_lens)
+    q_kvlen = np.concatenate([np.arange(n - m + 1, n + 1) for m, n in zip(q_lens, kv_lens)])
+    ref = vr.paged_attention(q, kv_ref, q_req, q_kvlen, indptr, indices)
+    assert np.array_equal(Bits(out), ref)
+
+
+# ---------------------------------------------------------------- sampler -------------------------
+@pytest.mark.parametrize("name", ["a", "b", "c", "d", "e", "tie"])
+def test_greedy_goldens(dev, golden, name):
+    from vox_serve_amd.sampling import Sampler, SamplingConfig
+    g = golden("g1_sampler")
+    ids = Sampler.run_sampling(T(g[f"greedy_{name}_logits"], dev), SamplingConfig(greedy=True))
+    assert np.array_equal(ids.cpu().numpy().astype(np.int32), g[f"greedy_{name}_ids"])
+
+
+def test_repetition_penalty_and_update_goldens(dev, golden):
+    from vox_serve_amd.sampling import Sampler
+    g = golden("g1_sampler")
+    out = Sampler.apply_repetition_penalty(T(g["pen_logits"], dev), torch.from_numpy(g["pen_cache"]).to(dev).bool(), 1.3)
+    assert np.array_equal(Bits(out), g["pen_out"])
+    for tag, window in (("glob", -1), ("win", 3)):
+        c = torch.from_numpy(g[f"upd_{tag}_in"]).to(dev).bool()
+        Sampler.update_repetition_penalty_cache(c, torch.from_numpy(g[f"upd_{tag}_ids"]).to(dev)[:, None], window)
+        assert np.array_equal(c.cpu().numpy().astype(np.uint8), g[f"upd_{tag}_out"])
+
+
+@pytest.mark.parametrize("B,V,k,p,mp,T_", [(4, 3072, 50, 1.0, 0.0, 0.9), (8, 2048, 50, 1.0, 0.0, 0.9),
+                                          (3, 2051, 25, 0.8, 0.0, 1.0), (2, 6564, 25, 1.0, 0.1, 0.7),
+                                          (5, 512, 200, 0.95, 0.0, 1.3), (2, 300, 256, 1.0, 0.0, 1.0)])
+def test_stochastic_sampler_bit_exact(dev, B, V, k, p, mp, T_):
+    from vox_serve_amd import _native as N
+    rng = np.random.default_rng(V + k)
+    logits = vr.f2bf(rng.standard_normal((B, V)).astype(np.float32) * 3)
+    logits[0, : V // 2] = logits[0, 0]            # heavy ties: exercises ordered tie selection
+    lt = T(logits, dev)
+    out = torch.empty(B, dtype=torch.int32, device=dev)
+    for off in range(12):
+        cfg = N.SamplingCfg(0, k, p, mp, T_, 1.0)
+        N.check(N.lib().vox_sample(N.ctx(), N.stream(), N.ptr(lt), B, V, cfg, 77, off, N.ptr(out)))
+        ref = vr.sample(logits, top_k=k, top_p=p, min_p=mp, temperature=T_, seed=77, offset=off)
+        assert np.array_equal(out.cpu().numpy(), ref), off

@@ -1,0 +1,153 @@
+"""ctypes binding of libvoxhip.so (the C ABI declared in include/voxhip.h).
+
+The HIP library is the product path: there is NO CPU fallback.  Loading fails loudly when the shared
+object is missing, and every compute entry point raises if no MI355X context can be created.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvoxhip.so")
+
+
+class VoxError(RuntimeError):
+    pass
+
+
+class SamplingCfg(Structure):
+    _fields_ = [("greedy", c_int32), ("top_k", c_int32), ("top_p", c_float), ("min_p", c_float),
+                ("temperature", c_float), ("repetition_penalty", c_float)]
+
+
+class StackConfig(Structure):
+    _fields_ = [(n, c_int32) for n in ("hidden", "layers", "heads", "kv_heads", "head_dim", "ffn")] + \
+               [("eps", c_float)] + \
+               [(n, c_int32) for n in ("qk_norm", "qkv_bias", "rope_dim", "rope_interleave", "page_size",
+                                       "max_rows", "max_kvlen")]
+
+
+class LayerWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in ("wqkv", "bqkv", "wo", "wgate", "wup", "wdown", "ln1", "ln2", "qnorm", "knorm")]
+
+
+class Rows(Structure):
+    _fields_ = [(n, c_void_p) for n in ("pos", "q_req", "q_kvlen", "page", "slot", "kv_indptr", "kv_indices")] + \
+               [("n_rows", c_int32), ("max_kvlen", c_int32)]
+
+
+class Qwen3Config(Structure):
+    _fields_ = [("talker", StackConfig), ("depth", StackConfig)] + \
+               [(n, c_int32) for n in ("vocab", "text_vocab", "text_hidden", "depth_vocab", "n_groups", "eos_id",
+                                       "tts_pad_id", "max_batch")]
+
+
+class Qwen3Weights(Structure):
+    _fields_ = [("talker_layers", POINTER(LayerWeights)), ("depth_layers", POINTER(LayerWeights)),
+                ("talker_norm", c_void_p), ("depth_norm", c_void_p), ("codec_embedding", c_void_p),
+                ("text_embedding", c_void_p), ("tp_fc1_w", c_void_p), ("tp_fc1_b", c_void_p), ("tp_fc2_w", c_void_p),
+                ("tp_fc2_b", c_void_p), ("codec_head", c_void_p), ("depth_codec_embedding", POINTER(c_void_p)),
+                ("depth_lm_head", c_void_p), ("mtp_w", c_void_p), ("mtp_b", c_void_p), ("talker_rope", c_void_p),
+                ("depth_rope", c_void_p), ("talker_rope_max_pos", c_int32), ("depth_rope_max_pos", c_int32)]
+
+
+class Qwen3IO(Structure):
+    _fields_ = [("input_ids", c_void_p), ("input_masks", c_void_p), ("input_features", c_void_p), ("pos", c_void_p),
+                ("kvlen", c_void_p), ("page", c_void_p), ("slot", c_void_p), ("kv_indptr", c_void_p),
+                ("kv_indices", c_void_p), ("kv", c_void_p), ("kv_layer_stride", c_int64), ("out_ids", c_void_p),
+                ("out_logits", c_void_p), ("out_hidden", c_void_p), ("out_depth_logits", c_void_p),
+                ("next_features", c_void_p), ("rng_offset", c_void_p)]
+
+
+_SIGS = {
+    "vox_abi_version": (c_int, []),
+    "vox_last_error": (c_char_p, []),
+    "vox_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "vox_ctx_destroy": (None, [c_void_p]),
+    "vox_ctx_props": (c_int, [c_void_p, POINTER(c_int64)]),
+    "vox_graph_begin": (c_int, [c_void_p, c_void_p]),
+    "vox_graph_end": (c_int, [c_void_p, c_void_p, POINTER(c_void_p)]),
+    "vox_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "vox_graph_destroy": (None, [c_void_p]),
+    "vox_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
+    "vox_rope_table_host": (c_int, [c_void_p, c_int, c_int, c_double, c_double, c_int, c_double, c_double, c_int]),
+    "vox_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                         c_int, c_int, c_int, c_void_p, c_int]),
+    "vox_kv_append": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                              c_int, c_int]),
+    "vox_attn_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "vox_paged_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float]),
+    "vox_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                           c_int]),
+    "vox_linear_silu_mul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "vox_suppress": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),
+    "vox_rep_penalty": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float]),
+    "vox_rep_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "vox_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(SamplingCfg), c_uint64, c_uint64,
+                           c_void_p]),
+    "vox_stack_create": (c_int, [c_void_p, POINTER(StackConfig), POINTER(LayerWeights), c_void_p, c_void_p, c_int,
+                                 POINTER(c_void_p)]),
+    "vox_stack_destroy": (None, [c_void_p]),
+    "vox_stack_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(Rows)]),
+    "vox_qwen3_create": (c_int, [c_void_p, POINTER(Qwen3Config), POINTER(Qwen3Weights), POINTER(c_void_p)]),
+    "vox_qwen3_destroy": (None, [c_void_p]),
+    "vox_qwen3_frame": (c_int, [c_void_p, c_void_p, POINTER(Qwen3IO), c_int, c_int, POINTER(SamplingCfg), c_uint64,
+                                c_int]),
+    "vox_qwen3_prefill": (c_int, [c_void_p, c_void_p, POINTER(Qwen3IO), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_int, c_int, POINTER(SamplingCfg), c_uint64, c_int]),
+}
+
+# symbols added by later translation units (codec); bound if present, listed so the export test sees them
+_OPTIONAL_SIGS = {}
+
+_lib = None
+_ctx = None
+
+
+def lib():
+    """Load libvoxhip.so.  Raises (never falls back) if the shared object is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VoxError(f"{LIB_PATH} not found: build it with `python -m vox_serve_amd.build` "
+                           "(the HIP library is the only compute path; there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in {**_SIGS, **_OPTIONAL_SIGS}.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.vox_abi_version() != 1:
+            raise VoxError("libvoxhip ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise VoxError(f"libvoxhip error {status}: {lib().vox_last_error().decode()}")
+
+
+def ctx():
+    """Process-wide context on the current torch device (one process per GPU)."""
+    global _ctx
+    if _ctx is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise VoxError("no HIP device visible: libvoxhip needs an MI355X (there is no CPU fallback)")
+        h = c_void_p()
+        check(lib().vox_ctx_create(torch.cuda.current_device(), ctypes.byref(h)))
+        _ctx = h
+    return _ctx
+
+
+def stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  Tensors must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libvoxhip takes contiguous tensors"
+    return c_void_p(t.data_ptr())

@@ -1,0 +1,542 @@
+// Host-side engines of libvoxhip: context / hipGraph capture, the generic decoder stack
+// (vox_stack_*) and the Qwen3-TTS frame engine (vox_qwen3_*): talker step + on-device sampling +
+// the whole 15-step depth loop enqueued on one stream with no host round trip, so one hipGraph holds
+// an entire audio frame (the reference needs 16 graph replays, 16 plan() syncs and >=16*B .item() syncs
+// per frame: worker/cuda_graph_worker.py:946-1160, model/qwen3_tts.py:1935-1997).
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "vox_internal.h"
+
+static thread_local char g_err[512] = "";
+
+int vox_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+int vox_abi_version(void) { return VOX_ABI_VERSION; }
+const char* vox_last_error(void) { return g_err; }
+
+int vox_ctx_create(int device, vox_ctx** out) {
+    if (!out) return vox_fail(VOX_ERR_INVALID, "ctx_create: out is NULL");
+    int n = 0;
+    VOX_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return vox_fail(VOX_ERR_INVALID, "ctx_create: device %d of %d", device, n);
+    VOX_HIP(hipSetDevice(device));
+    hipDeviceProp_t p;
+    VOX_HIP(hipGetDeviceProperties(&p, device));
+    vox_ctx* c = new vox_ctx();
+    c->device = device;
+    c->n_cu = p.multiProcessorCount;
+    c->lds_bytes = (int64_t)p.maxSharedMemoryPerMultiProcessor;
+    c->hbm_bytes = (int64_t)p.totalGlobalMem;
+    *out = c;
+    return VOX_OK;
+}
+void vox_ctx_destroy(vox_ctx* ctx) { delete ctx; }
+int vox_ctx_props(vox_ctx* ctx, int64_t out[3]) {
+    if (!ctx || !out) return vox_fail(VOX_ERR_INVALID, "ctx_props: NULL");
+    out[0] = ctx->n_cu; out[1] = ctx->lds_bytes; out[2] = ctx->hbm_bytes;
+    return VOX_OK;
+}
+
+int vox_graph_begin(vox_ctx* ctx, void* stream) {
+    (void)ctx;
+    VOX_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return VOX_OK;
+}
+int vox_graph_end(vox_ctx* ctx, void* stream, vox_graph** out) {
+    (void)ctx;
+    hipGraph_t g = nullptr;
+    VOX_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+    hipGraphExec_t e = nullptr;
+    hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    if (err != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return vox_fail(VOX_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(err));
+    }
+    vox_graph* vg = new vox_graph();
+    vg->graph = g;
+    vg->exec = e;
+    *out = vg;
+    return VOX_OK;
+}
+int vox_graph_launch(vox_graph* g, void* stream) {
+    if (!g) return vox_fail(VOX_ERR_INVALID, "graph_launch: NULL");
+    VOX_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return VOX_OK;
+}
+void vox_graph_destroy(vox_graph* g) {
+    if (!g) return;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-op ABI
+// ---------------------------------------------------------------------------------------------------
+int vox_rmsnorm(vox_ctx* ctx, void* stream, const void* x, const void* w, void* y, int rows, int cols, float eps) {
+    (void)ctx;
+    return vox_launch_rmsnorm((hipStream_t)stream, x, w, y, rows, cols, eps);
+}
+
+int vox_rope_table_host(float* cs, int max_pos, int rot, double theta, double scale, int llama31, double lo,
+                        double hi, int old_ctx) {
+    if (!cs || rot <= 0 || rot % 2) return vox_fail(VOX_ERR_INVALID, "rope_table: bad args");
+    const int half = rot / 2;
+    for (int i = 0; i < half; ++i) {
+        double f = 1.0 / pow(theta, (double)(2 * i) / (double)rot);
+        if (llama31) {
+            double smooth = (f * old_ctx / (2.0 * M_PI) - lo) / (hi - lo);
+            smooth = smooth < 0 ? 0 : (smooth > 1 ? 1 : smooth);
+            f = (1.0 - smooth) * (f / scale) + smooth * f;
+        } else {
+            f = f / scale;
+        }
+        const float ff = (float)f;
+        for (int p = 0; p < max_pos; ++p) {
+            const float ang = (float)p * ff;
+            cs[((size_t)p * half + i) * 2 + 0] = (float)cos((double)ang);
+            cs[((size_t)p * half + i) * 2 + 1] = (float)sin((double)ang);
+        }
+    }
+    return VOX_OK;
+}
+
+int vox_rope(vox_ctx* ctx, void* stream, const void* q, const void* k, void* q_out, void* k_out, const int32_t* pos,
+             int N, int Hq, int Hkv, int D, int rot, int interleave, const float* cs, int table_max_pos) {
+    (void)ctx;
+    HeadCall c;
+    c.q_src = q; c.k_src = k; c.q_stride = (long)Hq * D; c.k_stride = (long)Hkv * D;
+    c.q_out = q_out; c.k_out = k_out; c.cs = cs; c.pos = pos; c.N = N; c.Hq = Hq; c.Hkv = Hkv; c.D = D;
+    c.rot = rot; c.interleave = interleave; c.table_max_pos = table_max_pos; c.page_size = 1;
+    return vox_launch_head_prepare((hipStream_t)stream, c);
+}
+
+int vox_kv_append(vox_ctx* ctx, void* stream, void* kv, const void* k, const void* v, const int32_t* page,
+                  const int32_t* slot, int N, int page_size, int Hkv, int D) {
+    (void)ctx;
+    return vox_launch_kv_append((hipStream_t)stream, kv, k, v, page, slot, N, page_size, Hkv, D);
+}
+
+static inline int n_chunks(int kvlen) { return kvlen <= 0 ? 1 : (kvlen + VOX_ATTN_CHUNK - 1) / VOX_ATTN_CHUNK; }
+
+int64_t vox_attn_workspace_bytes(int Nq, int Hq, int D, int max_kvlen) {
+    return (int64_t)Nq * Hq * n_chunks(max_kvlen) * (D + 2) * 4;
+}
+
+int vox_paged_attention(vox_ctx* ctx, void* stream, const void* q, const void* kv, const int32_t* q_req,
+                        const int32_t* q_kvlen, const int32_t* indptr, const int32_t* indices, void* out, void* ws,
+                        int Nq, int Hq, int Hkv, int D, int page_size, int max_kvlen, float scale) {
+    (void)ctx;
+    const int mc = n_chunks(max_kvlen);
+    AttnCall c;
+    c.q = q; c.kv = kv; c.q_req = q_req; c.q_kvlen = q_kvlen; c.indptr = indptr; c.indices = indices;
+    c.part_o = (float*)ws; c.part_ml = (float*)ws + (size_t)Nq * Hq * mc * D; c.scale = scale; c.Nq = Nq;
+    c.Hq = Hq; c.Hkv = Hkv; c.D = D; c.page_size = page_size; c.max_chunks = mc; c.max_kvlen = max_kvlen;
+    VOX_TRY(vox_launch_attn_partial((hipStream_t)stream, c));
+    return vox_launch_attn_merge((hipStream_t)stream, c.part_o, c.part_ml, q_kvlen, out, Nq, Hq, D, mc);
+}
+
+int vox_linear(vox_ctx* ctx, void* stream, const void* W, const void* bias, const void* x, const void* residual,
+               void* y, int B, int N, int K, int act) {
+    LinearCall c;
+    c.W = W; c.bias = bias; c.x = x; c.residual = residual; c.y = y; c.B = B; c.N = N; c.K = K;
+    c.pro = VOX_PRO_COPY; c.epi = act ? VOX_EPI_SILU : VOX_EPI_STORE;
+    return vox_launch_linear(ctx, (hipStream_t)stream, c);
+}
+int vox_linear_silu_mul(vox_ctx* ctx, void* stream, const void* Wg, const void* Wu, const void* x, void* h, int B,
+                        int N, int K) {
+    LinearCall c;
+    c.W = Wg; c.W2 = Wu; c.x = x; c.y = h; c.B = B; c.N = N; c.K = K;
+    c.pro = VOX_PRO_COPY; c.epi = VOX_EPI_SILU_MUL;
+    return vox_launch_linear(ctx, (hipStream_t)stream, c);
+}
+
+int vox_suppress(vox_ctx* ctx, void* stream, void* logits, int B, int V, const int32_t* ids, int n) {
+    (void)ctx;
+    return vox_launch_suppress((hipStream_t)stream, logits, B, V, ids, n);
+}
+int vox_rep_penalty(vox_ctx* ctx, void* stream, void* logits, const uint8_t* cache, int B, int W, int C, int V,
+                    float penalty) {
+    (void)ctx;
+    return vox_launch_rep_penalty((hipStream_t)stream, logits, cache, B, W, C, V, penalty);
+}
+int vox_rep_update(vox_ctx* ctx, void* stream, uint8_t* cache, const int32_t* ids, int B, int W, int C, int V,
+                   int window) {
+    (void)ctx;
+    return vox_launch_rep_update((hipStream_t)stream, cache, ids, B, W, C, V, window);
+}
+int vox_sample(vox_ctx* ctx, void* stream, const void* logits, int B, int V, const vox_sampling_config* cfg,
+               uint64_t seed, uint64_t offset, int32_t* out_ids) {
+    (void)ctx;
+    if (!cfg) return vox_fail(VOX_ERR_INVALID, "sample: cfg NULL");
+    SampleCall c;
+    c.logits = const_cast<void*>(logits); c.B = B; c.V = V; c.cfg = *cfg; c.cfg.repetition_penalty = 1.0f;
+    c.seed = seed; c.offset = offset; c.out_ids = out_ids;
+    return vox_launch_sample((hipStream_t)stream, c);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// decoder stack
+// ---------------------------------------------------------------------------------------------------
+struct vox_stack {
+    vox_ctx* ctx;
+    vox_stack_config cfg;
+    std::vector<vox_layer_weights> layers;
+    const void* final_norm;
+    const float* rope;
+    int rope_max_pos;
+    // workspace
+    void *qkv, *q, *h;
+    float* attn_ws;
+    size_t attn_ws_floats;
+};
+
+static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t kv_stride, const vox_rows* r) {
+    const vox_stack_config& c = s->cfg;
+    const int n = r->n_rows;
+    if (n <= 0) return VOX_OK;
+    if (n > c.max_rows) return vox_fail(VOX_ERR_INVALID, "stack_forward: %d rows > max_rows %d", n, c.max_rows);
+    const int nq = c.heads * c.head_dim, nkv = c.kv_heads * c.head_dim, nqkv = nq + 2 * nkv;
+    const int mc = n_chunks(r->max_kvlen);
+    const size_t need = (size_t)n * c.heads * mc * (c.head_dim + 2);
+    if (need > s->attn_ws_floats)
+        return vox_fail(VOX_ERR_INVALID, "stack_forward: attention workspace too small (%zu > %zu floats)", need,
+                        s->attn_ws_floats);
+    float* part_o = s->attn_ws;
+    float* part_ml = s->attn_ws + (size_t)n * c.heads * mc * c.head_dim;
+    const float scale = 1.0f / sqrtf((float)c.head_dim);
+    for (int l = 0; l < c.layers; ++l) {
+        const vox_layer_weights& w = s->layers[l];
+        void* kvl = (char*)kv + (size_t)l * kv_stride * 2;
+        LinearCall a;  // input_layernorm + fused q/k/v projection
+        a.W = w.wqkv; a.bias = w.bqkv; a.x = x; a.norm_w = w.ln1; a.eps = c.eps; a.y = s->qkv;
+        a.B = n; a.N = nqkv; a.K = c.hidden; a.pro = VOX_PRO_RMSNORM; a.epi = VOX_EPI_STORE;
+        VOX_TRY(vox_launch_linear(s->ctx, st, a));
+        HeadCall hc;  // per-head norm + RoPE + paged append
+        hc.q_src = s->qkv; hc.k_src = (bf16_t*)s->qkv + nq; hc.v_src = (bf16_t*)s->qkv + nq + nkv;
+        hc.q_stride = hc.k_stride = hc.v_stride = nqkv;
+        hc.q_out = s->q; hc.kv = kvl; hc.qn = c.qk_norm ? w.qnorm : nullptr; hc.kn = c.qk_norm ? w.knorm : nullptr;
+        hc.cs = s->rope; hc.pos = r->pos; hc.page = r->page; hc.slot = r->slot; hc.eps = c.eps; hc.N = n;
+        hc.Hq = c.heads; hc.Hkv = c.kv_heads; hc.D = c.head_dim; hc.rot = c.rope_dim; hc.interleave = c.rope_interleave;
+        hc.page_size = c.page_size; hc.table_max_pos = s->rope_max_pos;
+        VOX_TRY(vox_launch_head_prepare(st, hc));
+        AttnCall ac;
+        ac.q = s->q; ac.kv = kvl; ac.q_req = r->q_req; ac.q_kvlen = r->q_kvlen; ac.indptr = r->kv_indptr;
+        ac.indices = r->kv_indices; ac.part_o = part_o; ac.part_ml = part_ml; ac.scale = scale; ac.Nq = n;
+        ac.Hq = c.heads; ac.Hkv = c.kv_heads; ac.D = c.head_dim; ac.page_size = c.page_size; ac.max_chunks = mc;
+        ac.max_kvlen = r->max_kvlen;
+        VOX_TRY(vox_launch_attn_partial(st, ac));
+        LinearCall o;  // merge partials + o_proj + residual
+        o.W = w.wo; o.residual = x; o.y = x; o.part_o = part_o; o.part_ml = part_ml; o.kvlen = r->q_kvlen;
+        o.B = n; o.N = c.hidden; o.K = nq; o.Hq = c.heads; o.D = c.head_dim; o.max_chunks = mc;
+        o.pro = VOX_PRO_ATTN; o.epi = VOX_EPI_STORE;
+        VOX_TRY(vox_launch_linear(s->ctx, st, o));
+        LinearCall g;  // post_attention_layernorm + gate/up + SiLU*up
+        g.W = w.wgate; g.W2 = w.wup; g.x = x; g.norm_w = w.ln2; g.eps = c.eps; g.y = s->h;
+        g.B = n; g.N = c.ffn; g.K = c.hidden; g.pro = VOX_PRO_RMSNORM; g.epi = VOX_EPI_SILU_MUL;
+        VOX_TRY(vox_launch_linear(s->ctx, st, g));
+        LinearCall d;  // down + residual
+        d.W = w.wdown; d.x = s->h; d.residual = x; d.y = x; d.B = n; d.N = c.hidden; d.K = c.ffn;
+        d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE;
+        VOX_TRY(vox_launch_linear(s->ctx, st, d));
+    }
+    return VOX_OK;
+}
+
+extern "C" {
+
+int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_weights* layers, const void* final_norm,
+                     const float* rope, int rope_max_pos, vox_stack** out) {
+    if (!ctx || !cfg || !layers || !out) return vox_fail(VOX_ERR_INVALID, "stack_create: NULL argument");
+    if (cfg->hidden % 8 || cfg->head_dim % 8 || cfg->ffn % 8 || cfg->heads % cfg->kv_heads)
+        return vox_fail(VOX_ERR_INVALID, "stack_create: dims must be multiples of 8 and heads %% kv_heads == 0");
+    vox_stack* s = new vox_stack();
+    s->ctx = ctx;
+    s->cfg = *cfg;
+    s->layers.assign(layers, layers + cfg->layers);
+    s->final_norm = final_norm;
+    s->rope = rope;
+    s->rope_max_pos = rope_max_pos;
+    const size_t nq = (size_t)cfg->heads * cfg->head_dim, nkv = (size_t)cfg->kv_heads * cfg->head_dim;
+    const size_t R = cfg->max_rows;
+    s->attn_ws_floats = (size_t)R * cfg->heads * n_chunks(cfg->max_kvlen) * (cfg->head_dim + 2);
+    if (hipMalloc(&s->qkv, R * (nq + 2 * nkv) * 2) != hipSuccess || hipMalloc(&s->q, R * nq * 2) != hipSuccess ||
+        hipMalloc(&s->h, R * cfg->ffn * 2) != hipSuccess ||
+        hipMalloc((void**)&s->attn_ws, s->attn_ws_floats * 4) != hipSuccess) {
+        delete s;
+        return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc failed");
+    }
+    *out = s;
+    return VOX_OK;
+}
+void vox_stack_destroy(vox_stack* s) {
+    if (!s) return;
+    (void)hipFree(s->qkv); (void)hipFree(s->q); (void)hipFree(s->h); (void)hipFree(s->attn_ws);
+    delete s;
+}
+
+int vox_stack_forward(vox_stack* s, void* stream, void* x, void* y, void* kv, int64_t kv_layer_stride,
+                      const vox_rows* rows) {
+    if (!s || !rows) return vox_fail(VOX_ERR_INVALID, "stack_forward: NULL");
+    hipStream_t st = (hipStream_t)stream;
+    VOX_TRY(stack_layers(s, st, x, kv, kv_layer_stride, rows));
+    if (y && s->final_norm)
+        VOX_TRY(vox_launch_rmsnorm(st, x, s->final_norm, y, rows->n_rows, s->cfg.hidden, s->cfg.eps));
+    return VOX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// Qwen3-TTS frame engine
+// ---------------------------------------------------------------------------------------------------
+struct vox_qwen3 {
+    vox_ctx* ctx;
+    vox_qwen3_config cfg;
+    vox_qwen3_weights w;
+    std::vector<const void*> depth_emb;
+    vox_stack *talker, *depth;
+    // device buffers
+    void *te, *t1, *text, *x, *depth_x, *dx, *dlogits, *dkv;
+    int32_t* iota;           // 0..max(2*max_batch, ...)
+    int32_t* dmeta;          // depth plan arrays
+    int32_t* suppress;
+    int n_suppress;
+    int64_t dkv_stride;
+    // depth meta offsets (in int32 elements) for i==1 and per i>=2
+    int32_t *d1_pos, *d1_req, *d1_kvlen, *d1_slot, *d_indptr, *odd_rows;
+    std::vector<int32_t*> di_pos, di_kvlen;
+};
+
+__global__ void k_frame_init(int* out_ids, int stride, int col, int val, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out_ids[(size_t)b * stride + col] = val;
+}
+__global__ void k_qwen3_feedback(const int* out_ids, int* input_ids, uint8_t* masks, const bf16_t* next_feat,
+                                 bf16_t* feat, uint64_t* rng, int G1, int H, int pad_id, int B) {
+    const int b = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int j = 0; j < G1; ++j) input_ids[(size_t)b * G1 + j] = 0;
+        input_ids[(size_t)b * G1] = out_ids[(size_t)b * G1];
+        input_ids[(size_t)b * G1 + G1 - 1] = pad_id;
+        masks[b] = 1;
+        if (b == 0 && rng) *rng += 1;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H; i += gridDim.x * 256)
+        feat[(size_t)b * H + i] = next_feat[(size_t)b * H + i];
+}
+__global__ void k_rng_bump(uint64_t* rng) { *rng += 1; }
+__global__ void k_copy_rows(const bf16_t* src, long src_stride, bf16_t* dst, long dst_stride, int H) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H; i += gridDim.x * 256)
+        dst[(size_t)b * dst_stride + i] = src[(size_t)b * src_stride + i];
+}
+
+static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int B, const vox_sampling_config* sc,
+                      uint64_t seed, int feedback) {
+    // Runs after out_logits [B,vocab] and depth_x rows 2b (hidden) are in place:
+    // codebook-0 sampling, the depth loop, and the feedback of the next step's inputs.
+    const vox_qwen3_config& c = m->cfg;
+    const int H = c.talker.hidden, Hd = c.depth.hidden, G = c.n_groups, G1 = G + 1;
+    hipLaunchKernelGGL(k_frame_init, dim3((B + 63) / 64), dim3(64), 0, st, io->out_ids, G1, G, c.tts_pad_id, B);
+    {
+        SampleCall s;
+        s.logits = io->out_logits; s.B = B; s.V = c.vocab; s.suppress_ids = m->suppress; s.n_suppress = m->n_suppress;
+        s.cfg = *sc; s.cfg.repetition_penalty = 1.0f;  // Qwen3: cache never persisted => identity
+        s.seed = seed; s.offset = 0; s.offset_dev = io->rng_offset; s.offset_mul = (uint64_t)G;
+        s.out_ids = io->out_ids; s.out_stride = G1; s.out_col = 0;
+        s.emb_table = m->w.codec_embedding; s.emb_vocab = c.vocab; s.H = H;
+        s.emb_dst = (bf16_t*)m->depth_x + H; s.emb_dst_stride = 2L * H;
+        VOX_TRY(vox_launch_sample(st, s));
+    }
+    for (int i = 1; i < G; ++i) {
+        const int rows = i == 1 ? 2 * B : B;
+        LinearCall p;  // small_to_mtp_projection
+        p.W = m->w.mtp_w; p.bias = m->w.mtp_b; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
+        p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE;
+        VOX_TRY(vox_launch_linear(m->ctx, st, p));
+        vox_rows r{};
+        r.pos = i == 1 ? m->d1_pos : m->di_pos[i];
+        r.q_req = i == 1 ? m->d1_req : m->iota;
+        r.q_kvlen = i == 1 ? m->d1_kvlen : m->di_kvlen[i];
+        r.page = r.q_req;
+        r.slot = i == 1 ? m->d1_slot : m->di_pos[i];
+        r.kv_indptr = m->d_indptr;
+        r.kv_indices = m->iota;
+        r.n_rows = rows;
+        r.max_kvlen = i + 1;
+        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r));
+        void* dl = io->out_depth_logits ? (void*)((bf16_t*)io->out_depth_logits + (size_t)(i - 1) * c.max_batch * c.depth_vocab)
+                                        : m->dlogits;
+        LinearCall h;  // depth final norm + lm_head[i-1]
+        h.W = (const bf16_t*)m->w.depth_lm_head + (size_t)(i - 1) * c.depth_vocab * Hd;
+        h.x = m->dx; h.x_rows = i == 1 ? m->odd_rows : nullptr; h.norm_w = m->w.depth_norm; h.eps = c.depth.eps;
+        h.y = dl; h.B = B; h.N = c.depth_vocab; h.K = Hd; h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
+        VOX_TRY(vox_launch_linear(m->ctx, st, h));
+        SampleCall s;
+        s.logits = dl; s.B = B; s.V = c.depth_vocab; s.cfg = *sc; s.cfg.repetition_penalty = 1.0f;
+        s.seed = seed; s.offset = (uint64_t)i; s.offset_dev = io->rng_offset; s.offset_mul = (uint64_t)G;
+        s.out_ids = io->out_ids; s.out_stride = G1; s.out_col = i;
+        s.emb_table = m->depth_emb[i - 1]; s.emb_vocab = c.depth_vocab; s.H = H;
+        s.emb_dst = m->depth_x; s.emb_dst_stride = H;
+        s.feat_acc = io->next_features; s.feat_init = i == 1;
+        VOX_TRY(vox_launch_sample(st, s));
+    }
+    if (feedback) {
+        hipLaunchKernelGGL(k_qwen3_feedback, dim3((H + 255) / 256, B), dim3(256), 0, st, io->out_ids, io->input_ids,
+                           io->input_masks, (const bf16_t*)io->next_features, (bf16_t*)io->input_features,
+                           io->rng_offset, G1, H, c.tts_pad_id, B);
+    } else if (io->rng_offset) {
+        hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, io->rng_offset);
+    }
+    return VOX_OK;
+}
+
+static int qwen3_embed(vox_qwen3* m, hipStream_t st, const int32_t* ids, const uint8_t* masks, const void* feats,
+                       int n) {
+    const vox_qwen3_config& c = m->cfg;
+    const int H = c.talker.hidden, G1 = c.n_groups + 1;
+    VOX_TRY(vox_launch_gather(st, m->w.text_embedding, ids, G1, G1 - 1, m->te, c.text_hidden, n, c.text_hidden,
+                              c.text_vocab));
+    LinearCall f1;
+    f1.W = m->w.tp_fc1_w; f1.bias = m->w.tp_fc1_b; f1.x = m->te; f1.y = m->t1; f1.B = n; f1.N = c.text_hidden;
+    f1.K = c.text_hidden; f1.pro = VOX_PRO_COPY; f1.epi = VOX_EPI_SILU;
+    VOX_TRY(vox_launch_linear(m->ctx, st, f1));
+    LinearCall f2;
+    f2.W = m->w.tp_fc2_w; f2.bias = m->w.tp_fc2_b; f2.x = m->t1; f2.y = m->text; f2.B = n; f2.N = H;
+    f2.K = c.text_hidden; f2.pro = VOX_PRO_COPY; f2.epi = VOX_EPI_STORE;
+    VOX_TRY(vox_launch_linear(m->ctx, st, f2));
+    return vox_launch_qwen3_mix(st, m->text, m->w.codec_embedding, ids, G1, masks, feats, m->x, n, H, c.vocab);
+}
+
+extern "C" {
+
+int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_weights* w, vox_qwen3** out) {
+    if (!ctx || !cfg || !w || !out) return vox_fail(VOX_ERR_INVALID, "qwen3_create: NULL argument");
+    if (cfg->n_groups < 2 || cfg->max_batch < 1) return vox_fail(VOX_ERR_INVALID, "qwen3_create: bad config");
+    vox_qwen3* m = new vox_qwen3();
+    m->ctx = ctx;
+    m->cfg = *cfg;
+    m->w = *w;
+    m->depth_emb.assign(w->depth_codec_embedding, w->depth_codec_embedding + cfg->n_groups - 1);
+    const int B = cfg->max_batch, G = cfg->n_groups, H = cfg->talker.hidden, Hd = cfg->depth.hidden;
+    vox_stack_config tc = cfg->talker, dc = cfg->depth;
+    dc.page_size = G;
+    dc.max_rows = 2 * B;
+    dc.max_kvlen = G;
+    int s = vox_stack_create(ctx, &tc, w->talker_layers, w->talker_norm, w->talker_rope, w->talker_rope_max_pos, &m->talker);
+    if (s != VOX_OK) { delete m; return s; }
+    s = vox_stack_create(ctx, &dc, w->depth_layers, w->depth_norm, w->depth_rope, w->depth_rope_max_pos, &m->depth);
+    if (s != VOX_OK) { vox_stack_destroy(m->talker); delete m; return s; }
+    const size_t R = tc.max_rows;
+    m->dkv_stride = (int64_t)B * 2 * G * dc.kv_heads * dc.head_dim;
+    bool ok = hipMalloc(&m->te, R * cfg->text_hidden * 2) == hipSuccess &&
+              hipMalloc(&m->t1, R * cfg->text_hidden * 2) == hipSuccess &&
+              hipMalloc(&m->text, R * H * 2) == hipSuccess && hipMalloc(&m->x, R * H * 2) == hipSuccess &&
+              hipMalloc(&m->depth_x, (size_t)2 * B * H * 2) == hipSuccess &&
+              hipMalloc(&m->dx, (size_t)2 * B * Hd * 2) == hipSuccess &&
+              hipMalloc(&m->dlogits, (size_t)B * cfg->depth_vocab * 2) == hipSuccess &&
+              hipMalloc(&m->dkv, (size_t)dc.layers * m->dkv_stride * 2) == hipSuccess;
+    if (!ok) return vox_fail(VOX_ERR_NOMEM, "qwen3_create: hipMalloc failed");
+    VOX_HIP(hipMemset(m->dkv, 0, (size_t)dc.layers * m->dkv_stride * 2));
+    // static plan arrays of the depth loop (worker/base.py:559-612)
+    const int niota = (int)(R > (size_t)2 * B + 1 ? R : 2 * B + 1);
+    std::vector<int32_t> host;
+    auto push = [&](const std::vector<int32_t>& v) { size_t o = host.size(); host.insert(host.end(), v.begin(), v.end()); return o; };
+    std::vector<int32_t> iota(niota), d1p(2 * B), d1r(2 * B), d1k(2 * B), odd(B), indptr(B + 1);
+    for (int i = 0; i < niota; ++i) iota[i] = i;
+    for (int b = 0; b < B; ++b) {
+        d1p[2 * b] = 0; d1p[2 * b + 1] = 1; d1r[2 * b] = d1r[2 * b + 1] = b;
+        d1k[2 * b] = 1; d1k[2 * b + 1] = 2; odd[b] = 2 * b + 1;
+    }
+    for (int b = 0; b <= B; ++b) indptr[b] = b;
+    const size_t o_iota = push(iota), o_d1p = push(d1p), o_d1r = push(d1r), o_d1k = push(d1k), o_odd = push(odd),
+                 o_ind = push(indptr);
+    std::vector<size_t> o_pos(G, 0), o_kvl(G, 0);
+    for (int i = 2; i < G; ++i) {
+        o_pos[i] = push(std::vector<int32_t>(B, i));
+        o_kvl[i] = push(std::vector<int32_t>(B, i + 1));
+    }
+    std::vector<int32_t> sup;
+    for (int i = cfg->vocab - 1024; i < cfg->vocab; ++i)
+        if (i >= 0 && i != cfg->eos_id) sup.push_back(i);   // qwen3_tts.py:1082-1086
+    const size_t o_sup = push(sup);
+    if (hipMalloc((void**)&m->dmeta, host.size() * 4) != hipSuccess) return vox_fail(VOX_ERR_NOMEM, "qwen3_create: hipMalloc");
+    VOX_HIP(hipMemcpy(m->dmeta, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    m->iota = m->dmeta + o_iota; m->d1_pos = m->dmeta + o_d1p; m->d1_req = m->dmeta + o_d1r;
+    m->d1_kvlen = m->dmeta + o_d1k; m->d1_slot = m->d1_pos; m->odd_rows = m->dmeta + o_odd;
+    m->d_indptr = m->dmeta + o_ind;
+    m->di_pos.assign(G, nullptr); m->di_kvlen.assign(G, nullptr);
+    for (int i = 2; i < G; ++i) { m->di_pos[i] = m->dmeta + o_pos[i]; m->di_kvlen[i] = m->dmeta + o_kvl[i]; }
+    m->suppress = m->dmeta + o_sup;
+    m->n_suppress = (int)sup.size();
+    *out = m;
+    return VOX_OK;
+}
+
+void vox_qwen3_destroy(vox_qwen3* m) {
+    if (!m) return;
+    vox_stack_destroy(m->talker); vox_stack_destroy(m->depth);
+    for (void* p : {m->te, m->t1, m->text, m->x, m->depth_x, m->dx, m->dlogits, m->dkv, (void*)m->dmeta}) (void)hipFree(p);
+    delete m;
+}
+
+static int qwen3_head(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int B, const int32_t* x_rows) {
+    const vox_qwen3_config& c = m->cfg;
+    const int H = c.talker.hidden;
+    LinearCall h;  // talker final norm (-> hidden for the depth model) + codec_head
+    h.W = m->w.codec_head; h.x = m->x; h.x_rows = x_rows; h.norm_w = m->w.talker_norm; h.eps = c.talker.eps;
+    h.x_out = m->depth_x; h.x_out_stride = 2L * H; h.y = io->out_logits; h.B = B; h.N = c.vocab; h.K = H;
+    h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
+    VOX_TRY(vox_launch_linear(m->ctx, st, h));
+    if (io->out_hidden)
+        hipLaunchKernelGGL(k_copy_rows, dim3((H + 255) / 256, B), dim3(256), 0, st, (const bf16_t*)m->depth_x, 2L * H,
+                           (bf16_t*)io->out_hidden, (long)H, H);
+    return VOX_OK;
+}
+
+int vox_qwen3_frame(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int B, int max_kvlen,
+                    const vox_sampling_config* sc, uint64_t seed, int feedback) {
+    if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "qwen3_frame: NULL");
+    if (B < 1 || B > m->cfg.max_batch) return vox_fail(VOX_ERR_INVALID, "qwen3_frame: batch %d > max_batch", B);
+    hipStream_t st = (hipStream_t)stream;
+    VOX_TRY(qwen3_embed(m, st, io->input_ids, io->input_masks, io->input_features, B));
+    vox_rows r{};
+    r.pos = io->pos; r.q_req = m->iota; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
+    r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = B; r.max_kvlen = max_kvlen;
+    VOX_TRY(stack_layers(m->talker, st, m->x, io->kv, io->kv_layer_stride, &r));
+    VOX_TRY(qwen3_head(m, st, io, B, nullptr));
+    return qwen3_tail(m, st, io, B, sc, seed, feedback);
+}
+
+int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const int32_t* row_ids,
+                      const uint8_t* row_masks, const void* row_features, const int32_t* q_req, int n_rows,
+                      const int32_t* last_rows, int n_req, int max_kvlen, const vox_sampling_config* sc, uint64_t seed,
+                      int feedback) {
+    if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "qwen3_prefill: NULL");
+    if (n_req < 1 || n_req > m->cfg.max_batch || n_rows > m->cfg.talker.max_rows)
+        return vox_fail(VOX_ERR_INVALID, "qwen3_prefill: n_req %d / n_rows %d out of range", n_req, n_rows);
+    hipStream_t st = (hipStream_t)stream;
+    VOX_TRY(qwen3_embed(m, st, row_ids, row_masks, row_features, n_rows));
+    vox_rows r{};
+    r.pos = io->pos; r.q_req = q_req; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
+    r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = n_rows; r.max_kvlen = max_kvlen;
+    VOX_TRY(stack_layers(m->talker, st, m->x, io->kv, io->kv_layer_stride, &r));
+    VOX_TRY(qwen3_head(m, st, io, n_req, last_rows));
+    return qwen3_tail(m, st, io, n_req, sc, seed, feedback);
+}
+
+}  // extern "C"

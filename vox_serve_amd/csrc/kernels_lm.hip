@@ -1,0 +1,547 @@
+// gfx950 kernels of the speech-LM decode step: weight-streaming linear (fixed-order GEMV), RMSNorm,
+// RoPE (+ per-head q/k norm + paged KV append), chunked paged attention.  wave64, 256-thread blocks.
+//
+// Weight-streaming linear: decode at B<=8 rows is HBM-bound (1 FLOP/byte/row) — weights go straight
+// from HBM to VGPRs with 16-byte non-temporal loads (no LDS round trip: each weight byte is used by
+// exactly one wave), the few activation rows sit in LDS, MFMA is deliberately not used here.
+#include "vox_internal.h"
+
+// ================================================================================================
+// linear
+// ================================================================================================
+enum { PRO_COPY = 0, PRO_RMSNORM = 1, PRO_ATTN = 2 };
+enum { EPI_STORE = 0, EPI_SILU = 1, EPI_SILU_MUL = 2 };
+
+struct LinArgs {
+    const bf16_t *W, *W2, *bias, *x, *residual, *nw;
+    bf16_t *y, *x_out;
+    const float *part_o, *part_ml;
+    const int* kvlen;
+    const int* x_rows;   // optional row indirection: x row b = x + x_rows[b]*x_stride
+    long x_stride, x_out_stride;
+    float eps;
+    int B, N, K, Hq, D, max_chunks;
+};
+
+__device__ __forceinline__ const uint4* x_row_ptr(const LinArgs& a, int row) {
+    const long r = a.x_rows ? a.x_rows[row] : row;
+    return reinterpret_cast<const uint4*>(a.x + r * a.x_stride);
+}
+
+template <int PRO>
+__device__ __forceinline__ void stage_x(const LinArgs& a, uint4* xs, int b0, int bt) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = a.K >> 3;
+    if (PRO == PRO_COPY) {
+        for (int b = 0; b < bt; ++b) {
+            const uint4* src = x_row_ptr(a, b0 + b);
+            for (int i = tid; i < nch; i += 256) xs[b * nch + i] = src[i];
+        }
+    } else if (PRO == PRO_RMSNORM) {
+        const uint4* nw = reinterpret_cast<const uint4*>(a.nw);
+        for (int b = wave; b < bt; b += 4) {
+            const uint4* xr = x_row_ptr(a, b0 + b);
+            float s = 0.0f;
+            for (int c = lane; c < nch; c += 64) s = sq8(xr[c], s);
+            s = butterfly<64>(s);
+            const float rinv = 1.0f / sqrtf(s / (float)a.K + a.eps);
+            for (int c = lane; c < nch; c += 64) {
+                uint4 v = xr[c], w = nw[c], o;
+                o.x = (u32)f2bf((bflo(v.x) * rinv) * bflo(w.x)) | ((u32)f2bf((bfhi(v.x) * rinv) * bfhi(w.x)) << 16);
+                o.y = (u32)f2bf((bflo(v.y) * rinv) * bflo(w.y)) | ((u32)f2bf((bfhi(v.y) * rinv) * bfhi(w.y)) << 16);
+                o.z = (u32)f2bf((bflo(v.z) * rinv) * bflo(w.z)) | ((u32)f2bf((bfhi(v.z) * rinv) * bfhi(w.z)) << 16);
+                o.w = (u32)f2bf((bflo(v.w) * rinv) * bflo(w.w)) | ((u32)f2bf((bfhi(v.w) * rinv) * bfhi(w.w)) << 16);
+                xs[b * nch + c] = o;
+                if (a.x_out && blockIdx.x == 0)
+                    reinterpret_cast<uint4*>(a.x_out + (size_t)(b0 + b) * a.x_out_stride)[c] = o;
+            }
+        }
+    } else {  // PRO_ATTN: merge the attention partials of row b into x[b, h*D+d]
+        bf16_t* xb = reinterpret_cast<bf16_t*>(xs);
+        const int HD = a.Hq * a.D;
+        for (int e = tid; e < bt * HD; e += 256) {
+            const int b = e / HD, h = (e % HD) / a.D, d = e % a.D;
+            const int row = b0 + b;
+            const int nc = (a.kvlen[row] + VOX_TC - 1) / VOX_TC;
+            const float* ml = a.part_ml + ((size_t)row * a.Hq + h) * a.max_chunks * 2;
+            const float* po = a.part_o + ((size_t)row * a.Hq + h) * a.max_chunks * a.D + d;
+            float M = -INFINITY;
+            for (int c = 0; c < nc; ++c) M = fmaxf(M, ml[2 * c]);
+            float L = 0.0f, O = 0.0f;
+            for (int c = 0; c < nc; ++c) {
+                const float w = exp2_c((ml[2 * c] - M) * VOX_LOG2E);
+                L = __fmaf_rn(ml[2 * c + 1], w, L);
+                O = __fmaf_rn(po[(size_t)c * a.D], w, O);
+            }
+            xb[e] = f2bf(O / L);
+        }
+    }
+}
+
+template <int BT, int R, int PRO, int EPI>
+__global__ __launch_bounds__(256) void k_linear(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* xs = reinterpret_cast<uint4*>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = a.K >> 3;
+    constexpr int OUT = (EPI == EPI_SILU_MUL) ? R / 2 : R;
+    constexpr int U = (R * BT >= 16) ? 2 : 4;  // chunk-steps issued together (loads in flight per lane = U*R)
+    const int n0 = (blockIdx.x * 4 + wave) * OUT;
+
+    const uint4* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int n = n0 + (EPI == EPI_SILU_MUL ? (r % OUT) : r);
+        n = n < a.N ? n : a.N - 1;
+        const bf16_t* base = (EPI == EPI_SILU_MUL && r >= OUT) ? a.W2 : a.W;
+        wrow[r] = reinterpret_cast<const uint4*>(base + (size_t)n * a.K);
+    }
+
+    for (int b0 = 0; b0 < a.B; b0 += BT) {
+        const int bt = (a.B - b0) < BT ? (a.B - b0) : BT;
+        if (b0 > 0) __syncthreads();
+        stage_x<PRO>(a, xs, b0, bt);
+        __syncthreads();
+
+        float acc[R][BT];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int b = 0; b < BT; ++b) acc[r][b] = 0.0f;
+
+        for (int c = lane; c < nch; c += 64 * U) {
+            uint4 w[U][R];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (c + 64 * u < nch) w[u][r] = ldg_nt(wrow[r] + c + 64 * u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (c + 64 * u < nch) {
+#pragma unroll
+                    for (int b = 0; b < BT; ++b) {
+                        const uint4 xv = xs[b * nch + c + 64 * u];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r][b] = dot8(w[u][r], xv, acc[r][b]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int b = 0; b < BT; ++b) acc[r][b] = butterfly<64>(acc[r][b]);
+
+#pragma unroll
+        for (int o = 0; o < OUT; ++o)
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                if (lane == o * BT + b && b < bt && n0 + o < a.N) {
+                    const int n = n0 + o;
+                    const size_t oi = (size_t)(b0 + b) * a.N + n;
+                    bf16_t r;
+                    if (EPI == EPI_SILU_MUL) {
+                        const float g = bfround(acc[o][b]);
+                        const float u = bfround(acc[o + OUT][b]);
+                        r = f2bf(bfround(silu_c(g)) * u);
+                    } else {
+                        float v = acc[o][b];
+                        if (a.bias) v = v + bf2f(a.bias[n]);
+                        r = f2bf(v);
+                        if (EPI == EPI_SILU) r = f2bf(silu_c(bf2f(r)));
+                        if (a.residual) r = f2bf(bf2f(a.residual[oi]) + bf2f(r));
+                    }
+                    a.y[oi] = r;
+                }
+            }
+    }
+}
+
+template <int BT, int R, int PRO, int EPI>
+static int launch_linear_t(hipStream_t st, const LinArgs& a) {
+    constexpr int OUT = (EPI == EPI_SILU_MUL) ? R / 2 : R;
+    const int grid = (a.N + 4 * OUT - 1) / (4 * OUT);
+    const size_t smem = (size_t)BT * a.K * 2;
+    auto kern = k_linear<BT, R, PRO, EPI>;
+    if (smem > 64 * 1024) {
+        static bool done = false;  // per instantiation
+        if (!done) {
+            VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
+    return VOX_OK;
+}
+
+template <int PRO, int EPI>
+static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
+    // batch tile: smallest of {1,2,4,8} covering B (B>8 loops tiles of 8 inside the kernel)
+    int bt = a.B <= 1 ? 1 : a.B <= 2 ? 2 : a.B <= 4 ? 4 : 8;
+    while (bt > 1 && (size_t)bt * a.K * 2 > 144 * 1024) bt >>= 1;
+    // rows per wave: keep >= ~1 block per CU; fewer rows/wave when N is small
+    constexpr bool SM = (EPI == EPI_SILU_MUL);
+    const int outs = a.N;
+    int r;  // outputs per wave
+    if (bt >= 4) r = (outs / 8 >= n_cu) ? 2 : 1;
+    else r = (outs / 16 >= n_cu) ? 4 : (outs / 8 >= n_cu) ? 2 : 1;
+    if ((size_t)bt * a.K * 2 > 160 * 1024) return vox_fail(VOX_ERR_INVALID, "linear: K too large for LDS staging");
+#define VOX_LIN(BT_, R_)                                                             \
+    if (bt == BT_ && r == R_) return launch_linear_t<BT_, (SM ? 2 * R_ : R_), PRO, EPI>(st, a);
+    VOX_LIN(1, 4) VOX_LIN(1, 2) VOX_LIN(1, 1) VOX_LIN(2, 4) VOX_LIN(2, 2) VOX_LIN(2, 1)
+    VOX_LIN(4, 2) VOX_LIN(4, 1) VOX_LIN(8, 2) VOX_LIN(8, 1)
+#undef VOX_LIN
+    return vox_fail(VOX_ERR_INVALID, "linear: no kernel variant");
+}
+
+int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
+    if (c.K % 8 != 0 || c.B <= 0 || c.N <= 0) return vox_fail(VOX_ERR_INVALID, "linear: K%8!=0 or empty");
+    LinArgs a{};
+    a.W = (const bf16_t*)c.W; a.W2 = (const bf16_t*)c.W2; a.bias = (const bf16_t*)c.bias;
+    a.x = (const bf16_t*)c.x; a.residual = (const bf16_t*)c.residual; a.nw = (const bf16_t*)c.norm_w;
+    a.y = (bf16_t*)c.y; a.x_out = (bf16_t*)c.x_out; a.part_o = c.part_o; a.part_ml = c.part_ml;
+    a.kvlen = c.kvlen; a.x_rows = c.x_rows; a.x_stride = c.x_stride ? c.x_stride : c.K;
+    a.x_out_stride = c.x_out_stride ? c.x_out_stride : c.K; a.eps = c.eps; a.B = c.B; a.N = c.N; a.K = c.K; a.Hq = c.Hq; a.D = c.D;
+    a.max_chunks = c.max_chunks;
+    const int ncu = ctx->n_cu;
+#define VOX_PE(P, E) if (c.pro == P && c.epi == E) return launch_linear_pe<P, E>(st, a, ncu);
+    VOX_PE(PRO_COPY, EPI_STORE) VOX_PE(PRO_COPY, EPI_SILU) VOX_PE(PRO_COPY, EPI_SILU_MUL)
+    VOX_PE(PRO_RMSNORM, EPI_STORE) VOX_PE(PRO_RMSNORM, EPI_SILU_MUL) VOX_PE(PRO_ATTN, EPI_STORE)
+#undef VOX_PE
+    return vox_fail(VOX_ERR_INVALID, "linear: unsupported prologue/epilogue combination");
+}
+
+// ================================================================================================
+// standalone RMSNorm (one wave per row)
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = H >> 3;
+    const uint4* xr = reinterpret_cast<const uint4*>(x) + (size_t)row * nch;
+    const uint4* nw = reinterpret_cast<const uint4*>(w);
+    uint4* yr = reinterpret_cast<uint4*>(y) + (size_t)row * nch;
+    float s = 0.0f;
+    for (int c = lane; c < nch; c += 64) s = sq8(xr[c], s);
+    s = butterfly<64>(s);
+    const float rinv = 1.0f / sqrtf(s / (float)H + eps);
+    for (int c = lane; c < nch; c += 64) {
+        uint4 v = xr[c], g = nw[c], o;
+        o.x = (u32)f2bf((bflo(v.x) * rinv) * bflo(g.x)) | ((u32)f2bf((bfhi(v.x) * rinv) * bfhi(g.x)) << 16);
+        o.y = (u32)f2bf((bflo(v.y) * rinv) * bflo(g.y)) | ((u32)f2bf((bfhi(v.y) * rinv) * bfhi(g.y)) << 16);
+        o.z = (u32)f2bf((bflo(v.z) * rinv) * bflo(g.z)) | ((u32)f2bf((bfhi(v.z) * rinv) * bfhi(g.z)) << 16);
+        o.w = (u32)f2bf((bflo(v.w) * rinv) * bflo(g.w)) | ((u32)f2bf((bfhi(v.w) * rinv) * bfhi(g.w)) << 16);
+        yr[c] = o;
+    }
+}
+
+int vox_launch_rmsnorm(hipStream_t st, const void* x, const void* w, void* y, int rows, int H, float eps) {
+    if (H % 8) return vox_fail(VOX_ERR_INVALID, "rmsnorm: cols%8!=0");
+    if (rows <= 0) return VOX_OK;
+    hipLaunchKernelGGL(k_rmsnorm, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)w,
+                       (bf16_t*)y, rows, H, eps);
+    return VOX_OK;
+}
+
+// ================================================================================================
+// head prepare: [per-head RMSNorm] -> RoPE -> q buffer / paged KV append.  One wave per (row, head).
+// ================================================================================================
+struct HeadArgs {
+    const bf16_t *q_src, *k_src, *v_src;  // row strides below (elements)
+    long q_stride, k_stride, v_stride;
+    bf16_t *q_out, *k_out;                // [N,Hq,D] / [N,Hkv,D] (k_out optional)
+    bf16_t* kv;                           // paged cache layer or NULL
+    const bf16_t *qn, *kn;
+    const float* cs;
+    const int *pos, *page, *slot;
+    float eps;
+    int Hq, Hkv, D, rot, interleave, page_size, table_max_pos;
+};
+
+__global__ __launch_bounds__(64) void k_head_prepare(HeadArgs a) {
+    __shared__ float sh[512];
+    __shared__ __attribute__((aligned(16))) bf16_t so[512];
+    const int head = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+    const int D = a.D, lpt = D >> 3;
+    const int kind = head < a.Hq ? 0 : (head < a.Hq + a.Hkv ? 1 : 2);
+    const int h = kind == 0 ? head : (kind == 1 ? head - a.Hq : head - a.Hq - a.Hkv);
+    const bf16_t* src = kind == 0 ? a.q_src + (size_t)n * a.q_stride + (size_t)h * D
+                       : kind == 1 ? a.k_src + (size_t)n * a.k_stride + (size_t)h * D
+                                   : a.v_src + (size_t)n * a.v_stride + (size_t)h * D;
+    if (kind == 2 && !a.v_src) return;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (lane < lpt) v = reinterpret_cast<const uint4*>(src)[lane];
+    bf16_t* dst = nullptr;
+    const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
+    if (kind == 0) dst = a.q_out + ((size_t)n * a.Hq + h) * D;
+    else if (a.kv) {
+        const int pg = a.page[n];
+        if (pg >= 0)
+            dst = a.kv + (size_t)pg * ps + ((size_t)(kind == 2 ? a.page_size : 0) + a.slot[n]) * a.Hkv * D + (size_t)h * D;
+    } else if (kind == 1 && a.k_out) dst = a.k_out + ((size_t)n * a.Hkv + h) * D;
+    if (kind == 2) {
+        if (dst && lane < lpt) reinterpret_cast<uint4*>(dst)[lane] = v;
+        return;
+    }
+    float e[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+    const bf16_t* nw = kind == 0 ? a.qn : a.kn;
+    if (nw) {
+        float s = sq8(v, 0.0f);
+        s = butterfly<64>(s);
+        const float rinv = 1.0f / sqrtf(s / (float)D + a.eps);
+        if (lane < lpt) {
+            const uint4 g = reinterpret_cast<const uint4*>(nw)[lane];
+            const float gw[8] = {bflo(g.x), bfhi(g.x), bflo(g.y), bfhi(g.y), bflo(g.z), bfhi(g.z), bflo(g.w), bfhi(g.w)};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = bfround((e[i] * rinv) * gw[i]);
+        }
+    }
+    if (lane < lpt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sh[lane * 8 + i] = e[i];
+            so[lane * 8 + i] = f2bf(e[i]);
+        }
+    }
+    __syncthreads();
+    if (a.cs) {
+        const int half = a.rot >> 1;
+        int p = a.pos[n];
+        p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
+        const float* t = a.cs + (size_t)p * half * 2;
+        for (int i = lane; i < half; i += 64) {
+            const int ia = a.interleave ? 2 * i : i, ib = a.interleave ? 2 * i + 1 : i + half;
+            const float x = sh[ia], y = sh[ib], c = t[2 * i], s = t[2 * i + 1];
+            const float xc = x * c, yc = y * c;
+            so[ia] = f2bf(__fmaf_rn(-y, s, xc));
+            so[ib] = f2bf(__fmaf_rn(x, s, yc));
+        }
+        __syncthreads();
+    }
+    if (dst && lane < lpt) reinterpret_cast<uint4*>(dst)[lane] = reinterpret_cast<const uint4*>(so)[lane];
+}
+
+int vox_launch_head_prepare(hipStream_t st, const HeadCall& c) {
+    if (c.D % 8 || c.D > 512 || c.N <= 0) return c.N <= 0 ? VOX_OK : vox_fail(VOX_ERR_INVALID, "head_prepare: bad D");
+    HeadArgs a{};
+    a.q_src = (const bf16_t*)c.q_src; a.k_src = (const bf16_t*)c.k_src; a.v_src = (const bf16_t*)c.v_src;
+    a.q_stride = c.q_stride; a.k_stride = c.k_stride; a.v_stride = c.v_stride;
+    a.q_out = (bf16_t*)c.q_out; a.k_out = (bf16_t*)c.k_out; a.kv = (bf16_t*)c.kv;
+    a.qn = (const bf16_t*)c.qn; a.kn = (const bf16_t*)c.kn; a.cs = c.cs; a.pos = c.pos; a.page = c.page;
+    a.slot = c.slot; a.eps = c.eps; a.Hq = c.Hq; a.Hkv = c.Hkv; a.D = c.D; a.rot = c.rot;
+    a.interleave = c.interleave; a.page_size = c.page_size; a.table_max_pos = c.table_max_pos;
+    const int heads = c.Hq + c.Hkv + (c.v_src ? c.Hkv : 0);
+    hipLaunchKernelGGL(k_head_prepare, dim3(heads, c.N), dim3(64), 0, st, a);
+    return VOX_OK;
+}
+
+// ================================================================================================
+// chunked paged attention: one block per (chunk of 32 KV tokens, kv head, query row)
+// ================================================================================================
+struct AttnArgs {
+    const bf16_t *q, *kv;
+    const int *q_req, *q_kvlen, *indptr, *indices;
+    float *part_o, *part_ml;
+    float scale;
+    int Hq, Hkv, page_size, max_chunks;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
+    constexpr int LPT = D / 8;        // lanes per token
+    constexpr int TPW = 64 / LPT;     // tokens per wave pass
+    constexpr int GMAX = 16;
+    __shared__ __attribute__((aligned(16))) uint4 Ks[VOX_TC * LPT];
+    __shared__ __attribute__((aligned(16))) uint4 Vs[VOX_TC * LPT];
+    __shared__ __attribute__((aligned(16))) uint4 Qs[GMAX * LPT];
+    __shared__ float S[GMAX][VOX_TC];
+    __shared__ float Ms[GMAX];
+
+    const int c = blockIdx.x, hk = blockIdx.y, row = blockIdx.z;
+    const int L = a.q_kvlen[row];
+    const int t0 = c * VOX_TC;
+    if (t0 >= L) return;
+    const int nt = (L - t0) < VOX_TC ? (L - t0) : VOX_TC;
+    const int G = a.Hq / a.Hkv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int* pages = a.indices + a.indptr[a.q_req[row]];
+    const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
+
+    for (int i = tid; i < VOX_TC * LPT; i += 256) {
+        const int t = i / LPT, j = i % LPT;
+        uint4 kx = make_uint4(0, 0, 0, 0), vx = kx;
+        if (t < nt) {
+            const int tok = t0 + t;
+            const bf16_t* base = a.kv + (size_t)pages[tok / a.page_size] * ps +
+                                 ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
+            kx = reinterpret_cast<const uint4*>(base)[j];
+            vx = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
+        }
+        Ks[i] = kx;
+        Vs[i] = vx;
+    }
+    for (int i = tid; i < G * LPT; i += 256) {
+        const int g = i / LPT, j = i % LPT;
+        Qs[i] = reinterpret_cast<const uint4*>(a.q + ((size_t)row * a.Hq + hk * G + g) * D)[j];
+    }
+    __syncthreads();
+
+    // scores: LPT lanes per token, butterfly over LPT lanes
+    for (int tb = wave * TPW; tb < VOX_TC; tb += 4 * TPW) {
+        const int tt = tb + lane / LPT, j = lane % LPT;
+        const uint4 kx = Ks[tt * LPT + j];
+        for (int g = 0; g < G; ++g) {
+            float d = dot8(Qs[g * LPT + j], kx, 0.0f);
+            d = butterfly<LPT>(d);
+            if (j == 0) S[g][tt] = d * a.scale;
+        }
+    }
+    __syncthreads();
+    // chunk max + p = exp2((s-m)*log2e): 32 lanes per q head
+    for (int pr = tid; pr < G * VOX_TC; pr += 256) {
+        const int g = pr / VOX_TC, t = pr % VOX_TC;
+        const float s = t < nt ? S[g][t] : -INFINITY;
+        float m = s;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, VOX_WAVE));
+        const float p = t < nt ? exp2_c((s - m) * VOX_LOG2E) : 0.0f;
+        S[g][t] = p;
+        if (t == 0) Ms[g] = m;
+    }
+    __syncthreads();
+    // PV: one thread per (q head, d); sequential over tokens
+    const bf16_t* Vb = reinterpret_cast<const bf16_t*>(Vs);
+    for (int e = tid; e < G * D; e += 256) {
+        const int g = e / D, d = e % D;
+        float o = 0.0f, l = 0.0f;
+        for (int t = 0; t < nt; ++t) {
+            const float p = S[g][t];
+            l = l + p;
+            o = __fmaf_rn(p, bf2f(Vb[t * D + d]), o);
+        }
+        const size_t hi = (size_t)row * a.Hq + hk * G + g;
+        a.part_o[(hi * a.max_chunks + c) * D + d] = o;
+        if (d == 0) {
+            a.part_ml[(hi * a.max_chunks + c) * 2 + 0] = Ms[g];
+            a.part_ml[(hi * a.max_chunks + c) * 2 + 1] = l;
+        }
+    }
+}
+
+int vox_launch_attn_partial(hipStream_t st, const AttnCall& c) {
+    if (c.Nq <= 0) return VOX_OK;
+    if (c.Hq % c.Hkv || c.Hq / c.Hkv > 16) return vox_fail(VOX_ERR_INVALID, "attention: unsupported GQA group");
+    AttnArgs a{};
+    a.q = (const bf16_t*)c.q; a.kv = (const bf16_t*)c.kv; a.q_req = c.q_req; a.q_kvlen = c.q_kvlen;
+    a.indptr = c.indptr; a.indices = c.indices; a.part_o = c.part_o; a.part_ml = c.part_ml; a.scale = c.scale;
+    a.Hq = c.Hq; a.Hkv = c.Hkv; a.page_size = c.page_size; a.max_chunks = c.max_chunks;
+    int nchunk = (c.max_kvlen + VOX_TC - 1) / VOX_TC;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > c.max_chunks) return vox_fail(VOX_ERR_INVALID, "attention: max_kvlen exceeds workspace");
+    dim3 grid(nchunk, c.Hkv, c.Nq);
+    if (c.D == 128) hipLaunchKernelGGL(k_attn_partial<128>, grid, dim3(256), 0, st, a);
+    else if (c.D == 64) hipLaunchKernelGGL(k_attn_partial<64>, grid, dim3(256), 0, st, a);
+    else if (c.D == 16) hipLaunchKernelGGL(k_attn_partial<16>, grid, dim3(256), 0, st, a);
+    else return vox_fail(VOX_ERR_INVALID, "attention: head_dim must be 16, 64 or 128");
+    return VOX_OK;
+}
+
+// merge partials -> bf16 out [Nq,Hq,D] (standalone op path; the engine merges inside the o_proj prologue)
+__global__ __launch_bounds__(256) void k_attn_merge(const float* part_o, const float* part_ml, const int* kvlen,
+                                                    bf16_t* out, int Hq, int D, int max_chunks, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int HD = Hq * D;
+    const int row = e / HD, h = (e % HD) / D, d = e % D;
+    const int nc = (kvlen[row] + VOX_TC - 1) / VOX_TC;
+    const float* ml = part_ml + ((size_t)row * Hq + h) * max_chunks * 2;
+    const float* po = part_o + ((size_t)row * Hq + h) * max_chunks * D + d;
+    float M = -INFINITY;
+    for (int c = 0; c < nc; ++c) M = fmaxf(M, ml[2 * c]);
+    float L = 0.0f, O = 0.0f;
+    for (int c = 0; c < nc; ++c) {
+        const float w = exp2_c((ml[2 * c] - M) * VOX_LOG2E);
+        L = __fmaf_rn(ml[2 * c + 1], w, L);
+        O = __fmaf_rn(po[(size_t)c * D], w, O);
+    }
+    out[e] = f2bf(O / L);
+}
+
+int vox_launch_attn_merge(hipStream_t st, const float* part_o, const float* part_ml, const int* kvlen, void* out,
+                          int Nq, int Hq, int D, int max_chunks) {
+    const int total = Nq * Hq * D;
+    if (total <= 0) return VOX_OK;
+    hipLaunchKernelGGL(k_attn_merge, dim3((total + 255) / 256), dim3(256), 0, st, part_o, part_ml, kvlen,
+                       (bf16_t*)out, Hq, D, max_chunks, total);
+    return VOX_OK;
+}
+
+// ================================================================================================
+// small elementwise / gather kernels
+// ================================================================================================
+// dst[b*dst_stride + i] = table[ids[b*id_stride+id_off]*H + i]
+__global__ __launch_bounds__(256) void k_gather_rows(const bf16_t* table, const int* ids, int id_stride, int id_off,
+                                                     bf16_t* dst, long dst_stride, int H, int vocab) {
+    const int b = blockIdx.y;
+    int id = ids[(size_t)b * id_stride + id_off];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const uint4* src = reinterpret_cast<const uint4*>(table + (size_t)id * H);
+    uint4* d = reinterpret_cast<uint4*>(dst + (size_t)b * dst_stride);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < (H >> 3); i += gridDim.x * 256) d[i] = src[i];
+}
+int vox_launch_gather(hipStream_t st, const void* table, const int* ids, int id_stride, int id_off, void* dst,
+                      long dst_stride, int B, int H, int vocab) {
+    if (B <= 0) return VOX_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3((H / 8 + 255) / 256, B), dim3(256), 0, st, (const bf16_t*)table, ids,
+                       id_stride, id_off, (bf16_t*)dst, dst_stride, H, vocab);
+    return VOX_OK;
+}
+
+// Qwen3 input mix (qwen3_tts.py:1836-1852): e = mask ? bf16(text + codec_emb[id0]) : text; y = bf16(e + feat)
+__global__ __launch_bounds__(256) void k_qwen3_mix(const bf16_t* text, const bf16_t* codec_table, const int* ids,
+                                                   int id_stride, const uint8_t* mask, const bf16_t* feat, bf16_t* y,
+                                                   int H, int vocab) {
+    const int b = blockIdx.y;
+    int id = ids[(size_t)b * id_stride];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const bool m = mask[b] != 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H; i += gridDim.x * 256) {
+        const size_t j = (size_t)b * H + i;
+        bf16_t e = text[j];
+        if (m) e = f2bf(bf2f(e) + bf2f(codec_table[(size_t)id * H + i]));
+        y[j] = f2bf(bf2f(e) + bf2f(feat[j]));
+    }
+}
+int vox_launch_qwen3_mix(hipStream_t st, const void* text, const void* codec_table, const int* ids, int id_stride,
+                         const uint8_t* mask, const void* feat, void* y, int B, int H, int vocab) {
+    if (B <= 0) return VOX_OK;
+    hipLaunchKernelGGL(k_qwen3_mix, dim3((H + 255) / 256, B), dim3(256), 0, st, (const bf16_t*)text,
+                       (const bf16_t*)codec_table, ids, id_stride, mask, (const bf16_t*)feat, (bf16_t*)y, H, vocab);
+    return VOX_OK;
+}
+
+__global__ __launch_bounds__(256) void k_kv_append(bf16_t* kv, const bf16_t* k, const bf16_t* v, const int* page,
+                                                   const int* slot, int page_size, int HD8) {
+    const int n = blockIdx.y;
+    const int pg = page[n];
+    if (pg < 0) return;
+    const size_t ps8 = (size_t)2 * page_size * HD8;
+    uint4* kd = reinterpret_cast<uint4*>(kv) + (size_t)pg * ps8 + (size_t)slot[n] * HD8;
+    uint4* vd = kd + (size_t)page_size * HD8;
+    const uint4* ks = reinterpret_cast<const uint4*>(k) + (size_t)n * HD8;
+    const uint4* vs = reinterpret_cast<const uint4*>(v) + (size_t)n * HD8;
+    for (int i = threadIdx.x; i < HD8; i += 256) {
+        kd[i] = ks[i];
+        vd[i] = vs[i];
+    }
+}
+int vox_launch_kv_append(hipStream_t st, void* kv, const void* k, const void* v, const int* page, const int* slot,
+                         int N, int page_size, int Hkv, int D) {
+    if (N <= 0) return VOX_OK;
+    if ((Hkv * D) % 8) return vox_fail(VOX_ERR_INVALID, "kv_append: Hkv*D%8!=0");
+    hipLaunchKernelGGL(k_kv_append, dim3(1, N), dim3(256), 0, st, (bf16_t*)kv, (const bf16_t*)k, (const bf16_t*)v,
+                       page, slot, page_size, Hkv * D / 8);
+    return VOX_OK;
+}

@@ -1,0 +1,326 @@
+// On-device sampler: suppress mask, repetition penalty, greedy argmax (first max on ties), top-k / top-p /
+// min-p multinomial from a Philox4x32-10 stream, fused with the embedding gather of the sampled id.
+// One 256-thread block per logits row.  Replaces vox_serve/sampling.py + the python per-request loops of
+// Qwen3TTSModel.sampling / depth_sampling (model/qwen3_tts.py:1863-2004).  Integer/bit-exact contract:
+// oracle/voxref.c::vr_argmax / vr_sample.
+#include "vox_internal.h"
+
+#define SAMP_KMAX 256
+
+__device__ __forceinline__ u32 key_of(bf16_t b) {
+    if (b == 0x8000) b = 0;  // -0 == +0
+    return (b & 0x8000) ? (u32)(~b & 0xffff) : (u32)(b | 0x8000);
+}
+__device__ __forceinline__ bf16_t bits_of(u32 key) { return (key & 0x8000) ? (bf16_t)(key & 0x7fff) : (bf16_t)(~key & 0xffff); }
+
+__device__ __forceinline__ u32 philox_u32(uint64_t seed, uint64_t offset, u32 row) {
+    u32 c0 = (u32)offset, c1 = (u32)(offset >> 32), c2 = row, c3 = 0;
+    u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n1 = (u32)p1;
+        const u32 n2 = (u32)(p0 >> 32) ^ c3 ^ k1, n3 = (u32)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+struct SampArgs {
+    bf16_t* logits;
+    const int* suppress_ids;
+    const uint8_t* rep_cache;
+    const uint64_t* offset_dev;
+    int* out_ids;
+    const bf16_t* emb_table;
+    bf16_t *emb_dst, *feat_acc;
+    uint64_t seed, offset, offset_mul;
+    long emb_dst_stride;
+    float top_p, min_p, temperature, penalty;
+    int V, n_suppress, W, C, greedy, top_k, out_stride, out_col, emb_vocab, H, feat_init;
+};
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const u32 lo = __shfl_xor((u32)v, off, VOX_WAVE), hi = __shfl_xor((u32)(v >> 32), off, VOX_WAVE);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_sample(SampArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned long long red[4];
+    __shared__ int hist[256];
+    __shared__ int sh_i[8];
+    __shared__ u32 cand_key[SAMP_KMAX], srt_key[SAMP_KMAX];
+    __shared__ int cand_idx[SAMP_KMAX], srt_idx[SAMP_KMAX];
+    __shared__ float pe[SAMP_KMAX];
+    __shared__ int wcnt[4];
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = a.V;
+    bf16_t* lg = a.logits + (size_t)b * V;
+
+    if (a.n_suppress > 0) {
+        for (int j = tid; j < a.n_suppress; j += 256) lg[a.suppress_ids[j]] = 0xFF7F;
+        __syncthreads();
+    }
+    if (a.rep_cache && a.penalty != 1.0f) {
+        for (int v = tid; v < V; v += 256) {
+            int m = 0;
+            for (int w = 0; w < a.W; ++w) m |= a.rep_cache[(((size_t)b * a.W + w) * a.C) * V + v];
+            if (m) {
+                const float l = bf2f(lg[v]);
+                lg[v] = f2bf(l > 0.0f ? l / a.penalty : l * a.penalty);
+            }
+        }
+        __syncthreads();
+    }
+
+    int picked;
+    if (a.greedy) {
+        unsigned long long best = 0;
+        for (int v = tid; v < V; v += 256) {
+            const unsigned long long c = ((unsigned long long)key_of(lg[v]) << 32) | (u32)(0xFFFFFFFFu - (u32)v);
+            best = c > best ? c : best;
+        }
+        best = wave_max_u64(best);
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        unsigned long long m = red[0];
+        for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+        picked = (int)(0xFFFFFFFFu - (u32)m);
+    } else {
+        uint16_t* keys = reinterpret_cast<uint16_t*>(smem);
+        const int k = a.top_k < V ? a.top_k : V;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int v = tid; v < V; v += 256) {
+            const u32 ky = key_of(f2bf(bf2f(lg[v]) / a.temperature));
+            keys[v] = (uint16_t)ky;
+            atomicAdd(&hist[ky >> 8], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, b1 = 255;
+            for (; b1 > 0; --b1) {
+                if (cum + hist[b1] >= k) break;
+                cum += hist[b1];
+            }
+            sh_i[0] = b1;
+            sh_i[1] = cum;  // elements strictly above bin b1
+        }
+        __syncthreads();
+        const int b1 = sh_i[0], above1 = sh_i[1];
+        __syncthreads();
+        hist[tid] = 0;
+        __syncthreads();
+        for (int v = tid; v < V; v += 256)
+            if ((keys[v] >> 8) == b1) atomicAdd(&hist[keys[v] & 0xff], 1);
+        __syncthreads();
+        if (tid == 0) {
+            int cum = above1, b2 = 255;
+            for (; b2 > 0; --b2) {
+                if (cum + hist[b2] >= k) break;
+                cum += hist[b2];
+            }
+            sh_i[2] = (b1 << 8) | b2;
+            sh_i[3] = k - cum;                 // r: ties to take (by ascending index)
+            sh_i[4] = hist[b2] > (k - cum);    // more ties than needed -> ordered selection
+            sh_i[5] = 0;                       // candidate counter
+            sh_i[6] = 0;                       // running tie count
+        }
+        __syncthreads();
+        const u32 T = (u32)sh_i[2];
+        const int r = sh_i[3], need_order = sh_i[4];
+        if (!need_order) {
+            for (int v = tid; v < V; v += 256) {
+                const u32 ky = keys[v];
+                if (ky >= T) {
+                    const int s = atomicAdd(&sh_i[5], 1);
+                    cand_key[s] = ky;
+                    cand_idx[s] = v;
+                }
+            }
+        } else {
+            for (int base = 0; base < V; base += 256) {
+                const int v = base + tid;
+                const u32 ky = v < V ? keys[v] : 0;
+                const bool tie = v < V && ky == T;
+                const unsigned long long bal = __ballot(tie);
+                if (lane == 0) wcnt[wave] = __popcll(bal);
+                __syncthreads();
+                int before = sh_i[6];
+                for (int w = 0; w < wave; ++w) before += wcnt[w];
+                before += __popcll(bal & ((1ull << lane) - 1ull));
+                const bool sel = (v < V && ky > T) || (tie && before < r);
+                if (sel) {
+                    const int s = atomicAdd(&sh_i[5], 1);
+                    cand_key[s] = ky;
+                    cand_idx[s] = v;
+                }
+                __syncthreads();
+                if (tid == 0) sh_i[6] += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            }
+        }
+        __syncthreads();
+        const int n0 = sh_i[5];  // == k
+        for (int j = tid; j < n0; j += 256) {
+            const u32 kj = cand_key[j];
+            const int ij = cand_idx[j];
+            int rank = 0;
+            for (int i = 0; i < n0; ++i) rank += (cand_key[i] > kj) || (cand_key[i] == kj && cand_idx[i] < ij);
+            srt_key[rank] = kj;
+            srt_idx[rank] = ij;
+        }
+        __syncthreads();
+        const float mval = bf2f(bits_of(srt_key[0]));
+        for (int j = tid; j < n0; j += 256) pe[j] = exp2_c((bf2f(bits_of(srt_key[j])) - mval) * VOX_LOG2E);
+        __syncthreads();
+        if (tid == 0) {
+            int n = n0;
+            float tot = 0.0f;
+            for (int j = 0; j < n; ++j) tot = tot + pe[j];
+            if (a.min_p > 0.0f) {
+                int kk = 0;
+                while (kk < n && pe[kk] >= a.min_p * pe[0]) ++kk;
+                n = kk;
+                tot = 0.0f;
+                for (int j = 0; j < n; ++j) tot = tot + pe[j];
+            }
+            if (a.top_p < 1.0f) {
+                float c = 0.0f;
+                const float thr = a.top_p * tot;
+                int kk = 0;
+                while (kk < n) {
+                    c = c + pe[kk];
+                    ++kk;
+                    if (c >= thr) break;
+                }
+                n = kk;
+                tot = c;
+            }
+            const uint64_t off = a.offset + (a.offset_dev ? (*a.offset_dev) * a.offset_mul : 0ull);
+            const float u = (float)(philox_u32(a.seed, off, (u32)b) >> 8) * (1.0f / 16777216.0f);
+            const float thr = u * tot;
+            float c = 0.0f;
+            int pick = n - 1;
+            for (int j = 0; j < n; ++j) {
+                c = c + pe[j];
+                if (c > thr) {
+                    pick = j;
+                    break;
+                }
+            }
+            sh_i[7] = srt_idx[pick];
+        }
+        __syncthreads();
+        picked = sh_i[7];
+    }
+    if (tid == 0) a.out_ids[(size_t)b * a.out_stride + a.out_col] = picked;
+
+    if (a.emb_table) {
+        int id = picked < 0 ? 0 : (picked >= a.emb_vocab ? a.emb_vocab - 1 : picked);
+        const uint4* src = reinterpret_cast<const uint4*>(a.emb_table + (size_t)id * a.H);
+        uint4* dst = a.emb_dst ? reinterpret_cast<uint4*>(a.emb_dst + (size_t)b * a.emb_dst_stride) : nullptr;
+        uint4* fa = a.feat_acc ? reinterpret_cast<uint4*>(a.feat_acc + (size_t)b * a.H) : nullptr;
+        for (int i = tid; i < (a.H >> 3); i += 256) {
+            const uint4 e = src[i];
+            if (dst) dst[i] = e;
+            if (fa) {
+                uint4 f = a.feat_init ? make_uint4(0, 0, 0, 0) : fa[i];
+                uint4 o;
+                o.x = (u32)f2bf(bflo(f.x) + bflo(e.x)) | ((u32)f2bf(bfhi(f.x) + bfhi(e.x)) << 16);
+                o.y = (u32)f2bf(bflo(f.y) + bflo(e.y)) | ((u32)f2bf(bfhi(f.y) + bfhi(e.y)) << 16);
+                o.z = (u32)f2bf(bflo(f.z) + bflo(e.z)) | ((u32)f2bf(bfhi(f.z) + bfhi(e.z)) << 16);
+                o.w = (u32)f2bf(bflo(f.w) + bflo(e.w)) | ((u32)f2bf(bfhi(f.w) + bfhi(e.w)) << 16);
+                fa[i] = o;
+            }
+        }
+    }
+}
+
+int vox_launch_sample(hipStream_t st, const SampleCall& c) {
+    if (c.B <= 0) return VOX_OK;
+    const bool greedy = c.cfg.greedy || c.cfg.temperature == 0.0f ||
+                        (c.cfg.top_k <= 0 && !(c.cfg.top_p < 1.0f) && !(c.cfg.min_p > 0.0f));
+    SampArgs a{};
+    a.logits = (bf16_t*)c.logits; a.suppress_ids = c.suppress_ids; a.rep_cache = c.rep_cache;
+    a.offset_dev = c.offset_dev; a.out_ids = c.out_ids; a.emb_table = (const bf16_t*)c.emb_table;
+    a.emb_dst = (bf16_t*)c.emb_dst; a.feat_acc = (bf16_t*)c.feat_acc; a.seed = c.seed; a.offset = c.offset;
+    a.offset_mul = c.offset_mul; a.emb_dst_stride = c.emb_dst_stride; a.top_p = c.cfg.top_p;
+    a.min_p = c.cfg.min_p; a.temperature = c.cfg.temperature; a.penalty = c.cfg.repetition_penalty;
+    a.V = c.V; a.n_suppress = c.n_suppress; a.W = c.W; a.C = c.C; a.greedy = greedy ? 1 : 0;
+    a.top_k = c.cfg.top_k; a.out_stride = c.out_stride; a.out_col = c.out_col; a.emb_vocab = c.emb_vocab;
+    a.H = c.H; a.feat_init = c.feat_init;
+    size_t smem = 0;
+    if (!greedy) {
+        if (c.cfg.top_k <= 0 || c.cfg.top_k > SAMP_KMAX)
+            return vox_fail(VOX_ERR_INVALID, "sample: stochastic modes need 1 <= top_k <= %d (top_p/min_p-only not yet built)", SAMP_KMAX);
+        if (c.V > 32768) return vox_fail(VOX_ERR_INVALID, "sample: stochastic vocab > 32768 not yet built");
+        smem = (size_t)c.V * 2;
+    }
+    if (c.emb_table && (c.H % 8)) return vox_fail(VOX_ERR_INVALID, "sample: H%8!=0");
+    hipLaunchKernelGGL(k_sample, dim3(c.B), dim3(256), smem, st, a);
+    return VOX_OK;
+}
+
+// ---- standalone pieces for the drop-in Sampler API -------------------------------------------------
+__global__ void k_suppress(bf16_t* lg, int V, const int* ids, int n) {
+    const int b = blockIdx.y;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256) lg[(size_t)b * V + ids[j]] = 0xFF7F;
+}
+int vox_launch_suppress(hipStream_t st, void* logits, int B, int V, const int* ids, int n) {
+    if (B <= 0 || n <= 0) return VOX_OK;
+    hipLaunchKernelGGL(k_suppress, dim3((n + 255) / 256, B), dim3(256), 0, st, (bf16_t*)logits, V, ids, n);
+    return VOX_OK;
+}
+
+__global__ void k_rep_penalty(bf16_t* lg, const uint8_t* cache, int W, int C, int V, float p) {
+    const int b = blockIdx.y;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+        int m = 0;
+        for (int w = 0; w < W; ++w) m |= cache[(((size_t)b * W + w) * C) * V + v];
+        if (m) {
+            const float l = bf2f(lg[(size_t)b * V + v]);
+            lg[(size_t)b * V + v] = f2bf(l > 0.0f ? l / p : l * p);
+        }
+    }
+}
+int vox_launch_rep_penalty(hipStream_t st, void* logits, const uint8_t* cache, int B, int W, int C, int V, float p) {
+    if (B <= 0) return VOX_OK;
+    hipLaunchKernelGGL(k_rep_penalty, dim3((V + 255) / 256, B), dim3(256), 0, st, (bf16_t*)logits, cache, W, C, V, p);
+    return VOX_OK;
+}
+
+// window shift (one block per batch row), then the leak-faithful set: every row gets every request's id
+__global__ void k_rep_shift(uint8_t* cache, int W, int C, int V) {
+    uint8_t* cb = cache + (size_t)blockIdx.x * W * C * V;
+    const size_t plane = (size_t)C * V;
+    for (int w = 0; w + 1 < W; ++w) {
+        for (size_t i = threadIdx.x; i < plane; i += blockDim.x) cb[w * plane + i] = cb[(w + 1) * plane + i];
+        __syncthreads();
+    }
+    for (size_t i = threadIdx.x; i < plane; i += blockDim.x) cb[(size_t)(W - 1) * plane + i] = 0;
+}
+__global__ void k_rep_set(uint8_t* cache, const int* ids, int B, int W, int C, int V, int only_last) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over B(rows) * W * B(ids)
+    const int total = B * W * B;
+    if (i >= total) return;
+    const int b = i / (W * B), w = (i / B) % W, j = i % B;
+    if (only_last && w != W - 1) return;
+    cache[(((size_t)b * W + w) * C) * V + ids[j]] = 1;
+}
+int vox_launch_rep_update(hipStream_t st, uint8_t* cache, const int* ids, int B, int W, int C, int V, int window) {
+    if (B <= 0) return VOX_OK;
+    if (window > 1) hipLaunchKernelGGL(k_rep_shift, dim3(B), dim3(256), 0, st, cache, W, C, V);
+    const int total = B * W * B;
+    hipLaunchKernelGGL(k_rep_set, dim3((total + 255) / 256), dim3(256), 0, st, cache, ids, B, W, C, V,
+                       window > 1 ? 1 : 0);
+    return VOX_OK;
+}

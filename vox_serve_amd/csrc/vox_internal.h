@@ -1,0 +1,107 @@
+// Internal (non-ABI) declarations shared by the libvoxhip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/voxhip.h"
+#include "vox_device.h"
+
+int vox_fail(int code, const char* fmt, ...);
+
+#define VOX_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return vox_fail(VOX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                               \
+    } while (0)
+#define VOX_TRY(expr)               \
+    do {                            \
+        int _s = (expr);            \
+        if (_s != VOX_OK) return _s; \
+    } while (0)
+
+struct vox_ctx {
+    int device;
+    int n_cu;
+    int64_t lds_bytes, hbm_bytes;
+};
+
+struct vox_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+// ---- kernel launchers (kernels_lm.hip) ----------------------------------------------------------
+struct LinearCall {
+    const void *W = nullptr, *W2 = nullptr, *bias = nullptr, *x = nullptr, *residual = nullptr, *norm_w = nullptr;
+    void *y = nullptr, *x_out = nullptr;
+    const float *part_o = nullptr, *part_ml = nullptr;
+    const int* kvlen = nullptr;
+    const int* x_rows = nullptr;
+    long x_stride = 0, x_out_stride = 0;  // elements; 0 = K
+    float eps = 1e-6f;
+    int B = 0, N = 0, K = 0, Hq = 0, D = 0, max_chunks = 0;
+    int pro = 0, epi = 0;  // PRO_* / EPI_*
+};
+enum { VOX_PRO_COPY = 0, VOX_PRO_RMSNORM = 1, VOX_PRO_ATTN = 2 };
+enum { VOX_EPI_STORE = 0, VOX_EPI_SILU = 1, VOX_EPI_SILU_MUL = 2 };
+int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c);
+int vox_launch_rmsnorm(hipStream_t st, const void* x, const void* w, void* y, int rows, int H, float eps);
+
+struct HeadCall {
+    const void *q_src = nullptr, *k_src = nullptr, *v_src = nullptr;
+    long q_stride = 0, k_stride = 0, v_stride = 0;
+    void *q_out = nullptr, *k_out = nullptr, *kv = nullptr;
+    const void *qn = nullptr, *kn = nullptr;
+    const float* cs = nullptr;
+    const int *pos = nullptr, *page = nullptr, *slot = nullptr;
+    float eps = 1e-6f;
+    int N = 0, Hq = 0, Hkv = 0, D = 0, rot = 0, interleave = 0, page_size = 0, table_max_pos = 0;
+};
+int vox_launch_head_prepare(hipStream_t st, const HeadCall& c);
+
+struct AttnCall {
+    const void *q = nullptr, *kv = nullptr;
+    const int *q_req = nullptr, *q_kvlen = nullptr, *indptr = nullptr, *indices = nullptr;
+    float *part_o = nullptr, *part_ml = nullptr;
+    float scale = 1.0f;
+    int Nq = 0, Hq = 0, Hkv = 0, D = 0, page_size = 0, max_chunks = 0, max_kvlen = 0;
+};
+int vox_launch_attn_partial(hipStream_t st, const AttnCall& c);
+int vox_launch_attn_merge(hipStream_t st, const float* part_o, const float* part_ml, const int* kvlen, void* out,
+                          int Nq, int Hq, int D, int max_chunks);
+int vox_launch_gather(hipStream_t st, const void* table, const int* ids, int id_stride, int id_off, void* dst,
+                      long dst_stride, int B, int H, int vocab);
+int vox_launch_qwen3_mix(hipStream_t st, const void* text, const void* codec_table, const int* ids, int id_stride,
+                         const uint8_t* mask, const void* feat, void* y, int B, int H, int vocab);
+int vox_launch_kv_append(hipStream_t st, void* kv, const void* k, const void* v, const int* page, const int* slot,
+                         int N, int page_size, int Hkv, int D);
+
+// ---- sampler (sampler.hip) ------------------------------------------------------------------------
+struct SampleCall {
+    void* logits = nullptr;            // bf16 [B,V] (row stride V), modified in place by suppress/penalty
+    int B = 0, V = 0;
+    const int* suppress_ids = nullptr; // device
+    int n_suppress = 0;
+    const uint8_t* rep_cache = nullptr; // [B,W,C,V]
+    int W = 0, C = 0;
+    vox_sampling_config cfg{};
+    uint64_t seed = 0, offset = 0;
+    const uint64_t* offset_dev = nullptr;  // optional device counter added to offset
+    uint64_t offset_mul = 1;               // effective offset = offset + (*offset_dev) * offset_mul
+    int* out_ids = nullptr;            // out_ids[b*out_stride + out_col]
+    int out_stride = 1, out_col = 0;
+    // fused tail: embedding of the sampled id
+    const void* emb_table = nullptr;   // [emb_vocab, H] bf16
+    int emb_vocab = 0, H = 0;
+    void* emb_dst = nullptr;           // row b at emb_dst + b*emb_dst_stride (elements)
+    long emb_dst_stride = 0;
+    void* feat_acc = nullptr;          // [B,H] bf16: feat = bf16(feat + emb) (qwen3_tts.py:2002)
+    int feat_init = 0;                 // 1: feat = emb' where emb' = bf16(0 + emb)
+};
+int vox_launch_sample(hipStream_t st, const SampleCall& c);
+int vox_launch_suppress(hipStream_t st, void* logits, int B, int V, const int* ids, int n);
+int vox_launch_rep_penalty(hipStream_t st, void* logits, const uint8_t* cache, int B, int W, int C, int V, float p);
+int vox_launch_rep_update(hipStream_t st, uint8_t* cache, const int* ids, int B, int W, int C, int V, int window);

@@ -1,0 +1,245 @@
+"""Host side of the Qwen3-TTS frame engine (libvoxhip `vox_qwen3_*`).
+
+Mirrors what CudaGraphWorker does for the LM hot loop in the reference
+(/root/reference/vox_serve/worker/cuda_graph_worker.py:57-183 buffers, :353-486 decode graphs,
+:946-1160 run_lm_decode + run_lm_depth) with one difference in kind: a whole audio frame — talker
+step, codebook-0 sampling, 15 depth steps with their sampling and embedding feedback — is ONE hipGraph
+replay with no host synchronisation inside; the host only uploads the few plan() integers per frame.
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+@dataclass
+class StackCfg:
+    hidden: int
+    layers: int
+    heads: int
+    kv_heads: int
+    head_dim: int
+    ffn: int
+    eps: float = 1e-6
+    rope_theta: float = 1e6
+    rope_scale: float = 1.0
+    rope_dim: Optional[int] = None
+    rope_interleave: bool = False
+    rope_llama31: Optional[tuple] = None
+    qk_norm: bool = True
+    qkv_bias: bool = False
+
+
+@dataclass
+class Qwen3Cfg:
+    """Defaults = Qwen3-TTS-12Hz-1.7B (reference dataclass defaults, model/qwen3_tts.py:112-253)."""
+    talker: StackCfg = field(default_factory=lambda: StackCfg(2048, 28, 16, 8, 128, 6144))
+    depth: StackCfg = field(default_factory=lambda: StackCfg(1024, 5, 16, 8, 128, 3072))
+    vocab: int = 3072
+    text_vocab: int = 151936
+    text_hidden: int = 2048
+    depth_vocab: int = 2048
+    n_groups: int = 16
+    eos_id: int = 2150
+    tts_pad_id: int = 151671
+    max_pos: int = 4096
+
+
+def rope_table(max_pos, c: StackCfg, device):
+    rot = c.rope_dim or c.head_dim
+    host = np.empty((max_pos, rot // 2, 2), np.float32)
+    lo, hi, ctx = c.rope_llama31 if c.rope_llama31 else (1.0, 4.0, 8192)
+    N.check(N.lib().vox_rope_table_host(host.ctypes.data_as(ctypes.c_void_p), max_pos, rot, float(c.rope_theta),
+                                        float(c.rope_scale), 1 if c.rope_llama31 else 0, float(lo), float(hi), int(ctx)))
+    return torch.from_numpy(host).to(device)
+
+
+def _stack_config(c: StackCfg, page_size, max_rows, max_kvlen) -> N.StackConfig:
+    return N.StackConfig(c.hidden, c.layers, c.heads, c.kv_heads, c.head_dim, c.ffn, c.eps, int(c.qk_norm),
+                         int(c.qkv_bias), c.rope_dim or c.head_dim, int(c.rope_interleave), page_size, max_rows,
+                         max_kvlen)
+
+
+def pack_stack_weights(W: Dict[str, torch.Tensor], prefix: str, c: StackCfg, keep: list):
+    """Reference state_dict names -> per-layer pointer structs; q/k/v rows concatenated (layout only)."""
+    arr = (N.LayerWeights * c.layers)()
+    for i in range(c.layers):
+        p = f"{prefix}.layers.{i}."
+        wqkv = torch.cat([W[p + "self_attn.q_proj.weight"], W[p + "self_attn.k_proj.weight"],
+                          W[p + "self_attn.v_proj.weight"]], 0).contiguous()
+        bqkv = None
+        if c.qkv_bias:
+            bqkv = torch.cat([W[p + "self_attn.q_proj.bias"], W[p + "self_attn.k_proj.bias"],
+                              W[p + "self_attn.v_proj.bias"]], 0).contiguous()
+        ts = dict(wqkv=wqkv, bqkv=bqkv, wo=W[p + "self_attn.o_proj.weight"], wgate=W[p + "mlp.gate_proj.weight"],
+                  wup=W[p + "mlp.up_proj.weight"], wdown=W[p + "mlp.down_proj.weight"],
+                  ln1=W[p + "input_layernorm.weight"], ln2=W[p + "post_attention_layernorm.weight"],
+                  qnorm=W.get(p + "self_attn.q_norm.weight"), knorm=W.get(p + "self_attn.k_norm.weight"))
+        for k, t in ts.items():
+            if t is not None:
+                t = t.contiguous()
+                keep.append(t)
+                setattr(arr[i], k, t.data_ptr())
+    return arr
+
+
+class Qwen3Engine:
+    def __init__(self, cfg: Qwen3Cfg, weights: Dict[str, torch.Tensor], max_batch=8, page_size=128, max_pages=256,
+                 max_seq_len=2304, max_prefill_rows=1024, keep_depth_logits=False, device="cuda"):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.max_batch, self.page_size, self.max_pages, self.max_seq_len = max_batch, page_size, max_pages, max_seq_len
+        self.L = N.lib()
+        self.ctx = N.ctx()
+        dev = self.device
+        W = {k: (v if v.is_cuda else v.to(dev)) for k, v in weights.items()}
+        self._keep = []
+        t, d = cfg.talker, cfg.depth
+        G, G1, H = cfg.n_groups, cfg.n_groups + 1, t.hidden
+        self.max_rows = max(max_prefill_rows, max_batch)
+        self.t_rope = rope_table(cfg.max_pos, t, dev)
+        self.d_rope = rope_table(64, d, dev)
+        self.tl = pack_stack_weights(W, "talker.model", t, self._keep)
+        self.dl = pack_stack_weights(W, "talker.code_predictor.model", d, self._keep)
+        qc = N.Qwen3Config(_stack_config(t, page_size, self.max_rows, max_seq_len),
+                           _stack_config(d, G, 2 * max_batch, G), cfg.vocab, cfg.text_vocab, cfg.text_hidden,
+                           cfg.depth_vocab, G, cfg.eos_id, cfg.tts_pad_id, max_batch)
+        demb = [W[f"talker.code_predictor.model.codec_embedding.{j}.weight"].contiguous() for j in range(G - 1)]
+        self._demb_arr = (ctypes.c_void_p * (G - 1))(*[e.data_ptr() for e in demb])
+        lm_head = torch.stack([W[f"talker.code_predictor.lm_head.{j}.weight"] for j in range(G - 1)], 0).contiguous()
+
+        def P(name):
+            x = W[name].contiguous()
+            self._keep.append(x)
+            return x.data_ptr()
+        self._keep += demb + [lm_head]
+        qw = N.Qwen3Weights(
+            ctypes.cast(self.tl, ctypes.POINTER(N.LayerWeights)), ctypes.cast(self.dl, ctypes.POINTER(N.LayerWeights)),
+            P("talker.model.norm.weight"), P("talker.code_predictor.model.norm.weight"),
+            P("talker.model.codec_embedding.weight"), P("talker.model.text_embedding.weight"),
+            P("talker.text_projection.linear_fc1.weight"), P("talker.text_projection.linear_fc1.bias"),
+            P("talker.text_projection.linear_fc2.weight"), P("talker.text_projection.linear_fc2.bias"),
+            P("talker.codec_head.weight"), ctypes.cast(self._demb_arr, ctypes.POINTER(ctypes.c_void_p)),
+            lm_head.data_ptr(), P("talker.code_predictor.small_to_mtp_projection.weight"),
+            P("talker.code_predictor.small_to_mtp_projection.bias"), self.t_rope.data_ptr(), self.d_rope.data_ptr(),
+            cfg.max_pos, 64)
+        h = ctypes.c_void_p()
+        N.check(self.L.vox_qwen3_create(self.ctx, ctypes.byref(qc), ctypes.byref(qw), ctypes.byref(h)))
+        self.h = h
+
+        # graph-stable device buffers (cuda_graph_worker.py:383-390)
+        i32 = dict(dtype=torch.int32, device=dev)
+        R = self.max_rows
+        self.input_ids = torch.zeros(max_batch, G1, **i32)
+        self.input_masks = torch.ones(max_batch, dtype=torch.uint8, device=dev)
+        self.input_features = torch.zeros(max_batch, H, dtype=torch.bfloat16, device=dev)
+        # one int32 plan block, uploaded with a single async copy per frame:
+        # [pos R | kvlen R | page R | slot R | q_req R | last_rows B | indptr B+1 | indices max_pages]
+        self._plan_layout = {}
+        off = 0
+        for name, n in (("pos", R), ("kvlen", R), ("page", R), ("slot", R), ("q_req", R), ("last_rows", max_batch),
+                        ("indptr", max_batch + 1), ("indices", max_pages)):
+            self._plan_layout[name] = (off, n)
+            off += n
+        self.plan_dev = torch.zeros(off, **i32)
+        self.plan_host = torch.zeros(off, dtype=torch.int32).pin_memory()
+        self.kv = torch.zeros(t.layers, max_pages, 2, page_size, t.kv_heads, t.head_dim, dtype=torch.bfloat16, device=dev)
+        self.out_ids = torch.zeros(max_batch, G1, **i32)
+        self.out_logits = torch.zeros(max_batch, cfg.vocab, dtype=torch.bfloat16, device=dev)
+        self.out_hidden = torch.zeros(max_batch, H, dtype=torch.bfloat16, device=dev)
+        self.out_depth_logits = (torch.zeros(G - 1, max_batch, cfg.depth_vocab, dtype=torch.bfloat16, device=dev)
+                                 if keep_depth_logits else None)
+        self.next_features = torch.zeros(max_batch, H, dtype=torch.bfloat16, device=dev)
+        self.rng_offset = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.row_ids = torch.zeros(R, G1, **i32)
+        self.row_masks = torch.zeros(R, dtype=torch.uint8, device=dev)
+        self.row_feats = torch.zeros(R, H, dtype=torch.bfloat16, device=dev)
+        self._graphs = {}
+        self.keep_hidden = True
+
+    # ---- plan upload -------------------------------------------------------------------------------
+    def _pd(self, name):
+        off, n = self._plan_layout[name]
+        return self.plan_dev[off:off + n]
+
+    def _ph(self, name):
+        off, n = self._plan_layout[name]
+        return self.plan_host[off:off + n]
+
+    def upload_plan(self, **arrays):
+        """Host int lists/arrays -> the pinned block -> one async H2D copy (no synchronisation)."""
+        for name, a in arrays.items():
+            a = np.asarray(a, dtype=np.int32)
+            self._ph(name)[: len(a)] = torch.from_numpy(a)
+        self.plan_dev.copy_(self.plan_host, non_blocking=True)
+
+    def _io(self):
+        return N.Qwen3IO(self.input_ids.data_ptr(), self.input_masks.data_ptr(), self.input_features.data_ptr(),
+                         self._pd("pos").data_ptr(), self._pd("kvlen").data_ptr(), self._pd("page").data_ptr(),
+                         self._pd("slot").data_ptr(), self._pd("indptr").data_ptr(), self._pd("indices").data_ptr(),
+                         self.kv.data_ptr(), self.kv[0].numel(), self.out_ids.data_ptr(), self.out_logits.data_ptr(),
+                         self.out_hidden.data_ptr() if self.keep_hidden else None,
+                         self.out_depth_logits.data_ptr() if self.out_depth_logits is not None else None,
+                         self.next_features.data_ptr(), self.rng_offset.data_ptr())
+
+    @staticmethod
+    def sampling_cfg(greedy=True, top_k=0, top_p=1.0, min_p=0.0, temperature=1.0):
+        return N.SamplingCfg(int(greedy), int(top_k or 0), float(1.0 if top_p is None else top_p),
+                             float(min_p or 0.0), float(temperature), 1.0)
+
+    # ---- one frame ---------------------------------------------------------------------------------
+    def frame(self, batch, max_kvlen, sampling=None, seed=0, feedback=True, use_graph=True):
+        """Enqueue one frame on the current stream.  plan arrays / inputs must already be on the device."""
+        sampling = sampling or self.sampling_cfg()
+        bucket = max(256, 1 << (int(max_kvlen) - 1).bit_length())       # kv-length bucket bounds the attention grid
+        bucket = min(bucket, self.max_seq_len)
+        if max_kvlen > bucket:
+            raise N.VoxError(f"kv length {max_kvlen} exceeds max_seq_len {self.max_seq_len}")
+        if not use_graph:
+            io = self._io()
+            N.check(self.L.vox_qwen3_frame(self.h, N.stream(), ctypes.byref(io), batch, bucket, ctypes.byref(sampling),
+                                           seed, int(feedback)))
+            return
+        key = (batch, bucket, bytes(sampling), seed, bool(feedback), self.keep_hidden)
+        g = self._graphs.get(key)
+        if g is None:
+            io = self._io()
+            st = N.stream()
+            # warm-up outside capture (sets kernel attributes), on a scratch copy of the mutable state
+            saved = [x.clone() for x in (self.input_ids, self.input_masks, self.input_features, self.rng_offset)]
+            N.check(self.L.vox_qwen3_frame(self.h, st, ctypes.byref(io), batch, bucket, ctypes.byref(sampling), seed,
+                                           int(feedback)))
+            torch.cuda.current_stream().synchronize()
+            for dst, src in zip((self.input_ids, self.input_masks, self.input_features, self.rng_offset), saved):
+                dst.copy_(src)
+            torch.cuda.current_stream().synchronize()
+            N.check(self.L.vox_graph_begin(self.ctx, st))
+            try:
+                N.check(self.L.vox_qwen3_frame(self.h, st, ctypes.byref(io), batch, bucket, ctypes.byref(sampling),
+                                               seed, int(feedback)))
+            finally:
+                gh = ctypes.c_void_p()
+                N.check(self.L.vox_graph_end(self.ctx, st, ctypes.byref(gh)))
+            g = self._graphs[key] = gh
+        N.check(self.L.vox_graph_launch(g, N.stream()))
+
+    def prefill(self, n_rows, n_req, max_kvlen, sampling=None, seed=0, feedback=True):
+        """Ragged prefill of rows staged in row_ids/row_masks/row_feats + plan arrays (eager, not captured)."""
+        sampling = sampling or self.sampling_cfg()
+        io = self._io()
+        N.check(self.L.vox_qwen3_prefill(self.h, N.stream(), ctypes.byref(io), self.row_ids.data_ptr(),
+                                         self.row_masks.data_ptr(), self.row_feats.data_ptr(),
+                                         self._pd("q_req").data_ptr(), n_rows, self._pd("last_rows").data_ptr(), n_req,
+                                         min(max(32, max_kvlen), self.max_seq_len), ctypes.byref(sampling), seed,
+                                         int(feedback)))
+
+    def close(self):
+        for g in self._graphs.values():
+            self.L.vox_graph_destroy(g)
+        self._graphs.clear()
+        if self.h:
+            self.L.vox_qwen3_destroy(self.h)
+            self.h = None

@@ -1,0 +1,86 @@
+"""Drop-in for /root/reference/vox_serve/sampling.py: SamplingConfig + Sampler with the same dispatch
+order (sampling.py:85-118), repetition-penalty semantics (sampling.py:122-146) and cache update incl. the
+reference's cross-request leak (sampling.py:150-178).  Runs in libvoxhip's on-device
+sampler; stochastic modes draw from a seeded Philox4x32-10 stream (the reference's draw is
+flashinfer-internal and not reproducible; the support set / probabilities follow its contract).
+"""
+import itertools
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _native as N
+
+
+@dataclass
+class SamplingConfig:
+    top_p: Optional[float] = None
+    top_k: Optional[int] = None
+    min_p: Optional[float] = None
+    temperature: float = 1.0
+    max_tokens: Optional[int] = None
+    repetition_penalty: Optional[float] = None
+    repetition_window: Optional[int] = None  # -1 for global window
+    cfg_scale: Optional[float] = None
+    greedy: bool = False
+
+
+def native_config(config: SamplingConfig) -> N.SamplingCfg:
+    """SamplingConfig -> vox_sampling_config following Sampler.run_sampling's dispatch order."""
+    greedy = config.greedy or config.temperature == 0.0
+    top_k, top_p, min_p = 0, 1.0, 0.0
+    if not greedy:
+        if config.top_k is not None and config.top_p is not None:
+            top_k, top_p = config.top_k, config.top_p
+        elif config.top_k is not None:
+            top_k = config.top_k
+        elif config.top_p is not None:
+            top_p = config.top_p
+        elif config.min_p is not None:
+            min_p = config.min_p
+        else:
+            greedy = True
+    return N.SamplingCfg(int(greedy), int(top_k), float(top_p), float(min_p),
+                         float(config.temperature if not greedy else 1.0), 1.0)
+
+
+class Sampler:
+    seed = 0
+    _offset = itertools.count()
+
+    @classmethod
+    def manual_seed(cls, seed: int):
+        cls.seed, cls._offset = int(seed), itertools.count()
+
+    @classmethod
+    def run_sampling(cls, logits: torch.Tensor, config: SamplingConfig) -> torch.Tensor:
+        lg = logits.contiguous()
+        if lg.dtype != torch.bfloat16:
+            lg = lg.to(torch.bfloat16)
+        b, v = lg.shape
+        out = torch.empty(b, dtype=torch.int32, device=lg.device)
+        nc = native_config(config)
+        N.check(N.lib().vox_sample(N.ctx(), N.stream(), N.ptr(lg), b, v, nc, cls.seed, next(cls._offset), N.ptr(out)))
+        return out.long() if nc.greedy else out
+
+    @classmethod
+    def apply_repetition_penalty(cls, logits: torch.Tensor, repetition_cache: torch.Tensor, penalty: float):
+        b, c1, v = logits.shape
+        if c1 != 1:
+            raise NotImplementedError("multi-codebook logits: only the codebook-0 form used by the hot path is native")
+        out = logits.contiguous().clone()
+        cache = repetition_cache.contiguous().view(torch.uint8)
+        _, w, c, _ = cache.shape
+        N.check(N.lib().vox_rep_penalty(N.ctx(), N.stream(), N.ptr(out), N.ptr(cache), b, w, c, v, float(penalty)))
+        return out
+
+    @classmethod
+    def update_repetition_penalty_cache(cls, repetition_cache: torch.Tensor, output_ids: torch.Tensor, window_size: int):
+        if output_ids.shape[1] != 1:
+            raise NotImplementedError("only the codebook-0 form used by the hot path is native")
+        assert repetition_cache.is_contiguous()
+        b, w, c, v = repetition_cache.shape
+        ids = output_ids[:, 0].to(torch.int32).contiguous()
+        N.check(N.lib().vox_rep_update(N.ctx(), N.stream(), N.ptr(repetition_cache.view(torch.uint8)), N.ptr(ids), b, w,
+                                       c, v, int(window_size)))
