@@ -202,6 +202,7 @@ def sample(logits, top_k=0, top_p=1.0, min_p=0.0, temperature=1.0, seed=0, offse
 def gather(table, ids):
     table = u16(table)
     ids = i32(ids)
+    assert ids.min() >= 0 and ids.max() < table.shape[0], "gather: id out of range"
     y = np.empty((len(ids), table.shape[1]), np.uint16)
     lib().vr_gather(_p(table, c_u16p), _p(ids, c_i32p), _p(y, c_u16p), len(ids), table.shape[1])
     return y

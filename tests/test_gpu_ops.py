@@ -58,8 +58,8 @@ def test_linear_silu_mul_bit_exact(dev, B, N_, K):
     rng = np.random.default_rng(N_ + K + B)
     Wg, Wu, x = rnd(rng, N_, K, s=0.05), rnd(rng, N_, K, s=0.05), rnd(rng, B, K)
     h = torch.empty(B, N_, dtype=torch.bfloat16, device=dev)
-    N.check(N.lib().vox_linear_silu_mul(N.ctx(), N.stream(), N.ptr(T(Wg, dev)), N.ptr(T(Wu, dev)), N.ptr(T(x, dev)),
-                                        N.ptr(h), B, N_, K))
+    Wgt, Wut, xt = T(Wg, dev), T(Wu, dev), T(x, dev)        # keep alive: ptr() does not own the tensor
+    N.check(N.lib().vox_linear_silu_mul(N.ctx(), N.stream(), N.ptr(Wgt), N.ptr(Wut), N.ptr(xt), N.ptr(h), B, N_, K))
     assert np.array_equal(Bits(h), vr.linear_silu_mul(Wg, Wu, x))
 
 

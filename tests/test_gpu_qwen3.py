@@ -134,5 +134,5 @@ def test_tiny_b9_batch_tiles(dev):
 
 def test_full_size_qwen3_1p7b_one_frame(dev):
     """Qwen3-TTS-1.7B shapes (28+5 layers, random weights): 12-token prefill + 2 decode frames, greedy."""
-    cfg = QR.Qwen3Cfg(text_vocab=4096, max_pos=1024)        # text table shrunk (gathered, not streamed); rest full
+    cfg = QR.Qwen3Cfg(text_vocab=4096, tts_pad_id=4095, max_pos=1024)   # text table shrunk (gathered, not streamed)
     run_parity(dev, cfg, QR.random_weights(cfg, 0, 0.02), [12], 2, page=128, max_pages=8)

@@ -159,6 +159,22 @@ class Qwen3Engine:
         self.row_feats = torch.zeros(R, H, dtype=torch.bfloat16, device=dev)
         self._graphs = {}
         self.keep_hidden = True
+        # hipGraph capture needs a non-default stream; all engine work runs on this one, fenced against the
+        # caller's current stream on entry and exit.
+        self.stream = torch.cuda.Stream(device=dev)
+
+    class _OnStream:
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            self.eng.stream.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.eng.stream)
+            self.ctx.__enter__()
+
+        def __exit__(self, *exc):
+            self.ctx.__exit__(*exc)
+            torch.cuda.current_stream().wait_stream(self.eng.stream)
 
     # ---- plan upload -------------------------------------------------------------------------------
     def _pd(self, name):
@@ -171,10 +187,12 @@ class Qwen3Engine:
 
     def upload_plan(self, **arrays):
         """Host int lists/arrays -> the pinned block -> one async H2D copy (no synchronisation)."""
+        self.stream.synchronize()       # the previous frame may still read the pinned block's last upload
         for name, a in arrays.items():
             a = np.asarray(a, dtype=np.int32)
             self._ph(name)[: len(a)] = torch.from_numpy(a)
-        self.plan_dev.copy_(self.plan_host, non_blocking=True)
+        with self._OnStream(self):
+            self.plan_dev.copy_(self.plan_host, non_blocking=True)
 
     def _io(self):
         return N.Qwen3IO(self.input_ids.data_ptr(), self.input_masks.data_ptr(), self.input_features.data_ptr(),
@@ -198,6 +216,10 @@ class Qwen3Engine:
         bucket = min(bucket, self.max_seq_len)
         if max_kvlen > bucket:
             raise N.VoxError(f"kv length {max_kvlen} exceeds max_seq_len {self.max_seq_len}")
+        with self._OnStream(self):
+            self._frame_on_stream(batch, bucket, sampling, seed, feedback, use_graph)
+
+    def _frame_on_stream(self, batch, bucket, sampling, seed, feedback, use_graph):
         if not use_graph:
             io = self._io()
             N.check(self.L.vox_qwen3_frame(self.h, N.stream(), ctypes.byref(io), batch, bucket, ctypes.byref(sampling),
@@ -229,6 +251,10 @@ class Qwen3Engine:
     def prefill(self, n_rows, n_req, max_kvlen, sampling=None, seed=0, feedback=True):
         """Ragged prefill of rows staged in row_ids/row_masks/row_feats + plan arrays (eager, not captured)."""
         sampling = sampling or self.sampling_cfg()
+        with self._OnStream(self):
+            self._prefill_on_stream(n_rows, n_req, max_kvlen, sampling, seed, feedback)
+
+    def _prefill_on_stream(self, n_rows, n_req, max_kvlen, sampling, seed, feedback):
         io = self._io()
         N.check(self.L.vox_qwen3_prefill(self.h, N.stream(), ctypes.byref(io), self.row_ids.data_ptr(),
                                          self.row_masks.data_ptr(), self.row_feats.data_ptr(),
