@@ -1,0 +1,46 @@
+"""Quick LM-only frame timing (development aid; bench.py is the contract)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
+from vox_serve_amd.synth import synth_qwen3_weights
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+use_graph = (sys.argv[3] != "eager") if len(sys.argv) > 3 else True
+dev = torch.device("cuda")
+cfg = Qwen3Cfg()
+W = synth_qwen3_weights(cfg, dev, seed=0)
+eng = Qwen3Engine(cfg, W, max_batch=B, page_size=128, max_pages=max(64, 4 * B), max_seq_len=2304, max_prefill_rows=128)
+eng.keep_hidden = False
+n = 75
+ps = 128
+for b in range(B):
+    eng.kv[:, b * 3:(b + 1) * 3].normal_(0, 0.5)
+kvlen0 = 200
+sc = eng.sampling_cfg(greedy=True)
+eng.input_ids.zero_(); eng.input_ids[:, -1] = cfg.tts_pad_id
+def plan(kvlen):
+    pages = [[b * 3 + j for j in range((kvlen + ps - 1) // ps)] for b in range(B)]
+    indptr = np.cumsum([0] + [len(p) for p in pages]); indices = sum(pages, [])
+    eng.upload_plan(pos=[kvlen] * B, kvlen=[kvlen] * B, page=[p[-1] for p in pages], slot=[(kvlen - 1) % ps] * B,
+                    indptr=indptr, indices=indices)
+for w in range(5):
+    plan(kvlen0 + w); eng.frame(B, kvlen0 + w, sc, use_graph=use_graph)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+gpu_ms = 0.0
+for f in range(frames):
+    plan(kvlen0 + 5 + f)
+    with eng._OnStream(eng):
+        ev0.record()
+    eng.frame(B, kvlen0 + 5 + f, sc, use_graph=use_graph)
+    with eng._OnStream(eng):
+        ev1.record()
+    eng.stream.synchronize()
+    ids = eng.out_ids[:B].cpu()
+    gpu_ms += ev0.elapsed_time(ev1)
+t1 = time.perf_counter()
+print(f"B={B} graph={use_graph} wall {(t1-t0)/frames*1e3:.3f} ms/frame, gpu {gpu_ms/frames:.3f} ms/frame, "
+      f"samples/s {B*1920*frames/(t1-t0):.0f}; tokens {ids[0,:4].tolist()}")

@@ -199,12 +199,15 @@ struct vox_stack {
     const float* rope;
     int rope_max_pos;
     // workspace
-    void *qkv, *q, *h;
+    void *qkv, *q, *h, *attn_out;
     float* attn_ws;
     size_t attn_ws_floats;
 };
 
-static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t kv_stride, const vox_rows* r) {
+// decode_rows: every row is the newest token of a distinct request (its K/V are not read by any other row), so the
+// head norm / RoPE / KV append fuse into the attention kernel; otherwise (prefill) a separate pass appends first.
+static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t kv_stride, const vox_rows* r,
+                        bool decode_rows = false) {
     const vox_stack_config& c = s->cfg;
     const int n = r->n_rows;
     if (n <= 0) return VOX_OK;
@@ -232,17 +235,23 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         hc.cs = s->rope; hc.pos = r->pos; hc.page = r->page; hc.slot = r->slot; hc.eps = c.eps; hc.N = n;
         hc.Hq = c.heads; hc.Hkv = c.kv_heads; hc.D = c.head_dim; hc.rot = c.rope_dim; hc.interleave = c.rope_interleave;
         hc.page_size = c.page_size; hc.table_max_pos = s->rope_max_pos;
-        VOX_TRY(vox_launch_head_prepare(st, hc));
+        if (!decode_rows) VOX_TRY(vox_launch_head_prepare(st, hc));
         AttnCall ac;
+        if (decode_rows) {
+            ac.qkv = s->qkv; ac.qn = hc.qn; ac.kn = hc.kn; ac.cs = s->rope; ac.pos = r->pos; ac.page = r->page;
+            ac.slot = r->slot; ac.eps = c.eps; ac.rot = c.rope_dim; ac.interleave = c.rope_interleave;
+            ac.table_max_pos = s->rope_max_pos;
+        }
         ac.q = s->q; ac.kv = kvl; ac.q_req = r->q_req; ac.q_kvlen = r->q_kvlen; ac.indptr = r->kv_indptr;
         ac.indices = r->kv_indices; ac.part_o = part_o; ac.part_ml = part_ml; ac.scale = scale; ac.Nq = n;
         ac.Hq = c.heads; ac.Hkv = c.kv_heads; ac.D = c.head_dim; ac.page_size = c.page_size; ac.max_chunks = mc;
         ac.max_kvlen = r->max_kvlen;
+        ac.out = s->attn_out;
         VOX_TRY(vox_launch_attn_partial(st, ac));
-        LinearCall o;  // merge partials + o_proj + residual
-        o.W = w.wo; o.residual = x; o.y = x; o.part_o = part_o; o.part_ml = part_ml; o.kvlen = r->q_kvlen;
-        o.B = n; o.N = c.hidden; o.K = nq; o.Hq = c.heads; o.D = c.head_dim; o.max_chunks = mc;
-        o.pro = VOX_PRO_ATTN; o.epi = VOX_EPI_STORE;
+        if (mc > 1) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc));
+        LinearCall o;  // o_proj + residual
+        o.W = w.wo; o.x = s->attn_out; o.residual = x; o.y = x; o.B = n; o.N = c.hidden; o.K = nq;
+        o.pro = VOX_PRO_COPY; o.epi = VOX_EPI_STORE;
         VOX_TRY(vox_launch_linear(s->ctx, st, o));
         LinearCall g;  // post_attention_layernorm + gate/up + SiLU*up
         g.W = w.wgate; g.W2 = w.wup; g.x = x; g.norm_w = w.ln2; g.eps = c.eps; g.y = s->h;
@@ -274,7 +283,7 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
     const size_t R = cfg->max_rows;
     s->attn_ws_floats = (size_t)R * cfg->heads * n_chunks(cfg->max_kvlen) * (cfg->head_dim + 2);
     if (hipMalloc(&s->qkv, R * (nq + 2 * nkv) * 2) != hipSuccess || hipMalloc(&s->q, R * nq * 2) != hipSuccess ||
-        hipMalloc(&s->h, R * cfg->ffn * 2) != hipSuccess ||
+        hipMalloc(&s->h, R * cfg->ffn * 2) != hipSuccess || hipMalloc(&s->attn_out, R * nq * 2) != hipSuccess ||
         hipMalloc((void**)&s->attn_ws, s->attn_ws_floats * 4) != hipSuccess) {
         delete s;
         return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc failed");
@@ -284,7 +293,7 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
 }
 void vox_stack_destroy(vox_stack* s) {
     if (!s) return;
-    (void)hipFree(s->qkv); (void)hipFree(s->q); (void)hipFree(s->h); (void)hipFree(s->attn_ws);
+    (void)hipFree(s->qkv); (void)hipFree(s->q); (void)hipFree(s->h); (void)hipFree(s->attn_out); (void)hipFree(s->attn_ws);
     delete s;
 }
 
@@ -378,7 +387,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         r.kv_indices = m->iota;
         r.n_rows = rows;
         r.max_kvlen = i + 1;
-        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r));
+        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1));
         void* dl = io->out_depth_logits ? (void*)((bf16_t*)io->out_depth_logits + (size_t)(i - 1) * c.max_batch * c.depth_vocab)
                                         : m->dlogits;
         LinearCall h;  // depth final norm + lm_head[i-1]
@@ -517,7 +526,7 @@ int vox_qwen3_frame(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int B, i
     vox_rows r{};
     r.pos = io->pos; r.q_req = m->iota; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
     r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = B; r.max_kvlen = max_kvlen;
-    VOX_TRY(stack_layers(m->talker, st, m->x, io->kv, io->kv_layer_stride, &r));
+    VOX_TRY(stack_layers(m->talker, st, m->x, io->kv, io->kv_layer_stride, &r, true));
     VOX_TRY(qwen3_head(m, st, io, B, nullptr));
     return qwen3_tail(m, st, io, B, sc, seed, feedback);
 }

@@ -28,8 +28,18 @@ __device__ __forceinline__ const uint4* x_row_ptr(const LinArgs& a, int row) {
     return reinterpret_cast<const uint4*>(a.x + r * a.x_stride);
 }
 
+__device__ __forceinline__ uint4 norm_chunk(uint4 v, uint4 w, float rinv) {
+    uint4 o;
+    o.x = (u32)f2bf((bflo(v.x) * rinv) * bflo(w.x)) | ((u32)f2bf((bfhi(v.x) * rinv) * bfhi(w.x)) << 16);
+    o.y = (u32)f2bf((bflo(v.y) * rinv) * bflo(w.y)) | ((u32)f2bf((bfhi(v.y) * rinv) * bfhi(w.y)) << 16);
+    o.z = (u32)f2bf((bflo(v.z) * rinv) * bflo(w.z)) | ((u32)f2bf((bfhi(v.z) * rinv) * bfhi(w.z)) << 16);
+    o.w = (u32)f2bf((bflo(v.w) * rinv) * bflo(w.w)) | ((u32)f2bf((bfhi(v.w) * rinv) * bfhi(w.w)) << 16);
+    return o;
+}
+
+// skip_row0: row `wave` of tile 0 was already staged from registers by the caller (fast path)
 template <int PRO>
-__device__ __forceinline__ void stage_x(const LinArgs& a, uint4* xs, int b0, int bt) {
+__device__ __forceinline__ void stage_x(const LinArgs& a, uint4* xs, int b0, int bt, int bt_cap, bool skip_row0 = false) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nch = a.K >> 3;
     if (PRO == PRO_COPY) {
@@ -39,41 +49,71 @@ __device__ __forceinline__ void stage_x(const LinArgs& a, uint4* xs, int b0, int
         }
     } else if (PRO == PRO_RMSNORM) {
         const uint4* nw = reinterpret_cast<const uint4*>(a.nw);
-        for (int b = wave; b < bt; b += 4) {
+        for (int b = wave + (skip_row0 ? 4 : 0); b < bt; b += 4) {
             const uint4* xr = x_row_ptr(a, b0 + b);
             float s = 0.0f;
             for (int c = lane; c < nch; c += 64) s = sq8(xr[c], s);
             s = butterfly<64>(s);
             const float rinv = 1.0f / sqrtf(s / (float)a.K + a.eps);
             for (int c = lane; c < nch; c += 64) {
-                uint4 v = xr[c], w = nw[c], o;
-                o.x = (u32)f2bf((bflo(v.x) * rinv) * bflo(w.x)) | ((u32)f2bf((bfhi(v.x) * rinv) * bfhi(w.x)) << 16);
-                o.y = (u32)f2bf((bflo(v.y) * rinv) * bflo(w.y)) | ((u32)f2bf((bfhi(v.y) * rinv) * bfhi(w.y)) << 16);
-                o.z = (u32)f2bf((bflo(v.z) * rinv) * bflo(w.z)) | ((u32)f2bf((bfhi(v.z) * rinv) * bfhi(w.z)) << 16);
-                o.w = (u32)f2bf((bflo(v.w) * rinv) * bflo(w.w)) | ((u32)f2bf((bfhi(v.w) * rinv) * bfhi(w.w)) << 16);
+                const uint4 o = norm_chunk(xr[c], nw[c], rinv);
                 xs[b * nch + c] = o;
                 if (a.x_out && blockIdx.x == 0)
                     reinterpret_cast<uint4*>(a.x_out + (size_t)(b0 + b) * a.x_out_stride)[c] = o;
             }
         }
     } else {  // PRO_ATTN: merge the attention partials of row b into x[b, h*D+d]
+        // phase 1: one thread per (row, head): global max, per-chunk weights exp2((m_c-M)*log2e) and the
+        // sequentially accumulated denominator -> LDS;  phase 2: one thread per element, coalesced over d.
         bf16_t* xb = reinterpret_cast<bf16_t*>(xs);
-        const int HD = a.Hq * a.D;
+        float* wts = reinterpret_cast<float*>(xs + (size_t)bt_cap * nch);   // [bt][Hq][max_chunks+1]
+        const int HD = a.Hq * a.D, ws = a.max_chunks + 1;
+        for (int p = tid; p < bt * a.Hq; p += 256) {
+            const int b = p / a.Hq, h = p % a.Hq;
+            const int row = b0 + b;
+            const int nc = (a.kvlen[row] + VOX_TC - 1) / VOX_TC;
+            const float2* ml = reinterpret_cast<const float2*>(a.part_ml + ((size_t)row * a.Hq + h) * a.max_chunks * 2);
+            float M = -INFINITY;
+            for (int c0 = 0; c0 < nc; c0 += 8) {         // 8 independent loads in flight
+                float2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (c0 + j < nc) ? ml[c0 + j] : make_float2(-INFINITY, 0.0f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) M = fmaxf(M, v[j].x);
+            }
+            float L = 0.0f;
+            for (int c0 = 0; c0 < nc; c0 += 8) {
+                float2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (c0 + j < nc) ? ml[c0 + j] : make_float2(-INFINITY, 0.0f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (c0 + j < nc) {
+                        const float w = exp2_c((v[j].x - M) * VOX_LOG2E);
+                        L = __fmaf_rn(v[j].y, w, L);
+                        wts[(size_t)p * ws + c0 + j] = w;
+                    }
+                }
+            }
+            wts[(size_t)p * ws + a.max_chunks] = L;
+        }
+        __syncthreads();
         for (int e = tid; e < bt * HD; e += 256) {
             const int b = e / HD, h = (e % HD) / a.D, d = e % a.D;
             const int row = b0 + b;
             const int nc = (a.kvlen[row] + VOX_TC - 1) / VOX_TC;
-            const float* ml = a.part_ml + ((size_t)row * a.Hq + h) * a.max_chunks * 2;
             const float* po = a.part_o + ((size_t)row * a.Hq + h) * a.max_chunks * a.D + d;
-            float M = -INFINITY;
-            for (int c = 0; c < nc; ++c) M = fmaxf(M, ml[2 * c]);
-            float L = 0.0f, O = 0.0f;
-            for (int c = 0; c < nc; ++c) {
-                const float w = exp2_c((ml[2 * c] - M) * VOX_LOG2E);
-                L = __fmaf_rn(ml[2 * c + 1], w, L);
-                O = __fmaf_rn(po[(size_t)c * a.D], w, O);
+            const float* w = wts + (size_t)(b * a.Hq + h) * ws;
+            float O = 0.0f;
+            for (int c0 = 0; c0 < nc; c0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (c0 + j < nc) ? po[(size_t)(c0 + j) * a.D] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j < nc) O = __fmaf_rn(v[j], w[c0 + j], O);
             }
-            xb[e] = f2bf(O / L);
+            xb[e] = f2bf(O / w[a.max_chunks]);
         }
     }
 }
@@ -97,10 +137,53 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
         wrow[r] = reinterpret_cast<const uint4*>(base + (size_t)n * a.K);
     }
 
+    // The first group of weight chunks is requested BEFORE the activation prologue: weights do not depend on
+    // x, so their HBM latency overlaps the norm / merge work and the barrier.
+    // RMSNorm prologue fast path: the activation row this wave normalises (row `wave` of tile 0) is requested
+    // first, so it is not queued behind the weight stream (vmcnt retires in order).
+    constexpr int XC = 4;
+    const bool xfast = (PRO == PRO_RMSNORM) && nch <= 64 * XC && wave < a.B;
+    uint4 xr0[XC], nw0[XC];
+    if (xfast) {
+        const uint4* xr = x_row_ptr(a, wave);
+        const uint4* nwp = reinterpret_cast<const uint4*>(a.nw);
+#pragma unroll
+        for (int j = 0; j < XC; ++j) {
+            xr0[j] = make_uint4(0, 0, 0, 0);
+            nw0[j] = xr0[j];
+            if (lane + 64 * j < nch) {
+                xr0[j] = xr[lane + 64 * j];
+                nw0[j] = nwp[lane + 64 * j];
+            }
+        }
+    }
+    uint4 w[U][R];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (lane + 64 * u < nch) w[u][r] = ldg_nt(wrow[r] + lane + 64 * u);
+    if (xfast) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < XC; ++j) s = sq8(xr0[j], s);   // absent chunks are zero: same sum as the guarded loop
+        s = butterfly<64>(s);
+        const float rinv = 1.0f / sqrtf(s / (float)a.K + a.eps);
+#pragma unroll
+        for (int j = 0; j < XC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
+                const uint4 o = norm_chunk(xr0[j], nw0[j], rinv);
+                xs[wave * nch + c] = o;
+                if (a.x_out && blockIdx.x == 0) reinterpret_cast<uint4*>(a.x_out + (size_t)wave * a.x_out_stride)[c] = o;
+            }
+        }
+    }
+
     for (int b0 = 0; b0 < a.B; b0 += BT) {
         const int bt = (a.B - b0) < BT ? (a.B - b0) : BT;
         if (b0 > 0) __syncthreads();
-        stage_x<PRO>(a, xs, b0, bt);
+        stage_x<PRO>(a, xs, b0, bt, BT, (PRO == PRO_RMSNORM) && b0 == 0 && nch <= 64 * XC);
         __syncthreads();
 
         float acc[R][BT];
@@ -110,12 +193,13 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
             for (int b = 0; b < BT; ++b) acc[r][b] = 0.0f;
 
         for (int c = lane; c < nch; c += 64 * U) {
-            uint4 w[U][R];
+            if (c != lane || b0 > 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+                for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (c + 64 * u < nch) w[u][r] = ldg_nt(wrow[r] + c + 64 * u);
+                    for (int r = 0; r < R; ++r)
+                        if (c + 64 * u < nch) w[u][r] = ldg_nt(wrow[r] + c + 64 * u);
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (c + 64 * u < nch) {
@@ -162,7 +246,7 @@ template <int BT, int R, int PRO, int EPI>
 static int launch_linear_t(hipStream_t st, const LinArgs& a) {
     constexpr int OUT = (EPI == EPI_SILU_MUL) ? R / 2 : R;
     const int grid = (a.N + 4 * OUT - 1) / (4 * OUT);
-    const size_t smem = (size_t)BT * a.K * 2;
+    const size_t smem = (size_t)BT * a.K * 2 + (PRO == PRO_ATTN ? (size_t)BT * a.Hq * (a.max_chunks + 1) * 4 : 0);
     auto kern = k_linear<BT, R, PRO, EPI>;
     if (smem > 64 * 1024) {
         static bool done = false;  // per instantiation
@@ -184,9 +268,10 @@ static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
     // rows per wave: keep >= ~1 block per CU; fewer rows/wave when N is small
     constexpr bool SM = (EPI == EPI_SILU_MUL);
     const int outs = a.N;
-    int r;  // outputs per wave
-    if (bt >= 4) r = (outs / 8 >= n_cu) ? 2 : 1;
-    else r = (outs / 16 >= n_cu) ? 4 : (outs / 8 >= n_cu) ? 2 : 1;
+    int r;  // outputs per wave: keep >= 2 blocks per CU in flight where N allows (latency hiding)
+    (void)n_cu;
+    if (SM) r = 1;                                   // one gate row + one up row per wave
+    else r = (bt <= 2 && outs >= 8192) ? 2 : 1;
     if ((size_t)bt * a.K * 2 > 160 * 1024) return vox_fail(VOX_ERR_INVALID, "linear: K too large for LDS staging");
 #define VOX_LIN(BT_, R_)                                                             \
     if (bt == BT_ && r == R_) return launch_linear_t<BT_, (SM ? 2 * R_ : R_), PRO, EPI>(st, a);
@@ -346,9 +431,60 @@ struct AttnArgs {
     float *part_o, *part_ml;
     float scale;
     int Hq, Hkv, page_size, max_chunks;
+    // fused decode mode: q/k/v of each row's own (newest) token come straight from the projection output;
+    // per-head norm + RoPE happen here and the block owning the last chunk appends K/V to the cache.
+    const bf16_t* qkv;      // [N, (Hq+2Hkv)*D]
+    bf16_t* kv_w;           // writable alias of kv
+    const bf16_t *qn, *kn;
+    const float* cs;
+    const int *pos, *page, *slot;
+    float eps;
+    int rot, interleave, table_max_pos;
+    bf16_t* out;   // single-chunk launches write the final bf16 output here (merge of one chunk == o/l)
 };
 
+// norm (optional) + rope of one head held as one 16-byte chunk per lane (lanes < LPT); result as bf16 bits in
+// `out` (LDS, D elements).  sh: LDS scratch of D floats.  All 64 lanes of the wave must call this.
 template <int D>
+__device__ __forceinline__ void prep_head(const bf16_t* src, const bf16_t* nw, float eps, const float* cs_row,
+                                          int rot, int interleave, float* sh, bf16_t* out, int lane) {
+    constexpr int LPT = D / 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (lane < LPT) v = reinterpret_cast<const uint4*>(src)[lane];
+    float e[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+    if (nw) {
+        float s = sq8(v, 0.0f);
+        s = butterfly<64>(s);
+        const float rinv = 1.0f / sqrtf(s / (float)D + eps);
+        if (lane < LPT) {
+            const uint4 g = reinterpret_cast<const uint4*>(nw)[lane];
+            const float gw[8] = {bflo(g.x), bfhi(g.x), bflo(g.y), bfhi(g.y), bflo(g.z), bfhi(g.z), bflo(g.w), bfhi(g.w)};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = bfround((e[i] * rinv) * gw[i]);
+        }
+    }
+    if (lane < LPT) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sh[lane * 8 + i] = e[i];
+            out[lane * 8 + i] = f2bf(e[i]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (cs_row) {
+        const int half = rot >> 1;
+        for (int i = lane; i < half; i += 64) {
+            const int ia = interleave ? 2 * i : i, ib = interleave ? 2 * i + 1 : i + half;
+            const float x = sh[ia], y = sh[ib], c = cs_row[2 * i], sn = cs_row[2 * i + 1];
+            const float xc = x * c, yc = y * c;
+            out[ia] = f2bf(__fmaf_rn(-y, sn, xc));
+            out[ib] = f2bf(__fmaf_rn(x, sn, yc));
+        }
+    }
+}
+
+template <int D, bool FUSED>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
     constexpr int LPT = D / 8;        // lanes per token
     constexpr int TPW = 64 / LPT;     // tokens per wave pass
@@ -358,6 +494,8 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 Qs[GMAX * LPT];
     __shared__ float S[GMAX][VOX_TC];
     __shared__ float Ms[GMAX];
+    __shared__ float Sh[FUSED ? 4 * D : 1];
+    __shared__ __attribute__((aligned(16))) bf16_t Knew[FUSED ? D : 8];
 
     const int c = blockIdx.x, hk = blockIdx.y, row = blockIdx.z;
     const int L = a.q_kvlen[row];
@@ -368,11 +506,12 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int* pages = a.indices + a.indptr[a.q_req[row]];
     const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
+    const bool own_last = FUSED && (t0 + nt == L);   // this chunk holds the row's newest token (index L-1)
 
     for (int i = tid; i < VOX_TC * LPT; i += 256) {
         const int t = i / LPT, j = i % LPT;
         uint4 kx = make_uint4(0, 0, 0, 0), vx = kx;
-        if (t < nt) {
+        if (t < nt && !(own_last && t == nt - 1)) {
             const int tok = t0 + t;
             const bf16_t* base = a.kv + (size_t)pages[tok / a.page_size] * ps +
                                  ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
@@ -382,11 +521,44 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
         Ks[i] = kx;
         Vs[i] = vx;
     }
-    for (int i = tid; i < G * LPT; i += 256) {
-        const int g = i / LPT, j = i % LPT;
-        Qs[i] = reinterpret_cast<const uint4*>(a.q + ((size_t)row * a.Hq + hk * G + g) * D)[j];
+    if (!FUSED) {
+        for (int i = tid; i < G * LPT; i += 256) {
+            const int g = i / LPT, j = i % LPT;
+            Qs[i] = reinterpret_cast<const uint4*>(a.q + ((size_t)row * a.Hq + hk * G + g) * D)[j];
+        }
+    } else {
+        const int nqkv = (a.Hq + 2 * a.Hkv) * D;
+        const bf16_t* raw = a.qkv + (size_t)row * nqkv;
+        int p = a.pos[row];
+        p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
+        const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
+        // heads 0..G-1: q heads of this kv head; head G: the new k (only where needed)
+        const int nh = G + (own_last ? 1 : 0);
+        for (int h = wave; h < nh; h += 4) {
+            const bool isk = h == G;
+            const bf16_t* src = isk ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * G + h) * D;
+            bf16_t* dst = isk ? Knew : reinterpret_cast<bf16_t*>(Qs) + (size_t)h * D;
+            prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, Sh + wave * D, dst, lane);
+        }
     }
     __syncthreads();
+    if (own_last) {
+        // place the new token into the tile and append it to the paged cache (page < 0: graph padding row)
+        const bf16_t* vraw = a.qkv + (size_t)row * (a.Hq + 2 * a.Hkv) * D + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D;
+        const int pg = a.page[row];
+        if (tid < LPT) {
+            const uint4 kx = reinterpret_cast<const uint4*>(Knew)[tid];
+            const uint4 vx = reinterpret_cast<const uint4*>(vraw)[tid];
+            Ks[(nt - 1) * LPT + tid] = kx;
+            Vs[(nt - 1) * LPT + tid] = vx;
+            if (pg >= 0) {
+                bf16_t* base = a.kv_w + (size_t)pg * ps + ((size_t)a.slot[row] * a.Hkv + hk) * D;
+                reinterpret_cast<uint4*>(base)[tid] = kx;
+                reinterpret_cast<uint4*>(base + (size_t)a.page_size * a.Hkv * D)[tid] = vx;
+            }
+        }
+        __syncthreads();
+    }
 
     // scores: LPT lanes per token, butterfly over LPT lanes
     for (int tb = wave * TPW; tb < VOX_TC; tb += 4 * TPW) {
@@ -422,6 +594,10 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
             o = __fmaf_rn(p, bf2f(Vb[t * D + d]), o);
         }
         const size_t hi = (size_t)row * a.Hq + hk * G + g;
+        if (a.out) {   // one chunk: w = exp2(0) = 1, O = fma(o,1,0) = o, L = l
+            a.out[hi * D + d] = f2bf(o / l);
+            continue;
+        }
         a.part_o[(hi * a.max_chunks + c) * D + d] = o;
         if (d == 0) {
             a.part_ml[(hi * a.max_chunks + c) * 2 + 0] = Ms[g];
@@ -437,15 +613,25 @@ int vox_launch_attn_partial(hipStream_t st, const AttnCall& c) {
     a.q = (const bf16_t*)c.q; a.kv = (const bf16_t*)c.kv; a.q_req = c.q_req; a.q_kvlen = c.q_kvlen;
     a.indptr = c.indptr; a.indices = c.indices; a.part_o = c.part_o; a.part_ml = c.part_ml; a.scale = c.scale;
     a.Hq = c.Hq; a.Hkv = c.Hkv; a.page_size = c.page_size; a.max_chunks = c.max_chunks;
+    a.qkv = (const bf16_t*)c.qkv; a.kv_w = (bf16_t*)const_cast<void*>(c.kv); a.qn = (const bf16_t*)c.qn;
+    a.kn = (const bf16_t*)c.kn; a.cs = c.cs; a.pos = c.pos; a.page = c.page; a.slot = c.slot; a.eps = c.eps;
+    a.rot = c.rot; a.interleave = c.interleave; a.table_max_pos = c.table_max_pos;
+    a.out = nullptr;
     int nchunk = (c.max_kvlen + VOX_TC - 1) / VOX_TC;
     if (nchunk < 1) nchunk = 1;
     if (nchunk > c.max_chunks) return vox_fail(VOX_ERR_INVALID, "attention: max_kvlen exceeds workspace");
+    if (nchunk == 1) a.out = (bf16_t*)c.out;
     dim3 grid(nchunk, c.Hkv, c.Nq);
-    if (c.D == 128) hipLaunchKernelGGL(k_attn_partial<128>, grid, dim3(256), 0, st, a);
-    else if (c.D == 64) hipLaunchKernelGGL(k_attn_partial<64>, grid, dim3(256), 0, st, a);
-    else if (c.D == 16) hipLaunchKernelGGL(k_attn_partial<16>, grid, dim3(256), 0, st, a);
-    else return vox_fail(VOX_ERR_INVALID, "attention: head_dim must be 16, 64 or 128");
-    return VOX_OK;
+    const bool fused = c.qkv != nullptr;
+#define VOX_ATT(D_)                                                                           \
+    if (c.D == D_) {                                                                          \
+        if (fused) hipLaunchKernelGGL((k_attn_partial<D_, true>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((k_attn_partial<D_, false>), grid, dim3(256), 0, st, a);      \
+        return VOX_OK;                                                                        \
+    }
+    VOX_ATT(128) VOX_ATT(64) VOX_ATT(16)
+#undef VOX_ATT
+    return vox_fail(VOX_ERR_INVALID, "attention: head_dim must be 16, 64 or 128");
 }
 
 // merge partials -> bf16 out [Nq,Hq,D] (standalone op path; the engine merges inside the o_proj prologue)

@@ -68,6 +68,13 @@ struct AttnCall {
     float *part_o = nullptr, *part_ml = nullptr;
     float scale = 1.0f;
     int Nq = 0, Hq = 0, Hkv = 0, D = 0, page_size = 0, max_chunks = 0, max_kvlen = 0;
+    // fused decode mode (qkv != NULL): per-head norm + RoPE + KV append of each row's own token inside the kernel
+    const void *qkv = nullptr, *qn = nullptr, *kn = nullptr;
+    const float* cs = nullptr;
+    const int *pos = nullptr, *page = nullptr, *slot = nullptr;
+    float eps = 1e-6f;
+    int rot = 0, interleave = 0, table_max_pos = 0;
+    void* out = nullptr;   // bf16 [Nq,Hq,D]: written directly when the launch covers a single chunk
 };
 int vox_launch_attn_partial(hipStream_t st, const AttnCall& c);
 int vox_launch_attn_merge(hipStream_t st, const float* part_o, const float* part_ml, const int* kvlen, void* out,

@@ -1,0 +1,48 @@
+"""Synthetic (random-init) weights of the named architectures, generated on the device.  There is no network
+for checkpoints on the bench box: SURVEY §8d recipe — N(0, 0.02^2) bf16, norm weights 1, seed 0."""
+import torch
+
+
+def synth_qwen3_weights(cfg, device, seed=0, std=0.02):
+    g = torch.Generator(device=device).manual_seed(seed)
+
+    def w(*shape):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(torch.bfloat16)
+
+    def ones(n):
+        return torch.ones(n, device=device, dtype=torch.bfloat16)
+
+    W = {}
+
+    def stack(prefix, c):
+        for i in range(c.layers):
+            p = f"{prefix}.layers.{i}."
+            W[p + "self_attn.q_proj.weight"] = w(c.heads * c.head_dim, c.hidden)
+            W[p + "self_attn.k_proj.weight"] = w(c.kv_heads * c.head_dim, c.hidden)
+            W[p + "self_attn.v_proj.weight"] = w(c.kv_heads * c.head_dim, c.hidden)
+            W[p + "self_attn.o_proj.weight"] = w(c.hidden, c.heads * c.head_dim)
+            W[p + "self_attn.q_norm.weight"] = ones(c.head_dim)
+            W[p + "self_attn.k_norm.weight"] = ones(c.head_dim)
+            W[p + "mlp.gate_proj.weight"] = w(c.ffn, c.hidden)
+            W[p + "mlp.up_proj.weight"] = w(c.ffn, c.hidden)
+            W[p + "mlp.down_proj.weight"] = w(c.hidden, c.ffn)
+            W[p + "input_layernorm.weight"] = ones(c.hidden)
+            W[p + "post_attention_layernorm.weight"] = ones(c.hidden)
+        W[prefix + ".norm.weight"] = ones(c.hidden)
+
+    H = cfg.talker.hidden
+    stack("talker.model", cfg.talker)
+    W["talker.model.codec_embedding.weight"] = w(cfg.vocab, H)
+    W["talker.model.text_embedding.weight"] = w(cfg.text_vocab, cfg.text_hidden)
+    W["talker.text_projection.linear_fc1.weight"] = w(cfg.text_hidden, cfg.text_hidden)
+    W["talker.text_projection.linear_fc1.bias"] = w(cfg.text_hidden)
+    W["talker.text_projection.linear_fc2.weight"] = w(H, cfg.text_hidden)
+    W["talker.text_projection.linear_fc2.bias"] = w(H)
+    W["talker.codec_head.weight"] = w(cfg.vocab, H)
+    stack("talker.code_predictor.model", cfg.depth)
+    for j in range(cfg.n_groups - 1):
+        W[f"talker.code_predictor.model.codec_embedding.{j}.weight"] = w(cfg.depth_vocab, H)
+        W[f"talker.code_predictor.lm_head.{j}.weight"] = w(cfg.depth_vocab, cfg.depth.hidden)
+    W["talker.code_predictor.small_to_mtp_projection.weight"] = w(cfg.depth.hidden, H)
+    W["talker.code_predictor.small_to_mtp_projection.bias"] = w(cfg.depth.hidden)
+    return W
