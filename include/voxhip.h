@@ -197,6 +197,56 @@ int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const 
                       const int32_t* last_rows, int n_req, int max_kvlen, const vox_sampling_config* sampling,
                       uint64_t seed, int feedback);
 
+/* ---- Qwen3-TTS 12 Hz codec decoder (token -> waveform), streaming ------------------------------------
+ * replaces Qwen3TTSTokenizerV2Decoder.forward_chunk (tokenizer/qwen3_codec.py:1541-1666), the DecoderCache
+ * plumbing (tokenizer/base.py:7-173) and CudaGraphWorker.run_detokenize's cache cat / copy-in / copy-out
+ * (worker/cuda_graph_worker.py:1217-1241) with in-place per-slot state.                                */
+typedef struct vox_codec vox_codec;
+
+typedef struct { /* one conv / transposed conv / linear as an implicit GEMM; w: bf16 [n_taps][n][cin] */
+    const void* w;
+    const float* bias;     /* [bias_mod] or NULL */
+    int32_t n_taps, n, cin, bias_mod;
+} vox_conv_w;
+typedef struct { const float *alpha, *inv_beta; } vox_snake_w; /* exp(alpha), 1/(exp(beta)+1e-9) */
+typedef struct {
+    const float *ln1, *scale1, *ln2, *scale2;
+    vox_conv_w qkv, o, gate_up, down;
+} vox_codec_layer_w;
+typedef struct {
+    vox_conv_w tconv, pw1, pw2;
+    const float *dw_w, *dw_b, *ln_w, *ln_b, *gamma;
+} vox_codec_up_w;
+typedef struct { vox_snake_w act1, act2; vox_conv_w conv1, conv2; } vox_codec_res_w;
+typedef struct { vox_snake_w snake0; vox_conv_w tconv; vox_codec_res_w res[3]; } vox_codec_block_w;
+typedef struct {
+    const float* emb;      /* [num_quantizers][codebook_size][vq_dim] = embedding_sum / clamp(cluster_usage) */
+    vox_conv_w rvq_first_out, rvq_rest_out, pre_conv, in_proj, out_proj, dec0;
+    vox_codec_layer_w layers[16];
+    const float* final_norm;
+    const float* inv_freq; /* [head_dim/2] */
+    vox_codec_up_w up[2];
+    vox_codec_block_w blocks[4];
+    vox_snake_w final_snake;
+    const float* final_w;  /* [C][7] */
+    float final_b;
+} vox_codec_weights;
+typedef struct {
+    int32_t codebook_size, codebook_dim, vq_dim, latent_dim, decoder_dim, hidden, intermediate, head_dim, num_heads,
+        num_layers, num_quantizers, window, rates[4], n_blocks, n_upsample;
+    float rms_eps, rope_theta;
+} vox_codec_config;
+
+int vox_codec_create(vox_ctx* ctx, const vox_codec_config* cfg, const vox_codec_weights* w, int max_batch, int max_slots,
+                     int frames_per_chunk, vox_codec** out);
+void vox_codec_destroy(vox_codec* m);
+int64_t vox_codec_state_bytes(vox_codec* m); /* streaming state per slot */
+/* a new request takes over `slot`: zero its state (audio_decoder_initial_cache, model/qwen3_tts.py:1243-1260) */
+int vox_codec_reset_slot(vox_codec* m, void* stream, int slot);
+/* codes int32 [n, T, code_stride] (first num_quantizers columns), slots int32 [n], out fp32 [n, T*hop] */
+int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int code_stride, const int32_t* slots, int n,
+                           int T, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -257,7 +257,52 @@ def g3_qwen3_lm(ns):
     print("g3 ok; frame tokens", out["f2_tokens"][:, :6])
 
 
-ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm}
+def _ref_codec(ns, cfg, W, dtype):
+    qc = ns.qwen3_codec
+    rc = qc.Qwen3TTSTokenizerV2DecoderConfig(
+        latent_dim=cfg.latent_dim, codebook_dim=cfg.codebook_dim, codebook_size=cfg.codebook_size,
+        decoder_dim=cfg.decoder_dim, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+        head_dim=cfg.head_dim, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_heads,
+        num_hidden_layers=cfg.num_layers, num_quantizers=cfg.num_quantizers, rms_norm_eps=cfg.rms_eps,
+        rope_theta=int(cfg.rope_theta), sliding_window=cfg.sliding_window, upsample_rates=list(cfg.upsample_rates),
+        upsampling_ratios=list(cfg.upsampling_ratios))
+    m = qc.Qwen3TTSTokenizerV2Decoder(rc)
+    sd = m.state_dict()
+    from oracle import qwen3_codec_ref as CR
+    shapes = CR.param_shapes(cfg)
+    assert set(shapes) == set(sd), (set(shapes) ^ set(sd))
+    for k, v in sd.items():
+        assert tuple(v.shape) == shapes[k], (k, v.shape, shapes[k])
+    m.load_state_dict({k: v.clone() for k, v in W.items()})
+    return m.to(dtype).eval()
+
+
+def g4_qwen3_codec(ns):
+    """Qwen3 12 Hz codec decoder, streaming forward_chunk (qwen3_codec.py:1541-1666): the reference module
+    itself, seeded synthetic weights (oracle.qwen3_codec_ref.random_codec_weights), fp32 and bf16."""
+    from oracle import qwen3_codec_ref as CR
+    out = {}
+    for tag, cfg, B, nfr, chunks in (("tiny", CR.tiny_codec_cfg(), 2, 12, (4, 3)), ("full", CR.CodecCfg(), 2, 30, (10,))):
+        W = CR.random_codec_weights(cfg, seed=0)
+        g = torch.Generator().manual_seed(5)
+        codes = torch.randint(0, cfg.codebook_size, (B, cfg.num_quantizers, nfr), generator=g)
+        out[f"{tag}_codes"] = codes.numpy().astype(np.int32)
+        for dt_name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            m = _ref_codec(ns, cfg, W, dt)
+            for ch in chunks:
+                cache = m.init_cache(B, torch.device("cpu"), dt, ch)
+                wavs = []
+                for t0 in range(0, nfr, ch):
+                    wav, cache = m.forward_chunk(codes[:, :, t0:t0 + ch], cache)
+                    wavs.append(wav.float().clone())
+                wav = torch.cat(wavs, -1)
+                out[f"{tag}_{dt_name}_c{ch}"] = wav.numpy().astype(np.float32 if tag == "tiny" else np.float16)
+                print(tag, dt_name, ch, tuple(wav.shape), "rms", float(wav.pow(2).mean().sqrt()), "max", float(wav.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "g4_qwen3_codec.npz"), **out)
+    print("g4 ok")
+
+
+ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec}
 
 if __name__ == "__main__":
     ns = H.boot()

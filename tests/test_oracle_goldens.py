@@ -165,3 +165,37 @@ def test_qwen3_lm_against_reference_worker(golden):
         tok_mismatch += int((out != g[f"f{f}_tokens"]).sum())
     # greedy ids agree except where bf16 near-ties flip (different fp32 summation order)
     assert tok_mismatch <= 6, tok_mismatch
+
+
+# ---------------------------------------------------------------- g4: Qwen3 codec (streaming) -----
+def _codec_run(cfg, codes, chunk):
+    import torch
+    from oracle import qwen3_codec_ref as CR
+    m = CR.Qwen3CodecRef(cfg, CR.random_codec_weights(cfg, seed=0))
+    st = m.init_state(codes.shape[0])
+    c = torch.from_numpy(codes.astype(np.int64))
+    return torch.cat([m.forward_chunk(c[:, :, t:t + chunk], st) for t in range(0, c.shape[2], chunk)], -1).numpy()
+
+
+def test_codec_oracle_vs_reference_tiny(golden):
+    """Oracle ("mixed" numerics) vs the reference module run in fp32 and in bf16, and chunk-size invariance."""
+    from oracle import qwen3_codec_ref as CR
+    g = golden("g4_qwen3_codec")
+    cfg = CR.tiny_codec_cfg()
+    w4, w3 = _codec_run(cfg, g["tiny_codes"], 4), _codec_run(cfg, g["tiny_codes"], 3)
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    assert rms(w4) > 0.05
+    assert rms(w4 - w3) < 2e-6                                   # streaming state is exact: chunking-invariant (Q5)
+    assert rms(w4 - g["tiny_fp32_c4"]) < 2e-3                    # vs fp32 reference: bf16 operand rounding only
+    assert rms(w4 - g["tiny_bf16_c4"]) < 2e-2                    # vs the bf16 reference pipeline
+    assert rms(g["tiny_fp32_c4"] - g["tiny_bf16_c4"]) < 2e-2     # the reference's own fp32-vs-bf16 spread, same scale
+
+
+@pytest.mark.slow
+def test_codec_oracle_vs_reference_full(golden):
+    from oracle import qwen3_codec_ref as CR
+    g = golden("g4_qwen3_codec")
+    w = _codec_run(CR.CodecCfg(), g["full_codes"][:1, :, :10], 10)
+    ref = g["full_fp32_c10"][:1, :, :19200].astype(np.float32)
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    assert rms(ref) > 0.05 and rms(w - ref) < 3e-3

@@ -1,0 +1,564 @@
+// Qwen3-TTS 12 Hz codec decoder (token -> waveform), streaming, for gfx950.
+// Replaces Qwen3TTSTokenizerV2Decoder.forward_chunk (vox_serve/tokenizer/qwen3_codec.py:1541-1666) and the
+// per-request DecoderCache cat / copy-in / copy-out of CudaGraphWorker.run_detokenize
+// (worker/cuda_graph_worker.py:1217-1241: ~57 MiB per request per chunk) with in-place per-slot state
+// (conv tails + a 72-slot bf16 KV ring: ~2.6 MiB per request).
+//
+// Layout: activations fp32, time-major [rows = (request, t)][channels] so that
+//   * every conv / transposed conv / linear is ONE implicit GEMM  out[t, n] = sum_tap sum_c A[t - off_tap, c] * W[tap][n][c]
+//     on the matrix cores (v_mfma_f32_16x16x4_f32: fp32 operands, exact fp32 products and accumulation —
+//     the waveform parity bar of 1e-4 RMS is not reachable with bf16-rounded activations);
+//   * a transposed conv with stride r writes r*Cout contiguous values per input row = r output rows: no scatter;
+//   * LayerNorm / RMSNorm / depthwise conv run over the contiguous channel axis.
+// Weights stay bf16 in HBM ([tap][N][Cin], packed once on the host side) and are widened when staged to LDS.
+#include "vox_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ================================================================================================
+// implicit-GEMM convolution on fp32-input MFMA.  Block 256 threads = 2x2 waves, tile 64(M) x 64(N) x 32(K).
+// ================================================================================================
+#define CG_BM 64
+#define CG_BN 64
+#define CG_BK 32
+#define CG_LD (CG_BK + 4)   // LDS row stride in floats (16-byte aligned rows, spreads banks)
+#define CG_MAXTAPS 8
+
+struct ConvGemmArgs {
+    const float* x;        // [n*L, Cin] current-chunk input rows
+    const float* state;    // [slots, P, Cin] history rows (NULL when no tap looks back)
+    const int* slots;      // [n] state slot of each request in this batch
+    const bf16_t* w;       // [taps][N][Cin]
+    const float* bias;     // [bias_mod] or NULL
+    const float* res;      // [M, N] residual or NULL
+    const float* scale;    // [N] multiplier applied before the residual add, or NULL
+    float* out;            // [M, N]
+    int M, N, Cin, L, P, n_taps, bias_mod, gelu;
+    int off[CG_MAXTAPS];   // row look-back of each tap
+};
+
+__global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[CG_BM * CG_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[CG_BN * CG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * CG_BM, n0 = blockIdx.x * CG_BN;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging roles: A: thread -> (row = tid/4, 8 floats at col (tid%4)*8);  B: thread -> (row = tid/4, 8 bf16 at (tid%4)*8)
+    const int sr = tid >> 2, sc = (tid & 3) * 8;
+    const int am = m0 + sr;
+    const bool a_ok = am < a.M;
+    const int ab = a_ok ? am / a.L : 0, at = a_ok ? am % a.L : 0;
+    const int bn = n0 + sr;
+    const bool b_ok = bn < a.N;
+
+    for (int tap = 0; tap < a.n_taps; ++tap) {
+        const int st = at - a.off[tap];
+        const float* arow = nullptr;
+        if (a_ok) {
+            if (st >= 0) arow = a.x + ((size_t)ab * a.L + st) * a.Cin;
+            else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[ab] * a.P + (a.P + st)) * a.Cin;
+        }
+        const bf16_t* brow = b_ok ? a.w + ((size_t)tap * a.N + bn) * a.Cin : nullptr;
+        for (int c0 = 0; c0 < a.Cin; c0 += CG_BK) {
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (arow) {
+                v0 = *reinterpret_cast<const float4*>(arow + c0 + sc);
+                v1 = *reinterpret_cast<const float4*>(arow + c0 + sc + 4);
+            }
+            uint4 wv = make_uint4(0, 0, 0, 0);
+            if (brow) wv = *reinterpret_cast<const uint4*>(brow + c0 + sc);
+            __syncthreads();   // previous tile fully consumed
+            *reinterpret_cast<float4*>(&As[sr * CG_LD + sc]) = v0;
+            *reinterpret_cast<float4*>(&As[sr * CG_LD + sc + 4]) = v1;
+            *reinterpret_cast<float4*>(&Bs[sr * CG_LD + sc]) = make_float4(bflo(wv.x), bfhi(wv.x), bflo(wv.y), bfhi(wv.y));
+            *reinterpret_cast<float4*>(&Bs[sr * CG_LD + sc + 4]) = make_float4(bflo(wv.z), bfhi(wv.z), bflo(wv.w), bfhi(wv.w));
+            __syncthreads();
+            // each lane owns k = 4*(lane>>4)+s of every 16-wide K block: one float4 per operand feeds 4 MFMA steps
+            const int fr = lane & 15, fk = (lane >> 4) * 4;
+#pragma unroll
+            for (int kb = 0; kb < CG_BK; kb += 16) {
+                float4 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(&As[(wm + i * 16 + fr) * CG_LD + kb + fk]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 16 + fr) * CG_LD + kb + fk]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // epilogue: D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + j * 16 + (lane & 15);
+            if (n >= a.N) continue;
+            const float bv = a.bias ? a.bias[n % a.bias_mod] : 0.0f;
+            const float sv = a.scale ? a.scale[n] : 1.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + (lane >> 4) * 4 + r;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                const size_t o = (size_t)m * a.N + n;
+                if (a.res) v = a.res[o] + sv * v;
+                else if (a.scale) v = sv * v;
+                a.out[o] = v;
+            }
+        }
+}
+
+// ================================================================================================
+// small kernels
+// ================================================================================================
+// RVQ decode: q0 = emb[0][code0], qr = sum_{k>=1} emb[k][code_k] (sequential in k)      qwen3_codec.py:1204-1210
+__global__ __launch_bounds__(256) void k_rvq(const int* codes, int code_stride, const float* emb, int Q, int bins, int vq,
+                                             float* q0, float* qr) {
+    const int row = blockIdx.x;
+    const int* cr = codes + (size_t)row * code_stride;
+    for (int d = threadIdx.x; d < vq; d += 256) {
+        int c0 = cr[0];
+        c0 = c0 < 0 ? 0 : (c0 >= bins ? bins - 1 : c0);          // postprocess clamps to [0, bins-1] (qwen3_tts.py:2027)
+        q0[(size_t)row * vq + d] = emb[((size_t)c0) * vq + d];
+        float s = 0.0f;
+        for (int k = 1; k < Q; ++k) {
+            int c = cr[k];
+            c = c < 0 ? 0 : (c >= bins ? bins - 1 : c);
+            s = s + emb[((size_t)k * bins + c) * vq + d];
+        }
+        qr[(size_t)row * vq + d] = s;
+    }
+}
+
+// new_state = last P rows of [state ++ x]; one thread per (request, channel), ascending rows (in-place safe)
+__global__ __launch_bounds__(256) void k_state_update(float* state, const int* slots, const float* x, int L, int P, int C) {
+    const int b = blockIdx.y;
+    float* s = state + (size_t)slots[b] * P * C;
+    const float* xb = x + (size_t)b * L * C;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256)
+        for (int j = 0; j < P; ++j) {
+            const int e = L + j;   // index into ext = [state(P) ++ x(L)]
+            s[(size_t)j * C + c] = e < P ? s[(size_t)e * C + c] : xb[(size_t)(e - P) * C + c];
+        }
+}
+
+// SnakeBeta: y = x + inv_beta[c] * sin(x * alpha[c])^2          qwen3_codec.py:1004-1018 (alpha/beta pre-exponentiated)
+__global__ __launch_bounds__(256) void k_snake(const float* x, const float* alpha, const float* inv_beta, float* y,
+                                               size_t total, int C) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float v = x[i];
+        const float s = sinf(v * alpha[c]);
+        y[i] = v + inv_beta[c] * (s * s);
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// codec RMSNorm: y = w * (x * rsqrt(mean(x^2) + eps))       qwen3_codec.py:713-718
+__global__ __launch_bounds__(256) void k_rmsnorm_f32(const float* x, const float* w, float* y, int C, float eps) {
+    __shared__ float red[4];
+    const float* xr = x + (size_t)blockIdx.x * C;
+    float s = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) s += xr[c] * xr[c];
+    s = block_sum(s, red);
+    const float r = rsqrtf(s / (float)C + eps);
+    for (int c = threadIdx.x; c < C; c += 256) y[(size_t)blockIdx.x * C + c] = w[c] * (xr[c] * r);
+}
+
+// RoPE (NeoX halves) on q in place; k rotated and v written to the bf16 KV ring.   qwen3_codec.py:212-236, 614-631
+// qkv [rows, 3*HD]; ring [slots][Wn][2][HD] bf16; pos[slot] = tokens already in the window's history.
+__global__ __launch_bounds__(256) void k_codec_rope_kv(float* qkv, bf16_t* ring, const int* slots, const long* pos, int T,
+                                                       int H, int D, int Wn, const float* inv_freq) {
+    const int row = blockIdx.x, b = row / T, t = row % T;
+    const int HD = H * D, half = D / 2;
+    const long p = pos[slots[b]] + t;
+    float* q = qkv + (size_t)row * 3 * HD;
+    float* k = q + HD;
+    const float* v = q + 2 * HD;
+    bf16_t* rk = ring + (((size_t)slots[b] * Wn + (p % Wn)) * 2) * HD;
+    bf16_t* rv = rk + HD;
+    for (int e = threadIdx.x; e < H * half; e += 256) {
+        const int h = e / half, i = e % half;
+        const float ang = (float)p * inv_freq[i];
+        const float c = cosf(ang), s = sinf(ang);
+        const int ia = h * D + i, ib = ia + half;
+        const float qa = q[ia], qb = q[ib], ka = k[ia], kb = k[ib];
+        q[ia] = qa * c - qb * s;
+        q[ib] = qb * c + qa * s;
+        rk[ia] = f2bf(ka * c - kb * s);
+        rk[ib] = f2bf(kb * c + ka * s);
+    }
+    for (int e = threadIdx.x; e < HD; e += 256) rv[e] = f2bf(v[e]);
+}
+
+// windowed attention over the ring.  Query i (absolute position p0+i) sees absolute positions
+// [p0+T-Wn, p0+i]; positions < 0 are the reference's never-written zero slots, which stay visible.
+__global__ __launch_bounds__(128) void k_codec_attn(const float* qkv, const bf16_t* ring, const int* slots, const long* pos,
+                                                    float* out, int T, int H, int D, int Wn) {
+    extern __shared__ float sm[];   // K [Wn][D], V [Wn][D], P [Wn]
+    float* Ks = sm;
+    float* Vs = sm + (size_t)Wn * D;
+    float* Ps = Vs + (size_t)Wn * D;
+    __shared__ float red[2];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int HD = H * D;
+    const long p0 = pos[slots[b]];
+    const long lo = p0 + T - Wn;   // absolute position of logical slot 0
+    for (int e = threadIdx.x; e < Wn * D; e += 128) {
+        const int j = e / D, d = e % D;
+        const long ap = lo + j;
+        float kv = 0.0f, vv = 0.0f;
+        if (ap >= 0) {
+            const bf16_t* r = ring + (((size_t)slots[b] * Wn + (ap % Wn)) * 2) * HD + (size_t)h * D + d;
+            kv = bf2f(r[0]);
+            vv = bf2f(r[HD]);
+        }
+        Ks[e] = kv;
+        Vs[e] = vv;
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)D);
+    for (int i = 0; i < T; ++i) {
+        const float* q = qkv + ((size_t)(b * T + i)) * 3 * HD + (size_t)h * D;
+        const int nvis = Wn - T + i + 1;
+        float mx = -INFINITY;
+        for (int j = threadIdx.x; j < Wn; j += 128) {
+            float s = -INFINITY;
+            if (j < nvis) {
+                s = 0.0f;
+                for (int d = 0; d < D; ++d) s += q[d] * Ks[j * D + d];
+                s *= scale;
+            }
+            Ps[j] = s;
+            mx = fmaxf(mx, s);
+        }
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(red[0], red[1]);
+        float ls = 0.0f;
+        for (int j = threadIdx.x; j < Wn; j += 128) {
+            const float pj = j < nvis ? expf(Ps[j] - mx) : 0.0f;
+            Ps[j] = pj;
+            ls += pj;
+        }
+        for (int off = 32; off >= 1; off >>= 1) ls += __shfl_xor(ls, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ls;
+        __syncthreads();
+        ls = red[0] + red[1];
+        for (int d = threadIdx.x; d < D; d += 128) {
+            float o = 0.0f;
+            for (int j = 0; j < nvis; ++j) o += Ps[j] * Vs[j * D + d];
+            out[((size_t)(b * T + i)) * HD + (size_t)h * D + d] = o / ls;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pos_advance(long* pos, const int* slots, int n, int T) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < n) pos[slots[b]] += T;
+}
+
+// h[m][i] = silu(gu[m][i]) * gu[m][I+i]
+__global__ __launch_bounds__(256) void k_silu_mul_f32(const float* gu, float* h, size_t rows, int I) {
+    const size_t total = rows * I;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t m = e / I;
+        const int i = (int)(e % I);
+        const float g = gu[m * 2 * I + i], u = gu[m * 2 * I + I + i];
+        h[e] = (g / (1.0f + expf(-g))) * u;
+    }
+}
+
+// ConvNeXt front: causal depthwise conv k=7 (+bias) then LayerNorm over channels.   qwen3_codec.py:447-450
+__global__ __launch_bounds__(256) void k_dwconv_ln(const float* x, const float* state, const int* slots, const float* w,
+                                                   const float* wb, const float* lnw, const float* lnb, float* y, int L,
+                                                   int C, float eps) {
+    __shared__ float red[4];
+    extern __shared__ float ybuf[];   // [C]
+    const int row = blockIdx.x, b = row / L, t = row % L;
+    const float* st = state + (size_t)slots[b] * 6 * C;
+    float s1 = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = wb[c];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int e = t + k;   // index into ext = [state(6) ++ x]
+            const float v = e < 6 ? st[(size_t)e * C + c] : x[((size_t)b * L + (e - 6)) * C + c];
+            acc += w[c * 7 + k] * v;
+        }
+        ybuf[c] = acc;
+        s1 += acc;
+    }
+    const float mean = block_sum(s1, red) / (float)C;
+    float s2 = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float d = ybuf[c] - mean;
+        s2 += d * d;
+    }
+    const float rstd = rsqrtf(block_sum(s2, red) / (float)C + eps);
+    for (int c = threadIdx.x; c < C; c += 256) y[(size_t)row * C + c] = (ybuf[c] - mean) * rstd * lnw[c] + lnb[c];
+}
+
+// final causal conv k=7, C -> 1, + clamp(-1,1).  One wave per output sample group.
+__global__ __launch_bounds__(256) void k_final_conv(const float* x, const float* state, const int* slots, const float* w,
+                                                    float bias, float* out, int L, int C) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= L) return;
+    const float* st = state + (size_t)slots[b] * 6 * C;
+    float acc = 0.0f;
+    for (int e = lane; e < 7 * C; e += 64) {
+        const int k = e / C, c = e % C;
+        const int r = t + k;
+        const float v = r < 6 ? st[(size_t)r * C + c] : x[((size_t)b * L + (r - 6)) * C + c];
+        acc += w[c * 7 + k] * v;
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[(size_t)b * L + t] = fminf(1.0f, fmaxf(-1.0f, acc + bias));
+}
+
+// ================================================================================================
+// engine
+// ================================================================================================
+#include <vector>
+
+struct vox_codec {
+    vox_ctx* ctx;
+    vox_codec_config cfg;
+    vox_codec_weights w;
+    int max_batch, max_slots, T;
+    // state (per slot)
+    float *st_pre, *st_dw[2], *st_dec0, *st_tc[4], *st_ru[4][3], *st_final;
+    bf16_t* ring;   // [layers][slots][Wn][2][HD]
+    long* pos;      // [slots]
+    // work buffers
+    float* buf[4];
+    size_t buf_floats;
+    float *q0, *qr;
+};
+
+static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const float* state, const int* slots, int n,
+                     int L, int P, const int* offs, float* out, const float* res, const float* scale, int gelu) {
+    if (w.cin % CG_BK) return vox_fail(VOX_ERR_INVALID, "codec gemm: Cin %d %% %d != 0", w.cin, CG_BK);
+    if (w.n_taps > CG_MAXTAPS) return vox_fail(VOX_ERR_INVALID, "codec gemm: too many taps");
+    ConvGemmArgs a{};
+    a.x = x; a.state = state; a.slots = slots; a.w = (const bf16_t*)w.w; a.bias = w.bias; a.res = res; a.scale = scale;
+    a.out = out; a.M = n * L; a.N = w.n; a.Cin = w.cin; a.L = L; a.P = P; a.n_taps = w.n_taps;
+    a.bias_mod = w.bias_mod > 0 ? w.bias_mod : w.n; a.gelu = gelu;
+    for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
+    dim3 grid((w.n + CG_BN - 1) / CG_BN, (a.M + CG_BM - 1) / CG_BM);
+    hipLaunchKernelGGL(k_conv_gemm, grid, dim3(256), 0, st, a);
+    return VOX_OK;
+}
+
+static void snake(hipStream_t st, const float* x, const vox_snake_w& s, float* y, size_t rows, int C) {
+    const size_t total = rows * C;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_snake, dim3(grid), dim3(256), 0, st, x, s.alpha, s.inv_beta, y, total, C);
+}
+static void state_update(hipStream_t st, float* state, const int* slots, const float* x, int n, int L, int P, int C) {
+    hipLaunchKernelGGL(k_state_update, dim3((C + 255) / 256, n), dim3(256), 0, st, state, slots, x, L, P, C);
+}
+
+extern "C" {
+
+int vox_codec_create(vox_ctx* ctx, const vox_codec_config* cfg, const vox_codec_weights* w, int max_batch, int max_slots,
+                     int frames_per_chunk, vox_codec** out) {
+    if (!ctx || !cfg || !w || !out) return vox_fail(VOX_ERR_INVALID, "codec_create: NULL");
+    if (cfg->n_blocks != 4 || cfg->n_upsample != 2 || cfg->num_layers > 16)
+        return vox_fail(VOX_ERR_INVALID, "codec_create: expects 4 decoder blocks, 2 upsample stages");
+    vox_codec* m = new vox_codec();
+    m->ctx = ctx; m->cfg = *cfg; m->w = *w; m->max_batch = max_batch; m->max_slots = max_slots; m->T = frames_per_chunk;
+    const int S = max_slots, HD = cfg->num_heads * cfg->head_dim;
+    size_t L = frames_per_chunk;
+    auto zalloc = [&](float** p, size_t n) { return hipMalloc((void**)p, n * 4) == hipSuccess && hipMemset(*p, 0, n * 4) == hipSuccess; };
+    bool ok = zalloc(&m->st_pre, (size_t)S * 2 * cfg->codebook_dim);
+    for (int u = 0; u < 2; ++u) ok = ok && zalloc(&m->st_dw[u], (size_t)S * 6 * cfg->latent_dim);
+    ok = ok && zalloc(&m->st_dec0, (size_t)S * 6 * cfg->latent_dim);
+    size_t maxf = (size_t)L * (4 * cfg->latent_dim) * 4;   // ConvNeXt hidden at 4L rows
+    L *= 4;
+    for (int b = 0; b < 4; ++b) {
+        const int cin = cfg->decoder_dim >> b, cout = cfg->decoder_dim >> (b + 1);
+        ok = ok && zalloc(&m->st_tc[b], (size_t)S * cin);
+        L *= cfg->rates[b];
+        for (int u = 0; u < 3; ++u) {
+            const int d = u == 0 ? 1 : (u == 1 ? 3 : 9);
+            ok = ok && zalloc(&m->st_ru[b][u], (size_t)S * 6 * d * cout);
+        }
+        if (L * cout > maxf) maxf = L * cout;
+        if ((L / cfg->rates[b]) * cin > maxf) maxf = (L / cfg->rates[b]) * cin;
+    }
+    ok = ok && zalloc(&m->st_final, (size_t)S * 6 * (cfg->decoder_dim >> 4));
+    const size_t ring_elems = (size_t)cfg->num_layers * S * cfg->window * 2 * HD;
+    ok = ok && hipMalloc((void**)&m->ring, ring_elems * 2) == hipSuccess && hipMemset(m->ring, 0, ring_elems * 2) == hipSuccess;
+    ok = ok && hipMalloc((void**)&m->pos, (size_t)S * 8) == hipSuccess && hipMemset(m->pos, 0, (size_t)S * 8) == hipSuccess;
+    m->buf_floats = maxf * max_batch;
+    for (int i = 0; i < 4; ++i) ok = ok && hipMalloc((void**)&m->buf[i], m->buf_floats * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&m->q0, (size_t)max_batch * frames_per_chunk * cfg->vq_dim * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&m->qr, (size_t)max_batch * frames_per_chunk * cfg->vq_dim * 4) == hipSuccess;
+    if (!ok) return vox_fail(VOX_ERR_NOMEM, "codec_create: hipMalloc failed");
+    *out = m;
+    return VOX_OK;
+}
+
+void vox_codec_destroy(vox_codec* m) {
+    if (!m) return;
+    (void)hipFree(m->st_pre); (void)hipFree(m->st_dec0); (void)hipFree(m->st_final); (void)hipFree(m->ring);
+    (void)hipFree(m->pos); (void)hipFree(m->q0); (void)hipFree(m->qr);
+    for (int u = 0; u < 2; ++u) (void)hipFree(m->st_dw[u]);
+    for (int b = 0; b < 4; ++b) {
+        (void)hipFree(m->st_tc[b]);
+        for (int u = 0; u < 3; ++u) (void)hipFree(m->st_ru[b][u]);
+    }
+    for (int i = 0; i < 4; ++i) (void)hipFree(m->buf[i]);
+    delete m;
+}
+
+int64_t vox_codec_state_bytes(vox_codec* m) {
+    if (!m) return 0;
+    const vox_codec_config& c = m->cfg;
+    int64_t f = 2 * c.codebook_dim + 6 * c.latent_dim * 3 + 6 * (c.decoder_dim >> 4);
+    for (int b = 0; b < 4; ++b) f += (c.decoder_dim >> b) + 6 * 13 * (c.decoder_dim >> (b + 1));
+    return f * 4 + (int64_t)c.num_layers * c.window * 2 * c.num_heads * c.head_dim * 2 + 8;
+}
+
+// Zero the streaming state of one slot (a new request takes it over).  Replaces audio_decoder_initial_cache
+// (model/qwen3_tts.py:1243-1260).
+int vox_codec_reset_slot(vox_codec* m, void* stream, int slot) {
+    if (!m || slot < 0 || slot >= m->max_slots) return vox_fail(VOX_ERR_INVALID, "codec_reset_slot: bad slot");
+    hipStream_t st = (hipStream_t)stream;
+    const vox_codec_config& c = m->cfg;
+    auto z = [&](float* p, size_t per) { return hipMemsetAsync(p + (size_t)slot * per, 0, per * 4, st); };
+    VOX_HIP(z(m->st_pre, (size_t)2 * c.codebook_dim));
+    for (int u = 0; u < 2; ++u) VOX_HIP(z(m->st_dw[u], (size_t)6 * c.latent_dim));
+    VOX_HIP(z(m->st_dec0, (size_t)6 * c.latent_dim));
+    for (int b = 0; b < 4; ++b) {
+        VOX_HIP(z(m->st_tc[b], (size_t)(c.decoder_dim >> b)));
+        for (int u = 0; u < 3; ++u) VOX_HIP(z(m->st_ru[b][u], (size_t)6 * (u == 0 ? 1 : (u == 1 ? 3 : 9)) * (c.decoder_dim >> (b + 1))));
+    }
+    VOX_HIP(z(m->st_final, (size_t)6 * (c.decoder_dim >> 4)));
+    const size_t HD = (size_t)c.num_heads * c.head_dim, per = (size_t)c.window * 2 * HD;
+    for (int l = 0; l < c.num_layers; ++l)
+        VOX_HIP(hipMemsetAsync(m->ring + ((size_t)l * m->max_slots + slot) * per, 0, per * 2, st));
+    VOX_HIP(hipMemsetAsync(m->pos + slot, 0, 8, st));
+    return VOX_OK;
+}
+
+// codes: int32 [n, T, code_stride] (first num_quantizers columns used); slots: int32 [n]; out: fp32 [n, T*hop]
+int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int code_stride, const int32_t* slots, int n,
+                           int T, float* out) {
+    if (!m || !codes || !slots || !out) return vox_fail(VOX_ERR_INVALID, "codec_decode_chunk: NULL");
+    if (n < 1 || n > m->max_batch || T < 1 || T > m->T) return vox_fail(VOX_ERR_INVALID, "codec_decode_chunk: n=%d T=%d out of range", n, T);
+    hipStream_t st = (hipStream_t)stream;
+    const vox_codec_config& c = m->cfg;
+    const vox_codec_weights& w = m->w;
+    const int HD = c.num_heads * c.head_dim, H = c.hidden, LD = c.latent_dim;
+    float *A = m->buf[0], *B = m->buf[1], *C = m->buf[2], *D = m->buf[3];
+    const int off0[1] = {0};
+    int L = T;
+
+    hipLaunchKernelGGL(k_rvq, dim3(n * L), dim3(256), 0, st, codes, code_stride, w.emb, c.num_quantizers, c.codebook_size,
+                       c.vq_dim, m->q0, m->qr);
+    VOX_TRY(conv_gemm(st, w.rvq_first_out, m->q0, nullptr, slots, n, L, 0, off0, A, nullptr, nullptr, 0));
+    VOX_TRY(conv_gemm(st, w.rvq_rest_out, m->qr, nullptr, slots, n, L, 0, off0, B, A, nullptr, 0));      // B = A + rest
+    const int off3[3] = {2, 1, 0};
+    VOX_TRY(conv_gemm(st, w.pre_conv, B, m->st_pre, slots, n, L, 2, off3, A, nullptr, nullptr, 0));      // [nL, latent]
+    state_update(st, m->st_pre, slots, B, n, L, 2, c.codebook_dim);
+    // ---- transformer (hidden H) ----
+    VOX_TRY(conv_gemm(st, w.in_proj, A, nullptr, slots, n, L, 0, off0, B, nullptr, nullptr, 0));          // h = B [nL,H]
+    for (int l = 0; l < c.num_layers; ++l) {
+        const vox_codec_layer_w& lw = w.layers[l];
+        bf16_t* ring = m->ring + (size_t)l * m->max_slots * c.window * 2 * HD;
+        hipLaunchKernelGGL(k_rmsnorm_f32, dim3(n * L), dim3(256), 0, st, B, lw.ln1, C, H, c.rms_eps);
+        VOX_TRY(conv_gemm(st, lw.qkv, C, nullptr, slots, n, L, 0, off0, D, nullptr, nullptr, 0));        // D [nL,3HD]
+        hipLaunchKernelGGL(k_codec_rope_kv, dim3(n * L), dim3(256), 0, st, D, ring, slots, m->pos, L, c.num_heads,
+                           c.head_dim, c.window, w.inv_freq);
+        hipLaunchKernelGGL(k_codec_attn, dim3(c.num_heads, n), dim3(128), (size_t)(2 * c.window * c.head_dim + c.window) * 4,
+                           st, D, ring, slots, m->pos, C, L, c.num_heads, c.head_dim, c.window);         // C [nL,HD]
+        VOX_TRY(conv_gemm(st, lw.o, C, nullptr, slots, n, L, 0, off0, B, B, lw.scale1, 0));              // h += s1*o(attn)
+        hipLaunchKernelGGL(k_rmsnorm_f32, dim3(n * L), dim3(256), 0, st, B, lw.ln2, C, H, c.rms_eps);
+        VOX_TRY(conv_gemm(st, lw.gate_up, C, nullptr, slots, n, L, 0, off0, D, nullptr, nullptr, 0));    // D [nL,2I]
+        hipLaunchKernelGGL(k_silu_mul_f32, dim3((n * L * c.intermediate + 255) / 256), dim3(256), 0, st, D, C,
+                           (size_t)n * L, c.intermediate);
+        VOX_TRY(conv_gemm(st, lw.down, C, nullptr, slots, n, L, 0, off0, B, B, lw.scale2, 0));           // h += s2*down
+    }
+    hipLaunchKernelGGL(k_pos_advance, dim3((n + 255) / 256), dim3(256), 0, st, m->pos, slots, n, L);
+    hipLaunchKernelGGL(k_rmsnorm_f32, dim3(n * L), dim3(256), 0, st, B, w.final_norm, C, H, c.rms_eps);
+    VOX_TRY(conv_gemm(st, w.out_proj, C, nullptr, slots, n, L, 0, off0, A, nullptr, nullptr, 0));         // A [nL,latent]
+    // ---- upsample x2 x2 with ConvNeXt ----
+    for (int u = 0; u < 2; ++u) {
+        const vox_codec_up_w& uw = w.up[u];
+        VOX_TRY(conv_gemm(st, uw.tconv, A, nullptr, slots, n, L, 0, off0, B, nullptr, nullptr, 0));      // B [n*2L, latent]
+        L *= 2;
+        hipLaunchKernelGGL(k_dwconv_ln, dim3(n * L), dim3(256), (size_t)LD * 4, st, B, m->st_dw[u], slots, uw.dw_w, uw.dw_b,
+                           uw.ln_w, uw.ln_b, C, L, LD, 1e-6f);
+        state_update(st, m->st_dw[u], slots, B, n, L, 6, LD);
+        VOX_TRY(conv_gemm(st, uw.pw1, C, nullptr, slots, n, L, 0, off0, D, nullptr, nullptr, 1));        // GELU
+        VOX_TRY(conv_gemm(st, uw.pw2, D, nullptr, slots, n, L, 0, off0, A, B, uw.gamma, 0));             // A = B + gamma*pw2
+    }
+    // ---- decoder ----
+    const int off7[7] = {6, 5, 4, 3, 2, 1, 0};
+    VOX_TRY(conv_gemm(st, w.dec0, A, m->st_dec0, slots, n, L, 6, off7, B, nullptr, nullptr, 0));          // B [nL, decoder_dim]
+    state_update(st, m->st_dec0, slots, A, n, L, 6, LD);
+    float* h = B;      // current activations
+    float* t1 = A;
+    float* t2 = C;
+    float* t3 = D;
+    for (int b = 0; b < 4; ++b) {
+        const vox_codec_block_w& bw = w.blocks[b];
+        const int cin = c.decoder_dim >> b, cout = c.decoder_dim >> (b + 1), r = c.rates[b];
+        snake(st, h, bw.snake0, t1, (size_t)n * L, cin);
+        const int offt[2] = {0, 1};
+        VOX_TRY(conv_gemm(st, bw.tconv, t1, m->st_tc[b], slots, n, L, 1, offt, t2, nullptr, nullptr, 0)); // t2 [n*L*r, cout]
+        state_update(st, m->st_tc[b], slots, t1, n, L, 1, cin);
+        L *= r;
+        { float* x = h; h = t2; t2 = x; }
+        for (int u = 0; u < 3; ++u) {
+            const vox_codec_res_w& rw = bw.res[u];
+            const int d = u == 0 ? 1 : (u == 1 ? 3 : 9);
+            const int offd[7] = {6 * d, 5 * d, 4 * d, 3 * d, 2 * d, d, 0};
+            snake(st, h, rw.act1, t1, (size_t)n * L, cout);
+            VOX_TRY(conv_gemm(st, rw.conv1, t1, m->st_ru[b][u], slots, n, L, 6 * d, offd, t3, nullptr, nullptr, 0));
+            state_update(st, m->st_ru[b][u], slots, t1, n, L, 6 * d, cout);
+            snake(st, t3, rw.act2, t1, (size_t)n * L, cout);
+            VOX_TRY(conv_gemm(st, rw.conv2, t1, nullptr, slots, n, L, 0, off0, h, h, nullptr, 0));        // h += conv2(...)
+        }
+    }
+    const int cl = c.decoder_dim >> 4;
+    snake(st, h, w.final_snake, t1, (size_t)n * L, cl);
+    hipLaunchKernelGGL(k_final_conv, dim3((L + 3) / 4, n), dim3(256), 0, st, t1, m->st_final, slots, w.final_w, w.final_b, out,
+                       L, cl);
+    state_update(st, m->st_final, slots, t1, n, L, 6, cl);
+    return VOX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,250 @@
+"""Qwen3-TTS 12 Hz codec decoder on MI355X — host side of libvoxhip `vox_codec_*`.
+
+Drop-in for the decode half of /root/reference/vox_serve/tokenizer/qwen3_codec.py:
+  Qwen3TTSDecoder.decode_chunk / init_cache           qwen3_codec.py:1865-1903
+  Qwen3TTSTokenizerV2Decoder.forward_chunk            qwen3_codec.py:1541-1666
+  Qwen3TTSDecoderCache                                qwen3_codec.py:33-85
+Weights are taken under the reference's state_dict names (HF checkpoint layout) and re-laid out once into
+the [tap][Cout][Cin] bf16 form the implicit-GEMM kernel streams; codebooks are normalised once
+(embedding_sum / clamp(cluster_usage), qwen3_codec.py:1159-1162).
+"""
+import ctypes
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import _native as N
+from .base import DecoderCache
+
+
+@dataclass
+class Qwen3CodecConfig:
+    """Defaults = Qwen3TTSTokenizerV2DecoderConfig (qwen3_codec.py:88-113)."""
+    codebook_size: int = 2048
+    codebook_dim: int = 512
+    latent_dim: int = 1024
+    decoder_dim: int = 1536
+    hidden_size: int = 512
+    intermediate_size: int = 1024
+    head_dim: int = 64
+    num_heads: int = 16
+    num_layers: int = 8
+    num_quantizers: int = 16
+    rms_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    sliding_window: int = 72
+    upsample_rates: List[int] = field(default_factory=lambda: [8, 5, 4, 3])
+    upsampling_ratios: List[int] = field(default_factory=lambda: [2, 2])
+
+    @property
+    def total_upsample(self) -> int:
+        return int(math.prod(self.upsample_rates + self.upsampling_ratios))
+
+
+# ---- ctypes mirrors of include/voxhip.h ------------------------------------------------------------
+class ConvW(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("n_taps", ctypes.c_int32), ("n", ctypes.c_int32),
+                ("cin", ctypes.c_int32), ("bias_mod", ctypes.c_int32)]
+
+
+class SnakeW(ctypes.Structure):
+    _fields_ = [("alpha", ctypes.c_void_p), ("inv_beta", ctypes.c_void_p)]
+
+
+class LayerW(ctypes.Structure):
+    _fields_ = [("ln1", ctypes.c_void_p), ("scale1", ctypes.c_void_p), ("ln2", ctypes.c_void_p), ("scale2", ctypes.c_void_p),
+                ("qkv", ConvW), ("o", ConvW), ("gate_up", ConvW), ("down", ConvW)]
+
+
+class UpW(ctypes.Structure):
+    _fields_ = [("tconv", ConvW), ("pw1", ConvW), ("pw2", ConvW), ("dw_w", ctypes.c_void_p), ("dw_b", ctypes.c_void_p),
+                ("ln_w", ctypes.c_void_p), ("ln_b", ctypes.c_void_p), ("gamma", ctypes.c_void_p)]
+
+
+class ResW(ctypes.Structure):
+    _fields_ = [("act1", SnakeW), ("act2", SnakeW), ("conv1", ConvW), ("conv2", ConvW)]
+
+
+class BlockW(ctypes.Structure):
+    _fields_ = [("snake0", SnakeW), ("tconv", ConvW), ("res", ResW * 3)]
+
+
+class CodecWeights(ctypes.Structure):
+    _fields_ = [("emb", ctypes.c_void_p), ("rvq_first_out", ConvW), ("rvq_rest_out", ConvW), ("pre_conv", ConvW),
+                ("in_proj", ConvW), ("out_proj", ConvW), ("dec0", ConvW), ("layers", LayerW * 16),
+                ("final_norm", ctypes.c_void_p), ("inv_freq", ctypes.c_void_p), ("up", UpW * 2), ("blocks", BlockW * 4),
+                ("final_snake", SnakeW), ("final_w", ctypes.c_void_p), ("final_b", ctypes.c_float)]
+
+
+class CodecConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("codebook_size", "codebook_dim", "vq_dim", "latent_dim", "decoder_dim", "hidden",
+                                              "intermediate", "head_dim", "num_heads", "num_layers", "num_quantizers",
+                                              "window")] + \
+               [("rates", ctypes.c_int32 * 4), ("n_blocks", ctypes.c_int32), ("n_upsample", ctypes.c_int32),
+                ("rms_eps", ctypes.c_float), ("rope_theta", ctypes.c_float)]
+
+
+def _bind(L):
+    if getattr(L, "_codec_bound", False):
+        return
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.vox_codec_create.restype, L.vox_codec_create.argtypes = ci, [vp, ctypes.POINTER(CodecConfig), ctypes.POINTER(CodecWeights),
+                                                                  ci, ci, ci, ctypes.POINTER(vp)]
+    L.vox_codec_destroy.restype, L.vox_codec_destroy.argtypes = None, [vp]
+    L.vox_codec_state_bytes.restype, L.vox_codec_state_bytes.argtypes = ctypes.c_int64, [vp]
+    L.vox_codec_reset_slot.restype, L.vox_codec_reset_slot.argtypes = ci, [vp, vp, ci]
+    L.vox_codec_decode_chunk.restype, L.vox_codec_decode_chunk.argtypes = ci, [vp, vp, vp, ci, vp, ci, ci, vp]
+    L._codec_bound = True
+
+
+@dataclass
+class Qwen3TTSDecoderCache(DecoderCache):
+    """Handle on the in-place streaming state of one request: `slot` indexes the engine's state arrays.
+    A [1]-shaped int32 tensor so that DecoderCache.cat / __getitem__ / copy_from keep their meaning."""
+    slot: Optional[torch.Tensor] = None
+
+
+class Qwen3TTSDecoder:
+    """decode_chunk / init_cache surface of the reference's Qwen3TTSDecoder (qwen3_codec.py:1789-1903)."""
+
+    def __init__(self, weights: Dict[str, torch.Tensor], config: Optional[Qwen3CodecConfig] = None, device="cuda",
+                 max_batch=8, max_slots=64, detokenize_interval=10):
+        self.cfg = c = config or Qwen3CodecConfig()
+        self.device = torch.device(device)
+        self.max_batch, self.max_slots, self.interval = max_batch, max_slots, detokenize_interval
+        self.L = N.lib()
+        _bind(self.L)
+        self._keep = []
+        W = weights
+        dev = self.device
+
+        def f32(t):
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        def conv(wp, bias=None, bias_mod=0):
+            """wp: [taps, N, Cin] float tensor -> bf16 device tensor"""
+            wp = wp.detach().to(device=dev, dtype=torch.bfloat16).contiguous()
+            self._keep.append(wp)
+            return ConvW(wp.data_ptr(), f32(bias) if bias is not None else None, wp.shape[0], wp.shape[1], wp.shape[2],
+                         bias_mod)
+
+        def lin(name, bias=True):
+            return conv(W[name + ".weight"].float()[None], W.get(name + ".bias") if bias else None)
+
+        def causal(name):        # Conv1d [Cout, Cin, K] -> taps k=0..K-1 (look-back (K-1-k)*dil), qwen3_codec.py:239-340
+            w = W[name + ".conv.weight"].float()
+            return conv(w.permute(2, 0, 1), W[name + ".conv.bias"])
+
+        def tconv(name, stride):  # ConvTranspose1d [Cin, Cout, K]: y[t*s+j] = x[t] W[:,:,j] + x[t-1] W[:,:,j+s]
+            w = W[name + ".conv.weight"].float()
+            cin, cout, k = w.shape
+            taps = [w[:, :, j0:j0 + stride].permute(2, 1, 0).reshape(stride * cout, cin) for j0 in range(0, k, stride)]
+            return conv(torch.stack(taps, 0), W[name + ".conv.bias"], bias_mod=cout)
+
+        def snake(name):
+            a = torch.exp(W[name + ".alpha"].float().cpu())
+            ib = 1.0 / (torch.exp(W[name + ".beta"].float().cpu()) + 1e-9)
+            return SnakeW(f32(a), f32(ib))
+
+        cw = CodecWeights()
+        embs = []
+        for name, n in (("rvq_first", 1), ("rvq_rest", c.num_quantizers - 1)):
+            for j in range(n):
+                p = f"quantizer.{name}.vq.layers.{j}._codebook."
+                embs.append(W[p + "embedding_sum"].float().cpu() / W[p + "cluster_usage"].float().cpu().clamp(min=1e-5)[:, None])
+        cw.emb = f32(torch.stack(embs, 0))
+        cw.rvq_first_out = conv(W["quantizer.rvq_first.output_proj.weight"].float()[:, :, 0][None])
+        cw.rvq_rest_out = conv(W["quantizer.rvq_rest.output_proj.weight"].float()[:, :, 0][None])
+        cw.pre_conv = causal("pre_conv")
+        cw.in_proj = lin("pre_transformer.input_proj")
+        cw.out_proj = lin("pre_transformer.output_proj")
+        cw.dec0 = causal("decoder.0")
+        for i in range(c.num_layers):
+            p = f"pre_transformer.layers.{i}."
+            lw = cw.layers[i]
+            lw.ln1, lw.ln2 = f32(W[p + "input_layernorm.weight"]), f32(W[p + "post_attention_layernorm.weight"])
+            lw.scale1, lw.scale2 = f32(W[p + "self_attn_layer_scale.scale"]), f32(W[p + "mlp_layer_scale.scale"])
+            lw.qkv = conv(torch.cat([W[p + "self_attn.q_proj.weight"], W[p + "self_attn.k_proj.weight"],
+                                     W[p + "self_attn.v_proj.weight"]], 0).float()[None])
+            lw.o = conv(W[p + "self_attn.o_proj.weight"].float()[None])
+            lw.gate_up = conv(torch.cat([W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"]], 0).float()[None])
+            lw.down = conv(W[p + "mlp.down_proj.weight"].float()[None])
+        cw.final_norm = f32(W["pre_transformer.norm.weight"])
+        cw.inv_freq = f32(1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32) / c.head_dim)))
+        for u, f_ in enumerate(c.upsampling_ratios):
+            p = f"upsample.{u}."
+            uw = cw.up[u]
+            uw.tconv = tconv(p + "0", f_)
+            uw.pw1, uw.pw2 = lin(p + "1.pwconv1"), lin(p + "1.pwconv2")
+            uw.dw_w, uw.dw_b = f32(W[p + "1.dwconv.conv.weight"].reshape(-1, 7)), f32(W[p + "1.dwconv.conv.bias"])
+            uw.ln_w, uw.ln_b, uw.gamma = f32(W[p + "1.norm.weight"]), f32(W[p + "1.norm.bias"]), f32(W[p + "1.gamma"])
+        for b, r in enumerate(c.upsample_rates):
+            p = f"decoder.{b + 1}.block."
+            bw = cw.blocks[b]
+            bw.snake0 = snake(p + "0")
+            bw.tconv = tconv(p + "1", r)
+            for u in range(3):
+                q = f"{p}{u + 2}."
+                rw = bw.res[u]
+                rw.act1, rw.act2 = snake(q + "act1"), snake(q + "act2")
+                rw.conv1, rw.conv2 = causal(q + "conv1"), causal(q + "conv2")
+        nb = len(c.upsample_rates)
+        cw.final_snake = snake(f"decoder.{nb + 1}")
+        cw.final_w = f32(W[f"decoder.{nb + 2}.conv.weight"].reshape(-1, 7))
+        cw.final_b = float(W[f"decoder.{nb + 2}.conv.bias"].float().item())
+        self._cw = cw
+        cc = CodecConfig(c.codebook_size, c.codebook_dim, c.codebook_dim // 2, c.latent_dim, c.decoder_dim, c.hidden_size,
+                         c.intermediate_size, c.head_dim, c.num_heads, c.num_layers, c.num_quantizers, c.sliding_window,
+                         (ctypes.c_int32 * 4)(*c.upsample_rates), len(c.upsample_rates), len(c.upsampling_ratios),
+                         c.rms_eps, c.rope_theta)
+        h = ctypes.c_void_p()
+        N.check(self.L.vox_codec_create(N.ctx(), ctypes.byref(cc), ctypes.byref(cw), max_batch, max_slots,
+                                        detokenize_interval, ctypes.byref(h)))
+        self.h = h
+        self._free_slots = list(range(max_slots))
+        self.hop = c.total_upsample
+        self._out = torch.empty(max_batch, detokenize_interval * self.hop, dtype=torch.float32, device=dev)
+
+    @property
+    def state_bytes_per_request(self) -> int:
+        return int(self.L.vox_codec_state_bytes(self.h))
+
+    # ---- slot management (the reference allocates a fresh 57 MiB cache object per request) -------------
+    def init_cache(self, batch_size: int = 1, device=None, dtype=None, detokenize_interval: int = None):
+        slots = []
+        for _ in range(batch_size):
+            if not self._free_slots:
+                raise RuntimeError("codec: no free streaming slot (raise max_slots)")
+            s = self._free_slots.pop(0)
+            N.check(self.L.vox_codec_reset_slot(self.h, N.stream(), s))
+            slots.append(s)
+        return Qwen3TTSDecoderCache(slot=torch.tensor(slots, dtype=torch.int32, device=self.device))
+
+    def release_cache(self, cache: Qwen3TTSDecoderCache):
+        for s in cache.slot.tolist():
+            self._free_slots.append(int(s))
+
+    def decode_chunk(self, codes: torch.Tensor, decoder_cache: Qwen3TTSDecoderCache, code_layout: str = "BQT"):
+        """codes: [B, num_quantizers, T] (reference layout) or, with code_layout="BTQ", [B, T, >=num_quantizers]
+        (the worker's token buffer, no transpose).  Returns (wav fp32 [B,1,T*hop], the same cache)."""
+        if code_layout == "BQT":
+            codes = codes.transpose(1, 2)
+        codes = codes.to(device=self.device, dtype=torch.int32).contiguous()
+        b, t, stride = codes.shape
+        if stride < self.cfg.num_quantizers:
+            raise ValueError(f"Expected {self.cfg.num_quantizers} layer of codes, got {stride}")
+        slots = decoder_cache.slot.to(torch.int32).contiguous()
+        out = self._out[:b, : t * self.hop]
+        if not out.is_contiguous():
+            out = torch.empty(b, t * self.hop, dtype=torch.float32, device=self.device)
+        N.check(self.L.vox_codec_decode_chunk(self.h, N.stream(), N.ptr(codes), stride, N.ptr(slots), b, t, N.ptr(out)))
+        return out[:, None, :], decoder_cache
+
+    def close(self):
+        if self.h:
+            self.L.vox_codec_destroy(self.h)
+            self.h = None
