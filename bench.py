@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""bench.py — the streaming TTS hot loop of vox-serve on MI355X: Qwen3-TTS-1.7B (bf16, random-init weights of the
+named architecture, synthetic fixed-length prompts), speech-token decode + token->waveform codec.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one audio frame (1920 samples at 24 kHz) for the whole batch of B concurrent requests: one hipGraph
+replay = talker decode step + codebook-0 sampling + the 15-step depth loop (+ feedback of the next inputs), the
+host-side plan upload and token read-back, and every 10th step one codec chunk (10 frames -> 19200 samples per
+request) with PCM16 packing and D2H.  value = audio samples/s over all ranks (weak scaling: B per GPU fixed).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PROMPT_TOKENS = 75         # 64 text tokens + 11 layout tokens
+INTERVAL = 10              # detokenize_interval default (qwen3_tts.py:965)
+KV_BYTES_PER_TOKEN = 28 * 2 * 8 * 128 * 2
+
+
+def algorithmic_bytes_per_frame(B, kv_mean):
+    talker = 28 * 50.33e6 * 2 + 3072 * 2048 * 2 + (2048 * 2048 * 2 + 4096) * 2     # layers + codec_head + text_projection
+    depth = (5 * 15.73e6 + 2048 * 1024 + 1024) * 2 + 15 * 2048 * 1024 * 2          # read once per frame
+    return talker + depth + B * kv_mean * KV_BYTES_PER_TOKEN + B * KV_BYTES_PER_TOKEN
+
+
+class Loop:
+    """B concurrent requests in lock-step on one GPU: the worker's decode + detokenize hot loop."""
+
+    def __init__(self, B, max_frames, dev):
+        from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
+        from vox_serve_amd.synth import synth_qwen3_codec_weights, synth_qwen3_weights
+        from vox_serve_amd.tokenizer.qwen3_codec import Qwen3TTSDecoder
+        self.B, self.dev, self.cfg = B, dev, Qwen3Cfg()
+        self.ps = 128
+        self.pages_per_req = (PROMPT_TOKENS + max_frames + self.ps) // self.ps + 1
+        W = self.W = synth_qwen3_weights(self.cfg, dev, seed=0)
+        self.eng = Qwen3Engine(self.cfg, W, max_batch=B, page_size=self.ps, max_pages=B * self.pages_per_req + 1,
+                               max_seq_len=2304, max_prefill_rows=128)
+        self.eng.keep_hidden = False
+        self.codec = Qwen3TTSDecoder(synth_qwen3_codec_weights(seed=0), device=dev, max_batch=B, max_slots=B,
+                                     detokenize_interval=INTERVAL)
+        self.sc = self.eng.sampling_cfg(greedy=True)
+        self.tok_ring = torch.zeros(B, INTERVAL, self.cfg.n_groups + 1, dtype=torch.int32, device=dev)
+        self.pages = [[b * self.pages_per_req + j for j in range(self.pages_per_req)] for b in range(B)]
+        self.kvlen = [0] * B
+        self.nframe = 0
+        self.samples = 0
+        self.rng = np.random.default_rng(1)
+        self.frame_ev = []
+
+    def start_requests(self):
+        """Prefill every request (one per step, like the scheduler) -> first frame."""
+        e, c = self.eng, self.cfg
+        self.cache = self.codec.init_cache(self.B)
+        first_inputs = []
+        for b in range(self.B):
+            n = PROMPT_TOKENS
+            ids = np.zeros((n, c.n_groups + 1), np.int32)
+            ids[:, -1] = self.rng.integers(0, 151000, n)
+            ids[:, 0] = self.rng.integers(0, 2048, n)
+            e.row_ids[:n] = torch.from_numpy(ids).to(self.dev)
+            e.row_masks[:n] = 0
+            e.row_masks[n - 1:n] = 1
+            e.row_feats[:n].zero_()
+            pg = self.pages[b]
+            e.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[pg[t // self.ps] for t in range(n)],
+                          slot=[t % self.ps for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1],
+                          indptr=[0, (n + self.ps - 1) // self.ps], indices=pg[: (n + self.ps - 1) // self.ps])
+            e.prefill(n, 1, n, self.sc, feedback=True)
+            first_inputs.append((e.input_ids[0].clone(), e.input_features[0].clone(), e.out_ids[0].clone()))
+            self.kvlen[b] = n
+        for b, (ii, ff, oo) in enumerate(first_inputs):
+            e.input_ids[b], e.input_features[b] = ii, ff
+            self.tok_ring[b, 0] = oo
+        e.input_masks[: self.B] = 1
+        self.nframe = 1
+        self.pos = [PROMPT_TOKENS + 1] * self.B              # quirk Q1: first decode position is n+1 (worker/base.py:299)
+
+    def step(self, timed_events=None):
+        """One frame for the whole batch."""
+        e, B, ps = self.eng, self.B, self.ps
+        indptr, indices, page, slot = [0], [], [], []
+        for b in range(B):
+            self.kvlen[b] += 1
+            npg = (self.kvlen[b] + ps - 1) // ps
+            indptr.append(indptr[-1] + npg)
+            indices += self.pages[b][:npg]
+            page.append(self.pages[b][npg - 1])
+            slot.append((self.kvlen[b] - 1) % ps)
+        e.upload_plan(pos=self.pos, kvlen=self.kvlen, page=page, slot=slot, indptr=indptr, indices=indices)
+        if timed_events is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(e.stream)
+        e.frame(B, max(self.kvlen), self.sc, feedback=True, use_graph=True)
+        if timed_events is not None:
+            ev1.record(e.stream)
+            timed_events.append((ev0, ev1))
+        self.tok_ring[:, self.nframe % INTERVAL] = e.out_ids[:B]
+        ids = e.out_ids[:B].cpu()                              # the scheduler needs the tokens (EOS / max_tokens checks)
+        self.pos = [p + 1 for p in self.pos]
+        self.nframe += 1
+        pcm = None
+        if self.nframe % INTERVAL == 0:
+            wav, _ = self.codec.decode_chunk(self.tok_ring, self.cache, code_layout="BTQ")
+            pcm = (wav[:, 0] * 32767).to(torch.int16).cpu().numpy()      # worker/base.py:658-672
+            self.samples += pcm.size
+        return ids, pcm
+
+
+def cpu_baseline(loop, budget_s=25.0):
+    """The CPU oracle (oracle/voxref.c, OpenMP; oracle/qwen3_codec_ref.py, torch CPU) on the same workload:
+    talker+depth decode frames at B=1 with kv=75, plus one codec chunk.  Reported, never the product path."""
+    from oracle import qwen3_codec_ref as CR
+    from oracle import qwen3_ref as QR
+    from oracle import voxref as vr
+    cores = os.cpu_count() or 1
+    ref_cfg = QR.Qwen3Cfg(max_pos=256)
+    src = {k: v.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16) for k, v in loop.W.items()}
+    m = QR.Qwen3Ref(ref_cfg, src, page_size=128, max_pages=2, max_batch=1)
+    req = QR.RefRequest()
+    rng = np.random.default_rng(1)
+    n = 8                                         # short prefill just to have a live request (not timed)
+    ids = np.zeros((n, 17), np.int32)
+    ids[:, -1] = rng.integers(0, 151000, n)
+    lg, hid = m.prefill(req, ids, np.ones(n, np.uint8), np.zeros((n, 2048), np.uint16))
+    m.frame([req], lg, hid)
+    t0 = time.perf_counter()
+    nf = 0
+    while nf < 1 or (time.perf_counter() - t0 < budget_s * 0.6 and nf < 8):
+        m.frame([req])
+        nf += 1
+    t_lm = (time.perf_counter() - t0) / nf
+    tthreads = min(cores, 16)                     # torch-CPU conv stops scaling (and collapses) far below 256 threads
+    torch.set_num_threads(tthreads)
+    ccfg = CR.CodecCfg()
+    cm = CR.Qwen3CodecRef(ccfg, CR.random_codec_weights(ccfg, seed=0))
+    st = cm.init_state(1)
+    codes = torch.randint(0, 2048, (1, 16, INTERVAL))
+    t1 = time.perf_counter()
+    cm.forward_chunk(codes, st)
+    t_codec = time.perf_counter() - t1
+    per_frame = t_lm + t_codec / INTERVAL
+    return {"value": 1920.0 / per_frame, "unit": "audio samples/s", "cores": cores, "kind": "port",
+            "sample": f"{nf} LM frames (talker 28L + 15x depth 5L, B=1, kv~{n}) {t_lm:.2f} s/frame on {cores} OpenMP threads "
+                      f"+ 1 codec chunk (10 frames) {t_codec:.2f} s on {tthreads} torch threads; "
+                      f"oracle = C fixed-order fp32 + torch-CPU codec"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="concurrent requests per GPU (BASELINE configs: 1 and 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ttfa-requests", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)         # RCCL; used only for the barrier + max-reduce
+
+    B = args.batch
+    loop = Loop(B, args.steps + args.warmup + 64, dev)
+
+    # ---- TTFA (p50): request start -> first PCM chunk on the host, batch-1 streaming, outside the timed steps ----
+    ttfa = []
+    if rank == 0 and args.ttfa_requests > 0:
+        solo = loop if B == 1 else None
+        if solo is not None:
+            for _ in range(args.ttfa_requests):
+                solo.kvlen, solo.samples = [0] * B, 0
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                solo.start_requests()
+                pcm = None
+                while pcm is None:
+                    _, pcm = solo.step()
+                ttfa.append((time.perf_counter() - t0) * 1e3)
+                solo.codec.release_cache(solo.cache)
+
+    loop.kvlen, loop.samples = [0] * B, 0
+    loop.start_requests()
+    for _ in range(args.warmup):
+        loop.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    loop.samples = 0
+    kv_start = loop.kvlen[0]
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loop.step(events)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frame_gpu_s = float(np.mean([a.elapsed_time(b) for a, b in events])) * 1e-3
+
+    if rank == 0:
+        kv_mean = kv_start + args.steps / 2
+        alg = algorithmic_bytes_per_frame(B, kv_mean)
+        samples_total = world * B * 1920 * args.steps
+        out = {
+            "metric": "audio samples/sec, Qwen3-TTS-1.7B streaming decode + codec",
+            "value": samples_total / dt, "unit": "audio samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Qwen3-TTS-1.7B bf16, batch={B}/GPU streaming, greedy, {PROMPT_TOKENS}-token prompt, "
+                                   f"detokenize_interval {INTERVAL}, page_size 128", "batch_per_gpu": B,
+                       "frames_per_request": args.steps, "parallelism": f"dp{world} (independent replicas, no collective on the data path)"},
+            "realtime_factor": samples_total / dt / 24000.0 / (world * B),
+            "ttfa_ms_p50": float(np.median(ttfa)) if ttfa else None,
+            "roofline": {"bound": "hbm", "achieved": alg / frame_gpu_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / frame_gpu_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "launch": "one hipGraph replay = one LM frame (talker + 15 depth steps + sampling)",
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": frame_gpu_s * 1e3},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(loop)
+            except Exception as ex:  # the baseline is a reported extra; never let it hide the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(ex)[:200]}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

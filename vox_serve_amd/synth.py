@@ -46,3 +46,43 @@ def synth_qwen3_weights(cfg, device, seed=0, std=0.02):
     W["talker.code_predictor.small_to_mtp_projection.weight"] = w(cfg.depth.hidden, H)
     W["talker.code_predictor.small_to_mtp_projection.bias"] = w(cfg.depth.hidden)
     return W
+
+
+def synth_qwen3_codec_weights(cfg=None, seed=0):
+    """Random-init Qwen3 12 Hz codec decoder weights (CPU fp32 tensors holding bf16-representable values), scaled so
+    that the waveform stays O(0.1) through the 12 stacked residual units."""
+    import math
+    from .tokenizer.qwen3_codec import Qwen3CodecConfig, param_shapes
+    cfg = cfg or Qwen3CodecConfig()
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    for k, s in param_shapes(cfg).items():
+        if k.endswith("cluster_usage"):
+            t = 1.0 + torch.rand(s, generator=g)
+        elif k.endswith("embedding_sum"):
+            t = torch.randn(s, generator=g)
+        elif k.endswith(("layernorm.weight", "norm.weight")):
+            t = 1.0 + 0.1 * torch.randn(s, generator=g)
+        elif k.endswith((".alpha", ".beta")):
+            t = 0.3 * torch.randn(s, generator=g)
+        elif k.endswith("layer_scale.scale"):
+            t = torch.full(s, 0.05)
+        elif k.endswith(".gamma"):
+            t = torch.full(s, 0.1)
+        elif k.endswith(".bias"):
+            t = 0.02 * torch.randn(s, generator=g)
+        else:
+            fan_in = s[1] * (s[2] if len(s) == 3 else 1)
+            if "block.1.conv.weight" in k:
+                fan_in = s[0] * 2
+            elif "upsample" in k and k.endswith("0.conv.weight"):
+                fan_in = s[0]
+            elif k.endswith("dwconv.conv.weight"):
+                fan_in = 7
+            t = torch.randn(s, generator=g) / math.sqrt(fan_in)
+            if k.endswith("conv2.conv.weight"):
+                t = t * 0.25
+            if s[0] == 1:
+                t = t * 0.1
+        W[k] = t.to(torch.bfloat16).float()
+    return W

@@ -43,6 +43,55 @@ class Qwen3CodecConfig:
         return int(math.prod(self.upsample_rates + self.upsampling_ratios))
 
 
+def param_shapes(c: Qwen3CodecConfig) -> Dict[str, tuple]:
+    """state_dict names -> shapes of the decoder half of the Qwen3-TTS-Tokenizer-12Hz checkpoint."""
+    S = {}
+    H, L, I, qd = c.hidden_size, c.latent_dim, c.intermediate_size, c.num_heads * c.head_dim
+    for i in range(c.num_layers):
+        p = f"pre_transformer.layers.{i}."
+        for n_, sh in (("self_attn.q_proj", (qd, H)), ("self_attn.k_proj", (qd, H)), ("self_attn.v_proj", (qd, H)),
+                       ("self_attn.o_proj", (H, qd)), ("mlp.gate_proj", (I, H)), ("mlp.up_proj", (I, H)),
+                       ("mlp.down_proj", (H, I))):
+            S[p + n_ + ".weight"] = sh
+        for n_ in ("input_layernorm.weight", "post_attention_layernorm.weight", "self_attn_layer_scale.scale",
+                   "mlp_layer_scale.scale"):
+            S[p + n_] = (H,)
+    S["pre_transformer.norm.weight"] = (H,)
+    S["pre_transformer.input_proj.weight"], S["pre_transformer.input_proj.bias"] = (H, L), (H,)
+    S["pre_transformer.output_proj.weight"], S["pre_transformer.output_proj.bias"] = (L, H), (L,)
+    vq = c.codebook_dim // 2
+    for name, n in (("rvq_first", 1), ("rvq_rest", c.num_quantizers - 1)):
+        S[f"quantizer.{name}.input_proj.weight"] = (vq, c.codebook_dim, 1)
+        S[f"quantizer.{name}.output_proj.weight"] = (c.codebook_dim, vq, 1)
+        for j in range(n):
+            S[f"quantizer.{name}.vq.layers.{j}._codebook.cluster_usage"] = (c.codebook_size,)
+            S[f"quantizer.{name}.vq.layers.{j}._codebook.embedding_sum"] = (c.codebook_size, vq)
+    S["pre_conv.conv.weight"], S["pre_conv.conv.bias"] = (L, c.codebook_dim, 3), (L,)
+    for u, f_ in enumerate(c.upsampling_ratios):
+        p = f"upsample.{u}."
+        S.update({p + "0.conv.weight": (L, L, f_), p + "0.conv.bias": (L,), p + "1.gamma": (L,),
+                  p + "1.dwconv.conv.weight": (L, 1, 7), p + "1.dwconv.conv.bias": (L,), p + "1.norm.weight": (L,),
+                  p + "1.norm.bias": (L,), p + "1.pwconv1.weight": (4 * L, L), p + "1.pwconv1.bias": (4 * L,),
+                  p + "1.pwconv2.weight": (L, 4 * L), p + "1.pwconv2.bias": (L,)})
+    S["decoder.0.conv.weight"], S["decoder.0.conv.bias"] = (c.decoder_dim, L, 7), (c.decoder_dim,)
+    for b, r in enumerate(c.upsample_rates):
+        cin, cout = c.decoder_dim // 2 ** b, c.decoder_dim // 2 ** (b + 1)
+        p = f"decoder.{b + 1}.block."
+        S.update({p + "0.alpha": (cin,), p + "0.beta": (cin,), p + "1.conv.weight": (cin, cout, 2 * r),
+                  p + "1.conv.bias": (cout,)})
+        for u in range(3):
+            q = f"{p}{u + 2}."
+            for a in ("act1", "act2"):
+                S[q + a + ".alpha"], S[q + a + ".beta"] = (cout,), (cout,)
+            S[q + "conv1.conv.weight"], S[q + "conv1.conv.bias"] = (cout, cout, 7), (cout,)
+            S[q + "conv2.conv.weight"], S[q + "conv2.conv.bias"] = (cout, cout, 1), (cout,)
+    nb = len(c.upsample_rates)
+    cl = c.decoder_dim // 2 ** nb
+    S[f"decoder.{nb + 1}.alpha"], S[f"decoder.{nb + 1}.beta"] = (cl,), (cl,)
+    S[f"decoder.{nb + 2}.conv.weight"], S[f"decoder.{nb + 2}.conv.bias"] = (1, cl, 7), (1,)
+    return S
+
+
 # ---- ctypes mirrors of include/voxhip.h ------------------------------------------------------------
 class ConvW(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("n_taps", ctypes.c_int32), ("n", ctypes.c_int32),
