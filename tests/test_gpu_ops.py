@@ -34,7 +34,8 @@ def rnd(rng, *shape, s=1.0):
 
 
 @pytest.mark.parametrize("B,N_,K", [(1, 64, 256), (1, 2048, 2048), (2, 1030, 1024), (3, 512, 6144), (4, 4096, 2048),
-                                    (5, 96, 512), (8, 3072, 1024), (9, 128, 2048), (19, 256, 768), (1, 7, 64)])
+                                    (5, 96, 512), (8, 3072, 1024), (9, 128, 2048), (19, 256, 768), (1, 7, 64),
+                                    (16, 2048, 2048), (32, 4096, 2048), (32, 2048, 6144), (75, 1000, 1024), (33, 64, 96)])
 def test_linear_bit_exact(dev, B, N_, K):
     from vox_serve_amd import _native as N
     rng = np.random.default_rng(B * 1000 + N_ + K)
@@ -49,10 +50,16 @@ def test_linear_bit_exact(dev, B, N_, K):
             ref = vr.silu(ref)
         if use_res:
             ref = vr.add(res, ref)
-        assert np.array_equal(Bits(y), ref), (use_bias, use_res, act)
+        if B <= 8 or K % 32:
+            assert np.array_equal(Bits(y), ref), (use_bias, use_res, act)      # fixed-order VALU path: bit-exact
+        else:   # > 8 rows: bf16 MFMA path, fp32 accumulation in MFMA order -> neighbouring bf16 value at most
+            # (with a residual the 1-ulp difference of y is measured against a possibly smaller sum: absolute slack)
+            assert bf16_close(Bits(y), ref, ulps=1, atol=0.04 if use_res else 2e-3).all(), (use_bias, use_res, act)
+            assert (Bits(y) == ref).mean() > 0.97
 
 
-@pytest.mark.parametrize("B,N_,K", [(1, 6144, 2048), (2, 768, 256), (4, 3072, 1024), (8, 520, 512), (11, 64, 128)])
+@pytest.mark.parametrize("B,N_,K", [(1, 6144, 2048), (2, 768, 256), (4, 3072, 1024), (8, 520, 512), (11, 64, 128),
+                                    (32, 6144, 2048), (75, 3072, 1024)])
 def test_linear_silu_mul_bit_exact(dev, B, N_, K):
     from vox_serve_amd import _native as N
     rng = np.random.default_rng(N_ + K + B)
@@ -60,7 +67,11 @@ def test_linear_silu_mul_bit_exact(dev, B, N_, K):
     h = torch.empty(B, N_, dtype=torch.bfloat16, device=dev)
     Wgt, Wut, xt = T(Wg, dev), T(Wu, dev), T(x, dev)        # keep alive: ptr() does not own the tensor
     N.check(N.lib().vox_linear_silu_mul(N.ctx(), N.stream(), N.ptr(Wgt), N.ptr(Wut), N.ptr(xt), N.ptr(h), B, N_, K))
-    assert np.array_equal(Bits(h), vr.linear_silu_mul(Wg, Wu, x))
+    ref = vr.linear_silu_mul(Wg, Wu, x)
+    if B <= 8:
+        assert np.array_equal(Bits(h), ref)
+    else:
+        assert bf16_close(Bits(h), ref, ulps=2, atol=2e-3).all() and (Bits(h) == ref).mean() > 0.95
 
 
 @pytest.mark.parametrize("rows,H", [(1, 2048), (5, 128), (33, 1024), (64, 64), (3, 4096)])

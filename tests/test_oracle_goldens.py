@@ -168,34 +168,48 @@ def test_qwen3_lm_against_reference_worker(golden):
 
 
 # ---------------------------------------------------------------- g4: Qwen3 codec (streaming) -----
-def _codec_run(cfg, codes, chunk):
+def _codec_run(cfg, codes, chunk, exact):
+    """exact=True: contraction operands stay fp32 (the mode the HIP codec computes in: fp32-input MFMA);
+    exact=False: operands rounded to bf16 (what a bf16-MFMA codec would compute)."""
     import torch
     from oracle import qwen3_codec_ref as CR
-    m = CR.Qwen3CodecRef(cfg, CR.random_codec_weights(cfg, seed=0))
-    st = m.init_state(codes.shape[0])
-    c = torch.from_numpy(codes.astype(np.int64))
-    return torch.cat([m.forward_chunk(c[:, :, t:t + chunk], st) for t in range(0, c.shape[2], chunk)], -1).numpy()
+    keep = CR.bfr
+    if exact:
+        CR.bfr = lambda x: x
+    try:
+        m = CR.Qwen3CodecRef(cfg, CR.random_codec_weights(cfg, seed=0))
+        st = m.init_state(codes.shape[0])
+        c = torch.from_numpy(codes.astype(np.int64))
+        return torch.cat([m.forward_chunk(c[:, :, t:t + chunk], st) for t in range(0, c.shape[2], chunk)], -1).numpy()
+    finally:
+        CR.bfr = keep
+
+
+_rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
 
 
 def test_codec_oracle_vs_reference_tiny(golden):
-    """Oracle ("mixed" numerics) vs the reference module run in fp32 and in bf16, and chunk-size invariance."""
+    """The restatement against the reference module itself (tiny config, two chunk sizes): in fp32 mode it agrees
+    to fp32 round-off, i.e. every streaming-state rule (conv tails, transposed-conv overlap, KV window incl. the
+    unmasked zero slots of quirk Q4, RoPE offset) is reproduced; bf16 operand rounding alone moves the waveform by
+    ~1e-2 RMS, the same distance the reference's own bf16 pipeline sits from its fp32 self."""
     from oracle import qwen3_codec_ref as CR
     g = golden("g4_qwen3_codec")
     cfg = CR.tiny_codec_cfg()
-    w4, w3 = _codec_run(cfg, g["tiny_codes"], 4), _codec_run(cfg, g["tiny_codes"], 3)
-    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
-    assert rms(w4) > 0.05
-    assert rms(w4 - w3) < 2e-6                                   # streaming state is exact: chunking-invariant (Q5)
-    assert rms(w4 - g["tiny_fp32_c4"]) < 2e-3                    # vs fp32 reference: bf16 operand rounding only
-    assert rms(w4 - g["tiny_bf16_c4"]) < 2e-2                    # vs the bf16 reference pipeline
-    assert rms(g["tiny_fp32_c4"] - g["tiny_bf16_c4"]) < 2e-2     # the reference's own fp32-vs-bf16 spread, same scale
+    for ch in (4, 3):
+        e = _codec_run(cfg, g["tiny_codes"], ch, exact=True)
+        assert _rms(e) > 0.05
+        assert _rms(e - g[f"tiny_fp32_c{ch}"]) < 5e-6, ch
+    spread = _rms(g["tiny_fp32_c4"] - g["tiny_bf16_c4"])
+    mixed = _codec_run(cfg, g["tiny_codes"], 4, exact=False)
+    assert 1e-3 < _rms(mixed - g["tiny_fp32_c4"]) < 2e-2 and 1e-3 < spread < 3e-2
 
 
 @pytest.mark.slow
 def test_codec_oracle_vs_reference_full(golden):
+    """Qwen3 12 Hz decoder at its real size, first chunk of request 0 (fixture stored as fp16: ~5e-5 of its own)."""
     from oracle import qwen3_codec_ref as CR
     g = golden("g4_qwen3_codec")
-    w = _codec_run(CR.CodecCfg(), g["full_codes"][:1, :, :10], 10)
+    w = _codec_run(CR.CodecCfg(), g["full_codes"][:1, :, :10], 10, exact=True)
     ref = g["full_fp32_c10"][:1, :, :19200].astype(np.float32)
-    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
-    assert rms(ref) > 0.05 and rms(w - ref) < 3e-3
+    assert _rms(ref) > 0.05 and _rms(w - ref) < 1.5e-4

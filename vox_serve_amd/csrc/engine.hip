@@ -207,7 +207,7 @@ struct vox_stack {
 // decode_rows: every row is the newest token of a distinct request (its K/V are not read by any other row), so the
 // head norm / RoPE / KV append fuse into the attention kernel; otherwise (prefill) a separate pass appends first.
 static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t kv_stride, const vox_rows* r,
-                        bool decode_rows = false) {
+                        bool decode_rows = false, int fixed_order = 0) {
     const vox_stack_config& c = s->cfg;
     const int n = r->n_rows;
     if (n <= 0) return VOX_OK;
@@ -227,6 +227,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         LinearCall a;  // input_layernorm + fused q/k/v projection
         a.W = w.wqkv; a.bias = w.bqkv; a.x = x; a.norm_w = w.ln1; a.eps = c.eps; a.y = s->qkv;
         a.B = n; a.N = nqkv; a.K = c.hidden; a.pro = VOX_PRO_RMSNORM; a.epi = VOX_EPI_STORE;
+        a.fixed_order = fixed_order;
         VOX_TRY(vox_launch_linear(s->ctx, st, a));
         HeadCall hc;  // per-head norm + RoPE + paged append
         hc.q_src = s->qkv; hc.k_src = (bf16_t*)s->qkv + nq; hc.v_src = (bf16_t*)s->qkv + nq + nkv;
@@ -252,14 +253,17 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         LinearCall o;  // o_proj + residual
         o.W = w.wo; o.x = s->attn_out; o.residual = x; o.y = x; o.B = n; o.N = c.hidden; o.K = nq;
         o.pro = VOX_PRO_COPY; o.epi = VOX_EPI_STORE;
+        o.fixed_order = fixed_order;
         VOX_TRY(vox_launch_linear(s->ctx, st, o));
         LinearCall g;  // post_attention_layernorm + gate/up + SiLU*up
         g.W = w.wgate; g.W2 = w.wup; g.x = x; g.norm_w = w.ln2; g.eps = c.eps; g.y = s->h;
         g.B = n; g.N = c.ffn; g.K = c.hidden; g.pro = VOX_PRO_RMSNORM; g.epi = VOX_EPI_SILU_MUL;
+        g.fixed_order = fixed_order;
         VOX_TRY(vox_launch_linear(s->ctx, st, g));
         LinearCall d;  // down + residual
         d.W = w.wdown; d.x = s->h; d.residual = x; d.y = x; d.B = n; d.N = c.hidden; d.K = c.ffn;
         d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE;
+        d.fixed_order = fixed_order;
         VOX_TRY(vox_launch_linear(s->ctx, st, d));
     }
     return VOX_OK;
@@ -375,7 +379,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         const int rows = i == 1 ? 2 * B : B;
         LinearCall p;  // small_to_mtp_projection
         p.W = m->w.mtp_w; p.bias = m->w.mtp_b; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
-        p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE;
+        p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8;
         VOX_TRY(vox_launch_linear(m->ctx, st, p));
         vox_rows r{};
         r.pos = i == 1 ? m->d1_pos : m->di_pos[i];
@@ -387,7 +391,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         r.kv_indices = m->iota;
         r.n_rows = rows;
         r.max_kvlen = i + 1;
-        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1));
+        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= 8));
         void* dl = io->out_depth_logits ? (void*)((bf16_t*)io->out_depth_logits + (size_t)(i - 1) * c.max_batch * c.depth_vocab)
                                         : m->dlogits;
         LinearCall h;  // depth final norm + lm_head[i-1]

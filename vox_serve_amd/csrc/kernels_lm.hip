@@ -281,6 +281,187 @@ static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
     return vox_fail(VOX_ERR_INVALID, "linear: no kernel variant");
 }
 
+// ================================================================================================
+// linear for 9..N rows: bf16 MFMA, weights streamed once per 16/32-row tile.
+// Used for batched decode (B > 8) and prefill.  Each wave owns 16 output columns (weight rows): the B
+// fragment of v_mfma_f32_16x16x32_bf16 is exactly one 16-byte load per lane straight from HBM
+// (row n0+(lane&15), k-block (lane>>4)*8), the activation tile sits in LDS (row-padded by 16 B so the 16
+// rows of an A fragment hit distinct banks).  fp32 accumulation in MFMA order: parity with the oracle is to
+// bf16 rounding, not bit-exact (rows <= 8 keep the fixed-order VALU kernel above).
+// ================================================================================================
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define MF_KS 1024   // K segment staged in LDS at a time
+
+__device__ __forceinline__ bf16x8_t as_bf8(uint4 v) {
+    union { uint4 u; bf16x8_t b; } c;
+    c.u = v;
+    return c.b;
+}
+
+template <int MT, int PRO, int EPI>
+__global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BT = 16 * MT;
+    constexpr int LDK = MF_KS + 8;                  // padded row stride (elements)
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);   // [BT][LDK]
+    float* rinv = reinterpret_cast<float*>(smem + (size_t)BT * LDK * 2);   // [BT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // one 16-column tile per block; the four waves interleave the K steps (step s -> wave s%4) and their partial
+    // accumulators are summed in wave order through LDS: N/16 blocks keep the whole chip streaming even at N=1024.
+    const int n0 = blockIdx.x * 16;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    int nrow = n0 + fr;
+    nrow = nrow < a.N ? nrow : a.N - 1;
+    const bf16_t* wrow = a.W + (size_t)nrow * a.K;
+    const bf16_t* wrow2 = (EPI == EPI_SILU_MUL) ? a.W2 + (size_t)nrow * a.K : nullptr;
+
+    for (int b0 = 0; b0 < a.B; b0 += BT) {
+        const int bt = (a.B - b0) < BT ? (a.B - b0) : BT;
+        if (PRO == PRO_RMSNORM) {
+            __syncthreads();
+            for (int b = wave; b < bt; b += 4) {
+                const uint4* xr = x_row_ptr(a, b0 + b);
+                float ss = 0.0f;
+                for (int c = lane; c < (a.K >> 3); c += 64) ss = sq8(xr[c], ss);
+                ss = butterfly<64>(ss);
+                if (lane == 0) rinv[b] = 1.0f / sqrtf(ss / (float)a.K + a.eps);
+            }
+            __syncthreads();
+        }
+        f32x4_t acc[MT], acc2[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            acc2[m] = acc[m];
+        }
+        constexpr int U = 8;
+        uint4 wv[U], wv2[U];
+        // software pipeline: the weight loads of the NEXT group are in flight while x is staged / MFMAs run
+        auto issue = [&](int k0, int s0, int ks) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = s0 + 128 * u;
+                if (kk < ks) {
+                    wv[u] = ldg_nt(reinterpret_cast<const uint4*>(wrow + k0 + kk + fk));
+                    if (EPI == EPI_SILU_MUL) wv2[u] = ldg_nt(reinterpret_cast<const uint4*>(wrow2 + k0 + kk + fk));
+                }
+            }
+        };
+        issue(0, 32 * wave, a.K < MF_KS ? a.K : MF_KS);
+        for (int k0 = 0; k0 < a.K; k0 += MF_KS) {
+            const int ks = (a.K - k0) < MF_KS ? (a.K - k0) : MF_KS;
+            const int nch = ks >> 3;
+            __syncthreads();
+            for (int i = tid; i < BT * nch; i += 256) {
+                const int b = i / nch, c = i % nch;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (b < bt) {
+                    v = x_row_ptr(a, b0 + b)[(k0 >> 3) + c];
+                    if (PRO == PRO_RMSNORM) {
+                        v = norm_chunk(v, reinterpret_cast<const uint4*>(a.nw)[(k0 >> 3) + c], rinv[b]);
+                        if (a.x_out && blockIdx.x == 0)
+                            reinterpret_cast<uint4*>(a.x_out + (size_t)(b0 + b) * a.x_out_stride)[(k0 >> 3) + c] = v;
+                    }
+                }
+                *reinterpret_cast<uint4*>(xs + (size_t)b * LDK + c * 8) = v;
+            }
+            __syncthreads();
+            for (int s0 = 32 * wave; s0 < ks; s0 += 128 * U) {
+                uint4 cw[U], cw2[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    cw[u] = wv[u];
+                    if (EPI == EPI_SILU_MUL) cw2[u] = wv2[u];
+                }
+                // prefetch the following group (same segment, or the first group of the next segment)
+                if (s0 + 128 * U < ks) issue(k0, s0 + 128 * U, ks);
+                else if (k0 + MF_KS < a.K) issue(k0 + MF_KS, 32 * wave, (a.K - k0 - MF_KS) < MF_KS ? (a.K - k0 - MF_KS) : MF_KS);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int kk = s0 + 128 * u;
+                    if (kk < ks) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const uint4 xa = *reinterpret_cast<const uint4*>(xs + (size_t)(m * 16 + fr) * LDK + kk + fk);
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xa), as_bf8(cw[u]), acc[m], 0, 0, 0);
+                            if (EPI == EPI_SILU_MUL)
+                                acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xa), as_bf8(cw2[u]), acc2[m], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // cross-wave reduction (fixed order: wave 0 + 1 + 2 + 3), then wave 0 runs the epilogue
+        __syncthreads();
+        f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);   // the x tile is dead now: [3 waves][2 sets][MT][64 lanes]
+        if (wave > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                red[(((wave - 1) * 2 + 0) * MT + m) * 64 + lane] = acc[m];
+                if (EPI == EPI_SILU_MUL) red[(((wave - 1) * 2 + 1) * MT + m) * 64 + lane] = acc2[m];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m] += red[((w * 2 + 0) * MT + m) * 64 + lane];
+                    if (EPI == EPI_SILU_MUL) acc2[m] += red[((w * 2 + 1) * MT + m) * 64 + lane];
+                }
+        }
+        // D: column n = lane&15, rows (lane>>4)*4 + r
+        const int n = n0 + fr;
+        if (wave == 0 && n < a.N) {
+            const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = m * 16 + (lane >> 4) * 4 + r;
+                    if (b >= bt) continue;
+                    const size_t oi = (size_t)(b0 + b) * a.N + n;
+                    bf16_t o;
+                    if (EPI == EPI_SILU_MUL) {
+                        const float g = bfround(acc[m][r]), u = bfround(acc2[m][r]);
+                        o = f2bf(bfround(silu_c(g)) * u);
+                    } else {
+                        float v = acc[m][r];
+                        if (a.bias) v = v + bv;
+                        o = f2bf(v);
+                        if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
+                        if (a.residual) o = f2bf(bf2f(a.residual[oi]) + bf2f(o));
+                    }
+                    a.y[oi] = o;
+                }
+        }
+    }
+}
+
+template <int MT, int PRO, int EPI>
+static int launch_linear_mfma_t(hipStream_t st, const LinArgs& a) {
+    constexpr int BT = 16 * MT;
+    const size_t smem = (size_t)BT * (MF_KS + 8) * 2 + BT * 4;
+    auto kern = k_linear_mfma<MT, PRO, EPI>;
+    if (smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((a.N + 15) / 16), dim3(256), smem, st, a);
+    return VOX_OK;
+}
+
+template <int PRO, int EPI>
+static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a) {
+    if (a.B <= 16) return launch_linear_mfma_t<1, PRO, EPI>(st, a);
+    return launch_linear_mfma_t<2, PRO, EPI>(st, a);
+}
+
 int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     if (c.K % 8 != 0 || c.B <= 0 || c.N <= 0) return vox_fail(VOX_ERR_INVALID, "linear: K%8!=0 or empty");
     LinArgs a{};
@@ -291,6 +472,13 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     a.x_out_stride = c.x_out_stride ? c.x_out_stride : c.K; a.eps = c.eps; a.B = c.B; a.N = c.N; a.K = c.K; a.Hq = c.Hq; a.D = c.D;
     a.max_chunks = c.max_chunks;
     const int ncu = ctx->n_cu;
+    if (c.B > 8 && !c.fixed_order && c.pro != PRO_ATTN && c.K % 32 == 0) {   // > 8 rows: MFMA path (weights streamed once per 32-row tile)
+#define VOX_PM(P, E) if (c.pro == P && c.epi == E) return launch_linear_mfma_pe<P, E>(st, a);
+        VOX_PM(PRO_COPY, EPI_STORE) VOX_PM(PRO_COPY, EPI_SILU) VOX_PM(PRO_COPY, EPI_SILU_MUL)
+        VOX_PM(PRO_RMSNORM, EPI_STORE) VOX_PM(PRO_RMSNORM, EPI_SILU_MUL)
+#undef VOX_PM
+        return vox_fail(VOX_ERR_INVALID, "linear(mfma): unsupported prologue/epilogue combination");
+    }
 #define VOX_PE(P, E) if (c.pro == P && c.epi == E) return launch_linear_pe<P, E>(st, a, ncu);
     VOX_PE(PRO_COPY, EPI_STORE) VOX_PE(PRO_COPY, EPI_SILU) VOX_PE(PRO_COPY, EPI_SILU_MUL)
     VOX_PE(PRO_RMSNORM, EPI_STORE) VOX_PE(PRO_RMSNORM, EPI_SILU_MUL) VOX_PE(PRO_ATTN, EPI_STORE)

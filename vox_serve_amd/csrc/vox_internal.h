@@ -44,6 +44,7 @@ struct LinearCall {
     float eps = 1e-6f;
     int B = 0, N = 0, K = 0, Hq = 0, D = 0, max_chunks = 0;
     int pro = 0, epi = 0;  // PRO_* / EPI_*
+    int fixed_order = 0;   // 1: keep the fixed-order VALU kernel even above 8 rows (depth step 1 of a <= 8 request frame)
 };
 enum { VOX_PRO_COPY = 0, VOX_PRO_RMSNORM = 1, VOX_PRO_ATTN = 2 };
 enum { VOX_EPI_STORE = 0, VOX_EPI_SILU = 1, VOX_EPI_SILU_MUL = 2 };
