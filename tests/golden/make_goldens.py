@@ -302,7 +302,97 @@ def g4_qwen3_codec(ns):
     print("g4 ok")
 
 
-ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec}
+class FakePlugin:
+    """Deterministic stand-in for a model plugin: exercises only the HOST logic of worker + scheduler."""
+    model_name = "fake"
+    supports_input_streaming = False
+    needs_input_masks = True
+    needs_input_features = True
+    use_repetition_penalty = False
+    supports_audio_input = False
+    needs_watermarking = False
+    detokenize_interval = 4
+    detokenize_overlap = 0
+    n_codebooks = 3
+
+    def __init__(self, PreprocessOutput):
+        self.PO = PreprocessOutput
+
+    def preprocess(self, prompt=None, audio_path=None, **kw):
+        n = int(prompt)
+        toks = torch.arange(n * 3, dtype=torch.long).view(n, 3)
+        return self.PO(input_tokens=toks, input_masks=torch.ones(n, 3, dtype=torch.bool),
+                       input_features=torch.zeros(n, 8))
+
+    def postprocess(self, token_ids, **kw):
+        b, t, _ = token_ids.shape            # 5 samples per token, value = f(token ids)
+        base = (token_ids[:, :, 0].float() % 97) / 100.0 - 0.4
+        return base.repeat_interleave(5, dim=1)[:, None, :]
+
+
+def g6_host_traces(ns):
+    """Scripted arrivals through the reference's own prepare_lm_inputs / _select_* / run_detokenize / free_kv_cache."""
+    import hashlib
+    import logging
+    torch.cuda.synchronize = lambda *a, **k: None
+    from vox_serve.model.base import PreprocessOutput
+    from vox_serve.scheduler.base import Scheduler
+    MW, R = ns.ModelWorker, ns.requests.Request
+    w = MW.__new__(MW)
+    w.model, w.device, w.detokenizer_device, w.page_size, w.max_batch_size = FakePlugin(PreprocessOutput), "cpu", "cpu", 4, 8
+    w.empty_pages = queue.Queue()
+    for i in range(12):
+        w.empty_pages.put(i)
+    w.needs_watermarking, w.logger, w.nvtx_enabled = False, logging.getLogger("g6"), False
+    s = Scheduler.__new__(Scheduler)
+    s.model_worker, s.max_batch_size, s.active_requests = w, 8, []
+    arrivals = {0: [("A", 6)], 1: [("B", 3)], 4: [("C", 9)]}
+    finish_after = {"A": 9, "B": 5, "C": 6}        # frames until "EOS"
+    trace = []
+    for step in range(24):
+        for rid, n in arrivals.get(step, []):
+            s.active_requests.append(R(request_id=rid, prompt=str(n)))
+        s.active_requests = [r for r in s.active_requests if not r.done_all]
+        detok = s._select_detokenize_requests()
+        lm = s._select_lm_requests()
+        li = w.prepare_lm_inputs(lm, detok)
+        w.run_detokenize(detok)
+        rec = {"step": step, "detok": [(r.request_id, list(r.audio_decode_idx)) for r in detok],
+               "lm": [r.request_id for r in lm], "pcm": []}
+        for r in detok:
+            while not r.output_audio.empty():
+                b = r.output_audio.get()
+                rec["pcm"].append((r.request_id, len(b), hashlib.sha256(b).hexdigest()[:16]))
+            if r.done_all:
+                w.free_kv_cache(r)
+        if li is not None:
+            rec.update(qo=li["qo_indptr"], indptr=li["paged_kv_indptr"], indices=li["paged_kv_indices"],
+                       last=li["paged_kv_last_page_len"], pos=li["position_ids"].tolist(), is_prefill=li["is_prefill"],
+                       n_rows=int(li["input_ids"].shape[0]))
+        for r in lm:      # stand-in for the LM: one frame per selected request
+            k = len(r.lm_output_tokens)
+            row = torch.tensor([[100 * (ord(r.request_id) - 64) + k, k, 7]], dtype=torch.long)
+            r.input_tokens, r.input_masks, r.input_features = row, torch.ones(1, 3, dtype=torch.bool), torch.zeros(1, 8)
+            r.lm_output_tokens.append(row)
+            if k + 1 >= finish_after[r.request_id]:
+                r.done_lm_generation, r.finish_reason = True, "stop_id_encountered"
+            else:
+                r.lm_output_audio_tokens.append(row)
+        rec["pages"] = {r.request_id: list(r.kv_pages or []) for r in s.active_requests}
+        rec["done"] = [r.request_id for r in s.active_requests if r.done_all]
+        trace.append(rec)
+        if step > 6 and not [r for r in s.active_requests if not r.done_all]:
+            break
+    free = []
+    while not w.empty_pages.empty():
+        free.append(w.empty_pages.get())
+    import json
+    with open(os.path.join(HERE, "g6_host_traces.json"), "w") as f:
+        json.dump({"trace": trace, "free_pages_after": free}, f, indent=0)
+    print("g6 ok", len(trace), "steps; pcm chunks", sum(len(t["pcm"]) for t in trace))
+
+
+ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces}
 
 if __name__ == "__main__":
     ns = H.boot()

@@ -1,0 +1,240 @@
+"""CPU tests of the host side: worker bookkeeping + scheduler policy against traces captured from the reference's own
+ModelWorker / Scheduler (tests/golden/g6_host_traces.json), the wire format, the C-ABI export table, the DP pool over
+gloo (world_size 2), DecoderCache semantics and the Qwen3 prompt layout."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakePlugin:
+    model_name = "fake"
+    supports_input_streaming = False
+    needs_input_masks = True
+    needs_input_features = True
+    use_repetition_penalty = False
+    supports_audio_input = False
+    needs_watermarking = False
+    has_depth_transformer = False
+    detokenize_interval = 4
+    detokenize_overlap = 0
+    n_codebooks = 3
+
+    def preprocess(self, prompt=None, audio_path=None, **kw):
+        from vox_serve_amd.model.base import PreprocessOutput
+        n = int(prompt)
+        return PreprocessOutput(input_tokens=torch.arange(n * 3, dtype=torch.long).view(n, 3),
+                                input_masks=torch.ones(n, 3, dtype=torch.bool), input_features=torch.zeros(n, 8))
+
+    def postprocess(self, token_ids, **kw):
+        base = (token_ids[:, :, 0].float() % 97) / 100.0 - 0.4
+        return base.repeat_interleave(5, dim=1)[:, None, :]
+
+
+def test_worker_and_scheduler_replay_reference_trace():
+    from vox_serve_amd.requests import Request
+    from vox_serve_amd.scheduler import Scheduler
+    from vox_serve_amd.worker import ModelWorker
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "g6_host_traces.json")))
+    w = ModelWorker(model=FakePlugin(), max_batch_size=8, max_num_pages=12, page_size=4, device="cpu")
+    s = Scheduler(w, max_batch_size=8)
+    arrivals = {0: [("A", 6)], 1: [("B", 3)], 4: [("C", 9)]}
+    finish_after = {"A": 9, "B": 5, "C": 6}
+    for rec in g["trace"]:
+        step = rec["step"]
+        for rid, n in arrivals.get(step, []):
+            s.active_requests.append(Request(request_id=rid, prompt=str(n)))
+        s.active_requests = [r for r in s.active_requests if not r.done_all]
+        detok = s._select_detokenize_requests()
+        lm = s._select_lm_requests()
+        li = w.prepare_lm_inputs(lm, detok)
+        w.run_detokenize(detok)
+        assert [[r.request_id, list(r.audio_decode_idx)] for r in detok] == rec["detok"], step
+        assert [r.request_id for r in lm] == rec["lm"], step
+        pcm = []
+        for r in detok:
+            while not r.output_audio.empty():
+                b = r.output_audio.get()
+                pcm.append([r.request_id, len(b), hashlib.sha256(b).hexdigest()[:16]])
+            if r.done_all:
+                w.free_kv_cache(r)
+        assert pcm == rec["pcm"], step                     # padding rule, trim length and PCM16 truncation
+        if li is not None:
+            for k, gk in (("qo_indptr", "qo"), ("paged_kv_indptr", "indptr"), ("paged_kv_indices", "indices"),
+                          ("paged_kv_last_page_len", "last")):
+                assert li[k] == rec[gk], (step, k)
+            assert li["position_ids"].tolist() == rec["pos"] and li["is_prefill"] == rec["is_prefill"]
+            assert int(li["input_ids"].shape[0]) == rec["n_rows"]
+        else:
+            assert "qo" not in rec
+        for r in lm:
+            k = len(r.lm_output_tokens)
+            row = torch.tensor([[100 * (ord(r.request_id) - 64) + k, k, 7]], dtype=torch.long)
+            r.input_tokens, r.input_masks, r.input_features = row, torch.ones(1, 3, dtype=torch.bool), torch.zeros(1, 8)
+            r.lm_output_tokens.append(row)
+            if k + 1 >= finish_after[r.request_id]:
+                r.done_lm_generation, r.finish_reason = True, "stop_id_encountered"
+            else:
+                r.lm_output_audio_tokens.append(row)
+        assert {r.request_id: list(r.kv_pages or []) for r in s.active_requests} == rec["pages"], step
+        assert [r.request_id for r in s.active_requests if r.done_all] == rec["done"], step
+    free = []
+    while not w.empty_pages.empty():
+        free.append(w.empty_pages.get())
+    assert free == g["free_pages_after"]                   # FIFO free list order after all frees
+
+
+def test_wire_format_and_full_loop_with_fake_lm():
+    from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
+    from vox_serve_amd.worker import ModelWorker
+
+    class W(ModelWorker):
+        def run_lm_prefill(self, reqs, li):
+            self._fake(reqs)
+
+        def run_lm_decode(self, reqs, li):
+            self._fake(reqs)
+
+        def _fake(self, reqs):
+            for r in reqs:
+                k = len(r.lm_output_tokens)
+                row = torch.tensor([[k + 1, k, 7]], dtype=torch.long)
+                r.input_tokens, r.input_masks, r.input_features = row, torch.ones(1, 3, dtype=torch.bool), torch.zeros(1, 8)
+                r.lm_output_tokens.append(row)
+                if k + 1 >= 6:
+                    r.done_lm_generation, r.finish_reason = True, "stop_id_encountered"
+                else:
+                    r.lm_output_audio_tokens.append(row)
+    t = QueueTransport()
+    s = Scheduler(W(model=FakePlugin(), max_num_pages=16, page_size=4, device="cpu"), transport=t)
+    t.requests.put(encode_request("r1", "5"))
+    t.requests.put(b"garbage-without-delimiter")
+    t.requests.put(encode_request("r2", "2", is_streaming=False))
+    s.run_until_idle(200)
+    msgs = []
+    while not t.results.empty():
+        msgs.append(t.results.get())
+    for rid in (b"r1", b"r2"):
+        mine = [m for m in msgs if m.startswith(rid + b"|")]
+        assert mine[-1].startswith(rid + b"|COMPLETION|")
+        assert json.loads(mine[-1].split(b"|", 2)[2]) == {"status": "completed", "reason": "stop_id_encountered"}
+        audio = b"".join(m.split(b"|", 2)[2] for m in mine[:-1])
+        # 5 audio frames: one full chunk of 4 (20 samples) + a padded chunk of 1 trimmed to int(20*(1-0.5)/4)=2 samples
+        assert len(audio) == 2 * (20 + 2)
+    assert s.model_worker.empty_pages.qsize() == 16      # every page returned
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "voxhip.h")).read()
+    declared = set(re.findall(r"\b(vox_[a-z0-9_]+)\s*\(", hdr))
+    so = os.path.join(ROOT, "vox_serve_amd", "libvoxhip.so")
+    if not os.path.exists(so):
+        from vox_serve_amd import build
+        build.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    exported = set(re.findall(r"\bT (vox_[a-z0-9_]+)", out))
+    assert declared and declared <= exported, sorted(declared - exported)
+    import ctypes
+    L = ctypes.CDLL(so)                 # loads without a GPU; no compute entry point is called here
+    assert L.vox_abi_version() == 1
+    from vox_serve_amd import _native
+    assert set(_native._SIGS) <= exported
+
+
+def test_product_never_imports_the_oracle():
+    for dp, _, files in os.walk(os.path.join(ROOT, "vox_serve_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b|libvoxref|voxref\.h|import_module\(.oracle", txt, re.M), f
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vox_serve_amd import _native as N
+    with pytest.raises(N.VoxError):
+        N.ctx()
+
+
+def test_decoder_cache_ops():
+    from vox_serve_amd.tokenizer.qwen3_codec import Qwen3TTSDecoderCache as C
+    a, b = C(slot=torch.tensor([3], dtype=torch.int32)), C(slot=torch.tensor([5], dtype=torch.int32))
+    cat = C.cat([a, b])
+    assert cat.slot.tolist() == [3, 5] and cat[1:].slot.tolist() == [5]
+    a.copy_from(b)
+    assert a.slot.tolist() == [5]
+    with pytest.raises(ValueError):
+        C.cat([])
+
+
+def test_qwen3_prompt_layout_matches_reference_rules():
+    """custom-voice layout: 3 role + codec prefix (3, or 4 with a language id) + speaker + tts_bos + P text + tts_eos +
+    (tts_pad, codec_bos)  (qwen3_tts.py:1617-1626, 1640-1778): 64 text tokens with a language id -> 75 rows."""
+    from vox_serve_amd.model.qwen3_tts import Qwen3TTSModel, Qwen3TTSTokens
+    m = Qwen3TTSModel.__new__(Qwen3TTSModel)
+    m.tokens, m.tts_model_type = Qwen3TTSTokens(spk_id={"vivian": 3066}), "custom_voice"
+    from vox_serve_amd.engine import Qwen3Cfg
+    m.config = Qwen3Cfg()
+    P = 64
+    ids = [11, 12, 13] + list(range(1000, 1000 + P)) + [21, 22, 23, 24, 25]
+    toks, masks = m.layout(ids, language="english", speaker="Vivian")
+    t = m.tokens
+    assert toks.shape == (P + 11, 17)
+    assert toks[:3, -1].tolist() == [11, 12, 13] and not masks[:3, -1].any()
+    assert toks[3:7, 0].tolist() == [t.codec_think, t.codec_think_bos, 2050, t.codec_think_eos]
+    assert toks[3:8, -1].tolist() == [t.tts_pad] * 5 and toks[7, 0] == 3066
+    assert (toks[8, -1], toks[8, 0]) == (t.tts_bos, t.codec_pad)
+    assert toks[9:9 + P, -1].tolist() == list(range(1000, 1000 + P)) and (toks[9:9 + P, 0] == t.codec_pad).all()
+    assert (toks[-2, -1], toks[-2, 0]) == (t.tts_eos, t.codec_pad) and (toks[-1, -1], toks[-1, 0]) == (t.tts_pad, t.codec_bos)
+    assert masks[3:, -1].all()
+    toks2, _ = m.layout(ids, language="auto", speaker="vivian")
+    assert toks2.shape[0] == P + 10 and toks2[3:6, 0].tolist() == [t.codec_nothink, t.codec_think_bos, t.codec_think_eos]
+
+
+def test_registry_errors():
+    from vox_serve_amd.model import load_model
+    with pytest.raises(ValueError):
+        load_model("no-such-model", device="cpu")
+
+
+DP_SCRIPT = r"""
+import os, sys, hashlib, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from vox_serve_amd.worker.dp_pool import broadcast_weights, run_sharded, route
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = torch.Generator().manual_seed(0)
+ref = {"a": torch.randn(1000, generator=g), "b": torch.randn(37, 5, generator=g).to(torch.bfloat16), "c": torch.randn(3, generator=g)}
+w = {k: (v.clone() if rank == 0 else torch.zeros_like(v)) for k, v in ref.items()}
+broadcast_weights(w, src=0, bucket_bytes=1024)
+assert all(torch.equal(w[k], ref[k]) for k in ref), "weight broadcast"
+reqs = [f"req{i}" for i in range(7)]
+def serve(mine):           # stand-in for scheduler+worker: output depends only on the request, as in real DP
+    return {r: hashlib.sha256((r + "|" + "".join(f"{float(x):.6f}" for x in w["c"])).encode()).digest() for r in mine}
+out = run_sharded(reqs, serve)
+if rank == 0:
+    single = serve(reqs)
+    assert out == single, "DP-N output for request i must equal the single-process output"
+    assert [route(i, world) for i in range(4)] == [0, 1, 0, 1]
+    print("DP_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_dp_pool_two_ranks_gloo(tmp_path):
+    script = tmp_path / "dp.py"
+    script.write_text(DP_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0 and "DP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -1,0 +1,63 @@
+"""Model registry (drop-in for /root/reference/vox_serve/model/__init__.py:17-179): MODEL_REGISTRY, register_model,
+load_model.  Checkpoints come from a local directory of safetensors (no network on the serving box); sampling
+overrides replace the model defaults field by field like the reference (model/__init__.py:132-156)."""
+import glob
+import os
+from typing import Callable, Dict
+
+from ..sampling import SamplingConfig
+from .base import BaseLM, BaseLMWithDepth, PreprocessOutput  # noqa: F401
+
+MODEL_REGISTRY: Dict[str, Callable] = {}
+
+
+def register_model(*names):
+    def deco(fn):
+        for n in names:
+            MODEL_REGISTRY[n] = fn
+        return fn
+    return deco
+
+
+def _load_safetensors_dir(path, device):
+    from safetensors.torch import load_file
+    sd = {}
+    for f in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
+        sd.update(load_file(f, device=str(device)))
+    return sd
+
+
+@register_model("qwen3-tts", "Qwen/Qwen3-TTS-12Hz-1.7B-CustomVoice", "qwen3-tts-voice-design",
+                "Qwen/Qwen3-TTS-12Hz-1.7B-VoiceDesign")
+def _qwen3(model_name, device="cuda:0", weights=None, codec_weights=None, checkpoint_dir=None, codec_checkpoint_dir=None,
+           synthetic=False, **kw):
+    from .qwen3_tts import Qwen3TTSModel
+    if weights is None:
+        if synthetic or checkpoint_dir is None:
+            if not synthetic:
+                raise FileNotFoundError("no checkpoint_dir given (offline box): pass checkpoint_dir=... or synthetic=True")
+            from ..engine import Qwen3Cfg
+            from ..synth import synth_qwen3_codec_weights, synth_qwen3_weights
+            weights, codec_weights = synth_qwen3_weights(Qwen3Cfg(), device), synth_qwen3_codec_weights()
+        else:
+            weights = _load_safetensors_dir(checkpoint_dir, device)
+            codec_weights = {k.removeprefix("decoder."): v for k, v in
+                             _load_safetensors_dir(codec_checkpoint_dir or checkpoint_dir, "cpu").items()}
+    mtype = "voice_design" if "design" in model_name.lower() else "custom_voice"
+    return Qwen3TTSModel(model_name, weights, codec_weights, device=device, tts_model_type=mtype, **kw)
+
+
+def load_model(model_name: str, device: str = "cuda", top_p=None, top_k=None, min_p=None, temperature=None,
+               max_tokens=None, repetition_penalty=None, repetition_window=None, cfg_scale=None, greedy=False,
+               enable_torch_compile=False, audio_decoder_device=None, detokenize_interval=None, **kw):
+    if model_name not in MODEL_REGISTRY:
+        raise ValueError(f"Model {model_name} not supported. Supported models are: {sorted(MODEL_REGISTRY)}")
+    m = MODEL_REGISTRY[model_name](model_name, device=device, audio_decoder_device=audio_decoder_device,
+                                   detokenize_interval=detokenize_interval, **kw)
+    overrides = dict(top_p=top_p, top_k=top_k, min_p=min_p, temperature=temperature, max_tokens=max_tokens,
+                     repetition_penalty=repetition_penalty, repetition_window=repetition_window, cfg_scale=cfg_scale)
+    if greedy or any(v is not None for v in overrides.values()):      # per-field override (model/__init__.py:132-156)
+        cur = m.default_sampling_config
+        m.default_sampling_config = SamplingConfig(greedy=greedy, **{k: (v if v is not None else getattr(cur, k))
+                                                                     for k, v in overrides.items()})
+    return m

@@ -1,0 +1,186 @@
+"""Continuous-batching scheduler — policy and wire format of /root/reference/vox_serve/scheduler/base.py:
+  _step                         :135-165   detokenize-select -> lm-select -> prepare -> detokenize -> send -> prefill|decode
+  _select_lm_requests           :234-300   at most ONE new prefill per step, piggy-backed by <= 7 decode rows; else all decodes
+  _select_detokenize_requests   :302-333
+  _send_responses               :335-363   `id|AUDIO|<pcm16le>` and `id|COMPLETION|{json}`
+  _handle_request_payload       :404-429   `{json}|audio_data_placeholder`
+The transport is pluggable: ZeroMQ PUSH/PULL over ipc:// exactly like the reference when pyzmq is installed
+(scheduler/base.py:103-125), in-process queues otherwise (tests, benchmarks).
+"""
+import json
+import logging
+import queue
+import time
+from typing import List, Optional
+
+from ..requests import Request
+
+
+class QueueTransport:
+    """In-process stand-in for the two ZeroMQ sockets (same non-blocking recv / send semantics)."""
+
+    def __init__(self):
+        self.requests, self.results = queue.Queue(), queue.Queue()
+
+    def recv_request(self) -> Optional[bytes]:
+        try:
+            return self.requests.get_nowait()
+        except queue.Empty:
+            return None
+
+    def send_result(self, payload: bytes):
+        self.results.put(payload)
+
+
+class ZmqTransport:
+    def __init__(self, request_socket_path="/tmp/vox_serve_request.ipc", result_socket_path="/tmp/vox_serve_result.ipc"):
+        import zmq
+        self.zmq = zmq
+        ctx = zmq.Context()
+        self.request_socket = ctx.socket(zmq.PULL)
+        self.request_socket.setsockopt(zmq.RCVHWM, 256)
+        self.request_socket.bind(f"ipc://{request_socket_path}")
+        self.result_socket = ctx.socket(zmq.PUSH)
+        self.result_socket.setsockopt(zmq.SNDHWM, 1024)
+        self.result_socket.setsockopt(zmq.LINGER, 0)
+        self.result_socket.connect(f"ipc://{result_socket_path}")
+
+    def recv_request(self):
+        try:
+            return self.request_socket.recv(flags=self.zmq.NOBLOCK)
+        except self.zmq.Again:
+            return None
+
+    def send_result(self, payload: bytes):
+        self.result_socket.send(payload)
+
+
+class Scheduler:
+    def __init__(self, model_worker, max_batch_size: int = 8, transport=None, async_scheduling: bool = False, **kwargs):
+        self.model_worker = model_worker
+        self.max_batch_size = max_batch_size
+        self.transport = transport or QueueTransport()
+        self.async_scheduling = async_scheduling
+        self.active_requests: List[Request] = []
+        self.logger = logging.getLogger(__name__)
+        self.available_batch_sizes = model_worker.available_batch_sizes
+        self.sample_rate, self.bytes_per_sample, self.channels = 24000, 2, 1
+
+    # ---- one iteration of the hot loop ----
+    def _step(self):
+        self._prepare_requests()
+        detokenize_requests = self._select_detokenize_requests()
+        lm_requests = self._select_lm_requests()
+        lm_inputs = self.model_worker.prepare_lm_inputs(lm_requests, detokenize_requests)
+        self.model_worker.run_detokenize(detokenize_requests)
+        self._send_responses(detokenize_requests)
+        if lm_inputs is not None and lm_inputs["is_prefill"]:
+            self.model_worker.run_lm_prefill(lm_requests, lm_inputs)
+        else:
+            self.model_worker.run_lm_decode(lm_requests, lm_inputs)
+
+    def run_forever(self):
+        while True:
+            self._step()
+
+    def run_until_idle(self, max_steps: int = 100000):
+        for _ in range(max_steps):
+            self._step()
+            if not self.active_requests and self.transport.requests.empty():
+                return
+
+    # ---- selection policies ----
+    def _select_lm_requests(self):
+        lm_requests = []
+        max_prefill_batch_size = getattr(self.model_worker, "prefill_graph_batch_size", self.max_batch_size)
+        max_seq_len = max(getattr(self.model_worker, "cuda_graph_seq_len_buckets", [1024]))
+        prefill_requests, decode_requests = [], []
+        for req in self.active_requests:
+            if req.done_lm_generation:
+                continue
+            (decode_requests if req.done_lm_prefill else prefill_requests).append(req)
+        if prefill_requests:
+            current_batch_size, current_seq_len = 0, 0
+            for req in prefill_requests:
+                req_seq_len = req.input_length if req.input_length else 0
+                if current_batch_size + 1 <= max_prefill_batch_size and current_seq_len + req_seq_len <= max_seq_len:
+                    lm_requests.append(req)
+                    current_batch_size += 1
+                    current_seq_len += req_seq_len
+                    if current_batch_size >= max_prefill_batch_size:
+                        break
+                break      # allow only one prefill request for now (scheduler/base.py:281-282)
+            remaining_slots = max_prefill_batch_size - len(lm_requests)
+        else:
+            remaining_slots = self.max_batch_size
+        for i in range(remaining_slots):
+            if len(lm_requests) >= self.max_batch_size or i >= len(decode_requests):
+                break
+            lm_requests.append(decode_requests[i])
+        return lm_requests
+
+    def _select_detokenize_requests(self):
+        out = []
+        interval = self.model_worker.detokenize_interval
+        step = interval - self.model_worker.detokenize_overlap
+        for req in self.active_requests:
+            if len(out) >= self.max_batch_size:
+                break
+            nxt = req.next_audio_decode_idx[-1] + step if req.next_audio_decode_idx else 0
+            if req.done_lm_generation:
+                if nxt < len(req.lm_output_audio_tokens):
+                    req.next_audio_decode_idx = [nxt]
+                else:
+                    req.done_all = True
+                out.append(req)
+            elif nxt + interval <= len(req.lm_output_audio_tokens):
+                req.next_audio_decode_idx = [nxt]
+                out.append(req)
+        return out
+
+    # ---- wire format ----
+    def _send_responses(self, detokenize_requests):
+        for req in detokenize_requests:
+            while not req.output_audio.empty():
+                chunk = req.output_audio.get()
+                if req.is_streaming:
+                    req.chunk_send_timestamps.append(time.time())
+                    req.chunk_durations.append(self._calculate_chunk_duration(chunk))
+                self.transport.send_result(req.request_id.encode("utf-8") + b"|AUDIO|" + chunk)
+            if req.done_all:
+                self.model_worker.free_kv_cache(req)
+                msg = {"status": "completed", "reason": req.finish_reason or "unknown"}
+                self.transport.send_result(req.request_id.encode("utf-8") + b"|COMPLETION|" + json.dumps(msg).encode("utf-8"))
+
+    def _calculate_chunk_duration(self, audio_chunk: bytes) -> float:
+        return len(audio_chunk) // (self.channels * self.bytes_per_sample) / self.sample_rate
+
+    def _handle_request_payload(self, message_payload: bytes):
+        pos = message_payload.find(b"|")
+        if pos == -1:
+            self.logger.warning(f"Received malformed audio message: {message_payload[:50]}...")
+            return None
+        d = json.loads(message_payload[:pos].decode("utf-8"))
+        return Request(request_id=d["request_id"], prompt=d["prompt"],
+                       audio_path=d.get("audio_path") if self.model_worker.supports_audio_input else None,
+                       is_streaming=d.get("is_streaming", False), is_pressing=d.get("is_streaming", False),
+                       model_kwargs=d.get("model_kwargs", {}))
+
+    def _prepare_requests(self):
+        while True:
+            payload = self.transport.recv_request()
+            if payload is None:
+                break
+            try:
+                req = self._handle_request_payload(payload)
+                if req:
+                    self.active_requests.append(req)
+            except Exception as e:          # malformed request: log and keep serving (scheduler/base.py:444-449)
+                self.logger.error(f"Error receiving requests: {e}")
+        self.active_requests = [r for r in self.active_requests if not r.done_all]
+
+
+def encode_request(request_id: str, prompt: str, is_streaming=True, model_kwargs=None, audio_path=None) -> bytes:
+    """Client side of the wire format (launch.py:522-531)."""
+    return json.dumps({"request_id": request_id, "prompt": prompt, "audio_path": audio_path, "is_streaming": is_streaming,
+                       "model_kwargs": model_kwargs or {}}).encode("utf-8") + b"|audio_data_placeholder"

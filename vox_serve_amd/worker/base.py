@@ -1,0 +1,311 @@
+"""ModelWorker — the per-GPU executor the schedulers call (drop-in surface of
+/root/reference/vox_serve/worker/base.py:14-790 and worker/cuda_graph_worker.py:12-1280).
+
+Host bookkeeping follows the reference line by line where it is observable from outside:
+  prepare_lm_inputs   worker/base.py:210-360   FIFO page allocation, page growth, position ids incl. quirk Q1
+  free_kv_cache       worker/base.py:757-771
+  run_detokenize      worker/base.py:616-693 / cuda_graph_worker.py:1162-1280   last-chunk padding by repeating the final
+                      token, trim int(len*(n-0.5)/interval), PCM16 truncation, done_all rule
+  run_lm_prefill / run_lm_decode   cuda_graph_worker.py:806-1160 — but one native call per step: the whole frame (talker,
+                      sampling, 15 depth steps, feedback) is a single hipGraph replay; the python per-request loops of
+                      Qwen3TTSModel.sampling / depth_sampling (qwen3_tts.py:1931-1962, 1995-2002) run once per frame on
+                      one D2H copy of the sampled ids instead of >= 16*B `.item()` synchronisations.
+"""
+import logging
+import queue
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from ..requests import LMInputs, Request
+from ..sampling import native_config
+from ..tokenizer.base import DecoderCache
+
+
+class ModelWorker:
+    def __init__(self, model_name: str = None, max_batch_size: int = 8, max_num_pages: int = 2048, page_size: int = 128,
+                 top_p: float = None, top_k: int = None, min_p: float = None, temperature: float = None,
+                 max_tokens: int = None, repetition_penalty: float = None, repetition_window: int = None,
+                 cfg_scale: float = None, greedy: bool = False, enable_nvtx: bool = False,
+                 enable_torch_compile: bool = False, detokenizer_device: Optional[str] = None, dp_rank: int = 0,
+                 dp_size: int = 1, detokenize_interval: int = None, model=None, device: str = "cuda:0", seed: int = 0):
+        if model is None:
+            from ..model import load_model
+            model = load_model(model_name, device=device, top_p=top_p, top_k=top_k, min_p=min_p, temperature=temperature,
+                               max_tokens=max_tokens, repetition_penalty=repetition_penalty,
+                               repetition_window=repetition_window, cfg_scale=cfg_scale, greedy=greedy,
+                               audio_decoder_device=detokenizer_device, detokenize_interval=detokenize_interval,
+                               max_batch_size=max_batch_size, max_num_pages=max_num_pages, page_size=page_size)
+        self.model = model
+        self.device = device
+        self.detokenizer_device = detokenizer_device or device
+        self.max_batch_size, self.max_num_pages, self.page_size = max_batch_size, max_num_pages, page_size
+        self.dp_rank, self.dp_size = dp_rank, dp_size
+        base = logging.getLogger(__name__)
+        self.logger = logging.LoggerAdapter(base, {}) if dp_size > 1 else base
+        if dp_size > 1:
+            self.logger.process = lambda msg, kw: (f"[DP {dp_rank}/{dp_size}] {msg}", kw)
+        self.nvtx_enabled = enable_nvtx
+        self.seed = seed
+        self.empty_pages = queue.Queue()
+        for i in range(max_num_pages):
+            self.empty_pages.put(i)
+        self.needs_watermarking = getattr(model, "needs_watermarking", False)
+        self.has_depth_transformer = getattr(model, "has_depth_transformer", False)
+        self._resident = None        # request ids whose next inputs already sit in the engine's rows (feedback path)
+        self._next_feats = None
+
+    # ---- properties read by schedulers (scheduler/base.py:127, 243-245) ----
+    detokenize_interval = property(lambda self: self.model.detokenize_interval)
+    detokenize_overlap = property(lambda self: self.model.detokenize_overlap)
+    supports_audio_input = property(lambda self: self.model.supports_audio_input)
+
+    @property
+    def available_batch_sizes(self) -> Optional[List[int]]:
+        return None
+
+    prefill_graph_batch_size = 8                      # cuda_graph_worker.py:62
+    cuda_graph_seq_len_buckets = [1024]               # cuda_graph_worker.py:61
+
+    # -------------------------------------------------------------------------------------------------
+    def prepare_lm_inputs(self, lm_requests: List[Request], detokenize_requests: List[Request]) -> Optional[LMInputs]:
+        for req in detokenize_requests:
+            req.audio_decode_idx = req.next_audio_decode_idx.copy()
+        if len(lm_requests) == 0:
+            return None
+        qo_indptr, paged_kv_indptr, paged_kv_indices, paged_kv_last_page_len = [0], [0], [], []
+        input_ids_list, position_ids_list, feats, masks, reps = [], [], [], [], []
+        is_prefill = any(not req.done_lm_prefill for req in lm_requests)
+        ps = self.page_size
+        for req in lm_requests:
+            if not req.done_lm_prefill:
+                if req.is_input_streaming and not self.model.supports_input_streaming:
+                    raise ValueError(f"Input streaming is not supported by model {self.model.model_name}. "
+                                     f"Only Qwen3-TTS models support input streaming mode.")
+                kw = req.model_kwargs.copy()
+                if req.is_input_streaming:
+                    kw["is_input_streaming"] = True
+                pre = self.model.preprocess(prompt=req.prompt, audio_path=req.audio_path, **kw)
+                req.input_tokens = pre.input_tokens
+                if req.input_tokens is not None:
+                    req.input_length = req.input_tokens.shape[0]
+                if pre.input_features is not None:
+                    req.input_features = pre.input_features
+                if pre.input_masks is not None:
+                    req.input_masks = pre.input_masks
+                if pre.repetition_cache is not None:
+                    req.repetition_cache = pre.repetition_cache
+                if getattr(pre, "decoder_cache", None) is not None:
+                    req.decoder_cache = pre.decoder_cache
+                n = len(req.input_tokens)
+                input_ids_list.append(req.input_tokens)
+                position_ids_list.extend(range(n))
+                feats.append(req.input_features)
+                masks.append(req.input_masks)
+                reps.append(req.repetition_cache)
+                req.kv_token_len = n
+                req.kv_pages = [self.empty_pages.get_nowait() for _ in range((n + ps - 1) // ps)]
+                req.kv_last_page_len = n % ps or ps
+                qo_indptr.append(qo_indptr[-1] + n)
+                req.next_position_id = n + 1          # quirk Q1 (worker/base.py:299)
+                req.done_lm_prefill = True
+            else:
+                if req.is_input_streaming:
+                    self._inject_streaming_text_token(req)
+                input_ids_list.append(req.input_tokens)
+                feats.append(req.input_features)
+                masks.append(req.input_masks)
+                reps.append(req.repetition_cache)
+                req.kv_token_len += 1
+                req.kv_last_page_len += 1
+                if req.kv_last_page_len > ps:
+                    req.kv_pages.append(self.empty_pages.get_nowait())
+                    req.kv_last_page_len = 1
+                qo_indptr.append(qo_indptr[-1] + 1)
+                position_ids_list.append(req.next_position_id)
+                req.next_position_id += 1
+            paged_kv_indptr.append(paged_kv_indptr[-1] + len(req.kv_pages))
+            paged_kv_indices.extend(req.kv_pages)
+            paged_kv_last_page_len.append(req.kv_last_page_len)
+        input_ids = torch.cat([t.to("cpu") for t in input_ids_list], dim=0)
+        position_ids = torch.tensor(position_ids_list, dtype=torch.int32)
+        input_masks = (torch.cat([m.to("cpu") for m in masks if m is not None], dim=0)
+                       if self.model.needs_input_masks and masks else None)
+        input_features = None
+        if self.model.needs_input_features and feats:
+            fl = [f for f in feats if f is not None]
+            dev = next((f.device for f in fl if f.is_cuda), torch.device("cpu"))   # decode rows live on the GPU
+            input_features = torch.cat([f.to(dev) for f in fl], dim=0)
+        repetition_cache = (torch.stack([c for c in reps if c is not None], dim=0)
+                            if self.model.use_repetition_penalty and reps and all(c is not None for c in reps) else None)
+        return {"qo_indptr": qo_indptr, "paged_kv_indptr": paged_kv_indptr, "paged_kv_indices": paged_kv_indices,
+                "paged_kv_last_page_len": paged_kv_last_page_len, "input_ids": input_ids, "position_ids": position_ids,
+                "input_features": input_features, "input_masks": input_masks, "repetition_cache": repetition_cache,
+                "is_prefill": is_prefill}
+
+    def _inject_streaming_text_token(self, req: Request) -> None:
+        """worker/base.py:362-394: next queued text token, then tts_eos once, then tts_pad."""
+        tk = self.model.tokens
+        try:
+            req.input_tokens[0, -1] = req.pending_text_tokens.get_nowait()
+            req.text_token_cursor += 1
+        except queue.Empty:
+            if req.text_complete and not req.eos_injected:
+                req.input_tokens[0, -1] = tk.tts_eos
+                req.eos_injected = True
+            else:
+                req.input_tokens[0, -1] = tk.tts_pad
+        self._resident = None        # the text column changed on the host: restage
+
+    # -------------------------------------------------------------------------------------------------
+    def _sampling(self):
+        return native_config(self.model.default_sampling_config)
+
+    def _token_plan(self, lm_inputs: LMInputs):
+        """Per-row (request, visible kv length, page, slot) exactly as FlashInferPrefillWrapper.plan derives them
+        (flashinfer_utils.py:86-124): rows are right-aligned to the end of their request's KV."""
+        ps = self.page_size
+        qo, ip, idx, last = (lm_inputs[k] for k in ("qo_indptr", "paged_kv_indptr", "paged_kv_indices", "paged_kv_last_page_len"))
+        q_req, kvlen, page, slot = [], [], [], []
+        for r in range(len(last)):
+            m = qo[r + 1] - qo[r]
+            n = (ip[r + 1] - ip[r] - 1) * ps + last[r]
+            for j in range(m):
+                t = n - m + j
+                q_req.append(r); kvlen.append(t + 1); page.append(idx[ip[r] + t // ps]); slot.append(t % ps)
+        return q_req, kvlen, page, slot
+
+    def _stage_features(self, feats, dst):
+        dst[: feats.shape[0]].copy_(feats.to(dst.device, dst.dtype))
+
+    def run_lm_prefill(self, requests: List[Request], lm_inputs: LMInputs):
+        if len(requests) == 0:
+            return None
+        e = self.model.engine
+        n_rows, n_req = int(lm_inputs["input_ids"].shape[0]), len(requests)
+        if n_rows > e.max_rows:
+            raise RuntimeError(f"No suitable prefill graph found for batch_size={n_req}, seq_len={n_rows}")
+        q_req, kvlen, page, slot = self._token_plan(lm_inputs)
+        e.row_ids[:n_rows].copy_(lm_inputs["input_ids"].to(torch.int32))
+        e.row_masks[:n_rows].copy_(lm_inputs["input_masks"][:, -1].to(torch.uint8))
+        self._stage_features(lm_inputs["input_features"], e.row_feats)
+        qo = lm_inputs["qo_indptr"]
+        e.upload_plan(pos=lm_inputs["position_ids"].numpy(), kvlen=kvlen, page=page, slot=slot, q_req=q_req,
+                      last_rows=[q - 1 for q in qo[1:]], indptr=lm_inputs["paged_kv_indptr"],
+                      indices=lm_inputs["paged_kv_indices"])
+        e.prefill(n_rows, n_req, max(kvlen), self._sampling(), seed=self.seed, feedback=True)
+        self._after_frame(requests)
+        return None
+
+    def run_lm_decode(self, requests: List[Request], lm_inputs: LMInputs):
+        if len(requests) == 0:
+            return None
+        e = self.model.engine
+        B = len(requests)
+        ids = [r.request_id for r in requests]
+        if self._resident != ids:        # batch composition changed: restage the per-request inputs
+            e.input_ids[:B].copy_(lm_inputs["input_ids"].to(torch.int32))
+            e.input_masks[:B].copy_(lm_inputs["input_masks"][:, -1].to(torch.uint8))
+            self._stage_features(lm_inputs["input_features"], e.input_features)
+        e.upload_plan(pos=lm_inputs["position_ids"].numpy(), kvlen=[r.kv_token_len for r in requests],
+                      page=[r.kv_pages[-1] for r in requests], slot=[r.kv_last_page_len - 1 for r in requests],
+                      indptr=lm_inputs["paged_kv_indptr"], indices=lm_inputs["paged_kv_indices"])
+        e.frame(B, max(r.kv_token_len for r in requests), self._sampling(), seed=self.seed, feedback=True)
+        self._after_frame(requests)
+        return None
+
+    def _after_frame(self, requests: List[Request]):
+        """The request-state half of Qwen3TTSModel.sampling + depth_sampling (qwen3_tts.py:1931-1962, 1995-2002)."""
+        e, m = self.model.engine, self.model
+        B = len(requests)
+        out = e.out_ids[:B].cpu().to(torch.long)                      # the one synchronisation of the step
+        feats = e.next_features[:B].clone()
+        C = m.n_codebooks
+        pad = m.config.tts_pad_id
+        for i, req in enumerate(requests):
+            row = out[i:i + 1].clone()
+            req.input_tokens = torch.zeros(1, C, dtype=torch.long)
+            req.input_tokens[0, 0] = row[0, 0]
+            if not getattr(req, "is_input_streaming", False):
+                req.input_tokens[0, -1] = pad
+            req.input_masks = torch.ones(1, C, dtype=torch.bool)
+            req.input_features = feats[i:i + 1]
+            req.lm_output_tokens.append(row)
+            if not m.is_stop_id(row[0, 0]):
+                req.lm_output_audio_tokens.append(row)
+            else:
+                req.done_lm_generation = True
+                req.finish_reason = "stop_id_encountered"
+        for req in requests:
+            if req.next_position_id > m.max_tokens:
+                req.done_lm_generation = True
+                req.finish_reason = "max_tokens_reached"
+        self._resident = [r.request_id for r in requests]
+
+    # -------------------------------------------------------------------------------------------------
+    def run_detokenize(self, requests: List[Request]):
+        if len(requests) == 0:
+            return
+        interval = self.detokenize_interval
+        token_ids, mapping = [], []
+        for ri, req in enumerate(requests):
+            for ci in range(len(req.audio_decode_idx)):
+                d = req.audio_decode_idx[ci]
+                new = list(req.lm_output_audio_tokens[d: d + interval])
+                if not new:
+                    continue
+                if len(new) < interval:
+                    new.extend([new[-1]] * (interval - len(new)))      # pad by repeating the final token
+                token_ids.append(torch.cat(new, dim=0))
+                mapping.append((ri, ci))
+        if token_ids:
+            batch = torch.stack(token_ids, dim=0)
+            caches = [requests[ri].decoder_cache for ri, _ in mapping]
+            cache = DecoderCache.cat(caches) if all(c is not None for c in caches) else None
+            audio = self.model.postprocess(batch, decoder_cache=cache)
+            if self.needs_watermarking:
+                audio = self.run_watermark(audio)
+            audio_np = audio.detach().float().cpu().numpy()
+            for i, (ri, ci) in enumerate(mapping):
+                req = requests[ri]
+                d = req.audio_decode_idx[ci]
+                a16 = (audio_np[i] * 32767).astype(np.int16)
+                n_last = len(req.lm_output_audio_tokens[d: d + interval])
+                if n_last < interval:
+                    a16 = a16[:, : int(a16.shape[1] * (n_last - 0.5) / interval)]
+                req.output_audio.put(a16.tobytes())
+        for req in requests:
+            if req.done_lm_generation and req.audio_decode_idx and (
+                    req.audio_decode_idx[-1] + interval >= len(req.lm_output_audio_tokens)):
+                req.done_all = True
+
+    def run_watermark(self, audio):
+        return audio          # hook kept (worker/base.py:104-121); Qwen3 needs none
+
+    def nvtx_range_push(self, name: str):
+        if self.nvtx_enabled:
+            torch.cuda.synchronize()
+            torch.cuda.nvtx.range_push(name)      # roctx on ROCm builds of torch
+
+    def nvtx_range_pop(self):
+        if self.nvtx_enabled:
+            torch.cuda.synchronize()
+            torch.cuda.nvtx.range_pop()
+
+    def free_kv_cache(self, request: Request):
+        if getattr(request, "kv_pages", None):
+            for p in request.kv_pages:
+                self.empty_pages.put(p)
+            request.kv_pages = []
+            request.kv_token_len = 0
+            request.kv_last_page_len = 0
+        dc = getattr(request, "decoder_cache", None)
+        if dc is not None and hasattr(self.model, "audio_decoder") and hasattr(self.model.audio_decoder, "release_cache"):
+            self.model.audio_decoder.release_cache(dc)
+            request.decoder_cache = None
+
+
+# The reference's default worker is the graph-capturing subclass; here graph capture lives in the engine.
+CudaGraphWorker = ModelWorker
+HipGraphWorker = ModelWorker
