@@ -139,6 +139,12 @@ typedef struct { /* device int32 arrays describing one ragged forward (FlashInfe
     const int32_t *pos, *q_req, *q_kvlen, *page, *slot, *kv_indptr, *kv_indices;
     int32_t n_rows;
     int32_t max_kvlen; /* grid bound for this call (<= cfg.max_kvlen) */
+    /* optional hints that shorten the dependent-load chain of decode rows (all 0 / NULL = unused): */
+    const int32_t* page_table; /* [n_rows][pt_stride]: page of KV block j of row i (same content as indices/indptr) */
+    int32_t pt_stride;
+    int32_t fixed_kvlen;       /* > 0: every row attends to exactly this many tokens */
+    int32_t fixed_pos;         /* >= 0 with fixed_kvlen: every row's position id */
+    int32_t identity_pages;    /* request r owns the single page r and row i belongs to request i */
 } vox_rows;
 
 /* x [n_rows,hidden] bf16 is updated in place layer by layer; y (may alias x) = final RMSNorm(x).
@@ -173,6 +179,8 @@ typedef struct { /* device buffers owned by the caller (graph-stable addresses) 
     uint8_t* input_masks;    /* [max_batch] (mask of the last column, qwen3_tts.py:1848) */
     void* input_features;    /* [max_batch, H] bf16 */
     int32_t *pos, *kvlen, *page, *slot, *kv_indptr, *kv_indices; /* plan() outputs */
+    int32_t* page_table;     /* optional [max_batch][pt_stride] per-row page table for decode frames (may be NULL) */
+    int64_t pt_stride;
     void* kv;                /* talker KV [layers][P,2,page,Hkv,D] */
     int64_t kv_layer_stride;
     int32_t* out_ids;        /* [max_batch, n_groups+1] sampled frame */

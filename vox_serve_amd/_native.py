@@ -33,7 +33,8 @@ class LayerWeights(Structure):
 
 class Rows(Structure):
     _fields_ = [(n, c_void_p) for n in ("pos", "q_req", "q_kvlen", "page", "slot", "kv_indptr", "kv_indices")] + \
-               [("n_rows", c_int32), ("max_kvlen", c_int32)]
+               [("n_rows", c_int32), ("max_kvlen", c_int32), ("page_table", c_void_p), ("pt_stride", c_int32),
+                ("fixed_kvlen", c_int32), ("fixed_pos", c_int32), ("identity_pages", c_int32)]
 
 
 class Qwen3Config(Structure):
@@ -54,7 +55,8 @@ class Qwen3Weights(Structure):
 class Qwen3IO(Structure):
     _fields_ = [("input_ids", c_void_p), ("input_masks", c_void_p), ("input_features", c_void_p), ("pos", c_void_p),
                 ("kvlen", c_void_p), ("page", c_void_p), ("slot", c_void_p), ("kv_indptr", c_void_p),
-                ("kv_indices", c_void_p), ("kv", c_void_p), ("kv_layer_stride", c_int64), ("out_ids", c_void_p),
+                ("kv_indices", c_void_p), ("page_table", c_void_p), ("pt_stride", c_int64), ("kv", c_void_p),
+                ("kv_layer_stride", c_int64), ("out_ids", c_void_p),
                 ("out_logits", c_void_p), ("out_hidden", c_void_p), ("out_depth_logits", c_void_p),
                 ("next_features", c_void_p), ("rng_offset", c_void_p)]
 

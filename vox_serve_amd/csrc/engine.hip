@@ -242,6 +242,8 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
             ac.qkv = s->qkv; ac.qn = hc.qn; ac.kn = hc.kn; ac.cs = s->rope; ac.pos = r->pos; ac.page = r->page;
             ac.slot = r->slot; ac.eps = c.eps; ac.rot = c.rope_dim; ac.interleave = c.rope_interleave;
             ac.table_max_pos = s->rope_max_pos;
+            ac.ptab = r->page_table; ac.pt_stride = r->pt_stride; ac.identity_pages = r->identity_pages;
+            if (r->fixed_kvlen > 0) { ac.fixed_kvlen = r->fixed_kvlen; ac.fixed_pos = r->fixed_pos; }
         }
         ac.q = s->q; ac.kv = kvl; ac.q_req = r->q_req; ac.q_kvlen = r->q_kvlen; ac.indptr = r->kv_indptr;
         ac.indices = r->kv_indices; ac.part_o = part_o; ac.part_ml = part_ml; ac.scale = scale; ac.Nq = n;
@@ -391,6 +393,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         r.kv_indices = m->iota;
         r.n_rows = rows;
         r.max_kvlen = i + 1;
+        if (i > 1) { r.fixed_kvlen = i + 1; r.fixed_pos = i; r.identity_pages = 1; }
         VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= 8));
         void* dl = io->out_depth_logits ? (void*)((bf16_t*)io->out_depth_logits + (size_t)(i - 1) * c.max_batch * c.depth_vocab)
                                         : m->dlogits;
@@ -530,6 +533,7 @@ int vox_qwen3_frame(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int B, i
     vox_rows r{};
     r.pos = io->pos; r.q_req = m->iota; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
     r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = B; r.max_kvlen = max_kvlen;
+    r.page_table = io->page_table; r.pt_stride = (int32_t)io->pt_stride;
     VOX_TRY(stack_layers(m->talker, st, m->x, io->kv, io->kv_layer_stride, &r, true));
     VOX_TRY(qwen3_head(m, st, io, B, nullptr));
     return qwen3_tail(m, st, io, B, sc, seed, feedback);

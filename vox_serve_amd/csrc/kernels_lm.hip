@@ -139,6 +139,16 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
 
     // The first group of weight chunks is requested BEFORE the activation prologue: weights do not depend on
     // x, so their HBM latency overlaps the norm / merge work and the barrier.
+    // epilogue operands (residual, bias) of the first batch tile are requested up front as well: lane o*BT+b owns output
+    // (o, b); reading them only in the epilogue would add one more dependent HBM/L2 round trip to every kernel.
+    float res_pre = 0.0f, bias_pre = 0.0f;
+    {
+        const int po = lane / BT, pb = lane % BT;
+        if (EPI != EPI_SILU_MUL && lane < OUT * BT && pb < a.B && n0 + po < a.N) {
+            if (a.residual) res_pre = bf2f(a.residual[(size_t)pb * a.N + n0 + po]);
+            if (a.bias) bias_pre = bf2f(a.bias[n0 + po]);
+        }
+    }
     // RMSNorm prologue fast path: the activation row this wave normalises (row `wave` of tile 0) is requested
     // first, so it is not queued behind the weight stream (vmcnt retires in order).
     constexpr int XC = 4;
@@ -231,10 +241,10 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
                         r = f2bf(bfround(silu_c(g)) * u);
                     } else {
                         float v = acc[o][b];
-                        if (a.bias) v = v + bf2f(a.bias[n]);
+                        if (a.bias) v = v + (b0 == 0 ? bias_pre : bf2f(a.bias[n]));
                         r = f2bf(v);
                         if (EPI == EPI_SILU) r = f2bf(silu_c(bf2f(r)));
-                        if (a.residual) r = f2bf(bf2f(a.residual[oi]) + bf2f(r));
+                        if (a.residual) r = f2bf((b0 == 0 ? res_pre : bf2f(a.residual[oi])) + bf2f(r));
                     }
                     a.y[oi] = r;
                 }
@@ -628,6 +638,12 @@ struct AttnArgs {
     const int *pos, *page, *slot;
     float eps;
     int rot, interleave, table_max_pos;
+    // shortcuts that cut the dependent-load chain in front of the K/V tile loads:
+    const int* ptab;     // optional per-row page table [rows][pt_stride] (else indices[indptr[q_req[row]] + j])
+    int pt_stride;
+    int fixed_kvlen;     // > 0: every row sees exactly this many tokens (depth loop: known on the host)
+    int fixed_pos;       // >= 0: every row's RoPE position
+    int identity_pages;  // 1: request r owns the single page r and q_req[row] == row (depth loop)
     bf16_t* out;   // single-chunk launches write the final bf16 output here (merge of one chunk == o/l)
 };
 
@@ -686,13 +702,14 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Knew[FUSED ? D : 8];
 
     const int c = blockIdx.x, hk = blockIdx.y, row = blockIdx.z;
-    const int L = a.q_kvlen[row];
+    const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
     const int t0 = c * VOX_TC;
     if (t0 >= L) return;
     const int nt = (L - t0) < VOX_TC ? (L - t0) : VOX_TC;
     const int G = a.Hq / a.Hkv;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int* pages = a.indices + a.indptr[a.q_req[row]];
+    const int* pages = a.identity_pages ? nullptr
+                       : (a.ptab ? a.ptab + (size_t)row * a.pt_stride : a.indices + a.indptr[a.q_req[row]]);
     const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
     const bool own_last = FUSED && (t0 + nt == L);   // this chunk holds the row's newest token (index L-1)
 
@@ -701,8 +718,8 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
         uint4 kx = make_uint4(0, 0, 0, 0), vx = kx;
         if (t < nt && !(own_last && t == nt - 1)) {
             const int tok = t0 + t;
-            const bf16_t* base = a.kv + (size_t)pages[tok / a.page_size] * ps +
-                                 ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
+            const int pgi = pages ? pages[tok / a.page_size] : row;
+            const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
             kx = reinterpret_cast<const uint4*>(base)[j];
             vx = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
         }
@@ -717,7 +734,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
     } else {
         const int nqkv = (a.Hq + 2 * a.Hkv) * D;
         const bf16_t* raw = a.qkv + (size_t)row * nqkv;
-        int p = a.pos[row];
+        int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
         p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
         const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
         // heads 0..G-1: q heads of this kv head; head G: the new k (only where needed)
@@ -733,14 +750,15 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
     if (own_last) {
         // place the new token into the tile and append it to the paged cache (page < 0: graph padding row)
         const bf16_t* vraw = a.qkv + (size_t)row * (a.Hq + 2 * a.Hkv) * D + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D;
-        const int pg = a.page[row];
+        const int pg = a.identity_pages ? row : a.page[row];
+        const int sl = a.identity_pages ? (L - 1) : a.slot[row];
         if (tid < LPT) {
             const uint4 kx = reinterpret_cast<const uint4*>(Knew)[tid];
             const uint4 vx = reinterpret_cast<const uint4*>(vraw)[tid];
             Ks[(nt - 1) * LPT + tid] = kx;
             Vs[(nt - 1) * LPT + tid] = vx;
             if (pg >= 0) {
-                bf16_t* base = a.kv_w + (size_t)pg * ps + ((size_t)a.slot[row] * a.Hkv + hk) * D;
+                bf16_t* base = a.kv_w + (size_t)pg * ps + ((size_t)sl * a.Hkv + hk) * D;
                 reinterpret_cast<uint4*>(base)[tid] = kx;
                 reinterpret_cast<uint4*>(base + (size_t)a.page_size * a.Hkv * D)[tid] = vx;
             }
@@ -804,6 +822,8 @@ int vox_launch_attn_partial(hipStream_t st, const AttnCall& c) {
     a.qkv = (const bf16_t*)c.qkv; a.kv_w = (bf16_t*)const_cast<void*>(c.kv); a.qn = (const bf16_t*)c.qn;
     a.kn = (const bf16_t*)c.kn; a.cs = c.cs; a.pos = c.pos; a.page = c.page; a.slot = c.slot; a.eps = c.eps;
     a.rot = c.rot; a.interleave = c.interleave; a.table_max_pos = c.table_max_pos;
+    a.ptab = c.ptab; a.pt_stride = c.pt_stride; a.fixed_kvlen = c.fixed_kvlen; a.fixed_pos = c.fixed_pos;
+    a.identity_pages = c.identity_pages;
     a.out = nullptr;
     int nchunk = (c.max_kvlen + VOX_TC - 1) / VOX_TC;
     if (nchunk < 1) nchunk = 1;

@@ -76,6 +76,8 @@ struct AttnCall {
     float eps = 1e-6f;
     int rot = 0, interleave = 0, table_max_pos = 0;
     void* out = nullptr;   // bf16 [Nq,Hq,D]: written directly when the launch covers a single chunk
+    const int* ptab = nullptr;
+    int pt_stride = 0, fixed_kvlen = 0, fixed_pos = -1, identity_pages = 0;
 };
 int vox_launch_attn_partial(hipStream_t st, const AttnCall& c);
 int vox_launch_attn_merge(hipStream_t st, const float* part_o, const float* part_ml, const int* kvlen, void* out,

@@ -140,8 +140,9 @@ class Qwen3Engine:
         # [pos R | kvlen R | page R | slot R | q_req R | last_rows B | indptr B+1 | indices max_pages]
         self._plan_layout = {}
         off = 0
+        self.pt_stride = (max_seq_len + page_size - 1) // page_size + 1
         for name, n in (("pos", R), ("kvlen", R), ("page", R), ("slot", R), ("q_req", R), ("last_rows", max_batch),
-                        ("indptr", max_batch + 1), ("indices", max_pages)):
+                        ("indptr", max_batch + 1), ("indices", max_pages), ("ptab", max_batch * self.pt_stride)):
             self._plan_layout[name] = (off, n)
             off += n
         self.plan_dev = torch.zeros(off, **i32)
@@ -191,6 +192,12 @@ class Qwen3Engine:
         for name, a in arrays.items():
             a = np.asarray(a, dtype=np.int32)
             self._ph(name)[: len(a)] = torch.from_numpy(a)
+        if "indptr" in arrays and "indices" in arrays and len(arrays["indptr"]) - 1 <= self.max_batch:
+            ip, ix = np.asarray(arrays["indptr"], dtype=np.int64), np.asarray(arrays["indices"], dtype=np.int32)
+            pt = self._ph("ptab").view(self.max_batch, self.pt_stride)      # per-row page table (decode frames)
+            for b in range(len(ip) - 1):
+                n = min(int(ip[b + 1] - ip[b]), self.pt_stride)
+                pt[b, :n] = torch.from_numpy(ix[ip[b]: ip[b] + n])
         with self._OnStream(self):
             self.plan_dev.copy_(self.plan_host, non_blocking=True)
 
@@ -198,7 +205,7 @@ class Qwen3Engine:
         return N.Qwen3IO(self.input_ids.data_ptr(), self.input_masks.data_ptr(), self.input_features.data_ptr(),
                          self._pd("pos").data_ptr(), self._pd("kvlen").data_ptr(), self._pd("page").data_ptr(),
                          self._pd("slot").data_ptr(), self._pd("indptr").data_ptr(), self._pd("indices").data_ptr(),
-                         self.kv.data_ptr(), self.kv[0].numel(), self.out_ids.data_ptr(), self.out_logits.data_ptr(),
+                         self._pd("ptab").data_ptr(), self.pt_stride, self.kv.data_ptr(), self.kv[0].numel(), self.out_ids.data_ptr(), self.out_logits.data_ptr(),
                          self.out_hidden.data_ptr() if self.keep_hidden else None,
                          self.out_depth_logits.data_ptr() if self.out_depth_logits is not None else None,
                          self.next_features.data_ptr(), self.rng_offset.data_ptr())
