@@ -8,7 +8,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint8, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvoxhip.so")
+LIB_PATH = os.environ.get("VOX_LIB", os.path.join(HERE, "libvoxhip.so"))   # VOX_LIB: development override
 
 
 class VoxError(RuntimeError):

@@ -8,7 +8,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvoxhip.so")
 SOURCES = ["kernels_lm.hip", "sampler.hip", "engine.hip", "codec.hip"]
 # -ffp-contract=off: the numeric contract spells every fused multiply-add as an explicit fmaf
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"] + \
+    os.environ.get("VOX_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():

@@ -309,7 +309,9 @@ __device__ __forceinline__ bf16x8_t as_bf8(uint4 v) {
     return c.b;
 }
 
-template <int MT, int PRO, int EPI>
+// FULL: K % MF_KS == 0 and N % 16 == 0 — every range guard compiles away (at one wave per SIMD the kernel is
+// instruction-issue bound, each guard is a divergent-branch sequence); padded batch rows re-read the last real row.
+template <int MT, int PRO, int EPI, bool FULL>
 __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BT = 16 * MT;
@@ -345,59 +347,96 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
             acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             acc2[m] = acc[m];
         }
-        constexpr int U = 8;
-        uint4 wv[U], wv2[U];
-        // software pipeline: the weight loads of the NEXT group are in flight while x is staged / MFMAs run
-        auto issue = [&](int k0, int s0, int ks) {
+        // Software pipeline over K segments of MF_KS: while segment s is multiplied, the activation chunks of s+1 are
+        // already on their way to registers and, queued BEHIND them (vmcnt retires in order), the weight fragments
+        // of s+1.  One group of U = MF_KS/32/4 fragment loads per wave per segment.
+        constexpr int U = MF_KS / 32 / 4;
+        constexpr int RPW = BT / 4;          // activation rows staged per wave
+        constexpr int CPL = MF_KS / 8 / 64;  // 16-byte chunks per lane per row
+        uint4 wv[U], wv2[U], xv[RPW][CPL], gv[CPL];
+        auto issue_x = [&](int k0, int ks) {
+            const int nch = ks >> 3;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                gv[j] = make_uint4(0, 0, 0, 0);
+                if (PRO == PRO_RMSNORM && (FULL || lane + 64 * j < nch)) gv[j] = reinterpret_cast<const uint4*>(a.nw)[(k0 >> 3) + lane + 64 * j];
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int bb = wave + 4 * r;
+                if (FULL) {
+                    const uint4* xr = x_row_ptr(a, b0 + (bb < bt ? bb : bt - 1)) + (k0 >> 3);
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) xv[r][j] = xr[lane + 64 * j];
+                } else {
+                    const uint4* xr = bb < bt ? x_row_ptr(a, b0 + bb) + (k0 >> 3) : nullptr;
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) {
+                        xv[r][j] = make_uint4(0, 0, 0, 0);
+                        if (xr && lane + 64 * j < nch) xv[r][j] = xr[lane + 64 * j];
+                    }
+                }
+            }
+        };
+        auto issue_w = [&](int k0, int ks) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int kk = s0 + 128 * u;
-                if (kk < ks) {
+                const int kk = 32 * wave + 128 * u;
+                if (FULL || kk < ks) {
                     wv[u] = ldg_nt(reinterpret_cast<const uint4*>(wrow + k0 + kk + fk));
                     if (EPI == EPI_SILU_MUL) wv2[u] = ldg_nt(reinterpret_cast<const uint4*>(wrow2 + k0 + kk + fk));
                 }
             }
         };
-        issue(0, 32 * wave, a.K < MF_KS ? a.K : MF_KS);
+        {
+            const int ks0 = a.K < MF_KS ? a.K : MF_KS;
+            issue_x(0, ks0);
+            issue_w(0, ks0);
+        }
         for (int k0 = 0; k0 < a.K; k0 += MF_KS) {
             const int ks = (a.K - k0) < MF_KS ? (a.K - k0) : MF_KS;
             const int nch = ks >> 3;
-            __syncthreads();
-            for (int i = tid; i < BT * nch; i += 256) {
-                const int b = i / nch, c = i % nch;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (b < bt) {
-                    v = x_row_ptr(a, b0 + b)[(k0 >> 3) + c];
-                    if (PRO == PRO_RMSNORM) {
-                        v = norm_chunk(v, reinterpret_cast<const uint4*>(a.nw)[(k0 >> 3) + c], rinv[b]);
-                        if (a.x_out && blockIdx.x == 0)
-                            reinterpret_cast<uint4*>(a.x_out + (size_t)(b0 + b) * a.x_out_stride)[(k0 >> 3) + c] = v;
+            __syncthreads();   // the previous segment's MFMAs are done with the LDS tile
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int bb = wave + 4 * r;
+                const float ri = PRO == PRO_RMSNORM ? rinv[FULL ? (bb < bt ? bb : bt - 1) : (bb < bt ? bb : 0)] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const int c = lane + 64 * j;
+                    if (FULL || c < nch) {
+                        uint4 o = xv[r][j];
+                        if (PRO == PRO_RMSNORM && (FULL || bb < bt)) {
+                            o = norm_chunk(o, gv[j], ri);
+                            if (a.x_out && blockIdx.x == 0 && bb < bt)
+                                reinterpret_cast<uint4*>(a.x_out + (size_t)(b0 + bb) * a.x_out_stride)[(k0 >> 3) + c] = o;
+                        }
+                        *reinterpret_cast<uint4*>(xs + (size_t)bb * LDK + c * 8) = o;
                     }
                 }
-                *reinterpret_cast<uint4*>(xs + (size_t)b * LDK + c * 8) = v;
             }
             __syncthreads();
-            for (int s0 = 32 * wave; s0 < ks; s0 += 128 * U) {
-                uint4 cw[U], cw2[U];
+            uint4 cw[U], cw2[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    cw[u] = wv[u];
-                    if (EPI == EPI_SILU_MUL) cw2[u] = wv2[u];
-                }
-                // prefetch the following group (same segment, or the first group of the next segment)
-                if (s0 + 128 * U < ks) issue(k0, s0 + 128 * U, ks);
-                else if (k0 + MF_KS < a.K) issue(k0 + MF_KS, 32 * wave, (a.K - k0 - MF_KS) < MF_KS ? (a.K - k0 - MF_KS) : MF_KS);
+            for (int u = 0; u < U; ++u) {
+                cw[u] = wv[u];
+                if (EPI == EPI_SILU_MUL) cw2[u] = wv2[u];
+            }
+            if (k0 + MF_KS < a.K) {
+                const int nks = (a.K - k0 - MF_KS) < MF_KS ? (a.K - k0 - MF_KS) : MF_KS;
+                issue_x(k0 + MF_KS, nks);
+                issue_w(k0 + MF_KS, nks);
+            }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int kk = s0 + 128 * u;
-                    if (kk < ks) {
+            for (int u = 0; u < U; ++u) {
+                const int kk = 32 * wave + 128 * u;
+                if (FULL || kk < ks) {
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            const uint4 xa = *reinterpret_cast<const uint4*>(xs + (size_t)(m * 16 + fr) * LDK + kk + fk);
-                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xa), as_bf8(cw[u]), acc[m], 0, 0, 0);
-                            if (EPI == EPI_SILU_MUL)
-                                acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xa), as_bf8(cw2[u]), acc2[m], 0, 0, 0);
-                        }
+                    for (int m = 0; m < MT; ++m) {
+                        const uint4 xa = *reinterpret_cast<const uint4*>(xs + (size_t)(m * 16 + fr) * LDK + kk + fk);
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xa), as_bf8(cw[u]), acc[m], 0, 0, 0);
+                        if (EPI == EPI_SILU_MUL)
+                            acc2[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xa), as_bf8(cw2[u]), acc2[m], 0, 0, 0);
                     }
                 }
             }
@@ -450,11 +489,11 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
     }
 }
 
-template <int MT, int PRO, int EPI>
+template <int MT, int PRO, int EPI, bool FULL>
 static int launch_linear_mfma_t(hipStream_t st, const LinArgs& a) {
     constexpr int BT = 16 * MT;
     const size_t smem = (size_t)BT * (MF_KS + 8) * 2 + BT * 4;
-    auto kern = k_linear_mfma<MT, PRO, EPI>;
+    auto kern = k_linear_mfma<MT, PRO, EPI, FULL>;
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -468,8 +507,9 @@ static int launch_linear_mfma_t(hipStream_t st, const LinArgs& a) {
 
 template <int PRO, int EPI>
 static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a) {
-    if (a.B <= 16) return launch_linear_mfma_t<1, PRO, EPI>(st, a);
-    return launch_linear_mfma_t<2, PRO, EPI>(st, a);
+    const bool full = (a.K % MF_KS == 0) && (a.N % 16 == 0);
+    if (a.B <= 16) return full ? launch_linear_mfma_t<1, PRO, EPI, true>(st, a) : launch_linear_mfma_t<1, PRO, EPI, false>(st, a);
+    return full ? launch_linear_mfma_t<2, PRO, EPI, true>(st, a) : launch_linear_mfma_t<2, PRO, EPI, false>(st, a);
 }
 
 int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
