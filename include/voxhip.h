@@ -205,6 +205,45 @@ int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const 
                       const int32_t* last_rows, int n_req, int max_kvlen, const vox_sampling_config* sampling,
                       uint64_t seed, int feedback);
 
+/* ---- single-stack speech LM engine (GLM-4-Voice, CosyVoice2 LLM, Orpheus-style families) ------------------
+ * replaces <Family>Model.forward + sampling (model/glm_voice.py:517-590, model/cosyvoice2.py:1008-1090) and
+ * the decode/prefill graph replays of CudaGraphWorker (worker/cuda_graph_worker.py:806-1056).                */
+typedef struct vox_lm vox_lm;
+typedef struct {
+    vox_stack_config stack;
+    int32_t vocab_in, vocab_out;
+    int32_t ids_stride;   /* columns of input_ids (n_codebooks); column 0 is embedded */
+    int32_t input_mode;   /* 0: x = embedding[id];  1: x = mask ? input_features : embedding[clamp(id)] (cosyvoice2.py:1020-1024) */
+    int32_t max_batch;
+} vox_lm_config;
+typedef struct {
+    const vox_layer_weights* layers;
+    const void *final_norm, *embedding /*[vocab_in,H]*/, *head_w /*[vocab_out,H]*/, *head_b /*[vocab_out] or NULL*/;
+    const float* rope;
+    int32_t rope_max_pos;
+} vox_lm_weights;
+typedef struct {
+    int32_t* input_ids;      /* [max_batch, ids_stride] */
+    uint8_t* input_masks;    /* [max_batch] (mode 1) */
+    void* input_features;    /* [max_batch, H] bf16 (mode 1) */
+    int32_t *pos, *kvlen, *page, *slot, *kv_indptr, *kv_indices, *page_table;
+    int64_t pt_stride;
+    void* kv;
+    int64_t kv_layer_stride;
+    int32_t* out_ids;        /* [max_batch] */
+    void* out_logits;        /* [max_batch, vocab_out] bf16 (after the repetition penalty) */
+    uint8_t* rep_cache;      /* optional [max_batch, rep_w, 1, vocab_out]; penalty applied and cache updated in place */
+    int32_t rep_w, rep_window;
+    uint64_t* rng_offset;
+} vox_lm_io;
+int vox_lm_create(vox_ctx* ctx, const vox_lm_config* cfg, const vox_lm_weights* w, vox_lm** out);
+void vox_lm_destroy(vox_lm* m);
+int vox_lm_frame(vox_lm* m, void* stream, const vox_lm_io* io, int batch, int max_kvlen,
+                 const vox_sampling_config* sampling, uint64_t seed, int feedback);
+int vox_lm_prefill(vox_lm* m, void* stream, const vox_lm_io* io, const int32_t* row_ids, const uint8_t* row_masks,
+                   const void* row_features, const int32_t* q_req, int n_rows, const int32_t* last_rows, int n_req,
+                   int max_kvlen, const vox_sampling_config* sampling, uint64_t seed, int feedback);
+
 /* ---- Qwen3-TTS 12 Hz codec decoder (token -> waveform), streaming ------------------------------------
  * replaces Qwen3TTSTokenizerV2Decoder.forward_chunk (tokenizer/qwen3_codec.py:1541-1666), the DecoderCache
  * plumbing (tokenizer/base.py:7-173) and CudaGraphWorker.run_detokenize's cache cat / copy-in / copy-out

@@ -357,7 +357,7 @@ static uint32_t philox_u32(uint64_t seed, uint64_t offset, uint32_t row) {
 /*
  * Stochastic sampling contract (our own; the reference's draw is flashinfer-internal):
  *   x = bf16(l / T) per element (sampling.py:31,44,57,71 operate in the logits dtype);
- *   eligible set: top_k>0 -> the k largest by (value desc, index asc); then softmax over the eligible
+ *   top_k>0 (else the bucket mode below): the k largest by (value desc, index asc); softmax over the eligible
  *   set (fp32, EXP2, sequential sum in that sorted order); top_p<1 -> shortest sorted prefix whose
  *   cumulative probability >= top_p; min_p>0 -> p >= min_p*pmax;
  *   draw u = (philox>>8)*2^-24 in [0,1); pick the first sorted entry whose running cumulative sum
@@ -376,8 +376,163 @@ static int cmp_pair(const void* a, const void* b) {
     if (x->v < y->v) return 1;
     return x->i - y->i;
 }
+/*
+ * Full-vocabulary ("bucket") mode, used when top_k <= 0: top-p-only / min-p-only sampling over vocabularies
+ * of any size (GLM-4-Voice 168960, Orpheus 156940; sampling.py:41-52,69-80).  bf16 logits take at most 65536
+ * distinct values, so the sorted order is a histogram over the 16-bit sortable key, and every element of a
+ * bucket has the same probability.  Contract (fixed order, reproducible by one GPU block per row):
+ *   p(key)   = EXP2((value(key) - value(kmax)) * LOG2E), kmax = largest non-empty key
+ *   mass(key)= (float)count * p(key); 0 when min_p > 0 and p(key) < min_p * 1.0f
+ *   C[h]     = sequential sum of mass over the 256 keys of coarse bin h = key>>8, descending key
+ *   find(thr, cmp): walk coarse bins descending with acc (+= C[h]) until C[h] > 0 && cmp(acc + C[h], thr);
+ *              inside, walk keys descending with acc2 (+= mass) until mass > 0 && cmp(acc2 + mass, thr);
+ *              inside the bucket, the smallest j in [1,count] with cmp(acc2 + (float)j * p, thr)
+ *              (fallbacks: last non-empty bucket of the bin / j = count; no bin: last eligible bucket).
+ *   top_p < 1: (k*, j*) = find(top_p * tot, >=); the nucleus is every bucket above k* plus the first j*
+ *              elements of k* in ascending index order; tot' = acc2 + (float)j* * p(k*)
+ *   draw:      (kp, j) = find(u * tot', >) over the nucleus; the answer is the j-th element (ascending
+ *              index) whose key is kp.
+ */
+static inline uint32_t key_of(bf16 b) {
+    if (b == 0x8000) b = 0;
+    return (b & 0x8000) ? (uint32_t)(~b & 0xffff) : (uint32_t)(b | 0x8000);
+}
+static inline bf16 bits_of(uint32_t key) { return (key & 0x8000) ? (bf16)(key & 0x7fff) : (bf16)(~key & 0xffff); }
+
+typedef struct {
+    const uint32_t* hist;
+    float m, min_cut;
+    int lim_key;      /* -1: none; else keys below are outside the nucleus */
+    uint32_t lim_cnt; /* count of lim_key inside the nucleus */
+} bk_ctx;
+static inline float bk_p(const bk_ctx* c, uint32_t key) { return vr_exp2((bf2f(bits_of(key)) - c->m) * VR_LOG2E); }
+static inline uint32_t bk_count(const bk_ctx* c, uint32_t key) {
+    if ((int)key < c->lim_key) return 0;
+    return (int)key == c->lim_key ? c->lim_cnt : c->hist[key];
+}
+static inline float bk_mass(const bk_ctx* c, uint32_t key) {
+    uint32_t n = bk_count(c, key);
+    if (!n) return 0.0f;
+    float p = bk_p(c, key);
+    if (c->min_cut > 0.0f && p < c->min_cut) return 0.0f;
+    return (float)n * p;
+}
+static float bk_coarse(const bk_ctx* c, int h) {
+    float s = 0.0f;
+    for (int f = 255; f >= 0; --f) s = s + bk_mass(c, (uint32_t)(h << 8 | f));
+    return s;
+}
+static inline int bk_cmp(float a, float thr, int strict) { return strict ? a > thr : a >= thr; }
+/* returns the bucket key, *j (1-based count inside it) and *tot (cumulative mass through that element) */
+static int bk_find(const bk_ctx* c, float thr, int strict, uint32_t* j, float* tot) {
+    float acc = 0.0f;
+    int hf = -1, last_h = -1;
+    for (int h = 255; h >= 0; --h) {
+        float ch = bk_coarse(c, h);
+        if (ch > 0.0f) {
+            last_h = h;
+            if (bk_cmp(acc + ch, thr, strict)) {
+                hf = h;
+                break;
+            }
+        }
+        acc = acc + ch;
+    }
+    int whole = 0;
+    if (hf < 0) { /* nothing crossed: last eligible bucket, all of it */
+        hf = last_h;
+        whole = 1;
+        acc = 0.0f;
+    }
+    float acc2 = acc;
+    int kp = -1, last_k = -1;
+    for (int f = 255; f >= 0; --f) {
+        uint32_t key = (uint32_t)(hf << 8 | f);
+        float mk = bk_mass(c, key);
+        if (mk > 0.0f) {
+            last_k = (int)key;
+            if (!whole && bk_cmp(acc2 + mk, thr, strict)) {
+                kp = (int)key;
+                break;
+            }
+            acc2 = acc2 + mk;
+        }
+    }
+    if (kp < 0) {
+        *j = bk_count(c, (uint32_t)last_k);
+        *tot = acc2;
+        return last_k;
+    }
+    uint32_t n = bk_count(c, (uint32_t)kp), lo = 1, hi = n;
+    float p = bk_p(c, (uint32_t)kp);
+    while (lo < hi) { /* smallest j with cmp(acc2 + j*p, thr); j = n always satisfies it */
+        uint32_t mid = (lo + hi) >> 1;
+        if (bk_cmp(acc2 + (float)mid * p, thr, strict)) hi = mid;
+        else lo = mid + 1;
+    }
+    *j = lo;
+    *tot = acc2 + (float)lo * p;
+    return kp;
+}
+
+static void sample_bucket(const bf16* lg, int V, float top_p, float min_p, float temperature, uint64_t seed,
+                          uint64_t offset, int b, int* out, int* support, int kmax) {
+    uint32_t* hist = (uint32_t*)calloc(65536, sizeof(uint32_t));
+    uint16_t* keys = (uint16_t*)malloc(sizeof(uint16_t) * V);
+    uint32_t kmx = 0;
+    for (int v = 0; v < V; ++v) {
+        uint32_t k = key_of(f2bf(bf2f(lg[v]) / temperature));
+        keys[v] = (uint16_t)k;
+        hist[k]++;
+        if (k > kmx) kmx = k;
+    }
+    bk_ctx c = {hist, bf2f(bits_of(kmx)), min_p > 0.0f ? min_p * 1.0f : 0.0f, -1, 0};
+    float tot = 0.0f;
+    for (int h = 255; h >= 0; --h) tot = tot + bk_coarse(&c, h);
+    if (top_p < 1.0f) {
+        uint32_t js;
+        float t2;
+        int ks = bk_find(&c, top_p * tot, 0, &js, &t2);
+        c.lim_key = ks;
+        c.lim_cnt = js;
+        tot = t2;
+    }
+    if (support) { /* eligible ids in sorted order (value desc, index asc), -1 padded */
+        int n = 0;
+        for (int k = 65535; k >= 0 && n < kmax; --k) {
+            if (bk_mass(&c, (uint32_t)k) <= 0.0f) continue;
+            uint32_t left = bk_count(&c, (uint32_t)k);
+            for (int v = 0; v < V && left && n < kmax; ++v)
+                if (keys[v] == k) {
+                    support[n++] = v;
+                    --left;
+                }
+        }
+        for (; n < kmax; ++n) support[n] = -1;
+    }
+    float u = (float)(philox_u32(seed, offset, (uint32_t)b) >> 8) * (1.0f / 16777216.0f);
+    uint32_t j;
+    float t3;
+    int kp = bk_find(&c, u * tot, 1, &j, &t3);
+    int pick = -1;
+    for (int v = 0; v < V; ++v)
+        if (keys[v] == kp && --j == 0) {
+            pick = v;
+            break;
+        }
+    *out = pick;
+    free(hist);
+    free(keys);
+}
+
 void vr_sample(const bf16* logits, int B, int V, int top_k, float top_p, float min_p, float temperature,
                uint64_t seed, uint64_t offset, int* out, int* support, int kmax) {
+    if (top_k <= 0) {
+        for (int b = 0; b < B; ++b)
+            sample_bucket(logits + (size_t)b * V, V, top_p, min_p, temperature, seed, offset, b, out + b,
+                          support ? support + (size_t)b * kmax : NULL, kmax);
+        return;
+    }
     vr_pair* pr = (vr_pair*)malloc(sizeof(vr_pair) * V);
     float* pe = (float*)malloc(sizeof(float) * V);
     for (int b = 0; b < B; ++b) {

@@ -257,6 +257,132 @@ def g3_qwen3_lm(ns):
     print("g3 ok; frame tokens", out["f2_tokens"][:, :6])
 
 
+
+# --------------------------------------------------------------------------------------------------
+def _lm_worker(ns, m, c, page, P):
+    import logging
+    FU, MW = ns.flashinfer_utils, ns.ModelWorker
+    cpu = torch.device("cpu")
+    w = MW.__new__(MW)
+    w.model, w.device, w.page_size, w.max_batch_size = m, "cpu", page, 4
+    w.empty_pages = queue.Queue()
+    for i in range(P):
+        w.empty_pages.put(i)
+    w.prefill_wrapper = FU.FlashInferPrefillWrapper(torch.empty(1), c.heads, c.kv_heads, c.heads * c.head_dim, page, device=cpu)
+    w.decode_wrapper = FU.FlashInferDecodeWrapper(torch.empty(1), c.heads, c.kv_heads, c.heads * c.head_dim, page, device=cpu)
+    w.kv_cache = torch.zeros(c.layers, P, 2, page, c.kv_heads, c.head_dim, dtype=torch.bfloat16)
+    w.has_depth_transformer = False
+    w.logger = logging.getLogger("golden")
+    w.nvtx_enabled = False
+    return w
+
+
+def _drive_lm(ns, w, m, prompts, n_steps, out, tag, rep_shape=None):
+    """One prefill per request, then n_steps batched decode steps through the reference worker (greedy)."""
+    from vox_serve.model.base import PreprocessOutput
+    rec = []
+    f0 = m.forward
+
+    def fwd(**kw):
+        lg = f0(**kw)
+        rec.append(lg.clone())
+        return lg
+    m.forward = fwd
+    reqs = []
+
+    cl = lambda t: None if t is None else t.clone()
+
+    def run(task):
+        try:
+            task.send(None)
+        except StopIteration:
+            pass
+    for r, pp in enumerate(prompts):
+        req = ns.requests.Request(request_id=str(r), prompt="x")
+        rc = torch.zeros(*rep_shape, dtype=torch.bool) if rep_shape else None
+        m.preprocess = (lambda pp=pp, rc=rc: (lambda prompt=None, audio_path=None, **kw: PreprocessOutput(
+            input_tokens=pp["ids"], input_masks=cl(pp.get("masks")), input_features=cl(pp.get("feats")),
+            repetition_cache=rc)))()      # clones: CosyVoice2Model.sampling zeroes these in place (cosyvoice2.py:1062-1064)
+        li = w.prepare_lm_inputs([req], [])
+        run(w.run_lm_prefill([req], li))
+        out[f"{tag}_r{r}_prefill_logits"] = bits(rec[-1][-1:, 0])
+        out[f"{tag}_r{r}_tok0"] = req.lm_output_tokens[-1].numpy().astype(np.int32)[0]
+        out[f"{tag}_r{r}_next_pos"] = np.int32(req.next_position_id)
+        reqs.append(req)
+    for f in range(n_steps):
+        li = w.prepare_lm_inputs(reqs, [])
+        out[f"{tag}_f{f}_pos"] = li["position_ids"].numpy().astype(np.int32)
+        run(w.run_lm_decode(reqs, li))
+        out[f"{tag}_f{f}_logits"] = bits(rec[-1][:, 0])
+        out[f"{tag}_f{f}_tokens"] = np.stack([r.lm_output_tokens[-1].numpy().astype(np.int32)[0] for r in reqs])
+    out[f"{tag}_kv_final"] = bits(w.kv_cache)
+
+
+def g7_single_stack_lms(ns):
+    """Tiny GLM-4-Voice and CosyVoice2 LMs through the reference's modules + worker (glm_voice.py, cosyvoice2.py)."""
+    torch.cuda.synchronize = lambda *a, **k: None
+    from vox_serve.model import cosyvoice2 as CV
+    from vox_serve.model import glm_voice as GV
+    from oracle import lm_ref as LR
+    out = {"page": np.int32(16), "P": np.int32(24)}
+    g = torch.Generator().manual_seed(5)
+
+    # ---- GLM-4-Voice, greedy ----
+    cfg = LR.tiny_glm_cfg()
+    c = cfg.stack
+    S = LR.random_glm_state_dict(cfg, seed=3, std=0.08)
+    gc = GV.GLMVoiceConfig(ffn_hidden_size=c.ffn, hidden_size=c.hidden, multi_query_group_num=c.kv_heads,
+                           num_attention_heads=c.heads, num_hidden_layers=c.layers, num_layers=c.layers,
+                           padded_vocab_size=cfg.vocab_out, vocab_size=cfg.vocab_out, layernorm_epsilon=c.eps)
+    net = GV.GLMVoiceForCausalLM(gc).to(torch.bfloat16)
+    missing, unexpected = net.load_state_dict({k: vr.to_torch(v) for k, v in S.items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    prompts = [{"ids": torch.randint(0, cfg.vocab_in, (n, 1), generator=g)} for n in (11, 19)]
+    for i, pp in enumerate(prompts):
+        out[f"glm_r{i}_ids"] = pp["ids"].numpy().astype(np.int32)[:, 0]
+    m = GV.GLMVoiceModel.__new__(GV.GLMVoiceModel)
+    m.model, m.config, m.device, m.dtype = net, gc, "cpu", torch.bfloat16
+    m._num_attention_heads, m._num_key_value_heads = c.heads, c.kv_heads
+    m._num_hidden_layers, m._hidden_size = c.layers, c.hidden
+    m.stop_token_ids, m.audio_offset = [cfg.vocab_out - 3, cfg.vocab_out - 2, cfg.vocab_out - 1], cfg.vocab_out // 2
+    m.default_sampling_config = ns.sampling.SamplingConfig(greedy=True)
+    _drive_lm(ns, _lm_worker(ns, m, c, 16, 24), m, prompts, 4, out, "glm")
+
+    # ---- CosyVoice2: prefill rows are input_features (mask 1), decode rows are speech_embedding[id] ----
+    cfg = LR.tiny_cosyvoice2_cfg()
+    c = cfg.stack
+    S = LR.random_cosyvoice2_state_dict(cfg, seed=4, std=0.08)
+    cc = CV.CosyVoice2Config()
+    cc.llm_input_size = cc.llm_output_size = cc.hidden_size = c.hidden
+    cc.speech_token_size, cc.intermediate_size = cfg.vocab_out - 3, c.ffn
+    cc.num_attention_heads, cc.num_key_value_heads, cc.num_hidden_layers = c.heads, c.kv_heads, c.layers
+    cc.vocab_size = S["llm.model.model.embed_tokens.weight"].shape[0]
+    net = CV.CosyVoice2ForCausalLM(cc).to(torch.bfloat16)
+    missing, unexpected = net.load_state_dict({k: vr.to_torch(v) for k, v in S.items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    m = CV.CosyVoice2Model.__new__(CV.CosyVoice2Model)
+    m.model, m.config, m.device, m.dtype = net, cc, "cpu", torch.bfloat16
+    m._num_attention_heads, m._num_key_value_heads = c.heads, c.kv_heads
+    m._num_hidden_layers, m._hidden_size = c.layers, c.hidden
+    m.stop_token_ids = [cc.speech_token_size + i for i in range(3)]
+    m.default_sampling_config = ns.sampling.SamplingConfig(greedy=True)
+    prompts = []
+    for i, n in enumerate((9, 14)):
+        ids = torch.randint(0, cc.vocab_size, (n, 1), generator=g)
+        feats = (0.08 * torch.randn(n, c.hidden, generator=g)).to(torch.bfloat16)
+        prompts.append({"ids": ids, "masks": torch.ones(n, 1, dtype=torch.bool), "feats": feats})
+        out[f"cosy_r{i}_ids"], out[f"cosy_r{i}_feats"] = ids.numpy().astype(np.int32)[:, 0], bits(feats)
+    _drive_lm(ns, _lm_worker(ns, m, c, 16, 24), m, prompts, 4, out, "cosy")
+    # same prompts with a persisted per-request repetition cache (sliding window 2, penalty 2.0): the greedy run
+    # above repeats a token, so the penalty changes the outcome (sampling.py:121-178, cosyvoice2.py:1046-1058)
+    m.forward = type(m).forward.__get__(m)
+    m.default_sampling_config = ns.sampling.SamplingConfig(greedy=True, repetition_penalty=2.0, repetition_window=2)
+    _drive_lm(ns, _lm_worker(ns, m, c, 16, 24), m, prompts, 4, out, "cosyrep", (2, 1, cfg.vocab_out))
+    np.savez_compressed(os.path.join(HERE, "g7_single_stack_lms.npz"), **out)
+    for t in ("glm", "cosy", "cosyrep"):
+        print("g7", t, [out[f"{t}_f{f}_tokens"].ravel().tolist() for f in range(4)])
+
+
 def _ref_codec(ns, cfg, W, dtype):
     qc = ns.qwen3_codec
     rc = qc.Qwen3TTSTokenizerV2DecoderConfig(
@@ -392,7 +518,8 @@ def g6_host_traces(ns):
     print("g6 ok", len(trace), "steps; pcm chunks", sum(len(t["pcm"]) for t in trace))
 
 
-ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces}
+ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
+       "g7": g7_single_stack_lms}
 
 if __name__ == "__main__":
     ns = H.boot()

@@ -1,0 +1,245 @@
+"""Parity of the single-stack speech-LM engine (libvoxhip vox_lm_* through the C ABI: GLM-4-Voice, CosyVoice2) against
+the CPU oracle (oracle/lm_ref.py), which is itself pinned to the reference modules by tests/golden/g7.
+
+Bar: <= 8 rows per call -> BIT-EXACT logits, sampled ids, repetition caches and KV contents, free-running, under
+greedy, seeded top-k, seeded top-p-only (the full-vocabulary sampler) and repetition penalty with a persisted
+cache.  Longer prefills run the bf16-MFMA linears: statistical bf16 bar, then the oracle adopts the GPU state.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lm_ref as LR
+from oracle import voxref as vr
+from tests.conftest import bf16_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def build(dev, family, cfg, S, B, page, max_pages, rep_window=None, max_seq_len=512):
+    """Reference-named state dict S (numpy bf16 bits) -> product plugin packers -> LMEngine."""
+    from vox_serve_amd.engine import LMEngine
+    St = {k: vr.to_torch(v).to(dev) for k, v in S.items()}
+    c = cfg.stack
+    if family == "glm":
+        from vox_serve_amd.model.glm_voice import GLMVoiceConfig, pack_glm_weights
+        pc = GLMVoiceConfig(ffn_hidden_size=c.ffn, hidden_size=c.hidden, multi_query_group_num=c.kv_heads,
+                            num_attention_heads=c.heads, num_layers=c.layers, padded_vocab_size=cfg.vocab_out,
+                            vocab_size=cfg.vocab_out)
+        layers, norm, emb, head = pack_glm_weights(St, pc)
+        head_b = None
+    else:
+        from vox_serve_amd.model.cosyvoice2 import CosyVoice2Config, pack_cosyvoice2_weights
+        pc = CosyVoice2Config(llm_input_size=c.hidden, llm_output_size=c.hidden, speech_token_size=cfg.vocab_out - 3,
+                              hidden_size=c.hidden, intermediate_size=c.ffn, num_attention_heads=c.heads,
+                              num_key_value_heads=c.kv_heads, num_hidden_layers=c.layers)
+        layers, norm, emb, head, head_b = pack_cosyvoice2_weights(St, pc)
+    ecfg = pc.lm_cfg(max_pos=cfg.max_pos)
+    return LMEngine(ecfg, layers, norm, emb, head, head_b, max_batch=B, page_size=page, max_pages=max_pages,
+                    max_seq_len=max_seq_len, max_prefill_rows=128, rep_window=rep_window, device=dev)
+
+
+def run_parity(dev, family, cfg, S, prompt_lens, n_steps, page=16, max_pages=48, sampler_kw=None, penalty=1.0, window=None):
+    rng = np.random.default_rng(11)
+    B = len(prompt_lens)
+    W = (LR.from_glm_state_dict if family == "glm" else LR.from_cosyvoice2_state_dict)(cfg, S)
+    ref = LR.LMRef(cfg, W, page_size=page, max_pages=max_pages)
+    use_rep = penalty != 1.0
+    eng = build(dev, family, cfg, S, B, page, max_pages, rep_window=window if use_rep else None)
+    seed, step = 4321, [0]
+    if sampler_kw:
+        sc = eng.sampling_cfg(greedy=False, repetition_penalty=penalty, **sampler_kw)
+        sampler = lambda lg: vr.sample(lg, seed=seed, offset=step[0], **sampler_kw)
+    else:
+        sc, sampler = eng.sampling_cfg(greedy=True, repetition_penalty=penalty), None
+    H, V = cfg.stack.hidden, cfg.vocab_out
+    Wn = (window if window and window > 0 else 1)
+    reqs, synced = [], False
+    state_ids = torch.zeros(B, 1, dtype=torch.int32, device=dev)
+    state_rep = torch.zeros(B, Wn, 1, V, dtype=torch.uint8, device=dev)
+    for r, n in enumerate(prompt_lens):
+        ids = rng.integers(0, cfg.vocab_in if family == "glm" else 640, n).astype(np.int32)
+        masks = feats = None
+        if cfg.input_mode == 1:
+            masks = np.ones(n, np.uint8)
+            masks[n // 2] = 0                                   # one row falls back to the embedding table
+            ids[n // 2] = rng.integers(0, cfg.vocab_in)
+            feats = vr.f2bf((0.08 * rng.standard_normal((n, H))).astype(np.float32))
+        req = LR.LMRequest(rep_cache=np.zeros((Wn, 1, V), np.uint8) if use_rep else None)
+        lg = ref.prefill(req, ids, masks, feats)
+        tok, pen = ref.sample(lg, [req], sampler, penalty, window)
+        eng.row_ids[:n, 0] = torch.from_numpy(ids).to(dev)
+        if masks is not None:
+            eng.row_masks[:n] = torch.from_numpy(masks).to(dev)
+            eng.row_feats[:n] = vr.to_torch(feats).to(dev)
+        eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[req.kv_pages[t // page] for t in range(n)],
+                        slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1],
+                        indptr=[0, len(req.kv_pages)], indices=req.kv_pages)
+        eng.rng_offset.fill_(step[0])
+        if use_rep:
+            eng.rep_cache[0].zero_()
+        eng.prefill(n, 1, n, sc, seed=seed, feedback=True)
+        torch.cuda.synchronize()
+        got_lg, got = vr.from_torch(eng.out_logits[:1]), eng.out_ids[:1].cpu().numpy()
+        if n <= 8:
+            assert np.array_equal(got_lg, pen), f"prefill logits r{r}"
+            assert np.array_equal(got, tok), f"prefill token r{r}"
+        else:
+            fa, fb = vr.bf2f(got_lg).astype(np.float64), vr.bf2f(pen).astype(np.float64)
+            assert np.sqrt(np.mean((fa - fb) ** 2) / np.mean(fb ** 2)) < 0.02, f"prefill logits r{r}"
+            assert bf16_close(got_lg, pen, ulps=4, atol=0.05).mean() > 0.99
+            req.input_ids = got.reshape(1, 1).astype(np.int32)
+            req.tokens[-1] = int(got[0])
+            if use_rep:
+                req.rep_cache = eng.rep_cache[0].cpu().numpy().copy()
+            synced = True
+        assert int(eng.input_ids[0, 0]) == int(req.input_ids[0, 0])
+        if cfg.input_mode == 1:
+            assert int(eng.input_masks[0]) == 0
+        state_ids[r] = eng.input_ids[0]
+        if use_rep:
+            state_rep[r] = eng.rep_cache[0]
+            assert np.array_equal(eng.rep_cache[0].cpu().numpy(), req.rep_cache), f"rep cache r{r}"
+        reqs.append(req)
+    if synced:
+        kv_gpu = vr.from_torch(eng.kv)
+        for l in range(len(ref.kv)):
+            ref.kv[l][:] = kv_gpu[l]
+    step[0] = 1
+    eng.input_ids[:B] = state_ids
+    eng.input_masks[:B] = 0
+    if use_rep:
+        eng.rep_cache[:B] = state_rep
+    eng.rng_offset.fill_(step[0])
+    for f in range(n_steps):
+        lg = ref.decode(reqs)
+        tok, pen = ref.sample(lg, reqs, sampler, penalty, window)
+        indptr, indices = [0], []
+        for q in reqs:
+            indptr.append(indptr[-1] + len(q.kv_pages))
+            indices += q.kv_pages
+        eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
+                        page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
+                        indptr=indptr, indices=indices)
+        eng.frame(B, max(q.kv_token_len for q in reqs), sc, seed=seed, feedback=True, use_graph=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(vr.from_torch(eng.out_logits[:B]), pen), f"logits step {f}"
+        assert np.array_equal(eng.out_ids[:B].cpu().numpy(), tok), f"tokens step {f}"
+        if use_rep:
+            assert np.array_equal(eng.rep_cache[:B].cpu().numpy(), np.stack([q.rep_cache for q in reqs])), f"rep {f}"
+        step[0] += 1
+    kv_gpu = vr.from_torch(eng.kv)
+    used = sorted({p for q in reqs for p in q.kv_pages})
+    for l in range(len(ref.kv)):
+        assert np.array_equal(kv_gpu[l][used], ref.kv[l][used]), f"kv layer {l}"
+    eng.close()
+    return [q.tokens for q in reqs]
+
+
+def test_glm_tiny_greedy(dev):
+    cfg = LR.tiny_glm_cfg()
+    run_parity(dev, "glm", cfg, LR.random_glm_state_dict(cfg, seed=3, std=0.08), [5, 8, 3], 20)
+
+
+def test_glm_tiny_top_p_only(dev):
+    """GLM-4-Voice defaults: top_p 0.8, temperature 0.8, no top-k (glm_voice.py:358-366) -> bucket sampler."""
+    cfg = LR.tiny_glm_cfg()
+    toks = run_parity(dev, "glm", cfg, LR.random_glm_state_dict(cfg, seed=3, std=0.08), [6, 7], 24,
+                      sampler_kw=dict(top_k=0, top_p=0.8, temperature=0.8))
+    assert len({t for q in toks for t in q}) > 8          # it really samples
+
+
+def test_glm_tiny_long_prefill_then_exact_decode(dev):
+    cfg = LR.tiny_glm_cfg()
+    run_parity(dev, "glm", cfg, LR.random_glm_state_dict(cfg, seed=3, std=0.08), [37, 21], 12)
+
+
+def test_cosyvoice2_tiny_greedy_and_topk(dev):
+    cfg = LR.tiny_cosyvoice2_cfg()
+    S = LR.random_cosyvoice2_state_dict(cfg, seed=4, std=0.08)
+    run_parity(dev, "cosy", cfg, S, [7, 4, 8], 20)
+    run_parity(dev, "cosy", cfg, S, [7, 4], 20, sampler_kw=dict(top_k=25, temperature=1.0))
+
+
+def test_cosyvoice2_tiny_repetition_window(dev):
+    """Persisted per-request repetition cache, sliding window 2 and global window, penalty 2.0 (sampling.py:121-178)."""
+    cfg = LR.tiny_cosyvoice2_cfg()
+    S = LR.random_cosyvoice2_state_dict(cfg, seed=4, std=0.08)
+    run_parity(dev, "cosy", cfg, S, [8, 6], 16, penalty=2.0, window=2)
+    run_parity(dev, "cosy", cfg, S, [8, 6], 16, penalty=2.0, window=-1, sampler_kw=dict(top_k=0, top_p=0.9, temperature=0.7))
+
+
+def test_against_reference_goldens(dev, golden):
+    """GPU engine vs the tokens the reference modules produced (g7): prompts of 11/19 and 9/14 tokens take the MFMA
+    prefill, so logits are compared at bf16 tolerance and greedy tokens may flip only on near-ties."""
+    g = golden("g7_single_stack_lms")
+    page, P = int(g["page"]), int(g["P"])
+    for fam, tag in (("glm", "glm"), ("cosy", "cosy")):
+        if fam == "glm":
+            cfg = LR.tiny_glm_cfg()
+            S = LR.random_glm_state_dict(cfg, seed=3, std=0.08)
+        else:
+            cfg = LR.tiny_cosyvoice2_cfg()
+            S = LR.random_cosyvoice2_state_dict(cfg, seed=4, std=0.08)
+        eng = build(dev, fam, cfg, S, 2, page, P)
+        sc = eng.sampling_cfg(greedy=True)
+        pages, lens, free, mism = [], [], list(range(P)), 0
+        for r in range(2):
+            ids = g[f"{fam}_r{r}_ids"]
+            n = len(ids)
+            pg = [free.pop(0) for _ in range((n + page - 1) // page)]
+            eng.row_ids[:n, 0] = torch.from_numpy(ids).to(dev)
+            if fam == "cosy":
+                eng.row_masks[:n] = 1
+                eng.row_feats[:n] = vr.to_torch(g[f"cosy_r{r}_feats"]).to(dev)
+            eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[pg[t // page] for t in range(n)],
+                            slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1], indptr=[0, len(pg)],
+                            indices=pg)
+            eng.prefill(n, 1, n, sc, feedback=False)
+            torch.cuda.synchronize()
+            assert bf16_close(vr.from_torch(eng.out_logits[:1]), g[f"{tag}_r{r}_prefill_logits"], ulps=4, atol=6e-2).all()
+            mism += int(eng.out_ids[0].item() != g[f"{tag}_r{r}_tok0"][0])
+            pages.append(pg)
+            lens.append(n)
+        toks = np.array([g[f"{tag}_r{r}_tok0"][0] for r in range(2)], np.int32)
+        for f in range(4):
+            eng.input_ids[:2, 0] = torch.from_numpy(toks).to(dev)          # teacher forcing with the reference's tokens
+            eng.input_masks[:2] = 0
+            lens = [n + 1 for n in lens]
+            for r in range(2):
+                if lens[r] > len(pages[r]) * page:
+                    pages[r].append(free.pop(0))
+            eng.upload_plan(pos=g[f"{tag}_f{f}_pos"], kvlen=lens, page=[pages[r][(lens[r] - 1) // page] for r in range(2)],
+                            slot=[(lens[r] - 1) % page for r in range(2)], indptr=[0, len(pages[0]), len(pages[0]) + len(pages[1])],
+                            indices=pages[0] + pages[1])
+            eng.frame(2, max(lens), sc, feedback=False)
+            torch.cuda.synchronize()
+            assert bf16_close(vr.from_torch(eng.out_logits[:2]), g[f"{tag}_f{f}_logits"], ulps=4, atol=6e-2).all(), (tag, f)
+            mism += int((eng.out_ids[:2].cpu().numpy() != g[f"{tag}_f{f}_tokens"][:, 0]).sum())
+            toks = g[f"{tag}_f{f}_tokens"][:, 0].astype(np.int32)
+        assert mism <= 1, (tag, mism)
+        eng.close()
+
+
+@pytest.mark.slow
+def test_glm_full_width_two_layers(dev):
+    """GLM-4-Voice-9B layer shapes (4096 hidden, 32/2 heads, FFN 13696, vocab 168960), 2 of the 40 layers: bit-exact
+    decode under the model's default top-p-only sampling over the full 168960-entry vocabulary."""
+    cfg = LR.glm_cfg(layers=2, max_pos=512)
+    S = LR.random_glm_state_dict(cfg, seed=1, std=0.02)
+    run_parity(dev, "glm", cfg, S, [4, 6], 6, page=128, max_pages=8, sampler_kw=dict(top_k=0, top_p=0.8, temperature=0.8))
+
+
+@pytest.mark.slow
+def test_cosyvoice2_full_size(dev):
+    """CosyVoice2-0.5B at full size (24 layers x 896, 14/2 heads of 64, FFN 4864, 6564 speech ids), top-k 25."""
+    cfg = LR.cosyvoice2_cfg(max_pos=512)
+    S = LR.random_cosyvoice2_state_dict(cfg, seed=2, std=0.02)
+    run_parity(dev, "cosy", cfg, S, [5, 3], 6, page=128, max_pages=8, sampler_kw=dict(top_k=25, temperature=1.0))

@@ -220,3 +220,28 @@ def test_stochastic_sampler_bit_exact(dev, B, V, k, p, mp, T_):
         N.check(N.lib().vox_sample(N.ctx(), N.stream(), N.ptr(lt), B, V, cfg, 77, off, N.ptr(out)))
         ref = vr.sample(logits, top_k=k, top_p=p, min_p=mp, temperature=T_, seed=77, offset=off)
         assert np.array_equal(out.cpu().numpy(), ref), off
+
+
+@pytest.mark.parametrize("B,V,k,p,mp,T_", [(2, 168960, 0, 0.8, 0.0, 0.8),      # GLM-4-Voice defaults (glm_voice.py:358-366)
+                                          (4, 156940, 0, 0.8, 0.0, 0.6),      # Orpheus defaults (orpheus.py:260-268)
+                                          (3, 3072, 0, 1.0, 0.1, 1.0),        # Zonos min-p (zonos.py:591-599)
+                                          (2, 65536, 0, 0.9, 0.05, 0.7), (2, 4096, 0, 0.0, 0.0, 1.0),
+                                          (2, 2048, 0, 1.0, 0.0, 1.0),        # full multinomial
+                                          (2, 168960, 50, 1.0, 0.0, 0.9), (2, 156940, 25, 0.8, 0.0, 1.0)])
+def test_full_vocab_sampler_bit_exact(dev, B, V, k, p, mp, T_):
+    """top-p-only / min-p-only ("bucket" contract) and top-k over vocabularies too large for LDS."""
+    from vox_serve_amd import _native as N
+    rng = np.random.default_rng(V + k + int(p * 100))
+    logits = vr.f2bf(rng.standard_normal((B, V)).astype(np.float32) * 3)
+    logits[0, : V // 2] = logits[0, 0]            # one huge bucket on row 0
+    logits[-1, ::3] = vr.f2bf(np.float32(4.0))    # the top bucket holds a third of the row
+    lt = T(logits, dev)
+    out = torch.empty(B, dtype=torch.int32, device=dev)
+    cfg = N.SamplingCfg(0, k, p, mp, T_, 1.0)
+    for off in range(10):
+        N.check(N.lib().vox_sample(N.ctx(), N.stream(), N.ptr(lt), B, V, cfg, 1234, off, N.ptr(out)))
+        ref = vr.sample(logits, top_k=k, top_p=p, min_p=mp, temperature=T_, seed=1234, offset=off)
+        assert np.array_equal(out.cpu().numpy(), ref), (off, out.cpu().numpy(), ref)
+    # the histogram scratch must be left all-zero: a repeated call agrees
+    N.check(N.lib().vox_sample(N.ctx(), N.stream(), N.ptr(lt), B, V, cfg, 1234, 9, N.ptr(out)))
+    assert np.array_equal(out.cpu().numpy(), ref)

@@ -167,6 +167,61 @@ def test_qwen3_lm_against_reference_worker(golden):
     assert tok_mismatch <= 6, tok_mismatch
 
 
+# ---------------------------------------------------------------- g7: GLM-4-Voice / CosyVoice2 LMs -
+def _g7_case(g, tag):
+    from oracle import lm_ref as LR
+    if tag == "glm":
+        cfg = LR.tiny_glm_cfg()
+        W = LR.from_glm_state_dict(cfg, LR.random_glm_state_dict(cfg, seed=3, std=0.08))
+    else:
+        cfg = LR.tiny_cosyvoice2_cfg()
+        W = LR.from_cosyvoice2_state_dict(cfg, LR.random_cosyvoice2_state_dict(cfg, seed=4, std=0.08))
+    return cfg, W, LR.LMRef(cfg, W, page_size=int(g["page"]), max_pages=int(g["P"]))
+
+
+@pytest.mark.parametrize("tag", ["glm", "cosy", "cosyrep"])
+def test_single_stack_lm_against_reference_worker(golden, tag):
+    """Prefill + 4 decode steps, B=2, greedy, oracle vs the reference modules driven by the reference worker.
+    cosyrep adds the persisted per-request repetition cache (window 2, penalty 2.0)."""
+    from oracle import lm_ref as LR
+    g = golden("g7_single_stack_lms")
+    fam = "glm" if tag == "glm" else "cosy"
+    cfg, W, m = _g7_case(g, fam)
+    rep = tag == "cosyrep"
+    reqs, mism = [], 0
+    for r in range(2):
+        req = LR.LMRequest(rep_cache=np.zeros((2, 1, cfg.vocab_out), np.uint8) if rep else None)
+        ids = g[f"{fam}_r{r}_ids"]
+        feats = g[f"{fam}_r{r}_feats"] if fam == "cosy" else None
+        logits = m.prefill(req, ids, np.ones(len(ids), np.uint8) if fam == "cosy" else None, feats)
+        assert req.next_position_id == int(g[f"{tag}_r{r}_next_pos"])
+        assert bf16_close(logits, g[f"{tag}_r{r}_prefill_logits"], ulps=4, atol=5e-2).all()
+        ids0, _ = m.sample(logits, [req], penalty=2.0 if rep else 1.0, window=2)
+        mism += int(ids0[0] != g[f"{tag}_r{r}_tok0"][0])
+        req.input_ids = g[f"{tag}_r{r}_tok0"].reshape(1, 1).copy()         # teacher-force the reference's token
+        if rep:
+            req.rep_cache[:] = 0
+            req.rep_cache[-1, 0, int(g[f"{tag}_r{r}_tok0"][0])] = 1
+        reqs.append(req)
+    for f in range(4):
+        logits = m.decode(reqs)
+        assert np.array_equal(np.array([r.next_position_id - 1 for r in reqs]), g[f"{tag}_f{f}_pos"])
+        assert bf16_close(logits, g[f"{tag}_f{f}_logits"], ulps=4, atol=5e-2).all()
+        caches = [r.rep_cache.copy() for r in reqs] if rep else None
+        ids, _ = m.sample(logits, reqs, penalty=2.0 if rep else 1.0, window=2)
+        want = g[f"{tag}_f{f}_tokens"][:, 0]
+        mism += int((ids != want).sum())
+        for b, r in enumerate(reqs):                                        # teacher forcing, cache included
+            r.input_ids = want[b].reshape(1, 1).copy()
+            if rep and ids[b] != want[b]:
+                c = caches[b][None].copy()
+                vr.rep_update(c, want[b:b + 1], 2)
+                r.rep_cache = c[0]
+    assert mism <= 1, mism
+    kv = np.stack(m.kv)
+    assert bf16_close(kv, g[f"{tag}_kv_final"], ulps=4, atol=3e-2).mean() > 0.999
+
+
 # ---------------------------------------------------------------- g4: Qwen3 codec (streaming) -----
 def _codec_run(cfg, codes, chunk, exact):
     """exact=True: contraction operands stay fp32 (the mode the HIP codec computes in: fp32-input MFMA);

@@ -38,10 +38,19 @@ int vox_ctx_create(int device, vox_ctx** out) {
     c->n_cu = p.multiProcessorCount;
     c->lds_bytes = (int64_t)p.maxSharedMemoryPerMultiProcessor;
     c->hbm_bytes = (int64_t)p.totalGlobalMem;
+    c->samp_ws = nullptr;
+    if (hipMalloc(&c->samp_ws, SAMP_WS_BYTES) != hipSuccess || hipMemset(c->samp_ws, 0, SAMP_WS_BYTES) != hipSuccess) {
+        delete c;
+        return vox_fail(VOX_ERR_NOMEM, "ctx_create: sampler scratch");
+    }
     *out = c;
     return VOX_OK;
 }
-void vox_ctx_destroy(vox_ctx* ctx) { delete ctx; }
+void vox_ctx_destroy(vox_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipFree(ctx->samp_ws);
+    delete ctx;
+}
 int vox_ctx_props(vox_ctx* ctx, int64_t out[3]) {
     if (!ctx || !out) return vox_fail(VOX_ERR_INVALID, "ctx_props: NULL");
     out[0] = ctx->n_cu; out[1] = ctx->lds_bytes; out[2] = ctx->hbm_bytes;
@@ -178,9 +187,9 @@ int vox_rep_update(vox_ctx* ctx, void* stream, uint8_t* cache, const int32_t* id
 }
 int vox_sample(vox_ctx* ctx, void* stream, const void* logits, int B, int V, const vox_sampling_config* cfg,
                uint64_t seed, uint64_t offset, int32_t* out_ids) {
-    (void)ctx;
     if (!cfg) return vox_fail(VOX_ERR_INVALID, "sample: cfg NULL");
     SampleCall c;
+    c.ws = ctx ? ctx->samp_ws : nullptr;
     c.logits = const_cast<void*>(logits); c.B = B; c.V = V; c.cfg = *cfg; c.cfg.repetition_penalty = 1.0f;
     c.seed = seed; c.offset = offset; c.out_ids = out_ids;
     return vox_launch_sample((hipStream_t)stream, c);
@@ -374,7 +383,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         s.seed = seed; s.offset = 0; s.offset_dev = io->rng_offset; s.offset_mul = (uint64_t)G;
         s.out_ids = io->out_ids; s.out_stride = G1; s.out_col = 0;
         s.emb_table = m->w.codec_embedding; s.emb_vocab = c.vocab; s.H = H;
-        s.emb_dst = (bf16_t*)m->depth_x + H; s.emb_dst_stride = 2L * H;
+        s.emb_dst = (bf16_t*)m->depth_x + H; s.emb_dst_stride = 2L * H; s.ws = m->ctx->samp_ws;
         VOX_TRY(vox_launch_sample(st, s));
     }
     for (int i = 1; i < G; ++i) {
@@ -408,7 +417,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         s.out_ids = io->out_ids; s.out_stride = G1; s.out_col = i;
         s.emb_table = m->depth_emb[i - 1]; s.emb_vocab = c.depth_vocab; s.H = H;
         s.emb_dst = m->depth_x; s.emb_dst_stride = H;
-        s.feat_acc = io->next_features; s.feat_init = i == 1;
+        s.feat_acc = io->next_features; s.feat_init = i == 1; s.ws = m->ctx->samp_ws;
         VOX_TRY(vox_launch_sample(st, s));
     }
     if (feedback) {
@@ -554,6 +563,113 @@ int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const 
     VOX_TRY(stack_layers(m->talker, st, m->x, io->kv, io->kv_layer_stride, &r));
     VOX_TRY(qwen3_head(m, st, io, n_req, last_rows));
     return qwen3_tail(m, st, io, n_req, sc, seed, feedback);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// single-stack LM engine (GLM-4-Voice, CosyVoice2, ...)
+// ---------------------------------------------------------------------------------------------------
+struct vox_lm {
+    vox_ctx* ctx;
+    vox_lm_config cfg;
+    vox_lm_weights w;
+    vox_stack* stack;
+    void *x, *hidden;
+    int32_t* iota;
+};
+
+// x[b] = mask[b] ? feat[b] : x[b]     (cosyvoice2.py:1024)
+__global__ __launch_bounds__(256) void k_where_rows(bf16_t* x, const uint8_t* mask, const bf16_t* feat, int H) {
+    const int b = blockIdx.y;
+    if (!mask[b]) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H; i += gridDim.x * 256) x[(size_t)b * H + i] = feat[(size_t)b * H + i];
+}
+// next step inputs: ids[b,0] = sampled id; (mode 1) mask = 0 (features no longer used: cosyvoice2.py:1062-1064)
+__global__ void k_lm_feedback(const int* out_ids, int* input_ids, int stride, uint8_t* masks, uint64_t* rng, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        input_ids[(size_t)b * stride] = out_ids[b];
+        if (masks) masks[b] = 0;
+    }
+    if (b == 0 && rng) *rng += 1;
+}
+
+static int lm_run(vox_lm* m, hipStream_t st, const vox_lm_io* io, const int32_t* ids, const uint8_t* masks,
+                  const void* feats, const vox_rows& r, bool decode_rows, const int32_t* last_rows, int n_req,
+                  const vox_sampling_config* sc, uint64_t seed, int feedback) {
+    const vox_lm_config& c = m->cfg;
+    const int H = c.stack.hidden, n = r.n_rows;
+    VOX_TRY(vox_launch_gather(st, m->w.embedding, ids, c.ids_stride, 0, m->x, H, n, H, c.vocab_in));
+    if (c.input_mode == 1 && masks && feats)
+        hipLaunchKernelGGL(k_where_rows, dim3((H + 255) / 256, n), dim3(256), 0, st, (bf16_t*)m->x, masks, (const bf16_t*)feats, H);
+    VOX_TRY(stack_layers(m->stack, st, m->x, io->kv, io->kv_layer_stride, &r, decode_rows, n <= 8));
+    LinearCall h;   // final norm + output head
+    h.W = m->w.head_w; h.bias = m->w.head_b; h.x = m->x; h.x_rows = last_rows; h.norm_w = m->w.final_norm; h.eps = c.stack.eps;
+    h.y = io->out_logits; h.B = n_req; h.N = c.vocab_out; h.K = H; h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
+    h.fixed_order = n_req <= 8;
+    VOX_TRY(vox_launch_linear(m->ctx, st, h));
+    SampleCall s;
+    s.logits = io->out_logits; s.B = n_req; s.V = c.vocab_out; s.cfg = *sc; s.seed = seed; s.offset = 0;
+    s.offset_dev = io->rng_offset; s.offset_mul = 1; s.out_ids = io->out_ids; s.out_stride = 1; s.out_col = 0;
+    s.ws = m->ctx->samp_ws;
+    if (io->rep_cache && sc->repetition_penalty != 1.0f) { s.rep_cache = io->rep_cache; s.W = io->rep_w; s.C = 1; }
+    else s.cfg.repetition_penalty = 1.0f;
+    VOX_TRY(vox_launch_sample(st, s));
+    if (io->rep_cache && sc->repetition_penalty != 1.0f)
+        VOX_TRY(vox_launch_rep_update(st, io->rep_cache, io->out_ids, n_req, io->rep_w, 1, c.vocab_out, io->rep_window));
+    if (feedback)
+        hipLaunchKernelGGL(k_lm_feedback, dim3((n_req + 63) / 64), dim3(64), 0, st, io->out_ids, io->input_ids, c.ids_stride,
+                           c.input_mode == 1 ? io->input_masks : nullptr, io->rng_offset, n_req);
+    else if (io->rng_offset)
+        hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, io->rng_offset);
+    return VOX_OK;
+}
+
+extern "C" {
+
+int vox_lm_create(vox_ctx* ctx, const vox_lm_config* cfg, const vox_lm_weights* w, vox_lm** out) {
+    if (!ctx || !cfg || !w || !out) return vox_fail(VOX_ERR_INVALID, "lm_create: NULL argument");
+    vox_lm* m = new vox_lm();
+    m->ctx = ctx; m->cfg = *cfg; m->w = *w;
+    int s = vox_stack_create(ctx, &cfg->stack, w->layers, w->final_norm, w->rope, w->rope_max_pos, &m->stack);
+    if (s != VOX_OK) { delete m; return s; }
+    const size_t R = cfg->stack.max_rows;
+    std::vector<int32_t> iota(R);
+    for (size_t i = 0; i < R; ++i) iota[i] = (int32_t)i;
+    if (hipMalloc(&m->x, R * cfg->stack.hidden * 2) != hipSuccess || hipMalloc((void**)&m->iota, R * 4) != hipSuccess)
+        return vox_fail(VOX_ERR_NOMEM, "lm_create: hipMalloc failed");
+    VOX_HIP(hipMemcpy(m->iota, iota.data(), R * 4, hipMemcpyHostToDevice));
+    *out = m;
+    return VOX_OK;
+}
+void vox_lm_destroy(vox_lm* m) {
+    if (!m) return;
+    vox_stack_destroy(m->stack);
+    (void)hipFree(m->x); (void)hipFree(m->iota);
+    delete m;
+}
+int vox_lm_frame(vox_lm* m, void* stream, const vox_lm_io* io, int B, int max_kvlen, const vox_sampling_config* sc,
+                 uint64_t seed, int feedback) {
+    if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "lm_frame: NULL");
+    if (B < 1 || B > m->cfg.max_batch) return vox_fail(VOX_ERR_INVALID, "lm_frame: batch %d > max_batch", B);
+    vox_rows r{};
+    r.pos = io->pos; r.q_req = m->iota; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
+    r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = B; r.max_kvlen = max_kvlen;
+    r.page_table = io->page_table; r.pt_stride = (int32_t)io->pt_stride;
+    return lm_run(m, (hipStream_t)stream, io, io->input_ids, io->input_masks, io->input_features, r, true, nullptr, B, sc,
+                  seed, feedback);
+}
+int vox_lm_prefill(vox_lm* m, void* stream, const vox_lm_io* io, const int32_t* row_ids, const uint8_t* row_masks,
+                   const void* row_features, const int32_t* q_req, int n_rows, const int32_t* last_rows, int n_req,
+                   int max_kvlen, const vox_sampling_config* sc, uint64_t seed, int feedback) {
+    if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "lm_prefill: NULL");
+    if (n_req < 1 || n_req > m->cfg.max_batch || n_rows > m->cfg.stack.max_rows)
+        return vox_fail(VOX_ERR_INVALID, "lm_prefill: n_req %d / n_rows %d out of range", n_req, n_rows);
+    vox_rows r{};
+    r.pos = io->pos; r.q_req = q_req; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
+    r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = n_rows; r.max_kvlen = max_kvlen;
+    return lm_run(m, (hipStream_t)stream, io, row_ids, row_masks, row_features, r, false, last_rows, n_req, sc, seed, feedback);
 }
 
 }  // extern "C"

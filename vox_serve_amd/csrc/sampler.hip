@@ -6,6 +6,7 @@
 #include "vox_internal.h"
 
 #define SAMP_KMAX 256
+#define SAMP_LDS_VMAX 32768
 
 __device__ __forceinline__ u32 key_of(bf16_t b) {
     if (b == 0x8000) b = 0;  // -0 == +0
@@ -40,6 +41,8 @@ struct SampArgs {
     long emb_dst_stride;
     float top_p, min_p, temperature, penalty;
     int V, n_suppress, W, C, greedy, top_k, out_stride, out_col, emb_vocab, H, feat_init;
+    u32* ws_hist;        // [rows][65536], all-zero between launches (bucket mode)
+    uint16_t* ws_keys;   // [rows][SAMP_WS_VMAX] (bucket mode; top-k mode when V > 32768)
 };
 
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
@@ -50,6 +53,49 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
         v = o > v ? o : v;
     }
     return v;
+}
+
+// write the sampled id and (optionally) gather its embedding row / accumulate the next-frame feature
+__device__ __forceinline__ void emit_pick(const SampArgs& a, int b, int picked, int tid, int nthr) {
+    if (tid == 0) a.out_ids[(size_t)b * a.out_stride + a.out_col] = picked;
+    if (a.emb_table) {
+        int id = picked < 0 ? 0 : (picked >= a.emb_vocab ? a.emb_vocab - 1 : picked);
+        const uint4* src = reinterpret_cast<const uint4*>(a.emb_table + (size_t)id * a.H);
+        uint4* dst = a.emb_dst ? reinterpret_cast<uint4*>(a.emb_dst + (size_t)b * a.emb_dst_stride) : nullptr;
+        uint4* fa = a.feat_acc ? reinterpret_cast<uint4*>(a.feat_acc + (size_t)b * a.H) : nullptr;
+        for (int i = tid; i < (a.H >> 3); i += nthr) {
+            const uint4 e = src[i];
+            if (dst) dst[i] = e;
+            if (fa) {
+                uint4 f = a.feat_init ? make_uint4(0, 0, 0, 0) : fa[i];
+                uint4 o;
+                o.x = (u32)f2bf(bflo(f.x) + bflo(e.x)) | ((u32)f2bf(bfhi(f.x) + bfhi(e.x)) << 16);
+                o.y = (u32)f2bf(bflo(f.y) + bflo(e.y)) | ((u32)f2bf(bfhi(f.y) + bfhi(e.y)) << 16);
+                o.z = (u32)f2bf(bflo(f.z) + bflo(e.z)) | ((u32)f2bf(bfhi(f.z) + bfhi(e.z)) << 16);
+                o.w = (u32)f2bf(bflo(f.w) + bflo(e.w)) | ((u32)f2bf(bfhi(f.w) + bfhi(e.w)) << 16);
+                fa[i] = o;
+            }
+        }
+    }
+}
+
+// suppress mask + repetition penalty, in place on the row (sampling.py:101-127, qwen3_tts.py:1894-1895)
+__device__ __forceinline__ void preprocess_row(const SampArgs& a, bf16_t* lg, int b, int tid, int nthr) {
+    if (a.n_suppress > 0) {
+        for (int j = tid; j < a.n_suppress; j += nthr) lg[a.suppress_ids[j]] = 0xFF7F;
+        __syncthreads();
+    }
+    if (a.rep_cache && a.penalty != 1.0f) {
+        for (int v = tid; v < a.V; v += nthr) {
+            int m = 0;
+            for (int w = 0; w < a.W; ++w) m |= a.rep_cache[(((size_t)b * a.W + w) * a.C) * a.V + v];
+            if (m) {
+                const float l = bf2f(lg[v]);
+                lg[v] = f2bf(l > 0.0f ? l / a.penalty : l * a.penalty);
+            }
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
@@ -66,21 +112,7 @@ __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
     const int V = a.V;
     bf16_t* lg = a.logits + (size_t)b * V;
 
-    if (a.n_suppress > 0) {
-        for (int j = tid; j < a.n_suppress; j += 256) lg[a.suppress_ids[j]] = 0xFF7F;
-        __syncthreads();
-    }
-    if (a.rep_cache && a.penalty != 1.0f) {
-        for (int v = tid; v < V; v += 256) {
-            int m = 0;
-            for (int w = 0; w < a.W; ++w) m |= a.rep_cache[(((size_t)b * a.W + w) * a.C) * V + v];
-            if (m) {
-                const float l = bf2f(lg[v]);
-                lg[v] = f2bf(l > 0.0f ? l / a.penalty : l * a.penalty);
-            }
-        }
-        __syncthreads();
-    }
+    preprocess_row(a, lg, b, tid, 256);
 
     int picked;
     if (a.greedy) {
@@ -96,7 +128,7 @@ __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
         for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
         picked = (int)(0xFFFFFFFFu - (u32)m);
     } else {
-        uint16_t* keys = reinterpret_cast<uint16_t*>(smem);
+        uint16_t* keys = V <= SAMP_LDS_VMAX ? reinterpret_cast<uint16_t*>(smem) : a.ws_keys + (size_t)b * SAMP_WS_VMAX;
         const int k = a.top_k < V ? a.top_k : V;
         hist[tid] = 0;
         __syncthreads();
@@ -105,6 +137,7 @@ __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
             keys[v] = (uint16_t)ky;
             atomicAdd(&hist[ky >> 8], 1);
         }
+        __threadfence_block();   // keys may live in global scratch (V > SAMP_LDS_VMAX)
         __syncthreads();
         if (tid == 0) {
             int cum = 0, b1 = 255;
@@ -222,33 +255,233 @@ __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
         __syncthreads();
         picked = sh_i[7];
     }
-    if (tid == 0) a.out_ids[(size_t)b * a.out_stride + a.out_col] = picked;
+    emit_pick(a, b, picked, tid, 256);
+}
 
-    if (a.emb_table) {
-        int id = picked < 0 ? 0 : (picked >= a.emb_vocab ? a.emb_vocab - 1 : picked);
-        const uint4* src = reinterpret_cast<const uint4*>(a.emb_table + (size_t)id * a.H);
-        uint4* dst = a.emb_dst ? reinterpret_cast<uint4*>(a.emb_dst + (size_t)b * a.emb_dst_stride) : nullptr;
-        uint4* fa = a.feat_acc ? reinterpret_cast<uint4*>(a.feat_acc + (size_t)b * a.H) : nullptr;
-        for (int i = tid; i < (a.H >> 3); i += 256) {
-            const uint4 e = src[i];
-            if (dst) dst[i] = e;
-            if (fa) {
-                uint4 f = a.feat_init ? make_uint4(0, 0, 0, 0) : fa[i];
-                uint4 o;
-                o.x = (u32)f2bf(bflo(f.x) + bflo(e.x)) | ((u32)f2bf(bfhi(f.x) + bfhi(e.x)) << 16);
-                o.y = (u32)f2bf(bflo(f.y) + bflo(e.y)) | ((u32)f2bf(bfhi(f.y) + bfhi(e.y)) << 16);
-                o.z = (u32)f2bf(bflo(f.z) + bflo(e.z)) | ((u32)f2bf(bfhi(f.z) + bfhi(e.z)) << 16);
-                o.w = (u32)f2bf(bflo(f.w) + bflo(e.w)) | ((u32)f2bf(bfhi(f.w) + bfhi(e.w)) << 16);
-                fa[i] = o;
+// ---- full-vocabulary ("bucket") mode: top-p-only / min-p-only over any V -------------------------
+// Contract: oracle/voxref.c::sample_bucket / bk_find.  One 1024-thread block per row.  The 65536-bin key
+// histogram lives in a per-context global scratch (L2-resident, 256 KiB per row) that is all-zero between
+// launches; the sortable keys are kept beside it so later passes do not redo the temperature division.
+struct BK {
+    const u32* hist;
+    float m, min_cut;
+    int lim_key;
+    u32 lim_cnt;
+};
+__device__ __forceinline__ u32 ld_l2(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float bk_p(const BK& c, u32 key) { return exp2_c((bf2f(bits_of(key)) - c.m) * VOX_LOG2E); }
+__device__ __forceinline__ u32 bk_count(const BK& c, u32 key, u32 raw) {
+    if ((int)key < c.lim_key) return 0;
+    return (int)key == c.lim_key ? c.lim_cnt : raw;
+}
+__device__ __forceinline__ float bk_mass(const BK& c, u32 key, u32 n) {
+    if (!n) return 0.0f;
+    const float p = bk_p(c, key);
+    if (c.min_cut > 0.0f && p < c.min_cut) return 0.0f;
+    return (float)n * p;
+}
+__device__ __forceinline__ bool bk_cmp(float a, float thr, int strict) { return strict ? a > thr : a >= thr; }
+
+struct BKShared {
+    float Cc[256];   // coarse masses of the current (possibly restricted) histogram
+    u32 fcnt[256];   // counts of the bin being searched
+    float fm[256];   // masses of the bin being searched
+    int hf, whole, kp;
+    u32 j;
+    float acc, tot;
+};
+
+// all threads of the block call this; result in S.kp / S.j / S.tot
+__device__ void bk_find_blk(const BK& c, float thr, int strict, BKShared& S, int tid) {
+    if (tid == 0) {
+        float acc = 0.0f;
+        int hf = -1, last_h = -1;
+        for (int h = 255; h >= 0; --h) {
+            const float ch = S.Cc[h];
+            if (ch > 0.0f) {
+                last_h = h;
+                if (bk_cmp(acc + ch, thr, strict)) {
+                    hf = h;
+                    break;
+                }
+            }
+            acc = acc + ch;
+        }
+        S.whole = 0;
+        if (hf < 0) {
+            hf = last_h;
+            S.whole = 1;
+            acc = 0.0f;
+        }
+        S.hf = hf;
+        S.acc = acc;
+    }
+    __syncthreads();
+    const int hf = S.hf;
+    if (tid < 256) {
+        const u32 key = (u32)(hf << 8 | tid);
+        const u32 n = bk_count(c, key, ld_l2(c.hist + key));
+        S.fcnt[tid] = n;
+        S.fm[tid] = bk_mass(c, key, n);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float acc2 = S.acc;
+        int kp = -1, last_k = -1;
+        const int whole = S.whole;
+        for (int f = 255; f >= 0; --f) {
+            const float mk = S.fm[f];
+            if (mk > 0.0f) {
+                last_k = hf << 8 | f;
+                if (!whole && bk_cmp(acc2 + mk, thr, strict)) {
+                    kp = hf << 8 | f;
+                    break;
+                }
+                acc2 = acc2 + mk;
             }
         }
+        if (kp < 0) {
+            S.kp = last_k;
+            S.j = S.fcnt[last_k & 255];
+            S.tot = acc2;
+        } else {
+            const u32 n = S.fcnt[kp & 255];
+            u32 lo = 1, hi = n;
+            const float p = bk_p(c, (u32)kp);
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (bk_cmp(acc2 + (float)mid * p, thr, strict)) hi = mid;
+                else lo = mid + 1;
+            }
+            S.kp = kp;
+            S.j = lo;
+            S.tot = acc2 + (float)lo * p;
+        }
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_sample_bucket(SampArgs a) {
+    __shared__ u32 tile[256][33];
+    __shared__ BKShared S;
+    __shared__ u32 wred[16];
+    __shared__ int sh_pick;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = a.V;
+    bf16_t* lg = a.logits + (size_t)b * V;
+    u32* hist = a.ws_hist + (size_t)b * 65536;
+    uint16_t* keys = a.ws_keys + (size_t)b * SAMP_WS_VMAX;
+
+    preprocess_row(a, lg, b, tid, 1024);
+
+    // pass 1: keys, histogram, largest key
+    u32 kmx = 0;
+    for (int v = tid; v < V; v += 1024) {
+        const u32 ky = key_of(f2bf(bf2f(lg[v]) / a.temperature));
+        keys[v] = (uint16_t)ky;
+        atomicAdd(hist + ky, 1u);
+        kmx = ky > kmx ? ky : kmx;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const u32 o = __shfl_xor(kmx, off, VOX_WAVE);
+        kmx = o > kmx ? o : kmx;
+    }
+    if (lane == 0) wred[wave] = kmx;
+    __threadfence();
+    __syncthreads();
+    kmx = wred[0];
+    for (int w = 1; w < 16; ++w) kmx = wred[w] > kmx ? wred[w] : kmx;
+
+    BK c;
+    c.hist = hist; c.m = bf2f(bits_of(kmx)); c.min_cut = a.min_p > 0.0f ? a.min_p * 1.0f : 0.0f;
+    c.lim_key = -1; c.lim_cnt = 0;
+
+    // pass 2: coarse masses, thread h sums its 256 keys in descending order; tiles staged coalesced
+    float csum = 0.0f;
+    for (int t = 7; t >= 0; --t) {
+        __syncthreads();
+        for (int e = tid; e < 8192; e += 1024) {
+            const int h = e >> 5, f = e & 31;
+            tile[h][f] = ld_l2(hist + (h << 8) + (t << 5) + f);
+        }
+        __syncthreads();
+        if (tid < 256)
+            for (int f = 31; f >= 0; --f) csum = csum + bk_mass(c, (u32)(tid << 8 | t << 5 | f), tile[tid][f]);
+    }
+    if (tid < 256) S.Cc[tid] = csum;
+    __syncthreads();
+
+    float tot;
+    if (tid == 0) {
+        float t0 = 0.0f;
+        for (int h = 255; h >= 0; --h) t0 = t0 + S.Cc[h];
+        S.tot = t0;
+    }
+    __syncthreads();
+    tot = S.tot;
+    if (a.top_p < 1.0f) {
+        bk_find_blk(c, a.top_p * tot, 0, S, tid);
+        c.lim_key = S.kp;
+        c.lim_cnt = S.j;
+        tot = S.tot;
+        __syncthreads();
+        // restricted coarse masses: bins below the limit vanish, the limit's bin is re-summed
+        const int lh = c.lim_key >> 8;   // == S.hf: fcnt still holds that bin's raw counts
+        if (tid < 256) {
+            const u32 key = (u32)(lh << 8 | tid);
+            S.fm[tid] = bk_mass(c, key, bk_count(c, key, S.fcnt[tid]));
+            if (tid < lh) S.Cc[tid] = 0.0f;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float s2 = 0.0f;
+            for (int f = 255; f >= 0; --f) s2 = s2 + S.fm[f];
+            S.Cc[lh] = s2;
+        }
+        __syncthreads();
+    }
+    const uint64_t off = a.offset + (a.offset_dev ? (*a.offset_dev) * a.offset_mul : 0ull);
+    const float u = (float)(philox_u32(a.seed, off, (u32)b) >> 8) * (1.0f / 16777216.0f);
+    bk_find_blk(c, u * tot, 1, S, tid);
+    const u32 kp = (u32)S.kp, j = S.j;
+
+    // pass 3: the j-th element (ascending index) whose key is kp; wave w owns a contiguous index range
+    const int chunk = ((V + 15) / 16 + 63) & ~63;
+    const int lo = wave * chunk, hi = min(V, lo + chunk);
+    u32 cnt = 0;
+    for (int base = lo; base < hi; base += 64) {
+        const int v = base + lane;
+        cnt += __popcll(__ballot(v < hi && keys[v] == kp));
+    }
+    if (lane == 0) wred[wave] = cnt;
+    if (tid == 0) sh_pick = -1;
+    __syncthreads();
+    u32 before = 0;
+    for (int w = 0; w < wave; ++w) before += wred[w];
+    if (before < j && j <= before + cnt) {
+        u32 run = before;
+        for (int base = lo; base < hi; base += 64) {
+            const int v = base + lane;
+            const bool mt = v < hi && keys[v] == kp;
+            const unsigned long long bal = __ballot(mt);
+            const u32 mine = run + __popcll(bal & ((1ull << lane) - 1ull)) + 1;
+            if (mt && mine == j) sh_pick = v;
+            run += __popcll(bal);
+            if (run >= j) break;
+        }
+    }
+    // leave the histogram all-zero for the next launch
+    uint4* hz = reinterpret_cast<uint4*>(hist);
+    for (int i = tid; i < 16384; i += 1024) hz[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    emit_pick(a, b, sh_pick, tid, 1024);
 }
 
 int vox_launch_sample(hipStream_t st, const SampleCall& c) {
     if (c.B <= 0) return VOX_OK;
-    const bool greedy = c.cfg.greedy || c.cfg.temperature == 0.0f ||
-                        (c.cfg.top_k <= 0 && !(c.cfg.top_p < 1.0f) && !(c.cfg.min_p > 0.0f));
+    // top_k <= 0 with top_p >= 1 and min_p <= 0 is the full multinomial (top_p_sampling(p=1.0), sampling.py:41-52)
+    const bool greedy = c.cfg.greedy || c.cfg.temperature == 0.0f;
     SampArgs a{};
     a.logits = (bf16_t*)c.logits; a.suppress_ids = c.suppress_ids; a.rep_cache = c.rep_cache;
     a.offset_dev = c.offset_dev; a.out_ids = c.out_ids; a.emb_table = (const bf16_t*)c.emb_table;
@@ -258,14 +491,26 @@ int vox_launch_sample(hipStream_t st, const SampleCall& c) {
     a.V = c.V; a.n_suppress = c.n_suppress; a.W = c.W; a.C = c.C; a.greedy = greedy ? 1 : 0;
     a.top_k = c.cfg.top_k; a.out_stride = c.out_stride; a.out_col = c.out_col; a.emb_vocab = c.emb_vocab;
     a.H = c.H; a.feat_init = c.feat_init;
+    a.ws_hist = (u32*)c.ws;
+    a.ws_keys = c.ws ? reinterpret_cast<uint16_t*>((char*)c.ws + (size_t)SAMP_WS_ROWS * 65536 * 4) : nullptr;
+    if (c.emb_table && (c.H % 8)) return vox_fail(VOX_ERR_INVALID, "sample: H%8!=0");
     size_t smem = 0;
     if (!greedy) {
-        if (c.cfg.top_k <= 0 || c.cfg.top_k > SAMP_KMAX)
-            return vox_fail(VOX_ERR_INVALID, "sample: stochastic modes need 1 <= top_k <= %d (top_p/min_p-only not yet built)", SAMP_KMAX);
-        if (c.V > 32768) return vox_fail(VOX_ERR_INVALID, "sample: stochastic vocab > 32768 not yet built");
-        smem = (size_t)c.V * 2;
+        if (c.cfg.min_p > 1.0f) return vox_fail(VOX_ERR_INVALID, "sample: min_p > 1");
+        const bool bucket = c.cfg.top_k <= 0;
+        if (bucket || c.V > SAMP_LDS_VMAX) {
+            if (!c.ws) return vox_fail(VOX_ERR_INVALID, "sample: this mode needs the context's sampler scratch");
+            if (c.B > SAMP_WS_ROWS || c.V > SAMP_WS_VMAX)
+                return vox_fail(VOX_ERR_INVALID, "sample: B %d > %d or V %d > %d", c.B, SAMP_WS_ROWS, c.V, SAMP_WS_VMAX);
+        }
+        if (bucket) {
+            hipLaunchKernelGGL(k_sample_bucket, dim3(c.B), dim3(1024), 0, st, a);
+            return VOX_OK;
+        }
+        if (c.cfg.top_k > SAMP_KMAX)
+            return vox_fail(VOX_ERR_INVALID, "sample: top_k %d > %d", c.cfg.top_k, SAMP_KMAX);
+        smem = c.V <= SAMP_LDS_VMAX ? (size_t)c.V * 2 : 0;
     }
-    if (c.emb_table && (c.H % 8)) return vox_fail(VOX_ERR_INVALID, "sample: H%8!=0");
     hipLaunchKernelGGL(k_sample, dim3(c.B), dim3(256), smem, st, a);
     return VOX_OK;
 }

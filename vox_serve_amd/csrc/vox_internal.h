@@ -26,7 +26,12 @@ struct vox_ctx {
     int device;
     int n_cu;
     int64_t lds_bytes, hbm_bytes;
+    void* samp_ws;   // sampler scratch: SAMP_WS_ROWS x (65536 u32 histogram, all-zero between launches) + keys
 };
+// sampler scratch geometry (sampler.hip): one LM stream per context uses it at a time
+#define SAMP_WS_ROWS 64
+#define SAMP_WS_VMAX 262144
+#define SAMP_WS_BYTES ((size_t)SAMP_WS_ROWS * (65536 * 4 + SAMP_WS_VMAX * 2))
 
 struct vox_graph {
     hipGraph_t graph;
@@ -110,6 +115,7 @@ struct SampleCall {
     long emb_dst_stride = 0;
     void* feat_acc = nullptr;          // [B,H] bf16: feat = bf16(feat + emb) (qwen3_tts.py:2002)
     int feat_init = 0;                 // 1: feat = emb' where emb' = bf16(0 + emb)
+    void* ws = nullptr;                // ctx->samp_ws (needed by top-p/min-p-only modes and V > 32768)
 };
 int vox_launch_sample(hipStream_t st, const SampleCall& c);
 int vox_launch_suppress(hipStream_t st, void* logits, int B, int V, const int* ids, int n);

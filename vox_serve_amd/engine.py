@@ -229,8 +229,7 @@ class Qwen3Engine:
     def _frame_on_stream(self, batch, bucket, sampling, seed, feedback, use_graph):
         if not use_graph:
             io = self._io()
-            N.check(self.L.vox_qwen3_frame(self.h, N.stream(), ctypes.byref(io), batch, bucket, ctypes.byref(sampling),
-                                           seed, int(feedback)))
+            self._native_frame(io, N.stream(), batch, bucket, sampling, seed, feedback)
             return
         key = (batch, bucket, bytes(sampling), seed, bool(feedback), self.keep_hidden)
         g = self._graphs.get(key)
@@ -238,17 +237,16 @@ class Qwen3Engine:
             io = self._io()
             st = N.stream()
             # warm-up outside capture (sets kernel attributes), on a scratch copy of the mutable state
-            saved = [x.clone() for x in (self.input_ids, self.input_masks, self.input_features, self.rng_offset)]
-            N.check(self.L.vox_qwen3_frame(self.h, st, ctypes.byref(io), batch, bucket, ctypes.byref(sampling), seed,
-                                           int(feedback)))
+            state = self._mutable_state()
+            saved = [x.clone() for x in state]
+            self._native_frame(io, st, batch, bucket, sampling, seed, feedback)
             torch.cuda.current_stream().synchronize()
-            for dst, src in zip((self.input_ids, self.input_masks, self.input_features, self.rng_offset), saved):
+            for dst, src in zip(state, saved):
                 dst.copy_(src)
             torch.cuda.current_stream().synchronize()
             N.check(self.L.vox_graph_begin(self.ctx, st))
             try:
-                N.check(self.L.vox_qwen3_frame(self.h, st, ctypes.byref(io), batch, bucket, ctypes.byref(sampling),
-                                               seed, int(feedback)))
+                self._native_frame(io, st, batch, bucket, sampling, seed, feedback)
             finally:
                 gh = ctypes.c_void_p()
                 N.check(self.L.vox_graph_end(self.ctx, st, ctypes.byref(gh)))
@@ -261,18 +259,154 @@ class Qwen3Engine:
         with self._OnStream(self):
             self._prefill_on_stream(n_rows, n_req, max_kvlen, sampling, seed, feedback)
 
+    def _mutable_state(self):
+        return [self.input_ids, self.input_masks, self.input_features, self.rng_offset]
+
+    def _native_frame(self, io, st, batch, bucket, sampling, seed, feedback):
+        N.check(self.L.vox_qwen3_frame(self.h, st, ctypes.byref(io), batch, bucket, ctypes.byref(sampling), seed,
+                                       int(feedback)))
+
+    def _native_prefill(self, *args):
+        N.check(self.L.vox_qwen3_prefill(*args))
+
+    def _native_destroy(self):
+        self.L.vox_qwen3_destroy(self.h)
+
     def _prefill_on_stream(self, n_rows, n_req, max_kvlen, sampling, seed, feedback):
         io = self._io()
-        N.check(self.L.vox_qwen3_prefill(self.h, N.stream(), ctypes.byref(io), self.row_ids.data_ptr(),
+        self._native_prefill(self.h, N.stream(), ctypes.byref(io), self.row_ids.data_ptr(),
                                          self.row_masks.data_ptr(), self.row_feats.data_ptr(),
                                          self._pd("q_req").data_ptr(), n_rows, self._pd("last_rows").data_ptr(), n_req,
                                          min(max(32, max_kvlen), self.max_seq_len), ctypes.byref(sampling), seed,
-                                         int(feedback)))
+                                         int(feedback))
 
     def close(self):
         for g in self._graphs.values():
             self.L.vox_graph_destroy(g)
         self._graphs.clear()
         if self.h:
-            self.L.vox_qwen3_destroy(self.h)
+            self._native_destroy()
             self.h = None
+
+
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class LMCfg:
+    """Single-stack speech LM (GLM-4-Voice, CosyVoice2 LLM, ...)."""
+    stack: StackCfg
+    vocab_in: int
+    vocab_out: int
+    n_codebooks: int = 1
+    input_mode: int = 0          # 1: x = mask ? input_features : embedding[id]   (cosyvoice2.py:1020-1024)
+    max_pos: int = 4096
+
+
+class LMIO(ctypes.Structure):
+    _fields_ = [("input_ids", ctypes.c_void_p), ("input_masks", ctypes.c_void_p), ("input_features", ctypes.c_void_p),
+                ("pos", ctypes.c_void_p), ("kvlen", ctypes.c_void_p), ("page", ctypes.c_void_p), ("slot", ctypes.c_void_p),
+                ("kv_indptr", ctypes.c_void_p), ("kv_indices", ctypes.c_void_p), ("page_table", ctypes.c_void_p),
+                ("pt_stride", ctypes.c_int64), ("kv", ctypes.c_void_p), ("kv_layer_stride", ctypes.c_int64),
+                ("out_ids", ctypes.c_void_p), ("out_logits", ctypes.c_void_p), ("rep_cache", ctypes.c_void_p),
+                ("rep_w", ctypes.c_int32), ("rep_window", ctypes.c_int32), ("rng_offset", ctypes.c_void_p)]
+
+
+class LMConfigC(ctypes.Structure):
+    _fields_ = [("stack", N.StackConfig), ("vocab_in", ctypes.c_int32), ("vocab_out", ctypes.c_int32),
+                ("ids_stride", ctypes.c_int32), ("input_mode", ctypes.c_int32), ("max_batch", ctypes.c_int32)]
+
+
+class LMWeightsC(ctypes.Structure):
+    _fields_ = [("layers", ctypes.POINTER(N.LayerWeights)), ("final_norm", ctypes.c_void_p), ("embedding", ctypes.c_void_p),
+                ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p), ("rope", ctypes.c_void_p),
+                ("rope_max_pos", ctypes.c_int32)]
+
+
+class LMEngine(Qwen3Engine):
+    """Host side of `vox_lm_*`: same plan / stream / hipGraph machinery as Qwen3Engine, one decoder stack.
+    `layers`: list of dicts with keys wqkv,bqkv,wo,wgate,wup,wdown,ln1,ln2 (+qnorm,knorm) -> bf16 tensors."""
+
+    def __init__(self, cfg: LMCfg, layers, final_norm, embedding, head_w, head_b=None, max_batch=8, page_size=128,
+                 max_pages=256, max_seq_len=2304, max_prefill_rows=1024, rep_window=None, device="cuda"):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.max_batch, self.page_size, self.max_pages, self.max_seq_len = max_batch, page_size, max_pages, max_seq_len
+        self.L, self.ctx = N.lib(), N.ctx()
+        L = self.L
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        L.vox_lm_create.restype, L.vox_lm_create.argtypes = ci, [vp, ctypes.POINTER(LMConfigC), ctypes.POINTER(LMWeightsC), ctypes.POINTER(vp)]
+        L.vox_lm_destroy.restype, L.vox_lm_destroy.argtypes = None, [vp]
+        L.vox_lm_frame.restype, L.vox_lm_frame.argtypes = ci, [vp, vp, ctypes.POINTER(LMIO), ci, ci, ctypes.POINTER(N.SamplingCfg), ctypes.c_uint64, ci]
+        L.vox_lm_prefill.restype, L.vox_lm_prefill.argtypes = ci, [vp, vp, ctypes.POINTER(LMIO), vp, vp, vp, vp, ci, vp, ci, ci, ctypes.POINTER(N.SamplingCfg), ctypes.c_uint64, ci]
+        dev, c = self.device, cfg.stack
+        self._keep = []
+        arr = (N.LayerWeights * c.layers)()
+        for i, lw in enumerate(layers):
+            for k, t in lw.items():
+                if t is not None:
+                    t = t.to(dev).contiguous()
+                    self._keep.append(t)
+                    setattr(arr[i], k, t.data_ptr())
+        self.rope = rope_table(cfg.max_pos, c, dev)
+        self.max_rows = max(max_prefill_rows, max_batch)
+        keep = lambda t: (self._keep.append(t.to(dev).contiguous()) or self._keep[-1].data_ptr()) if t is not None else None
+        cc = LMConfigC(_stack_config(c, page_size, self.max_rows, max_seq_len), cfg.vocab_in, cfg.vocab_out, cfg.n_codebooks,
+                       cfg.input_mode, max_batch)
+        cw = LMWeightsC(ctypes.cast(arr, ctypes.POINTER(N.LayerWeights)), keep(final_norm), keep(embedding), keep(head_w),
+                        keep(head_b), self.rope.data_ptr(), cfg.max_pos)
+        self._arr = arr
+        h = ctypes.c_void_p()
+        N.check(L.vox_lm_create(self.ctx, ctypes.byref(cc), ctypes.byref(cw), ctypes.byref(h)))
+        self.h = h
+        i32 = dict(dtype=torch.int32, device=dev)
+        R, H, C = self.max_rows, c.hidden, cfg.n_codebooks
+        self.input_ids = torch.zeros(max_batch, C, **i32)
+        self.input_masks = torch.zeros(max_batch, dtype=torch.uint8, device=dev)
+        self.input_features = torch.zeros(max_batch, H, dtype=torch.bfloat16, device=dev)
+        self.pt_stride = (max_seq_len + page_size - 1) // page_size + 1
+        self._plan_layout, off = {}, 0
+        for name, n in (("pos", R), ("kvlen", R), ("page", R), ("slot", R), ("q_req", R), ("last_rows", max_batch),
+                        ("indptr", max_batch + 1), ("indices", max_pages), ("ptab", max_batch * self.pt_stride)):
+            self._plan_layout[name] = (off, n)
+            off += n
+        self.plan_dev = torch.zeros(off, **i32)
+        self.plan_host = torch.zeros(off, dtype=torch.int32).pin_memory()
+        self.kv = torch.zeros(c.layers, max_pages, 2, page_size, c.kv_heads, c.head_dim, dtype=torch.bfloat16, device=dev)
+        self.out_ids = torch.zeros(max_batch, **i32)
+        self.out_logits = torch.zeros(max_batch, cfg.vocab_out, dtype=torch.bfloat16, device=dev)
+        self.rep_window = rep_window
+        self.rep_cache = None
+        if rep_window is not None:
+            self.rep_w = rep_window if rep_window > 0 else 1
+            self.rep_cache = torch.zeros(max_batch, self.rep_w, 1, cfg.vocab_out, dtype=torch.uint8, device=dev)
+        self.rng_offset = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.row_ids = torch.zeros(R, C, **i32)
+        self.row_masks = torch.zeros(R, dtype=torch.uint8, device=dev)
+        self.row_feats = torch.zeros(R, H, dtype=torch.bfloat16, device=dev)
+        self._graphs, self.keep_hidden = {}, False
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def _io(self):
+        return LMIO(self.input_ids.data_ptr(), self.input_masks.data_ptr(), self.input_features.data_ptr(),
+                    self._pd("pos").data_ptr(), self._pd("kvlen").data_ptr(), self._pd("page").data_ptr(),
+                    self._pd("slot").data_ptr(), self._pd("indptr").data_ptr(), self._pd("indices").data_ptr(),
+                    self._pd("ptab").data_ptr(), self.pt_stride, self.kv.data_ptr(), self.kv[0].numel(),
+                    self.out_ids.data_ptr(), self.out_logits.data_ptr(),
+                    self.rep_cache.data_ptr() if self.rep_cache is not None else None,
+                    self.rep_w if self.rep_cache is not None else 0, self.rep_window or 0, self.rng_offset.data_ptr())
+
+    def _mutable_state(self):
+        st = [self.input_ids, self.input_masks, self.rng_offset]
+        return st + ([self.rep_cache] if self.rep_cache is not None else [])
+
+    def _native_frame(self, io, st, batch, bucket, sampling, seed, feedback):
+        N.check(self.L.vox_lm_frame(self.h, st, ctypes.byref(io), batch, bucket, ctypes.byref(sampling), seed, int(feedback)))
+
+    def _native_prefill(self, *args):
+        N.check(self.L.vox_lm_prefill(*args))
+
+    def _native_destroy(self):
+        self.L.vox_lm_destroy(self.h)
+
+    @staticmethod
+    def sampling_cfg(greedy=True, top_k=0, top_p=1.0, min_p=0.0, temperature=1.0, repetition_penalty=1.0):
+        return N.SamplingCfg(int(greedy), int(top_k or 0), float(1.0 if top_p is None else top_p), float(min_p or 0.0),
+                             float(temperature), float(repetition_penalty or 1.0))

@@ -47,6 +47,35 @@ def _qwen3(model_name, device="cuda:0", weights=None, codec_weights=None, checkp
     return Qwen3TTSModel(model_name, weights, codec_weights, device=device, tts_model_type=mtype, **kw)
 
 
+def _single_stack(model_name, cls_path, cfg_path, synth_name, device, weights, checkpoint_dir, synthetic, kw):
+    import importlib
+    mod = importlib.import_module(cls_path[0], __package__)
+    cls, cfg_cls = getattr(mod, cls_path[1]), getattr(mod, cfg_path)
+    config = kw.pop("config", None) or cfg_cls()
+    if weights is None:
+        if checkpoint_dir is not None:
+            weights = _load_safetensors_dir(checkpoint_dir, device)
+        elif synthetic:
+            from .. import synth
+            weights = getattr(synth, synth_name)(config, device)
+        else:
+            raise FileNotFoundError("no checkpoint_dir given (offline box): pass checkpoint_dir=... or synthetic=True")
+    kw.pop("detokenize_interval", None)
+    return cls(model_name, weights, config=config, device=device, **kw)
+
+
+@register_model("glm", "zai-org/glm-4-voice-9b")
+def _glm(model_name, device="cuda:0", weights=None, checkpoint_dir=None, synthetic=False, **kw):
+    return _single_stack(model_name, (".glm_voice", "GLMVoiceModel"), "GLMVoiceConfig", "synth_glm_weights", device,
+                         weights, checkpoint_dir, synthetic, kw)
+
+
+@register_model("cosyvoice2", "FunAudioLLM/CosyVoice2-0.5B")
+def _cosyvoice2(model_name, device="cuda:0", weights=None, checkpoint_dir=None, synthetic=False, **kw):
+    return _single_stack(model_name, (".cosyvoice2", "CosyVoice2Model"), "CosyVoice2Config", "synth_cosyvoice2_weights",
+                         device, weights, checkpoint_dir, synthetic, kw)
+
+
 def load_model(model_name: str, device: str = "cuda", top_p=None, top_k=None, min_p=None, temperature=None,
                max_tokens=None, repetition_penalty=None, repetition_window=None, cfg_scale=None, greedy=False,
                enable_torch_compile=False, audio_decoder_device=None, detokenize_interval=None, **kw):

@@ -86,3 +86,52 @@ def synth_qwen3_codec_weights(cfg=None, seed=0):
                 t = t * 0.1
         W[k] = t.to(torch.bfloat16).float()
     return W
+
+
+def _gen(device, seed, std):
+    g = torch.Generator(device=device).manual_seed(seed)
+    w = lambda *shape: (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(torch.bfloat16)
+    ones = lambda n: torch.ones(n, device=device, dtype=torch.bfloat16)
+    return w, ones
+
+
+def synth_glm_weights(c, device, seed=0, std=0.02):
+    """Random-init GLM-4-Voice state_dict (reference names, glm_voice.py:85-305); c: model.glm_voice.GLMVoiceConfig."""
+    w, ones = _gen(device, seed, std)
+    d = c.hidden_size // c.num_attention_heads
+    qkv = c.hidden_size + 2 * d * c.multi_query_group_num
+    W = {"transformer.embedding.word_embeddings.weight": w(c.padded_vocab_size, c.hidden_size),
+         "transformer.encoder.final_layernorm.weight": ones(c.hidden_size),
+         "transformer.output_layer.weight": w(c.padded_vocab_size, c.hidden_size)}
+    for i in range(c.num_layers):
+        p = f"transformer.encoder.layers.{i}."
+        W[p + "self_attention.query_key_value.weight"] = w(qkv, c.hidden_size)
+        W[p + "self_attention.query_key_value.bias"] = w(qkv)
+        W[p + "self_attention.dense.weight"] = w(c.hidden_size, c.hidden_size)
+        W[p + "mlp.dense_h_to_4h.weight"] = w(2 * c.ffn_hidden_size, c.hidden_size)
+        W[p + "mlp.dense_4h_to_h.weight"] = w(c.hidden_size, c.ffn_hidden_size)
+        W[p + "input_layernorm.weight"] = ones(c.hidden_size)
+        W[p + "post_attention_layernorm.weight"] = ones(c.hidden_size)
+    return W
+
+
+def synth_cosyvoice2_weights(c, device, seed=0, std=0.02):
+    """Random-init CosyVoice2 LLM state_dict (reference names, cosyvoice2.py:106-316); c: CosyVoice2Config."""
+    w, ones = _gen(device, seed, std)
+    H, d = c.hidden_size, c.hidden_size // c.num_attention_heads
+    V = c.speech_token_size + 3
+    W = {"llm.model.model.embed_tokens.weight": w(c.vocab_size, H), "llm.model.model.norm.weight": ones(H),
+         "llm_embedding.weight": w(2, H), "llm_decoder.weight": w(V, H), "llm_decoder.bias": w(V),
+         "speech_embedding.weight": w(V, H)}
+    for i in range(c.num_hidden_layers):
+        p = f"llm.model.model.layers.{i}."
+        for n, rows in (("q", c.num_attention_heads), ("k", c.num_key_value_heads), ("v", c.num_key_value_heads)):
+            W[p + f"self_attn.{n}_proj.weight"] = w(rows * d, H)
+            W[p + f"self_attn.{n}_proj.bias"] = w(rows * d)
+        W[p + "self_attn.o_proj.weight"] = w(H, c.num_attention_heads * d)
+        W[p + "mlp.gate_proj.weight"] = w(c.intermediate_size, H)
+        W[p + "mlp.up_proj.weight"] = w(c.intermediate_size, H)
+        W[p + "mlp.down_proj.weight"] = w(H, c.intermediate_size)
+        W[p + "input_layernorm.weight"] = ones(H)
+        W[p + "post_attention_layernorm.weight"] = ones(H)
+    return W

@@ -54,6 +54,7 @@ class ModelWorker:
         self.needs_watermarking = getattr(model, "needs_watermarking", False)
         self.has_depth_transformer = getattr(model, "has_depth_transformer", False)
         self._resident = None        # request ids whose next inputs already sit in the engine's rows (feedback path)
+        self._resident_reqs = []     # ... and the requests themselves (their repetition-cache rows live in the engine)
         self._next_feats = None
 
     # ---- properties read by schedulers (scheduler/base.py:127, 243-245) ----
@@ -160,7 +161,10 @@ class ModelWorker:
 
     # -------------------------------------------------------------------------------------------------
     def _sampling(self):
-        return native_config(self.model.default_sampling_config)
+        cfg = native_config(self.model.default_sampling_config)
+        if getattr(self.model.engine, "rep_cache", None) is not None:       # persisted caches: the penalty is live
+            cfg.repetition_penalty = float(self.model.default_sampling_config.repetition_penalty)
+        return cfg
 
     def _token_plan(self, lm_inputs: LMInputs):
         """Per-row (request, visible kv length, page, slot) exactly as FlashInferPrefillWrapper.plan derives them
@@ -188,8 +192,11 @@ class ModelWorker:
             raise RuntimeError(f"No suitable prefill graph found for batch_size={n_req}, seq_len={n_rows}")
         q_req, kvlen, page, slot = self._token_plan(lm_inputs)
         e.row_ids[:n_rows].copy_(lm_inputs["input_ids"].to(torch.int32))
-        e.row_masks[:n_rows].copy_(lm_inputs["input_masks"][:, -1].to(torch.uint8))
-        self._stage_features(lm_inputs["input_features"], e.row_feats)
+        if lm_inputs["input_masks"] is not None:
+            e.row_masks[:n_rows].copy_(lm_inputs["input_masks"][:, -1].to(torch.uint8))
+        if lm_inputs["input_features"] is not None:
+            self._stage_features(lm_inputs["input_features"], e.row_feats)
+        self._stage_repetition(requests, e)
         qo = lm_inputs["qo_indptr"]
         e.upload_plan(pos=lm_inputs["position_ids"].numpy(), kvlen=kvlen, page=page, slot=slot, q_req=q_req,
                       last_rows=[q - 1 for q in qo[1:]], indptr=lm_inputs["paged_kv_indptr"],
@@ -206,8 +213,11 @@ class ModelWorker:
         ids = [r.request_id for r in requests]
         if self._resident != ids:        # batch composition changed: restage the per-request inputs
             e.input_ids[:B].copy_(lm_inputs["input_ids"].to(torch.int32))
-            e.input_masks[:B].copy_(lm_inputs["input_masks"][:, -1].to(torch.uint8))
-            self._stage_features(lm_inputs["input_features"], e.input_features)
+            if lm_inputs["input_masks"] is not None:
+                e.input_masks[:B].copy_(lm_inputs["input_masks"][:, -1].to(torch.uint8))
+            if lm_inputs["input_features"] is not None:
+                self._stage_features(lm_inputs["input_features"], e.input_features)
+            self._stage_repetition(requests, e)
         e.upload_plan(pos=lm_inputs["position_ids"].numpy(), kvlen=[r.kv_token_len for r in requests],
                       page=[r.kv_pages[-1] for r in requests], slot=[r.kv_last_page_len - 1 for r in requests],
                       indptr=lm_inputs["paged_kv_indptr"], indices=lm_inputs["paged_kv_indices"])
@@ -215,11 +225,32 @@ class ModelWorker:
         self._after_frame(requests)
         return None
 
+    def _stage_repetition(self, requests: List[Request], e):
+        """Per-request repetition caches live in the engine's rows while a batch is resident; when the batch changes the
+        old rows go back to their requests and the new ones are copied in (the reference re-stacks them every step:
+        worker/base.py:344-347, and stores the rows back after sampling: glm_voice.py:585-588)."""
+        rc = getattr(e, "rep_cache", None)
+        if rc is None:
+            return
+        for i, req in enumerate(self._resident_reqs):
+            if req.repetition_cache is not None and not req.done_all:
+                req.repetition_cache = rc[i].to(torch.bool)
+        for i, req in enumerate(requests):
+            if req.repetition_cache is not None:
+                rc[i].copy_(req.repetition_cache.to(rc.device, torch.uint8))
+        self._resident_reqs = []
+
     def _after_frame(self, requests: List[Request]):
-        """The request-state half of Qwen3TTSModel.sampling + depth_sampling (qwen3_tts.py:1931-1962, 1995-2002)."""
+        """The request-state half of the plugin's `sampling` (+ `depth_sampling`), once per frame on one D2H copy."""
         e, m = self.model.engine, self.model
         B = len(requests)
         out = e.out_ids[:B].cpu().to(torch.long)                      # the one synchronisation of the step
+        self._resident = [r.request_id for r in requests]
+        self._resident_reqs = list(requests)
+        if hasattr(m, "update_requests"):                              # single-stack families
+            m.update_requests(requests, out.view(B, -1))
+            return
+        # Qwen3-TTS: qwen3_tts.py:1931-1962, 1995-2002
         feats = e.next_features[:B].clone()
         C = m.n_codebooks
         pad = m.config.tts_pad_id
@@ -241,7 +272,6 @@ class ModelWorker:
             if req.next_position_id > m.max_tokens:
                 req.done_lm_generation = True
                 req.finish_reason = "max_tokens_reached"
-        self._resident = [r.request_id for r in requests]
 
     # -------------------------------------------------------------------------------------------------
     def run_detokenize(self, requests: List[Request]):
