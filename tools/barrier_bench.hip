@@ -1,0 +1,121 @@
+// Development microbench: persistent-kernel phases separated by a grid barrier vs one kernel per phase in a hipGraph.
+// A "phase" is a wave-per-column bf16 GEMV y[N] = W[N,K] x[K] whose input is the previous phase's output.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float bflo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ bf16_t f2bf(float f) { uint32_t u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
+__device__ __forceinline__ float dot8(uint4 w, uint4 x, float s) {
+    s = fmaf(bflo(w.x), bflo(x.x), s); s = fmaf(bfhi(w.x), bfhi(x.x), s);
+    s = fmaf(bflo(w.y), bflo(x.y), s); s = fmaf(bfhi(w.y), bfhi(x.y), s);
+    s = fmaf(bflo(w.z), bflo(x.z), s); s = fmaf(bfhi(w.z), bfhi(x.z), s);
+    s = fmaf(bflo(w.w), bflo(x.w), s); s = fmaf(bfhi(w.w), bfhi(x.w), s);
+    return s;
+}
+__device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+// K = 64*8*KC elements; each wave owns CPW consecutive columns
+template <int KC, int CPW, int MODE>   // MODE 0: barrier only, 1: prefetch weights before the barrier, 2: load after
+__global__ __launch_bounds__(256) void k_persist(const bf16_t* W, bf16_t* xb, unsigned* ctr, int phases, int nmat, int N) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int K = 512 * KC;
+    for (int p = 0; p < phases; ++p) {
+        if (MODE == 0) { grid_barrier(ctr, (unsigned)(p + 1) * gridDim.x); continue; }
+        const bf16_t* Wp = W + (size_t)(p % nmat) * N * K;
+        uint4 w[CPW][KC];
+        if (MODE == 1) {
+#pragma unroll
+            for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                for (int j = 0; j < KC; ++j) w[c][j] = *reinterpret_cast<const uint4*>(Wp + (size_t)(gw * CPW + c) * K + (j * 64 + lane) * 8);
+        }
+        if (p > 0) grid_barrier(ctr, (unsigned)p * gridDim.x);
+        const bf16_t* x = xb + (size_t)(p & 1) * 8192;
+        bf16_t* y = xb + (size_t)((p + 1) & 1) * 8192;
+        uint4 xv[KC];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) xv[j] = *reinterpret_cast<const uint4*>(x + (j * 64 + lane) * 8);
+        if (MODE == 2) {
+#pragma unroll
+            for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                for (int j = 0; j < KC; ++j) w[c][j] = *reinterpret_cast<const uint4*>(Wp + (size_t)(gw * CPW + c) * K + (j * 64 + lane) * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) s = dot8(w[c][j], xv[j], s);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == 0) y[(gw * CPW + c) % 8192] = f2bf(s * 0.01f);
+        }
+    }
+}
+template <int KC, int CPW>
+__global__ __launch_bounds__(256) void k_phase(const bf16_t* Wp, const bf16_t* x, bf16_t* y, int N) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int K = 512 * KC;
+    uint4 w[CPW][KC], xv[KC];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int j = 0; j < KC; ++j) w[c][j] = *reinterpret_cast<const uint4*>(Wp + (size_t)(gw * CPW + c) * K + (j * 64 + lane) * 8);
+#pragma unroll
+    for (int j = 0; j < KC; ++j) xv[j] = *reinterpret_cast<const uint4*>(x + (j * 64 + lane) * 8);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) s = dot8(w[c][j], xv[j], s);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) y[(gw * CPW + c) % 8192] = f2bf(s * 0.01f);
+    }
+}
+template <int KC, int CPW>
+void run(const char* name, int grid, int nmat, bf16_t* W, bf16_t* xb, unsigned* ctr, hipStream_t st) {
+    const int phases = 400, N = grid * 4 * CPW, K = 512 * KC;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float ms;
+    auto timeit = [&](auto fn) { fn(); CK(hipStreamSynchronize(st)); CK(hipEventRecord(a, st)); fn(); CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); return ms * 1000 / phases; };
+    float t0 = timeit([&] { CK(hipMemsetAsync(ctr, 0, 4, st)); hipLaunchKernelGGL((k_persist<KC, CPW, 0>), dim3(grid), dim3(256), 0, st, W, xb, ctr, phases, nmat, N); });
+    float t1 = timeit([&] { CK(hipMemsetAsync(ctr, 0, 4, st)); hipLaunchKernelGGL((k_persist<KC, CPW, 1>), dim3(grid), dim3(256), 0, st, W, xb, ctr, phases, nmat, N); });
+    float t2 = timeit([&] { CK(hipMemsetAsync(ctr, 0, 4, st)); hipLaunchKernelGGL((k_persist<KC, CPW, 2>), dim3(grid), dim3(256), 0, st, W, xb, ctr, phases, nmat, N); });
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int p = 0; p < phases; ++p)
+        hipLaunchKernelGGL((k_phase<KC, CPW>), dim3(grid), dim3(256), 0, st, W + (size_t)(p % nmat) * N * K, xb + (size_t)(p & 1) * 8192, xb + (size_t)((p + 1) & 1) * 8192, N);
+    CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    float t3 = timeit([&] { CK(hipGraphLaunch(ge, st)); });
+    const double mb = (double)N * K * 2 / 1e6;
+    printf("%-10s grid %3d N %5d K %4d (%5.1f MB/phase, %d mats = %4.0f MB) | barrier %5.2f  persist+prefetch %5.2f  persist %5.2f  graph %5.2f us/phase | %4.2f / %4.2f TB/s\n",
+           name, grid, N, K, mb, nmat, mb * nmat, t0, t1, t2, t3, mb / t1 / 1e6 * 1e6 / 1e6, mb / t3 / 1e6 * 1e6 / 1e6);
+}
+int main() {
+    bf16_t* W; size_t wb = (size_t)512 << 20; CK(hipMalloc(&W, wb)); CK(hipMemset(W, 0x3c, wb));
+    bf16_t* xb; CK(hipMalloc(&xb, 8192 * 2 * 2)); CK(hipMemset(xb, 0x3c, 8192 * 4));
+    unsigned* ctr; CK(hipMalloc(&ctr, 64));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    // depth-like: K=1024 (KC=2), 4 cols/wave -> N=4096 (8 MB); nmat 20 = 160 MB (fits MALL) and 60 = 480MB (HBM)
+    run<2, 4>("K1024x4", 256, 20, W, xb, ctr, st);
+    run<2, 4>("K1024x4", 256, 60, W, xb, ctr, st);
+    run<2, 1>("K1024x1", 256, 60, W, xb, ctr, st);
+    // talker-like: K=2048 (KC=4), 4 cols/wave -> N=4096 (16 MB)
+    run<4, 4>("K2048x4", 256, 30, W, xb, ctr, st);
+    run<4, 2>("K2048x2", 512, 30, W, xb, ctr, st);
+    run<4, 6>("K2048x6", 256, 20, W, xb, ctr, st);
+    run<2, 4>("K1024x4", 512, 30, W, xb, ctr, st);
+    return 0;
+}

@@ -215,6 +215,14 @@ struct vox_stack {
 
 // decode_rows: every row is the newest token of a distinct request (its K/V are not read by any other row), so the
 // head norm / RoPE / KV append fuse into the attention kernel; otherwise (prefill) a separate pass appends first.
+// development-only timing ablation (VOX_ABLATE bitmask; results are wrong when set): 1 attention, 2 depth loop,
+// 4 talker layers, 8 samplers, 16 qkv, 32 o_proj, 64 gate/up, 128 down
+static int ablate() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VOX_ABLATE"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t kv_stride, const vox_rows* r,
                         bool decode_rows = false, int fixed_order = 0) {
     const vox_stack_config& c = s->cfg;
@@ -237,7 +245,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         a.W = w.wqkv; a.bias = w.bqkv; a.x = x; a.norm_w = w.ln1; a.eps = c.eps; a.y = s->qkv;
         a.B = n; a.N = nqkv; a.K = c.hidden; a.pro = VOX_PRO_RMSNORM; a.epi = VOX_EPI_STORE;
         a.fixed_order = fixed_order;
-        VOX_TRY(vox_launch_linear(s->ctx, st, a));
+        if (!(ablate() & 16)) VOX_TRY(vox_launch_linear(s->ctx, st, a));
         HeadCall hc;  // per-head norm + RoPE + paged append
         hc.q_src = s->qkv; hc.k_src = (bf16_t*)s->qkv + nq; hc.v_src = (bf16_t*)s->qkv + nq + nkv;
         hc.q_stride = hc.k_stride = hc.v_stride = nqkv;
@@ -259,23 +267,23 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         ac.Hq = c.heads; ac.Hkv = c.kv_heads; ac.D = c.head_dim; ac.page_size = c.page_size; ac.max_chunks = mc;
         ac.max_kvlen = r->max_kvlen;
         ac.out = s->attn_out;
-        VOX_TRY(vox_launch_attn_partial(st, ac));
-        if (mc > 1) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc));
+        if (!(ablate() & 1)) VOX_TRY(vox_launch_attn_partial(st, ac));
+        if (mc > 1 && !(ablate() & 1)) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc));
         LinearCall o;  // o_proj + residual
         o.W = w.wo; o.x = s->attn_out; o.residual = x; o.y = x; o.B = n; o.N = c.hidden; o.K = nq;
         o.pro = VOX_PRO_COPY; o.epi = VOX_EPI_STORE;
         o.fixed_order = fixed_order;
-        VOX_TRY(vox_launch_linear(s->ctx, st, o));
+        if (!(ablate() & 32)) VOX_TRY(vox_launch_linear(s->ctx, st, o));
         LinearCall g;  // post_attention_layernorm + gate/up + SiLU*up
         g.W = w.wgate; g.W2 = w.wup; g.x = x; g.norm_w = w.ln2; g.eps = c.eps; g.y = s->h;
         g.B = n; g.N = c.ffn; g.K = c.hidden; g.pro = VOX_PRO_RMSNORM; g.epi = VOX_EPI_SILU_MUL;
         g.fixed_order = fixed_order;
-        VOX_TRY(vox_launch_linear(s->ctx, st, g));
+        if (!(ablate() & 64)) VOX_TRY(vox_launch_linear(s->ctx, st, g));
         LinearCall d;  // down + residual
         d.W = w.wdown; d.x = s->h; d.residual = x; d.y = x; d.B = n; d.N = c.hidden; d.K = c.ffn;
         d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE;
         d.fixed_order = fixed_order;
-        VOX_TRY(vox_launch_linear(s->ctx, st, d));
+        if (!(ablate() & 128)) VOX_TRY(vox_launch_linear(s->ctx, st, d));
     }
     return VOX_OK;
 }
@@ -386,7 +394,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         s.emb_dst = (bf16_t*)m->depth_x + H; s.emb_dst_stride = 2L * H; s.ws = m->ctx->samp_ws;
         VOX_TRY(vox_launch_sample(st, s));
     }
-    for (int i = 1; i < G; ++i) {
+    for (int i = 1; i < G && !(ablate() & 2); ++i) {
         const int rows = i == 1 ? 2 * B : B;
         LinearCall p;  // small_to_mtp_projection
         p.W = m->w.mtp_w; p.bias = m->w.mtp_b; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
@@ -418,7 +426,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         s.emb_table = m->depth_emb[i - 1]; s.emb_vocab = c.depth_vocab; s.H = H;
         s.emb_dst = m->depth_x; s.emb_dst_stride = H;
         s.feat_acc = io->next_features; s.feat_init = i == 1; s.ws = m->ctx->samp_ws;
-        VOX_TRY(vox_launch_sample(st, s));
+        if (!(ablate() & 8)) VOX_TRY(vox_launch_sample(st, s));
     }
     if (feedback) {
         hipLaunchKernelGGL(k_qwen3_feedback, dim3((H + 255) / 256, B), dim3(256), 0, st, io->out_ids, io->input_ids,
@@ -543,7 +551,7 @@ int vox_qwen3_frame(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int B, i
     r.pos = io->pos; r.q_req = m->iota; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
     r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = B; r.max_kvlen = max_kvlen;
     r.page_table = io->page_table; r.pt_stride = (int32_t)io->pt_stride;
-    VOX_TRY(stack_layers(m->talker, st, m->x, io->kv, io->kv_layer_stride, &r, true));
+    if (!(ablate() & 4)) VOX_TRY(stack_layers(m->talker, st, m->x, io->kv, io->kv_layer_stride, &r, true));
     VOX_TRY(qwen3_head(m, st, io, B, nullptr));
     return qwen3_tail(m, st, io, B, sc, seed, feedback);
 }

@@ -30,10 +30,10 @@ __device__ __forceinline__ const uint4* x_row_ptr(const LinArgs& a, int row) {
 
 __device__ __forceinline__ uint4 norm_chunk(uint4 v, uint4 w, float rinv) {
     uint4 o;
-    o.x = (u32)f2bf((bflo(v.x) * rinv) * bflo(w.x)) | ((u32)f2bf((bfhi(v.x) * rinv) * bfhi(w.x)) << 16);
-    o.y = (u32)f2bf((bflo(v.y) * rinv) * bflo(w.y)) | ((u32)f2bf((bfhi(v.y) * rinv) * bfhi(w.y)) << 16);
-    o.z = (u32)f2bf((bflo(v.z) * rinv) * bflo(w.z)) | ((u32)f2bf((bfhi(v.z) * rinv) * bfhi(w.z)) << 16);
-    o.w = (u32)f2bf((bflo(v.w) * rinv) * bflo(w.w)) | ((u32)f2bf((bfhi(v.w) * rinv) * bfhi(w.w)) << 16);
+    o.x = pack_bf2((bflo(v.x) * rinv) * bflo(w.x), (bfhi(v.x) * rinv) * bfhi(w.x));
+    o.y = pack_bf2((bflo(v.y) * rinv) * bflo(w.y), (bfhi(v.y) * rinv) * bfhi(w.y));
+    o.z = pack_bf2((bflo(v.z) * rinv) * bflo(w.z), (bfhi(v.z) * rinv) * bfhi(w.z));
+    o.w = pack_bf2((bflo(v.w) * rinv) * bflo(w.w), (bfhi(v.w) * rinv) * bfhi(w.w));
     return o;
 }
 
@@ -252,6 +252,134 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-resident GEMV for 1..2 rows: K == 512*KC, every wave is independent (no LDS, no barrier).
+// Lane l owns chunks l, l+64, ... of every row it touches — exactly the canonical DOT / RMSNorm lane
+// assignment — so the activation rows go straight from L2 into the registers that feed dot8, every wave
+// redoes the (tiny) RMSNorm reduction itself instead of waiting on wave 0 behind a barrier, and all of a
+// wave's weight bytes (R rows x K) are requested in one burst before anything waits.  Same arithmetic,
+// bit for bit, as k_linear.
+template <int BT, int KC, int R, int PRO, int EPI>
+__global__ __launch_bounds__(256) void k_gemv(LinArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int OUT = (EPI == EPI_SILU_MUL) ? R / 2 : R;
+    const int n0 = (blockIdx.x * 4 + wave) * OUT;
+    if (n0 >= a.N) return;
+
+    uint4 xv[BT][KC], nwv[KC];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        const uint4* xr = x_row_ptr(a, b < a.B ? b : 0);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) xv[b][j] = xr[lane + 64 * j];
+    }
+    if (PRO == PRO_RMSNORM) {
+        const uint4* nwp = reinterpret_cast<const uint4*>(a.nw);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) nwv[j] = nwp[lane + 64 * j];
+    }
+    uint4 w[R][KC];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int n = n0 + (EPI == EPI_SILU_MUL ? (r % OUT) : r);
+        n = n < a.N ? n : a.N - 1;
+        const bf16_t* base = (EPI == EPI_SILU_MUL && r >= OUT) ? a.W2 : a.W;
+        const uint4* wr = reinterpret_cast<const uint4*>(base + (size_t)n * a.K);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) w[r][j] = ldg_nt(wr + lane + 64 * j);
+    }
+    float res_pre = 0.0f, bias_pre = 0.0f;
+    {
+        const int po = lane / BT, pb = lane % BT;
+        if (EPI != EPI_SILU_MUL && lane < OUT * BT && pb < a.B && n0 + po < a.N) {
+            if (a.residual) res_pre = bf2f(a.residual[(size_t)pb * a.N + n0 + po]);
+            if (a.bias) bias_pre = bf2f(a.bias[n0 + po]);
+        }
+    }
+    if (PRO == PRO_RMSNORM) {
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) s = sq8(xv[b][j], s);
+            s = butterfly<64>(s);
+            const float rinv = 1.0f / sqrtf(s / (float)a.K + a.eps);
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                xv[b][j] = norm_chunk(xv[b][j], nwv[j], rinv);
+                if (a.x_out && blockIdx.x == 0 && wave == 0 && b < a.B)
+                    reinterpret_cast<uint4*>(a.x_out + (size_t)b * a.x_out_stride)[lane + 64 * j] = xv[b][j];
+            }
+        }
+    }
+    float acc[R][BT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) s = dot8(w[r][j], xv[b][j], s);
+            acc[r][b] = butterfly<64>(s);
+        }
+#pragma unroll
+    for (int o = 0; o < OUT; ++o)
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            if (lane == o * BT + b && b < a.B && n0 + o < a.N) {
+                const int n = n0 + o;
+                const size_t oi = (size_t)b * a.N + n;
+                bf16_t r;
+                if (EPI == EPI_SILU_MUL) {
+                    const float g = bfround(acc[o][b]);
+                    const float u = bfround(acc[o + OUT][b]);
+                    r = f2bf(bfround(silu_c(g)) * u);
+                } else {
+                    float v = acc[o][b];
+                    if (a.bias) v = v + bias_pre;
+                    r = f2bf(v);
+                    if (EPI == EPI_SILU) r = f2bf(silu_c(bf2f(r)));
+                    if (a.residual) r = f2bf(res_pre + bf2f(r));
+                }
+                a.y[oi] = r;
+            }
+        }
+}
+
+#ifndef VOX_GEMV_COLS      // output columns per wave (development knob; 0 = heuristic)
+#define VOX_GEMV_COLS 0
+#endif
+template <int BT, int KC, int PRO, int EPI>
+static int launch_gemv_k(hipStream_t st, const LinArgs& a) {
+    constexpr bool SM = (EPI == EPI_SILU_MUL);
+    // columns per wave: enough waves to cover the 1024 SIMDs a few times over, as many bytes in flight per wave
+    // as the register file allows (R*KC 16-byte loads per lane)
+    int cols = VOX_GEMV_COLS;
+    if (cols == 0) cols = (a.N / (SM ? 1 : 1) >= 4096 && KC <= 4) ? 2 : 1;
+    if (SM) cols = cols > 2 ? 2 : cols;
+    while (cols > 1 && cols * (SM ? 2 : 1) * KC > 24) cols >>= 1;
+#define VOX_GV(C_)                                                                                       \
+    if (cols == C_) {                                                                                    \
+        hipLaunchKernelGGL((k_gemv<BT, KC, (SM ? 2 * C_ : C_), PRO, EPI>), dim3((a.N + 4 * C_ - 1) / (4 * C_)), \
+                           dim3(256), 0, st, a);                                                         \
+        return VOX_OK;                                                                                   \
+    }
+    VOX_GV(1) VOX_GV(2) VOX_GV(4)
+#undef VOX_GV
+    return vox_fail(VOX_ERR_INVALID, "gemv: no variant");
+}
+template <int PRO, int EPI>
+static int launch_gemv(hipStream_t st, const LinArgs& a, bool* handled) {
+    *handled = true;
+    const int kc = a.K / 512;
+#define VOX_GK(B_, K_) if (a.B <= B_ && kc == K_) return launch_gemv_k<B_, K_, PRO, EPI>(st, a);
+    VOX_GK(1, 2) VOX_GK(1, 4) VOX_GK(1, 6) VOX_GK(1, 8) VOX_GK(1, 12)
+    VOX_GK(2, 2) VOX_GK(2, 4) VOX_GK(2, 6) VOX_GK(2, 8) VOX_GK(2, 12)
+#undef VOX_GK
+    *handled = false;
+    return VOX_OK;
+}
+
 template <int BT, int R, int PRO, int EPI>
 static int launch_linear_t(hipStream_t st, const LinArgs& a) {
     constexpr int OUT = (EPI == EPI_SILU_MUL) ? R / 2 : R;
@@ -273,6 +401,13 @@ static int launch_linear_t(hipStream_t st, const LinArgs& a) {
 template <int PRO, int EPI>
 static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
     // batch tile: smallest of {1,2,4,8} covering B (B>8 loops tiles of 8 inside the kernel)
+#ifndef VOX_NO_GEMV
+    if (PRO != PRO_ATTN && a.B <= 2 && a.K % 512 == 0) {       // register-resident, barrier-free variant
+        bool handled = false;
+        const int rc = launch_gemv<(PRO == PRO_ATTN ? PRO_COPY : PRO), EPI>(st, a, &handled);
+        if (handled) return rc;
+    }
+#endif
     int bt = a.B <= 1 ? 1 : a.B <= 2 ? 2 : a.B <= 4 ? 4 : 8;
     while (bt > 1 && (size_t)bt * a.K * 2 > 144 * 1024) bt >>= 1;
     // rows per wave: keep >= ~1 block per CU; fewer rows/wave when N is small

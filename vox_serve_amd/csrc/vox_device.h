@@ -14,11 +14,21 @@ typedef uint32_t u32;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((u32)h) << 16); }
 __device__ __forceinline__ float bflo(u32 w) { return __uint_as_float(w << 16); }          // element 0 of a pair
 __device__ __forceinline__ float bfhi(u32 w) { return __uint_as_float(w & 0xffff0000u); }  // element 1 of a pair
+// fp32 -> bf16, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950 (same results as the integer recipe of
+// oracle/voxref.c::f2bf for every non-NaN input; at one wave per SIMD instruction count is time)
+typedef __bf16 vox_bf2 __attribute__((ext_vector_type(2)));
+typedef float vox_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    u32 u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    union { __bf16 b; bf16_t u; } c;
+    c.b = (__bf16)f;
+    return c.u;
+}
+// two values at once: element 0 in the low half
+__device__ __forceinline__ u32 pack_bf2(float lo, float hi) {
+    const vox_f2 v = {lo, hi};
+    union { vox_bf2 b; u32 u; } c;
+    c.b = __builtin_convertvector(v, vox_bf2);
+    return c.u;
 }
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
 
