@@ -42,3 +42,47 @@ chain([(4096, 1024)], 75, "4096x1024 repeated")
 chain([(1024, 2048)], 150, "1024x2048 repeated")
 chain([(4096, 1024), (1024, 2048), (2048, 1024), (3072, 1024), (1024, 3072)], 30, "depth-like mix (5 shapes)")
 chain([(4096, 2048), (2048, 2048), (6144, 2048), (2048, 6144)], 28, "talker-like mix (4 shapes)")
+
+
+def stack_chain(reps=15):
+    """Depth-transformer-shaped stack (5 layers, 1 decode row) through vox_stack_forward, `reps` calls in one graph."""
+    from vox_serve_amd.engine import StackCfg, _stack_config, rope_table
+    c = StackCfg(1024, 5, 16, 8, 128, 3072)
+    sc = _stack_config(c, 16, 2, 16)
+    arr = (N.LayerWeights * c.layers)()
+    keep = []
+    mk = lambda *s: (keep.append(torch.randn(*s, device=dev, dtype=torch.bfloat16) * 0.02) or keep[-1])
+    for i in range(c.layers):
+        for k, t in dict(wqkv=mk(4096, 1024), wo=mk(1024, 2048), wgate=mk(3072, 1024), wup=mk(3072, 1024), wdown=mk(1024, 3072),
+                         ln1=mk(1024) + 1, ln2=mk(1024) + 1, qnorm=mk(128) + 1, knorm=mk(128) + 1).items():
+            keep.append(t)
+            setattr(arr[i], k, t.data_ptr())
+    fn = mk(1024) + 1
+    rope = rope_table(64, c, dev)
+    h = ctypes.c_void_p()
+    N.check(L.vox_stack_create(ctx, ctypes.byref(sc), arr, fn.data_ptr(), rope.data_ptr(), 64, ctypes.byref(h)))
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    pos, qreq, kvl, page, slot, indptr, indices = i32([5]), i32([0]), i32([6]), i32([0]), i32([5]), i32([0, 1]), i32([0])
+    rows = N.Rows(pos.data_ptr(), qreq.data_ptr(), kvl.data_ptr(), page.data_ptr(), slot.data_ptr(), indptr.data_ptr(),
+                  indices.data_ptr(), 1, 6, None, 0, 6, 5, 1)
+    kv = torch.randn(5, 1, 2, 16, 8, 128, device=dev, dtype=torch.bfloat16)
+    x = torch.randn(2, 1024, device=dev, dtype=torch.bfloat16)
+    with torch.cuda.stream(st):
+        def body():
+            for _ in range(reps):
+                N.check(L.vox_stack_forward(h, N.stream(), x.data_ptr(), None, kv.data_ptr(), kv[0].numel(), ctypes.byref(rows)))
+        body(); st.synchronize()
+        N.check(L.vox_graph_begin(ctx, N.stream())); body()
+        g = ctypes.c_void_p(); N.check(L.vox_graph_end(ctx, N.stream(), ctypes.byref(g)))
+        for _ in range(3): N.check(L.vox_graph_launch(g, N.stream()))
+        st.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): N.check(L.vox_graph_launch(g, N.stream()))
+        e1.record(); st.synchronize()
+    us = e0.elapsed_time(e1) * 1000 / 5
+    print(f"stack chain: {reps} x 5 layers: {us:8.1f} us total, {us/reps/5:6.2f} us/layer  (VOX_ABLATE={os.environ.get('VOX_ABLATE','0')}, VOX_DEV={os.environ.get('VOX_DEV','0')})")
+
+
+for r in (3, 15, 30, 60):
+    stack_chain(r)

@@ -208,9 +208,11 @@ struct vox_stack {
     const float* rope;
     int rope_max_pos;
     // workspace
-    void *qkv, *q, *h, *attn_out;
+    void *qkv, *q, *h, *attn_out, *xn, *skws;
+    size_t skws_bytes;
     float* attn_ws;
     size_t attn_ws_floats;
+    int keep_weights = 0;   // the stack runs many times per frame (depth loop): keep its weights cache-resident
 };
 
 // decode_rows: every row is the newest token of a distinct request (its K/V are not read by any other row), so the
@@ -244,7 +246,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         LinearCall a;  // input_layernorm + fused q/k/v projection
         a.W = w.wqkv; a.bias = w.bqkv; a.x = x; a.norm_w = w.ln1; a.eps = c.eps; a.y = s->qkv;
         a.B = n; a.N = nqkv; a.K = c.hidden; a.pro = VOX_PRO_RMSNORM; a.epi = VOX_EPI_STORE;
-        a.fixed_order = fixed_order;
+        a.fixed_order = fixed_order; a.keep_weights = s->keep_weights; a.splitk_ws = s->skws; a.splitk_ws_bytes = s->skws_bytes; a.norm_scratch = s->xn;
         if (!(ablate() & 16)) VOX_TRY(vox_launch_linear(s->ctx, st, a));
         HeadCall hc;  // per-head norm + RoPE + paged append
         hc.q_src = s->qkv; hc.k_src = (bf16_t*)s->qkv + nq; hc.v_src = (bf16_t*)s->qkv + nq + nkv;
@@ -267,22 +269,31 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         ac.Hq = c.heads; ac.Hkv = c.kv_heads; ac.D = c.head_dim; ac.page_size = c.page_size; ac.max_chunks = mc;
         ac.max_kvlen = r->max_kvlen;
         ac.out = s->attn_out;
-        if (!(ablate() & 1)) VOX_TRY(vox_launch_attn_partial(st, ac));
-        if (mc > 1 && !(ablate() & 1)) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc));
         LinearCall o;  // o_proj + residual
         o.W = w.wo; o.x = s->attn_out; o.residual = x; o.y = x; o.B = n; o.N = c.hidden; o.K = nq;
         o.pro = VOX_PRO_COPY; o.epi = VOX_EPI_STORE;
-        o.fixed_order = fixed_order;
-        if (!(ablate() & 32)) VOX_TRY(vox_launch_linear(s->ctx, st, o));
+        o.fixed_order = fixed_order; o.keep_weights = s->keep_weights; o.splitk_ws = s->skws; o.splitk_ws_bytes = s->skws_bytes;
+        if (decode_rows && c.max_kvlen <= 16 && !(ablate() & 256) && vox_attn1_linear_supported(ac, o)) {
+            VOX_TRY(vox_launch_attn1_linear(st, ac, o));     // short context: attention recomputed inside o_proj
+        } else {
+            if (ablate() & 1) {
+            } else if (decode_rows && c.max_kvlen <= 16 && !(ablate() & 512) && vox_attn_short_supported(ac)) {
+                VOX_TRY(vox_launch_attn_short(st, ac));      // one wave per (row, kv head), registers only
+            } else {
+                VOX_TRY(vox_launch_attn_partial(st, ac));
+                if (mc > 1) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc));
+            }
+            if (!(ablate() & 32)) VOX_TRY(vox_launch_linear(s->ctx, st, o));
+        }
         LinearCall g;  // post_attention_layernorm + gate/up + SiLU*up
         g.W = w.wgate; g.W2 = w.wup; g.x = x; g.norm_w = w.ln2; g.eps = c.eps; g.y = s->h;
         g.B = n; g.N = c.ffn; g.K = c.hidden; g.pro = VOX_PRO_RMSNORM; g.epi = VOX_EPI_SILU_MUL;
-        g.fixed_order = fixed_order;
+        g.fixed_order = fixed_order; g.keep_weights = s->keep_weights; g.splitk_ws = s->skws; g.splitk_ws_bytes = s->skws_bytes; g.norm_scratch = s->xn;
         if (!(ablate() & 64)) VOX_TRY(vox_launch_linear(s->ctx, st, g));
         LinearCall d;  // down + residual
         d.W = w.wdown; d.x = s->h; d.residual = x; d.y = x; d.B = n; d.N = c.hidden; d.K = c.ffn;
         d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE;
-        d.fixed_order = fixed_order;
+        d.fixed_order = fixed_order; d.keep_weights = s->keep_weights; d.splitk_ws = s->skws; d.splitk_ws_bytes = s->skws_bytes;
         if (!(ablate() & 128)) VOX_TRY(vox_launch_linear(s->ctx, st, d));
     }
     return VOX_OK;
@@ -305,8 +316,17 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
     const size_t nq = (size_t)cfg->heads * cfg->head_dim, nkv = (size_t)cfg->kv_heads * cfg->head_dim;
     const size_t R = cfg->max_rows;
     s->attn_ws_floats = (size_t)R * cfg->heads * n_chunks(cfg->max_kvlen) * (cfg->head_dim + 2);
+    {   // split-K GEMM partials: the widest of (qkv, o, gate+up, down) at 128 rows per pass
+        const size_t sh = (cfg->hidden + 255) / 256, sf = (cfg->ffn + 255) / 256, sq = (nq + 255) / 256;
+        size_t m = sh * (nq + 2 * nkv);
+        m = m > sq * cfg->hidden ? m : sq * cfg->hidden;
+        m = m > sh * 2 * cfg->ffn ? m : sh * 2 * cfg->ffn;
+        m = m > sf * cfg->hidden ? m : sf * cfg->hidden;
+        s->skws_bytes = R > 32 ? m * 128 * 4 : 256;
+    }
     if (hipMalloc(&s->qkv, R * (nq + 2 * nkv) * 2) != hipSuccess || hipMalloc(&s->q, R * nq * 2) != hipSuccess ||
         hipMalloc(&s->h, R * cfg->ffn * 2) != hipSuccess || hipMalloc(&s->attn_out, R * nq * 2) != hipSuccess ||
+        hipMalloc(&s->xn, R * cfg->hidden * 2) != hipSuccess || hipMalloc(&s->skws, s->skws_bytes) != hipSuccess ||
         hipMalloc((void**)&s->attn_ws, s->attn_ws_floats * 4) != hipSuccess) {
         delete s;
         return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc failed");
@@ -316,7 +336,7 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
 }
 void vox_stack_destroy(vox_stack* s) {
     if (!s) return;
-    (void)hipFree(s->qkv); (void)hipFree(s->q); (void)hipFree(s->h); (void)hipFree(s->attn_out); (void)hipFree(s->attn_ws);
+    (void)hipFree(s->qkv); (void)hipFree(s->q); (void)hipFree(s->h); (void)hipFree(s->attn_out); (void)hipFree(s->xn); (void)hipFree(s->skws); (void)hipFree(s->attn_ws);
     delete s;
 }
 
@@ -324,7 +344,9 @@ int vox_stack_forward(vox_stack* s, void* stream, void* x, void* y, void* kv, in
                       const vox_rows* rows) {
     if (!s || !rows) return vox_fail(VOX_ERR_INVALID, "stack_forward: NULL");
     hipStream_t st = (hipStream_t)stream;
-    VOX_TRY(stack_layers(s, st, x, kv, kv_layer_stride, rows));
+    // the decode-row hints promise one new token per request: take the fused (norm + RoPE + append in-kernel) path
+    const bool decode_rows = rows->fixed_kvlen > 0 || rows->page_table != nullptr || rows->identity_pages;
+    VOX_TRY(stack_layers(s, st, x, kv, kv_layer_stride, rows, decode_rows, rows->n_rows <= 8));
     if (y && s->final_norm)
         VOX_TRY(vox_launch_rmsnorm(st, x, s->final_norm, y, rows->n_rows, s->cfg.hidden, s->cfg.eps));
     return VOX_OK;
@@ -398,7 +420,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         const int rows = i == 1 ? 2 * B : B;
         LinearCall p;  // small_to_mtp_projection
         p.W = m->w.mtp_w; p.bias = m->w.mtp_b; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
-        p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8;
+        p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8; p.keep_weights = m->depth->keep_weights;
         VOX_TRY(vox_launch_linear(m->ctx, st, p));
         vox_rows r{};
         r.pos = i == 1 ? m->d1_pos : m->di_pos[i];
@@ -418,6 +440,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         h.W = (const bf16_t*)m->w.depth_lm_head + (size_t)(i - 1) * c.depth_vocab * Hd;
         h.x = m->dx; h.x_rows = i == 1 ? m->odd_rows : nullptr; h.norm_w = m->w.depth_norm; h.eps = c.depth.eps;
         h.y = dl; h.B = B; h.N = c.depth_vocab; h.K = Hd; h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
+        h.keep_weights = m->depth->keep_weights;
         VOX_TRY(vox_launch_linear(m->ctx, st, h));
         SampleCall s;
         s.logits = dl; s.B = B; s.V = c.depth_vocab; s.cfg = *sc; s.cfg.repetition_penalty = 1.0f;
@@ -474,6 +497,7 @@ int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_
     if (s != VOX_OK) { delete m; return s; }
     s = vox_stack_create(ctx, &dc, w->depth_layers, w->depth_norm, w->depth_rope, w->depth_rope_max_pos, &m->depth);
     if (s != VOX_OK) { vox_stack_destroy(m->talker); delete m; return s; }
+    m->depth->keep_weights = getenv("VOX_NO_KEEP") ? 0 : 1;   // 0.16 GB re-read 15 times per frame: Infinity-Cache resident
     const size_t R = tc.max_rows;
     m->dkv_stride = (int64_t)B * 2 * G * dc.kv_heads * dc.head_dim;
     bool ok = hipMalloc(&m->te, R * cfg->text_hidden * 2) == hipSuccess &&

@@ -21,6 +21,7 @@ struct LinArgs {
     long x_stride, x_out_stride;
     float eps;
     int B, N, K, Hq, D, max_chunks;
+    int keep;            // 1: weights are re-read soon (depth loop): plain loads, let them live in the Infinity Cache
 };
 
 __device__ __forceinline__ const uint4* x_row_ptr(const LinArgs& a, int row) {
@@ -285,8 +286,13 @@ __global__ __launch_bounds__(256) void k_gemv(LinArgs a) {
         n = n < a.N ? n : a.N - 1;
         const bf16_t* base = (EPI == EPI_SILU_MUL && r >= OUT) ? a.W2 : a.W;
         const uint4* wr = reinterpret_cast<const uint4*>(base + (size_t)n * a.K);
+        if (a.keep) {
 #pragma unroll
-        for (int j = 0; j < KC; ++j) w[r][j] = ldg_nt(wr + lane + 64 * j);
+            for (int j = 0; j < KC; ++j) w[r][j] = wr[lane + 64 * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < KC; ++j) w[r][j] = ldg_nt(wr + lane + 64 * j);
+        }
     }
     float res_pre = 0.0f, bias_pre = 0.0f;
     {
@@ -647,6 +653,297 @@ static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a) {
     return full ? launch_linear_mfma_t<2, PRO, EPI, true>(st, a) : launch_linear_mfma_t<2, PRO, EPI, false>(st, a);
 }
 
+// ================================================================================================
+// linear for many rows (prefill, 33+): bf16 MFMA straight from global memory, no LDS staging.
+// A block owns 16*NT output columns and ALL rows of a pass (up to 16*MT = 128), so the weights cross HBM once;
+// its four waves interleave the 32-wide K steps (step s -> wave s%4) and keep UK steps of fragments in flight:
+// one 16-byte load per lane per fragment, both for the weights (row n0+(lane&15), HBM, streaming) and for the
+// activations (row m*16+(lane&15), L2-resident: every block re-reads the same few hundred KB).  RMSNorm, when
+// needed, is applied once by k_rmsnorm in front (vox_launch_linear does it) instead of by every block.
+// fp32 accumulation in MFMA order (parity to bf16 rounding, like k_linear_mfma).
+__global__ void k_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps);
+
+template <int MT, int NT, int WV, int EPI>
+__global__ __launch_bounds__(64 * WV) void k_gemm_rows(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);   // [WV-1][SETS][MT][NT][64]
+    constexpr bool SM = (EPI == EPI_SILU_MUL);
+    constexpr int SETS = SM ? 2 : 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    const int n0 = blockIdx.x * 16 * NT;
+    const bf16_t* wrow[NT];
+    const bf16_t* wrow2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int n = n0 + t * 16 + fr;
+        n = n < a.N ? n : a.N - 1;
+        wrow[t] = a.W + (size_t)n * a.K + fk;
+        wrow2[t] = SM ? a.W2 + (size_t)n * a.K + fk : nullptr;
+    }
+    const int nsteps = a.K >> 5;
+    for (int b0 = 0; b0 < a.B; b0 += 16 * MT) {
+        const int bt = (a.B - b0) < 16 * MT ? (a.B - b0) : 16 * MT;
+        const bf16_t* xrow[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + fr;
+            xrow[m] = reinterpret_cast<const bf16_t*>(x_row_ptr(a, b0 + (r < bt ? r : bt - 1))) + fk;
+        }
+        f32x4_t acc[SETS][MT][NT];
+#pragma unroll
+        for (int z = 0; z < SETS; ++z)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[z][m][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // register double buffer: the fragments of this wave's next K step are in flight while the current multiply
+        uint4 wn[SETS][NT], xn[MT];
+        // every block walks K from its own starting point: at any instant the blocks read different activation
+        // lines, so the (small, shared) activation tile does not hot-spot a few L2 channels
+        const int rot = (int)((blockIdx.x * 37u) % (unsigned)nsteps);
+        auto issue = [&](int sidx) {
+            int sr = (sidx < nsteps ? sidx : wave) + rot;
+            sr = sr >= nsteps ? sr - nsteps : sr;
+            const int k = sr << 5;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                wn[0][t] = ldg_nt(reinterpret_cast<const uint4*>(wrow[t] + k));
+                if (SM) wn[SETS - 1][t] = ldg_nt(reinterpret_cast<const uint4*>(wrow2[t] + k));
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xn[m] = *reinterpret_cast<const uint4*>(xrow[m] + k);
+        };
+        constexpr bool DB = (SETS * MT * NT <= 5);   // register double buffer only where it does not force spills
+        if (DB) issue(wave);
+#pragma nounroll
+        for (int s0 = wave; s0 < nsteps; s0 += WV) {
+            uint4 wc[SETS][NT], xc[MT];
+            if (!DB) issue(s0);
+#pragma unroll
+            for (int z = 0; z < SETS; ++z)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) wc[z][t] = wn[z][t];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) xc[m] = xn[m];
+            if (DB) issue(s0 + WV);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[0][m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xc[m]), as_bf8(wc[0][t]), acc[0][m][t], 0, 0, 0);
+                    if (SM)
+                        acc[SETS - 1][m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xc[m]), as_bf8(wc[SETS - 1][t]), acc[SETS - 1][m][t], 0, 0, 0);
+                }
+        }
+        // cross-wave reduction in wave order, wave 0 runs the epilogue
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int z = 0; z < SETS; ++z)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) red[((((wave - 1) * SETS + z) * MT + m) * NT + t) * 64 + lane] = acc[z][m][t];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 0; w < WV - 1; ++w)
+#pragma unroll
+                for (int z = 0; z < SETS; ++z)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[z][m][t] += red[(((w * SETS + z) * MT + m) * NT + t) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = n0 + t * 16 + fr;
+                if (n >= a.N) continue;
+                const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int b = m * 16 + (lane >> 4) * 4 + r;
+                        if (b >= bt) continue;
+                        const size_t oi = (size_t)(b0 + b) * a.N + n;
+                        bf16_t o;
+                        if (SM) {
+                            const float g = bfround(acc[0][m][t][r]), u = bfround(acc[SETS - 1][m][t][r]);
+                            o = f2bf(bfround(silu_c(g)) * u);
+                        } else {
+                            float v = acc[0][m][t][r];
+                            if (a.bias) v = v + bv;
+                            o = f2bf(v);
+                            if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
+                            if (a.residual) o = f2bf(bf2f(a.residual[oi]) + bf2f(o));
+                        }
+                        a.y[oi] = o;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int MT, int NT, int WV, int EPI>
+static int launch_gemm_rows_t(hipStream_t st, const LinArgs& a) {
+    constexpr int SETS = (EPI == EPI_SILU_MUL) ? 2 : 1;
+    const size_t smem = (size_t)(WV - 1) * SETS * MT * NT * 64 * 16;
+    auto kern = k_gemm_rows<MT, NT, WV, EPI>;
+    if (smem > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((a.N + 16 * NT - 1) / (16 * NT)), dim3(64 * WV), smem, st, a);
+    return VOX_OK;
+}
+template <int EPI>
+static int launch_gemm_rows(hipStream_t st, const LinArgs& a) {
+    // rows per pass: all of them up to 128 (weights cross HBM once); waves per block: 8 K-interleaved waves keep
+    // >= 1024 waves in flight even at N = 2048
+    const int mt = a.B <= 48 ? 3 : a.B <= 80 ? 5 : 8;
+#define VOX_GR(M_)  if (mt == M_) return launch_gemm_rows_t<M_, 1, 8, EPI>(st, a);
+    VOX_GR(3) VOX_GR(5) VOX_GR(8)
+#undef VOX_GR
+    return vox_fail(VOX_ERR_INVALID, "gemm_rows: no variant");
+}
+
+// ================================================================================================
+// linear for prefill-sized row counts (33+): split-K bf16 MFMA GEMM, LDS-tiled, weights read exactly once.
+// Grid (Ntot/64, K/512): a block owns 64 output columns and one 512-wide K slab for ALL rows of the pass (<= 128), walks
+// the slab in 64-wide chunks through a double-buffered LDS tile pair (128-byte coalesced row segments of both the
+// weights and the activations), wave w multiplying n-tile w against every row tile.  fp32 partial sums go to a
+// workspace [slab][row][col]; k_splitk_reduce adds the slabs in slab order and runs the epilogue.  The K split is what
+// keeps >= 128 blocks streaming at N = 2048 while each block still re-uses its activation tile for 64 columns.
+template <int MT, int KS, bool SM>
+__global__ __launch_bounds__(256) void k_gemm_splitk(LinArgs a, float* part, int b0, int bt, int rows_stride) {
+    // one shot per block: the whole [64 x KS] weight slab and [BM x KS] activation slab are requested at once (every
+    // thread has all its 16-byte loads in flight together: one exposed memory latency per block instead of one per
+    // K chunk), parked in LDS, then multiplied.
+    constexpr int BM = 16 * MT, BN = 64, LDK = KS + 8, SEG = KS / 8;
+    constexpr int WL = BN * SEG / 256, XL = (BM * SEG + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ws = reinterpret_cast<bf16_t*>(smem);            // [BN][LDK]
+    bf16_t* Xs = Ws + BN * LDK;                              // [BM][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    const int Ntot = SM ? 2 * a.N : a.N;
+    const int col0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.y * KS;
+    const int klen = (a.K - k_begin) < KS ? (a.K - k_begin) : KS;      // multiple of 32
+    const int nseg = klen >> 3;
+    uint4 wreg[WL], xreg[XL];
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+        const int idx = tid + 256 * i, r = idx / SEG, seg = idx % SEG;
+        int col = col0 + r;
+        col = col < Ntot ? col : Ntot - 1;
+        const bf16_t* base = (SM && col >= a.N) ? a.W2 + (size_t)(col - a.N) * a.K : a.W + (size_t)col * a.K;
+        wreg[i] = make_uint4(0, 0, 0, 0);
+        if (seg < nseg) wreg[i] = ldg_nt(reinterpret_cast<const uint4*>(base + k_begin) + seg);
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int idx = tid + 256 * i, r = idx / SEG, seg = idx % SEG;
+        xreg[i] = make_uint4(0, 0, 0, 0);
+        if (idx < BM * SEG && seg < nseg)
+            xreg[i] = (x_row_ptr(a, b0 + (r < bt ? r : bt - 1)) + (k_begin >> 3))[seg];
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+        const int idx = tid + 256 * i;
+        *reinterpret_cast<uint4*>(&Ws[(idx / SEG) * LDK + (idx % SEG) * 8]) = wreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < BM * SEG) *reinterpret_cast<uint4*>(&Xs[(idx / SEG) * LDK + (idx % SEG) * 8]) = xreg[i];
+    }
+    __syncthreads();
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int kk = 0; kk < klen; kk += 32) {
+        const uint4 bw = *reinterpret_cast<const uint4*>(&Ws[(wave * 16 + fr) * LDK + kk + fk]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const uint4 ax = *reinterpret_cast<const uint4*>(&Xs[(m * 16 + fr) * LDK + kk + fk]);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(ax), as_bf8(bw), acc[m], 0, 0, 0);
+        }
+    }
+    const int col = col0 + wave * 16 + fr;
+    if (col < Ntot) {
+        float* dst = part + (size_t)blockIdx.y * rows_stride * Ntot + col;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * 16 + (lane >> 4) * 4 + r;
+                if (row < bt) dst[(size_t)row * Ntot] = acc[m][r];
+            }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* part, int S, int rows_stride, LinArgs a, int b0, int bt) {
+    constexpr bool SM = (EPI == EPI_SILU_MUL);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= bt * a.N) return;
+    const int row = idx / a.N, n = idx % a.N;
+    const int Ntot = SM ? 2 * a.N : a.N;
+    const float* p0 = part + (size_t)row * Ntot + n;
+    float v = 0.0f, u = 0.0f;
+    for (int sl = 0; sl < S; ++sl) {
+        v = v + p0[(size_t)sl * rows_stride * Ntot];
+        if (SM) u = u + p0[(size_t)sl * rows_stride * Ntot + a.N];
+    }
+    const size_t oi = (size_t)(b0 + row) * a.N + n;
+    bf16_t o;
+    if (SM) {
+        o = f2bf(bfround(silu_c(bfround(v))) * bfround(u));
+    } else {
+        if (a.bias) v = v + bf2f(a.bias[n]);
+        o = f2bf(v);
+        if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
+        if (a.residual) o = f2bf(bf2f(a.residual[oi]) + bf2f(o));
+    }
+    a.y[oi] = o;
+}
+
+template <int MT, int KS, bool SM>
+static void launch_gemm_splitk_t(hipStream_t st, const LinArgs& a, float* ws, int b0, int bt, int rs, dim3 grid) {
+    const size_t smem = (size_t)(16 * MT + 64) * (KS + 8) * 2;
+    auto kern = k_gemm_splitk<MT, KS, SM>;
+    static bool done = false;
+    if (!done && smem > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a, ws, b0, bt, rs);
+}
+template <int EPI>
+static int launch_gemm_splitk(hipStream_t st, const LinArgs& a, float* ws, size_t ws_bytes) {
+    constexpr bool SM = (EPI == EPI_SILU_MUL);
+    const int Ntot = SM ? 2 * a.N : a.N;
+    for (int b0 = 0; b0 < a.B; b0 += 128) {
+        const int bt = (a.B - b0) < 128 ? (a.B - b0) : 128;
+        const int mt = bt <= 64 ? 4 : bt <= 80 ? 5 : 8;
+        const int ks = 256;          // slab width: two blocks (tiles of (16 MT + 64) x 264 bf16) share a CU's 160 KB LDS
+        const int S = (a.K + ks - 1) / ks, rs = 16 * mt;
+        if ((size_t)S * rs * Ntot * 4 > ws_bytes) return vox_fail(VOX_ERR_INVALID, "linear: split-K workspace too small");
+        const dim3 grid((Ntot + 63) / 64, S);
+        if (mt == 4) launch_gemm_splitk_t<4, 256, SM>(st, a, ws, b0, bt, rs, grid);
+        else if (mt == 5) launch_gemm_splitk_t<5, 256, SM>(st, a, ws, b0, bt, rs, grid);
+        else launch_gemm_splitk_t<8, 256, SM>(st, a, ws, b0, bt, rs, grid);
+        hipLaunchKernelGGL((k_splitk_reduce<EPI>), dim3((bt * a.N + 255) / 256), dim3(256), 0, st, ws, S, rs, a, b0, bt);
+    }
+    return VOX_OK;
+}
+
 int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     if (c.K % 8 != 0 || c.B <= 0 || c.N <= 0) return vox_fail(VOX_ERR_INVALID, "linear: K%8!=0 or empty");
     LinArgs a{};
@@ -656,7 +953,33 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     a.kvlen = c.kvlen; a.x_rows = c.x_rows; a.x_stride = c.x_stride ? c.x_stride : c.K;
     a.x_out_stride = c.x_out_stride ? c.x_out_stride : c.K; a.eps = c.eps; a.B = c.B; a.N = c.N; a.K = c.K; a.Hq = c.Hq; a.D = c.D;
     a.max_chunks = c.max_chunks;
+    a.keep = c.keep_weights;
     const int ncu = ctx->n_cu;
+    static int dev = -1;   // development-only timing experiments (results are wrong when set)
+    if (dev < 0) { const char* e = getenv("VOX_DEV"); dev = e ? atoi(e) : 0; }
+    int pro = c.pro, epi = c.epi;
+    if ((dev & 1) && pro == PRO_RMSNORM) pro = PRO_COPY;
+    if (dev & 2) a.residual = nullptr;
+    if ((dev & 4) && epi == EPI_SILU_MUL) epi = EPI_STORE;
+    if (dev & 8) a.bias = nullptr;
+    if (c.B > 32 && !c.fixed_order && c.K % 32 == 0 && (pro == PRO_COPY || (pro == PRO_RMSNORM && c.norm_scratch && !a.x_rows && !a.x_out && a.x_stride == c.K))) {
+        // prefill-sized: normalise once (not in every block), then the LDS-free MFMA GEMM
+        if (pro == PRO_RMSNORM) {
+            if (a.x_rows) return vox_fail(VOX_ERR_INVALID, "linear: row indirection with a norm prologue at > 32 rows");
+            hipLaunchKernelGGL(k_rmsnorm, dim3((c.B + 3) / 4), dim3(256), 0, st, a.x, a.nw, (bf16_t*)c.norm_scratch, c.B, c.K, c.eps);
+            if (a.x_out) return vox_fail(VOX_ERR_INVALID, "linear: x_out with a norm prologue at > 32 rows");
+            a.x = (const bf16_t*)c.norm_scratch;
+            a.x_stride = c.K;
+        }
+        if (c.splitk_ws && c.K % 32 == 0 && !getenv("VOX_NO_SPLITK")) {
+            if (epi == EPI_STORE) return launch_gemm_splitk<EPI_STORE>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
+            if (epi == EPI_SILU) return launch_gemm_splitk<EPI_SILU>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
+            if (epi == EPI_SILU_MUL) return launch_gemm_splitk<EPI_SILU_MUL>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
+        }
+        if (epi == EPI_STORE) return launch_gemm_rows<EPI_STORE>(st, a);
+        if (epi == EPI_SILU) return launch_gemm_rows<EPI_SILU>(st, a);
+        if (epi == EPI_SILU_MUL) return launch_gemm_rows<EPI_SILU_MUL>(st, a);
+    }
     if (c.B > 8 && !c.fixed_order && c.pro != PRO_ATTN && c.K % 32 == 0) {   // > 8 rows: MFMA path (weights streamed once per 32-row tile)
 #define VOX_PM(P, E) if (c.pro == P && c.epi == E) return launch_linear_mfma_pe<P, E>(st, a);
         VOX_PM(PRO_COPY, EPI_STORE) VOX_PM(PRO_COPY, EPI_SILU) VOX_PM(PRO_COPY, EPI_SILU_MUL)
@@ -664,7 +987,7 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
 #undef VOX_PM
         return vox_fail(VOX_ERR_INVALID, "linear(mfma): unsupported prologue/epilogue combination");
     }
-#define VOX_PE(P, E) if (c.pro == P && c.epi == E) return launch_linear_pe<P, E>(st, a, ncu);
+#define VOX_PE(P, E) if (pro == P && epi == E) return launch_linear_pe<P, E>(st, a, ncu);
     VOX_PE(PRO_COPY, EPI_STORE) VOX_PE(PRO_COPY, EPI_SILU) VOX_PE(PRO_COPY, EPI_SILU_MUL)
     VOX_PE(PRO_RMSNORM, EPI_STORE) VOX_PE(PRO_RMSNORM, EPI_SILU_MUL) VOX_PE(PRO_ATTN, EPI_STORE)
 #undef VOX_PE
@@ -1017,6 +1340,253 @@ int vox_launch_attn_partial(hipStream_t st, const AttnCall& c) {
     return vox_fail(VOX_ERR_INVALID, "attention: head_dim must be 16, 64 or 128");
 }
 
+// ================================================================================================
+// Short-context decode attention (depth transformer: <= 16 visible tokens, D = 128, two q heads per kv head).
+// One WAVE per (row, kv head), no LDS, no barrier.  Lane = 16*grp + j holds 16-byte chunk j of: q head 0 (grp 0),
+// q head 1 (grp 1), the new k (grp 2), the new v (grp 3) — norm, RoPE (partner chunk = lane ^ 8) and the dot products
+// all stay in registers; K sits token-major (token 4u+grp in pass u), V chunk-major.  Same arithmetic and order as
+// k_attn_partial with one chunk (canonical DOT over 16 lanes, sequential l / o over tokens), bit for bit.
+__device__ __forceinline__ uint4 shfl4(uint4 v, int src) {
+    return make_uint4(__shfl(v.x, src, VOX_WAVE), __shfl(v.y, src, VOX_WAVE), __shfl(v.z, src, VOX_WAVE),
+                      __shfl(v.w, src, VOX_WAVE));
+}
+__device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int hk, int lane, bf16_t* out_row,
+                                                bool do_append) {
+    constexpr int D = 128, LPT = 16, TMAX = 16;
+    const int grp = lane >> 4, j = lane & 15;
+    const int nqkv = (at.Hq + 2 * at.Hkv) * D;
+    const size_t ps = (size_t)2 * at.page_size * at.Hkv * D;
+    const int L = at.fixed_kvlen > 0 ? at.fixed_kvlen : at.q_kvlen[row];
+    const int nt = L < TMAX ? L : TMAX;
+    const int* pages = at.identity_pages ? nullptr
+                       : (at.ptab ? at.ptab + (size_t)row * at.pt_stride : at.indices + at.indptr[at.q_req[row]]);
+    const bf16_t* raw = at.qkv + (size_t)row * nqkv;
+    const bf16_t* src = grp == 0 ? raw + (size_t)(hk * 2) * D
+                      : grp == 1 ? raw + (size_t)(hk * 2 + 1) * D
+                      : grp == 2 ? raw + (size_t)at.Hq * D + (size_t)hk * D
+                                 : raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D;
+    const uint4 v = reinterpret_cast<const uint4*>(src)[j];
+    const bf16_t* nwp = grp < 2 ? at.qn : (grp == 2 ? at.kn : nullptr);
+    uint4 gw4 = make_uint4(0, 0, 0, 0);
+    if (nwp) gw4 = reinterpret_cast<const uint4*>(nwp)[j];
+    int p = at.fixed_pos >= 0 ? at.fixed_pos : at.pos[row];
+    p = p < 0 ? 0 : (p >= at.table_max_pos ? at.table_max_pos - 1 : p);
+    float4 cs4[4];
+    {
+        const float4* cp = reinterpret_cast<const float4*>(at.cs + (size_t)p * D) + (j & 7) * 4;   // row = D/2 (c,s) pairs
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cs4[k] = cp[k];
+    }
+    // cached K (token-major) and V (chunk-major); token nt-1 is the new one
+    uint4 kr[4], vr[TMAX];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = u * 4 + grp;
+        kr[u] = make_uint4(0, 0, 0, 0);
+        if (t < nt - 1) {
+            const int pgi = pages ? pages[t / at.page_size] : row;
+            kr[u] = reinterpret_cast<const uint4*>(at.kv + (size_t)pgi * ps + ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[j];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        vr[t] = make_uint4(0, 0, 0, 0);
+        if (t < nt - 1) {
+            const int pgi = pages ? pages[t / at.page_size] : row;
+            vr[t] = reinterpret_cast<const uint4*>(at.kv + (size_t)pgi * ps + (size_t)at.page_size * at.Hkv * D +
+                                                   ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[j];
+        }
+    }
+    // per-head RMSNorm (prep_head: butterfly<64> over a head's 16 non-zero lanes == butterfly<16>)
+    float e[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
+    {
+        float s = sq8(v, 0.0f);
+        s = butterfly<16>(s);
+        const float rinv = 1.0f / sqrtf(s / (float)D + at.eps);
+        if (nwp) {
+            const float gw[8] = {bflo(gw4.x), bfhi(gw4.x), bflo(gw4.y), bfhi(gw4.y), bflo(gw4.z), bfhi(gw4.z), bflo(gw4.w), bfhi(gw4.w)};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = bfround((e[i] * rinv) * gw[i]);
+        }
+    }
+    // NeoX RoPE over the full head: element i < 64 pairs with i + 64, i.e. with the same slot of lane ^ 8
+    uint4 hq;
+    {
+        const float cc[8] = {cs4[0].x, cs4[0].z, cs4[1].x, cs4[1].z, cs4[2].x, cs4[2].z, cs4[3].x, cs4[3].z};
+        const float sn[8] = {cs4[0].y, cs4[0].w, cs4[1].y, cs4[1].w, cs4[2].y, cs4[2].w, cs4[3].y, cs4[3].w};
+        float r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float o = __shfl_xor(e[i], 8, VOX_WAVE);
+            const float mc = e[i] * cc[i];
+            r[i] = (j < 8) ? __fmaf_rn(-o, sn[i], mc) : __fmaf_rn(o, sn[i], mc);
+        }
+        hq.x = pack_bf2(r[0], r[1]); hq.y = pack_bf2(r[2], r[3]); hq.z = pack_bf2(r[4], r[5]); hq.w = pack_bf2(r[6], r[7]);
+        if (grp == 3) hq = v;
+    }
+    const uint4 q0c = shfl4(hq, j), q1c = shfl4(hq, 16 + j), knc = shfl4(hq, 32 + j), vnc = shfl4(hq, 48 + j);
+    if (do_append) {
+        const int pg = at.identity_pages ? row : at.page[row];
+        const int sl = at.identity_pages ? (L - 1) : at.slot[row];
+        if (pg >= 0 && grp >= 2) {
+            bf16_t* base = at.kv_w + (size_t)pg * ps + ((size_t)sl * at.Hkv + hk) * D;
+            if (grp == 3) base += (size_t)at.page_size * at.Hkv * D;
+            reinterpret_cast<uint4*>(base)[j] = hq;
+        }
+    }
+    // scores of token 4u+grp for both q heads, then the global max
+    float sc[2][4], m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = u * 4 + grp;
+        const uint4 kx = (t == nt - 1) ? knc : kr[u];
+        const float d0 = butterfly<16>(dot8(q0c, kx, 0.0f)) * at.scale;
+        const float d1 = butterfly<16>(dot8(q1c, kx, 0.0f)) * at.scale;
+        sc[0][u] = t < nt ? d0 : -INFINITY;
+        sc[1][u] = t < nt ? d1 : -INFINITY;
+        m0 = fmaxf(m0, sc[0][u]);
+        m1 = fmaxf(m1, sc[1][u]);
+    }
+    m0 = fmaxf(m0, __shfl_xor(m0, 16, VOX_WAVE)); m0 = fmaxf(m0, __shfl_xor(m0, 32, VOX_WAVE));
+    m1 = fmaxf(m1, __shfl_xor(m1, 16, VOX_WAVE)); m1 = fmaxf(m1, __shfl_xor(m1, 32, VOX_WAVE));
+    float pp[2][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = u * 4 + grp;
+        pp[0][u] = t < nt ? exp2_c((sc[0][u] - m0) * VOX_LOG2E) : 0.0f;
+        pp[1][u] = t < nt ? exp2_c((sc[1][u] - m1) * VOX_LOG2E) : 0.0f;
+    }
+    // PV: lane (g = grp & 1, chunk j) accumulates its 8 output dims sequentially over the tokens
+    const int g = grp & 1;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const int srcl = (t & 3) * 16 + j;
+        const float p0 = __shfl(pp[0][t >> 2], srcl, VOX_WAVE), p1 = __shfl(pp[1][t >> 2], srcl, VOX_WAVE);
+        if (t < nt) {
+            const float pt = g ? p1 : p0;
+            const uint4 vx = (t == nt - 1) ? vnc : vr[t];
+            l = l + pt;
+            o[0] = __fmaf_rn(pt, bflo(vx.x), o[0]); o[1] = __fmaf_rn(pt, bfhi(vx.x), o[1]);
+            o[2] = __fmaf_rn(pt, bflo(vx.y), o[2]); o[3] = __fmaf_rn(pt, bfhi(vx.y), o[3]);
+            o[4] = __fmaf_rn(pt, bflo(vx.z), o[4]); o[5] = __fmaf_rn(pt, bfhi(vx.z), o[5]);
+            o[6] = __fmaf_rn(pt, bflo(vx.w), o[6]); o[7] = __fmaf_rn(pt, bfhi(vx.w), o[7]);
+        }
+    }
+    if (grp < 2) {
+        uint4 r;
+        r.x = pack_bf2(o[0] / l, o[1] / l); r.y = pack_bf2(o[2] / l, o[3] / l);
+        r.z = pack_bf2(o[4] / l, o[5] / l); r.w = pack_bf2(o[6] / l, o[7] / l);
+        reinterpret_cast<uint4*>(out_row + (size_t)(hk * 2 + g) * D)[j] = r;
+    }
+}
+
+// standalone: one wave per (row, kv head), four pairs per block
+__global__ __launch_bounds__(256) void k_attn_short(AttnArgs at, int n_pairs) {
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= n_pairs) return;
+    const int row = pi / at.Hkv, hk = pi % at.Hkv;
+    attn_short_wave(at, row, hk, threadIdx.x & 63, at.out + (size_t)row * at.Hq * 128, true);
+}
+
+// Fused into the o_proj GEMV: every o_proj block recomputes the row's attention (8 waves: one (row, kv head) pair
+// each per round) into LDS while its weight rows are in flight, block 0 appends the new K/V to the cache.
+template <int BT, int KC, int R>
+__global__ __launch_bounds__(512) void k_attn1_linear(AttnArgs at, LinArgs a) {
+    __shared__ __attribute__((aligned(16))) uint4 xs[BT * KC * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 8 + wave) * R;
+    uint4 w[R][KC];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int n = n0 + r;
+        n = n < a.N ? n : a.N - 1;
+        const uint4* wr = reinterpret_cast<const uint4*>(a.W + (size_t)n * a.K);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) w[r][j] = wr[lane + 64 * j];     // depth weights: re-read every step, keep cached
+    }
+    float res_pre = 0.0f, bias_pre = 0.0f;
+    {
+        const int po = lane / BT, pb = lane % BT;
+        if (lane < R * BT && pb < a.B && n0 + po < a.N) {
+            if (a.residual) res_pre = bf2f(a.residual[(size_t)pb * a.N + n0 + po]);
+            if (a.bias) bias_pre = bf2f(a.bias[n0 + po]);
+        }
+    }
+    for (int pi = wave; pi < a.B * at.Hkv; pi += 8) {
+        const int row = pi / at.Hkv, hk = pi % at.Hkv;
+        attn_short_wave(at, row, hk, lane, reinterpret_cast<bf16_t*>(xs) + (size_t)row * a.K, blockIdx.x == 0);
+    }
+    __syncthreads();
+    if (n0 >= a.N) return;
+    float acc[R][BT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) sacc = dot8(w[r][j], xs[b * KC * 64 + lane + 64 * j], sacc);
+            acc[r][b] = butterfly<64>(sacc);
+        }
+#pragma unroll
+    for (int o = 0; o < R; ++o)
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            if (lane == o * BT + b && b < a.B && n0 + o < a.N) {
+                const int n = n0 + o;
+                float v = acc[o][b];
+                if (a.bias) v = v + bias_pre;
+                bf16_t r = f2bf(v);
+                if (a.residual) r = f2bf(res_pre + bf2f(r));
+                a.y[(size_t)b * a.N + n] = r;
+            }
+        }
+}
+
+static void fill_attn_args(AttnArgs& a, const AttnCall& c) {
+    a.q = (const bf16_t*)c.q; a.kv = (const bf16_t*)c.kv; a.q_req = c.q_req; a.q_kvlen = c.q_kvlen;
+    a.indptr = c.indptr; a.indices = c.indices; a.part_o = c.part_o; a.part_ml = c.part_ml; a.scale = c.scale;
+    a.Hq = c.Hq; a.Hkv = c.Hkv; a.page_size = c.page_size; a.max_chunks = c.max_chunks;
+    a.qkv = (const bf16_t*)c.qkv; a.kv_w = (bf16_t*)const_cast<void*>(c.kv); a.qn = (const bf16_t*)c.qn;
+    a.kn = (const bf16_t*)c.kn; a.cs = c.cs; a.pos = c.pos; a.page = c.page; a.slot = c.slot; a.eps = c.eps;
+    a.rot = c.rot; a.interleave = c.interleave; a.table_max_pos = c.table_max_pos;
+    a.ptab = c.ptab; a.pt_stride = c.pt_stride; a.fixed_kvlen = c.fixed_kvlen; a.fixed_pos = c.fixed_pos;
+    a.identity_pages = c.identity_pages;
+    a.out = nullptr;
+}
+
+// short-context decode attention: D 128, two q heads per kv head, full-width NeoX RoPE, <= 16 visible tokens
+bool vox_attn_short_supported(const AttnCall& c) {
+    return c.qkv && c.D == 128 && c.max_kvlen <= 16 && c.Nq >= 1 && c.Hkv > 0 && c.Hq == 2 * c.Hkv && c.rot == 128 &&
+           !c.interleave && c.cs;
+}
+int vox_launch_attn_short(hipStream_t st, const AttnCall& c) {
+    if (!vox_attn_short_supported(c) || !c.out) return vox_fail(VOX_ERR_INVALID, "attn_short: unsupported shape");
+    AttnArgs at{};
+    fill_attn_args(at, c);
+    at.out = (bf16_t*)c.out;
+    const int n_pairs = c.Nq * c.Hkv;
+    hipLaunchKernelGGL(k_attn_short, dim3((n_pairs + 3) / 4), dim3(256), 0, st, at, n_pairs);
+    return VOX_OK;
+}
+// true when the fused short-attention + o_proj kernel covers this call (else the caller launches the two kernels)
+bool vox_attn1_linear_supported(const AttnCall& c, const LinearCall& l) {
+    return vox_attn_short_supported(c) && c.Nq <= 2 && l.K == c.Hq * c.D && l.K == 2048 && l.pro == PRO_COPY &&
+           l.epi == EPI_STORE && !l.x_rows && l.B == c.Nq;
+}
+int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const LinearCall& l) {
+    if (!vox_attn1_linear_supported(c, l)) return vox_fail(VOX_ERR_INVALID, "attn1_linear: unsupported shape");
+    AttnArgs at{};
+    fill_attn_args(at, c);
+    LinArgs a{};
+    a.W = (const bf16_t*)l.W; a.bias = (const bf16_t*)l.bias; a.residual = (const bf16_t*)l.residual; a.y = (bf16_t*)l.y;
+    a.B = l.B; a.N = l.N; a.K = l.K;
+    const dim3 grid((l.N + 7) / 8);
+    if (l.B == 1) hipLaunchKernelGGL((k_attn1_linear<1, 4, 1>), grid, dim3(512), 0, st, at, a);
+    else hipLaunchKernelGGL((k_attn1_linear<2, 4, 1>), grid, dim3(512), 0, st, at, a);
+    return VOX_OK;
+}
 // merge partials -> bf16 out [Nq,Hq,D] (standalone op path; the engine merges inside the o_proj prologue)
 __global__ __launch_bounds__(256) void k_attn_merge(const float* part_o, const float* part_ml, const int* kvlen,
                                                     bf16_t* out, int Hq, int D, int max_chunks, int total) {

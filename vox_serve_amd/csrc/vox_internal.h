@@ -48,6 +48,10 @@ struct LinearCall {
     long x_stride = 0, x_out_stride = 0;  // elements; 0 = K
     float eps = 1e-6f;
     int B = 0, N = 0, K = 0, Hq = 0, D = 0, max_chunks = 0;
+    void* splitk_ws = nullptr;      // fp32 workspace of the > 32-row split-K GEMM: >= ceil(K/512) * 128 * Ntot * 4 bytes
+    size_t splitk_ws_bytes = 0;
+    void* norm_scratch = nullptr;   // [B,K] bf16: lets > 32-row calls with a norm prologue normalise once up front
+    int keep_weights = 0;   // weights are re-read within the frame (depth loop): do not stream them past the caches
     int pro = 0, epi = 0;  // PRO_* / EPI_*
     int fixed_order = 0;   // 1: keep the fixed-order VALU kernel even above 8 rows (depth step 1 of a <= 8 request frame)
 };
@@ -85,6 +89,10 @@ struct AttnCall {
     int pt_stride = 0, fixed_kvlen = 0, fixed_pos = -1, identity_pages = 0;
 };
 int vox_launch_attn_partial(hipStream_t st, const AttnCall& c);
+bool vox_attn_short_supported(const AttnCall& c);
+int vox_launch_attn_short(hipStream_t st, const AttnCall& c);
+bool vox_attn1_linear_supported(const AttnCall& c, const struct LinearCall& l);
+int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const struct LinearCall& l);
 int vox_launch_attn_merge(hipStream_t st, const float* part_o, const float* part_ml, const int* kvlen, void* out,
                           int Nq, int Hq, int D, int max_chunks);
 int vox_launch_gather(hipStream_t st, const void* table, const int* ids, int id_stride, int id_off, void* dst,
