@@ -12,6 +12,7 @@
 //   * LayerNorm / RMSNorm / depthwise conv run over the contiguous channel axis.
 // Weights stay bf16 in HBM ([tap][N][Cin], packed once on the host side) and are widened when staged to LDS.
 #include "vox_internal.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -20,8 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ================================================================================================
 #define CG_BM 64
 #define CG_BN 64
-#define CG_BK 32
-#define CG_LD (CG_BK + 4)   // LDS row stride in floats (16-byte aligned rows, spreads banks)
+#define CG_BK 32            // smallest K chunk (Cin granularity); 64-wide chunks are used where Cin allows
 #define CG_MAXTAPS 8
 
 struct ConvGemmArgs {
@@ -37,75 +37,114 @@ struct ConvGemmArgs {
     int off[CG_MAXTAPS];   // row look-back of each tap
 };
 
+// WM x WN 16x16 MFMA tiles per wave, 2 x 2 waves: block tile (32 WM) x (32 WN).  Smaller tiles are used when the
+// 64 x 64 grid would leave most of the 256 CUs idle (the mid-size decoder stages are MFMA-bound per CU).
+template <int BK, int WM, int WN>
 __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[CG_BM * CG_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[CG_BN * CG_LD];
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    constexpr int LD = BK + 4;          // LDS row stride in floats (16-byte aligned rows, spreads banks)
+    constexpr int SEG = BK / 8;         // 8-element segments per row
+    constexpr int NA = (BM * SEG + 255) / 256, NB = (BN * SEG + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * CG_BM, n0 = blockIdx.x * CG_BN;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wm = (wave >> 1) * 16 * WM, wn = (wave & 1) * 16 * WN;
 
-    f32x4 acc[2][2];
+    f32x4 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nck = a.Cin / BK, nit = a.n_taps * nck;
 
-    // staging roles: A: thread -> (row = tid/4, 8 floats at col (tid%4)*8);  B: thread -> (row = tid/4, 8 bf16 at (tid%4)*8)
-    const int sr = tid >> 2, sc = (tid & 3) * 8;
-    const int am = m0 + sr;
-    const bool a_ok = am < a.M;
-    const int ab = a_ok ? am / a.L : 0, at = a_ok ? am % a.L : 0;
-    const int bn = n0 + sr;
-    const bool b_ok = bn < a.N;
-
-    for (int tap = 0; tap < a.n_taps; ++tap) {
-        const int st = at - a.off[tap];
-        const float* arow = nullptr;
-        if (a_ok) {
-            if (st >= 0) arow = a.x + ((size_t)ab * a.L + st) * a.Cin;
-            else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[ab] * a.P + (a.P + st)) * a.Cin;
+    // staging slots of this thread: (row, segment) pairs of the A and B tiles
+    int a_b[NA], a_t[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + 256 * i, am = m0 + idx / SEG;
+        a_ok[i] = idx < BM * SEG && am < a.M;
+        a_b[i] = a_ok[i] ? am / a.L : 0;
+        a_t[i] = a_ok[i] ? am % a.L : 0;
+    }
+    // the operands of step it+1 are requested before the MFMAs of step it
+    float4 v0[NA], v1[NA];
+    uint4 wv[NB];
+    auto fetch = [&](int it) {
+        const int tap = it / nck, c0 = (it - tap * nck) * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int seg = (tid + 256 * i) % SEG;
+            v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v1[i] = v0[i];
+            if (a_ok[i]) {
+                const int st = a_t[i] - a.off[tap];
+                const float* arow = nullptr;
+                if (st >= 0) arow = a.x + ((size_t)a_b[i] * a.L + st) * a.Cin;
+                else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[a_b[i]] * a.P + (a.P + st)) * a.Cin;
+                if (arow) {
+                    v0[i] = *reinterpret_cast<const float4*>(arow + c0 + seg * 8);
+                    v1[i] = *reinterpret_cast<const float4*>(arow + c0 + seg * 8 + 4);
+                }
+            }
         }
-        const bf16_t* brow = b_ok ? a.w + ((size_t)tap * a.N + bn) * a.Cin : nullptr;
-        for (int c0 = 0; c0 < a.Cin; c0 += CG_BK) {
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            if (arow) {
-                v0 = *reinterpret_cast<const float4*>(arow + c0 + sc);
-                v1 = *reinterpret_cast<const float4*>(arow + c0 + sc + 4);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i, bn = n0 + idx / SEG;
+            wv[i] = make_uint4(0, 0, 0, 0);
+            if (idx < BN * SEG && bn < a.N)
+                wv[i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.N + bn) * a.Cin + c0 + (idx % SEG) * 8);
+        }
+    };
+    fetch(0);
+    for (int it = 0; it < nit; ++it) {
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BM * SEG) {
+                float* d = &As[(idx / SEG) * LD + (idx % SEG) * 8];
+                *reinterpret_cast<float4*>(d) = v0[i];
+                *reinterpret_cast<float4*>(d + 4) = v1[i];
             }
-            uint4 wv = make_uint4(0, 0, 0, 0);
-            if (brow) wv = *reinterpret_cast<const uint4*>(brow + c0 + sc);
-            __syncthreads();   // previous tile fully consumed
-            *reinterpret_cast<float4*>(&As[sr * CG_LD + sc]) = v0;
-            *reinterpret_cast<float4*>(&As[sr * CG_LD + sc + 4]) = v1;
-            *reinterpret_cast<float4*>(&Bs[sr * CG_LD + sc]) = make_float4(bflo(wv.x), bfhi(wv.x), bflo(wv.y), bfhi(wv.y));
-            *reinterpret_cast<float4*>(&Bs[sr * CG_LD + sc + 4]) = make_float4(bflo(wv.z), bfhi(wv.z), bflo(wv.w), bfhi(wv.w));
-            __syncthreads();
-            // each lane owns k = 4*(lane>>4)+s of every 16-wide K block: one float4 per operand feeds 4 MFMA steps
-            const int fr = lane & 15, fk = (lane >> 4) * 4;
+        }
 #pragma unroll
-            for (int kb = 0; kb < CG_BK; kb += 16) {
-                float4 af[2], bf[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4*>(&As[(wm + i * 16 + fr) * CG_LD + kb + fk]);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 16 + fr) * CG_LD + kb + fk]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                    }
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BN * SEG) {
+                float* d = &Bs[(idx / SEG) * LD + (idx % SEG) * 8];
+                *reinterpret_cast<float4*>(d) = make_float4(bflo(wv[i].x), bfhi(wv[i].x), bflo(wv[i].y), bfhi(wv[i].y));
+                *reinterpret_cast<float4*>(d + 4) = make_float4(bflo(wv[i].z), bfhi(wv[i].z), bflo(wv[i].w), bfhi(wv[i].w));
             }
+        }
+        __syncthreads();
+        if (it + 1 < nit) fetch(it + 1);
+        // each lane owns k = 4*(lane>>4)+s of every 16-wide K block: one float4 per operand feeds 4 MFMA steps
+        const int fr = lane & 15, fk = (lane >> 4) * 4;
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 16) {
+            float4 af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[(wm + i * 16 + fr) * LD + kb + fk]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 16 + fr) * LD + kb + fk]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
         }
     }
     // epilogue: D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < WN; ++j) {
             const int n = n0 + wn + j * 16 + (lane & 15);
             if (n >= a.N) continue;
             const float bv = a.bias ? a.bias[n % a.bias_mod] : 0.0f;
@@ -122,6 +161,91 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
                 a.out[o] = v;
             }
         }
+}
+
+// Few-row variant (M <= 48: the transformer and the first upsampling stages of a single request's chunk): tile
+// 16(M) x 64(N), one n-tile per wave, K walked in BK-wide chunks (128 where Cin allows) with the same one-step
+// register prefetch.  These stages run a handful of blocks: time = number of dependent K steps, so the steps are wide.
+template <int BK>
+__global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
+    constexpr int LD = BK + 4;
+    constexpr int NA = (16 * BK / 4 + 255) / 256;   // float4 per thread (activations)
+    constexpr int NB = 64 * BK / 8 / 256;           // uint4 per thread (weights)
+    constexpr int SEGA = BK / 4, SEGB = BK / 8;
+    __shared__ __attribute__((aligned(16))) float As[16 * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nck = a.Cin / BK, nit = a.n_taps * nck;
+    float4 av[NA];
+    uint4 bv[NB];
+    auto fetch = [&](int it) {
+        const int tap = it / nck, c0 = (it - tap * nck) * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 256 * i, r = idx / SEGA, seg = idx % SEGA;
+            av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int am = m0 + r;
+            if (idx < 16 * SEGA && am < a.M) {
+                const int ab = am / a.L, st = am % a.L - a.off[tap];
+                const float* arow = nullptr;
+                if (st >= 0) arow = a.x + ((size_t)ab * a.L + st) * a.Cin;
+                else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[ab] * a.P + (a.P + st)) * a.Cin;
+                if (arow) av[i] = *reinterpret_cast<const float4*>(arow + c0 + seg * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i, r = idx / SEGB, seg = idx % SEGB;
+            const int bn = n0 + r;
+            bv[i] = make_uint4(0, 0, 0, 0);
+            if (bn < a.N) bv[i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.N + bn) * a.Cin + c0 + seg * 8);
+        }
+    };
+    fetch(0);
+    for (int it = 0; it < nit; ++it) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 16 * SEGA) *reinterpret_cast<float4*>(&As[(idx / SEGA) * LD + (idx % SEGA) * 4]) = av[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + 256 * i;
+            float* d = &Bs[(idx / SEGB) * LD + (idx % SEGB) * 8];
+            *reinterpret_cast<float4*>(d) = make_float4(bflo(bv[i].x), bfhi(bv[i].x), bflo(bv[i].y), bfhi(bv[i].y));
+            *reinterpret_cast<float4*>(d + 4) = make_float4(bflo(bv[i].z), bfhi(bv[i].z), bflo(bv[i].w), bfhi(bv[i].w));
+        }
+        __syncthreads();
+        if (it + 1 < nit) fetch(it + 1);
+        const int fr = lane & 15, fk = (lane >> 4) * 4;
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 16) {
+            const float4 af = *reinterpret_cast<const float4*>(&As[fr * LD + kb + fk]);
+            const float4 bf = *reinterpret_cast<const float4*>(&Bs[(wave * 16 + fr) * LD + kb + fk]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc, 0, 0, 0);
+        }
+    }
+    const int n = n0 + wave * 16 + (lane & 15);
+    if (n >= a.N) return;
+    const float bvv = a.bias ? a.bias[n % a.bias_mod] : 0.0f;
+    const float sv = a.scale ? a.scale[n] : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (lane >> 4) * 4 + r;
+        if (m >= a.M) continue;
+        float v = acc[r] + bvv;
+        if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        const size_t o = (size_t)m * a.N + n;
+        if (a.res) v = a.res[o] + sv * v;
+        else if (a.scale) v = sv * v;
+        a.out[o] = v;
+    }
 }
 
 // ================================================================================================
@@ -217,67 +341,68 @@ __global__ __launch_bounds__(256) void k_codec_rope_kv(float* qkv, bf16_t* ring,
 
 // windowed attention over the ring.  Query i (absolute position p0+i) sees absolute positions
 // [p0+T-Wn, p0+i]; positions < 0 are the reference's never-written zero slots, which stay visible.
-__global__ __launch_bounds__(128) void k_codec_attn(const float* qkv, const bf16_t* ring, const int* slots, const long* pos,
+// One block per (head, request): K/V ring tile in LDS (row stride D+1: conflict-free both for "lane = key" in the
+// scores and "lane = dim" in PV), the T queries of the chunk spread over the four waves.
+__global__ __launch_bounds__(256) void k_codec_attn(const float* qkv, const bf16_t* ring, const int* slots, const long* pos,
                                                     float* out, int T, int H, int D, int Wn) {
-    extern __shared__ float sm[];   // K [Wn][D], V [Wn][D], P [Wn]
+    extern __shared__ float sm[];   // K [Wn][D+1], V [Wn][D+1], Q [T][D], P [4][Wn]
+    const int LD = D + 1;
     float* Ks = sm;
-    float* Vs = sm + (size_t)Wn * D;
-    float* Ps = Vs + (size_t)Wn * D;
-    __shared__ float red[2];
-    const int h = blockIdx.x, b = blockIdx.y;
+    float* Vs = Ks + (size_t)Wn * LD;
+    float* Qs = Vs + (size_t)Wn * LD;
+    float* Ps = Qs + (size_t)T * D;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int HD = H * D;
-    const long p0 = pos[slots[b]];
+    const int slot = slots[b];
+    const long p0 = pos[slot];
     const long lo = p0 + T - Wn;   // absolute position of logical slot 0
-    for (int e = threadIdx.x; e < Wn * D; e += 128) {
+    for (int e = tid; e < Wn * D; e += 256) {
         const int j = e / D, d = e % D;
         const long ap = lo + j;
         float kv = 0.0f, vv = 0.0f;
         if (ap >= 0) {
-            const bf16_t* r = ring + (((size_t)slots[b] * Wn + (ap % Wn)) * 2) * HD + (size_t)h * D + d;
+            const bf16_t* r = ring + (((size_t)slot * Wn + (ap % Wn)) * 2) * HD + (size_t)h * D + d;
             kv = bf2f(r[0]);
             vv = bf2f(r[HD]);
         }
-        Ks[e] = kv;
-        Vs[e] = vv;
+        Ks[j * LD + d] = kv;
+        Vs[j * LD + d] = vv;
     }
+    for (int e = tid; e < T * D; e += 256) Qs[e] = qkv[((size_t)(b * T + e / D)) * 3 * HD + (size_t)h * D + e % D];
     __syncthreads();
     const float scale = rsqrtf((float)D);
-    for (int i = 0; i < T; ++i) {
-        const float* q = qkv + ((size_t)(b * T + i)) * 3 * HD + (size_t)h * D;
+    float* P = Ps + (size_t)wave * Wn;
+    for (int i = wave; i < T; i += 4) {
+        const float* q = Qs + (size_t)i * D;
         const int nvis = Wn - T + i + 1;
         float mx = -INFINITY;
-        for (int j = threadIdx.x; j < Wn; j += 128) {
-            float s = -INFINITY;
+        for (int j = lane; j < Wn; j += 64) {
+            float sc = -INFINITY;
             if (j < nvis) {
-                s = 0.0f;
-                for (int d = 0; d < D; ++d) s += q[d] * Ks[j * D + d];
-                s *= scale;
+                sc = 0.0f;
+                for (int d = 0; d < D; ++d) sc = fmaf(q[d], Ks[j * LD + d], sc);
+                sc *= scale;
             }
-            Ps[j] = s;
-            mx = fmaxf(mx, s);
+            P[j] = sc;
+            mx = fmaxf(mx, sc);
         }
         for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-        __syncthreads();
-        mx = fmaxf(red[0], red[1]);
         float ls = 0.0f;
-        for (int j = threadIdx.x; j < Wn; j += 128) {
-            const float pj = j < nvis ? expf(Ps[j] - mx) : 0.0f;
-            Ps[j] = pj;
+        for (int j = lane; j < Wn; j += 64) {
+            const float pj = j < nvis ? expf(P[j] - mx) : 0.0f;
+            P[j] = pj;
             ls += pj;
         }
         for (int off = 32; off >= 1; off >>= 1) ls += __shfl_xor(ls, off, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ls;
-        __syncthreads();
-        ls = red[0] + red[1];
-        for (int d = threadIdx.x; d < D; d += 128) {
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int d = lane; d < D; d += 64) {
             float o = 0.0f;
-            for (int j = 0; j < nvis; ++j) o += Ps[j] * Vs[j * D + d];
+            for (int j = 0; j < nvis; ++j) o = fmaf(P[j], Vs[j * LD + d], o);
             out[((size_t)(b * T + i)) * HD + (size_t)h * D + d] = o / ls;
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
     }
 }
 
@@ -374,9 +499,22 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     a.out = out; a.M = n * L; a.N = w.n; a.Cin = w.cin; a.L = L; a.P = P; a.n_taps = w.n_taps;
     a.bias_mod = w.bias_mod > 0 ? w.bias_mod : w.n; a.gelu = gelu;
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
-    dim3 grid((w.n + CG_BN - 1) / CG_BN, (a.M + CG_BM - 1) / CG_BM);
-    hipLaunchKernelGGL(k_conv_gemm, grid, dim3(256), 0, st, a);
-    return VOX_OK;
+    if (a.M <= 48) {
+        const dim3 g((w.n + 63) / 64, (a.M + 15) / 16);
+        if (w.cin % 128 == 0) hipLaunchKernelGGL(k_conv_gemm_skinny<128>, g, dim3(256), 0, st, a);
+        else if (w.cin % 64 == 0) hipLaunchKernelGGL(k_conv_gemm_skinny<64>, g, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_conv_gemm_skinny<32>, g, dim3(256), 0, st, a);
+        return VOX_OK;
+    }
+    // tile: 64 x 64 unless that leaves most CUs idle (these GEMMs are MFMA-bound per CU)
+    const int b64 = ((w.n + 63) / 64) * ((a.M + 63) / 64);
+    const int wm = b64 >= 192 ? 2 : 1, wn = (b64 >= 192 || 2 * b64 >= 192) ? 2 : 1;
+    const dim3 grid((w.n + 32 * wn - 1) / (32 * wn), (a.M + 32 * wm - 1) / (32 * wm));
+#define VOX_CG(K_, M_, N_) if (wm == M_ && wn == N_) { hipLaunchKernelGGL((k_conv_gemm<K_, M_, N_>), grid, dim3(256), 0, st, a); return VOX_OK; }
+    if (w.cin % 64 == 0) { VOX_CG(64, 2, 2) VOX_CG(64, 1, 2) VOX_CG(64, 1, 1) }
+    VOX_CG(32, 2, 2) VOX_CG(32, 1, 2) VOX_CG(32, 1, 1)
+#undef VOX_CG
+    return vox_fail(VOX_ERR_INVALID, "codec gemm: no tile variant");
 }
 
 static void snake(hipStream_t st, const float* x, const vox_snake_w& s, float* y, size_t rows, int C) {
@@ -502,7 +640,8 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
         VOX_TRY(conv_gemm(st, lw.qkv, C, nullptr, slots, n, L, 0, off0, D, nullptr, nullptr, 0));        // D [nL,3HD]
         hipLaunchKernelGGL(k_codec_rope_kv, dim3(n * L), dim3(256), 0, st, D, ring, slots, m->pos, L, c.num_heads,
                            c.head_dim, c.window, w.inv_freq);
-        hipLaunchKernelGGL(k_codec_attn, dim3(c.num_heads, n), dim3(128), (size_t)(2 * c.window * c.head_dim + c.window) * 4,
+        hipLaunchKernelGGL(k_codec_attn, dim3(c.num_heads, n), dim3(256),
+                           (size_t)(2 * c.window * (c.head_dim + 1) + L * c.head_dim + 4 * c.window) * 4,
                            st, D, ring, slots, m->pos, C, L, c.num_heads, c.head_dim, c.window);         // C [nL,HD]
         VOX_TRY(conv_gemm(st, lw.o, C, nullptr, slots, n, L, 0, off0, B, B, lw.scale1, 0));              // h += s1*o(attn)
         hipLaunchKernelGGL(k_rmsnorm_f32, dim3(n * L), dim3(256), 0, st, B, lw.ln2, C, H, c.rms_eps);
