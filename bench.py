@@ -158,6 +158,19 @@ def cpu_baseline(loop, budget_s=25.0):
                       f"oracle = C fixed-order fp32 + torch-CPU codec"}
 
 
+def pmc_traffic(B):
+    """HBM bytes per LM graph launch from the committed rocprofv3 PMC passes of this same command (profiles/
+    round1_pmc_traffic.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py).  Counters cannot be read from inside the
+    timed run, so this is the recorded measurement for the same batch size, or null when none is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(f"batch_{B}")
+        return float(rec["fetch_corrected_bytes_per_launch"] + rec["write_raw_bytes_per_launch"]) if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,7 +249,7 @@ def main():
             "realtime_factor": samples_total / dt / 24000.0 / (world * B),
             "ttfa_ms_p50": float(np.median(ttfa)) if ttfa else None,
             "roofline": {"bound": "hbm", "achieved": alg / frame_gpu_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / frame_gpu_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": alg / frame_gpu_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(B),
                          "launch": "one hipGraph replay = one LM frame (talker + 15 depth steps + sampling)",
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": frame_gpu_s * 1e3},
         }
