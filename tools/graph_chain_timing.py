@@ -9,19 +9,19 @@ dev = torch.device("cuda")
 L, ctx = N.lib(), N.ctx()
 st = torch.cuda.Stream()
 
-def chain(shapes, reps, label):
+def chain(shapes, reps, label, B=1):
     """shapes: list of (N,K); chain x -> y -> ... with rotating weights."""
     Ws, bufs = [], {}
     for r in range(reps):
         for (Nn, K) in shapes:
             Ws.append(torch.randn(Nn, K, device=dev, dtype=torch.bfloat16) * 0.02)
-    x = {k: torch.randn(1, k, device=dev, dtype=torch.bfloat16) for k in {s[1] for s in shapes} | {s[0] for s in shapes}}
+    x = {k: torch.randn(B, k, device=dev, dtype=torch.bfloat16) for k in {s[1] for s in shapes} | {s[0] for s in shapes}}
     with torch.cuda.stream(st):
         def body():
             i = 0
             for r in range(reps):
                 for (Nn, K) in shapes:
-                    N.check(L.vox_linear(ctx, N.stream(), N.ptr(Ws[i]), None, N.ptr(x[K]), None, N.ptr(x[Nn]), 1, Nn, K, 0))
+                    N.check(L.vox_linear(ctx, N.stream(), N.ptr(Ws[i]), None, N.ptr(x[K]), None, N.ptr(x[Nn]), B, Nn, K, 0))
                     i += 1
         body(); st.synchronize()
         N.check(L.vox_graph_begin(ctx, N.stream())); body()
@@ -35,13 +35,14 @@ def chain(shapes, reps, label):
     n = reps * len(shapes)
     mb = sum(a * b * 2 for a, b in shapes) * reps / 1e6
     us = e0.elapsed_time(e1) * 1000 / 5
-    print(f"{label:28s} {n:4d} kernels {mb:7.1f} MB  {us/n:6.2f} us/kernel  {mb/us/1e6*1e6/1e6:5.2f} TB/s")
+    print(f"B={B} {label:28s} {n:4d} kernels {mb:7.1f} MB  {us/n:6.2f} us/kernel  {mb/us/1e6*1e6/1e6:5.2f} TB/s")
 
-chain([(1024, 1024)], 300, "1024x1024 repeated")
-chain([(4096, 1024)], 75, "4096x1024 repeated")
-chain([(1024, 2048)], 150, "1024x2048 repeated")
-chain([(4096, 1024), (1024, 2048), (2048, 1024), (3072, 1024), (1024, 3072)], 30, "depth-like mix (5 shapes)")
-chain([(4096, 2048), (2048, 2048), (6144, 2048), (2048, 6144)], 28, "talker-like mix (4 shapes)")
+if len(sys.argv) > 1 and sys.argv[1] == "rows":
+    for B in (1, 2, 4, 8):
+        chain([(1024, 2048)], 150, "1024x2048 repeated", B)
+        chain([(4096, 1024)], 75, "4096x1024 repeated", B)
+        chain([(2048, 6144)], 40, "2048x6144 repeated", B)
+    sys.exit(0)
 
 
 def stack_chain(reps=15):

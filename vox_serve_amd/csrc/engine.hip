@@ -322,7 +322,7 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
         m = m > sq * cfg->hidden ? m : sq * cfg->hidden;
         m = m > sh * 2 * cfg->ffn ? m : sh * 2 * cfg->ffn;
         m = m > sf * cfg->hidden ? m : sf * cfg->hidden;
-        s->skws_bytes = R > 32 ? m * 128 * 4 : 256;
+        s->skws_bytes = R > 8 ? m * 128 * 4 : 256;
     }
     if (hipMalloc(&s->qkv, R * (nq + 2 * nkv) * 2) != hipSuccess || hipMalloc(&s->q, R * nq * 2) != hipSuccess ||
         hipMalloc(&s->h, R * cfg->ffn * 2) != hipSuccess || hipMalloc(&s->attn_out, R * nq * 2) != hipSuccess ||
@@ -421,6 +421,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         LinearCall p;  // small_to_mtp_projection
         p.W = m->w.mtp_w; p.bias = m->w.mtp_b; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
         p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8; p.keep_weights = m->depth->keep_weights;
+        p.splitk_ws = m->depth->skws; p.splitk_ws_bytes = m->depth->skws_bytes;
         VOX_TRY(vox_launch_linear(m->ctx, st, p));
         vox_rows r{};
         r.pos = i == 1 ? m->d1_pos : m->di_pos[i];

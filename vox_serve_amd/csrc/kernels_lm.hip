@@ -214,11 +214,35 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (c + 64 * u < nch) {
+                    if constexpr (BT == 1) {
+                        const uint4 xv = xs[c + 64 * u];
 #pragma unroll
-                    for (int b = 0; b < BT; ++b) {
-                        const uint4 xv = xs[b * nch + c + 64 * u];
+                        for (int r = 0; r < R; ++r) acc[r][0] = dot8(w[u][r], xv, acc[r][0]);
+                    } else {
+                        // two rows per v_pk_fma_f32 (same IEEE fma per half, same order as dot8: bit-identical sums, half
+                        // the FMA issue slots); the unpacked weight chunk is shared by all row pairs
+                        float wf[R][8];
 #pragma unroll
-                        for (int r = 0; r < R; ++r) acc[r][b] = dot8(w[u][r], xv, acc[r][b]);
+                        for (int r = 0; r < R; ++r) {
+                            const uint4 wq = w[u][r];
+                            wf[r][0] = bflo(wq.x); wf[r][1] = bfhi(wq.x); wf[r][2] = bflo(wq.y); wf[r][3] = bfhi(wq.y);
+                            wf[r][4] = bflo(wq.z); wf[r][5] = bfhi(wq.z); wf[r][6] = bflo(wq.w); wf[r][7] = bfhi(wq.w);
+                        }
+#pragma unroll
+                        for (int bp = 0; bp < BT / 2; ++bp) {
+                            const uint4 x0 = xs[(2 * bp) * nch + c + 64 * u], x1 = xs[(2 * bp + 1) * nch + c + 64 * u];
+                            const vox_f2 xp[8] = {{bflo(x0.x), bflo(x1.x)}, {bfhi(x0.x), bfhi(x1.x)}, {bflo(x0.y), bflo(x1.y)},
+                                                  {bfhi(x0.y), bfhi(x1.y)}, {bflo(x0.z), bflo(x1.z)}, {bfhi(x0.z), bfhi(x1.z)},
+                                                  {bflo(x0.w), bflo(x1.w)}, {bfhi(x0.w), bfhi(x1.w)}};
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                vox_f2 a2 = {acc[r][2 * bp], acc[r][2 * bp + 1]};
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) a2 = __builtin_elementwise_fma((vox_f2){wf[r][e], wf[r][e]}, xp[e], a2);
+                                acc[r][2 * bp] = a2.x;
+                                acc[r][2 * bp + 1] = a2.y;
+                            }
+                        }
                     }
                 }
             }
@@ -319,15 +343,54 @@ __global__ __launch_bounds__(256) void k_gemv(LinArgs a) {
         }
     }
     float acc[R][BT];
+    if constexpr (BT == 1) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int b = 0; b < BT; ++b) {
+        for (int r = 0; r < R; ++r) {
             float s = 0.0f;
 #pragma unroll
-            for (int j = 0; j < KC; ++j) s = dot8(w[r][j], xv[b][j], s);
-            acc[r][b] = butterfly<64>(s);
+            for (int j = 0; j < KC; ++j) s = dot8(w[r][j], xv[0][j], s);
+            acc[r][0] = butterfly<64>(s);
         }
+    } else {
+        // two rows per v_pk_fma_f32: (w,w) x (x_b, x_b+1) + (acc_b, acc_b+1) — each half is the same IEEE fma, in the
+        // same e / chunk order as dot8, so the sums are bit-identical while the FMA issue count halves; the unpacked
+        // activation pair is shared by the R weight rows of the wave
+        constexpr int BP = BT >= 2 ? BT / 2 : 1;   // (BT == 1 never takes this branch)
+        vox_f2 acc2[R][BP];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int bp = 0; bp < BP; ++bp) acc2[r][bp] = (vox_f2){0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            vox_f2 xp[BP][8];
+#pragma unroll
+            for (int bp = 0; bp < BP; ++bp) {
+                const uint4 x0 = xv[2 * bp][j], x1 = xv[2 * bp + 1][j];
+                xp[bp][0] = (vox_f2){bflo(x0.x), bflo(x1.x)}; xp[bp][1] = (vox_f2){bfhi(x0.x), bfhi(x1.x)};
+                xp[bp][2] = (vox_f2){bflo(x0.y), bflo(x1.y)}; xp[bp][3] = (vox_f2){bfhi(x0.y), bfhi(x1.y)};
+                xp[bp][4] = (vox_f2){bflo(x0.z), bflo(x1.z)}; xp[bp][5] = (vox_f2){bfhi(x0.z), bfhi(x1.z)};
+                xp[bp][6] = (vox_f2){bflo(x0.w), bflo(x1.w)}; xp[bp][7] = (vox_f2){bfhi(x0.w), bfhi(x1.w)};
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint4 wq = w[r][j];
+                const float wf[8] = {bflo(wq.x), bfhi(wq.x), bflo(wq.y), bfhi(wq.y), bflo(wq.z), bfhi(wq.z), bflo(wq.w), bfhi(wq.w)};
+#pragma unroll
+                for (int bp = 0; bp < BP; ++bp)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        acc2[r][bp] = __builtin_elementwise_fma((vox_f2){wf[e], wf[e]}, xp[bp][e], acc2[r][bp]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int bp = 0; bp < BP; ++bp) {
+                acc[r][2 * bp] = butterfly<64>(acc2[r][bp].x);
+                acc[r][2 * bp + 1] = butterfly<64>(acc2[r][bp].y);
+            }
+    }
 #pragma unroll
     for (int o = 0; o < OUT; ++o)
 #pragma unroll
@@ -364,6 +427,8 @@ static int launch_gemv_k(hipStream_t st, const LinArgs& a) {
     if (cols == 0) cols = (a.N / (SM ? 1 : 1) >= 4096 && KC <= 4) ? 2 : 1;
     if (SM) cols = cols > 2 ? 2 : cols;
     while (cols > 1 && cols * (SM ? 2 : 1) * KC > 24) cols >>= 1;
+    if (BT >= 4 && !SM && a.N >= 2048) cols = 2;          // share the unpacked activation pairs between two weight rows
+    if (BT >= 4) while (cols > 1 && cols * (SM ? 2 : 1) * KC > 8) cols >>= 1;
 #define VOX_GV(C_)                                                                                       \
     if (cols == C_) {                                                                                    \
         hipLaunchKernelGGL((k_gemv<BT, KC, (SM ? 2 * C_ : C_), PRO, EPI>), dim3((a.N + 4 * C_ - 1) / (4 * C_)), \
@@ -422,7 +487,8 @@ static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
     int r;  // outputs per wave: keep >= 2 blocks per CU in flight where N allows (latency hiding)
     (void)n_cu;
     if (SM) r = 1;                                   // one gate row + one up row per wave
-    else r = (bt <= 2 && outs >= 8192) ? 2 : 1;
+    else r = ((bt <= 2 && outs >= 8192) || (bt >= 4 && outs >= 2048)) ? 2 : 1;   // >= 4 rows: two weight rows share the
+                                                                                     // unpacked activation pairs
     if ((size_t)bt * a.K * 2 > 160 * 1024) return vox_fail(VOX_ERR_INVALID, "linear: K too large for LDS staging");
 #define VOX_LIN(BT_, R_)                                                             \
     if (bt == BT_ && r == R_) return launch_linear_t<BT_, (SM ? 2 * R_ : R_), PRO, EPI>(st, a);
@@ -805,9 +871,9 @@ template <int EPI>
 static int launch_gemm_rows(hipStream_t st, const LinArgs& a) {
     // rows per pass: all of them up to 128 (weights cross HBM once); waves per block: 8 K-interleaved waves keep
     // >= 1024 waves in flight even at N = 2048
-    const int mt = a.B <= 48 ? 3 : a.B <= 80 ? 5 : 8;
+    const int mt = a.B <= 16 ? 1 : a.B <= 32 ? 2 : a.B <= 48 ? 3 : a.B <= 80 ? 5 : 8;
 #define VOX_GR(M_)  if (mt == M_) return launch_gemm_rows_t<M_, 1, 8, EPI>(st, a);
-    VOX_GR(3) VOX_GR(5) VOX_GR(8)
+    VOX_GR(1) VOX_GR(2) VOX_GR(3) VOX_GR(5) VOX_GR(8)
 #undef VOX_GR
     return vox_fail(VOX_ERR_INVALID, "gemm_rows: no variant");
 }
@@ -931,12 +997,14 @@ static int launch_gemm_splitk(hipStream_t st, const LinArgs& a, float* ws, size_
     const int Ntot = SM ? 2 * a.N : a.N;
     for (int b0 = 0; b0 < a.B; b0 += 128) {
         const int bt = (a.B - b0) < 128 ? (a.B - b0) : 128;
-        const int mt = bt <= 64 ? 4 : bt <= 80 ? 5 : 8;
+        const int mt = bt <= 16 ? 1 : bt <= 32 ? 2 : bt <= 64 ? 4 : bt <= 80 ? 5 : 8;
         const int ks = 256;          // slab width: two blocks (tiles of (16 MT + 64) x 264 bf16) share a CU's 160 KB LDS
         const int S = (a.K + ks - 1) / ks, rs = 16 * mt;
         if ((size_t)S * rs * Ntot * 4 > ws_bytes) return vox_fail(VOX_ERR_INVALID, "linear: split-K workspace too small");
         const dim3 grid((Ntot + 63) / 64, S);
-        if (mt == 4) launch_gemm_splitk_t<4, 256, SM>(st, a, ws, b0, bt, rs, grid);
+        if (mt == 1) launch_gemm_splitk_t<1, 256, SM>(st, a, ws, b0, bt, rs, grid);
+        else if (mt == 2) launch_gemm_splitk_t<2, 256, SM>(st, a, ws, b0, bt, rs, grid);
+        else if (mt == 4) launch_gemm_splitk_t<4, 256, SM>(st, a, ws, b0, bt, rs, grid);
         else if (mt == 5) launch_gemm_splitk_t<5, 256, SM>(st, a, ws, b0, bt, rs, grid);
         else launch_gemm_splitk_t<8, 256, SM>(st, a, ws, b0, bt, rs, grid);
         hipLaunchKernelGGL((k_splitk_reduce<EPI>), dim3((bt * a.N + 255) / 256), dim3(256), 0, st, ws, S, rs, a, b0, bt);
@@ -962,7 +1030,9 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     if (dev & 2) a.residual = nullptr;
     if ((dev & 4) && epi == EPI_SILU_MUL) epi = EPI_STORE;
     if (dev & 8) a.bias = nullptr;
-    if (c.B > 32 && !c.fixed_order && c.K % 32 == 0 && (pro == PRO_COPY || (pro == PRO_RMSNORM && c.norm_scratch && !a.x_rows && !a.x_out && a.x_stride == c.K))) {
+    static int rows_min = -1;   // development knob: smallest row count routed to the prefill GEMMs
+    if (rows_min < 0) { const char* e = getenv("VOX_ROWS_MIN"); rows_min = e ? atoi(e) : 17; }
+    if (c.B >= rows_min && !c.fixed_order && c.K % 32 == 0 && (pro == PRO_COPY || (pro == PRO_RMSNORM && c.norm_scratch && !a.x_rows && !a.x_out && a.x_stride == c.K))) {
         // prefill-sized: normalise once (not in every block), then the LDS-free MFMA GEMM
         if (pro == PRO_RMSNORM) {
             if (a.x_rows) return vox_fail(VOX_ERR_INVALID, "linear: row indirection with a norm prologue at > 32 rows");
