@@ -5,6 +5,7 @@ Runs only in the build container (needs /root/reference).  Output: tests/golden/
 
   python tests/golden/make_goldens.py [g1 g2 g3 g4 ...]
 """
+import json
 import os
 import queue
 import sys
@@ -518,8 +519,129 @@ def g6_host_traces(ns):
     print("g6 ok", len(trace), "steps; pcm chunks", sum(len(t["pcm"]) for t in trace))
 
 
+
+# --------------------------------------------------------------------------------------------------
+class _FakeTok:
+    """Deterministic stand-in for the HF tokenizer used by input_streaming.py: one token per 3 characters."""
+    def encode(self, text, add_special_tokens=False):
+        return [sum(map(ord, text[i:i + 3])) % 5000 + 10 for i in range(0, len(text), 3)]
+
+    def decode(self, ids, skip_special_tokens=True):
+        return "".join(f"<{i}>" for i in ids)
+
+
+def _scenario(rng, n_req, interval):
+    """Random request states: prefill pending / decoding / finished, streaming or not, various backlogs."""
+    reqs = []
+    for i in range(n_req):
+        kind = rng.choice(["prefill", "decode", "decode", "done"])
+        ntok = int(rng.integers(0, 4 * interval + 3))
+        step_taken = int(rng.integers(0, 3))
+        r = {"id": f"r{i}", "done_lm_prefill": kind != "prefill", "done_lm_generation": kind == "done",
+             "input_length": int(rng.choice([0, 40, 300, 700, 1100])), "n_tokens": 0 if kind == "prefill" else ntok,
+             "next_idx": [] if step_taken == 0 or kind == "prefill" else [int(rng.integers(0, max(1, ntok // 2)))],
+             "is_streaming": bool(rng.integers(0, 2)), "is_pressing": bool(rng.integers(0, 2)),
+             "is_input_streaming": bool(rng.integers(0, 3) == 0), "prefill_ready": bool(rng.integers(0, 2)),
+             "text_complete": bool(rng.integers(0, 2)), "n_pending_text": int(rng.integers(0, 3)),
+             "chunk_times": [float(x) for x in np.cumsum(rng.uniform(0.05, 0.3, int(rng.integers(0, 4))))],
+             }
+        r["chunk_durs"] = [float(rng.choice([0.8, 0.4, 1.6])) for _ in r["chunk_times"]]
+        reqs.append(r)
+    return reqs
+
+
+def _build_requests(R, spec):
+    out = []
+    for s_ in spec:
+        r = R(request_id=s_["id"], prompt="x")
+        r.done_lm_prefill, r.done_lm_generation = s_["done_lm_prefill"], s_["done_lm_generation"]
+        r.input_length = s_["input_length"] or None
+        r.lm_output_audio_tokens = [None] * s_["n_tokens"]
+        r.next_audio_decode_idx = list(s_["next_idx"])
+        r.is_streaming, r.is_pressing = s_["is_streaming"], s_["is_pressing"]
+        r.is_input_streaming, r.prefill_ready, r.text_complete = s_["is_input_streaming"], s_["prefill_ready"], s_["text_complete"]
+        for t in range(s_["n_pending_text"]):
+            r.pending_text_tokens.put(100 + t)
+        r.chunk_send_timestamps = [1000.0 + t for t in s_["chunk_times"]]
+        r.chunk_durations = list(s_["chunk_durs"])
+        out.append(r)
+    return out
+
+
+def g8_scheduler_policies(ns):
+    """Selection policies of the reference's Online / Offline / InputStreaming schedulers on scripted request states
+    (scheduler/online.py:16-295, offline.py:5-136, input_streaming.py:79-322), incl. the CudaGraphWorker limits."""
+    import logging
+    import types
+    from unittest import mock
+    from vox_serve.scheduler.input_streaming import InputStreamingScheduler
+    from vox_serve.scheduler.offline import OfflineScheduler
+    from vox_serve.scheduler.online import OnlineScheduler
+    from vox_serve.worker import CudaGraphWorker
+    R = ns.requests.Request
+    rng = np.random.default_rng(8)
+    cases = []
+    for ci in range(60):
+        interval, overlap = [(10, 0), (28, 3), (25, 0), (4, 1)][ci % 4]
+        maxb = int(rng.choice([2, 4, 8]))
+        graph_worker = ci % 3 == 0
+        spec = _scenario(rng, int(rng.integers(1, 9)), interval)
+        now = 1000.0 + float(rng.uniform(0, 3))
+        case = {"interval": interval, "overlap": overlap, "max_batch_size": maxb, "graph_worker": graph_worker,
+                "prefill_graph_batch_size": 4, "seq_len_buckets": [256, 512], "now": now, "requests": spec, "out": {}}
+        for name, cls in (("online", OnlineScheduler), ("offline", OfflineScheduler), ("input_streaming", InputStreamingScheduler)):
+            if graph_worker:
+                w = CudaGraphWorker.__new__(CudaGraphWorker)
+                w.prefill_graph_batch_size, w.cuda_graph_seq_len_buckets = 4, [256, 512]
+                w.model = types.SimpleNamespace(detokenize_interval=interval, detokenize_overlap=overlap)
+            else:
+                w = types.SimpleNamespace(detokenize_interval=interval, detokenize_overlap=overlap)
+            sch = cls.__new__(cls)
+            sch.model_worker, sch.max_batch_size, sch.detokenize_max_batch_size = w, maxb, maxb
+            sch.logger = logging.getLogger("golden")
+            sch.sample_rate, sch.bytes_per_sample, sch.channels = 24000, 2, 1
+            res = {}
+            sch.active_requests = _build_requests(R, spec)
+            if name == "online":
+                with mock.patch("time.time", return_value=now):
+                    sch._update_pressing_status()
+                res["pressing"] = [r.is_pressing for r in sch.active_requests]
+            res["lm"] = [r.request_id for r in sch._select_lm_requests()]
+            res["waiting_for_text"] = [bool(r.waiting_for_text) for r in sch.active_requests]
+            if name != "input_streaming":
+                sel = sch._select_detokenize_requests()
+                res["detok"] = [[r.request_id, list(r.next_audio_decode_idx), bool(r.done_all)] for r in sel]
+                res["done_all"] = [bool(r.done_all) for r in sch.active_requests]
+            case["out"][name] = res
+        cases.append(case)
+
+    # input-streaming message handling with a deterministic tokenizer
+    sch = InputStreamingScheduler.__new__(InputStreamingScheduler)
+    sch.logger = logging.getLogger("golden")
+    sch.model_worker = types.SimpleNamespace(supports_audio_input=False,
+                                             model=types.SimpleNamespace(text_tokenizer=_FakeTok()))
+    sch.active_requests = []
+    script = [b'a|TEXT_STREAM_START|{"is_streaming": true, "model_kwargs": {"language": "english"}}', b"a|TEXT_UPDATE|Hello the",
+              b"a|TEXT_UPDATE|re, this is a longer sentence.", b"b|TEXT_STREAM_START|", b"b|TEXT_COMPLETE|",
+              b"a|TEXT_UPDATE| More text", b"c|TEXT_STREAM_START|{}", b"c|TEXT_UPDATE|short", b"c|TEXT_COMPLETE|",
+              b"zz|TEXT_UPDATE|nobody", b"a|TEXT_COMPLETE|", b"a|TEXT_UPDATE|late"]
+    log = []
+    for i, msg in enumerate(script):
+        if i == 5:
+            sch.active_requests[0].done_lm_prefill = True        # the prefill of "a" has run by now
+        req = sch._handle_request_payload(msg)
+        if req is not None:
+            sch.active_requests.append(req)
+        log.append([{"id": r.request_id, "prompt": r.prompt, "buffer": r.input_text_buffer, "prefill_ready": r.prefill_ready,
+                     "pending": list(r.pending_text_tokens.queue), "total_text_tokens": r.total_text_tokens,
+                     "text_complete": r.text_complete, "done_all": r.done_all, "finish_reason": r.finish_reason,
+                     "is_streaming": r.is_streaming, "model_kwargs": r.model_kwargs} for r in sch.active_requests])
+    with open(os.path.join(HERE, "g8_scheduler_policies.json"), "w") as f:
+        json.dump({"cases": cases, "stream_script": [m.decode() for m in script], "stream_log": log}, f, indent=0)
+    print("g8 ok", len(cases), "policy cases;", sum(len(c["out"]["online"]["detok"]) for c in cases), "online detok picks")
+
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies}
 
 if __name__ == "__main__":
     ns = H.boot()

@@ -238,3 +238,134 @@ def test_dp_pool_two_ranks_gloo(tmp_path):
                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script), ROOT],
                          capture_output=True, text=True, env=env, timeout=240)
     assert out.returncode == 0 and "DP_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+# ---------------------------------------------------------------- g8: scheduler policies ------------------------------
+def _g8_requests(spec):
+    from vox_serve_amd.requests import Request
+    out = []
+    for s_ in spec:
+        r = Request(request_id=s_["id"], prompt="x")
+        r.done_lm_prefill, r.done_lm_generation = s_["done_lm_prefill"], s_["done_lm_generation"]
+        r.input_length = s_["input_length"] or None
+        r.lm_output_audio_tokens = [None] * s_["n_tokens"]
+        r.next_audio_decode_idx = list(s_["next_idx"])
+        r.is_streaming, r.is_pressing = s_["is_streaming"], s_["is_pressing"]
+        r.is_input_streaming, r.prefill_ready, r.text_complete = s_["is_input_streaming"], s_["prefill_ready"], s_["text_complete"]
+        for t in range(s_["n_pending_text"]):
+            r.pending_text_tokens.put(100 + t)
+        r.chunk_send_timestamps = [1000.0 + t for t in s_["chunk_times"]]
+        r.chunk_durations = list(s_["chunk_durs"])
+        out.append(r)
+    return out
+
+
+def test_scheduler_policies_match_reference():
+    """Online / Offline / InputStreaming selection on 60 scripted request states == what the reference classes chose."""
+    import json
+    import types
+    from vox_serve_amd.scheduler import load_scheduler
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8_scheduler_policies.json")))
+    for ci, case in enumerate(g["cases"]):
+        for name, want in case["out"].items():
+            w = types.SimpleNamespace(detokenize_interval=case["interval"], detokenize_overlap=case["overlap"],
+                                      available_batch_sizes=None, supports_audio_input=False)
+            if case["graph_worker"]:      # limits of the graph-capturing worker (cuda_graph_worker.py:61-62)
+                w.prefill_graph_batch_size, w.cuda_graph_seq_len_buckets = case["prefill_graph_batch_size"], case["seq_len_buckets"]
+            else:                          # eager worker: the reference falls back to (max_batch_size, 1024)
+                w.prefill_graph_batch_size, w.cuda_graph_seq_len_buckets = case["max_batch_size"], [1024]
+            sch = load_scheduler(name, model_worker=w, max_batch_size=case["max_batch_size"])
+            sch.active_requests = _g8_requests(case["requests"])
+            if name == "online":
+                sch._update_pressing_status(now=case["now"])
+                assert [r.is_pressing for r in sch.active_requests] == want["pressing"], (ci, name)
+            assert [r.request_id for r in sch._select_lm_requests()] == want["lm"], (ci, name, "lm")
+            assert [bool(r.waiting_for_text) for r in sch.active_requests] == want["waiting_for_text"], (ci, name)
+            if name != "input_streaming":
+                sel = sch._select_detokenize_requests()
+                got = [[r.request_id, list(r.next_audio_decode_idx), bool(r.done_all)] for r in sel]
+                assert got == want["detok"], (ci, name, got, want["detok"])
+                assert [bool(r.done_all) for r in sch.active_requests] == want["done_all"], (ci, name)
+
+
+def test_input_streaming_messages_match_reference():
+    import json
+    import types
+    from vox_serve_amd.scheduler import load_scheduler
+
+    class Tok:   # the deterministic tokenizer the golden generator used
+        def encode(self, text, add_special_tokens=False):
+            return [sum(map(ord, text[i:i + 3])) % 5000 + 10 for i in range(0, len(text), 3)]
+
+        def decode(self, ids, skip_special_tokens=True):
+            return "".join(f"<{i}>" for i in ids)
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8_scheduler_policies.json")))
+    w = types.SimpleNamespace(detokenize_interval=10, detokenize_overlap=0, available_batch_sizes=None,
+                              supports_audio_input=False, model=types.SimpleNamespace(text_tokenizer=Tok()))
+    sch = load_scheduler("input_streaming", model_worker=w, max_batch_size=4)
+    for i, (msg, want) in enumerate(zip(g["stream_script"], g["stream_log"])):
+        if i == 5:
+            sch.active_requests[0].done_lm_prefill = True
+        req = sch._handle_request_payload(msg.encode())
+        if req is not None:
+            sch.active_requests.append(req)
+        got = [{"id": r.request_id, "prompt": r.prompt, "buffer": r.input_text_buffer, "prefill_ready": r.prefill_ready,
+                "pending": list(r.pending_text_tokens.queue), "total_text_tokens": r.total_text_tokens,
+                "text_complete": r.text_complete, "done_all": r.done_all, "finish_reason": r.finish_reason,
+                "is_streaming": r.is_streaming, "model_kwargs": r.model_kwargs} for r in sch.active_requests]
+        assert got == want, (i, msg)
+
+
+def test_disaggregation_scheduler_runs_two_pipelines():
+    """LM thread + detokenizer thread over a fake worker: every request gets all of its audio and one completion."""
+    import types
+    import torch
+    from vox_serve_amd.scheduler import QueueTransport, encode_request, load_scheduler
+
+    class FakeWorker:
+        detokenize_interval, detokenize_overlap, supports_audio_input, available_batch_sizes = 4, 0, False, None
+        prefill_graph_batch_size, cuda_graph_seq_len_buckets = 8, [1024]
+
+        def __init__(self):
+            self.freed = []
+
+        def prepare_lm_inputs(self, lm, det):
+            for r in lm:
+                if not r.done_lm_prefill:
+                    r.done_lm_prefill, r.next_position_id = True, 1
+            return {"is_prefill": False}
+
+        def run_lm_prefill(self, reqs, li):
+            self.run_lm_decode(reqs, li)
+
+        def run_lm_decode(self, reqs, li):
+            for r in reqs:
+                r.lm_output_audio_tokens.append(torch.zeros(1, 1, dtype=torch.long))
+                if len(r.lm_output_audio_tokens) >= 10:
+                    r.done_lm_generation, r.finish_reason = True, "max_tokens_reached"
+
+        def run_detokenize(self, reqs):
+            for r in reqs:
+                for d in r.audio_decode_idx:
+                    n = len(r.lm_output_audio_tokens[d:d + 4])
+                    r.output_audio.put(bytes(2 * n))
+                if r.done_lm_generation and r.audio_decode_idx and r.audio_decode_idx[-1] + 4 >= len(r.lm_output_audio_tokens):
+                    r.done_all = True
+
+        def free_kv_cache(self, r):
+            self.freed.append(r.request_id)
+
+    tr, w = QueueTransport(), FakeWorker()
+    sch = load_scheduler("disaggregation", model_worker=w, max_batch_size=4, transport=tr)
+    for i in range(5):
+        tr.requests.put(encode_request(f"q{i}", "hello"))
+    sch.run_until_idle(timeout_s=30)
+    msgs = []
+    while not tr.results.empty():
+        msgs.append(tr.results.get())
+    for i in range(5):
+        audio = [m for m in msgs if m.startswith(f"q{i}|AUDIO|".encode())]
+        done = [m for m in msgs if m.startswith(f"q{i}|COMPLETION|".encode())]
+        assert sum(len(m.split(b"|", 2)[2]) for m in audio) == 20 and len(done) == 1, (i, len(audio), len(done))
+    assert sorted(w.freed) == [f"q{i}" for i in range(5)] and not sch.active_requests

@@ -90,34 +90,44 @@ class Scheduler:
                 return
 
     # ---- selection policies ----
-    def _select_lm_requests(self):
-        lm_requests = []
-        max_prefill_batch_size = getattr(self.model_worker, "prefill_graph_batch_size", self.max_batch_size)
-        max_seq_len = max(getattr(self.model_worker, "cuda_graph_seq_len_buckets", [1024]))
-        prefill_requests, decode_requests = [], []
+    prefill_len_default = 0        # budget of a prompt whose length is not known yet (offline.py:44 uses 200)
+
+    def _lm_candidates(self):
+        """(prefill, decode) requests that may run an LM step now, in arrival order."""
+        prefill, decode = [], []
         for req in self.active_requests:
             if req.done_lm_generation:
                 continue
-            (decode_requests if req.done_lm_prefill else prefill_requests).append(req)
-        if prefill_requests:
-            current_batch_size, current_seq_len = 0, 0
-            for req in prefill_requests:
-                req_seq_len = req.input_length if req.input_length else 0
-                if current_batch_size + 1 <= max_prefill_batch_size and current_seq_len + req_seq_len <= max_seq_len:
-                    lm_requests.append(req)
-                    current_batch_size += 1
-                    current_seq_len += req_seq_len
-                    if current_batch_size >= max_prefill_batch_size:
-                        break
-                break      # allow only one prefill request for now (scheduler/base.py:281-282)
-            remaining_slots = max_prefill_batch_size - len(lm_requests)
+            (decode if req.done_lm_prefill else prefill).append(req)
+        return prefill, decode
+
+    def _order_decodes(self, decodes):
+        return decodes
+
+    def _select_lm_requests(self):
+        """At most ONE new prefill per step (scheduler/base.py:281-282), piggy-backed by decode rows up to the prefill
+        batch size; without a prefill, decode rows up to max_batch_size."""
+        max_prefill_batch_size = getattr(self.model_worker, "prefill_graph_batch_size", self.max_batch_size)
+        max_seq_len = max(getattr(self.model_worker, "cuda_graph_seq_len_buckets", [1024]))
+        prefill, decode = self._lm_candidates()
+        picked = []
+        if prefill:
+            first = prefill[0]
+            n = first.input_length if first.input_length else self.prefill_len_default
+            if max_prefill_batch_size >= 1 and n <= max_seq_len:
+                picked.append(first)
+            slots = max_prefill_batch_size - len(picked)
         else:
-            remaining_slots = self.max_batch_size
-        for i in range(remaining_slots):
-            if len(lm_requests) >= self.max_batch_size or i >= len(decode_requests):
+            slots = self.max_batch_size
+        cap = self._lm_batch_cap(bool(prefill), max_prefill_batch_size)
+        for req in self._order_decodes(decode)[: max(0, slots)]:
+            if len(picked) >= cap:
                 break
-            lm_requests.append(decode_requests[i])
-        return lm_requests
+            picked.append(req)
+        return picked
+
+    def _lm_batch_cap(self, prefill_cycle: bool, max_prefill_batch_size: int) -> int:
+        return self.max_batch_size
 
     def _select_detokenize_requests(self):
         out = []
