@@ -205,6 +205,54 @@ int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const 
                       const int32_t* last_rows, int n_req, int max_kvlen, const vox_sampling_config* sampling,
                       uint64_t seed, int feedback);
 
+/* ---- CSM-1B frame engine: backbone decode + on-device sampling + 31-step depth loop --------------------
+ * replaces CSMModel.forward / sampling / depth_forward / depth_sampling (model/csm.py:637-770) and the depth loop of
+ * ModelWorker.run_lm_depth (worker/base.py:546-614).  Backbone input = sum over the 33 masked per-column embeddings
+ * (csm.py:647-653); the depth transformer consumes [backbone hidden, embedding of codebook 0] through
+ * inputs_embeds_projector and predicts codebook i with codebooks_head.weight[i-1] (csm.py:235-255).               */
+typedef struct vox_csm vox_csm;
+typedef struct {
+    vox_stack_config backbone, depth;
+    int32_t vocab;       /* audio vocabulary per codebook (2051) */
+    int32_t text_vocab;  /* rows of the text embedding */
+    int32_t n_codebooks; /* audio codebooks (32); input rows have n_codebooks + 1 columns, the last one is text */
+    int32_t max_batch;
+} vox_csm_config;
+typedef struct {
+    const vox_layer_weights* backbone_layers;
+    const vox_layer_weights* depth_layers;
+    const void *backbone_norm, *depth_norm;
+    const void* audio_embedding; /* [n_codebooks*vocab, H]: backbone_model.embed_tokens.embed_audio_tokens */
+    const void* text_embedding;  /* [text_vocab, H] */
+    const void* lm_head;         /* [vocab, H] */
+    const void* depth_proj;      /* [depth_hidden, H]: inputs_embeds_projector */
+    const void* depth_heads;     /* [n_codebooks-1, vocab, depth_hidden]: codebooks_head.weight transposed per codebook */
+    const float *backbone_rope, *depth_rope;
+    int32_t backbone_rope_max_pos, depth_rope_max_pos;
+} vox_csm_weights;
+typedef struct { /* device buffers owned by the caller (graph-stable addresses) */
+    int32_t* input_ids;      /* [max_batch, n_codebooks+1] */
+    uint8_t* input_masks;    /* [max_batch, n_codebooks+1] */
+    int32_t *pos, *kvlen, *page, *slot, *kv_indptr, *kv_indices;
+    int32_t* page_table;     /* optional per-row page table for decode frames */
+    int64_t pt_stride;
+    void* kv;
+    int64_t kv_layer_stride;
+    int32_t* out_ids;        /* [max_batch, n_codebooks+1] sampled frame (text column = codebook 0, csm.py:697) */
+    void* out_logits;        /* [max_batch, vocab] bf16 */
+    void* out_hidden;        /* optional [max_batch, H] bf16 backbone hidden (post-norm) */
+    void* out_depth_logits;  /* optional [n_codebooks-1, max_batch, vocab] bf16 */
+    uint64_t* rng_offset;
+} vox_csm_io;
+int vox_csm_create(vox_ctx* ctx, const vox_csm_config* cfg, const vox_csm_weights* w, vox_csm** out);
+void vox_csm_destroy(vox_csm* m);
+int vox_csm_frame(vox_csm* m, void* stream, const vox_csm_io* io, int batch, int max_kvlen,
+                  const vox_sampling_config* sampling, uint64_t seed, int feedback);
+int vox_csm_prefill(vox_csm* m, void* stream, const vox_csm_io* io, const int32_t* row_ids /*[n_rows,n_codebooks+1]*/,
+                    const uint8_t* row_masks /*[n_rows,n_codebooks+1]*/, const int32_t* q_req, int n_rows,
+                    const int32_t* last_rows, int n_req, int max_kvlen, const vox_sampling_config* sampling, uint64_t seed,
+                    int feedback);
+
 /* ---- single-stack speech LM engine (GLM-4-Voice, CosyVoice2 LLM, Orpheus-style families) ------------------
  * replaces <Family>Model.forward + sampling (model/glm_voice.py:517-590, model/cosyvoice2.py:1008-1090) and
  * the decode/prefill graph replays of CudaGraphWorker (worker/cuda_graph_worker.py:806-1056).                */

@@ -640,8 +640,123 @@ def g8_scheduler_policies(ns):
         json.dump({"cases": cases, "stream_script": [m.decode() for m in script], "stream_log": log}, f, indent=0)
     print("g8 ok", len(cases), "policy cases;", sum(len(c["out"]["online"]["detok"]) for c in cases), "online detok picks")
 
+
+# --------------------------------------------------------------------------------------------------
+def g9_csm_lm(ns):
+    """Tiny CSM (backbone + depth decoder) through the reference modules and the reference worker: prefill of two
+    requests (text rows + audio-context rows), then 3 decode frames, greedy (csm.py:55-313, 637-770)."""
+    import transformers
+    from unittest import mock
+    torch.cuda.synchronize = lambda *a, **k: None
+    from vox_serve.model import csm as CS
+    from vox_serve.model.base import PreprocessOutput
+    from oracle import csm_ref as CR
+    FU, MW = ns.flashinfer_utils, ns.ModelWorker
+    cfg = CR.tiny_csm_cfg()
+    b, d, C, V = cfg.backbone, cfg.depth, cfg.n_codebooks, cfg.vocab
+    W = CR.random_csm_state_dict(cfg, seed=7, std=0.08)
+    rs = {"factor": 32.0, "high_freq_factor": 4.0, "low_freq_factor": 1.0, "original_max_position_embeddings": 64, "rope_type": "llama3"}
+    dcfg = transformers.CsmDepthDecoderConfig(num_codebooks=C, backbone_hidden_size=b.hidden, vocab_size=V, hidden_size=d.hidden,
+                                              intermediate_size=d.ffn, num_hidden_layers=d.layers, num_attention_heads=d.heads,
+                                              num_key_value_heads=d.kv_heads, head_dim=d.head_dim, rms_norm_eps=d.eps,
+                                              rope_theta=d.rope_theta, rope_scaling=dict(rs), max_position_embeddings=33)
+    ccfg = transformers.CsmConfig(num_codebooks=C, vocab_size=V, text_vocab_size=cfg.text_vocab, hidden_size=b.hidden,
+                                  intermediate_size=b.ffn, num_hidden_layers=b.layers, num_attention_heads=b.heads,
+                                  num_key_value_heads=b.kv_heads, head_dim=b.head_dim, rms_norm_eps=b.eps, rope_theta=b.rope_theta,
+                                  rope_scaling=dict(rs), max_position_embeddings=cfg.max_pos, depth_decoder_config=dcfg,
+                                  tie_codebooks_embeddings=False)
+    for c_ in (ccfg, dcfg):           # attributes the reference reads (csm.py:66-70,72-83)
+        if getattr(c_, "rope_scaling", None) is None:
+            c_.rope_scaling = dict(rs)
+        if not hasattr(c_, "rope_theta"):
+            c_.rope_theta = b.rope_theta
+        if not hasattr(c_, "attention_bias"):
+            c_.attention_bias = False
+        if not hasattr(c_, "attention_dropout"):
+            c_.attention_dropout = 0.0
+    with mock.patch.object(transformers.AutoModel, "from_config", return_value=torch.nn.Identity()):
+        net = CS.CsmForConditionalGeneration(ccfg).to(torch.bfloat16)
+    missing, unexpected = net.load_state_dict({k: vr.to_torch(v) for k, v in W.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all("audio_tokens_offsets" in m_ or "codec_model" in m_ for m_ in missing), missing
+    m = CS.CSMModel.__new__(CS.CSMModel)
+    m.model, m.device, m.dtype, m.model_name = net, "cpu", torch.bfloat16, "tiny-csm"
+    m._num_attention_heads, m._num_key_value_heads, m._num_hidden_layers, m._hidden_size = b.heads, b.kv_heads, b.layers, b.hidden
+    m._depth_num_attention_heads, m._depth_num_key_value_heads = d.heads, d.kv_heads
+    m._depth_num_hidden_layers, m._depth_hidden_size = d.layers, d.hidden
+    m.stop_token_id = 0
+    m.default_sampling_config = ns.sampling.SamplingConfig(greedy=True)
+    page, P = 16, 24
+    cpu = torch.device("cpu")
+    import logging
+    w = MW.__new__(MW)
+    w.model, w.device, w.page_size, w.max_batch_size = m, "cpu", page, 4
+    w.empty_pages = queue.Queue()
+    for i in range(P):
+        w.empty_pages.put(i)
+    w.prefill_wrapper = FU.FlashInferPrefillWrapper(torch.empty(1), b.heads, b.kv_heads, b.heads * b.head_dim, page, device=cpu)
+    w.decode_wrapper = FU.FlashInferDecodeWrapper(torch.empty(1), b.heads, b.kv_heads, b.heads * b.head_dim, page, device=cpu)
+    w.kv_cache = torch.zeros(b.layers, P, 2, page, b.kv_heads, b.head_dim, dtype=torch.bfloat16)
+    w.has_depth_transformer = True
+    w.depth_attn_wrapper = FU.FlashInferPrefillWrapper(torch.empty(1), d.heads, d.kv_heads, d.heads * d.head_dim, page, device=cpu)
+    w.depth_kv_cache = torch.zeros(d.layers, P, 2, C, d.kv_heads, d.head_dim, dtype=torch.bfloat16)
+    w.logger, w.nvtx_enabled = logging.getLogger("golden"), False
+    rec = {"logits": [], "hidden": [], "dlogits": []}
+    f0, df0 = m.forward, m.depth_forward
+
+    def fwd(**kw):
+        lg, hs = f0(**kw)
+        rec["logits"].append(lg.clone()); rec["hidden"].append(hs.clone())
+        return lg, hs
+
+    def dfwd(**kw):
+        lg = df0(**kw)
+        rec["dlogits"].append(lg.clone())
+        return lg
+    m.forward, m.depth_forward = fwd, dfwd
+    g = torch.Generator().manual_seed(21)
+    out = {"page": np.int32(page), "P": np.int32(P)}
+    reqs = []
+    for r, (nt, na) in enumerate([(7, 5), (10, 0)]):      # text rows, then audio-context rows (csm.py:473-509)
+        n = nt + na
+        ids = torch.zeros(n, C + 1, dtype=torch.long)
+        masks = torch.zeros(n, C + 1, dtype=torch.bool)
+        ids[:nt, -1] = torch.randint(0, cfg.text_vocab, (nt,), generator=g)
+        masks[:nt, -1] = True
+        if na:
+            ids[nt:, :C] = torch.randint(1, V, (na, C), generator=g)
+            masks[nt:, :C] = True
+        out[f"r{r}_ids"], out[f"r{r}_masks"] = ids.numpy().astype(np.int32), masks.numpy().astype(np.uint8)
+        req = ns.requests.Request(request_id=str(r), prompt="x")
+        m.preprocess = (lambda ids=ids, masks=masks: (lambda prompt=None, audio_path=None, **kw:
+                        PreprocessOutput(input_tokens=ids, input_masks=masks)))()
+        li = w.prepare_lm_inputs([req], [])
+        n0 = len(rec["logits"])
+        w.run_lm_prefill([req], li)
+        out[f"r{r}_prefill_logits"] = bits(rec["logits"][n0][-1:, 0])
+        out[f"r{r}_prefill_hidden"] = bits(rec["hidden"][n0][-1:])
+        out[f"r{r}_frame0"] = req.lm_output_tokens[-1].numpy().astype(np.int32)[0]
+        out[f"r{r}_next_pos"] = np.int32(req.next_position_id)
+        out[f"r{r}_prefill_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 else x) for x in rec["dlogits"]])
+        rec["dlogits"].clear()
+        reqs.append(req)
+    for f in range(3):
+        li = w.prepare_lm_inputs(reqs, [])
+        out[f"f{f}_pos"] = li["position_ids"].numpy().astype(np.int32)
+        out[f"f{f}_in_ids"] = li["input_ids"].numpy().astype(np.int32)
+        out[f"f{f}_in_masks"] = li["input_masks"].numpy().astype(np.uint8)
+        w.run_lm_decode(reqs, li)
+        out[f"f{f}_logits"] = bits(rec["logits"][-1][:, 0])
+        out[f"f{f}_hidden"] = bits(rec["hidden"][-1])
+        out[f"f{f}_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 * len(reqs) else x) for x in rec["dlogits"]])
+        rec["dlogits"].clear()
+        out[f"f{f}_tokens"] = np.stack([r_.lm_output_tokens[-1].numpy().astype(np.int32)[0] for r_ in reqs])
+    out["kv_final"] = bits(w.kv_cache)
+    np.savez_compressed(os.path.join(HERE, "g9_csm_lm.npz"), **out)
+    print("g9 ok; frame tokens", out["f2_tokens"])
+
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm}
 
 if __name__ == "__main__":
     ns = H.boot()

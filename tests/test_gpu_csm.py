@@ -1,0 +1,188 @@
+"""Parity of the CSM-1B frame engine (libvoxhip vox_csm_* through the C ABI) against the CPU oracle
+(oracle/csm_ref.py, pinned to the reference CSM modules by tests/golden/g9): ragged prefill, then free-running batched
+decode — masked 33-column embedding sum, llama-3.1 RoPE backbone, 31-step (here 5-step) depth loop with per-codebook
+heads.  Bar: <= 8 rows per call -> BIT-EXACT logits, hidden states, depth logits and sampled ids (greedy and seeded
+top-k); longer prefills take the MFMA path (bf16 bar) and the oracle then adopts the GPU's state.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import csm_ref as CR
+from oracle import qwen3_ref as QR
+from oracle import voxref as vr
+from tests.conftest import bf16_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def to_engine_cfg(c: CR.CSMCfg):
+    from vox_serve_amd.engine import CSMCfg, StackCfg
+    conv = lambda s: StackCfg(s.hidden, s.layers, s.heads, s.kv_heads, s.head_dim, s.ffn, s.eps, s.rope_theta, s.rope_scale,
+                              None, False, s.rope_llama31, False, False)
+    return CSMCfg(conv(c.backbone), conv(c.depth), c.vocab, c.text_vocab, c.n_codebooks, c.max_pos)
+
+
+def make_prompt(rng, cfg, n_text, n_audio):
+    C, n = cfg.n_codebooks, n_text + n_audio
+    ids, masks = np.zeros((n, C + 1), np.int32), np.zeros((n, C + 1), np.uint8)
+    ids[:n_text, -1] = rng.integers(0, cfg.text_vocab, n_text)
+    masks[:n_text, -1] = 1
+    if n_audio:
+        ids[n_text:, :C] = rng.integers(1, cfg.vocab, (n_audio, C))
+        masks[n_text:, :C] = 1
+    return ids, masks
+
+
+def run_parity(dev, cfg, W, prompts, n_frames, page=16, max_pages=64, sampler_kw=None):
+    from vox_serve_amd.engine import CSMEngine
+    rng = np.random.default_rng(5)
+    B, C, C1 = len(prompts), cfg.n_codebooks, cfg.n_codebooks + 1
+    ref = CR.CSMRef(cfg, W, page_size=page, max_pages=max_pages, max_batch=B)
+    eng = CSMEngine(to_engine_cfg(cfg), {k: vr.to_torch(v).to(dev) for k, v in W.items()}, max_batch=B, page_size=page,
+                    max_pages=max_pages, max_seq_len=512, max_prefill_rows=128, keep_depth_logits=True, device=dev)
+    seed, frame_no = 99, [0]
+    if sampler_kw:
+        sc = eng.sampling_cfg(greedy=False, **sampler_kw)
+        sampler = lambda lg, i: vr.sample(lg, seed=seed, offset=frame_no[0] * C + i, **sampler_kw)
+    else:
+        sc, sampler = eng.sampling_cfg(greedy=True), None
+    reqs, synced = [], False
+    st_ids = torch.zeros(B, C1, dtype=torch.int32, device=dev)
+    st_masks = torch.zeros(B, C1, dtype=torch.uint8, device=dev)
+    for r, (nt, na) in enumerate(prompts):
+        ids, masks = make_prompt(rng, cfg, nt, na)
+        n = nt + na
+        req = QR.RefRequest()
+        lg, hid = ref.prefill(req, ids, masks)
+        out, _, _, dl = ref.frame([req], lg, hid, sampler)
+        eng.row_ids[:n] = torch.from_numpy(ids).to(dev)
+        eng.row_masks[:n] = torch.from_numpy(masks).to(dev)
+        eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[req.kv_pages[t // page] for t in range(n)],
+                        slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1],
+                        indptr=[0, len(req.kv_pages)], indices=req.kv_pages)
+        eng.rng_offset.fill_(frame_no[0])
+        eng.prefill(n, 1, n, sc, seed=seed, feedback=True)
+        torch.cuda.synchronize()
+        if n <= 8:
+            assert np.array_equal(vr.from_torch(eng.out_hidden[:1]), hid), f"prefill hidden r{r}"
+            assert np.array_equal(vr.from_torch(eng.out_logits[:1]), lg), f"prefill logits r{r}"
+            assert np.array_equal(vr.from_torch(eng.out_depth_logits[:, 0]), np.stack(dl)[:, 0]), f"prefill depth r{r}"
+            assert np.array_equal(eng.out_ids[:1].cpu().numpy(), out), f"prefill tokens r{r}"
+        else:
+            for name, a_, b_ in (("hidden", vr.from_torch(eng.out_hidden[:1]), hid), ("logits", vr.from_torch(eng.out_logits[:1]), lg)):
+                fa, fb = vr.bf2f(a_).astype(np.float64), vr.bf2f(b_).astype(np.float64)
+                assert np.sqrt(np.mean((fa - fb) ** 2) / np.mean(fb ** 2)) < 0.02, f"prefill {name} r{r}"
+                assert bf16_close(a_, b_, ulps=4, atol=0.05).mean() > 0.99, f"prefill {name} r{r}"
+            req.frames[-1] = eng.out_ids[0].cpu().numpy().copy()
+            req.input_ids = eng.input_ids[:1].cpu().numpy().astype(np.int32)
+            req.input_mask = eng.input_masks[:1].cpu().numpy().astype(np.uint8)
+            synced = True
+        assert np.array_equal(eng.input_ids[:1].cpu().numpy(), req.input_ids) and \
+            np.array_equal(eng.input_masks[:1].cpu().numpy(), req.input_mask), f"feedback r{r}"
+        st_ids[r], st_masks[r] = eng.input_ids[0], eng.input_masks[0]
+        reqs.append(req)
+    if synced:
+        kv_gpu = vr.from_torch(eng.kv)
+        for l in range(len(ref.kv)):
+            ref.kv[l][:] = kv_gpu[l]
+    frame_no[0] = 1
+    eng.input_ids[:B], eng.input_masks[:B] = st_ids, st_masks
+    eng.rng_offset.fill_(frame_no[0])
+    for f in range(n_frames):
+        lg, hid = ref.decode(reqs)
+        out, _, _, dl = ref.frame(reqs, lg, hid, sampler)
+        indptr, indices = [0], []
+        for q in reqs:
+            indptr.append(indptr[-1] + len(q.kv_pages))
+            indices += q.kv_pages
+        eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
+                        page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
+                        indptr=indptr, indices=indices)
+        eng.frame(B, max(q.kv_token_len for q in reqs), sc, seed=seed, feedback=True, use_graph=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(vr.from_torch(eng.out_hidden[:B]), hid), f"hidden f{f}"
+        assert np.array_equal(vr.from_torch(eng.out_logits[:B]), lg), f"logits f{f}"
+        assert np.array_equal(vr.from_torch(eng.out_depth_logits[:, :B]), np.stack(dl)), f"depth logits f{f}"
+        assert np.array_equal(eng.out_ids[:B].cpu().numpy(), out), f"tokens f{f}"
+        frame_no[0] += 1
+    used = sorted({p for q in reqs for p in q.kv_pages})
+    kv_gpu = vr.from_torch(eng.kv)
+    for l in range(len(ref.kv)):
+        assert np.array_equal(kv_gpu[l][used], ref.kv[l][used]), f"kv layer {l}"
+    eng.close()
+
+
+def test_csm_tiny_greedy(dev):
+    cfg = CR.tiny_csm_cfg()
+    run_parity(dev, cfg, CR.random_csm_state_dict(cfg, 7, 0.08), [(5, 3), (8, 0), (2, 2)], 24)
+
+
+def test_csm_tiny_topk(dev):
+    """CSM defaults: top_k 50, temperature 0.9 (csm.py:355-363), seeded Philox contract"""
+    cfg = CR.tiny_csm_cfg()
+    run_parity(dev, cfg, CR.random_csm_state_dict(cfg, 8, 0.08), [(4, 4), (6, 1)], 20, sampler_kw=dict(top_k=50, temperature=0.9))
+
+
+def test_csm_tiny_long_prefill_then_exact_decode(dev):
+    cfg = CR.tiny_csm_cfg()
+    run_parity(dev, cfg, CR.random_csm_state_dict(cfg, 9, 0.08), [(30, 11), (12, 9)], 10)
+
+
+def test_csm_against_reference_goldens(dev, golden):
+    """GPU engine vs the tokens the reference CSM modules produced (g9); prompts of 12 / 10 rows take the MFMA prefill."""
+    from vox_serve_amd.engine import CSMEngine
+    g = golden("g9_csm_lm")
+    cfg = CR.tiny_csm_cfg()
+    W = CR.random_csm_state_dict(cfg, seed=7, std=0.08)
+    page, P, C1 = int(g["page"]), int(g["P"]), cfg.n_codebooks + 1
+    eng = CSMEngine(to_engine_cfg(cfg), {k: vr.to_torch(v).to(dev) for k, v in W.items()}, max_batch=2, page_size=page,
+                    max_pages=P, max_seq_len=512, max_prefill_rows=64, device=dev)
+    sc = eng.sampling_cfg(greedy=True)
+    free, pages, lens, mism = list(range(P)), [], [], 0
+    for r in range(2):
+        ids, masks = g[f"r{r}_ids"], g[f"r{r}_masks"]
+        n = len(ids)
+        pg = [free.pop(0) for _ in range((n + page - 1) // page)]
+        eng.row_ids[:n], eng.row_masks[:n] = torch.from_numpy(ids).to(dev), torch.from_numpy(masks).to(dev)
+        eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[pg[t // page] for t in range(n)],
+                        slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1], indptr=[0, len(pg)], indices=pg)
+        eng.prefill(n, 1, n, sc, feedback=False)
+        torch.cuda.synchronize()
+        assert bf16_close(vr.from_torch(eng.out_logits[:1]), g[f"r{r}_prefill_logits"], ulps=4, atol=6e-2).all()
+        mism += int((eng.out_ids[0].cpu().numpy() != g[f"r{r}_frame0"]).sum())
+        pages.append(pg)
+        lens.append(n)
+    for f in range(3):
+        eng.input_ids[:2] = torch.from_numpy(g[f"f{f}_in_ids"]).to(dev)          # teacher forcing
+        eng.input_masks[:2] = torch.from_numpy(g[f"f{f}_in_masks"]).to(dev)
+        lens = [n + 1 for n in lens]
+        for r in range(2):
+            if lens[r] > len(pages[r]) * page:
+                pages[r].append(free.pop(0))
+        eng.upload_plan(pos=g[f"f{f}_pos"], kvlen=lens, page=[pages[r][(lens[r] - 1) // page] for r in range(2)],
+                        slot=[(lens[r] - 1) % page for r in range(2)], indptr=[0, len(pages[0]), len(pages[0]) + len(pages[1])],
+                        indices=pages[0] + pages[1])
+        eng.frame(2, max(lens), sc, feedback=False)
+        torch.cuda.synchronize()
+        assert bf16_close(vr.from_torch(eng.out_logits[:2]), g[f"f{f}_logits"], ulps=4, atol=6e-2).all(), f
+        mism += int((eng.out_ids[:2].cpu().numpy() != g[f"f{f}_tokens"]).sum())
+    assert mism <= 8, mism
+    eng.close()
+
+
+@pytest.mark.slow
+def test_csm_full_width_two_layers(dev):
+    """CSM-1B layer shapes (2048 hidden, 32/8 heads of 64, FFN 8192; depth 1024, 8/2 heads of 128, FFN 8192, vocab 2051,
+    32 codebooks -> 31 depth steps), 2 backbone + 2 depth layers: bit-exact decode."""
+    cfg = CR.CSMCfg(max_pos=512)
+    cfg.backbone.layers, cfg.depth.layers, cfg.text_vocab = 2, 2, 4096
+    run_parity(dev, cfg, CR.random_csm_state_dict(cfg, 3, 0.02), [(4, 2), (3, 0)], 3, page=128, max_pages=8,
+               sampler_kw=dict(top_k=50, temperature=0.9))

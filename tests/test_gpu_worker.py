@@ -77,3 +77,112 @@ def test_scheduler_worker_engine_codec_end_to_end():
     frames_audio = len(solo["r1"]["pcm"]) // 2 / hop
     assert 1 <= frames_audio <= 30 - n_prompt + 1
     m.engine.close(); m.audio_decoder.close()
+
+
+def _drive_worker(m, prompts, steps, page=16):
+    """ModelWorker host loop (prepare_lm_inputs / run_lm_prefill / run_lm_decode), one prefill per step like the scheduler."""
+    from vox_serve_amd.requests import Request
+    from vox_serve_amd.worker import ModelWorker
+    w = ModelWorker(model=m, max_batch_size=4, max_num_pages=64, page_size=page, device=m.device)
+    reqs = []
+    for i, kw in enumerate(prompts):
+        r = Request(request_id=f"w{i}", prompt="", model_kwargs=kw)
+        w.run_lm_prefill([r] + [], w.prepare_lm_inputs([r], []))
+        reqs.append(r)
+    for _ in range(steps):
+        live = [r for r in reqs if not r.done_lm_generation]
+        if not live:
+            break
+        w.run_lm_decode(live, w.prepare_lm_inputs(live, []))
+    return reqs, w
+
+
+def test_worker_drives_glm_cosyvoice2_and_csm_plugins():
+    """The single-stack and CSM plugins through ModelWorker: token streams equal the oracle's (short prompts: bit-exact),
+    stop / audio-token bookkeeping follows the reference plugins' `sampling`."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    from oracle import csm_ref as CR, lm_ref as LR, qwen3_ref as QR, voxref as vr
+    from vox_serve_amd.sampling import SamplingConfig
+    greedy = SamplingConfig(greedy=True)
+    kw = dict(device=str(dev), max_batch_size=4, page_size=16, max_num_pages=64, max_seq_len=512, max_prefill_tokens=64)
+
+    # ---- GLM-4-Voice (tiny) ----
+    from vox_serve_amd.model.glm_voice import GLMVoiceConfig, GLMVoiceModel
+    cfg = LR.tiny_glm_cfg()
+    c = cfg.stack
+    S = LR.random_glm_state_dict(cfg, seed=3, std=0.08)
+    pc = GLMVoiceConfig(ffn_hidden_size=c.ffn, hidden_size=c.hidden, multi_query_group_num=c.kv_heads, num_attention_heads=c.heads,
+                        num_layers=c.layers, padded_vocab_size=cfg.vocab_out, vocab_size=cfg.vocab_out,
+                        eos_token_id=[cfg.vocab_out - 3, cfg.vocab_out - 2, cfg.vocab_out - 1], audio_offset=cfg.vocab_out // 2)
+    m = GLMVoiceModel("tiny-glm", {k: vr.to_torch(v).to(dev) for k, v in S.items()}, config=pc, sampling=greedy, max_pos=512, **kw)
+    prompts = [[5, 17, 99, 300, 7], [1200, 4, 8]]
+    reqs, w = _drive_worker(m, [{"prompt_token_ids": p} for p in prompts], 12)
+    ref = LR.LMRef(cfg, LR.from_glm_state_dict(cfg, S), page_size=16, max_pages=64)
+    rr = []
+    for p in prompts:
+        q = LR.LMRequest()
+        ref.sample(ref.prefill(q, np.array(p, np.int32)), [q])
+        rr.append(q)
+    for _ in range(12):
+        ref.sample(ref.decode(rr), rr)
+    for q, r in zip(rr, reqs):
+        got = [int(t[0, 0]) for t in r.lm_output_tokens]
+        assert got == q.tokens[: len(got)], (got, q.tokens)
+        assert [int(t[0, 0]) for t in r.lm_output_audio_tokens] == [t for t in got if t >= pc.audio_offset and t not in pc.eos_token_id]
+    m.engine.close()
+
+    # ---- CosyVoice2 (tiny): prompt rows are embeddings, decode rows speech ids ----
+    from vox_serve_amd.model.cosyvoice2 import CosyVoice2Config, CosyVoice2Model
+    cfg = LR.tiny_cosyvoice2_cfg()
+    c = cfg.stack
+    S = LR.random_cosyvoice2_state_dict(cfg, seed=4, std=0.08)
+    St = {k: vr.to_torch(v).to(dev) for k, v in S.items()}
+    pc = CosyVoice2Config(llm_input_size=c.hidden, llm_output_size=c.hidden, speech_token_size=cfg.vocab_out - 3, hidden_size=c.hidden,
+                          intermediate_size=c.ffn, num_attention_heads=c.heads, num_key_value_heads=c.kv_heads, num_hidden_layers=c.layers)
+    ref_ids, ref_speech = torch.tensor([3, 9]), torch.tensor([7, 100])
+    m = CosyVoice2Model("tiny-cosy", St, config=pc, sampling=greedy, max_pos=512,
+                        speaker_ref={"ref_text_ids": ref_ids, "prompt_speech_token": ref_speech}, **kw)
+    reqs, w = _drive_worker(m, [{"prompt_token_ids": [11, 12]}], 10)
+    text = torch.cat([ref_ids, torch.tensor([11, 12])])
+    feats = torch.cat([St["llm_embedding.weight"][0][None], St["llm.model.model.embed_tokens.weight"][text.to(dev)],
+                       St["llm_embedding.weight"][1][None], St["speech_embedding.weight"][ref_speech.to(dev)]], 0)
+    ref = LR.LMRef(cfg, LR.from_cosyvoice2_state_dict(cfg, S), page_size=16, max_pages=64)
+    q = LR.LMRequest()
+    n = feats.shape[0]
+    ref.sample(ref.prefill(q, np.zeros(n, np.int32), np.ones(n, np.uint8), vr.from_torch(feats)), [q])
+    for _ in range(10):
+        ref.sample(ref.decode([q]), [q])
+    got = [int(t[0, 0]) for t in reqs[0].lm_output_tokens]
+    assert got == q.tokens[: len(got)], (got, q.tokens)
+    m.engine.close()
+
+    # ---- CSM (tiny) ----
+    from tests.test_gpu_csm import to_engine_cfg
+    from vox_serve_amd.model.csm import CSMModel
+    cfg = CR.tiny_csm_cfg()
+    W = CR.random_csm_state_dict(cfg, 7, 0.08)
+    m = CSMModel("tiny-csm", {k: vr.to_torch(v).to(dev) for k, v in W.items()}, config=to_engine_cfg(cfg), sampling=greedy, **kw)
+    reqs, w = _drive_worker(m, [{"prompt_token_ids": [4, 200, 31]}, {"prompt_token_ids": [9, 8, 7, 6, 5]}], 8)
+    ref = CR.CSMRef(cfg, W, page_size=16, max_pages=64, max_batch=4)
+    rr, frames = [], []
+    for p in ([4, 200, 31], [9, 8, 7, 6, 5]):
+        ids = np.zeros((len(p), cfg.n_codebooks + 1), np.int32)
+        masks = np.zeros_like(ids, dtype=np.uint8)
+        ids[:, -1], masks[:, -1] = p, 1
+        q = QR.RefRequest()
+        lg, hid = ref.prefill(q, ids, masks)
+        ref.frame([q], lg, hid)
+        rr.append(q)
+    for _ in range(8):
+        live = [q for q in rr if not (q.frames and q.frames[-1][0] == 0)]
+        if live:
+            ref.frame(live)
+    for q, r in zip(rr, reqs):
+        got = [t[0].tolist() for t in r.lm_output_tokens]
+        want = [f.tolist() for f in q.frames][: len(got)]
+        assert got == want, (got[:2], want[:2])
+        assert len(r.lm_output_audio_tokens) == sum(1 for f in got if f[0] != 0)
+    assert w.empty_pages.qsize() == 64 - sum(len(r.kv_pages) for r in reqs)
+    m.engine.close()

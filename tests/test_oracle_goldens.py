@@ -222,6 +222,41 @@ def test_single_stack_lm_against_reference_worker(golden, tag):
     assert bf16_close(kv, g[f"{tag}_kv_final"], ulps=4, atol=3e-2).mean() > 0.999
 
 
+# ---------------------------------------------------------------- g9: CSM backbone + depth decoder ----
+def test_csm_lm_against_reference_worker(golden):
+    """Prefill (text rows + audio-context rows) + 3 frames, B=2, greedy: oracle vs the reference CSM modules driven by
+    the reference worker (33-column masked embedding sum, llama-3.1 RoPE, per-codebook heads, output-row layout)."""
+    from oracle import csm_ref as CR
+    g = golden("g9_csm_lm")
+    cfg = CR.tiny_csm_cfg()
+    W = CR.random_csm_state_dict(cfg, seed=7, std=0.08)
+    m = CR.CSMRef(cfg, W, page_size=int(g["page"]), max_pages=int(g["P"]), max_batch=4)
+    reqs, mism = [], 0
+    for r in range(2):
+        req = QR.RefRequest()
+        logits, hid = m.prefill(req, g[f"r{r}_ids"], g[f"r{r}_masks"])
+        assert req.next_position_id == int(g[f"r{r}_next_pos"])
+        assert bf16_close(hid, g[f"r{r}_prefill_hidden"], ulps=4, atol=3e-2).all()
+        assert bf16_close(logits, g[f"r{r}_prefill_logits"], ulps=4, atol=5e-2).all()
+        out, _, _, dl = m.frame([req], logits, hid)
+        assert bf16_close(np.stack(dl)[:, 0], g[f"r{r}_prefill_dlogits"][:, 0], ulps=4, atol=5e-2).mean() > 0.995
+        mism += int((out[0] != g[f"r{r}_frame0"]).sum())
+        reqs.append(req)
+    for f in range(3):
+        for b, req in enumerate(reqs):                       # teacher forcing with the reference's inputs
+            req.input_ids = g[f"f{f}_in_ids"][b:b + 1].copy()
+            req.input_mask = g[f"f{f}_in_masks"][b:b + 1].copy()
+        logits, hid = m.decode(reqs)
+        assert np.array_equal(np.array([r.next_position_id - 1 for r in reqs]), g[f"f{f}_pos"])
+        assert bf16_close(hid, g[f"f{f}_hidden"], ulps=4, atol=3e-2).all()
+        assert bf16_close(logits, g[f"f{f}_logits"], ulps=4, atol=5e-2).all()
+        out, _, _, dl = m.frame(reqs, logits, hid)
+        # the oracle's own frame feeds back: its next inputs must have the reference's layout
+        assert all(r.input_ids.shape == (1, cfg.n_codebooks + 1) and r.input_mask[0, -1] == 0 for r in reqs)
+        mism += int((out != g[f"f{f}_tokens"]).sum())
+    assert mism <= 8, mism     # greedy ids agree except on bf16 near-ties; a flipped code changes the rest of that frame
+
+
 # ---------------------------------------------------------------- g4: Qwen3 codec (streaming) -----
 def _codec_run(cfg, codes, chunk, exact):
     """exact=True: contraction operands stay fp32 (the mode the HIP codec computes in: fp32-input MFMA);

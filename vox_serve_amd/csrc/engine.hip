@@ -601,6 +601,221 @@ int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const 
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------
+// CSM-1B frame engine
+// ---------------------------------------------------------------------------------------------------
+struct vox_csm {
+    vox_ctx* ctx;
+    vox_csm_config cfg;
+    vox_csm_weights w;
+    vox_stack *backbone, *depth;
+    void *x, *depth_x, *dx, *dlogits, *dkv;
+    int32_t* dmeta;
+    int32_t *iota, *d1_pos, *d1_req, *d1_kvlen, *d_indptr, *odd_rows;
+    std::vector<int32_t*> di_pos, di_kvlen;
+    int64_t dkv_stride;
+};
+
+// x[r] = bf16( sum_k mask[r,k] * emb_k[ids[r,k]] ), fp32, k ascending: audio codebooks 0..C-1 (table row k*V + id), then
+// the text column (csm.py:647-653: `(embeds * masks).sum(dim=1)` — one rounding at the end)
+__global__ __launch_bounds__(256) void k_csm_embed(const int* ids, const uint8_t* masks, const bf16_t* audio_emb,
+                                                   const bf16_t* text_emb, bf16_t* x, int C, int V, int text_vocab, int H) {
+    const int r = blockIdx.y, C1 = C + 1;
+    const int* id = ids + (size_t)r * C1;
+    const uint8_t* mk = masks + (size_t)r * C1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H; i += gridDim.x * 256) {
+        float acc = 0.0f;
+        for (int k = 0; k < C; ++k) {
+            if (!mk[k]) continue;
+            int t = id[k];
+            t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+            acc = acc + bf2f(audio_emb[((size_t)k * V + t) * H + i]);
+        }
+        if (mk[C]) {
+            int t = id[C];
+            t = t < 0 ? 0 : (t >= text_vocab ? text_vocab - 1 : t);
+            acc = acc + bf2f(text_emb[(size_t)t * H + i]);
+        }
+        x[(size_t)r * H + i] = f2bf(acc);
+    }
+}
+// output row: every column starts as codebook 0 (`output_ids.repeat(1, n_codebooks)`, csm.py:697)
+__global__ void k_csm_fill_row(int* out_ids, int C1, int B) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (b < B && j > 0 && j < C1) out_ids[(size_t)b * C1 + j] = out_ids[(size_t)b * C1];
+}
+// next frame inputs: the 32 sampled codes, text column 0 and masked out (csm.py:705-709, 764-765)
+__global__ void k_csm_feedback(const int* out_ids, int* input_ids, uint8_t* masks, uint64_t* rng, int C1, int B) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (b < B && j < C1) {
+        input_ids[(size_t)b * C1 + j] = j < C1 - 1 ? out_ids[(size_t)b * C1 + j] : 0;
+        masks[(size_t)b * C1 + j] = j < C1 - 1 ? 1 : 0;
+    }
+    if (b == 0 && j == 0 && rng) *rng += 1;
+}
+
+static int csm_head(vox_csm* m, hipStream_t st, const vox_csm_io* io, int B, const int32_t* x_rows) {
+    const vox_csm_config& c = m->cfg;
+    const int H = c.backbone.hidden;
+    LinearCall h;  // backbone final norm (-> hidden row of the depth input) + lm_head
+    h.W = m->w.lm_head; h.x = m->x; h.x_rows = x_rows; h.norm_w = m->w.backbone_norm; h.eps = c.backbone.eps;
+    h.x_out = m->depth_x; h.x_out_stride = 2L * H; h.y = io->out_logits; h.B = B; h.N = c.vocab; h.K = H;
+    h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
+    VOX_TRY(vox_launch_linear(m->ctx, st, h));
+    if (io->out_hidden)
+        hipLaunchKernelGGL(k_copy_rows, dim3((H + 255) / 256, B), dim3(256), 0, st, (const bf16_t*)m->depth_x, 2L * H,
+                           (bf16_t*)io->out_hidden, (long)H, H);
+    return VOX_OK;
+}
+
+static int csm_tail(vox_csm* m, hipStream_t st, const vox_csm_io* io, int B, const vox_sampling_config* sc, uint64_t seed,
+                    int feedback) {
+    const vox_csm_config& c = m->cfg;
+    const int H = c.backbone.hidden, Hd = c.depth.hidden, C = c.n_codebooks, C1 = C + 1, V = c.vocab;
+    {
+        SampleCall s;   // codebook 0 from the backbone logits; its embedding is the second row of the depth input
+        s.logits = io->out_logits; s.B = B; s.V = V; s.cfg = *sc; s.cfg.repetition_penalty = 1.0f;   // never persisted (Q3)
+        s.seed = seed; s.offset = 0; s.offset_dev = io->rng_offset; s.offset_mul = (uint64_t)C;
+        s.out_ids = io->out_ids; s.out_stride = C1; s.out_col = 0;
+        s.emb_table = m->w.audio_embedding; s.emb_vocab = V; s.H = H;
+        s.emb_dst = (bf16_t*)m->depth_x + H; s.emb_dst_stride = 2L * H; s.ws = m->ctx->samp_ws;
+        VOX_TRY(vox_launch_sample(st, s));
+    }
+    hipLaunchKernelGGL(k_csm_fill_row, dim3(B), dim3(64), 0, st, io->out_ids, C1, B);
+    for (int i = 1; i < C; ++i) {
+        const int rows = i == 1 ? 2 * B : B;
+        LinearCall p;  // inputs_embeds_projector (no bias)
+        p.W = m->w.depth_proj; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
+        p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8; p.keep_weights = m->depth->keep_weights;
+        p.splitk_ws = m->depth->skws; p.splitk_ws_bytes = m->depth->skws_bytes;
+        VOX_TRY(vox_launch_linear(m->ctx, st, p));
+        vox_rows r{};
+        r.pos = i == 1 ? m->d1_pos : m->di_pos[i];
+        r.q_req = i == 1 ? m->d1_req : m->iota;
+        r.q_kvlen = i == 1 ? m->d1_kvlen : m->di_kvlen[i];
+        r.page = r.q_req;
+        r.slot = i == 1 ? m->d1_pos : m->di_pos[i];
+        r.kv_indptr = m->d_indptr;
+        r.kv_indices = m->iota;
+        r.n_rows = rows;
+        r.max_kvlen = i + 1;
+        if (i > 1) { r.fixed_kvlen = i + 1; r.fixed_pos = i; r.identity_pages = 1; }
+        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= 8));
+        void* dl = io->out_depth_logits ? (void*)((bf16_t*)io->out_depth_logits + (size_t)(i - 1) * c.max_batch * V) : m->dlogits;
+        LinearCall h;  // depth final norm + codebooks_head[i-1]
+        h.W = (const bf16_t*)m->w.depth_heads + (size_t)(i - 1) * V * Hd;
+        h.x = m->dx; h.x_rows = i == 1 ? m->odd_rows : nullptr; h.norm_w = m->w.depth_norm; h.eps = c.depth.eps;
+        h.y = dl; h.B = B; h.N = V; h.K = Hd; h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
+        h.keep_weights = m->depth->keep_weights;
+        VOX_TRY(vox_launch_linear(m->ctx, st, h));
+        SampleCall s;
+        s.logits = dl; s.B = B; s.V = V; s.cfg = *sc; s.cfg.repetition_penalty = 1.0f;
+        s.seed = seed; s.offset = (uint64_t)i; s.offset_dev = io->rng_offset; s.offset_mul = (uint64_t)C;
+        s.out_ids = io->out_ids; s.out_stride = C1; s.out_col = i;
+        s.emb_table = (const bf16_t*)m->w.audio_embedding + (size_t)i * V * H; s.emb_vocab = V; s.H = H;   // embed_audio_tokens_single(ids, i)
+        s.emb_dst = m->depth_x; s.emb_dst_stride = H; s.ws = m->ctx->samp_ws;
+        VOX_TRY(vox_launch_sample(st, s));
+    }
+    if (feedback)
+        hipLaunchKernelGGL(k_csm_feedback, dim3(B), dim3(64), 0, st, io->out_ids, io->input_ids, io->input_masks, io->rng_offset, C1, B);
+    else if (io->rng_offset)
+        hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, io->rng_offset);
+    return VOX_OK;
+}
+
+static void csm_embed(vox_csm* m, hipStream_t st, const int32_t* ids, const uint8_t* masks, int n) {
+    const vox_csm_config& c = m->cfg;
+    const int H = c.backbone.hidden;
+    hipLaunchKernelGGL(k_csm_embed, dim3((H + 255) / 256, n), dim3(256), 0, st, ids, masks, (const bf16_t*)m->w.audio_embedding,
+                       (const bf16_t*)m->w.text_embedding, (bf16_t*)m->x, c.n_codebooks, c.vocab, c.text_vocab, H);
+}
+
+extern "C" {
+
+int vox_csm_create(vox_ctx* ctx, const vox_csm_config* cfg, const vox_csm_weights* w, vox_csm** out) {
+    if (!ctx || !cfg || !w || !out) return vox_fail(VOX_ERR_INVALID, "csm_create: NULL argument");
+    if (cfg->n_codebooks < 2 || cfg->n_codebooks > 63 || cfg->max_batch < 1) return vox_fail(VOX_ERR_INVALID, "csm_create: bad config");
+    vox_csm* m = new vox_csm();
+    m->ctx = ctx; m->cfg = *cfg; m->w = *w;
+    const int B = cfg->max_batch, C = cfg->n_codebooks, H = cfg->backbone.hidden, Hd = cfg->depth.hidden;
+    vox_stack_config bc = cfg->backbone, dc = cfg->depth;
+    dc.page_size = C; dc.max_rows = 2 * B; dc.max_kvlen = C;
+    int s = vox_stack_create(ctx, &bc, w->backbone_layers, w->backbone_norm, w->backbone_rope, w->backbone_rope_max_pos, &m->backbone);
+    if (s != VOX_OK) { delete m; return s; }
+    s = vox_stack_create(ctx, &dc, w->depth_layers, w->depth_norm, w->depth_rope, w->depth_rope_max_pos, &m->depth);
+    if (s != VOX_OK) { vox_stack_destroy(m->backbone); delete m; return s; }
+    m->depth->keep_weights = 1;   // re-read by each of the 31 dependent steps: keep them in the Infinity Cache
+    const size_t R = bc.max_rows;
+    m->dkv_stride = (int64_t)B * 2 * C * dc.kv_heads * dc.head_dim;
+    bool ok = hipMalloc(&m->x, R * H * 2) == hipSuccess && hipMalloc(&m->depth_x, (size_t)2 * B * H * 2) == hipSuccess &&
+              hipMalloc(&m->dx, (size_t)2 * B * Hd * 2) == hipSuccess &&
+              hipMalloc(&m->dlogits, (size_t)B * cfg->vocab * 2) == hipSuccess &&
+              hipMalloc(&m->dkv, (size_t)dc.layers * m->dkv_stride * 2) == hipSuccess;
+    if (!ok) return vox_fail(VOX_ERR_NOMEM, "csm_create: hipMalloc failed");
+    VOX_HIP(hipMemset(m->dkv, 0, (size_t)dc.layers * m->dkv_stride * 2));
+    const int niota = (int)(R > (size_t)2 * B + 1 ? R : 2 * B + 1);
+    std::vector<int32_t> host;
+    auto push = [&](const std::vector<int32_t>& v) { size_t o = host.size(); host.insert(host.end(), v.begin(), v.end()); return o; };
+    std::vector<int32_t> iota(niota), d1p(2 * B), d1r(2 * B), d1k(2 * B), odd(B), indptr(B + 1);
+    for (int i = 0; i < niota; ++i) iota[i] = i;
+    for (int b = 0; b < B; ++b) {
+        d1p[2 * b] = 0; d1p[2 * b + 1] = 1; d1r[2 * b] = d1r[2 * b + 1] = b;
+        d1k[2 * b] = 1; d1k[2 * b + 1] = 2; odd[b] = 2 * b + 1;
+    }
+    for (int b = 0; b <= B; ++b) indptr[b] = b;
+    const size_t o_iota = push(iota), o_d1p = push(d1p), o_d1r = push(d1r), o_d1k = push(d1k), o_odd = push(odd), o_ind = push(indptr);
+    std::vector<size_t> o_pos(C, 0), o_kvl(C, 0);
+    for (int i = 2; i < C; ++i) {
+        o_pos[i] = push(std::vector<int32_t>(B, i));
+        o_kvl[i] = push(std::vector<int32_t>(B, i + 1));
+    }
+    if (hipMalloc((void**)&m->dmeta, host.size() * 4) != hipSuccess) return vox_fail(VOX_ERR_NOMEM, "csm_create: hipMalloc");
+    VOX_HIP(hipMemcpy(m->dmeta, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    m->iota = m->dmeta + o_iota; m->d1_pos = m->dmeta + o_d1p; m->d1_req = m->dmeta + o_d1r; m->d1_kvlen = m->dmeta + o_d1k;
+    m->odd_rows = m->dmeta + o_odd; m->d_indptr = m->dmeta + o_ind;
+    m->di_pos.assign(C, nullptr); m->di_kvlen.assign(C, nullptr);
+    for (int i = 2; i < C; ++i) { m->di_pos[i] = m->dmeta + o_pos[i]; m->di_kvlen[i] = m->dmeta + o_kvl[i]; }
+    *out = m;
+    return VOX_OK;
+}
+void vox_csm_destroy(vox_csm* m) {
+    if (!m) return;
+    vox_stack_destroy(m->backbone); vox_stack_destroy(m->depth);
+    for (void* p : {m->x, m->depth_x, m->dx, m->dlogits, m->dkv, (void*)m->dmeta}) (void)hipFree(p);
+    delete m;
+}
+int vox_csm_frame(vox_csm* m, void* stream, const vox_csm_io* io, int B, int max_kvlen, const vox_sampling_config* sc,
+                  uint64_t seed, int feedback) {
+    if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "csm_frame: NULL");
+    if (B < 1 || B > m->cfg.max_batch) return vox_fail(VOX_ERR_INVALID, "csm_frame: batch %d > max_batch", B);
+    hipStream_t st = (hipStream_t)stream;
+    csm_embed(m, st, io->input_ids, io->input_masks, B);
+    vox_rows r{};
+    r.pos = io->pos; r.q_req = m->iota; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
+    r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = B; r.max_kvlen = max_kvlen;
+    r.page_table = io->page_table; r.pt_stride = (int32_t)io->pt_stride;
+    VOX_TRY(stack_layers(m->backbone, st, m->x, io->kv, io->kv_layer_stride, &r, true, B <= 8));
+    VOX_TRY(csm_head(m, st, io, B, nullptr));
+    return csm_tail(m, st, io, B, sc, seed, feedback);
+}
+int vox_csm_prefill(vox_csm* m, void* stream, const vox_csm_io* io, const int32_t* row_ids, const uint8_t* row_masks,
+                    const int32_t* q_req, int n_rows, const int32_t* last_rows, int n_req, int max_kvlen,
+                    const vox_sampling_config* sc, uint64_t seed, int feedback) {
+    if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "csm_prefill: NULL");
+    if (n_req < 1 || n_req > m->cfg.max_batch || n_rows > m->cfg.backbone.max_rows)
+        return vox_fail(VOX_ERR_INVALID, "csm_prefill: n_req %d / n_rows %d out of range", n_req, n_rows);
+    hipStream_t st = (hipStream_t)stream;
+    csm_embed(m, st, row_ids, row_masks, n_rows);
+    vox_rows r{};
+    r.pos = io->pos; r.q_req = q_req; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
+    r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = n_rows; r.max_kvlen = max_kvlen;
+    VOX_TRY(stack_layers(m->backbone, st, m->x, io->kv, io->kv_layer_stride, &r, false, n_rows <= 8));
+    VOX_TRY(csm_head(m, st, io, n_req, last_rows));
+    return csm_tail(m, st, io, n_req, sc, seed, feedback);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
 // single-stack LM engine (GLM-4-Voice, CosyVoice2, ...)
 // ---------------------------------------------------------------------------------------------------
 struct vox_lm {

@@ -444,7 +444,7 @@ static int launch_gemv(hipStream_t st, const LinArgs& a, bool* handled) {
     *handled = true;
     const int kc = a.K / 512;
 #define VOX_GK(B_, K_) if (a.B <= B_ && kc == K_) return launch_gemv_k<B_, K_, PRO, EPI>(st, a);
-    VOX_GK(1, 2) VOX_GK(1, 4) VOX_GK(1, 6) VOX_GK(1, 8) VOX_GK(1, 12)
+    VOX_GK(1, 2) VOX_GK(1, 4) VOX_GK(1, 6) VOX_GK(1, 8) VOX_GK(1, 12) VOX_GK(1, 16)
     VOX_GK(2, 2) VOX_GK(2, 4) VOX_GK(2, 6) VOX_GK(2, 8) VOX_GK(2, 12)
 #undef VOX_GK
     *handled = false;

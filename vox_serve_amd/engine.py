@@ -410,3 +410,125 @@ class LMEngine(Qwen3Engine):
     def sampling_cfg(greedy=True, top_k=0, top_p=1.0, min_p=0.0, temperature=1.0, repetition_penalty=1.0):
         return N.SamplingCfg(int(greedy), int(top_k or 0), float(1.0 if top_p is None else top_p), float(min_p or 0.0),
                              float(temperature), float(repetition_penalty or 1.0))
+
+
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class CSMCfg:
+    """CSM-1B (model/csm.py; transformers CsmConfig defaults): llama-3.2-1B-style backbone + 4-layer depth decoder."""
+    backbone: StackCfg = field(default_factory=lambda: StackCfg(2048, 16, 32, 8, 64, 8192, eps=1e-5, rope_theta=5e5,
+                                                                rope_scale=32.0, rope_llama31=(1.0, 4.0, 8192), qk_norm=False))
+    depth: StackCfg = field(default_factory=lambda: StackCfg(1024, 4, 8, 2, 128, 8192, eps=1e-5, rope_theta=5e5,
+                                                             rope_scale=32.0, rope_llama31=(1.0, 4.0, 8192), qk_norm=False))
+    vocab: int = 2051
+    text_vocab: int = 128256
+    n_codebooks: int = 32
+    max_pos: int = 2048
+
+
+class CsmConfigC(ctypes.Structure):
+    _fields_ = [("backbone", N.StackConfig), ("depth", N.StackConfig), ("vocab", ctypes.c_int32), ("text_vocab", ctypes.c_int32),
+                ("n_codebooks", ctypes.c_int32), ("max_batch", ctypes.c_int32)]
+
+
+class CsmWeightsC(ctypes.Structure):
+    _fields_ = [("backbone_layers", ctypes.POINTER(N.LayerWeights)), ("depth_layers", ctypes.POINTER(N.LayerWeights))] + \
+               [(n, ctypes.c_void_p) for n in ("backbone_norm", "depth_norm", "audio_embedding", "text_embedding", "lm_head",
+                                               "depth_proj", "depth_heads", "backbone_rope", "depth_rope")] + \
+               [("backbone_rope_max_pos", ctypes.c_int32), ("depth_rope_max_pos", ctypes.c_int32)]
+
+
+class CsmIO(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("input_ids", "input_masks", "pos", "kvlen", "page", "slot", "kv_indptr",
+                                               "kv_indices", "page_table")] + \
+               [("pt_stride", ctypes.c_int64), ("kv", ctypes.c_void_p), ("kv_layer_stride", ctypes.c_int64)] + \
+               [(n, ctypes.c_void_p) for n in ("out_ids", "out_logits", "out_hidden", "out_depth_logits", "rng_offset")]
+
+
+class CSMEngine(Qwen3Engine):
+    """Host side of `vox_csm_*`.  `weights`: the reference's state_dict names (CsmForConditionalGeneration):
+    backbone_model.layers.*, backbone_model.norm, backbone_model.embed_tokens.embed_audio_tokens, embed_text_tokens,
+    lm_head, depth_decoder.model.{layers,norm,inputs_embeds_projector}, depth_decoder.codebooks_head.weight [31,Hd,V]."""
+
+    def __init__(self, cfg: CSMCfg, weights: Dict[str, torch.Tensor], max_batch=8, page_size=128, max_pages=256,
+                 max_seq_len=2304, max_prefill_rows=1024, keep_depth_logits=False, device="cuda"):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.max_batch, self.page_size, self.max_pages, self.max_seq_len = max_batch, page_size, max_pages, max_seq_len
+        self.L, self.ctx = N.lib(), N.ctx()
+        L, vp, ci = self.L, ctypes.c_void_p, ctypes.c_int
+        L.vox_csm_create.restype, L.vox_csm_create.argtypes = ci, [vp, ctypes.POINTER(CsmConfigC), ctypes.POINTER(CsmWeightsC), ctypes.POINTER(vp)]
+        L.vox_csm_destroy.restype, L.vox_csm_destroy.argtypes = None, [vp]
+        L.vox_csm_frame.restype, L.vox_csm_frame.argtypes = ci, [vp, vp, ctypes.POINTER(CsmIO), ci, ci, ctypes.POINTER(N.SamplingCfg), ctypes.c_uint64, ci]
+        L.vox_csm_prefill.restype, L.vox_csm_prefill.argtypes = ci, [vp, vp, ctypes.POINTER(CsmIO), vp, vp, vp, ci, vp, ci, ci, ctypes.POINTER(N.SamplingCfg), ctypes.c_uint64, ci]
+        dev = self.device
+        W = {k: (v if v.is_cuda else v.to(dev)) for k, v in weights.items()}
+        self._keep = []
+        b, d = cfg.backbone, cfg.depth
+        C, C1, H, V = cfg.n_codebooks, cfg.n_codebooks + 1, b.hidden, cfg.vocab
+        self.max_rows = max(max_prefill_rows, max_batch)
+        self.b_rope, self.d_rope = rope_table(cfg.max_pos, b, dev), rope_table(64, d, dev)
+        self.bl = pack_stack_weights(W, "backbone_model", b, self._keep)
+        self.dl = pack_stack_weights(W, "depth_decoder.model", d, self._keep)
+        # codebooks_head.weight is [C-1, Hd, V] (x @ W): the GEMV streams rows of [V, Hd] -> transpose once (layout only)
+        heads = W["depth_decoder.codebooks_head.weight"].transpose(1, 2).contiguous()
+
+        def P(name):
+            x = W[name].contiguous()
+            self._keep.append(x)
+            return x.data_ptr()
+        self._keep.append(heads)
+        cc = CsmConfigC(_stack_config(b, page_size, self.max_rows, max_seq_len), _stack_config(d, C, 2 * max_batch, C), V,
+                        cfg.text_vocab, C, max_batch)
+        cw = CsmWeightsC(ctypes.cast(self.bl, ctypes.POINTER(N.LayerWeights)), ctypes.cast(self.dl, ctypes.POINTER(N.LayerWeights)),
+                         P("backbone_model.norm.weight"), P("depth_decoder.model.norm.weight"),
+                         P("backbone_model.embed_tokens.embed_audio_tokens.weight"), P("embed_text_tokens.weight"),
+                         P("lm_head.weight"), P("depth_decoder.model.inputs_embeds_projector.weight"), heads.data_ptr(),
+                         self.b_rope.data_ptr(), self.d_rope.data_ptr(), cfg.max_pos, 64)
+        h = ctypes.c_void_p()
+        N.check(L.vox_csm_create(self.ctx, ctypes.byref(cc), ctypes.byref(cw), ctypes.byref(h)))
+        self.h = h
+        i32 = dict(dtype=torch.int32, device=dev)
+        R = self.max_rows
+        self.input_ids = torch.zeros(max_batch, C1, **i32)
+        self.input_masks = torch.zeros(max_batch, C1, dtype=torch.uint8, device=dev)
+        self.pt_stride = (max_seq_len + page_size - 1) // page_size + 1
+        self._plan_layout, off = {}, 0
+        for name, n in (("pos", R), ("kvlen", R), ("page", R), ("slot", R), ("q_req", R), ("last_rows", max_batch),
+                        ("indptr", max_batch + 1), ("indices", max_pages), ("ptab", max_batch * self.pt_stride)):
+            self._plan_layout[name] = (off, n)
+            off += n
+        self.plan_dev = torch.zeros(off, **i32)
+        self.plan_host = torch.zeros(off, dtype=torch.int32).pin_memory()
+        self.kv = torch.zeros(b.layers, max_pages, 2, page_size, b.kv_heads, b.head_dim, dtype=torch.bfloat16, device=dev)
+        self.out_ids = torch.zeros(max_batch, C1, **i32)
+        self.out_logits = torch.zeros(max_batch, V, dtype=torch.bfloat16, device=dev)
+        self.out_hidden = torch.zeros(max_batch, H, dtype=torch.bfloat16, device=dev)
+        self.out_depth_logits = (torch.zeros(C - 1, max_batch, V, dtype=torch.bfloat16, device=dev) if keep_depth_logits else None)
+        self.rng_offset = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.row_ids = torch.zeros(R, C1, **i32)
+        self.row_masks = torch.zeros(R, C1, dtype=torch.uint8, device=dev)
+        self._graphs, self.keep_hidden = {}, True
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def _io(self):
+        return CsmIO(self.input_ids.data_ptr(), self.input_masks.data_ptr(), self._pd("pos").data_ptr(),
+                     self._pd("kvlen").data_ptr(), self._pd("page").data_ptr(), self._pd("slot").data_ptr(),
+                     self._pd("indptr").data_ptr(), self._pd("indices").data_ptr(), self._pd("ptab").data_ptr(),
+                     self.pt_stride, self.kv.data_ptr(), self.kv[0].numel(), self.out_ids.data_ptr(), self.out_logits.data_ptr(),
+                     self.out_hidden.data_ptr() if self.keep_hidden else None,
+                     self.out_depth_logits.data_ptr() if self.out_depth_logits is not None else None, self.rng_offset.data_ptr())
+
+    def _mutable_state(self):
+        return [self.input_ids, self.input_masks, self.rng_offset]
+
+    def _native_frame(self, io, st, batch, bucket, sampling, seed, feedback):
+        N.check(self.L.vox_csm_frame(self.h, st, ctypes.byref(io), batch, bucket, ctypes.byref(sampling), seed, int(feedback)))
+
+    def _native_destroy(self):
+        self.L.vox_csm_destroy(self.h)
+
+    def _prefill_on_stream(self, n_rows, n_req, max_kvlen, sampling, seed, feedback):
+        io = self._io()
+        N.check(self.L.vox_csm_prefill(self.h, N.stream(), ctypes.byref(io), self.row_ids.data_ptr(), self.row_masks.data_ptr(),
+                                       self._pd("q_req").data_ptr(), n_rows, self._pd("last_rows").data_ptr(), n_req,
+                                       min(max(32, max_kvlen), self.max_seq_len), ctypes.byref(sampling), seed, int(feedback)))

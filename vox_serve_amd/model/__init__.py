@@ -76,6 +76,23 @@ def _cosyvoice2(model_name, device="cuda:0", weights=None, checkpoint_dir=None, 
                          device, weights, checkpoint_dir, synthetic, kw)
 
 
+@register_model("csm", "sesame/csm-1b")
+def _csm(model_name, device="cuda:0", weights=None, checkpoint_dir=None, synthetic=False, **kw):
+    from ..engine import CSMCfg
+    from .csm import CSMModel
+    config = kw.pop("config", None) or CSMCfg()
+    if weights is None:
+        if checkpoint_dir is not None:
+            weights = _load_safetensors_dir(checkpoint_dir, device)
+        elif synthetic:
+            from ..synth import synth_csm_weights
+            weights = synth_csm_weights(config, device)
+        else:
+            raise FileNotFoundError("no checkpoint_dir given (offline box): pass checkpoint_dir=... or synthetic=True")
+    kw.pop("detokenize_interval", None)
+    return CSMModel(model_name, weights, config=config, device=device, **kw)
+
+
 def load_model(model_name: str, device: str = "cuda", top_p=None, top_k=None, min_p=None, temperature=None,
                max_tokens=None, repetition_penalty=None, repetition_window=None, cfg_scale=None, greedy=False,
                enable_torch_compile=False, audio_decoder_device=None, detokenize_interval=None, **kw):

@@ -135,3 +135,32 @@ def synth_cosyvoice2_weights(c, device, seed=0, std=0.02):
         W[p + "input_layernorm.weight"] = ones(H)
         W[p + "post_attention_layernorm.weight"] = ones(H)
     return W
+
+
+def synth_csm_weights(c, device, seed=0, std=0.02):
+    """Random-init CSM state_dict (reference names, csm.py:55-313); c: engine.CSMCfg."""
+    w, ones = _gen(device, seed, std)
+    W = {}
+
+    def stack(prefix, s):
+        for i in range(s.layers):
+            p = f"{prefix}.layers.{i}."
+            W[p + "self_attn.q_proj.weight"] = w(s.heads * s.head_dim, s.hidden)
+            W[p + "self_attn.k_proj.weight"] = w(s.kv_heads * s.head_dim, s.hidden)
+            W[p + "self_attn.v_proj.weight"] = w(s.kv_heads * s.head_dim, s.hidden)
+            W[p + "self_attn.o_proj.weight"] = w(s.hidden, s.heads * s.head_dim)
+            W[p + "mlp.gate_proj.weight"] = w(s.ffn, s.hidden)
+            W[p + "mlp.up_proj.weight"] = w(s.ffn, s.hidden)
+            W[p + "mlp.down_proj.weight"] = w(s.hidden, s.ffn)
+            W[p + "input_layernorm.weight"] = ones(s.hidden)
+            W[p + "post_attention_layernorm.weight"] = ones(s.hidden)
+        W[prefix + ".norm.weight"] = ones(s.hidden)
+    b, d = c.backbone, c.depth
+    stack("backbone_model", b)
+    W["backbone_model.embed_tokens.embed_audio_tokens.weight"] = w(c.n_codebooks * c.vocab, b.hidden)
+    W["embed_text_tokens.weight"] = w(c.text_vocab, b.hidden)
+    W["lm_head.weight"] = w(c.vocab, b.hidden)
+    stack("depth_decoder.model", d)
+    W["depth_decoder.model.inputs_embeds_projector.weight"] = w(d.hidden, b.hidden)
+    W["depth_decoder.codebooks_head.weight"] = w(c.n_codebooks - 1, d.hidden, c.vocab)
+    return W

@@ -192,8 +192,9 @@ class ModelWorker:
             raise RuntimeError(f"No suitable prefill graph found for batch_size={n_req}, seq_len={n_rows}")
         q_req, kvlen, page, slot = self._token_plan(lm_inputs)
         e.row_ids[:n_rows].copy_(lm_inputs["input_ids"].to(torch.int32))
-        if lm_inputs["input_masks"] is not None:
-            e.row_masks[:n_rows].copy_(lm_inputs["input_masks"][:, -1].to(torch.uint8))
+        if lm_inputs["input_masks"] is not None:     # Qwen3 consumes the text column's mask, CSM every column's
+            mk = lm_inputs["input_masks"] if e.row_masks.dim() == 2 else lm_inputs["input_masks"][:, -1]
+            e.row_masks[:n_rows].copy_(mk.to(torch.uint8))
         if lm_inputs["input_features"] is not None:
             self._stage_features(lm_inputs["input_features"], e.row_feats)
         self._stage_repetition(requests, e)
@@ -214,7 +215,8 @@ class ModelWorker:
         if self._resident != ids:        # batch composition changed: restage the per-request inputs
             e.input_ids[:B].copy_(lm_inputs["input_ids"].to(torch.int32))
             if lm_inputs["input_masks"] is not None:
-                e.input_masks[:B].copy_(lm_inputs["input_masks"][:, -1].to(torch.uint8))
+                mk = lm_inputs["input_masks"] if e.input_masks.dim() == 2 else lm_inputs["input_masks"][:, -1]
+                e.input_masks[:B].copy_(mk.to(torch.uint8))
             if lm_inputs["input_features"] is not None:
                 self._stage_features(lm_inputs["input_features"], e.input_features)
             self._stage_repetition(requests, e)
