@@ -342,6 +342,37 @@ int vox_codec_reset_slot(vox_codec* m, void* stream, int slot);
 int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int code_stride, const int32_t* slots, int n,
                            int T, float* out);
 
+/* ---- Mimi codec decoder (token -> waveform) for CSM, stateless per chunk -------------------------------------
+ * replaces MimiDecoder.decode / MimiModel.decode (tokenizer/mimi.py:2993-3022, 3085-3089) as CSMModel.postprocess calls
+ * it (model/csm.py:772-787): split RVQ decode, channel-wise x2 transposed-conv upsample, 8-layer causal transformer
+ * (LayerNorm, RoPE on interleaved pairs, LayerScale, GELU MLP), SEANet decoder (ratios 8,6,5,4).  Every chunk starts
+ * from zero history, like the reference.                                                                          */
+typedef struct vox_mimi vox_mimi;
+typedef struct {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *scale1, *scale2;
+    vox_conv_w qkv, o, fc1, fc2;
+} vox_mimi_layer_w;
+typedef struct { vox_conv_w tconv, conv1, conv2; } vox_mimi_block_w; /* ELU, transposed conv, [ELU conv k3, ELU conv k1] + skip */
+typedef struct {
+    const float* emb;           /* [n_q][bins][vq_dim] = embedding_sum / clamp(cluster_usage) */
+    vox_conv_w rvq_first_out, rvq_rest_out;
+    const float* up_w;          /* [dim][4]: channel-wise transposed conv, kernel 4, stride 2 */
+    vox_mimi_layer_w layers[16];
+    vox_conv_w dec0;
+    vox_mimi_block_w blocks[4];
+    const float* final_w;       /* [n_filters][last_kernel] */
+    float final_b;
+} vox_mimi_weights;
+typedef struct {
+    int32_t bins, vq_dim, dim, num_heads, num_layers, ffn, n_q, n_filters, ratios[4], kernel_size, last_kernel_size, context;
+    float max_period, ln_eps;
+} vox_mimi_config;
+int vox_mimi_create(vox_ctx* ctx, const vox_mimi_config* cfg, const vox_mimi_weights* w, int max_batch, int max_frames,
+                    vox_mimi** out);
+void vox_mimi_destroy(vox_mimi* m);
+/* codes int32 [n, T, code_stride] (first n_q columns, clamped to [0, bins-1]); out fp32 [n, T * 2 * prod(ratios)] */
+int vox_mimi_decode(vox_mimi* m, void* stream, const int32_t* codes, int code_stride, int n, int T, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -755,8 +755,44 @@ def g9_csm_lm(ns):
     np.savez_compressed(os.path.join(HERE, "g9_csm_lm.npz"), **out)
     print("g9 ok; frame tokens", out["f2_tokens"])
 
+
+# --------------------------------------------------------------------------------------------------
+def g5_mimi(ns):
+    """Mimi decode [2, n_q, 10] through the reference MimiModel (stateless, as CSMModel.postprocess calls it:
+    csm.py:772-787, mimi.py:2993-3022), tiny and full-size configuration, fp32."""
+    from oracle import mimi_ref as MR
+    M = ns.mimi
+    out = {}
+    for tag, cfg in (("tiny", MR.tiny_mimi_cfg()), ("full", MR.MimiCfg())):
+        W = MR.random_mimi_weights(cfg, seed=1)
+        sea = dict(M._seanet_kwargs)
+        sea.update(dimension=cfg.dim, n_filters=cfg.n_filters, ratios=list(cfg.ratios))
+        tr = dict(M._transformer_kwargs)
+        tr.update(d_model=cfg.dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers, dim_feedforward=cfg.ffn,
+                  input_dimension=cfg.dim, output_dimensions=[cfg.dim])
+        enc, dec = M.SEANetEncoder(**sea), M.SEANetDecoder(**sea)
+        model = M.MimiModel(enc, dec, M.SplitResidualVectorQuantizer(dimension=cfg.vq_dim, n_q=cfg.n_q, bins=cfg.bins,
+                                                                    input_dimension=cfg.dim, output_dimension=cfg.dim),
+                            channels=1, sample_rate=24000, frame_rate=24000 / enc.hop_length / 2,
+                            encoder_frame_rate=24000 / enc.hop_length, causal=True, resample_method="conv",
+                            encoder_transformer=None, decoder_transformer=M.ProjectedTransformer(device="cpu", **tr)).eval()
+        missing, unexpected = model.load_state_dict(W, strict=False)
+        assert not unexpected, unexpected
+        for mod in model.modules():
+            if hasattr(mod, "_initialized"):
+                mod._initialized.fill_(1)
+        model.set_num_codebooks(cfg.n_q)
+        g = torch.Generator().manual_seed(17)
+        codes = torch.randint(0, cfg.bins, (2, cfg.n_q, 10), generator=g)
+        codes[1, :, 7:] = codes[1, :, 6:7]                       # a run of repeated frames (the worker's tail padding)
+        wav = model.decode(codes)
+        out[f"{tag}_codes"] = codes.numpy().astype(np.int16)
+        out[f"{tag}_wav"] = wav.numpy().astype(np.float32 if tag == "tiny" else np.float16)
+        print("g5", tag, tuple(wav.shape), "rms", float(wav.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(HERE, "g5_mimi.npz"), **out)
+
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi}
 
 if __name__ == "__main__":
     ns = H.boot()

@@ -108,3 +108,47 @@ def test_full_size_codec_vs_reference_goldens(dev, golden):
     assert rms(got[:1, :, :19200] - ex) < 1e-4
     assert dec.state_bytes_per_request < 3 * 2 ** 20
     dec.close()
+
+
+# ---------------------------------------------------------------- Mimi (CSM's codec) ---------------------------------
+def _mimi_case(dev, cfg, seed, B, T):
+    from oracle import mimi_ref as MR
+    from vox_serve_amd.tokenizer.mimi import MimiConfig, MimiDecoder
+    W = MR.random_mimi_weights(cfg, seed=seed)
+    pc = MimiConfig(**{k: getattr(cfg, k) for k in MimiConfig.__dataclass_fields__ if hasattr(cfg, k)})
+    dec = MimiDecoder(W, pc, device=dev, max_batch=max(2, B), max_frames=T)
+    g = torch.Generator().manual_seed(seed)
+    codes = torch.randint(0, cfg.bins, (B, cfg.n_q, T), generator=g)
+    ref = MR.MimiRef(cfg, W).decode(codes).numpy()
+    got = dec.decode(codes).cpu().numpy()
+    dec.close()
+    return got, ref
+
+
+def test_mimi_tiny_matches_oracle(dev):
+    from oracle import mimi_ref as MR
+    got, ref = _mimi_case(dev, MR.tiny_mimi_cfg(), 1, 3, 10)
+    assert got.shape == ref.shape
+    assert np.sqrt(np.mean((got - ref) ** 2)) < 1e-4 and np.sqrt(np.mean(ref ** 2)) > 0.1
+
+
+@pytest.mark.slow
+def test_mimi_full_size_matches_oracle_and_reference(dev, golden):
+    """Mimi at the reference's configuration (512 dim, 8 layers, SEANet 8/6/5/4, 32 codebooks): RMS < 1e-4 vs the oracle
+    and vs the reference module's own output (g5, fp16 fixture)."""
+    from oracle import mimi_ref as MR
+    from vox_serve_amd.tokenizer.mimi import MimiConfig, MimiDecoder
+    cfg = MR.MimiCfg()
+    got, ref = _mimi_case(dev, cfg, 1, 2, 10)
+    assert got.shape == (2, 1, 19200)
+    assert np.sqrt(np.mean((got - ref) ** 2)) < 1e-4
+    g = golden("g5_mimi")
+    dec = MimiDecoder(MR.random_mimi_weights(cfg, seed=1), MimiConfig(), device=dev, max_batch=2, max_frames=10)
+    wav = dec.decode(torch.from_numpy(g["full_codes"].astype(np.int64))).cpu().numpy()
+    assert np.sqrt(np.mean((wav - g["full_wav"].astype(np.float32)) ** 2)) < 2e-4      # fixture is fp16-quantised
+    # the worker's layout: [B, T, 33] token rows, text column ignored
+    rows = torch.zeros(2, 10, 33, dtype=torch.long)
+    rows[:, :, :32] = torch.from_numpy(g["full_codes"].astype(np.int64)).transpose(1, 2)
+    wav2 = dec.decode(rows, code_layout="BTQ").cpu().numpy()
+    assert np.array_equal(wav, wav2)
+    dec.close()

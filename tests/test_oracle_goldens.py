@@ -303,3 +303,18 @@ def test_codec_oracle_vs_reference_full(golden):
     w = _codec_run(CR.CodecCfg(), g["full_codes"][:1, :, :10], 10, exact=True)
     ref = g["full_fp32_c10"][:1, :, :19200].astype(np.float32)
     assert _rms(ref) > 0.05 and _rms(w - ref) < 1.5e-4
+
+
+# ---------------------------------------------------------------- g5: Mimi decoder -------------------
+def test_mimi_oracle_against_reference_module(golden):
+    """oracle/mimi_ref.py vs the reference MimiModel.decode (stateless), tiny (fp32 fixture) and full size (fp16 fixture)."""
+    import torch
+    from oracle import mimi_ref as MR
+    g = golden("g5_mimi")
+    for tag, cfg, tol in (("tiny", MR.tiny_mimi_cfg(), 2e-6), ("full", MR.MimiCfg(), 1.5e-4)):
+        m = MR.MimiRef(cfg, MR.random_mimi_weights(cfg, seed=1))
+        wav = m.decode(torch.from_numpy(g[f"{tag}_codes"].astype(np.int64))).numpy()
+        ref = g[f"{tag}_wav"].astype(np.float32)
+        assert wav.shape == ref.shape == (2, 1, 10 * cfg.hop)
+        rms = float(np.sqrt(np.mean((wav - ref) ** 2)))
+        assert rms < tol and np.sqrt(np.mean(ref ** 2)) > 0.1, (tag, rms)

@@ -701,3 +701,223 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// Mimi decoder (CSM's codec), stateless per chunk.  Same building blocks: implicit-GEMM convolutions on fp32-input
+// MFMA (look-back rows before the chunk start read as zero = the reference's constant padding of a fresh state),
+// transposed conv with stride r = 2-tap GEMM writing r*Cout contiguous values per input row (the reference trims the
+// K-S rightmost samples: exactly the part the second tap of the NEXT chunk would add).
+// ================================================================================================
+// y[b, 2t+j, c] = x[b,t,c] * w[c][j] + x[b,t-1,c] * w[c][j+2]        (ConvTrUpsample1d, mimi.py:2272-2323)
+__global__ __launch_bounds__(256) void k_mimi_upsample(const float* x, const float* w, float* y, int L, int C, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t row = i / C;                     // output row = b*2L + 2t + j
+        const int tj = (int)(row % (2 * (size_t)L)), t = tj >> 1, j = tj & 1;
+        const size_t b = row / (2 * (size_t)L);
+        const float cur = x[(b * L + t) * C + c];
+        const float prev = t > 0 ? x[(b * L + t - 1) * C + c] : 0.0f;
+        y[i] = cur * w[c * 4 + j] + prev * w[c * 4 + j + 2];
+    }
+}
+__global__ __launch_bounds__(256) void k_layernorm_f32(const float* x, const float* w, const float* b, float* y, int C, float eps) {
+    __shared__ float red[8];
+    const float* xr = x + (size_t)blockIdx.x * C;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < C; i += 256) s += xr[i];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < C; i += 256) { const float d = xr[i] - mean; v += d * d; }
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + eps);
+    for (int i = threadIdx.x; i < C; i += 256) y[(size_t)blockIdx.x * C + i] = (xr[i] - mean) * rstd * w[i] + b[i];
+}
+__global__ __launch_bounds__(256) void k_elu(const float* x, float* y, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float v = x[i];
+        y[i] = v > 0.0f ? v : expm1f(v);
+    }
+}
+// causal attention inside one chunk of L <= 64 tokens with RoPE on interleaved pairs at positions 0..L-1
+// (apply_rope mimi.py:874-931; offset 0: stateless).  qkv rows [3][H][D]; one block per (head, request).
+__global__ __launch_bounds__(256) void k_mimi_attn(const float* qkv, float* out, int L, int H, int D, int context, float max_period) {
+    extern __shared__ float sm[];   // Q [L][D], K [L][D+1], V [L][D+1], P [4][L]
+    const int LD = D + 1;
+    float* Qs = sm;
+    float* Ks = Qs + (size_t)L * D;
+    float* Vs = Ks + (size_t)L * LD;
+    float* Ps = Vs + (size_t)L * LD;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HD = H * D;
+    for (int e = tid; e < L * (D / 2); e += 256) {
+        const int t = e / (D / 2), i = e % (D / 2);
+        const float* r = qkv + ((size_t)(b * L + t)) * 3 * HD + (size_t)h * D + 2 * i;
+        const float freq = expf((float)i * (-logf(max_period) * 2.0f / (float)D));
+        const float ang = freq * (float)t;
+        const float cr = cosf(ang), ci = sinf(ang);
+        const float qr = r[0], qi = r[1], kr = r[HD], ki = r[HD + 1];
+        Qs[t * D + 2 * i] = qr * cr - qi * ci;
+        Qs[t * D + 2 * i + 1] = qr * ci + qi * cr;
+        Ks[t * LD + 2 * i] = kr * cr - ki * ci;
+        Ks[t * LD + 2 * i + 1] = kr * ci + ki * cr;
+        Vs[t * LD + 2 * i] = r[2 * HD];
+        Vs[t * LD + 2 * i + 1] = r[2 * HD + 1];
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)D);
+    float* P = Ps + (size_t)wave * L;
+    for (int i = wave; i < L; i += 4) {
+        const float* q = Qs + (size_t)i * D;
+        const int j = lane;
+        const bool vis = j < L && j <= i && (i - j) < context;
+        float sc = -INFINITY;
+        if (vis) {
+            sc = 0.0f;
+            for (int d = 0; d < D; ++d) sc = fmaf(q[d], Ks[j * LD + d], sc);
+            sc *= scale;
+        }
+        float mx = sc;
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float pj = vis ? expf(sc - mx) : 0.0f;
+        float ls = pj;
+        for (int off = 32; off >= 1; off >>= 1) ls += __shfl_xor(ls, off, 64);
+        if (j < L) P[j] = pj;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int d = lane; d < D; d += 64) {
+            float o = 0.0f;
+            for (int jj = 0; jj <= i; ++jj) o = fmaf(P[jj], Vs[jj * LD + d], o);
+            out[((size_t)(b * L + i)) * HD + (size_t)h * D + d] = o / ls;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+}
+// last conv: C -> 1 channel, kernel K, zero history
+__global__ __launch_bounds__(256) void k_mimi_final(const float* x, const float* w, float bias, float* out, int L, int C, int K) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= L) return;
+    float acc = 0.0f;
+    for (int e = lane; e < K * C; e += 64) {
+        const int k = e / C, c = e % C;
+        const int r = t - (K - 1) + k;
+        if (r >= 0) acc += w[c * K + k] * x[((size_t)b * L + r) * C + c];
+    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[(size_t)b * L + t] = acc + bias;
+}
+
+struct vox_mimi {
+    vox_ctx* ctx;
+    vox_mimi_config cfg;
+    vox_mimi_weights w;
+    int max_batch, max_frames;
+    float *q0, *qr, *buf[4];
+    int32_t* zero_slots;
+};
+
+static void elu(hipStream_t st, const float* x, float* y, size_t total) {
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_elu, dim3(grid), dim3(256), 0, st, x, y, total);
+}
+
+extern "C" {
+
+int vox_mimi_create(vox_ctx* ctx, const vox_mimi_config* cfg, const vox_mimi_weights* w, int max_batch, int max_frames,
+                    vox_mimi** out) {
+    if (!ctx || !cfg || !w || !out) return vox_fail(VOX_ERR_INVALID, "mimi_create: NULL");
+    if (cfg->num_layers > 16 || cfg->dim % cfg->num_heads || 2 * max_frames > 64)
+        return vox_fail(VOX_ERR_INVALID, "mimi_create: <= 16 layers, <= 32 frames per chunk");
+    vox_mimi* m = new vox_mimi();
+    m->ctx = ctx; m->cfg = *cfg; m->w = *w; m->max_batch = max_batch; m->max_frames = max_frames;
+    // largest activation: rows x channels is the same (2T * 16 n_filters * prod so far / 2^i) at every SEANet stage up to
+    // the ratio products; bound it by the widest of each stage
+    size_t L = (size_t)2 * max_frames, ch = (size_t)16 * cfg->n_filters, maxf = L * ch;
+    for (int i = 0; i < 4; ++i) {
+        L *= cfg->ratios[i];
+        ch /= 2;
+        maxf = maxf > L * ch ? maxf : L * ch;
+    }
+    const size_t tr = (size_t)2 * max_frames * (3 * cfg->dim > cfg->ffn ? 3 * cfg->dim : cfg->ffn);
+    maxf = (maxf > tr ? maxf : tr) * max_batch;
+    bool ok = hipMalloc((void**)&m->q0, (size_t)max_batch * max_frames * cfg->vq_dim * 4) == hipSuccess &&
+              hipMalloc((void**)&m->qr, (size_t)max_batch * max_frames * cfg->vq_dim * 4) == hipSuccess &&
+              hipMalloc((void**)&m->zero_slots, (size_t)max_batch * 4) == hipSuccess;
+    for (int i = 0; i < 4; ++i) ok = ok && hipMalloc((void**)&m->buf[i], maxf * 4) == hipSuccess;
+    if (!ok) return vox_fail(VOX_ERR_NOMEM, "mimi_create: hipMalloc failed");
+    VOX_HIP(hipMemset(m->zero_slots, 0, (size_t)max_batch * 4));
+    *out = m;
+    return VOX_OK;
+}
+void vox_mimi_destroy(vox_mimi* m) {
+    if (!m) return;
+    (void)hipFree(m->q0); (void)hipFree(m->qr); (void)hipFree(m->zero_slots);
+    for (int i = 0; i < 4; ++i) (void)hipFree(m->buf[i]);
+    delete m;
+}
+int vox_mimi_decode(vox_mimi* m, void* stream, const int32_t* codes, int code_stride, int n, int T, float* out) {
+    if (!m || !codes || !out) return vox_fail(VOX_ERR_INVALID, "mimi_decode: NULL");
+    if (n < 1 || n > m->max_batch || T < 1 || T > m->max_frames) return vox_fail(VOX_ERR_INVALID, "mimi_decode: n=%d T=%d out of range", n, T);
+    hipStream_t st = (hipStream_t)stream;
+    const vox_mimi_config& c = m->cfg;
+    const vox_mimi_weights& w = m->w;
+    const int C = c.dim, H = c.num_heads, D = c.dim / c.num_heads;
+    const int* sl = m->zero_slots;
+    float *A = m->buf[0], *B = m->buf[1], *Cb = m->buf[2], *Db = m->buf[3];
+    const int off0[1] = {0};
+    int L = T;
+    hipLaunchKernelGGL(k_rvq, dim3(n * L), dim3(256), 0, st, codes, code_stride, w.emb, c.n_q, c.bins, c.vq_dim, m->q0, m->qr);
+    VOX_TRY(conv_gemm(st, w.rvq_first_out, m->q0, nullptr, sl, n, L, 0, off0, A, nullptr, nullptr, 0));
+    VOX_TRY(conv_gemm(st, w.rvq_rest_out, m->qr, nullptr, sl, n, L, 0, off0, B, A, nullptr, 0));            // B [nL, dim]
+    {
+        const size_t total = (size_t)n * 2 * L * C;
+        int grid = (int)((total + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(k_mimi_upsample, dim3(grid), dim3(256), 0, st, B, w.up_w, A, L, C, total);        // A [n*2L, dim]
+    }
+    L *= 2;
+    for (int l = 0; l < c.num_layers; ++l) {                                                                 // h = A
+        const vox_mimi_layer_w& lw = w.layers[l];
+        hipLaunchKernelGGL(k_layernorm_f32, dim3(n * L), dim3(256), 0, st, A, lw.ln1_w, lw.ln1_b, Cb, C, c.ln_eps);
+        VOX_TRY(conv_gemm(st, lw.qkv, Cb, nullptr, sl, n, L, 0, off0, Db, nullptr, nullptr, 0));             // Db [nL, 3*dim]
+        hipLaunchKernelGGL(k_mimi_attn, dim3(H, n), dim3(256), (size_t)(L * D + 2 * L * (D + 1) + 4 * L) * 4, st, Db, Cb, L, H, D,
+                           c.context, c.max_period);
+        VOX_TRY(conv_gemm(st, lw.o, Cb, nullptr, sl, n, L, 0, off0, A, A, lw.scale1, 0));                    // h += s1 * o(attn)
+        hipLaunchKernelGGL(k_layernorm_f32, dim3(n * L), dim3(256), 0, st, A, lw.ln2_w, lw.ln2_b, Cb, C, c.ln_eps);
+        VOX_TRY(conv_gemm(st, lw.fc1, Cb, nullptr, sl, n, L, 0, off0, Db, nullptr, nullptr, 1));             // GELU
+        VOX_TRY(conv_gemm(st, lw.fc2, Db, nullptr, sl, n, L, 0, off0, A, A, lw.scale2, 0));                  // h += s2 * mlp
+    }
+    // ---- SEANet decoder ----
+    int offk[CG_MAXTAPS];
+    for (int k = 0; k < c.kernel_size; ++k) offk[k] = c.kernel_size - 1 - k;
+    VOX_TRY(conv_gemm(st, w.dec0, A, nullptr, sl, n, L, 0, offk, B, nullptr, nullptr, 0));                   // B [nL, 16 nf]
+    float *h = B, *t1 = A, *t2 = Cb, *t3 = Db;
+    int ch = 16 * c.n_filters;
+    for (int b = 0; b < 4; ++b) {
+        const vox_mimi_block_w& bw = w.blocks[b];
+        const int r = c.ratios[b];
+        elu(st, h, t1, (size_t)n * L * ch);
+        const int offt[2] = {0, 1};
+        VOX_TRY(conv_gemm(st, bw.tconv, t1, nullptr, sl, n, L, 0, offt, t2, nullptr, nullptr, 0));           // t2 [n*L*r, ch/2]
+        L *= r;
+        ch /= 2;
+        { float* x = h; h = t2; t2 = x; }
+        elu(st, h, t1, (size_t)n * L * ch);
+        const int off3[3] = {2, 1, 0};
+        VOX_TRY(conv_gemm(st, bw.conv1, t1, nullptr, sl, n, L, 0, off3, t3, nullptr, nullptr, 0));           // t3 [nL, ch/2]
+        elu(st, t3, t1, (size_t)n * L * (ch / 2));
+        VOX_TRY(conv_gemm(st, bw.conv2, t1, nullptr, sl, n, L, 0, off0, h, h, nullptr, 0));                  // h += conv2(...)
+    }
+    elu(st, h, t1, (size_t)n * L * ch);
+    hipLaunchKernelGGL(k_mimi_final, dim3((L + 3) / 4, n), dim3(256), 0, st, t1, w.final_w, w.final_b, out, L, ch, c.last_kernel_size);
+    return VOX_OK;
+}
+
+}  // extern "C"

@@ -77,7 +77,7 @@ def _cosyvoice2(model_name, device="cuda:0", weights=None, checkpoint_dir=None, 
 
 
 @register_model("csm", "sesame/csm-1b")
-def _csm(model_name, device="cuda:0", weights=None, checkpoint_dir=None, synthetic=False, **kw):
+def _csm(model_name, device="cuda:0", weights=None, checkpoint_dir=None, codec_checkpoint_dir=None, synthetic=False, **kw):
     from ..engine import CSMCfg
     from .csm import CSMModel
     config = kw.pop("config", None) or CSMCfg()
@@ -90,6 +90,8 @@ def _csm(model_name, device="cuda:0", weights=None, checkpoint_dir=None, synthet
         else:
             raise FileNotFoundError("no checkpoint_dir given (offline box): pass checkpoint_dir=... or synthetic=True")
     kw.pop("detokenize_interval", None)
+    if codec_checkpoint_dir is not None and "codec_weights" not in kw:      # kyutai/moshiko-pytorch-bf16 tokenizer checkpoint
+        kw["codec_weights"] = _load_safetensors_dir(codec_checkpoint_dir, "cpu")
     return CSMModel(model_name, weights, config=config, device=device, **kw)
 
 

@@ -5,7 +5,7 @@ forward / sampling / depth_forward / depth_sampling (:637-770) collapse into one
 31 depth steps with per-codebook heads, feedback of the next inputs); `update_requests` is the request-state half of
 `sampling` incl. its quirks: the stop test reads the row BEFORE the depth loop fills it (every column = codebook 0, so
 "token_ids[-2] == 0" is "codebook 0 == 0", :604-606,697-721), and max_tokens is only examined on a stop token (:717-722).
-The Mimi detokenizer (`postprocess`, :772-787) is the next row of SURVEY §8f."""
+`postprocess` (:772-787) runs the native Mimi decoder (tokenizer/mimi.py), stateless per chunk like the reference."""
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -18,7 +18,7 @@ from .base import BaseLMWithDepth, PreprocessOutput
 class CSMModel(BaseLMWithDepth):
     def __init__(self, model_name: str, weights: Dict[str, torch.Tensor], config: Optional[CSMCfg] = None, text_tokenizer=None,
                  device="cuda:0", dtype=torch.bfloat16, audio_decoder_device=None, sampling: Optional[SamplingConfig] = None,
-                 max_batch_size=8, page_size=128, max_num_pages=2048, max_seq_len=2304, max_prefill_tokens=1024, **kw):
+                 codec_weights: Optional[Dict[str, torch.Tensor]] = None, codec_config=None, max_batch_size=8, page_size=128, max_num_pages=2048, max_seq_len=2304, max_prefill_tokens=1024, **kw):
         super().__init__(model_name, device, dtype, False, audio_decoder_device)
         self.config = config or CSMCfg()
         self.text_tokenizer = text_tokenizer
@@ -29,6 +29,11 @@ class CSMModel(BaseLMWithDepth):
                                 max_seq_len=max_seq_len, max_prefill_rows=max_prefill_tokens, device=device)
         self.engine.keep_hidden = False
         self.default_context = {"tokens": [], "tokens_mask": []}     # csm.py:511-569 builds it from prompt audio (Mimi encoder)
+        self.audio_decoder = None
+        if codec_weights is not None:
+            from ..tokenizer.mimi import MimiDecoder
+            self.audio_decoder = MimiDecoder(codec_weights, codec_config, num_codebooks=self.config.n_codebooks,
+                                             device=self.audio_decoder_device, max_batch=max_batch_size, max_frames=10)
 
     n_codebooks = property(lambda self: self.config.n_codebooks + 1)
     depth_n_codebooks = property(lambda self: self.config.n_codebooks)
@@ -113,5 +118,8 @@ class CSMModel(BaseLMWithDepth):
                 req.done_lm_generation, req.finish_reason = True, "stop_id_encountered"
 
     def postprocess(self, token_ids: torch.Tensor, **kwargs) -> torch.Tensor:
-        raise NotImplementedError("CSMModel: the Mimi detokenizer is not built yet (SURVEY.md §8f-2); the speech-LM frame "
-                                  "(backbone + 31-step depth loop) is native")
+        """token_ids [B, interval, 33] (last column = text, dropped; codes clamped to [0, 2047] in the RVQ kernel) ->
+        audio [B, 1, interval*1920]; Mimi is stateless per chunk like the reference (csm.py:772-787)."""
+        if self.audio_decoder is None:
+            raise RuntimeError("CSMModel: no Mimi weights loaded (pass codec_weights=...)")
+        return self.audio_decoder.decode(token_ids, code_layout="BTQ")
