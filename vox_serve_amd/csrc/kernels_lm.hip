@@ -719,167 +719,12 @@ static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a) {
     return full ? launch_linear_mfma_t<2, PRO, EPI, true>(st, a) : launch_linear_mfma_t<2, PRO, EPI, false>(st, a);
 }
 
-// ================================================================================================
-// linear for many rows (prefill, 33+): bf16 MFMA straight from global memory, no LDS staging.
-// A block owns 16*NT output columns and ALL rows of a pass (up to 16*MT = 128), so the weights cross HBM once;
-// its four waves interleave the 32-wide K steps (step s -> wave s%4) and keep UK steps of fragments in flight:
-// one 16-byte load per lane per fragment, both for the weights (row n0+(lane&15), HBM, streaming) and for the
-// activations (row m*16+(lane&15), L2-resident: every block re-reads the same few hundred KB).  RMSNorm, when
-// needed, is applied once by k_rmsnorm in front (vox_launch_linear does it) instead of by every block.
-// fp32 accumulation in MFMA order (parity to bf16 rounding, like k_linear_mfma).
 __global__ void k_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps);
 
-template <int MT, int NT, int WV, int EPI>
-__global__ __launch_bounds__(64 * WV) void k_gemm_rows(LinArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);   // [WV-1][SETS][MT][NT][64]
-    constexpr bool SM = (EPI == EPI_SILU_MUL);
-    constexpr int SETS = SM ? 2 : 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int fr = lane & 15, fk = (lane >> 4) * 8;
-    const int n0 = blockIdx.x * 16 * NT;
-    const bf16_t* wrow[NT];
-    const bf16_t* wrow2[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        int n = n0 + t * 16 + fr;
-        n = n < a.N ? n : a.N - 1;
-        wrow[t] = a.W + (size_t)n * a.K + fk;
-        wrow2[t] = SM ? a.W2 + (size_t)n * a.K + fk : nullptr;
-    }
-    const int nsteps = a.K >> 5;
-    for (int b0 = 0; b0 < a.B; b0 += 16 * MT) {
-        const int bt = (a.B - b0) < 16 * MT ? (a.B - b0) : 16 * MT;
-        const bf16_t* xrow[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int r = m * 16 + fr;
-            xrow[m] = reinterpret_cast<const bf16_t*>(x_row_ptr(a, b0 + (r < bt ? r : bt - 1))) + fk;
-        }
-        f32x4_t acc[SETS][MT][NT];
-#pragma unroll
-        for (int z = 0; z < SETS; ++z)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[z][m][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        // register double buffer: the fragments of this wave's next K step are in flight while the current multiply
-        uint4 wn[SETS][NT], xn[MT];
-        // every block walks K from its own starting point: at any instant the blocks read different activation
-        // lines, so the (small, shared) activation tile does not hot-spot a few L2 channels
-        const int rot = (int)((blockIdx.x * 37u) % (unsigned)nsteps);
-        auto issue = [&](int sidx) {
-            int sr = (sidx < nsteps ? sidx : wave) + rot;
-            sr = sr >= nsteps ? sr - nsteps : sr;
-            const int k = sr << 5;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                wn[0][t] = ldg_nt(reinterpret_cast<const uint4*>(wrow[t] + k));
-                if (SM) wn[SETS - 1][t] = ldg_nt(reinterpret_cast<const uint4*>(wrow2[t] + k));
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) xn[m] = *reinterpret_cast<const uint4*>(xrow[m] + k);
-        };
-        constexpr bool DB = (SETS * MT * NT <= 5);   // register double buffer only where it does not force spills
-        if (DB) issue(wave);
-#pragma nounroll
-        for (int s0 = wave; s0 < nsteps; s0 += WV) {
-            uint4 wc[SETS][NT], xc[MT];
-            if (!DB) issue(s0);
-#pragma unroll
-            for (int z = 0; z < SETS; ++z)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) wc[z][t] = wn[z][t];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) xc[m] = xn[m];
-            if (DB) issue(s0 + WV);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[0][m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xc[m]), as_bf8(wc[0][t]), acc[0][m][t], 0, 0, 0);
-                    if (SM)
-                        acc[SETS - 1][m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xc[m]), as_bf8(wc[SETS - 1][t]), acc[SETS - 1][m][t], 0, 0, 0);
-                }
-        }
-        // cross-wave reduction in wave order, wave 0 runs the epilogue
-        __syncthreads();
-        if (wave > 0) {
-#pragma unroll
-            for (int z = 0; z < SETS; ++z)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) red[((((wave - 1) * SETS + z) * MT + m) * NT + t) * 64 + lane] = acc[z][m][t];
-        }
-        __syncthreads();
-        if (wave == 0) {
-            for (int w = 0; w < WV - 1; ++w)
-#pragma unroll
-                for (int z = 0; z < SETS; ++z)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[z][m][t] += red[(((w * SETS + z) * MT + m) * NT + t) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int n = n0 + t * 16 + fr;
-                if (n >= a.N) continue;
-                const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int b = m * 16 + (lane >> 4) * 4 + r;
-                        if (b >= bt) continue;
-                        const size_t oi = (size_t)(b0 + b) * a.N + n;
-                        bf16_t o;
-                        if (SM) {
-                            const float g = bfround(acc[0][m][t][r]), u = bfround(acc[SETS - 1][m][t][r]);
-                            o = f2bf(bfround(silu_c(g)) * u);
-                        } else {
-                            float v = acc[0][m][t][r];
-                            if (a.bias) v = v + bv;
-                            o = f2bf(v);
-                            if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
-                            if (a.residual) o = f2bf(bf2f(a.residual[oi]) + bf2f(o));
-                        }
-                        a.y[oi] = o;
-                    }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-template <int MT, int NT, int WV, int EPI>
-static int launch_gemm_rows_t(hipStream_t st, const LinArgs& a) {
-    constexpr int SETS = (EPI == EPI_SILU_MUL) ? 2 : 1;
-    const size_t smem = (size_t)(WV - 1) * SETS * MT * NT * 64 * 16;
-    auto kern = k_gemm_rows<MT, NT, WV, EPI>;
-    if (smem > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            done = true;
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3((a.N + 16 * NT - 1) / (16 * NT)), dim3(64 * WV), smem, st, a);
-    return VOX_OK;
-}
-template <int EPI>
-static int launch_gemm_rows(hipStream_t st, const LinArgs& a) {
-    // rows per pass: all of them up to 128 (weights cross HBM once); waves per block: 8 K-interleaved waves keep
-    // >= 1024 waves in flight even at N = 2048
-    const int mt = a.B <= 16 ? 1 : a.B <= 32 ? 2 : a.B <= 48 ? 3 : a.B <= 80 ? 5 : 8;
-#define VOX_GR(M_)  if (mt == M_) return launch_gemm_rows_t<M_, 1, 8, EPI>(st, a);
-    VOX_GR(1) VOX_GR(2) VOX_GR(3) VOX_GR(5) VOX_GR(8)
-#undef VOX_GR
-    return vox_fail(VOX_ERR_INVALID, "gemm_rows: no variant");
-}
-
 // ================================================================================================
-// linear for prefill-sized row counts (33+): split-K bf16 MFMA GEMM, LDS-tiled, weights read exactly once.
+// linear for 17+ rows (batched decode above 16, prefill): split-K bf16 MFMA GEMM, LDS-tiled, weights read exactly once.
+// (Fusing the slab reduction into the last-arriving block was tried: the device-scope fence it needs writes back and
+// invalidates the XCD's L2 in every block — 3x slower than the separate k_splitk_reduce launch.)
 // Grid (Ntot/64, K/512): a block owns 64 output columns and one 512-wide K slab for ALL rows of the pass (<= 128), walks
 // the slab in 64-wide chunks through a double-buffered LDS tile pair (128-byte coalesced row segments of both the
 // weights and the activations), wave w multiplying n-tile w against every row tile.  fp32 partial sums go to a
@@ -1032,8 +877,9 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     if (dev & 8) a.bias = nullptr;
     static int rows_min = -1;   // development knob: smallest row count routed to the prefill GEMMs
     if (rows_min < 0) { const char* e = getenv("VOX_ROWS_MIN"); rows_min = e ? atoi(e) : 17; }
-    if (c.B >= rows_min && !c.fixed_order && c.K % 32 == 0 && (pro == PRO_COPY || (pro == PRO_RMSNORM && c.norm_scratch && !a.x_rows && !a.x_out && a.x_stride == c.K))) {
-        // prefill-sized: normalise once (not in every block), then the LDS-free MFMA GEMM
+    if (c.B >= rows_min && !c.fixed_order && c.K % 32 == 0 && c.splitk_ws &&
+        (pro == PRO_COPY || (pro == PRO_RMSNORM && c.norm_scratch && !a.x_rows && !a.x_out && a.x_stride == c.K))) {
+        // 17+ rows: normalise once (not in every block), then the split-K MFMA GEMM
         if (pro == PRO_RMSNORM) {
             if (a.x_rows) return vox_fail(VOX_ERR_INVALID, "linear: row indirection with a norm prologue at > 32 rows");
             hipLaunchKernelGGL(k_rmsnorm, dim3((c.B + 3) / 4), dim3(256), 0, st, a.x, a.nw, (bf16_t*)c.norm_scratch, c.B, c.K, c.eps);
@@ -1041,14 +887,9 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
             a.x = (const bf16_t*)c.norm_scratch;
             a.x_stride = c.K;
         }
-        if (c.splitk_ws && c.K % 32 == 0 && !getenv("VOX_NO_SPLITK")) {
-            if (epi == EPI_STORE) return launch_gemm_splitk<EPI_STORE>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
-            if (epi == EPI_SILU) return launch_gemm_splitk<EPI_SILU>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
-            if (epi == EPI_SILU_MUL) return launch_gemm_splitk<EPI_SILU_MUL>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
-        }
-        if (epi == EPI_STORE) return launch_gemm_rows<EPI_STORE>(st, a);
-        if (epi == EPI_SILU) return launch_gemm_rows<EPI_SILU>(st, a);
-        if (epi == EPI_SILU_MUL) return launch_gemm_rows<EPI_SILU_MUL>(st, a);
+        if (epi == EPI_STORE) return launch_gemm_splitk<EPI_STORE>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
+        if (epi == EPI_SILU) return launch_gemm_splitk<EPI_SILU>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
+        if (epi == EPI_SILU_MUL) return launch_gemm_splitk<EPI_SILU_MUL>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
     }
     if (c.B > 8 && !c.fixed_order && c.pro != PRO_ATTN && c.K % 32 == 0) {   // > 8 rows: MFMA path (weights streamed once per 32-row tile)
 #define VOX_PM(P, E) if (c.pro == P && c.epi == E) return launch_linear_mfma_pe<P, E>(st, a);
