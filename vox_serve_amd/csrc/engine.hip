@@ -240,6 +240,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
     float* part_o = s->attn_ws;
     float* part_ml = s->attn_ws + (size_t)n * c.heads * mc * c.head_dim;
     const float scale = 1.0f / sqrtf((float)c.head_dim);
+    bool xn_ready = false;   // s->xn holds norm(x) for the next norm-prologue linear (written by the producing GEMM's reduce)
     for (int l = 0; l < c.layers; ++l) {
         const vox_layer_weights& w = s->layers[l];
         void* kvl = (char*)kv + (size_t)l * kv_stride * 2;
@@ -247,6 +248,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         a.W = w.wqkv; a.bias = w.bqkv; a.x = x; a.norm_w = w.ln1; a.eps = c.eps; a.y = s->qkv;
         a.B = n; a.N = nqkv; a.K = c.hidden; a.pro = VOX_PRO_RMSNORM; a.epi = VOX_EPI_STORE;
         a.fixed_order = fixed_order; a.keep_weights = s->keep_weights; a.splitk_ws = s->skws; a.splitk_ws_bytes = s->skws_bytes; a.norm_scratch = s->xn;
+        if (xn_ready) a.x_prenormed = s->xn;
         if (!(ablate() & 16)) VOX_TRY(vox_launch_linear(s->ctx, st, a));
         HeadCall hc;  // per-head norm + RoPE + paged append
         hc.q_src = s->qkv; hc.k_src = (bf16_t*)s->qkv + nq; hc.v_src = (bf16_t*)s->qkv + nq + nkv;
@@ -273,6 +275,8 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         o.W = w.wo; o.x = s->attn_out; o.residual = x; o.y = x; o.B = n; o.N = c.hidden; o.K = nq;
         o.pro = VOX_PRO_COPY; o.epi = VOX_EPI_STORE;
         o.fixed_order = fixed_order; o.keep_weights = s->keep_weights; o.splitk_ws = s->skws; o.splitk_ws_bytes = s->skws_bytes;
+        xn_ready = vox_linear_is_rows_gemm(o);      // its reduce also writes post_attention_layernorm(x) for gate/up
+        if (xn_ready) { o.post_norm_w = w.ln2; o.post_norm_out = s->xn; }
         if (decode_rows && c.max_kvlen <= 16 && !(ablate() & 256) && vox_attn1_linear_supported(ac, o)) {
             VOX_TRY(vox_launch_attn1_linear(st, ac, o));     // short context: attention recomputed inside o_proj
         } else {
@@ -289,11 +293,14 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         g.W = w.wgate; g.W2 = w.wup; g.x = x; g.norm_w = w.ln2; g.eps = c.eps; g.y = s->h;
         g.B = n; g.N = c.ffn; g.K = c.hidden; g.pro = VOX_PRO_RMSNORM; g.epi = VOX_EPI_SILU_MUL;
         g.fixed_order = fixed_order; g.keep_weights = s->keep_weights; g.splitk_ws = s->skws; g.splitk_ws_bytes = s->skws_bytes; g.norm_scratch = s->xn;
+        if (xn_ready) g.x_prenormed = s->xn;
         if (!(ablate() & 64)) VOX_TRY(vox_launch_linear(s->ctx, st, g));
         LinearCall d;  // down + residual
         d.W = w.wdown; d.x = s->h; d.residual = x; d.y = x; d.B = n; d.N = c.hidden; d.K = c.ffn;
         d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE;
         d.fixed_order = fixed_order; d.keep_weights = s->keep_weights; d.splitk_ws = s->skws; d.splitk_ws_bytes = s->skws_bytes;
+        xn_ready = l + 1 < c.layers && vox_linear_is_rows_gemm(d);    // ... and the next layer's input_layernorm(x)
+        if (xn_ready) { d.post_norm_w = s->layers[l + 1].ln1; d.post_norm_out = s->xn; }
         if (!(ablate() & 128)) VOX_TRY(vox_launch_linear(s->ctx, st, d));
     }
     return VOX_OK;

@@ -21,6 +21,9 @@ struct LinArgs {
     long x_stride, x_out_stride;
     float eps;
     int B, N, K, Hq, D, max_chunks;
+    const bf16_t* post_nw;   // optional: RMSNorm weight of the NEXT linear; post_out = norm(y) written beside y (17+ rows path)
+    bf16_t* post_out;
+    float post_eps;
     int keep;            // 1: weights are re-read soon (depth loop): plain loads, let them live in the Infinity Cache
 };
 
@@ -825,6 +828,37 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* part, int S,
     a.y[oi] = o;
 }
 
+// Row-wise variant: one block per output row adds the slabs, runs the epilogue AND applies the RMSNorm the next linear
+// needs (post_out = norm(y) * post_nw): the separate k_rmsnorm launch of that linear disappears.  (Reduction tree of
+// the sum of squares is the block's, not the canonical lane order: this path is the bf16-rounding-parity one.)
+__global__ __launch_bounds__(1024) void k_splitk_reduce_rows(const float* part, int S, int rows_stride, LinArgs a, int b0) {
+    __shared__ float red[16];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* p0 = part + (size_t)row * a.N;
+    float ss = 0.0f;
+    for (int n = tid; n < a.N; n += 1024) {
+        float v = 0.0f;
+        for (int sl = 0; sl < S; ++sl) v = v + p0[(size_t)sl * rows_stride * a.N + n];
+        const size_t oi = (size_t)(b0 + row) * a.N + n;
+        if (a.bias) v = v + bf2f(a.bias[n]);
+        bf16_t o = f2bf(v);
+        if (a.residual) o = f2bf(bf2f(a.residual[oi]) + bf2f(o));
+        a.y[oi] = o;
+        const float f = bf2f(o);
+        ss = fmaf(f, f, ss);
+    }
+    ss = butterfly<64>(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int w = 0; w < 16; ++w) tot = tot + red[w];
+    const float rinv = 1.0f / sqrtf(tot / (float)a.N + a.post_eps);
+    for (int n = tid; n < a.N; n += 1024) {      // each thread re-reads exactly the y values it wrote
+        const size_t oi = (size_t)(b0 + row) * a.N + n;
+        a.post_out[oi] = f2bf((bf2f(a.y[oi]) * rinv) * bf2f(a.post_nw[n]));
+    }
+}
+
 template <int MT, int KS, bool SM>
 static void launch_gemm_splitk_t(hipStream_t st, const LinArgs& a, float* ws, int b0, int bt, int rs, dim3 grid) {
     const size_t smem = (size_t)(16 * MT + 64) * (KS + 8) * 2;
@@ -852,9 +886,23 @@ static int launch_gemm_splitk(hipStream_t st, const LinArgs& a, float* ws, size_
         else if (mt == 4) launch_gemm_splitk_t<4, 256, SM>(st, a, ws, b0, bt, rs, grid);
         else if (mt == 5) launch_gemm_splitk_t<5, 256, SM>(st, a, ws, b0, bt, rs, grid);
         else launch_gemm_splitk_t<8, 256, SM>(st, a, ws, b0, bt, rs, grid);
-        hipLaunchKernelGGL((k_splitk_reduce<EPI>), dim3((bt * a.N + 255) / 256), dim3(256), 0, st, ws, S, rs, a, b0, bt);
+        if (EPI == EPI_STORE && a.post_nw && a.post_out)
+            hipLaunchKernelGGL(k_splitk_reduce_rows, dim3(bt), dim3(1024), 0, st, ws, S, rs, a, b0);
+        else
+            hipLaunchKernelGGL((k_splitk_reduce<EPI>), dim3((bt * a.N + 255) / 256), dim3(256), 0, st, ws, S, rs, a, b0, bt);
     }
     return VOX_OK;
+}
+
+static int rows_gemm_min() {
+    static int rows_min = -1;   // development knob: smallest row count routed to the split-K GEMM
+    if (rows_min < 0) { const char* e = getenv("VOX_ROWS_MIN"); rows_min = e ? atoi(e) : 17; }
+    return rows_min;
+}
+// true when this call takes the 17+ rows split-K path (the only one that honours post_norm_* / x_prenormed)
+bool vox_linear_is_rows_gemm(const LinearCall& c) {
+    return c.B >= rows_gemm_min() && !c.fixed_order && c.K % 32 == 0 && c.splitk_ws != nullptr && !c.x_out &&
+           (c.pro == PRO_COPY || (c.pro == PRO_RMSNORM && (c.x_prenormed || (c.norm_scratch && !c.x_rows && (c.x_stride == 0 || c.x_stride == c.K)))));
 }
 
 int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
@@ -867,6 +915,7 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     a.x_out_stride = c.x_out_stride ? c.x_out_stride : c.K; a.eps = c.eps; a.B = c.B; a.N = c.N; a.K = c.K; a.Hq = c.Hq; a.D = c.D;
     a.max_chunks = c.max_chunks;
     a.keep = c.keep_weights;
+    a.post_nw = (const bf16_t*)c.post_norm_w; a.post_out = (bf16_t*)c.post_norm_out; a.post_eps = c.eps;
     const int ncu = ctx->n_cu;
     static int dev = -1;   // development-only timing experiments (results are wrong when set)
     if (dev < 0) { const char* e = getenv("VOX_DEV"); dev = e ? atoi(e) : 0; }
@@ -875,12 +924,12 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     if (dev & 2) a.residual = nullptr;
     if ((dev & 4) && epi == EPI_SILU_MUL) epi = EPI_STORE;
     if (dev & 8) a.bias = nullptr;
-    static int rows_min = -1;   // development knob: smallest row count routed to the prefill GEMMs
-    if (rows_min < 0) { const char* e = getenv("VOX_ROWS_MIN"); rows_min = e ? atoi(e) : 17; }
-    if (c.B >= rows_min && !c.fixed_order && c.K % 32 == 0 && c.splitk_ws &&
-        (pro == PRO_COPY || (pro == PRO_RMSNORM && c.norm_scratch && !a.x_rows && !a.x_out && a.x_stride == c.K))) {
+    if (vox_linear_is_rows_gemm(c) && (pro == PRO_COPY || pro == PRO_RMSNORM)) {
         // 17+ rows: normalise once (not in every block), then the split-K MFMA GEMM
-        if (pro == PRO_RMSNORM) {
+        if (pro == PRO_RMSNORM && c.x_prenormed) {
+            a.x = (const bf16_t*)c.x_prenormed;       // the producing linear already wrote norm(x) (post_norm_out)
+            a.x_stride = c.K;
+        } else if (pro == PRO_RMSNORM) {
             if (a.x_rows) return vox_fail(VOX_ERR_INVALID, "linear: row indirection with a norm prologue at > 32 rows");
             hipLaunchKernelGGL(k_rmsnorm, dim3((c.B + 3) / 4), dim3(256), 0, st, a.x, a.nw, (bf16_t*)c.norm_scratch, c.B, c.K, c.eps);
             if (a.x_out) return vox_fail(VOX_ERR_INVALID, "linear: x_out with a norm prologue at > 32 rows");

@@ -50,6 +50,11 @@ struct LinearCall {
     int B = 0, N = 0, K = 0, Hq = 0, D = 0, max_chunks = 0;
     void* splitk_ws = nullptr;      // fp32 workspace of the > 32-row split-K GEMM: >= ceil(K/512) * 128 * Ntot * 4 bytes
     size_t splitk_ws_bytes = 0;
+    // 17+ rows path only: the epilogue also writes RMSNorm(y) * post_norm_w (eps = this call's eps) to post_norm_out, and a
+    // later call passes that buffer as x_prenormed instead of re-normalising
+    const void* post_norm_w = nullptr;
+    void* post_norm_out = nullptr;
+    const void* x_prenormed = nullptr;
     void* norm_scratch = nullptr;   // [B,K] bf16: lets > 32-row calls with a norm prologue normalise once up front
     int keep_weights = 0;   // weights are re-read within the frame (depth loop): do not stream them past the caches
     int pro = 0, epi = 0;  // PRO_* / EPI_*
@@ -57,6 +62,7 @@ struct LinearCall {
 };
 enum { VOX_PRO_COPY = 0, VOX_PRO_RMSNORM = 1, VOX_PRO_ATTN = 2 };
 enum { VOX_EPI_STORE = 0, VOX_EPI_SILU = 1, VOX_EPI_SILU_MUL = 2 };
+bool vox_linear_is_rows_gemm(const LinearCall& c);
 int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c);
 int vox_launch_rmsnorm(hipStream_t st, const void* x, const void* w, void* y, int rows, int H, float eps);
 
