@@ -245,3 +245,73 @@ def test_full_vocab_sampler_bit_exact(dev, B, V, k, p, mp, T_):
     # the histogram scratch must be left all-zero: a repeated call agrees
     N.check(N.lib().vox_sample(N.ctx(), N.stream(), N.ptr(lt), B, V, cfg, 1234, 9, N.ptr(out)))
     assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_stack_forward_abi_bit_exact(dev):
+    """vox_stack_create / vox_stack_forward (the decoder-stack entry point of the C ABI) vs the oracle's RefStack:
+    a 7-token ragged prefill, then decode rows with the decode hints (per-row page table), llama-3.1 RoPE, QKV bias."""
+    import ctypes
+    from oracle import qwen3_ref as QR
+    from vox_serve_amd import _native as N
+    from vox_serve_amd.engine import StackCfg, _stack_config, rope_table
+    L, ctx = N.lib(), N.ctx()
+    oc = QR.StackCfg(256, 2, 4, 2, 64, 512, eps=1e-5, rope_theta=5e5, rope_scale=32.0, rope_llama31=(1.0, 4.0, 64), qk_norm=False, qkv_bias=True)
+    rng = np.random.default_rng(12)
+    w = lambda *s_: vr.f2bf(rng.standard_normal(s_, dtype=np.float32) * np.float32(0.08))
+    W = {"m.norm.weight": vr.f2bf(np.ones(256, np.float32))}
+    for i in range(2):
+        p = f"m.layers.{i}."
+        for n_, rows in (("q", 4), ("k", 2), ("v", 2)):
+            W[p + f"self_attn.{n_}_proj.weight"], W[p + f"self_attn.{n_}_proj.bias"] = w(rows * 64, 256), w(rows * 64)
+        W[p + "self_attn.o_proj.weight"] = w(256, 256)
+        W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"], W[p + "mlp.down_proj.weight"] = w(512, 256), w(512, 256), w(256, 512)
+        W[p + "input_layernorm.weight"] = vr.f2bf(1 + 0.1 * rng.standard_normal(256).astype(np.float32))
+        W[p + "post_attention_layernorm.weight"] = vr.f2bf(1 + 0.1 * rng.standard_normal(256).astype(np.float32))
+    ref = QR.RefStack(oc, W, "m", 128)
+    page, P = 8, 6
+    kv_ref = [np.zeros((P, 2, page, 2, 64), np.uint16) for _ in range(2)]
+    ec = StackCfg(256, 2, 4, 2, 64, 512, 1e-5, 5e5, 32.0, None, False, (1.0, 4.0, 64), False, True)
+    keep, arr = [], (N.LayerWeights * 2)()
+    for i in range(2):
+        p = f"m.layers.{i}."
+        ts = dict(wqkv=np.concatenate([W[p + f"self_attn.{n_}_proj.weight"] for n_ in "qkv"]),
+                  bqkv=np.concatenate([W[p + f"self_attn.{n_}_proj.bias"] for n_ in "qkv"]), wo=W[p + "self_attn.o_proj.weight"],
+                  wgate=W[p + "mlp.gate_proj.weight"], wup=W[p + "mlp.up_proj.weight"], wdown=W[p + "mlp.down_proj.weight"],
+                  ln1=W[p + "input_layernorm.weight"], ln2=W[p + "post_attention_layernorm.weight"])
+        for k, v in ts.items():
+            t = T(v, dev)
+            keep.append(t)
+            setattr(arr[i], k, t.data_ptr())
+    fn, rope = T(W["m.norm.weight"], dev), rope_table(128, ec, dev)
+    sc = _stack_config(ec, page, 16, 64)
+    h = ctypes.c_void_p()
+    N.check(L.vox_stack_create(ctx, ctypes.byref(sc), arr, fn.data_ptr(), rope.data_ptr(), 128, ctypes.byref(h)))
+    kv = torch.zeros(2, P, 2, page, 2, 64, dtype=torch.bfloat16, device=dev)
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    # prefill: request 0 = 4 tokens on pages [3,...], request 1 = 3 tokens on page [1]
+    x0 = w(7, 256)
+    pos, q_req, kvl = [0, 1, 2, 3, 0, 1, 2], [0, 0, 0, 0, 1, 1, 1], [1, 2, 3, 4, 1, 2, 3]
+    pg, sl, indptr, indices = [3, 3, 3, 3, 1, 1, 1], [0, 1, 2, 3, 0, 1, 2], [0, 1, 2], [3, 1]
+    want = ref.forward(x0.copy(), np.array(pos, np.int32), kv_ref, np.array(q_req, np.int32), np.array(kvl, np.int32),
+                       np.array(indptr, np.int32), np.array(indices, np.int32), np.array(pg, np.int32), np.array(sl, np.int32))
+    x, y = T(x0, dev), torch.empty(7, 256, dtype=torch.bfloat16, device=dev)
+    tens = [i32(v) for v in (pos, q_req, kvl, pg, sl, indptr, indices)]
+    rows = N.Rows(*[t.data_ptr() for t in tens], 7, 4, None, 0, 0, -1, 0)
+    N.check(L.vox_stack_forward(h, N.stream(), x.data_ptr(), y.data_ptr(), kv.data_ptr(), kv[0].numel(), ctypes.byref(rows)))
+    torch.cuda.synchronize()
+    assert np.array_equal(Bits(y), want)
+    # decode: one new token per request, per-row page table hint -> fused (norm + RoPE + append in-kernel) path
+    x1 = w(2, 256)
+    pos, q_req, kvl, pg, sl = [5, 4], [0, 1], [5, 4], [3, 1], [4, 3]      # positions follow quirk Q1 (n + 1)
+    want = ref.forward(x1.copy(), np.array(pos, np.int32), kv_ref, np.array(q_req, np.int32), np.array(kvl, np.int32),
+                       np.array(indptr, np.int32), np.array(indices, np.int32), np.array(pg, np.int32), np.array(sl, np.int32))
+    x, y = T(x1, dev), torch.empty(2, 256, dtype=torch.bfloat16, device=dev)
+    tens = [i32(v) for v in (pos, q_req, kvl, pg, sl, indptr, indices)]
+    ptab = i32([[3, 0], [1, 0]])
+    rows = N.Rows(*[t.data_ptr() for t in tens], 2, 5, ptab.data_ptr(), 2, 0, -1, 0)
+    N.check(L.vox_stack_forward(h, N.stream(), x.data_ptr(), y.data_ptr(), kv.data_ptr(), kv[0].numel(), ctypes.byref(rows)))
+    torch.cuda.synchronize()
+    assert np.array_equal(Bits(y), want)
+    for l in range(2):
+        assert np.array_equal(vr.from_torch(kv[l])[[1, 3]], kv_ref[l][[1, 3]]), l
+    L.vox_stack_destroy(h)

@@ -217,13 +217,18 @@ struct vox_stack {
 
 // decode_rows: every row is the newest token of a distinct request (its K/V are not read by any other row), so the
 // head norm / RoPE / KV append fuse into the attention kernel; otherwise (prefill) a separate pass appends first.
-// development-only timing ablation (VOX_ABLATE bitmask; results are wrong when set): 1 attention, 2 depth loop,
-// 4 talker layers, 8 samplers, 16 qkv, 32 o_proj, 64 gate/up, 128 down
+// Timing ablation for development builds only (-DVOX_DEV_KNOBS: VOX_ABLATE bitmask skips parts of the frame, results are
+// wrong when set): 1 attention, 2 depth loop, 4 talker layers, 8 samplers, 16 qkv, 32 o_proj, 64 gate/up, 128 down,
+// 256 / 512 older attention variants.  The shipped library compiles this to a constant 0.
+#ifdef VOX_DEV_KNOBS
 static int ablate() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("VOX_ABLATE"); v = e ? atoi(e) : 0; }
     return v;
 }
+#else
+static constexpr int ablate() { return 0; }
+#endif
 
 static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t kv_stride, const vox_rows* r,
                         bool decode_rows = false, int fixed_order = 0) {
@@ -505,7 +510,7 @@ int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_
     if (s != VOX_OK) { delete m; return s; }
     s = vox_stack_create(ctx, &dc, w->depth_layers, w->depth_norm, w->depth_rope, w->depth_rope_max_pos, &m->depth);
     if (s != VOX_OK) { vox_stack_destroy(m->talker); delete m; return s; }
-    m->depth->keep_weights = getenv("VOX_NO_KEEP") ? 0 : 1;   // 0.16 GB re-read 15 times per frame: Infinity-Cache resident
+    m->depth->keep_weights = 1;   // 0.16 GB re-read 15 times per frame: Infinity-Cache resident
     const size_t R = tc.max_rows;
     m->dkv_stride = (int64_t)B * 2 * G * dc.kv_heads * dc.head_dim;
     bool ok = hipMalloc(&m->te, R * cfg->text_hidden * 2) == hipSuccess &&

@@ -895,9 +895,13 @@ static int launch_gemm_splitk(hipStream_t st, const LinArgs& a, float* ws, size_
 }
 
 static int rows_gemm_min() {
-    static int rows_min = -1;   // development knob: smallest row count routed to the split-K GEMM
+#ifdef VOX_DEV_KNOBS
+    static int rows_min = -1;   // development builds: smallest row count routed to the split-K GEMM
     if (rows_min < 0) { const char* e = getenv("VOX_ROWS_MIN"); rows_min = e ? atoi(e) : 17; }
     return rows_min;
+#else
+    return 17;                  // 9..16 rows: one 16-row MFMA tile per block (k_linear_mfma) is faster (measured)
+#endif
 }
 // true when this call takes the 17+ rows split-K path (the only one that honours post_norm_* / x_prenormed)
 bool vox_linear_is_rows_gemm(const LinearCall& c) {
@@ -917,13 +921,15 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     a.keep = c.keep_weights;
     a.post_nw = (const bf16_t*)c.post_norm_w; a.post_out = (bf16_t*)c.post_norm_out; a.post_eps = c.eps;
     const int ncu = ctx->n_cu;
-    static int dev = -1;   // development-only timing experiments (results are wrong when set)
-    if (dev < 0) { const char* e = getenv("VOX_DEV"); dev = e ? atoi(e) : 0; }
     int pro = c.pro, epi = c.epi;
+#ifdef VOX_DEV_KNOBS        // development builds: strip features to time them (results are wrong when set)
+    static int dev = -1;
+    if (dev < 0) { const char* e = getenv("VOX_DEV"); dev = e ? atoi(e) : 0; }
     if ((dev & 1) && pro == PRO_RMSNORM) pro = PRO_COPY;
     if (dev & 2) a.residual = nullptr;
     if ((dev & 4) && epi == EPI_SILU_MUL) epi = EPI_STORE;
     if (dev & 8) a.bias = nullptr;
+#endif
     if (vox_linear_is_rows_gemm(c) && (pro == PRO_COPY || pro == PRO_RMSNORM)) {
         // 17+ rows: normalise once (not in every block), then the split-K MFMA GEMM
         if (pro == PRO_RMSNORM && c.x_prenormed) {
