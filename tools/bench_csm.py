@@ -1,0 +1,77 @@
+"""BASELINE config 3 on one MI355X: CSM-1B (random-init weights of the named architecture) + Mimi, B concurrent requests.
+One step = one audio frame for the batch: backbone decode + codebook-0 sampling + 31 depth steps (one hipGraph), host plan
+upload + token read-back, and every 10th step one stateless Mimi chunk (10 frames -> 19200 samples per request) with
+PCM16 packing.  Development measurement (bench.py is the contract); prints one JSON line."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from vox_serve_amd.engine import CSMCfg, CSMEngine
+from vox_serve_amd.synth import synth_csm_weights
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--warmup", type=int, default=20)
+args = ap.parse_args()
+B, dev = args.batch, torch.device("cuda")
+cfg = CSMCfg()
+eng = CSMEngine(cfg, synth_csm_weights(cfg, dev), max_batch=B, page_size=128, max_pages=4 * B + 1, max_seq_len=2304, max_prefill_rows=128)
+eng.keep_hidden = False
+# Mimi with random-init weights of the reference configuration
+from vox_serve_amd.synth import synth_mimi_weights
+from vox_serve_amd.tokenizer.mimi import MimiConfig, MimiDecoder
+mimi = MimiDecoder(synth_mimi_weights(MimiConfig(), seed=0), MimiConfig(), device=dev, max_batch=B, max_frames=10)
+C1, ps, n0 = cfg.n_codebooks + 1, 128, 64
+rng = np.random.default_rng(1)
+pages = [[b * 4 + j for j in range(4)] for b in range(B)]
+sc = eng.sampling_cfg(greedy=True)
+for b in range(B):                       # one prefill per request: 64 text rows
+    ids = np.zeros((n0, C1), np.int32); ids[:, -1] = rng.integers(0, 128000, n0)
+    masks = np.zeros((n0, C1), np.uint8); masks[:, -1] = 1
+    eng.row_ids[:n0], eng.row_masks[:n0] = torch.from_numpy(ids).to(dev), torch.from_numpy(masks).to(dev)
+    eng.upload_plan(pos=np.arange(n0), kvlen=np.arange(1, n0 + 1), page=[pages[b][0]] * n0, slot=np.arange(n0), q_req=np.zeros(n0),
+                    last_rows=[n0 - 1], indptr=[0, 1], indices=pages[b][:1])
+    eng.prefill(n0, 1, n0, sc, feedback=True)
+    st = (eng.input_ids[0].clone(), eng.input_masks[0].clone())
+    if b == 0:
+        states = []
+    states.append(st)
+for b, (i_, m_) in enumerate(states):
+    eng.input_ids[b], eng.input_masks[b] = i_, m_
+kv, pos = [n0] * B, [n0 + 1] * B
+ring = torch.zeros(B, 10, C1, dtype=torch.int32, device=dev)
+ev = []
+
+def step(i, timed):
+    global kv, pos
+    kv = [k + 1 for k in kv]
+    npg = [(k + ps - 1) // ps for k in kv]
+    indptr = np.concatenate([[0], np.cumsum(npg)])
+    eng.upload_plan(pos=pos, kvlen=kv, page=[pages[b][npg[b] - 1] for b in range(B)], slot=[(k - 1) % ps for k in kv],
+                    indptr=indptr, indices=sum([pages[b][:npg[b]] for b in range(B)], []))
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(eng.stream)
+    eng.frame(B, max(kv), sc, feedback=True)
+    if timed:
+        e1.record(eng.stream); ev.append((e0, e1))
+    ring[:, i % 10] = eng.out_ids[:B]
+    ids = eng.out_ids[:B].cpu()
+    pos = [p + 1 for p in pos]
+    if i % 10 == 9:
+        wav = mimi.decode(ring, code_layout="BTQ")
+        return (wav[:, 0] * 32767).to(torch.int16).cpu().numpy()
+
+for i in range(args.warmup):
+    step(i, False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(args.steps):
+    step(i, True)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+t1 = time.perf_counter(); mimi.decode(ring, code_layout="BTQ"); torch.cuda.synchronize(); t_codec = time.perf_counter() - t1
+frame_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+print(json.dumps({"workload": f"CSM-1B bf16 + Mimi, batch={B}, greedy, 64-token prompt, detokenize_interval 10",
+                  "audio_samples_per_s": B * 1920 * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                  "lm_frame_graph_ms": frame_ms, "mimi_chunk_ms": t_codec * 1e3, "realtime_factor_per_request": 1920 * args.steps / dt / 24000}))

@@ -164,3 +164,36 @@ def synth_csm_weights(c, device, seed=0, std=0.02):
     W["depth_decoder.model.inputs_embeds_projector.weight"] = w(d.hidden, b.hidden)
     W["depth_decoder.codebooks_head.weight"] = w(c.n_codebooks - 1, d.hidden, c.vocab)
     return W
+
+
+def synth_mimi_weights(cfg=None, seed=0):
+    """Random-init Mimi decoder weights (CPU fp32 tensors holding bf16-representable values): fan-in scaled so that the
+    activations stay O(1) through the SEANet stack; the last conv is scaled down so the waveform is O(0.1)."""
+    import math
+    from .tokenizer.mimi import MimiConfig, param_shapes
+    cfg = cfg or MimiConfig()
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    shapes = param_shapes(cfg)
+    last = max((k for k in shapes if k.startswith("decoder.model.") and k.endswith(".conv.conv.weight")), key=lambda k: int(k.split(".")[2]))
+    for k, s in shapes.items():
+        if k.endswith("cluster_usage"):
+            t = torch.rand(s, generator=g) * 3 + 0.5
+        elif k.endswith("embedding_sum"):
+            t = torch.randn(s, generator=g) * 2.0
+        elif k.endswith(".scale"):
+            t = torch.full(s, 0.1)
+        elif "norm" in k and k.endswith("weight"):
+            t = 1 + 0.1 * torch.randn(s, generator=g)
+        elif k.endswith("bias"):
+            t = 0.02 * torch.randn(s, generator=g)
+        elif "convtr" in k and k.startswith("decoder"):
+            t = torch.randn(s, generator=g) * math.sqrt(2.0 / (s[0] * 2))
+        elif k.startswith("upsample"):
+            t = 0.7 + 0.2 * torch.randn(s, generator=g)
+        else:
+            t = torch.randn(s, generator=g) * math.sqrt(1.5 / math.prod(s[1:]))
+        if k in (last, last.replace("weight", "bias")):
+            t = t * 0.01
+        W[k] = t.to(torch.bfloat16).to(torch.float32)
+    return W

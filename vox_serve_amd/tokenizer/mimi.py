@@ -43,6 +43,37 @@ class MimiConfig:
         return int(math.prod(self.ratios)) * self.upsample_stride
 
 
+def param_shapes(c: MimiConfig) -> Dict[str, tuple]:
+    """decoder-side state_dict names -> shapes of the Mimi checkpoint (mimi.py:20-71, 2548-2699, 1841-1895, 719-872)"""
+    S = {}
+    for name, nq in (("rvq_first", 1), ("rvq_rest", c.n_q - 1)):
+        for i in range(nq):
+            p = f"quantizer.{name}.vq.layers.{i}._codebook."
+            S[p + "embedding_sum"], S[p + "cluster_usage"] = (c.bins, c.vq_dim), (c.bins,)
+        S[f"quantizer.{name}.output_proj.weight"] = (c.dim, c.vq_dim, 1)
+    S["upsample.convtr.convtr.convtr.weight"] = (c.dim, 1, 2 * c.upsample_stride)
+    for l in range(c.num_layers):
+        p = f"decoder_transformer.transformer.layers.{l}."
+        S[p + "self_attn.in_projs.0.weight"], S[p + "self_attn.out_projs.0.weight"] = (3 * c.dim, c.dim), (c.dim, c.dim)
+        for n in ("norm1", "norm2"):
+            S[p + n + ".weight"], S[p + n + ".bias"] = (c.dim,), (c.dim,)
+        S[p + "linear1.weight"], S[p + "linear2.weight"] = (c.ffn, c.dim), (c.dim, c.ffn)
+        S[p + "layer_scale_1.scale"], S[p + "layer_scale_2.scale"] = (c.dim,), (c.dim,)
+    ch = 2 ** len(c.ratios) * c.n_filters
+    S["decoder.model.0.conv.conv.weight"], S["decoder.model.0.conv.conv.bias"] = (ch, c.dim, c.kernel_size), (ch,)
+    idx = 1
+    for r in c.ratios:
+        S[f"decoder.model.{idx + 1}.convtr.convtr.weight"], S[f"decoder.model.{idx + 1}.convtr.convtr.bias"] = (ch, ch // 2, 2 * r), (ch // 2,)
+        hid = ch // 2 // c.compress
+        p = f"decoder.model.{idx + 2}.block."
+        S[p + "1.conv.conv.weight"], S[p + "1.conv.conv.bias"] = (hid, ch // 2, c.residual_kernel_size), (hid,)
+        S[p + "3.conv.conv.weight"], S[p + "3.conv.conv.bias"] = (ch // 2, hid, 1), (ch // 2,)
+        idx += 3
+        ch //= 2
+    S[f"decoder.model.{idx + 1}.conv.conv.weight"], S[f"decoder.model.{idx + 1}.conv.conv.bias"] = (1, ch, c.last_kernel_size), (1,)
+    return S
+
+
 class MimiLayerW(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "scale1", "scale2")] + \
                [("qkv", ConvW), ("o", ConvW), ("fc1", ConvW), ("fc2", ConvW)]
