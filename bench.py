@@ -8,7 +8,8 @@ named architecture, synthetic fixed-length prompts), speech-token decode + token
 A "step" is one audio frame (1920 samples at 24 kHz) for the whole batch of B concurrent requests: one hipGraph
 replay = talker decode step + codebook-0 sampling + the 15-step depth loop (+ feedback of the next inputs), the
 host-side plan upload and token read-back, and every 10th step one codec chunk (10 frames -> 19200 samples per
-request) with PCM16 packing and D2H.  value = audio samples/s over all ranks (weak scaling: B per GPU fixed).
+request) with PCM16 packing and D2H; the chunk runs on its own HIP stream concurrently with the next LM frames (the
+disaggregation scheduler's two pipelines on one GPU) and all audio is on the host before the clock stops.  value = audio samples/s over all ranks (weak scaling: B per GPU fixed).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -59,6 +60,9 @@ class Loop:
         self.samples = 0
         self.rng = np.random.default_rng(1)
         self.frame_ev = []
+        self.codec_stream = torch.cuda.Stream(device=dev)
+        self.pcm_host = torch.zeros(B, INTERVAL * 1920, dtype=torch.int16).pin_memory()
+        self.pending = None
 
     def start_requests(self):
         """Prefill every request (one per step, like the scheduler) -> first frame."""
@@ -88,7 +92,7 @@ class Loop:
         self.nframe = 1
         self.pos = [PROMPT_TOKENS + 1] * self.B              # quirk Q1: first decode position is n+1 (worker/base.py:299)
 
-    def step(self, timed_events=None):
+    def step(self, timed_events=None, wait_pcm=False):
         """One frame for the whole batch."""
         e, B, ps = self.eng, self.B, self.ps
         indptr, indices, page, slot = [0], [], [], []
@@ -113,10 +117,31 @@ class Loop:
         self.nframe += 1
         pcm = None
         if self.nframe % INTERVAL == 0:
-            wav, _ = self.codec.decode_chunk(self.tok_ring, self.cache, code_layout="BTQ")
-            pcm = (wav[:, 0] * 32767).to(torch.int16).cpu().numpy()      # worker/base.py:658-672
-            self.samples += pcm.size
+            # the codec chunk runs on its own HIP stream, concurrently with the following LM frames (the
+            # disaggregation scheduler's two pipelines on one GPU); its PCM is collected one chunk later, or at once
+            # when the caller waits for it (TTFA)
+            done = self.collect_pcm()
+            snap = self.tok_ring.clone()
+            self.codec_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.codec_stream):
+                wav, _ = self.codec.decode_chunk(snap, self.cache, code_layout="BTQ")
+                self.pcm_host.copy_((wav[:, 0] * 32767).to(torch.int16), non_blocking=True)      # worker/base.py:658-672
+                ev = torch.cuda.Event()
+                ev.record(self.codec_stream)
+            snap.record_stream(self.codec_stream)
+            self.pending = ev
+            pcm = self.collect_pcm() if wait_pcm else done
         return ids, pcm
+
+    def collect_pcm(self):
+        """PCM16 of the chunk in flight (blocks until its D2H copy has landed), or None."""
+        if self.pending is None:
+            return None
+        self.pending.synchronize()
+        self.pending = None
+        pcm = self.pcm_host.numpy().copy()
+        self.samples += pcm.size
+        return pcm
 
 
 def cpu_baseline(loop, budget_s=25.0):
@@ -208,7 +233,7 @@ def main():
                 solo.start_requests()
                 pcm = None
                 while pcm is None:
-                    _, pcm = solo.step()
+                    _, pcm = solo.step(wait_pcm=True)
                 ttfa.append((time.perf_counter() - t0) * 1e3)
                 solo.codec.release_cache(solo.cache)
 
@@ -225,6 +250,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loop.step(events)
+    loop.collect_pcm()                     # the last chunk's audio must be on the host inside the timed region
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
