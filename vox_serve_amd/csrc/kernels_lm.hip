@@ -894,6 +894,173 @@ static int launch_gemm_splitk(hipStream_t st, const LinArgs& a, float* ws, size_
     return VOX_OK;
 }
 
+// ================================================================================================
+// linear for 9..32 rows (batched decode): full-K bf16 MFMA GEMM, ONE launch per linear (no partial-sum workspace, no
+// reduce kernel): at these row counts a frame is a chain of ~1000 dependent launches, so the second launch of the
+// split-K pair costs as much as the GEMM itself.  A block owns 16 output columns (gate/up: 16 + 16) for all rows; its
+// 8 waves split K into 8 contiguous ranges of KSTEPS*32, every lane requests ALL its weight fragments (one 16-byte
+// load per k-step, straight into the B operand layout) before anything waits, activations follow in groups; partial
+// accumulators meet in LDS and are added in wave order; prologue RMSNorm (sum of squares over the block's own
+// operand registers) and the bias / residual / SiLU*up epilogue are fused.  bf16-rounding parity (MFMA order).
+// ================================================================================================
+template <int MT, int KSTEPS, int PRO, int EPI, bool ROWSPLIT>
+__global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
+    constexpr bool SM = (EPI == EPI_SILU_MUL);
+    constexpr int NB = SM ? 2 : 1;
+    constexpr int G = (PRO == PRO_RMSNORM) ? KSTEPS : (KSTEPS <= 8 ? KSTEPS : 4);   // activation k-steps per group
+    constexpr int NG = KSTEPS / G;
+    __shared__ f32x4_t red[8][NB][MT][64];
+    __shared__ float ssq[8][16 * MT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    // ROWSPLIT (MT == 1 launched for 17..32 rows when N/16 <= 128): two blocks per column tile, one per 16-row tile, ids 8
+    // apart so that they land on the same XCD and the second reader of the weight tile hits that XCD's L2.
+    int ctile = blockIdx.x, r0 = 0;
+    if (ROWSPLIT) {
+        ctile = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+        r0 = ((blockIdx.x >> 3) & 1) * 16;
+    }
+    const int n0 = ctile * 16;
+    const int kbase = wave * (KSTEPS * 32) + fk;
+    const int bt = a.B - r0;
+    uint4 wv[NB][KSTEPS];
+    {
+        const uint4* w0 = reinterpret_cast<const uint4*>(a.W + (size_t)(n0 + fr) * a.K + kbase);
+        const uint4* w1 = SM ? reinterpret_cast<const uint4*>(a.W2 + (size_t)(n0 + fr) * a.K + kbase) : nullptr;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            wv[0][s] = a.keep ? w0[s * 4] : ldg_nt(w0 + s * 4);
+            if (SM) wv[1][s] = a.keep ? w1[s * 4] : ldg_nt(w1 + s * 4);
+        }
+    }
+    const uint4* xr[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int row = m * 16 + fr;
+        xr[m] = x_row_ptr(a, r0 + (row < bt ? row : bt - 1)) + (kbase >> 3);
+    }
+    f32x4_t acc[NB][MT];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[nb][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    uint4 xa[NG > 1 ? 2 : 1][MT][G];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < G; ++s) xa[0][m][s] = xr[m][s * 4];
+    __builtin_amdgcn_sched_barrier(0);      // every load above is issued before anything below waits on one of them
+    uint4 gv[PRO == PRO_RMSNORM ? G : 1];
+    float rinv[MT];
+    if (PRO == PRO_RMSNORM) {
+        const uint4* nw = reinterpret_cast<const uint4*>(a.nw) + (kbase >> 3);
+#pragma unroll
+        for (int s = 0; s < G; ++s) gv[s] = nw[s * 4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float ss = 0.0f;
+#pragma unroll
+            for (int s = 0; s < G; ++s) ss = sq8(xa[0][m][s], ss);
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            if (lane < 16) ssq[wave][m * 16 + fr] = ss;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += ssq[w][m * 16 + fr];
+            rinv[m] = 1.0f / sqrtf(t / (float)a.K + a.eps);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int s = 0; s < G; ++s) xa[(g + 1) & 1][m][s] = xr[m][((g + 1) * G + s) * 4];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < G; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                uint4 ax = xa[g & 1][m][s];
+                if (PRO == PRO_RMSNORM) ax = norm_chunk(ax, gv[s], rinv[m]);   // normalised right before use: no second copy
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(ax), as_bf8(wv[nb][g * G + s]), acc[nb][m], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) red[wave][nb][m][lane] = acc[nb][m];
+    __syncthreads();
+    if (tid >= MT * 64) return;
+    const int m = tid >> 6;            // thread (m, lane) finishes D fragment m: column n0+fr, rows m*16 + (lane>>4)*4 + r
+    f32x4_t v = red[0][0][m][lane], u = SM ? red[0][NB - 1][m][lane] : v;
+#pragma unroll
+    for (int w = 1; w < 8; ++w) {
+        v += red[w][0][m][lane];
+        if (SM) u += red[w][NB - 1][m][lane];
+    }
+    const int n = n0 + fr;
+    const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = m * 16 + (lane >> 4) * 4 + r;
+        if (b >= bt) continue;
+        const size_t oi = (size_t)(r0 + b) * a.N + n;
+        bf16_t o;
+        if (SM) {
+            o = f2bf(bfround(silu_c(bfround(v[r]))) * bfround(u[r]));
+        } else {
+            float f = v[r];
+            if (a.bias) f = f + bv;
+            o = f2bf(f);
+            if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
+            if (a.residual) o = f2bf(bf2f(a.residual[oi]) + bf2f(o));
+        }
+        a.y[oi] = o;
+    }
+}
+
+static bool fullk_shape_ok(int B, int N, int K, int pro, int epi) {
+    if (B < 9 || B > 32 || N % 16 || K % 256) return false;
+    const int ks = K / 256;
+    if (pro == PRO_RMSNORM && (epi == EPI_STORE || epi == EPI_SILU_MUL)) return ks == 4 || ks == 8;
+    if (pro == PRO_COPY && epi == EPI_STORE) return ks == 4 || ks == 8 || ks == 12 || ks == 24 || ks == 32;
+    return false;
+}
+template <int MT, int KSTEPS, int PRO, int EPI>
+static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a) {
+    if constexpr (MT == 2 && PRO == PRO_COPY) {
+        // few column tiles: per-CU load rate is the limit, so use twice the CUs (two 16-row blocks per column tile)
+        if (a.N / 16 <= 128 && (a.N / 16) % 8 == 0) {
+            hipLaunchKernelGGL((k_gemm_fullk<1, KSTEPS, PRO, EPI, true>), dim3(a.N / 8), dim3(512), 0, st, a);
+            return VOX_OK;
+        }
+    }
+    hipLaunchKernelGGL((k_gemm_fullk<MT, KSTEPS, PRO, EPI, false>), dim3(a.N / 16), dim3(512), 0, st, a);
+    return VOX_OK;
+}
+template <int PRO, int EPI>
+static int launch_gemm_fullk(hipStream_t st, const LinArgs& a) {
+    const int ks = a.K / 256;
+#define VOX_FK(KS) if (ks == KS) return a.B <= 16 ? launch_gemm_fullk_t<1, KS, PRO, EPI>(st, a) : launch_gemm_fullk_t<2, KS, PRO, EPI>(st, a);
+    VOX_FK(4) VOX_FK(8)
+    if constexpr (PRO == PRO_COPY) { VOX_FK(12) VOX_FK(24) VOX_FK(32) }
+#undef VOX_FK
+    return vox_fail(VOX_ERR_INVALID, "linear(full-K): unsupported K");
+}
+// true when this call takes the one-launch full-K path (9..32 rows, K a supported multiple of 256)
+static bool linear_is_fullk(const LinearCall& c) {
+    return !c.fixed_order && !c.x_out && fullk_shape_ok(c.B, c.N, c.K, c.pro, c.epi);
+}
+
 static int rows_gemm_min() {
 #ifdef VOX_DEV_KNOBS
     static int rows_min = -1;   // development builds: smallest row count routed to the split-K GEMM
@@ -905,7 +1072,7 @@ static int rows_gemm_min() {
 }
 // true when this call takes the 17+ rows split-K path (the only one that honours post_norm_* / x_prenormed)
 bool vox_linear_is_rows_gemm(const LinearCall& c) {
-    return c.B >= rows_gemm_min() && !c.fixed_order && c.K % 32 == 0 && c.splitk_ws != nullptr && !c.x_out &&
+    return !linear_is_fullk(c) && c.B >= rows_gemm_min() && !c.fixed_order && c.K % 32 == 0 && c.splitk_ws != nullptr && !c.x_out &&
            (c.pro == PRO_COPY || (c.pro == PRO_RMSNORM && (c.x_prenormed || (c.norm_scratch && !c.x_rows && (c.x_stride == 0 || c.x_stride == c.K)))));
 }
 
@@ -930,6 +1097,11 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     if ((dev & 4) && epi == EPI_SILU_MUL) epi = EPI_STORE;
     if (dev & 8) a.bias = nullptr;
 #endif
+    if (linear_is_fullk(c)) {
+        if (pro == PRO_RMSNORM && epi == EPI_STORE) return launch_gemm_fullk<PRO_RMSNORM, EPI_STORE>(st, a);
+        if (pro == PRO_RMSNORM && epi == EPI_SILU_MUL) return launch_gemm_fullk<PRO_RMSNORM, EPI_SILU_MUL>(st, a);
+        if (pro == PRO_COPY && epi == EPI_STORE) return launch_gemm_fullk<PRO_COPY, EPI_STORE>(st, a);
+    }
     if (vox_linear_is_rows_gemm(c) && (pro == PRO_COPY || pro == PRO_RMSNORM)) {
         // 17+ rows: normalise once (not in every block), then the split-K MFMA GEMM
         if (pro == PRO_RMSNORM && c.x_prenormed) {
