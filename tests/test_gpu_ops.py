@@ -319,55 +319,80 @@ def test_stack_forward_abi_bit_exact(dev):
 
 @pytest.mark.parametrize("n_rows", [12, 16, 24, 32, 48])
 def test_stack_forward_batched_rows_paths(dev, n_rows):
-    """9..32 rows take the one-launch full-K MFMA GEMM (norm prologue, SiLU*up / residual epilogues), 33+ the split-K
-    pair: one decoder layer at depth-transformer widths vs the oracle's RefStack.  MFMA accumulation order => the bar
-    is bf16-rounding parity (relative RMS <= 1 %, >= 98 % of elements within 4 bf16 ulp), not bit-exactness."""
+    """9..32 rows take the one-launch full-K MFMA GEMM (norm prologue, SiLU*up / residual epilogues, fragment-major
+    weights and activation hand-offs), 33+ the split-K pair: two decoder layers at depth-transformer widths vs the oracle's
+    RefStack, through the three attention routes that feed o_proj (single-chunk prefill rows; decode rows at a 41-token
+    context = chunked + merge; decode rows on a <= 16-token stack = one-wave short attention).  MFMA accumulation order =>
+    the bar is bf16-rounding parity (relative RMS <= 1 %, >= 98 % of elements within 4 bf16 ulp), not bit-exactness."""
     import ctypes
     from oracle import qwen3_ref as QR
     from vox_serve_amd import _native as N
     from vox_serve_amd.engine import StackCfg, _stack_config, rope_table
     L, ctx = N.lib(), N.ctx()
-    H, heads, kvh, D, F = 1024, 8, 2, 128, 3072
-    oc = QR.StackCfg(H, 1, heads, kvh, D, F, eps=1e-6, rope_theta=1e6, qk_norm=True, qkv_bias=False)
+    H, heads, kvh, D, F, NL = 1024, 8, 4, 128, 3072, 2
+    oc = QR.StackCfg(H, NL, heads, kvh, D, F, eps=1e-6, rope_theta=1e6, qk_norm=True, qkv_bias=False)
     rng = np.random.default_rng(n_rows)
     w = lambda *s_, sd=0.03: vr.f2bf(rng.standard_normal(s_, dtype=np.float32) * np.float32(sd))
     g = lambda n: vr.f2bf(1 + 0.1 * rng.standard_normal(n).astype(np.float32))
-    p = "m.layers.0."
-    W = {"m.norm.weight": g(H), p + "self_attn.q_proj.weight": w(heads * D, H), p + "self_attn.k_proj.weight": w(kvh * D, H),
-         p + "self_attn.v_proj.weight": w(kvh * D, H), p + "self_attn.o_proj.weight": w(H, heads * D),
-         p + "self_attn.q_norm.weight": g(D), p + "self_attn.k_norm.weight": g(D),
-         p + "mlp.gate_proj.weight": w(F, H), p + "mlp.up_proj.weight": w(F, H), p + "mlp.down_proj.weight": w(H, F),
-         p + "input_layernorm.weight": g(H), p + "post_attention_layernorm.weight": g(H)}
+    W = {"m.norm.weight": g(H)}
+    for l in range(NL):
+        p = f"m.layers.{l}."
+        W.update({p + "self_attn.q_proj.weight": w(heads * D, H), p + "self_attn.k_proj.weight": w(kvh * D, H),
+                  p + "self_attn.v_proj.weight": w(kvh * D, H), p + "self_attn.o_proj.weight": w(H, heads * D),
+                  p + "self_attn.q_norm.weight": g(D), p + "self_attn.k_norm.weight": g(D),
+                  p + "mlp.gate_proj.weight": w(F, H), p + "mlp.up_proj.weight": w(F, H), p + "mlp.down_proj.weight": w(H, F),
+                  p + "input_layernorm.weight": g(H), p + "post_attention_layernorm.weight": g(H)})
     ref = QR.RefStack(oc, W, "m", 64)
-    page = 8
-    kv_ref = [np.zeros((n_rows, 2, page, kvh, D), np.uint16)]
-    ec = StackCfg(H, 1, heads, kvh, D, F, 1e-6, 1e6, 1.0, None, False, None, True, False)
-    arr, keep = (N.LayerWeights * 1)(), []
-    ts = dict(wqkv=np.concatenate([W[p + f"self_attn.{n_}_proj.weight"] for n_ in "qkv"]), wo=W[p + "self_attn.o_proj.weight"],
-              wgate=W[p + "mlp.gate_proj.weight"], wup=W[p + "mlp.up_proj.weight"], wdown=W[p + "mlp.down_proj.weight"],
-              ln1=W[p + "input_layernorm.weight"], ln2=W[p + "post_attention_layernorm.weight"],
-              qnorm=W[p + "self_attn.q_norm.weight"], knorm=W[p + "self_attn.k_norm.weight"])
-    for k, v in ts.items():
-        t = T(v, dev)
-        keep.append(t)
-        setattr(arr[0], k, t.data_ptr())
+    page, ppr = 8, 6                                       # 6 pages of 8 slots per request
+    ec = StackCfg(H, NL, heads, kvh, D, F, 1e-6, 1e6, 1.0, None, False, None, True, False)
+    arr, keep = (N.LayerWeights * NL)(), []
+    for l in range(NL):
+        p = f"m.layers.{l}."
+        ts = dict(wqkv=np.concatenate([W[p + f"self_attn.{n_}_proj.weight"] for n_ in "qkv"]), wo=W[p + "self_attn.o_proj.weight"],
+                  wgate=W[p + "mlp.gate_proj.weight"], wup=W[p + "mlp.up_proj.weight"], wdown=W[p + "mlp.down_proj.weight"],
+                  ln1=W[p + "input_layernorm.weight"], ln2=W[p + "post_attention_layernorm.weight"],
+                  qnorm=W[p + "self_attn.q_norm.weight"], knorm=W[p + "self_attn.k_norm.weight"])
+        for k, v in ts.items():
+            t = T(v, dev)
+            keep.append(t)
+            setattr(arr[l], k, t.data_ptr())
     fn, rope = T(W["m.norm.weight"], dev), rope_table(64, ec, dev)
-    sc = _stack_config(ec, page, 64, 16)
-    h = ctypes.c_void_p()
-    N.check(L.vox_stack_create(ctx, ctypes.byref(sc), arr, fn.data_ptr(), rope.data_ptr(), 64, ctypes.byref(h)))
-    kv = torch.zeros(1, n_rows, 2, page, kvh, D, dtype=torch.bfloat16, device=dev)
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
-    x0 = w(n_rows, H, sd=1.0)
-    pos, q_req, kvl = [3] * n_rows, list(range(n_rows)), [1] * n_rows        # one single-token request per row
-    pg, sl, indptr, indices = list(range(n_rows)), [0] * n_rows, list(range(n_rows + 1)), list(range(n_rows))
     A = lambda v: np.array(v, np.int32)
-    want = ref.forward(x0.copy(), A(pos), kv_ref, A(q_req), A(kvl), A(indptr), A(indices), A(pg), A(sl))
-    x, y = T(x0, dev), torch.empty(n_rows, H, dtype=torch.bfloat16, device=dev)
-    tens = [i32(v) for v in (pos, q_req, kvl, pg, sl, indptr, indices)]
-    rows = N.Rows(*[t.data_ptr() for t in tens], n_rows, 1, None, 0, 0, -1, 0)
-    N.check(L.vox_stack_forward(h, N.stream(), x.data_ptr(), y.data_ptr(), kv.data_ptr(), kv[0].numel(), ctypes.byref(rows)))
-    torch.cuda.synchronize()
-    got, exp = vr.bf2f(Bits(y)).astype(np.float64), vr.bf2f(want).astype(np.float64)
-    assert np.sqrt(((got - exp) ** 2).mean() / (exp ** 2).mean()) <= 1e-2
-    assert bf16_close(Bits(y), want, ulps=4, atol=2e-2).mean() >= 0.98
-    L.vox_stack_destroy(h)
+    P = n_rows * ppr
+
+    def check(max_kvlen, kv_tokens, hints):
+        """every row = the newest token of its own request, which already holds kv_tokens tokens of random K/V"""
+        sc = _stack_config(ec, page, 64, max_kvlen)
+        h = ctypes.c_void_p()
+        N.check(L.vox_stack_create(ctx, ctypes.byref(sc), arr, fn.data_ptr(), rope.data_ptr(), 64, ctypes.byref(h)))
+        kv_ref = [np.zeros((P, 2, page, kvh, D), np.uint16) for _ in range(NL)]
+        for l in range(NL):
+            for r in range(n_rows):
+                for t in range(kv_tokens):
+                    kv_ref[l][r * ppr + t // page, :, t % page] = w(2, kvh, D, sd=0.5)
+        kv = torch.stack([T(k, dev) for k in kv_ref])
+        x0 = w(n_rows, H, sd=1.0)
+        n_new = kv_tokens + 1
+        pos, q_req, kvl = [n_new] * n_rows, list(range(n_rows)), [n_new] * n_rows
+        pg, sl = [r * ppr + kv_tokens // page for r in range(n_rows)], [kv_tokens % page] * n_rows
+        npg = kv_tokens // page + 1
+        indptr, indices = [r * npg for r in range(n_rows + 1)], [r * ppr + j for r in range(n_rows) for j in range(npg)]
+        want = ref.forward(x0.copy(), A(pos), kv_ref, A(q_req), A(kvl), A(indptr), A(indices), A(pg), A(sl))
+        x, y = T(x0, dev), torch.empty(n_rows, H, dtype=torch.bfloat16, device=dev)
+        tens = [i32(v) for v in (pos, q_req, kvl, pg, sl, indptr, indices)]
+        ptab = i32([[r * ppr + j for j in range(ppr)] for r in range(n_rows)])
+        rows = N.Rows(*[t.data_ptr() for t in tens], n_rows, n_new, ptab.data_ptr() if hints else None, ppr if hints else 0, 0, -1, 0)
+        N.check(L.vox_stack_forward(h, N.stream(), x.data_ptr(), y.data_ptr(), kv.data_ptr(), kv[0].numel(), ctypes.byref(rows)))
+        torch.cuda.synchronize()
+        got, exp = vr.bf2f(Bits(y)).astype(np.float64), vr.bf2f(want).astype(np.float64)
+        assert np.sqrt(((got - exp) ** 2).mean() / (exp ** 2).mean()) <= 1e-2, (max_kvlen, kv_tokens, hints)
+        assert bf16_close(Bits(y), want, ulps=4, atol=2e-2).mean() >= 0.98, (max_kvlen, kv_tokens, hints)
+        for l in range(NL):     # the new token's K/V landed where the oracle put them (bf16-rounding parity: their inputs went through the GEMMs)
+            gk, ek = vr.bf2f(vr.from_torch(kv[l])[pg, :, sl]).astype(np.float64), vr.bf2f(kv_ref[l][pg, :, sl]).astype(np.float64)
+            assert np.sqrt(((gk - ek) ** 2).mean() / (ek ** 2).mean()) <= 1e-2, l
+        L.vox_stack_destroy(h)
+
+    check(64, 0, False)      # prefill-style rows: head_prepare + single-chunk attention
+    check(64, 40, True)      # decode rows, 41-token context: fused chunked attention + merge
+    check(16, 2, True)       # decode rows on a short-context stack: one-wave attention (heads == 2 * kv heads)

@@ -210,6 +210,10 @@ struct vox_stack {
     // workspace
     void *qkv, *q, *h, *attn_out, *xn, *skws;
     size_t skws_bytes;
+    // 9..32 rows path: fragment-major copies of the layer weights (NULL where the shape is not eligible) and activations
+    struct FragW { void *qkv = nullptr, *o = nullptr, *gate = nullptr, *up = nullptr, *down = nullptr; };
+    std::vector<FragW> fw;
+    void *xfrag = nullptr, *hfrag = nullptr, *afrag = nullptr;
     float* attn_ws;
     size_t attn_ws_floats;
     int keep_weights = 0;   // the stack runs many times per frame (depth loop): keep its weights cache-resident
@@ -246,6 +250,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
     float* part_ml = s->attn_ws + (size_t)n * c.heads * mc * c.head_dim;
     const float scale = 1.0f / sqrtf((float)c.head_dim);
     bool xn_ready = false;   // s->xn holds norm(x) for the next norm-prologue linear (written by the producing GEMM's reduce)
+    bool xf_ready = false;   // s->xfrag holds x in fragment-major form (written by the producing full-K GEMM's epilogue)
     for (int l = 0; l < c.layers; ++l) {
         const vox_layer_weights& w = s->layers[l];
         void* kvl = (char*)kv + (size_t)l * kv_stride * 2;
@@ -254,6 +259,9 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         a.B = n; a.N = nqkv; a.K = c.hidden; a.pro = VOX_PRO_RMSNORM; a.epi = VOX_EPI_STORE;
         a.fixed_order = fixed_order; a.keep_weights = s->keep_weights; a.splitk_ws = s->skws; a.splitk_ws_bytes = s->skws_bytes; a.norm_scratch = s->xn;
         if (xn_ready) a.x_prenormed = s->xn;
+        const vox_stack::FragW fwl = s->fw.empty() ? vox_stack::FragW{} : s->fw[l];
+        a.W_frag = fwl.qkv;
+        if (xf_ready && vox_linear_is_fullk(a)) a.x_frag = s->xfrag;
         if (!(ablate() & 16)) VOX_TRY(vox_launch_linear(s->ctx, st, a));
         HeadCall hc;  // per-head norm + RoPE + paged append
         hc.q_src = s->qkv; hc.k_src = (bf16_t*)s->qkv + nq; hc.v_src = (bf16_t*)s->qkv + nq + nkv;
@@ -282,6 +290,22 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         o.fixed_order = fixed_order; o.keep_weights = s->keep_weights; o.splitk_ws = s->skws; o.splitk_ws_bytes = s->skws_bytes;
         xn_ready = vox_linear_is_rows_gemm(o);      // its reduce also writes post_attention_layernorm(x) for gate/up
         if (xn_ready) { o.post_norm_w = w.ln2; o.post_norm_out = s->xn; }
+        LinearCall g;  // post_attention_layernorm + gate/up + SiLU*up
+        g.W = w.wgate; g.W2 = w.wup; g.x = x; g.norm_w = w.ln2; g.eps = c.eps; g.y = s->h;
+        g.B = n; g.N = c.ffn; g.K = c.hidden; g.pro = VOX_PRO_RMSNORM; g.epi = VOX_EPI_SILU_MUL;
+        g.fixed_order = fixed_order; g.keep_weights = s->keep_weights; g.splitk_ws = s->skws; g.splitk_ws_bytes = s->skws_bytes; g.norm_scratch = s->xn;
+        LinearCall d;  // down + residual
+        d.W = w.wdown; d.x = s->h; d.residual = x; d.y = x; d.B = n; d.N = c.hidden; d.K = c.ffn;
+        d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE;
+        d.fixed_order = fixed_order; d.keep_weights = s->keep_weights; d.splitk_ws = s->skws; d.splitk_ws_bytes = s->skws_bytes;
+        // fragment-major hand-offs between consecutive full-K GEMMs (o -> gate/up -> down -> next layer's qkv)
+        const bool o_fk = s->xfrag && vox_linear_is_fullk(o), g_fk = s->xfrag && vox_linear_is_fullk(g), d_fk = s->xfrag && vox_linear_is_fullk(d);
+        o.W_frag = fwl.o; g.W_frag = fwl.gate; g.W2_frag = fwl.up; d.W_frag = fwl.down;
+        if (!fwl.gate || !fwl.up) g.W_frag = g.W2_frag = nullptr;
+        if (o_fk && !(decode_rows && c.max_kvlen <= 16 && vox_attn1_linear_supported(ac, o))) { ac.out_frag = s->afrag; o.x_frag = s->afrag; }
+        xf_ready = o_fk && g_fk;
+        if (xf_ready) { o.y_frag = s->xfrag; g.x_frag = s->xfrag; }
+        if (g_fk && d_fk) { g.y_frag = s->hfrag; g.y_rowmajor = 0; d.x_frag = s->hfrag; }
         if (decode_rows && c.max_kvlen <= 16 && !(ablate() & 256) && vox_attn1_linear_supported(ac, o)) {
             VOX_TRY(vox_launch_attn1_linear(st, ac, o));     // short context: attention recomputed inside o_proj
         } else {
@@ -290,22 +314,16 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
                 VOX_TRY(vox_launch_attn_short(st, ac));      // one wave per (row, kv head), registers only
             } else {
                 VOX_TRY(vox_launch_attn_partial(st, ac));
-                if (mc > 1) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc));
+                if (mc > 1) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc, ac.out_frag));
             }
             if (!(ablate() & 32)) VOX_TRY(vox_launch_linear(s->ctx, st, o));
         }
-        LinearCall g;  // post_attention_layernorm + gate/up + SiLU*up
-        g.W = w.wgate; g.W2 = w.wup; g.x = x; g.norm_w = w.ln2; g.eps = c.eps; g.y = s->h;
-        g.B = n; g.N = c.ffn; g.K = c.hidden; g.pro = VOX_PRO_RMSNORM; g.epi = VOX_EPI_SILU_MUL;
-        g.fixed_order = fixed_order; g.keep_weights = s->keep_weights; g.splitk_ws = s->skws; g.splitk_ws_bytes = s->skws_bytes; g.norm_scratch = s->xn;
         if (xn_ready) g.x_prenormed = s->xn;
         if (!(ablate() & 64)) VOX_TRY(vox_launch_linear(s->ctx, st, g));
-        LinearCall d;  // down + residual
-        d.W = w.wdown; d.x = s->h; d.residual = x; d.y = x; d.B = n; d.N = c.hidden; d.K = c.ffn;
-        d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE;
-        d.fixed_order = fixed_order; d.keep_weights = s->keep_weights; d.splitk_ws = s->skws; d.splitk_ws_bytes = s->skws_bytes;
         xn_ready = l + 1 < c.layers && vox_linear_is_rows_gemm(d);    // ... and the next layer's input_layernorm(x)
         if (xn_ready) { d.post_norm_w = s->layers[l + 1].ln1; d.post_norm_out = s->xn; }
+        xf_ready = d_fk && l + 1 < c.layers;                          // (the next qkv decides whether it can use it)
+        if (xf_ready) d.y_frag = s->xfrag;
         if (!(ablate() & 128)) VOX_TRY(vox_launch_linear(s->ctx, st, d));
     }
     return VOX_OK;
@@ -343,11 +361,37 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
         delete s;
         return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc failed");
     }
+    if (R > 8) {
+        // fragment-major weight copies for the 9..32 rows GEMM (rows * 2 bytes each: doubles the stack's weight footprint;
+        // the 1..8 rows GEMV and the 33+ rows split-K GEMM keep reading the caller's row-major tensors)
+        auto mk = [&](const void* src, int rows, int K, void** dst) -> bool {
+            *dst = nullptr;
+            if (!src || !vox_fullk_weight_ok(rows, K)) return true;
+            if (hipMalloc(dst, (size_t)rows * K * 2) != hipSuccess) return false;
+            return vox_launch_swizzle_frag(nullptr, src, *dst, rows, K) == VOX_OK;
+        };
+        s->fw.resize(cfg->layers);
+        bool ok = hipMalloc(&s->xfrag, (size_t)32 * cfg->hidden * 2) == hipSuccess && hipMalloc(&s->hfrag, (size_t)32 * cfg->ffn * 2) == hipSuccess &&
+                  hipMalloc(&s->afrag, (size_t)32 * nq * 2) == hipSuccess;
+        if (ok) { (void)hipMemset(s->afrag, 0, (size_t)32 * nq * 2); (void)hipMemset(s->xfrag, 0, (size_t)32 * cfg->hidden * 2); (void)hipMemset(s->hfrag, 0, (size_t)32 * cfg->ffn * 2); }
+        for (int l = 0; ok && l < cfg->layers; ++l) {
+            const vox_layer_weights& w = s->layers[l];
+            ok = mk(w.wqkv, (int)(nq + 2 * nkv), cfg->hidden, &s->fw[l].qkv) && mk(w.wo, cfg->hidden, (int)nq, &s->fw[l].o) &&
+                 mk(w.wgate, cfg->ffn, cfg->hidden, &s->fw[l].gate) && mk(w.wup, cfg->ffn, cfg->hidden, &s->fw[l].up) &&
+                 mk(w.wdown, cfg->hidden, cfg->ffn, &s->fw[l].down);
+        }
+        if (!ok || hipDeviceSynchronize() != hipSuccess) {
+            vox_stack_destroy(s);
+            return vox_fail(VOX_ERR_NOMEM, "stack_create: fragment-major weight copies failed");
+        }
+    }
     *out = s;
     return VOX_OK;
 }
 void vox_stack_destroy(vox_stack* s) {
     if (!s) return;
+    for (auto& f : s->fw) { (void)hipFree(f.qkv); (void)hipFree(f.o); (void)hipFree(f.gate); (void)hipFree(f.up); (void)hipFree(f.down); }
+    (void)hipFree(s->xfrag); (void)hipFree(s->hfrag); (void)hipFree(s->afrag);
     (void)hipFree(s->qkv); (void)hipFree(s->q); (void)hipFree(s->h); (void)hipFree(s->attn_out); (void)hipFree(s->xn); (void)hipFree(s->skws); (void)hipFree(s->attn_ws);
     delete s;
 }

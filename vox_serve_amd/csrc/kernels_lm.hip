@@ -25,7 +25,15 @@ struct LinArgs {
     bf16_t* post_out;
     float post_eps;
     int keep;            // 1: weights are re-read soon (depth loop): plain loads, let them live in the Infinity Cache
+    const bf16_t *W_frag, *W2_frag, *x_frag;   // fragment-major operands of the 9..32 rows path (see LinearCall)
+    bf16_t* y_frag;
+    int y_rowmajor;
 };
+
+// element offset of (row r, column k) of a [*, K] matrix in fragment-major form
+__device__ __forceinline__ size_t frag_off(int r, int k, int K) {
+    return ((size_t)(r >> 4) * (K >> 5) + (k >> 5)) * 512 + (size_t)(((r & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7));
+}
 
 __device__ __forceinline__ const uint4* x_row_ptr(const LinArgs& a, int row) {
     const long r = a.x_rows ? a.x_rows[row] : row;
@@ -924,20 +932,30 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
     const int kbase = wave * (KSTEPS * 32) + fk;
     const int bt = a.B - r0;
     uint4 wv[NB][KSTEPS];
+    const size_t fbase = (size_t)wave * KSTEPS * 64 + lane;      // uint4 offset of this wave's first fragment inside a tile row
     {
-        const uint4* w0 = reinterpret_cast<const uint4*>(a.W + (size_t)(n0 + fr) * a.K + kbase);
-        const uint4* w1 = SM ? reinterpret_cast<const uint4*>(a.W2 + (size_t)(n0 + fr) * a.K + kbase) : nullptr;
+        // row-major: lane (fr, g) reads 16 B of weight row n0+fr per k-step (16 rows x 64 B per wave request);
+        // fragment-major: the same register contents from ONE contiguous 1 KiB request
+        const bool wf = a.W_frag != nullptr;
+        const int wstep = wf ? 64 : 4;
+        const uint4* w0 = wf ? reinterpret_cast<const uint4*>(a.W_frag) + (size_t)ctile * (a.K >> 5) * 64 + fbase
+                             : reinterpret_cast<const uint4*>(a.W + (size_t)(n0 + fr) * a.K + kbase);
+        const uint4* w1 = !SM ? nullptr
+                          : wf ? reinterpret_cast<const uint4*>(a.W2_frag) + (size_t)ctile * (a.K >> 5) * 64 + fbase
+                               : reinterpret_cast<const uint4*>(a.W2 + (size_t)(n0 + fr) * a.K + kbase);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-            wv[0][s] = a.keep ? w0[s * 4] : ldg_nt(w0 + s * 4);
-            if (SM) wv[1][s] = a.keep ? w1[s * 4] : ldg_nt(w1 + s * 4);
+            wv[0][s] = a.keep ? w0[s * wstep] : ldg_nt(w0 + s * wstep);
+            if (SM) wv[1][s] = a.keep ? w1[s * wstep] : ldg_nt(w1 + s * wstep);
         }
     }
     const uint4* xr[MT];
+    const int xstep = a.x_frag ? 64 : 4;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = m * 16 + fr;
-        xr[m] = x_row_ptr(a, r0 + (row < bt ? row : bt - 1)) + (kbase >> 3);
+        xr[m] = a.x_frag ? reinterpret_cast<const uint4*>(a.x_frag) + (size_t)((r0 >> 4) + m) * (a.K >> 5) * 64 + fbase
+                         : x_row_ptr(a, r0 + (row < bt ? row : bt - 1)) + (kbase >> 3);
     }
     f32x4_t acc[NB][MT];
 #pragma unroll
@@ -948,7 +966,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int s = 0; s < G; ++s) xa[0][m][s] = xr[m][s * 4];
+        for (int s = 0; s < G; ++s) xa[0][m][s] = xr[m][s * xstep];
     __builtin_amdgcn_sched_barrier(0);      // every load above is issued before anything below waits on one of them
     uint4 gv[PRO == PRO_RMSNORM ? G : 1];
     float rinv[MT];
@@ -980,7 +998,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int s = 0; s < G; ++s) xa[(g + 1) & 1][m][s] = xr[m][((g + 1) * G + s) * 4];
+                for (int s = 0; s < G; ++s) xa[(g + 1) & 1][m][s] = xr[m][((g + 1) * G + s) * xstep];
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -1024,8 +1042,27 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
             if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
             if (a.residual) o = f2bf(bf2f(a.residual[oi]) + bf2f(o));
         }
-        a.y[oi] = o;
+        if (a.y_rowmajor) a.y[oi] = o;
+        if (a.y_frag) a.y_frag[frag_off(r0 + b, n, a.N)] = o;
     }
+}
+
+// row-major [rows][K] -> fragment-major (one thread per 16-byte chunk)
+__global__ __launch_bounds__(256) void k_swizzle_frag(const uint4* src, uint4* dst, int rows, int K) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // destination chunk index
+    const size_t total = (size_t)rows * (K >> 3);
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const size_t frag = i >> 6;
+    const int ks = (int)(frag % (K >> 5)), t = (int)(frag / (K >> 5));
+    const int r = t * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8;
+    dst[i] = src[((size_t)r * K + k) >> 3];
+}
+int vox_launch_swizzle_frag(hipStream_t st, const void* src, void* dst, int rows, int K) {
+    if (rows % 16 || K % 32) return vox_fail(VOX_ERR_INVALID, "swizzle_frag: rows %% 16 or K %% 32");
+    const size_t total = (size_t)rows * (K >> 3);
+    hipLaunchKernelGGL(k_swizzle_frag, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, rows, K);
+    return VOX_OK;
 }
 
 static bool fullk_shape_ok(int B, int N, int K, int pro, int epi) {
@@ -1060,6 +1097,11 @@ static int launch_gemm_fullk(hipStream_t st, const LinArgs& a) {
 static bool linear_is_fullk(const LinearCall& c) {
     return !c.fixed_order && !c.x_out && fullk_shape_ok(c.B, c.N, c.K, c.pro, c.epi);
 }
+bool vox_linear_is_fullk(const LinearCall& c) { return linear_is_fullk(c); }
+bool vox_fullk_weight_ok(int N, int K) {
+    const int ks = K / 256;
+    return N % 16 == 0 && K % 256 == 0 && (ks == 4 || ks == 8 || ks == 12 || ks == 24 || ks == 32);
+}
 
 static int rows_gemm_min() {
 #ifdef VOX_DEV_KNOBS
@@ -1087,6 +1129,15 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
     a.max_chunks = c.max_chunks;
     a.keep = c.keep_weights;
     a.post_nw = (const bf16_t*)c.post_norm_w; a.post_out = (bf16_t*)c.post_norm_out; a.post_eps = c.eps;
+    a.y_rowmajor = 1;
+    if (linear_is_fullk(c)) {
+        a.W_frag = (const bf16_t*)c.W_frag; a.W2_frag = (const bf16_t*)c.W2_frag; a.x_frag = (const bf16_t*)c.x_frag;
+        a.y_frag = (bf16_t*)c.y_frag; a.y_rowmajor = c.y_rowmajor || !c.y_frag;
+        if (c.epi == EPI_SILU_MUL && (a.W_frag == nullptr) != (a.W2_frag == nullptr))
+            return vox_fail(VOX_ERR_INVALID, "linear: W_frag and W2_frag must be given together");
+    } else if (c.x_frag && !c.x) {
+        return vox_fail(VOX_ERR_INVALID, "linear: fragment-major input outside the 9..32 rows path");
+    }
     const int ncu = ctx->n_cu;
     int pro = c.pro, epi = c.epi;
 #ifdef VOX_DEV_KNOBS        // development builds: strip features to time them (results are wrong when set)
@@ -1281,6 +1332,7 @@ struct AttnArgs {
     int fixed_pos;       // >= 0: every row's RoPE position
     int identity_pages;  // 1: request r owns the single page r and q_req[row] == row (depth loop)
     bf16_t* out;   // single-chunk launches write the final bf16 output here (merge of one chunk == o/l)
+    bf16_t* out_frag;   // optional fragment-major copy of the output (see LinearCall)
 };
 
 // norm (optional) + rope of one head held as one 16-byte chunk per lane (lanes < LPT); result as bf16 bits in
@@ -1438,6 +1490,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
         const size_t hi = (size_t)row * a.Hq + hk * G + g;
         if (a.out) {   // one chunk: w = exp2(0) = 1, O = fma(o,1,0) = o, L = l
             a.out[hi * D + d] = f2bf(o / l);
+            if (a.out_frag) a.out_frag[frag_off(row, (hk * G + g) * D + d, a.Hq * D)] = f2bf(o / l);
             continue;
         }
         a.part_o[(hi * a.max_chunks + c) * D + d] = o;
@@ -1464,7 +1517,7 @@ int vox_launch_attn_partial(hipStream_t st, const AttnCall& c) {
     int nchunk = (c.max_kvlen + VOX_TC - 1) / VOX_TC;
     if (nchunk < 1) nchunk = 1;
     if (nchunk > c.max_chunks) return vox_fail(VOX_ERR_INVALID, "attention: max_kvlen exceeds workspace");
-    if (nchunk == 1) a.out = (bf16_t*)c.out;
+    if (nchunk == 1) { a.out = (bf16_t*)c.out; a.out_frag = (bf16_t*)c.out_frag; }
     dim3 grid(nchunk, c.Hkv, c.Nq);
     const bool fused = c.qkv != nullptr;
 #define VOX_ATT(D_)                                                                           \
@@ -1616,6 +1669,7 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
         r.x = pack_bf2(o[0] / l, o[1] / l); r.y = pack_bf2(o[2] / l, o[3] / l);
         r.z = pack_bf2(o[4] / l, o[5] / l); r.w = pack_bf2(o[6] / l, o[7] / l);
         reinterpret_cast<uint4*>(out_row + (size_t)(hk * 2 + g) * D)[j] = r;
+        if (at.out_frag) *reinterpret_cast<uint4*>(at.out_frag + frag_off(row, (hk * 2 + g) * D + j * 8, at.Hq * D)) = r;
     }
 }
 
@@ -1704,6 +1758,7 @@ int vox_launch_attn_short(hipStream_t st, const AttnCall& c) {
     AttnArgs at{};
     fill_attn_args(at, c);
     at.out = (bf16_t*)c.out;
+    at.out_frag = (bf16_t*)c.out_frag;
     const int n_pairs = c.Nq * c.Hkv;
     hipLaunchKernelGGL(k_attn_short, dim3((n_pairs + 3) / 4), dim3(256), 0, st, at, n_pairs);
     return VOX_OK;
@@ -1727,7 +1782,7 @@ int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const LinearCall&
 }
 // merge partials -> bf16 out [Nq,Hq,D] (standalone op path; the engine merges inside the o_proj prologue)
 __global__ __launch_bounds__(256) void k_attn_merge(const float* part_o, const float* part_ml, const int* kvlen,
-                                                    bf16_t* out, int Hq, int D, int max_chunks, int total) {
+                                                    bf16_t* out, int Hq, int D, int max_chunks, int total, bf16_t* out_frag) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int HD = Hq * D;
@@ -1744,14 +1799,15 @@ __global__ __launch_bounds__(256) void k_attn_merge(const float* part_o, const f
         O = __fmaf_rn(po[(size_t)c * D], w, O);
     }
     out[e] = f2bf(O / L);
+    if (out_frag) out_frag[frag_off(row, e % HD, HD)] = f2bf(O / L);
 }
 
 int vox_launch_attn_merge(hipStream_t st, const float* part_o, const float* part_ml, const int* kvlen, void* out,
-                          int Nq, int Hq, int D, int max_chunks) {
+                          int Nq, int Hq, int D, int max_chunks, void* out_frag) {
     const int total = Nq * Hq * D;
     if (total <= 0) return VOX_OK;
     hipLaunchKernelGGL(k_attn_merge, dim3((total + 255) / 256), dim3(256), 0, st, part_o, part_ml, kvlen,
-                       (bf16_t*)out, Hq, D, max_chunks, total);
+                       (bf16_t*)out, Hq, D, max_chunks, total, (bf16_t*)out_frag);
     return VOX_OK;
 }
 

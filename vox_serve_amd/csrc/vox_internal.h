@@ -57,12 +57,22 @@ struct LinearCall {
     const void* x_prenormed = nullptr;
     void* norm_scratch = nullptr;   // [B,K] bf16: lets > 32-row calls with a norm prologue normalise once up front
     int keep_weights = 0;   // weights are re-read within the frame (depth loop): do not stream them past the caches
+    // 9..32 rows path (full-K MFMA GEMM) only — "fragment-major" operands: tile (t, k-step ks) of a [rows or cols][K] matrix
+    // is the 1 KiB block [64 lanes][8 bf16] an MFMA 16x16x32 operand register holds (lane = (row % 16) + 16 * ((k % 32) / 8)),
+    // at element offset ((t * (K / 32) + ks) * 512): every operand load is one contiguous 1 KiB wave request.
+    const void *W_frag = nullptr, *W2_frag = nullptr;   // pre-swizzled copies of W / W2 (vox_launch_swizzle_frag)
+    const void* x_frag = nullptr;                        // the input in fragment-major form (replaces x as the A operand)
+    void* y_frag = nullptr;                              // also write the output fragment-major (the next linear's x_frag)
+    int y_rowmajor = 1;                                  // 0: skip the row-major y (only y_frag is consumed)
     int pro = 0, epi = 0;  // PRO_* / EPI_*
     int fixed_order = 0;   // 1: keep the fixed-order VALU kernel even above 8 rows (depth step 1 of a <= 8 request frame)
 };
 enum { VOX_PRO_COPY = 0, VOX_PRO_RMSNORM = 1, VOX_PRO_ATTN = 2 };
 enum { VOX_EPI_STORE = 0, VOX_EPI_SILU = 1, VOX_EPI_SILU_MUL = 2 };
 bool vox_linear_is_rows_gemm(const LinearCall& c);
+bool vox_linear_is_fullk(const LinearCall& c);      // true: the call takes the 9..32 rows path that honours *_frag
+bool vox_fullk_weight_ok(int N, int K);             // a weight of this shape can be used fragment-major
+int vox_launch_swizzle_frag(hipStream_t st, const void* src, void* dst, int rows, int K);   // rows % 16 == 0, K % 32 == 0
 int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c);
 int vox_launch_rmsnorm(hipStream_t st, const void* x, const void* w, void* y, int rows, int H, float eps);
 
@@ -91,6 +101,7 @@ struct AttnCall {
     float eps = 1e-6f;
     int rot = 0, interleave = 0, table_max_pos = 0;
     void* out = nullptr;   // bf16 [Nq,Hq,D]: written directly when the launch covers a single chunk
+    void* out_frag = nullptr;   // optional: the same output ALSO in fragment-major form (A operand of a 9..32 rows o_proj)
     const int* ptab = nullptr;
     int pt_stride = 0, fixed_kvlen = 0, fixed_pos = -1, identity_pages = 0;
 };
@@ -100,7 +111,7 @@ int vox_launch_attn_short(hipStream_t st, const AttnCall& c);
 bool vox_attn1_linear_supported(const AttnCall& c, const struct LinearCall& l);
 int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const struct LinearCall& l);
 int vox_launch_attn_merge(hipStream_t st, const float* part_o, const float* part_ml, const int* kvlen, void* out,
-                          int Nq, int Hq, int D, int max_chunks);
+                          int Nq, int Hq, int D, int max_chunks, void* out_frag = nullptr);
 int vox_launch_gather(hipStream_t st, const void* table, const int* ids, int id_stride, int id_off, void* dst,
                       long dst_stride, int B, int H, int vocab);
 int vox_launch_qwen3_mix(hipStream_t st, const void* text, const void* codec_table, const int* ids, int id_stride,
