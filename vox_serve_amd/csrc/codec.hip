@@ -6,8 +6,10 @@
 //
 // Layout: activations fp32, time-major [rows = (request, t)][channels] so that
 //   * every conv / transposed conv / linear is ONE implicit GEMM  out[t, n] = sum_tap sum_c A[t - off_tap, c] * W[tap][n][c]
-//     on the matrix cores (v_mfma_f32_16x16x4_f32: fp32 operands, exact fp32 products and accumulation —
-//     the waveform parity bar of 1e-4 RMS is not reachable with bf16-rounded activations);
+//     on the matrix cores.  The waveform parity bar of 1e-4 RMS is not reachable with bf16-rounded activations, so the
+//     fp32 activation is split EXACTLY into three bf16 terms when it is staged (x = h + m + l, 24 mantissa bits) and each
+//     term meets the (already bf16) weight in v_mfma_f32_16x16x32_bf16: products exact, fp32 accumulation — the result
+//     of an fp32-input MFMA at 3/16 of its issue cost (the fp32 16x16x4 form made these kernels MFMA-bound per CU);
 //   * a transposed conv with stride r writes r*Cout contiguous values per input row = r output rows: no scatter;
 //   * LayerNorm / RMSNorm / depthwise conv run over the contiguous channel axis.
 // Weights stay bf16 in HBM ([tap][N][Cin], packed once on the host side) and are widened when staged to LDS.
@@ -15,9 +17,32 @@
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ cbf16x8 as_cbf8(uint4 v) {
+    union { uint4 u; cbf16x8 b; } c;
+    c.u = v;
+    return c.b;
+}
+// exact three-way split of 8 fp32 values into bf16 planes: x = h + m + l (each subtraction is exact in fp32)
+__device__ __forceinline__ void split3(const float4 lo4, const float4 hi4, uint4& h, uint4& m, uint4& l) {
+    const float x[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    unsigned short hb[8], mb[8], lb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hb[i] = f2bf(x[i]);
+        const float r1 = x[i] - bf2f(hb[i]);
+        mb[i] = f2bf(r1);
+        const float r2 = r1 - bf2f(mb[i]);
+        lb[i] = f2bf(r2);
+    }
+    h = make_uint4(hb[0] | (unsigned)hb[1] << 16, hb[2] | (unsigned)hb[3] << 16, hb[4] | (unsigned)hb[5] << 16, hb[6] | (unsigned)hb[7] << 16);
+    m = make_uint4(mb[0] | (unsigned)mb[1] << 16, mb[2] | (unsigned)mb[3] << 16, mb[4] | (unsigned)mb[5] << 16, mb[6] | (unsigned)mb[7] << 16);
+    l = make_uint4(lb[0] | (unsigned)lb[1] << 16, lb[2] | (unsigned)lb[3] << 16, lb[4] | (unsigned)lb[5] << 16, lb[6] | (unsigned)lb[7] << 16);
+}
 
 // ================================================================================================
-// implicit-GEMM convolution on fp32-input MFMA.  Block 256 threads = 2x2 waves, tile 64(M) x 64(N) x 32(K).
+// implicit-GEMM convolution on the matrix cores (fp32 activations split 3-way into bf16).  Block 256 threads = 2x2 waves.
 // ================================================================================================
 #define CG_BM 64
 #define CG_BN 64
@@ -42,11 +67,11 @@ struct ConvGemmArgs {
 template <int BK, int WM, int WN>
 __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
-    constexpr int LD = BK + 4;          // LDS row stride in floats (16-byte aligned rows, spreads banks)
+    constexpr int LD = BK + 8;          // LDS row stride in bf16 elements (+16 B: the 16 rows of a fragment read hit distinct banks)
     constexpr int SEG = BK / 8;         // 8-element segments per row
     constexpr int NA = (BM * SEG + 255) / 256, NB = (BN * SEG + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float As[BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t As[3][BM * LD];     // the h / m / l planes of the activation tile
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[BN * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wm = (wave >> 1) * 16 * WM, wn = (wave & 1) * 16 * WN;
@@ -104,40 +129,38 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
         for (int i = 0; i < NA; ++i) {
             const int idx = tid + 256 * i;
             if (idx < BM * SEG) {
-                float* d = &As[(idx / SEG) * LD + (idx % SEG) * 8];
-                *reinterpret_cast<float4*>(d) = v0[i];
-                *reinterpret_cast<float4*>(d + 4) = v1[i];
+                const int o = (idx / SEG) * LD + (idx % SEG) * 8;
+                uint4 h, m, l;
+                split3(v0[i], v1[i], h, m, l);
+                *reinterpret_cast<uint4*>(&As[0][o]) = h;
+                *reinterpret_cast<uint4*>(&As[1][o]) = m;
+                *reinterpret_cast<uint4*>(&As[2][o]) = l;
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < BN * SEG) {
-                float* d = &Bs[(idx / SEG) * LD + (idx % SEG) * 8];
-                *reinterpret_cast<float4*>(d) = make_float4(bflo(wv[i].x), bfhi(wv[i].x), bflo(wv[i].y), bfhi(wv[i].y));
-                *reinterpret_cast<float4*>(d + 4) = make_float4(bflo(wv[i].z), bfhi(wv[i].z), bflo(wv[i].w), bfhi(wv[i].w));
-            }
+            if (idx < BN * SEG) *reinterpret_cast<uint4*>(&Bs[(idx / SEG) * LD + (idx % SEG) * 8]) = wv[i];
         }
         __syncthreads();
         if (it + 1 < nit) fetch(it + 1);
-        // each lane owns k = 4*(lane>>4)+s of every 16-wide K block: one float4 per operand feeds 4 MFMA steps
-        const int fr = lane & 15, fk = (lane >> 4) * 4;
+        // lane (fr, g) holds 8 consecutive k of row fr of every 32-wide K block: one 16-byte LDS read per operand
+        const int fr = lane & 15, fk = (lane >> 4) * 8;
 #pragma unroll
-        for (int kb = 0; kb < BK; kb += 16) {
-            float4 af[WM], bf[WN];
+        for (int kb = 0; kb < BK; kb += 32) {
+            uint4 bfr[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[(wm + i * 16 + fr) * LD + kb + fk]);
+            for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(&Bs[(wn + j * 16 + fr) * LD + kb + fk]);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[(wn + j * 16 + fr) * LD + kb + fk]);
+            for (int t = 2; t >= 0; --t) {      // smallest term first
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i) {
+                    const uint4 afr = *reinterpret_cast<const uint4*>(&As[t][(wm + i * 16 + fr) * LD + kb + fk]);
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(afr), as_cbf8(bfr[j]), acc[i][j], 0, 0, 0);
                 }
+            }
         }
     }
     // epilogue: D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
@@ -168,12 +191,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
 // register prefetch.  These stages run a handful of blocks: time = number of dependent K steps, so the steps are wide.
 template <int BK>
 __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
-    constexpr int LD = BK + 4;
+    constexpr int LD = BK + 8;                      // bf16 elements
     constexpr int NA = (16 * BK / 4 + 255) / 256;   // float4 per thread (activations)
     constexpr int NB = 64 * BK / 8 / 256;           // uint4 per thread (weights)
     constexpr int SEGA = BK / 4, SEGB = BK / 8;
-    __shared__ __attribute__((aligned(16))) float As[16 * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[64 * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t As[3][16 * LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[64 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 64;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -209,26 +232,38 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < 16 * SEGA) *reinterpret_cast<float4*>(&As[(idx / SEGA) * LD + (idx % SEGA) * 4]) = av[i];
+            if (idx < 16 * SEGA) {      // 4 fp32 -> 4 bf16 per plane (8 bytes)
+                const float x4[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+                unsigned short hb[4], mb[4], lb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hb[e] = f2bf(x4[e]);
+                    const float r1 = x4[e] - bf2f(hb[e]);
+                    mb[e] = f2bf(r1);
+                    lb[e] = f2bf(r1 - bf2f(mb[e]));
+                }
+                const int o = (idx / SEGA) * LD + (idx % SEGA) * 4;
+                *reinterpret_cast<uint2*>(&As[0][o]) = make_uint2(hb[0] | (unsigned)hb[1] << 16, hb[2] | (unsigned)hb[3] << 16);
+                *reinterpret_cast<uint2*>(&As[1][o]) = make_uint2(mb[0] | (unsigned)mb[1] << 16, mb[2] | (unsigned)mb[3] << 16);
+                *reinterpret_cast<uint2*>(&As[2][o]) = make_uint2(lb[0] | (unsigned)lb[1] << 16, lb[2] | (unsigned)lb[3] << 16);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + 256 * i;
-            float* d = &Bs[(idx / SEGB) * LD + (idx % SEGB) * 8];
-            *reinterpret_cast<float4*>(d) = make_float4(bflo(bv[i].x), bfhi(bv[i].x), bflo(bv[i].y), bfhi(bv[i].y));
-            *reinterpret_cast<float4*>(d + 4) = make_float4(bflo(bv[i].z), bfhi(bv[i].z), bflo(bv[i].w), bfhi(bv[i].w));
+            *reinterpret_cast<uint4*>(&Bs[(idx / SEGB) * LD + (idx % SEGB) * 8]) = bv[i];
         }
         __syncthreads();
         if (it + 1 < nit) fetch(it + 1);
-        const int fr = lane & 15, fk = (lane >> 4) * 4;
+        const int fr = lane & 15, fk = (lane >> 4) * 8;
 #pragma unroll
-        for (int kb = 0; kb < BK; kb += 16) {
-            const float4 af = *reinterpret_cast<const float4*>(&As[fr * LD + kb + fk]);
-            const float4 bf = *reinterpret_cast<const float4*>(&Bs[(wave * 16 + fr) * LD + kb + fk]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc, 0, 0, 0);
+        for (int kb = 0; kb < BK; kb += 32) {
+            const uint4 bfr = *reinterpret_cast<const uint4*>(&Bs[(wave * 16 + fr) * LD + kb + fk]);
+#pragma unroll
+            for (int t = 2; t >= 0; --t) {
+                const uint4 afr = *reinterpret_cast<const uint4*>(&As[t][fr * LD + kb + fk]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(afr), as_cbf8(bfr), acc, 0, 0, 0);
+            }
         }
     }
     const int n = n0 + wave * 16 + (lane & 15);
@@ -703,7 +738,7 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
 }  // extern "C"
 
 // ================================================================================================
-// Mimi decoder (CSM's codec), stateless per chunk.  Same building blocks: implicit-GEMM convolutions on fp32-input
+// Mimi decoder (CSM's codec), stateless per chunk.  Same building blocks: implicit-GEMM convolutions on split-fp32
 // MFMA (look-back rows before the chunk start read as zero = the reference's constant padding of a fresh state),
 // transposed conv with stride r = 2-tap GEMM writing r*Cout contiguous values per input row (the reference trims the
 // K-S rightmost samples: exactly the part the second tap of the NEXT chunk would add).
