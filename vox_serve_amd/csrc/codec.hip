@@ -541,6 +541,17 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
         else hipLaunchKernelGGL(k_conv_gemm_skinny<32>, g, dim3(256), 0, st, a);
         return VOX_OK;
     }
+    // many-row stages (batched chunks, the late upsampling stages): 128-row tiles, 64 x (48|64) per wave — each LDS
+    // fragment read then feeds 3-4 MFMAs instead of 2 (the 64 x 64 tile is LDS-read bound with the 3-term split)
+    {
+        const int wnb = (w.n % 128 == 0 || w.n >= 256) ? 4 : (w.n > 64 && w.n <= 96) ? 3 : 0;
+        if (wnb && ((w.n + 32 * wnb - 1) / (32 * wnb)) * ((a.M + 127) / 128) >= 256) {
+            const dim3 gb((w.n + 32 * wnb - 1) / (32 * wnb), (a.M + 127) / 128);
+            if (wnb == 4) hipLaunchKernelGGL((k_conv_gemm<32, 4, 4>), gb, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_conv_gemm<32, 4, 3>), gb, dim3(256), 0, st, a);
+            return VOX_OK;
+        }
+    }
     // tile: 64 x 64 unless that leaves most CUs idle (these GEMMs are MFMA-bound per CU)
     const int b64 = ((w.n + 63) / 64) * ((a.M + 63) / 64);
     const int wm = b64 >= 192 ? 2 : 1, wn = (b64 >= 192 || 2 * b64 >= 192) ? 2 : 1;
