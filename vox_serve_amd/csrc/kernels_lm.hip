@@ -28,6 +28,7 @@ struct LinArgs {
     const bf16_t *W_frag, *W2_frag, *x_frag;   // fragment-major operands of the 9..32 rows path (see LinearCall)
     bf16_t* y_frag;
     int y_rowmajor;
+    int row_tiles;       // k_gemv only: > 1 = that many row tiles of BT rows, one block per (column group, row tile)
 };
 
 // element offset of (row r, column k) of a [*, K] matrix in fragment-major form
@@ -299,13 +300,22 @@ template <int BT, int KC, int R, int PRO, int EPI>
 __global__ __launch_bounds__(256) void k_gemv(LinArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int OUT = (EPI == EPI_SILU_MUL) ? R / 2 : R;
-    const int n0 = (blockIdx.x * 4 + wave) * OUT;
+    // 3..8 rows: the same kernel per row tile.  Block id = (x / 8) * 8T + tile * 8 + x % 8: the T blocks that stream the same
+    // weight rows are 8 ids apart = same XCD, dispatched together, so the weights cross HBM once and the other T - 1 reads hit
+    // that XCD's L2.  Per-row arithmetic is unchanged (bit-exact with the single-tile launch).
+    int bx = blockIdx.x, rb = 0;
+    if (a.row_tiles > 1) {
+        bx = (blockIdx.x / (8 * a.row_tiles)) * 8 + (blockIdx.x & 7);
+        rb = ((blockIdx.x >> 3) % a.row_tiles) * BT;
+    }
+    const int n0 = (bx * 4 + wave) * OUT;
     if (n0 >= a.N) return;
+    const int nb = a.B - rb;      // rows of this tile (>= 1)
 
     uint4 xv[BT][KC], nwv[KC];
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
-        const uint4* xr = x_row_ptr(a, b < a.B ? b : 0);
+        const uint4* xr = x_row_ptr(a, rb + (b < nb ? b : 0));
 #pragma unroll
         for (int j = 0; j < KC; ++j) xv[b][j] = xr[lane + 64 * j];
     }
@@ -332,8 +342,8 @@ __global__ __launch_bounds__(256) void k_gemv(LinArgs a) {
     float res_pre = 0.0f, bias_pre = 0.0f;
     {
         const int po = lane / BT, pb = lane % BT;
-        if (EPI != EPI_SILU_MUL && lane < OUT * BT && pb < a.B && n0 + po < a.N) {
-            if (a.residual) res_pre = bf2f(a.residual[(size_t)pb * a.N + n0 + po]);
+        if (EPI != EPI_SILU_MUL && lane < OUT * BT && pb < nb && n0 + po < a.N) {
+            if (a.residual) res_pre = bf2f(a.residual[(size_t)(rb + pb) * a.N + n0 + po]);
             if (a.bias) bias_pre = bf2f(a.bias[n0 + po]);
         }
     }
@@ -348,8 +358,8 @@ __global__ __launch_bounds__(256) void k_gemv(LinArgs a) {
 #pragma unroll
             for (int j = 0; j < KC; ++j) {
                 xv[b][j] = norm_chunk(xv[b][j], nwv[j], rinv);
-                if (a.x_out && blockIdx.x == 0 && wave == 0 && b < a.B)
-                    reinterpret_cast<uint4*>(a.x_out + (size_t)b * a.x_out_stride)[lane + 64 * j] = xv[b][j];
+                if (a.x_out && bx == 0 && wave == 0 && b < nb)
+                    reinterpret_cast<uint4*>(a.x_out + (size_t)(rb + b) * a.x_out_stride)[lane + 64 * j] = xv[b][j];
             }
         }
     }
@@ -406,9 +416,9 @@ __global__ __launch_bounds__(256) void k_gemv(LinArgs a) {
     for (int o = 0; o < OUT; ++o)
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
-            if (lane == o * BT + b && b < a.B && n0 + o < a.N) {
+            if (lane == o * BT + b && b < nb && n0 + o < a.N) {
                 const int n = n0 + o;
-                const size_t oi = (size_t)b * a.N + n;
+                const size_t oi = (size_t)(rb + b) * a.N + n;
                 bf16_t r;
                 if (EPI == EPI_SILU_MUL) {
                     const float g = bfround(acc[o][b]);
@@ -442,7 +452,9 @@ static int launch_gemv_k(hipStream_t st, const LinArgs& a) {
     if (BT >= 4) while (cols > 1 && cols * (SM ? 2 : 1) * KC > 8) cols >>= 1;
 #define VOX_GV(C_)                                                                                       \
     if (cols == C_) {                                                                                    \
-        hipLaunchKernelGGL((k_gemv<BT, KC, (SM ? 2 * C_ : C_), PRO, EPI>), dim3((a.N + 4 * C_ - 1) / (4 * C_)), \
+        const int gx = (a.N + 4 * C_ - 1) / (4 * C_);                                                    \
+        if (a.row_tiles > 1 && gx % 8) return vox_fail(VOX_ERR_INVALID, "gemv: row tiles need N/(4 cols) %% 8 == 0"); \
+        hipLaunchKernelGGL((k_gemv<BT, KC, (SM ? 2 * C_ : C_), PRO, EPI>), dim3(gx * (a.row_tiles > 1 ? a.row_tiles : 1)), \
                            dim3(256), 0, st, a);                                                         \
         return VOX_OK;                                                                                   \
     }
@@ -454,7 +466,8 @@ template <int PRO, int EPI>
 static int launch_gemv(hipStream_t st, const LinArgs& a, bool* handled) {
     *handled = true;
     const int kc = a.K / 512;
-#define VOX_GK(B_, K_) if (a.B <= B_ && kc == K_) return launch_gemv_k<B_, K_, PRO, EPI>(st, a);
+    const int rows_per_block = a.row_tiles > 1 ? 2 : a.B;
+#define VOX_GK(B_, K_) if (rows_per_block <= B_ && kc == K_) return launch_gemv_k<B_, K_, PRO, EPI>(st, a);
     VOX_GK(1, 2) VOX_GK(1, 4) VOX_GK(1, 6) VOX_GK(1, 8) VOX_GK(1, 12) VOX_GK(1, 16)
     VOX_GK(2, 2) VOX_GK(2, 4) VOX_GK(2, 6) VOX_GK(2, 8) VOX_GK(2, 12)
 #undef VOX_GK
@@ -480,6 +493,19 @@ static int launch_linear_t(hipStream_t st, const LinArgs& a) {
     return VOX_OK;
 }
 
+static bool gemv_row_tiles_ok(const LinArgs& a) {
+    const int kc = a.K / 512;
+    if (!(kc == 2 || kc == 4 || kc == 6 || kc == 8 || kc == 12)) return false;
+#ifdef VOX_DEV_KNOBS
+    static int mode = -1;       // development builds: 0 never, 1 cache-resident weights only, 2 always, 3 shipped rule
+    if (mode < 0) { const char* e = getenv("VOX_ROW_TILES"); mode = e ? atoi(e) : 3; }
+    if (mode == 0 || (mode == 1 && !a.keep)) return false;
+    if (mode == 1 || mode == 2) return true;
+#endif
+    // measured (B = 4 / 6 / 8 frames): always a win for the cache-resident depth weights; for weights streamed from HBM
+    // the 4th row tile's re-read starts to miss the L2, the LDS-staged 8-row kernel is faster there
+    return a.keep || a.B <= 6;
+}
 template <int PRO, int EPI>
 static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
     // batch tile: smallest of {1,2,4,8} covering B (B>8 loops tiles of 8 inside the kernel)
@@ -487,6 +513,13 @@ static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
     if (PRO != PRO_ATTN && a.B <= 2 && a.K % 512 == 0) {       // register-resident, barrier-free variant
         bool handled = false;
         const int rc = launch_gemv<(PRO == PRO_ATTN ? PRO_COPY : PRO), EPI>(st, a, &handled);
+        if (handled) return rc;
+    }
+    if (PRO != PRO_ATTN && a.B >= 3 && a.B <= 8 && a.K % 512 == 0 && a.N % 64 == 0 && gemv_row_tiles_ok(a)) {
+        LinArgs t = a;                                          // 3..8 rows: the 2-row kernel per row pair
+        t.row_tiles = (a.B + 1) / 2;
+        bool handled = false;
+        const int rc = launch_gemv<(PRO == PRO_ATTN ? PRO_COPY : PRO), EPI>(st, t, &handled);
         if (handled) return rc;
     }
 #endif
