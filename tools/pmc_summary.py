@@ -19,7 +19,7 @@ for r in rows:
     cnt[name] += 1
 frames = sum(v for k, v in cnt.items() if "k_qwen3_feedback" in k)
 codec = lambda k: any(t in k for t in ("conv_gemm", "codec", "snake", "dwconv", "rvq", "state_update", "_f32", "final_conv", "pos_advance"))
-torchk = lambda k: k.startswith("at::") or "rocclr" in k or "elementwise" in k
+torchk = lambda k: k.startswith("at::") or "rocclr" in k or "elementwise" in k or "k_swizzle_frag" in k   # (+ engine-creation kernels)
 lm = sum(v for k, v in by.items() if not codec(k) and not torchk(k))
 cd = sum(v for k, v in by.items() if codec(k))
 unit = 1024.0

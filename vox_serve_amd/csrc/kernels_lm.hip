@@ -766,7 +766,8 @@ static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a) {
 __global__ void k_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps);
 
 // ================================================================================================
-// linear for 17+ rows (batched decode above 16, prefill): split-K bf16 MFMA GEMM, LDS-tiled, weights read exactly once.
+// linear for 17+ rows where the full-K kernel below does not apply (33+ rows: prefill, depth step 1 of > 16 requests; or an
+// unsupported K): split-K bf16 MFMA GEMM, LDS-tiled, weights read exactly once.
 // (Fusing the slab reduction into the last-arriving block was tried: the device-scope fence it needs writes back and
 // invalidates the XCD's L2 in every block — 3x slower than the separate k_splitk_reduce launch.)
 // Grid (Ntot/64, K/512): a block owns 64 output columns and one 512-wide K slab for ALL rows of the pass (<= 128), walks
