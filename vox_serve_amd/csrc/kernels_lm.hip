@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = a.K >> 3;
     constexpr int OUT = (EPI == EPI_SILU_MUL) ? R / 2 : R;
-    constexpr int U = (R * BT >= 16) ? 2 : 4;  // chunk-steps issued together (loads in flight per lane = U*R)
+    constexpr int U = (R * BT >= 16) ? 2 : 4;  // chunk-steps issued together (loads in flight per lane = U*R); 4 vs 2 at R*BT >= 16: no difference (measured)
     const int n0 = (blockIdx.x * 4 + wave) * OUT;
 
     const uint4* wrow[R];
@@ -493,7 +493,7 @@ static int launch_linear_t(hipStream_t st, const LinArgs& a) {
     return VOX_OK;
 }
 
-static bool gemv_row_tiles_ok(const LinArgs& a) {
+static bool gemv_row_tiles_ok(const LinArgs& a, int pro) {
     const int kc = a.K / 512;
     if (!(kc == 2 || kc == 4 || kc == 6 || kc == 8 || kc == 12)) return false;
 #ifdef VOX_DEV_KNOBS
@@ -502,9 +502,10 @@ static bool gemv_row_tiles_ok(const LinArgs& a) {
     if (mode == 0 || (mode == 1 && !a.keep)) return false;
     if (mode == 1 || mode == 2) return true;
 #endif
-    // measured (B = 4 / 6 / 8 frames): always a win for the cache-resident depth weights; for weights streamed from HBM
-    // the 4th row tile's re-read starts to miss the L2, the LDS-staged 8-row kernel is faster there
-    return a.keep || a.B <= 6;
+    // measured (B = 4 / 6 / 7 / 8 frames): always a win for the cache-resident depth weights and for copy-prologue linears
+    // (o_proj, down); with 4 row tiles of weights streamed from HBM the norm-prologue linears (every wave redoes the norm of
+    // its two rows) are faster in the LDS-staged 8-row kernel
+    return a.keep || a.B <= 6 || pro == PRO_COPY;
 }
 template <int PRO, int EPI>
 static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
@@ -515,7 +516,7 @@ static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
         const int rc = launch_gemv<(PRO == PRO_ATTN ? PRO_COPY : PRO), EPI>(st, a, &handled);
         if (handled) return rc;
     }
-    if (PRO != PRO_ATTN && a.B >= 3 && a.B <= 8 && a.K % 512 == 0 && a.N % 64 == 0 && gemv_row_tiles_ok(a)) {
+    if (PRO != PRO_ATTN && a.B >= 3 && a.B <= 8 && a.K % 512 == 0 && a.N % 64 == 0 && gemv_row_tiles_ok(a, PRO)) {
         LinArgs t = a;                                          // 3..8 rows: the 2-row kernel per row pair
         t.row_tiles = (a.B + 1) / 2;
         bool handled = false;
