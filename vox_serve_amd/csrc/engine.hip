@@ -418,6 +418,7 @@ struct vox_qwen3 {
     vox_qwen3_config cfg;
     vox_qwen3_weights w;
     std::vector<const void*> depth_emb;
+    void* proj_tab = nullptr;   // [n_groups-2][depth_vocab][depth hidden]: small_to_mtp_projection(depth_emb[i][v]), tabulated once
     vox_stack *talker, *depth;
     // device buffers
     void *te, *t1, *text, *x, *depth_x, *dx, *dlogits, *dkv;
@@ -474,11 +475,13 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
     }
     for (int i = 1; i < G && !(ablate() & 2); ++i) {
         const int rows = i == 1 ? 2 * B : B;
-        LinearCall p;  // small_to_mtp_projection
-        p.W = m->w.mtp_w; p.bias = m->w.mtp_b; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
-        p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8; p.keep_weights = m->depth->keep_weights;
-        p.splitk_ws = m->depth->skws; p.splitk_ws_bytes = m->depth->skws_bytes;
-        VOX_TRY(vox_launch_linear(m->ctx, st, p));
+        if (i == 1 || !m->proj_tab) {     // (steps >= 2: the previous step's sampler gathered the tabulated projection into dx)
+            LinearCall p;  // small_to_mtp_projection
+            p.W = m->w.mtp_w; p.bias = m->w.mtp_b; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
+            p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8; p.keep_weights = m->depth->keep_weights;
+            p.splitk_ws = m->depth->skws; p.splitk_ws_bytes = m->depth->skws_bytes;
+            VOX_TRY(vox_launch_linear(m->ctx, st, p));
+        }
         vox_rows r{};
         r.pos = i == 1 ? m->d1_pos : m->di_pos[i];
         r.q_req = i == 1 ? m->d1_req : m->iota;
@@ -505,6 +508,11 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         s.out_ids = io->out_ids; s.out_stride = G1; s.out_col = i;
         s.emb_table = m->depth_emb[i - 1]; s.emb_vocab = c.depth_vocab; s.H = H;
         s.emb_dst = m->depth_x; s.emb_dst_stride = H;
+        if (m->proj_tab && i + 1 < G) {
+            s.emb_dst = nullptr;                 // the raw embedding only feeds the feature accumulation
+            s.emb2_table = (const bf16_t*)m->proj_tab + (size_t)(i - 1) * c.depth_vocab * Hd; s.H2 = Hd;
+            s.emb2_dst = m->dx; s.emb2_dst_stride = Hd;
+        }
         s.feat_acc = io->next_features; s.feat_init = i == 1; s.ws = m->ctx->samp_ws;
         if (!(ablate() & 8)) VOX_TRY(vox_launch_sample(st, s));
     }
@@ -597,6 +605,20 @@ int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_
     for (int i = 2; i < G; ++i) { m->di_pos[i] = m->dmeta + o_pos[i]; m->di_kvlen[i] = m->dmeta + o_kvl[i]; }
     m->suppress = m->dmeta + o_sup;
     m->n_suppress = (int)sup.size();
+    if (G > 2) {
+        // projection(embedding) tables for depth steps 2..G-1 (fixed-order kernel: bit-identical to the per-step launch
+        // they replace; G-2 launches fewer per frame)
+        const size_t tab = (size_t)cfg->depth_vocab * Hd;
+        if (hipMalloc(&m->proj_tab, (size_t)(G - 2) * tab * 2) != hipSuccess) return vox_fail(VOX_ERR_NOMEM, "qwen3_create: hipMalloc");
+        for (int i = 0; i + 2 < G; ++i) {
+            LinearCall p;
+            p.W = w->mtp_w; p.bias = w->mtp_b; p.x = m->depth_emb[i]; p.y = (bf16_t*)m->proj_tab + (size_t)i * tab;
+            p.B = cfg->depth_vocab; p.N = Hd; p.K = H; p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = 1;
+            const int rc = vox_launch_linear(ctx, nullptr, p);
+            if (rc != VOX_OK) return rc;
+        }
+        VOX_HIP(hipDeviceSynchronize());
+    }
     *out = m;
     return VOX_OK;
 }
@@ -604,6 +626,7 @@ int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_
 void vox_qwen3_destroy(vox_qwen3* m) {
     if (!m) return;
     vox_stack_destroy(m->talker); vox_stack_destroy(m->depth);
+    (void)hipFree(m->proj_tab);
     for (void* p : {m->te, m->t1, m->text, m->x, m->depth_x, m->dx, m->dlogits, m->dkv, (void*)m->dmeta}) (void)hipFree(p);
     delete m;
 }
@@ -665,6 +688,7 @@ struct vox_csm {
     vox_csm_weights w;
     vox_stack *backbone, *depth;
     void *x, *depth_x, *dx, *dlogits, *dkv;
+    void* proj_tab = nullptr;   // [C-2][V][depth hidden]: inputs_embeds_projector(audio_embedding[i*V + v]), i = 1..C-2, tabulated once
     int32_t* dmeta;
     int32_t *iota, *d1_pos, *d1_req, *d1_kvlen, *d_indptr, *odd_rows;
     std::vector<int32_t*> di_pos, di_kvlen;
@@ -739,11 +763,13 @@ static int csm_tail(vox_csm* m, hipStream_t st, const vox_csm_io* io, int B, con
     hipLaunchKernelGGL(k_csm_fill_row, dim3(B), dim3(64), 0, st, io->out_ids, C1, B);
     for (int i = 1; i < C; ++i) {
         const int rows = i == 1 ? 2 * B : B;
-        LinearCall p;  // inputs_embeds_projector (no bias)
-        p.W = m->w.depth_proj; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
-        p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8; p.keep_weights = m->depth->keep_weights;
-        p.splitk_ws = m->depth->skws; p.splitk_ws_bytes = m->depth->skws_bytes;
-        VOX_TRY(vox_launch_linear(m->ctx, st, p));
+        if (i == 1 || !m->proj_tab) {     // (steps >= 2: the previous step's sampler gathered the tabulated projection into dx)
+            LinearCall p;  // inputs_embeds_projector (no bias)
+            p.W = m->w.depth_proj; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
+            p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8; p.keep_weights = m->depth->keep_weights;
+            p.splitk_ws = m->depth->skws; p.splitk_ws_bytes = m->depth->skws_bytes;
+            VOX_TRY(vox_launch_linear(m->ctx, st, p));
+        }
         vox_rows r{};
         r.pos = i == 1 ? m->d1_pos : m->di_pos[i];
         r.q_req = i == 1 ? m->d1_req : m->iota;
@@ -769,6 +795,13 @@ static int csm_tail(vox_csm* m, hipStream_t st, const vox_csm_io* io, int B, con
         s.out_ids = io->out_ids; s.out_stride = C1; s.out_col = i;
         s.emb_table = (const bf16_t*)m->w.audio_embedding + (size_t)i * V * H; s.emb_vocab = V; s.H = H;   // embed_audio_tokens_single(ids, i)
         s.emb_dst = m->depth_x; s.emb_dst_stride = H; s.ws = m->ctx->samp_ws;
+        if (m->proj_tab) {
+            s.emb_table = nullptr; s.emb_dst = nullptr;        // the raw embedding has no other consumer
+            if (i + 1 < C) {
+                s.emb2_table = (const bf16_t*)m->proj_tab + (size_t)(i - 1) * V * Hd; s.H2 = Hd;
+                s.emb2_dst = m->dx; s.emb2_dst_stride = Hd;
+            }
+        }
         VOX_TRY(vox_launch_sample(st, s));
     }
     if (feedback)
@@ -830,12 +863,28 @@ int vox_csm_create(vox_ctx* ctx, const vox_csm_config* cfg, const vox_csm_weight
     m->odd_rows = m->dmeta + o_odd; m->d_indptr = m->dmeta + o_ind;
     m->di_pos.assign(C, nullptr); m->di_kvlen.assign(C, nullptr);
     for (int i = 2; i < C; ++i) { m->di_pos[i] = m->dmeta + o_pos[i]; m->di_kvlen[i] = m->dmeta + o_kvl[i]; }
+    if (C > 2) {
+        // projector(embedding) tables for depth steps 2..C-1 (fixed-order kernel: bit-identical to the per-step launch they
+        // replace; C-2 launches fewer per frame)
+        const size_t tab = (size_t)cfg->vocab * Hd;
+        if (hipMalloc(&m->proj_tab, (size_t)(C - 2) * tab * 2) != hipSuccess) return vox_fail(VOX_ERR_NOMEM, "csm_create: hipMalloc");
+        for (int i = 1; i + 1 < C; ++i) {
+            LinearCall p;
+            p.W = w->depth_proj; p.x = (const bf16_t*)w->audio_embedding + (size_t)i * cfg->vocab * H;
+            p.y = (bf16_t*)m->proj_tab + (size_t)(i - 1) * tab;
+            p.B = cfg->vocab; p.N = Hd; p.K = H; p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = 1;
+            const int rc = vox_launch_linear(ctx, nullptr, p);
+            if (rc != VOX_OK) return rc;
+        }
+        VOX_HIP(hipDeviceSynchronize());
+    }
     *out = m;
     return VOX_OK;
 }
 void vox_csm_destroy(vox_csm* m) {
     if (!m) return;
     vox_stack_destroy(m->backbone); vox_stack_destroy(m->depth);
+    (void)hipFree(m->proj_tab);
     for (void* p : {m->x, m->depth_x, m->dx, m->dlogits, m->dkv, (void*)m->dmeta}) (void)hipFree(p);
     delete m;
 }

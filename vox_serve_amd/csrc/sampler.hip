@@ -35,8 +35,10 @@ struct SampArgs {
     const uint8_t* rep_cache;
     const uint64_t* offset_dev;
     int* out_ids;
-    const bf16_t* emb_table;
-    bf16_t *emb_dst, *feat_acc;
+    const bf16_t *emb_table, *emb2_table;
+    bf16_t *emb_dst, *feat_acc, *emb2_dst;
+    long emb2_dst_stride;
+    int H2;
     uint64_t seed, offset, offset_mul;
     long emb_dst_stride;
     float top_p, min_p, temperature, penalty;
@@ -76,6 +78,12 @@ __device__ __forceinline__ void emit_pick(const SampArgs& a, int b, int picked, 
                 fa[i] = o;
             }
         }
+    }
+    if (a.emb2_table) {
+        const int id = picked < 0 ? 0 : (picked >= a.emb_vocab ? a.emb_vocab - 1 : picked);
+        const uint4* src = reinterpret_cast<const uint4*>(a.emb2_table + (size_t)id * a.H2);
+        uint4* dst = reinterpret_cast<uint4*>(a.emb2_dst + (size_t)b * a.emb2_dst_stride);
+        for (int i = tid; i < (a.H2 >> 3); i += nthr) dst[i] = src[i];
     }
 }
 
@@ -491,6 +499,8 @@ int vox_launch_sample(hipStream_t st, const SampleCall& c) {
     a.V = c.V; a.n_suppress = c.n_suppress; a.W = c.W; a.C = c.C; a.greedy = greedy ? 1 : 0;
     a.top_k = c.cfg.top_k; a.out_stride = c.out_stride; a.out_col = c.out_col; a.emb_vocab = c.emb_vocab;
     a.H = c.H; a.feat_init = c.feat_init;
+    a.emb2_table = (const bf16_t*)c.emb2_table; a.emb2_dst = (bf16_t*)c.emb2_dst; a.emb2_dst_stride = c.emb2_dst_stride; a.H2 = c.H2;
+    if (c.emb2_table && ((c.H2 % 8) || !c.emb2_dst || c.emb_vocab <= 0)) return vox_fail(VOX_ERR_INVALID, "sample: bad second gather");
     a.ws_hist = (u32*)c.ws;
     a.ws_keys = c.ws ? reinterpret_cast<uint16_t*>((char*)c.ws + (size_t)SAMP_WS_ROWS * 65536 * 4) : nullptr;
     if (c.emb_table && (c.H % 8)) return vox_fail(VOX_ERR_INVALID, "sample: H%8!=0");

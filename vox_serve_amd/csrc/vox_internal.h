@@ -138,6 +138,12 @@ struct SampleCall {
     int emb_vocab = 0, H = 0;
     void* emb_dst = nullptr;           // row b at emb_dst + b*emb_dst_stride (elements)
     long emb_dst_stride = 0;
+    // second gather of the same id from a table of pre-projected rows (the depth loop's next input: projection(embedding[id])
+    // is a pure function of id, tabulated once at engine creation with the same fixed-order kernel)
+    const void* emb2_table = nullptr;  // [emb_vocab, H2] bf16
+    int H2 = 0;
+    void* emb2_dst = nullptr;          // row b at emb2_dst + b*emb2_dst_stride (elements)
+    long emb2_dst_stride = 0;
     void* feat_acc = nullptr;          // [B,H] bf16: feat = bf16(feat + emb) (qwen3_tts.py:2002)
     int feat_init = 0;                 // 1: feat = emb' where emb' = bf16(0 + emb)
     void* ws = nullptr;                // ctx->samp_ws (needed by top-p/min-p-only modes and V > 32768)
