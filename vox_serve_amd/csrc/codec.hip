@@ -544,7 +544,7 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     // many-row stages (batched chunks, the late upsampling stages): 128-row tiles, 64 x (48|64) per wave — each LDS
     // fragment read then feeds 3-4 MFMAs instead of 2 (the 64 x 64 tile is LDS-read bound with the 3-term split)
     {
-        const int wnb = (w.n % 128 == 0 || w.n >= 256) ? 4 : (w.n > 64 && w.n <= 96) ? 3 : 0;
+        const int wnb = (w.n % 128 == 0 || w.n >= 256) ? 4 : ((w.n > 64 && w.n <= 96) || w.n % 96 == 0) ? 3 : 0;
         if (wnb && ((w.n + 32 * wnb - 1) / (32 * wnb)) * ((a.M + 127) / 128) >= 256) {
             const dim3 gb((w.n + 32 * wnb - 1) / (32 * wnb), (a.M + 127) / 128);
             if (wnb == 4) hipLaunchKernelGGL((k_conv_gemm<32, 4, 4>), gb, dim3(256), 0, st, a);

@@ -956,12 +956,13 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
     __shared__ float ssq[8][16 * MT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    // ROWSPLIT (MT == 1 launched for 17..32 rows when N/16 <= 128): two blocks per column tile, one per 16-row tile, ids 8
-    // apart so that they land on the same XCD and the second reader of the weight tile hits that XCD's L2.
+    // ROWSPLIT: row_tiles blocks per column tile, one per 16*MT-row tile, ids 8 apart so that they land on the same XCD and
+    // the later readers of the weight tile hit that XCD's L2 (17..32 rows with few column tiles: 2 x 16 rows on twice the
+    // CUs; 33..64 rows: 2 x 32 rows).
     int ctile = blockIdx.x, r0 = 0;
     if (ROWSPLIT) {
-        ctile = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
-        r0 = ((blockIdx.x >> 3) & 1) * 16;
+        ctile = (blockIdx.x / (8 * a.row_tiles)) * 8 + (blockIdx.x & 7);
+        r0 = ((blockIdx.x >> 3) % a.row_tiles) * (16 * MT);
     }
     const int n0 = ctile * 16;
     const int kbase = wave * (KSTEPS * 32) + fk;
@@ -1101,19 +1102,30 @@ int vox_launch_swizzle_frag(hipStream_t st, const void* src, void* dst, int rows
 }
 
 static bool fullk_shape_ok(int B, int N, int K, int pro, int epi) {
-    if (B < 9 || B > 32 || N % 16 || K % 256) return false;
+    if (B < 9 || B > 64 || N % 16 || K % 256) return false;
+    if (B > 32 && N % 128) return false;          // 33..64 rows: two 32-row tiles per column tile (block ids 8 apart)
     const int ks = K / 256;
     if (pro == PRO_RMSNORM && (epi == EPI_STORE || epi == EPI_SILU_MUL)) return ks == 4 || ks == 8;
     if (pro == PRO_COPY && epi == EPI_STORE) return ks == 4 || ks == 8 || ks == 12 || ks == 24 || ks == 32;
     return false;
 }
 template <int MT, int KSTEPS, int PRO, int EPI>
-static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a) {
-    if constexpr (MT == 2 && PRO == PRO_COPY) {
-        // few column tiles: per-CU load rate is the limit, so use twice the CUs (two 16-row blocks per column tile)
-        if (a.N / 16 <= 128 && (a.N / 16) % 8 == 0) {
-            hipLaunchKernelGGL((k_gemm_fullk<1, KSTEPS, PRO, EPI, true>), dim3(a.N / 8), dim3(512), 0, st, a);
+static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a0) {
+    LinArgs a = a0;
+    a.row_tiles = 1;
+    if constexpr (MT == 2) {
+        if (a.B > 32) {            // 33..64 rows: two 32-row blocks per column tile
+            a.row_tiles = 2;
+            hipLaunchKernelGGL((k_gemm_fullk<2, KSTEPS, PRO, EPI, true>), dim3(a.N / 16 * 2), dim3(512), 0, st, a);
             return VOX_OK;
+        }
+        if constexpr (PRO == PRO_COPY) {
+            // few column tiles: per-CU load rate is the limit, so use twice the CUs (two 16-row blocks per column tile)
+            if (a.N / 16 <= 128 && (a.N / 16) % 8 == 0) {
+                a.row_tiles = 2;
+                hipLaunchKernelGGL((k_gemm_fullk<1, KSTEPS, PRO, EPI, true>), dim3(a.N / 8), dim3(512), 0, st, a);
+                return VOX_OK;
+            }
         }
     }
     hipLaunchKernelGGL((k_gemm_fullk<MT, KSTEPS, PRO, EPI, false>), dim3(a.N / 16), dim3(512), 0, st, a);
