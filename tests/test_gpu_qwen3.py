@@ -188,3 +188,56 @@ def test_full_size_qwen3_1p7b_one_frame(dev):
     """Qwen3-TTS-1.7B shapes (28+5 layers, random weights): 12-token prefill + 2 decode frames, greedy."""
     cfg = QR.Qwen3Cfg(text_vocab=4096, tts_pad_id=4095, max_pos=1024)   # text table shrunk (gathered, not streamed)
     run_parity(dev, cfg, QR.random_weights(cfg, 0, 0.02), [12], 2, page=128, max_pages=8)
+
+
+def test_full_size_b32_rows_independent_and_close_to_the_exact_path(dev):
+    """BASELINE config 2 shapes (Qwen3-TTS-1.7B, 32 concurrent requests) through the batched path (full-K MFMA GEMMs on
+    fragment-major weights, 64-row depth step 1, chunked talker attention): size-independent properties —
+      (1) determinism: the same batch twice gives identical ids and logits;
+      (2) row independence: a request's outputs do not depend on which rows its neighbours occupy (batch permuted);
+      (3) the batched logits sit within bf16 rounding of the 1-row fixed-order path (the one pinned bit-exactly to the oracle)."""
+    from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    B, ps, kv0, frames = 32, 128, 40, 3
+    g = torch.Generator(device="cpu").manual_seed(5)
+    kv_req = (torch.randn(B, cfg.talker.layers, 2, kv0, cfg.talker.kv_heads, cfg.talker.head_dim, generator=g) * 0.5).to(torch.bfloat16)
+    ids0 = torch.randint(0, cfg.vocab, (B, cfg.n_groups + 1), generator=g, dtype=torch.int32)
+    ids0[:, -1] = cfg.tts_pad_id
+    feats0 = (torch.randn(B, cfg.talker.hidden, generator=g) * 0.05).to(torch.bfloat16)
+
+    def run(order, max_batch):
+        """order[r] = request placed in row r"""
+        n = len(order)
+        eng = Qwen3Engine(cfg, W, max_batch=max_batch, page_size=ps, max_pages=max(8, 2 * n), max_seq_len=512, max_prefill_rows=16)
+        eng.keep_hidden = False
+        for r, q in enumerate(order):
+            eng.kv[:, r, :, :kv0] = kv_req[q].to(dev)
+            eng.input_ids[r] = ids0[q].to(dev)
+            eng.input_features[r] = feats0[q].to(dev)
+        eng.input_masks[:n] = 0
+        sc = eng.sampling_cfg(greedy=True)
+        out_ids, out_logits = [], []
+        for f in range(frames):
+            L = kv0 + 1 + f
+            eng.upload_plan(pos=[L] * n, kvlen=[L] * n, page=list(range(n)), slot=[L - 1] * n, indptr=list(range(n + 1)), indices=list(range(n)))
+            eng.frame(n, L, sc, feedback=True)
+            torch.cuda.synchronize()
+            out_ids.append(eng.out_ids[:n].cpu().clone())
+            out_logits.append(eng.out_logits[:n].float().cpu().clone())
+        del eng
+        return torch.stack(out_ids), torch.stack(out_logits)
+
+    ident = list(range(B))
+    ids_a, lg_a = run(ident, B)
+    ids_b, lg_b = run(ident, B)
+    assert torch.equal(ids_a, ids_b) and torch.equal(lg_a, lg_b)                      # (1)
+    perm = torch.randperm(B, generator=g).tolist()
+    ids_p, lg_p = run(perm, B)
+    inv = [perm.index(q) for q in range(B)]                                            # row of request q in the permuted batch
+    assert torch.equal(ids_p[:, inv], ids_a) and torch.equal(lg_p[:, inv], lg_a)      # (2)
+    for q in (0, 13, 31):                                                              # (3) frame 0: same inputs on both paths
+        ids_1, lg_1 = run([q], 1)
+        a, e = lg_a[0, q].double(), lg_1[0, 0].double()
+        assert float(((a - e) ** 2).mean().sqrt() / (e ** 2).mean().sqrt()) <= 2e-2
