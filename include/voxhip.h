@@ -199,7 +199,10 @@ void vox_qwen3_destroy(vox_qwen3* m);
 int vox_qwen3_frame(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int batch, int max_kvlen,
                     const vox_sampling_config* sampling, uint64_t seed, int feedback);
 /* Ragged prefill of n_rows tokens (one or more requests); logits/hidden of row `last_rows[r]` go to
- * out_logits/out_hidden row r, then sampling + depth loop run for n_req rows as in vox_qwen3_frame. */
+ * out_logits/out_hidden row r, then sampling + depth loop run for n_req rows as in vox_qwen3_frame.
+ * n_req == 0 (here and in vox_lm_prefill / vox_csm_prefill): a context chunk of a prompt longer than the row capacity —
+ * embedding + decoder stack only (K/V appended at the rows' page/slot), nothing sampled, no state advanced; the chunk
+ * that holds the prompt's last row is a normal call (the reference raises for > 1024 tokens, cuda_graph_worker.py:61). */
 int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const int32_t* row_ids /*[n_rows,n_groups+1]*/,
                       const uint8_t* row_masks, const void* row_features, const int32_t* q_req, int n_rows,
                       const int32_t* last_rows, int n_req, int max_kvlen, const vox_sampling_config* sampling,

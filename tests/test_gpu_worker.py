@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def build(dev, max_tokens=None):
+def build(dev, max_tokens=None, max_prefill_tokens=64):
     from oracle import qwen3_ref as QR, voxref as vr           # weights recipe only (test side)
     from tests.test_gpu_codec import small_cfg
     from oracle import qwen3_codec_ref as CR
@@ -28,7 +28,7 @@ def build(dev, max_tokens=None):
                           codec_language_id={"english": 16}, spk_id={"a": 17})
     m = Qwen3TTSModel("tiny", W, CR.random_codec_weights(cc, 3), config=to_engine_cfg(cfg), codec_config=pc, tokens=toks,
                       device=str(dev), detokenize_interval=4, max_batch_size=4, page_size=16, max_num_pages=64,
-                      max_seq_len=512, max_prefill_tokens=64)
+                      max_seq_len=512, max_prefill_tokens=max_prefill_tokens)
     m.default_sampling_config = SamplingConfig(greedy=True, max_tokens=max_tokens, repetition_penalty=1.05, repetition_window=-1)
     return m, cfg
 
@@ -233,3 +233,30 @@ def test_csm_served_end_to_end_with_mimi():
         assert nbytes >= 2 * hop * 20 and nbytes % 2 == 0, (rid, nbytes)
     assert w.empty_pages.qsize() == 64
     m.engine.close(); m.audio_decoder.close()
+
+
+def test_long_prompt_is_prefilled_in_context_chunks():
+    """A prompt longer than the engine's row capacity (the reference never schedules it: one 1024-token bucket) is
+    prefilled in equal context chunks + a final chunk: same first frame, same K/V, same continuation as the unchunked
+    prefill of an engine with room for it (every chunk stays on the 33+ row GEMM path, so per-row arithmetic is identical)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    prompt = [1, 2, 3] + rng.integers(20, 500, 120).tolist() + [7, 8, 9, 10, 11]      # 128 template tokens -> 134 prefill rows
+    outs = []
+    for cap in (48, 256):
+        m, cfg = build(dev, max_tokens=200, max_prefill_tokens=cap)
+        reqs, w = _drive_worker(m, [{"prompt_token_ids": prompt, "speaker": "a"}], steps=6)
+        r = reqs[0]
+        toks = torch.cat([t.reshape(1, -1).cpu() for t in r.lm_output_tokens])
+        n = r.kv_token_len
+        kv = m.engine.kv[:, r.kv_pages].float().cpu().clone()
+        outs.append((toks, n, kv))
+        if cap == 48:
+            assert m.engine.max_rows == 48 and w.cuda_graph_seq_len_buckets[-1] > 134
+        m.engine.close(); m.audio_decoder.close()
+    (t0, n0, kv0), (t1, n1, kv1) = outs
+    assert n0 == n1 and t0.shape == t1.shape and t0.shape[0] == 7
+    assert torch.equal(t0, t1)
+    assert torch.equal(kv0, kv1)

@@ -665,7 +665,7 @@ int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const 
                       const int32_t* last_rows, int n_req, int max_kvlen, const vox_sampling_config* sc, uint64_t seed,
                       int feedback) {
     if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "qwen3_prefill: NULL");
-    if (n_req < 1 || n_req > m->cfg.max_batch || n_rows > m->cfg.talker.max_rows)
+    if (n_req < 0 || n_req > m->cfg.max_batch || n_rows > m->cfg.talker.max_rows)
         return vox_fail(VOX_ERR_INVALID, "qwen3_prefill: n_req %d / n_rows %d out of range", n_req, n_rows);
     hipStream_t st = (hipStream_t)stream;
     VOX_TRY(qwen3_embed(m, st, row_ids, row_masks, row_features, n_rows));
@@ -673,6 +673,7 @@ int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const 
     r.pos = io->pos; r.q_req = q_req; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
     r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = n_rows; r.max_kvlen = max_kvlen;
     VOX_TRY(stack_layers(m->talker, st, m->x, io->kv, io->kv_layer_stride, &r));
+    if (n_req == 0) return VOX_OK;      // context chunk of a long prompt: K/V appended, nothing sampled
     VOX_TRY(qwen3_head(m, st, io, n_req, last_rows));
     return qwen3_tail(m, st, io, n_req, sc, seed, feedback);
 }
@@ -906,7 +907,7 @@ int vox_csm_prefill(vox_csm* m, void* stream, const vox_csm_io* io, const int32_
                     const int32_t* q_req, int n_rows, const int32_t* last_rows, int n_req, int max_kvlen,
                     const vox_sampling_config* sc, uint64_t seed, int feedback) {
     if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "csm_prefill: NULL");
-    if (n_req < 1 || n_req > m->cfg.max_batch || n_rows > m->cfg.backbone.max_rows)
+    if (n_req < 0 || n_req > m->cfg.max_batch || n_rows > m->cfg.backbone.max_rows)
         return vox_fail(VOX_ERR_INVALID, "csm_prefill: n_req %d / n_rows %d out of range", n_req, n_rows);
     hipStream_t st = (hipStream_t)stream;
     csm_embed(m, st, row_ids, row_masks, n_rows);
@@ -914,6 +915,7 @@ int vox_csm_prefill(vox_csm* m, void* stream, const vox_csm_io* io, const int32_
     r.pos = io->pos; r.q_req = q_req; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
     r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = n_rows; r.max_kvlen = max_kvlen;
     VOX_TRY(stack_layers(m->backbone, st, m->x, io->kv, io->kv_layer_stride, &r, false, n_rows <= 8));
+    if (n_req == 0) return VOX_OK;      // context chunk of a long prompt
     VOX_TRY(csm_head(m, st, io, n_req, last_rows));
     return csm_tail(m, st, io, n_req, sc, seed, feedback);
 }
@@ -957,6 +959,7 @@ static int lm_run(vox_lm* m, hipStream_t st, const vox_lm_io* io, const int32_t*
     if (c.input_mode == 1 && masks && feats)
         hipLaunchKernelGGL(k_where_rows, dim3((H + 255) / 256, n), dim3(256), 0, st, (bf16_t*)m->x, masks, (const bf16_t*)feats, H);
     VOX_TRY(stack_layers(m->stack, st, m->x, io->kv, io->kv_layer_stride, &r, decode_rows, n <= 8));
+    if (n_req == 0) return VOX_OK;      // context chunk of a long prompt
     LinearCall h;   // final norm + output head
     h.W = m->w.head_w; h.bias = m->w.head_b; h.x = m->x; h.x_rows = last_rows; h.norm_w = m->w.final_norm; h.eps = c.stack.eps;
     h.y = io->out_logits; h.B = n_req; h.N = c.vocab_out; h.K = H; h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
@@ -1017,7 +1020,7 @@ int vox_lm_prefill(vox_lm* m, void* stream, const vox_lm_io* io, const int32_t* 
                    const void* row_features, const int32_t* q_req, int n_rows, const int32_t* last_rows, int n_req,
                    int max_kvlen, const vox_sampling_config* sc, uint64_t seed, int feedback) {
     if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "lm_prefill: NULL");
-    if (n_req < 1 || n_req > m->cfg.max_batch || n_rows > m->cfg.stack.max_rows)
+    if (n_req < 0 || n_req > m->cfg.max_batch || n_rows > m->cfg.stack.max_rows)
         return vox_fail(VOX_ERR_INVALID, "lm_prefill: n_req %d / n_rows %d out of range", n_req, n_rows);
     vox_rows r{};
     r.pos = io->pos; r.q_req = q_req; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;

@@ -56,6 +56,14 @@ class ModelWorker:
         self._resident = None        # request ids whose next inputs already sit in the engine's rows (feedback path)
         self._resident_reqs = []     # ... and the requests themselves (their repetition-cache rows live in the engine)
         self._next_feats = None
+        # long prompts: the reference has one 1024-token prefill bucket and never schedules anything longer
+        # (scheduler/base.py:283-286, cuda_graph_worker.py:61); here a single request longer than the engine's row
+        # capacity is prefilled in context chunks (run_lm_prefill), so the scheduler may pick prompts up to the
+        # engine's sequence capacity.
+        e = getattr(model, "engine", None)
+        cap = int(getattr(e, "max_seq_len", 0)) - 2
+        if cap > 1024:
+            self.cuda_graph_seq_len_buckets = [1024, cap]
 
     # ---- properties read by schedulers (scheduler/base.py:127, 243-245) ----
     detokenize_interval = property(lambda self: self.model.detokenize_interval)
@@ -189,7 +197,9 @@ class ModelWorker:
         e = self.model.engine
         n_rows, n_req = int(lm_inputs["input_ids"].shape[0]), len(requests)
         if n_rows > e.max_rows:
-            raise RuntimeError(f"No suitable prefill graph found for batch_size={n_req}, seq_len={n_rows}")
+            if n_req != 1:      # (the scheduler admits one prefill per step; the reference raises for every overflow)
+                raise RuntimeError(f"No suitable prefill graph found for batch_size={n_req}, seq_len={n_rows}")
+            return self._run_long_prefill(requests, lm_inputs)
         q_req, kvlen, page, slot = self._token_plan(lm_inputs)
         e.row_ids[:n_rows].copy_(lm_inputs["input_ids"].to(torch.int32))
         if lm_inputs["input_masks"] is not None:     # Qwen3 consumes the text column's mask, CSM every column's
@@ -203,6 +213,33 @@ class ModelWorker:
                       last_rows=[q - 1 for q in qo[1:]], indptr=lm_inputs["paged_kv_indptr"],
                       indices=lm_inputs["paged_kv_indices"])
         e.prefill(n_rows, n_req, max(kvlen), self._sampling(), seed=self.seed, feedback=True)
+        self._after_frame(requests)
+        return None
+
+    def _run_long_prefill(self, requests: List[Request], lm_inputs: LMInputs):
+        """One request whose prompt exceeds the engine's row capacity: equal context chunks append K/V (no head, no
+        sampling), the last chunk carries the prompt's final row and runs the normal prefill tail.  Per-row arithmetic is
+        that of the unchunked prefill (rows only ever see K/V at earlier positions)."""
+        e = self.model.engine
+        n_rows = int(lm_inputs["input_ids"].shape[0])
+        q_req, kvlen, page, slot = self._token_plan(lm_inputs)
+        n_chunks = -(-n_rows // e.max_rows)
+        size = -(-n_rows // n_chunks)
+        pos = lm_inputs["position_ids"].numpy()
+        ids = lm_inputs["input_ids"].to(torch.int32)
+        self._stage_repetition(requests, e)
+        for c in range(n_chunks):
+            a, b = c * size, min(n_rows, (c + 1) * size)
+            m, last = b - a, c == n_chunks - 1
+            e.row_ids[:m].copy_(ids[a:b])
+            if lm_inputs["input_masks"] is not None:
+                mk = lm_inputs["input_masks"] if e.row_masks.dim() == 2 else lm_inputs["input_masks"][:, -1]
+                e.row_masks[:m].copy_(mk[a:b].to(torch.uint8))
+            if lm_inputs["input_features"] is not None:
+                self._stage_features(lm_inputs["input_features"][a:b], e.row_feats)
+            e.upload_plan(pos=pos[a:b], kvlen=kvlen[a:b], page=page[a:b], slot=slot[a:b], q_req=[0] * m, last_rows=[m - 1],
+                          indptr=lm_inputs["paged_kv_indptr"], indices=lm_inputs["paged_kv_indices"])
+            e.prefill(m, 1 if last else 0, max(kvlen[a:b]), self._sampling(), seed=self.seed, feedback=True)
         self._after_frame(requests)
         return None
 
