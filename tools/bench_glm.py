@@ -1,0 +1,60 @@
+"""BASELINE config 4, one GPU's share: GLM-4-Voice-9B (random-init weights of the named architecture), B = 8 of the 64
+data-parallel requests, the model's default top-p 0.8 / T 0.8 sampling over the 168 960-entry vocabulary.  One step = one
+LM token for the batch (GLM emits 12.5 audio tokens/s; 25 tokens -> 44 032 samples at 22.05 kHz through the flow + HiFT
+detokenizer, which is not built: LM tokens/s is what this measures).  Development measurement; prints one JSON line."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from vox_serve_amd.engine import LMEngine
+from vox_serve_amd.model.glm_voice import GLMVoiceConfig, pack_glm_weights
+from vox_serve_amd.synth import synth_glm_weights
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--warmup", type=int, default=20)
+ap.add_argument("--greedy", action="store_true")
+args = ap.parse_args()
+B, dev = args.batch, torch.device("cuda")
+gc = GLMVoiceConfig()
+layers, norm, emb, head = pack_glm_weights(synth_glm_weights(gc, dev), gc)
+eng = LMEngine(gc.lm_cfg(4096), layers, norm, emb, head, None, max_batch=B, page_size=128, max_pages=4 * B + 1, max_seq_len=1024, max_prefill_rows=64)
+ps, n0 = 128, 64
+rng = np.random.default_rng(1)
+pages = [[b * 4 + j for j in range(4)] for b in range(B)]
+sc = eng.sampling_cfg(greedy=True) if args.greedy else eng.sampling_cfg(greedy=False, top_k=0, top_p=0.8, temperature=0.8)
+for b in range(B):                       # 64-token prompt per request
+    eng.kv[:, pages[b][0], :, :n0].normal_(0, 0.5)
+eng.input_ids[:B, 0] = torch.from_numpy(rng.integers(152353, 168000, B).astype(np.int32)).to(dev)
+kv, pos = [n0] * B, [n0 + 1] * B
+ev = []
+
+def step(timed):
+    global kv, pos
+    kv = [k + 1 for k in kv]
+    npg = [(k + ps - 1) // ps for k in kv]
+    indptr = np.concatenate([[0], np.cumsum(npg)])
+    eng.upload_plan(pos=pos, kvlen=kv, page=[pages[b][npg[b] - 1] for b in range(B)], slot=[(k - 1) % ps for k in kv],
+                    indptr=indptr, indices=sum([pages[b][:npg[b]] for b in range(B)], []))
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(eng.stream)
+    eng.frame(B, max(kv), sc, feedback=True)
+    if timed:
+        e1.record(eng.stream); ev.append((e0, e1))
+    ids = eng.out_ids[:B].cpu()
+    pos = [p + 1 for p in pos]
+
+for i in range(args.warmup):
+    step(False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(args.steps):
+    step(True)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+frame_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+wbytes = sum(t.numel() * 2 for l in layers for t in l.values()) + head.numel() * 2
+print(json.dumps({"workload": f"GLM-4-Voice-9B bf16 LM, batch={B}/GPU, {'greedy' if args.greedy else 'top-p 0.8 T 0.8 over 168960 ids'}, 64-token context",
+                  "lm_tokens_per_s": B * args.steps / dt, "audio_seconds_per_s": B * args.steps / dt / 12.5, "ms_per_step": dt / args.steps * 1e3,
+                  "lm_graph_ms": frame_ms, "weight_bytes_streamed": wbytes, "hbm_frac_of_8TBps": wbytes / (frame_ms * 1e-3) / 8e12}))
