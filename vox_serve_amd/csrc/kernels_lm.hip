@@ -531,7 +531,8 @@ static int launch_linear_pe(hipStream_t st, const LinArgs& a, int n_cu) {
     const int outs = a.N;
     int r;  // outputs per wave: keep >= 2 blocks per CU in flight where N allows (latency hiding)
     (void)n_cu;
-    if (SM) r = 1;                                   // one gate row + one up row per wave
+    if (SM) r = (bt >= 4 && outs >= 8192) ? 2 : 1;   // one gate row + one up row per wave (two of each for very wide FFNs at >= 4 rows:
+                                                     // GLM-4-Voice B=8 token 12.7 -> 11.3 ms)
     else r = ((bt <= 2 && outs >= 8192) || (bt >= 4 && outs >= 2048)) ? 2 : 1;   // >= 4 rows: two weight rows share the
                                                                                      // unpacked activation pairs
     if ((size_t)bt * a.K * 2 > 160 * 1024) return vox_fail(VOX_ERR_INVALID, "linear: K too large for LDS staging");
