@@ -375,6 +375,15 @@ int vox_mimi_create(vox_ctx* ctx, const vox_mimi_config* cfg, const vox_mimi_wei
 void vox_mimi_destroy(vox_mimi* m);
 /* codes int32 [n, T, code_stride] (first n_q columns, clamped to [0, bins-1]); out fp32 [n, T * 2 * prod(ratios)] */
 int vox_mimi_decode(vox_mimi* m, void* stream, const int32_t* codes, int code_stride, int n, int T, float* out);
+/* Streaming option (the reference decodes every 10-frame chunk from a fresh state, mimi.py:3085-3089, although
+ * the module carries streaming state, mimi.py:2042-2215,1213-1305): per-slot look-back rows of every causal / transposed
+ * conv input and a K/V ring (context + chunk rows, post-RoPE keys) per transformer layer, RoPE at absolute positions.  Chunked
+ * output == one decode of the whole sequence (tests/test_gpu_codec.py), at the same cost per chunk as the stateless call.
+ * vox_mimi_stream_enable allocates the state for max_slots requests (once); slots: device int32 [n], distinct. */
+int vox_mimi_stream_enable(vox_mimi* m, int max_slots);
+int vox_mimi_reset_slot(vox_mimi* m, void* stream, int slot);
+int vox_mimi_decode_chunk(vox_mimi* m, void* stream, const int32_t* codes, int code_stride, const int32_t* slots, int n, int T,
+                          float* out);
 
 #ifdef __cplusplus
 }

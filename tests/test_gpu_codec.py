@@ -152,3 +152,52 @@ def test_mimi_full_size_matches_oracle_and_reference(dev, golden):
     wav2 = dec.decode(rows, code_layout="BTQ").cpu().numpy()
     assert np.array_equal(wav, wav2)
     dec.close()
+
+
+def _mimi_stream_case(dev, cfg, seed, B, chunks, order=None):
+    """stateful chunked decode on the GPU vs ONE oracle decode of the whole sequence (the decoder is causal)"""
+    from oracle import mimi_ref as MR
+    from vox_serve_amd.tokenizer.mimi import MimiConfig, MimiDecoder
+    W = MR.random_mimi_weights(cfg, seed=seed)
+    pc = MimiConfig(**{k: getattr(cfg, k) for k in MimiConfig.__dataclass_fields__ if hasattr(cfg, k)})
+    T = sum(chunks)
+    dec = MimiDecoder(W, pc, device=dev, max_batch=max(2, B), max_frames=max(chunks))
+    dec.enable_streaming(B + 1)
+    g = torch.Generator().manual_seed(seed)
+    codes = torch.randint(0, cfg.bins, (B, cfg.n_q, T), generator=g)
+    ref = MR.MimiRef(cfg, W).decode(codes).numpy()
+    junk = dec.alloc_slot()                                  # a slot that saw other audio first, then is reused below
+    dec.decode_chunk(codes[:1, :, :chunks[0]], [junk])
+    dec.free_slot(junk)
+    slots = [dec.alloc_slot() for _ in range(B)]
+    got = np.zeros_like(ref)
+    t0, hop = 0, ref.shape[-1] // T
+    for ci, n in enumerate(chunks):
+        rows = list(range(B)) if order is None else order[ci % len(order)]
+        for grp in (rows if isinstance(rows[0], list) else [rows]):      # requests may arrive in separate calls
+            w = dec.decode_chunk(codes[grp, :, t0:t0 + n], [slots[r] for r in grp]).cpu().numpy()
+            got[grp, :, t0 * hop:(t0 + n) * hop] = w
+        t0 += n
+    dec.close()
+    return got, ref
+
+
+def test_mimi_streaming_equals_whole_sequence_decode(dev):
+    """per-slot streaming state (conv look-back rows, K/V ring with absolute RoPE positions).  Tiny config with a
+    24-row attention context so that 30 frames (60 transformer rows) wrap the ring and cross the context edge; equal and
+    ragged chunkings, requests batched together or in separate calls, a reused slot."""
+    from oracle import mimi_ref as MR
+    cfg = MR.tiny_mimi_cfg()
+    cfg.context = 24
+    for chunks, order in (([10, 10, 10], None), ([4, 10, 7, 9], None), ([10, 5, 10, 5], [[[0, 2], [1]], [[1], [2, 0]]])):
+        got, ref = _mimi_stream_case(dev, cfg, 2, 3, chunks, order)
+        assert np.sqrt(np.mean(ref ** 2)) > 0.1
+        assert np.sqrt(np.mean((got - ref) ** 2)) < 1e-4, chunks
+
+
+@pytest.mark.slow
+def test_mimi_streaming_full_size(dev):
+    from oracle import mimi_ref as MR
+    got, ref = _mimi_stream_case(dev, MR.MimiCfg(), 1, 2, [10, 10, 10])
+    assert got.shape == (2, 1, 57600)
+    assert np.sqrt(np.mean((got - ref) ** 2)) < 1e-4

@@ -260,3 +260,63 @@ def test_long_prompt_is_prefilled_in_context_chunks():
     assert n0 == n1 and t0.shape == t1.shape and t0.shape[0] == 7
     assert torch.equal(t0, t1)
     assert torch.equal(kv0, kv1)
+
+
+def test_csm_stateful_mimi_option_streams_without_seams():
+    """CSMModel(stateful_codec=True): every request keeps its Mimi state in a slot (allocated by preprocess, released with the
+    request), so the served PCM equals ONE Mimi decode of the request's whole code sequence (the reference's stateless
+    chunks differ from that at every chunk border)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    from oracle import csm_ref as CR, mimi_ref as MR, voxref as vr
+    from tests.test_gpu_csm import to_engine_cfg
+    from vox_serve_amd.model.csm import CSMModel
+    from vox_serve_amd.sampling import SamplingConfig
+    from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
+    from vox_serve_amd.tokenizer.mimi import MimiConfig
+    from vox_serve_amd.worker import ModelWorker
+    cfg, mc = CR.tiny_csm_cfg(), MR.tiny_mimi_cfg()
+    pc = MimiConfig(**{k: getattr(mc, k) for k in MimiConfig.__dataclass_fields__ if hasattr(mc, k)})
+    Wm = MR.random_mimi_weights(mc, 1)
+    pcm = {}
+    for stateful in (True, False):
+        m = CSMModel("tiny-csm", {k: vr.to_torch(v).to(dev) for k, v in CR.random_csm_state_dict(cfg, 7, 0.08).items()},
+                     config=to_engine_cfg(cfg), sampling=SamplingConfig(greedy=True), codec_weights=Wm, codec_config=pc, device=str(dev),
+                     max_batch_size=4, page_size=16, max_num_pages=64, max_seq_len=512, max_prefill_tokens=64, stateful_codec=stateful)
+        t = QueueTransport()
+        w = ModelWorker(model=m, max_batch_size=4, max_num_pages=64, page_size=16, device=m.device)
+        s = Scheduler(w, max_batch_size=4, transport=t)
+        for rid, ids in {"a": [4, 200, 31], "b": [9, 8, 7, 6, 5]}.items():
+            t.requests.put(encode_request(rid, "", model_kwargs={"prompt_token_ids": ids}))
+        reqs = {}
+        for _ in range(400):
+            s._step()
+            reqs.update({r.request_id: r for r in s.active_requests})
+            if all(len(r.lm_output_audio_tokens) >= 30 for r in s.active_requests) or not s.active_requests:
+                break
+        for r in s.active_requests:
+            r.done_lm_generation, r.finish_reason = True, "max_tokens_reached"
+        s.run_until_idle(200)
+        out = {"a": b"", "b": b""}
+        while not t.results.empty():
+            rid, kind, body = t.results.get().split(b"|", 2)
+            if kind == b"AUDIO":
+                out[rid.decode()] += body
+        pcm[stateful] = out
+        if stateful:
+            hop, interval = m.audio_decoder.hop, m.detokenize_interval
+            for rid, r in reqs.items():
+                codes = torch.cat(r.lm_output_audio_tokens, 0)[:, :mc.n_q].T[None].long()           # [1, Q, T]
+                n_full = (codes.shape[2] // interval) * interval                                    # whole chunks: no padding / trim
+                whole = MR.MimiRef(mc, Wm).decode(codes[:, :, :n_full]).numpy()[0, 0]
+                got = np.frombuffer(out[rid], dtype=np.int16)[: n_full * hop].astype(np.int32)
+                want = (whole * 32767).astype(np.int16).astype(np.int32)
+                assert got.shape == want.shape and n_full >= 2 * interval
+                assert np.abs(got - want).max() <= 2, rid                                           # int16 truncation of 1e-5-close floats
+            assert len(m.audio_decoder._free_slots) == m.audio_decoder.max_slots                     # slots returned
+        m.engine.close(); m.audio_decoder.close()
+    # same tokens either way (the codec does not feed back), different audio after the first chunk border
+    a_s, a_l = (np.frombuffer(pcm[k]["a"], dtype=np.int16) for k in (True, False))
+    n = min(len(a_s), len(a_l))
+    assert np.array_equal(a_s[:100], a_l[:100]) and not np.array_equal(a_s[:n], a_l[:n])

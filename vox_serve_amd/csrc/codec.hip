@@ -755,14 +755,16 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
 // K-S rightmost samples: exactly the part the second tap of the NEXT chunk would add).
 // ================================================================================================
 // y[b, 2t+j, c] = x[b,t,c] * w[c][j] + x[b,t-1,c] * w[c][j+2]        (ConvTrUpsample1d, mimi.py:2272-2323)
-__global__ __launch_bounds__(256) void k_mimi_upsample(const float* x, const float* w, float* y, int L, int C, size_t total) {
+// state (streaming): [slots][1][C] = the previous chunk's last input row; NULL = fresh state (zeros)
+__global__ __launch_bounds__(256) void k_mimi_upsample(const float* x, const float* w, float* y, int L, int C, size_t total,
+                                                        const float* state, const int* slots) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const size_t row = i / C;                     // output row = b*2L + 2t + j
         const int tj = (int)(row % (2 * (size_t)L)), t = tj >> 1, j = tj & 1;
         const size_t b = row / (2 * (size_t)L);
         const float cur = x[(b * L + t) * C + c];
-        const float prev = t > 0 ? x[(b * L + t - 1) * C + c] : 0.0f;
+        const float prev = t > 0 ? x[(b * L + t - 1) * C + c] : (state ? state[(size_t)slots[b] * C + c] : 0.0f);
         y[i] = cur * w[c * 4 + j] + prev * w[c * 4 + j + 2];
     }
 }
@@ -844,8 +846,85 @@ __global__ __launch_bounds__(256) void k_mimi_attn(const float* qkv, float* out,
         __threadfence_block();
     }
 }
+// Streaming variant: queries = the L new rows at absolute positions pos0 .. pos0+L-1 of the slot, keys = the slot's K/V ring
+// (post-RoPE K) + the new rows; visibility 0 <= p_q - p_k < context.  Ring capacity RC >= context + L - 1 so that a new key
+// never overwrites one an earlier query of the same chunk still sees.  One block per (head, request): the visible K window
+// (<= context + L - 1 rows) sits in LDS (row stride D+1), V is read from the ring (coalesced rows, L2-resident).
+__global__ __launch_bounds__(256) void k_mimi_attn_stream(const float* qkv, float* out, float* kring, float* vring, const long* pos,
+                                                           const int* slots, int L, int H, int D, int context, int RC, float max_period) {
+    extern __shared__ float sm[];   // Q [L][D], K [context+L][D+1], P [4][context+L]
+    const int LD = D + 1, W = context + L;
+    float* Qs = sm;
+    float* Ks = Qs + (size_t)L * D;
+    float* Ps = Ks + (size_t)W * LD;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HD = H * D;
+    const long p0 = pos[slots[b]];
+    float* kr = kring + (size_t)slots[b] * RC * HD + (size_t)h * D;     // row stride HD
+    float* vr = vring + (size_t)slots[b] * RC * HD + (size_t)h * D;
+    for (int e = tid; e < L * (D / 2); e += 256) {       // RoPE the new q / k at their absolute positions, append k / v
+        const int t = e / (D / 2), i = e % (D / 2);
+        const float* r = qkv + ((size_t)(b * L + t)) * 3 * HD + (size_t)h * D + 2 * i;
+        const float freq = expf((float)i * (-logf(max_period) * 2.0f / (float)D));
+        const float ang = freq * (float)(p0 + t);
+        const float cr = cosf(ang), ci = sinf(ang);
+        const float qr = r[0], qi = r[1], k0 = r[HD], k1 = r[HD + 1];
+        Qs[t * D + 2 * i] = qr * cr - qi * ci;
+        Qs[t * D + 2 * i + 1] = qr * ci + qi * cr;
+        const size_t ro = (size_t)((p0 + t) % RC) * HD + 2 * i;
+        kr[ro] = k0 * cr - k1 * ci;
+        kr[ro + 1] = k0 * ci + k1 * cr;
+        vr[ro] = r[2 * HD];
+        vr[ro + 1] = r[2 * HD + 1];
+    }
+    __syncthreads();                                       // (block-scope: this block is the only reader of its ring rows)
+    const long lo = (p0 - context + 1) > 0 ? (p0 - context + 1) : 0;     // oldest position any query of the chunk sees
+    const int nk = (int)(p0 + L - lo);                     // window rows [lo, p0+L)
+    for (int e = tid; e < nk * D; e += 256) {
+        const int j = e / D, d = e % D;
+        Ks[j * LD + d] = kr[(size_t)((lo + j) % RC) * HD + d];
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)D);
+    float* P = Ps + (size_t)wave * W;
+    for (int i = wave; i < L; i += 4) {
+        const float* q = Qs + (size_t)i * D;
+        const long pq = p0 + i;
+        float mx = -INFINITY;
+        for (int j = lane; j < nk; j += 64) {
+            const long pk = lo + j;
+            float sc = -INFINITY;
+            if (pk <= pq && (pq - pk) < context) {
+                sc = 0.0f;
+                for (int d = 0; d < D; ++d) sc = fmaf(q[d], Ks[j * LD + d], sc);
+                sc *= scale;
+            }
+            P[j] = sc;
+            mx = fmaxf(mx, sc);
+        }
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float ls = 0.0f;
+        for (int j = lane; j < nk; j += 64) {
+            const float pj = P[j] == -INFINITY ? 0.0f : expf(P[j] - mx);
+            P[j] = pj;
+            ls += pj;
+        }
+        for (int off = 32; off >= 1; off >>= 1) ls += __shfl_xor(ls, off, 64);
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int jlo = (int)((pq - context + 1 > lo ? pq - context + 1 : lo) - lo), jhi = (int)(pq - lo);
+        for (int d = lane; d < D; d += 64) {
+            float o = 0.0f;
+            for (int jj = jlo; jj <= jhi; ++jj) o = fmaf(P[jj], vr[(size_t)((lo + jj) % RC) * HD + d], o);
+            out[((size_t)(b * L + i)) * HD + (size_t)h * D + d] = o / ls;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+}
 // last conv: C -> 1 channel, kernel K, zero history
-__global__ __launch_bounds__(256) void k_mimi_final(const float* x, const float* w, float bias, float* out, int L, int C, int K) {
+__global__ __launch_bounds__(256) void k_mimi_final(const float* x, const float* w, float bias, float* out, int L, int C, int K,
+                                                     const float* state, const int* slots) {
     const int b = blockIdx.y;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= L) return;
@@ -854,6 +933,7 @@ __global__ __launch_bounds__(256) void k_mimi_final(const float* x, const float*
         const int k = e / C, c = e % C;
         const int r = t - (K - 1) + k;
         if (r >= 0) acc += w[c * K + k] * x[((size_t)b * L + r) * C + c];
+        else if (state) acc += w[c * K + k] * state[((size_t)slots[b] * (K - 1) + (K - 1 + r)) * C + c];   // streaming history
     }
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (lane == 0) out[(size_t)b * L + t] = acc + bias;
@@ -866,6 +946,12 @@ struct vox_mimi {
     int max_batch, max_frames;
     float *q0, *qr, *buf[4];
     int32_t* zero_slots;
+    // streaming state (vox_mimi_stream_enable), per slot: the look-back rows of every causal conv / transposed conv input,
+    // a K/V ring per transformer layer and the number of transformer-rate rows seen so far
+    int max_slots = 0, ring_cap = 0;
+    float *st_up = nullptr, *st_dec0 = nullptr, *st_tc[4] = {nullptr, nullptr, nullptr, nullptr},
+          *st_c1[4] = {nullptr, nullptr, nullptr, nullptr}, *st_final = nullptr, *kring = nullptr, *vring = nullptr;
+    long* pos = nullptr;
 };
 
 static void elu(hipStream_t st, const float* x, float* y, size_t total) {
@@ -905,17 +991,20 @@ int vox_mimi_create(vox_ctx* ctx, const vox_mimi_config* cfg, const vox_mimi_wei
 void vox_mimi_destroy(vox_mimi* m) {
     if (!m) return;
     (void)hipFree(m->q0); (void)hipFree(m->qr); (void)hipFree(m->zero_slots);
+    (void)hipFree(m->st_up); (void)hipFree(m->st_dec0); (void)hipFree(m->st_final); (void)hipFree(m->kring); (void)hipFree(m->vring); (void)hipFree(m->pos);
+    for (int b = 0; b < 4; ++b) { (void)hipFree(m->st_tc[b]); (void)hipFree(m->st_c1[b]); }
     for (int i = 0; i < 4; ++i) (void)hipFree(m->buf[i]);
     delete m;
 }
-int vox_mimi_decode(vox_mimi* m, void* stream, const int32_t* codes, int code_stride, int n, int T, float* out) {
-    if (!m || !codes || !out) return vox_fail(VOX_ERR_INVALID, "mimi_decode: NULL");
-    if (n < 1 || n > m->max_batch || T < 1 || T > m->max_frames) return vox_fail(VOX_ERR_INVALID, "mimi_decode: n=%d T=%d out of range", n, T);
-    hipStream_t st = (hipStream_t)stream;
+}  // extern "C"
+
+// slots == NULL: stateless chunk (fresh state: the reference's MimiDecoder.decode); else streaming on the given state slots
+static int mimi_run(vox_mimi* m, hipStream_t st, const int32_t* codes, int code_stride, const int32_t* slots, int n, int T, float* out) {
     const vox_mimi_config& c = m->cfg;
     const vox_mimi_weights& w = m->w;
     const int C = c.dim, H = c.num_heads, D = c.dim / c.num_heads;
-    const int* sl = m->zero_slots;
+    const bool S = slots != nullptr;
+    const int* sl = S ? slots : m->zero_slots;
     float *A = m->buf[0], *B = m->buf[1], *Cb = m->buf[2], *Db = m->buf[3];
     const int off0[1] = {0};
     int L = T;
@@ -926,24 +1015,35 @@ int vox_mimi_decode(vox_mimi* m, void* stream, const int32_t* codes, int code_st
         const size_t total = (size_t)n * 2 * L * C;
         int grid = (int)((total + 255) / 256);
         if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(k_mimi_upsample, dim3(grid), dim3(256), 0, st, B, w.up_w, A, L, C, total);        // A [n*2L, dim]
+        hipLaunchKernelGGL(k_mimi_upsample, dim3(grid), dim3(256), 0, st, B, w.up_w, A, L, C, total, S ? m->st_up : nullptr, sl);   // A [n*2L, dim]
+        if (S) state_update(st, m->st_up, sl, B, n, L, 1, C);
     }
     L *= 2;
     for (int l = 0; l < c.num_layers; ++l) {                                                                 // h = A
         const vox_mimi_layer_w& lw = w.layers[l];
         hipLaunchKernelGGL(k_layernorm_f32, dim3(n * L), dim3(256), 0, st, A, lw.ln1_w, lw.ln1_b, Cb, C, c.ln_eps);
         VOX_TRY(conv_gemm(st, lw.qkv, Cb, nullptr, sl, n, L, 0, off0, Db, nullptr, nullptr, 0));             // Db [nL, 3*dim]
-        hipLaunchKernelGGL(k_mimi_attn, dim3(H, n), dim3(256), (size_t)(L * D + 2 * L * (D + 1) + 4 * L) * 4, st, Db, Cb, L, H, D,
-                           c.context, c.max_period);
+        if (S) {
+            const size_t ring = (size_t)m->max_slots * m->ring_cap * C;
+            const size_t smem = ((size_t)L * D + (size_t)(c.context + L) * (D + 1) + 4 * (size_t)(c.context + L)) * 4;
+            hipLaunchKernelGGL(k_mimi_attn_stream, dim3(H, n), dim3(256), smem, st, Db, Cb, m->kring + l * ring, m->vring + l * ring,
+                               m->pos, sl, L, H, D, c.context, m->ring_cap, c.max_period);
+        } else {
+            hipLaunchKernelGGL(k_mimi_attn, dim3(H, n), dim3(256), (size_t)(L * D + 2 * L * (D + 1) + 4 * L) * 4, st, Db, Cb, L, H, D,
+                               c.context, c.max_period);
+        }
         VOX_TRY(conv_gemm(st, lw.o, Cb, nullptr, sl, n, L, 0, off0, A, A, lw.scale1, 0));                    // h += s1 * o(attn)
         hipLaunchKernelGGL(k_layernorm_f32, dim3(n * L), dim3(256), 0, st, A, lw.ln2_w, lw.ln2_b, Cb, C, c.ln_eps);
         VOX_TRY(conv_gemm(st, lw.fc1, Cb, nullptr, sl, n, L, 0, off0, Db, nullptr, nullptr, 1));             // GELU
         VOX_TRY(conv_gemm(st, lw.fc2, Db, nullptr, sl, n, L, 0, off0, A, A, lw.scale2, 0));                  // h += s2 * mlp
     }
+    if (S) hipLaunchKernelGGL(k_pos_advance, dim3((n + 255) / 256), dim3(256), 0, st, m->pos, sl, n, L);
     // ---- SEANet decoder ----
     int offk[CG_MAXTAPS];
     for (int k = 0; k < c.kernel_size; ++k) offk[k] = c.kernel_size - 1 - k;
-    VOX_TRY(conv_gemm(st, w.dec0, A, nullptr, sl, n, L, 0, offk, B, nullptr, nullptr, 0));                   // B [nL, 16 nf]
+    const int Pk = c.kernel_size - 1;
+    VOX_TRY(conv_gemm(st, w.dec0, A, S ? m->st_dec0 : nullptr, sl, n, L, S ? Pk : 0, offk, B, nullptr, nullptr, 0));   // B [nL, 16 nf]
+    if (S) state_update(st, m->st_dec0, sl, A, n, L, Pk, C);
     float *h = B, *t1 = A, *t2 = Cb, *t3 = Db;
     int ch = 16 * c.n_filters;
     for (int b = 0; b < 4; ++b) {
@@ -951,19 +1051,79 @@ int vox_mimi_decode(vox_mimi* m, void* stream, const int32_t* codes, int code_st
         const int r = c.ratios[b];
         elu(st, h, t1, (size_t)n * L * ch);
         const int offt[2] = {0, 1};
-        VOX_TRY(conv_gemm(st, bw.tconv, t1, nullptr, sl, n, L, 0, offt, t2, nullptr, nullptr, 0));           // t2 [n*L*r, ch/2]
+        VOX_TRY(conv_gemm(st, bw.tconv, t1, S ? m->st_tc[b] : nullptr, sl, n, L, S ? 1 : 0, offt, t2, nullptr, nullptr, 0));   // t2 [n*L*r, ch/2]
+        if (S) state_update(st, m->st_tc[b], sl, t1, n, L, 1, ch);
         L *= r;
         ch /= 2;
         { float* x = h; h = t2; t2 = x; }
         elu(st, h, t1, (size_t)n * L * ch);
         const int off3[3] = {2, 1, 0};
-        VOX_TRY(conv_gemm(st, bw.conv1, t1, nullptr, sl, n, L, 0, off3, t3, nullptr, nullptr, 0));           // t3 [nL, ch/2]
+        VOX_TRY(conv_gemm(st, bw.conv1, t1, S ? m->st_c1[b] : nullptr, sl, n, L, S ? 2 : 0, off3, t3, nullptr, nullptr, 0));   // t3 [nL, ch/2]
+        if (S) state_update(st, m->st_c1[b], sl, t1, n, L, 2, ch);
         elu(st, t3, t1, (size_t)n * L * (ch / 2));
         VOX_TRY(conv_gemm(st, bw.conv2, t1, nullptr, sl, n, L, 0, off0, h, h, nullptr, 0));                  // h += conv2(...)
     }
     elu(st, h, t1, (size_t)n * L * ch);
-    hipLaunchKernelGGL(k_mimi_final, dim3((L + 3) / 4, n), dim3(256), 0, st, t1, w.final_w, w.final_b, out, L, ch, c.last_kernel_size);
+    hipLaunchKernelGGL(k_mimi_final, dim3((L + 3) / 4, n), dim3(256), 0, st, t1, w.final_w, w.final_b, out, L, ch, c.last_kernel_size,
+                       S ? m->st_final : nullptr, sl);
+    if (S) state_update(st, m->st_final, sl, t1, n, L, c.last_kernel_size - 1, ch);
     return VOX_OK;
+}
+
+extern "C" {
+
+int vox_mimi_decode(vox_mimi* m, void* stream, const int32_t* codes, int code_stride, int n, int T, float* out) {
+    if (!m || !codes || !out) return vox_fail(VOX_ERR_INVALID, "mimi_decode: NULL");
+    if (n < 1 || n > m->max_batch || T < 1 || T > m->max_frames) return vox_fail(VOX_ERR_INVALID, "mimi_decode: n=%d T=%d out of range", n, T);
+    return mimi_run(m, (hipStream_t)stream, codes, code_stride, nullptr, n, T, out);
+}
+
+int vox_mimi_stream_enable(vox_mimi* m, int max_slots) {
+    if (!m || max_slots < 1 || m->max_slots) return vox_fail(VOX_ERR_INVALID, "mimi_stream_enable: bad argument or already enabled");
+    const vox_mimi_config& c = m->cfg;
+    if (c.kernel_size - 1 > 8 || c.last_kernel_size < 2) return vox_fail(VOX_ERR_INVALID, "mimi_stream_enable: unsupported kernel sizes");
+    const size_t S = max_slots, C = c.dim;
+    m->ring_cap = c.context + 2 * m->max_frames;           // >= context + L - 1
+    bool ok = hipMalloc((void**)&m->st_up, S * C * 4) == hipSuccess && hipMalloc((void**)&m->st_dec0, S * (c.kernel_size - 1) * C * 4) == hipSuccess &&
+              hipMalloc((void**)&m->kring, (size_t)c.num_layers * S * m->ring_cap * C * 4) == hipSuccess &&
+              hipMalloc((void**)&m->vring, (size_t)c.num_layers * S * m->ring_cap * C * 4) == hipSuccess &&
+              hipMalloc((void**)&m->pos, S * sizeof(long)) == hipSuccess;
+    size_t ch = (size_t)16 * c.n_filters;
+    for (int b = 0; ok && b < 4; ++b) {
+        ok = hipMalloc((void**)&m->st_tc[b], S * ch * 4) == hipSuccess && hipMalloc((void**)&m->st_c1[b], S * 2 * (ch / 2) * 4) == hipSuccess;
+        ch /= 2;
+    }
+    ok = ok && hipMalloc((void**)&m->st_final, S * (c.last_kernel_size - 1) * ch * 4) == hipSuccess;
+    if (!ok) return vox_fail(VOX_ERR_NOMEM, "mimi_stream_enable: hipMalloc failed");
+    m->max_slots = max_slots;
+    for (int sl = 0; sl < max_slots; ++sl) VOX_TRY(vox_mimi_reset_slot(m, nullptr, sl));
+    VOX_HIP(hipDeviceSynchronize());
+    return VOX_OK;
+}
+
+int vox_mimi_reset_slot(vox_mimi* m, void* stream, int slot) {
+    if (!m || slot < 0 || slot >= m->max_slots) return vox_fail(VOX_ERR_INVALID, "mimi_reset_slot: slot %d out of range", slot);
+    hipStream_t st = (hipStream_t)stream;
+    const vox_mimi_config& c = m->cfg;
+    const size_t C = c.dim;
+    VOX_HIP(hipMemsetAsync(m->st_up + (size_t)slot * C, 0, C * 4, st));
+    VOX_HIP(hipMemsetAsync(m->st_dec0 + (size_t)slot * (c.kernel_size - 1) * C, 0, (c.kernel_size - 1) * C * 4, st));
+    size_t ch = (size_t)16 * c.n_filters;
+    for (int b = 0; b < 4; ++b) {
+        VOX_HIP(hipMemsetAsync(m->st_tc[b] + (size_t)slot * ch, 0, ch * 4, st));
+        VOX_HIP(hipMemsetAsync(m->st_c1[b] + (size_t)slot * 2 * (ch / 2), 0, 2 * (ch / 2) * 4, st));
+        ch /= 2;
+    }
+    VOX_HIP(hipMemsetAsync(m->st_final + (size_t)slot * (c.last_kernel_size - 1) * ch, 0, (c.last_kernel_size - 1) * ch * 4, st));
+    VOX_HIP(hipMemsetAsync(m->pos + slot, 0, sizeof(long), st));     // (the K/V ring needs no clearing: only positions < pos are read)
+    return VOX_OK;
+}
+
+int vox_mimi_decode_chunk(vox_mimi* m, void* stream, const int32_t* codes, int code_stride, const int32_t* slots, int n, int T, float* out) {
+    if (!m || !codes || !out || !slots) return vox_fail(VOX_ERR_INVALID, "mimi_decode_chunk: NULL");
+    if (!m->max_slots) return vox_fail(VOX_ERR_INVALID, "mimi_decode_chunk: call vox_mimi_stream_enable first");
+    if (n < 1 || n > m->max_batch || T < 1 || T > m->max_frames) return vox_fail(VOX_ERR_INVALID, "mimi_decode_chunk: n=%d T=%d out of range", n, T);
+    return mimi_run(m, (hipStream_t)stream, codes, code_stride, slots, n, T, out);
 }
 
 }  // extern "C"

@@ -18,7 +18,8 @@ from .base import BaseLMWithDepth, PreprocessOutput
 class CSMModel(BaseLMWithDepth):
     def __init__(self, model_name: str, weights: Dict[str, torch.Tensor], config: Optional[CSMCfg] = None, text_tokenizer=None,
                  device="cuda:0", dtype=torch.bfloat16, audio_decoder_device=None, sampling: Optional[SamplingConfig] = None,
-                 codec_weights: Optional[Dict[str, torch.Tensor]] = None, codec_config=None, max_batch_size=8, page_size=128, max_num_pages=2048, max_seq_len=2304, max_prefill_tokens=1024, **kw):
+                 codec_weights: Optional[Dict[str, torch.Tensor]] = None, codec_config=None, max_batch_size=8, page_size=128, max_num_pages=2048, max_seq_len=2304, max_prefill_tokens=1024,
+                 stateful_codec: bool = False, **kw):
         super().__init__(model_name, device, dtype, False, audio_decoder_device)
         self.config = config or CSMCfg()
         self.text_tokenizer = text_tokenizer
@@ -34,6 +35,11 @@ class CSMModel(BaseLMWithDepth):
             from ..tokenizer.mimi import MimiDecoder
             self.audio_decoder = MimiDecoder(codec_weights, codec_config, num_codebooks=self.config.n_codebooks,
                                              device=self.audio_decoder_device, max_batch=max_batch_size, max_frames=10)
+            # option, NOT the reference's behaviour (it decodes every chunk from a fresh state: seams at chunk borders): each
+            # request keeps its Mimi streaming state in a slot, chunks continue seamlessly
+            if stateful_codec:
+                self.audio_decoder.enable_streaming(max(64, 2 * max_batch_size))
+        self.stateful_codec = bool(stateful_codec and self.audio_decoder is not None)
 
     n_codebooks = property(lambda self: self.config.n_codebooks + 1)
     depth_n_codebooks = property(lambda self: self.config.n_codebooks)
@@ -97,7 +103,8 @@ class CSMModel(BaseLMWithDepth):
         if context is None:
             toks = torch.cat(self.default_context["tokens"] + [toks], dim=0)
             mask = torch.cat(self.default_context["tokens_mask"] + [mask], dim=0)
-        return PreprocessOutput(input_tokens=toks, input_masks=mask, repetition_cache=None)
+        return PreprocessOutput(input_tokens=toks, input_masks=mask, repetition_cache=None,
+                                decoder_cache=self.audio_decoder_initial_cache(1) if self.stateful_codec else None)
 
     def update_requests(self, requests, out: torch.Tensor):
         """out [B, 33] int64 on the host (all 32 codes already sampled): csm.py:699-725 + 760-768."""
@@ -122,4 +129,10 @@ class CSMModel(BaseLMWithDepth):
         audio [B, 1, interval*1920]; Mimi is stateless per chunk like the reference (csm.py:772-787)."""
         if self.audio_decoder is None:
             raise RuntimeError("CSMModel: no Mimi weights loaded (pass codec_weights=...)")
+        cache = kwargs.get("decoder_cache")
+        if self.stateful_codec and cache is not None:
+            return self.audio_decoder.decode_chunk(token_ids, cache.slot.tolist(), code_layout="BTQ")
         return self.audio_decoder.decode(token_ids, code_layout="BTQ")
+
+    def audio_decoder_initial_cache(self, batch_size: int):
+        return self.audio_decoder.init_cache(batch_size) if self.stateful_codec else None

@@ -14,6 +14,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _native as N
+from .base import DecoderCache
 from .qwen3_codec import ConvW
 
 
@@ -104,7 +105,17 @@ def _bind(L):
                                                                 ctypes.POINTER(vp)]
     L.vox_mimi_destroy.restype, L.vox_mimi_destroy.argtypes = None, [vp]
     L.vox_mimi_decode.restype, L.vox_mimi_decode.argtypes = ci, [vp, vp, vp, ci, ci, ci, vp]
+    L.vox_mimi_stream_enable.restype, L.vox_mimi_stream_enable.argtypes = ci, [vp, ci]
+    L.vox_mimi_reset_slot.restype, L.vox_mimi_reset_slot.argtypes = ci, [vp, vp, ci]
+    L.vox_mimi_decode_chunk.restype, L.vox_mimi_decode_chunk.argtypes = ci, [vp, vp, vp, ci, vp, ci, ci, vp]
     L._mimi_bound = True
+
+
+@dataclass
+class MimiDecoderCache(DecoderCache):
+    """Handle on the in-place streaming state of one request (stateful option): `slot` indexes the engine's state arrays.
+    A [1]-shaped int32 tensor so that DecoderCache.cat / __getitem__ keep their meaning."""
+    slot: Optional[torch.Tensor] = None
 
 
 class MimiDecoder:
@@ -192,6 +203,49 @@ class MimiDecoder:
         for b0 in range(0, b, self.max_batch):
             nb = min(self.max_batch, b - b0)
             N.check(self.L.vox_mimi_decode(self.h, N.stream(), codes[b0:b0 + nb].data_ptr(), stride, nb, t, out[b0:b0 + nb].data_ptr()))
+        return out
+
+    # ---- streaming option (not the reference's behaviour: it decodes every chunk from a fresh state, mimi.py:3085-3089) ----
+    def enable_streaming(self, max_slots: int):
+        """Allocate per-request decoder state for `max_slots` concurrent requests (conv look-back rows + a K/V ring per
+        transformer layer): chunks decoded with `decode_chunk` then continue seamlessly from the previous chunk."""
+        N.check(self.L.vox_mimi_stream_enable(self.h, int(max_slots)))
+        self.max_slots = int(max_slots)
+        self._free_slots = list(range(self.max_slots))
+
+    def init_cache(self, batch_size: int = 1, **_) -> MimiDecoderCache:
+        return MimiDecoderCache(slot=torch.tensor([self.alloc_slot() for _ in range(batch_size)], dtype=torch.int32, device=self.device))
+
+    def release_cache(self, cache: MimiDecoderCache):
+        for s_ in cache.slot.tolist():
+            self.free_slot(s_)
+
+    def alloc_slot(self) -> int:
+        if not self._free_slots:
+            raise RuntimeError("MimiDecoder: no free streaming slot")
+        slot = self._free_slots.pop(0)
+        N.check(self.L.vox_mimi_reset_slot(self.h, N.stream(), slot))
+        return slot
+
+    def free_slot(self, slot: int):
+        self._free_slots.append(int(slot))
+
+    def decode_chunk(self, codes: torch.Tensor, slots, code_layout: str = "BQT") -> torch.Tensor:
+        """Streaming decode of one chunk per request: codes as in `decode`, slots = one state slot per row."""
+        if code_layout == "BQT":
+            codes = codes.transpose(1, 2)
+        codes = codes.to(device=self.device, dtype=torch.int32).contiguous()
+        b, t, stride = codes.shape
+        if stride < self.cfg.n_q:
+            raise ValueError(f"Expected {self.cfg.n_q} codebooks, got {stride}")
+        if len(slots) != b or len(set(int(x) for x in slots)) != b:
+            raise ValueError("decode_chunk: one distinct slot per row")
+        sl = torch.tensor([int(x) for x in slots], dtype=torch.int32, device=self.device)
+        out = torch.empty(b, 1, t * self.hop, dtype=torch.float32, device=self.device)
+        for b0 in range(0, b, self.max_batch):
+            nb = min(self.max_batch, b - b0)
+            N.check(self.L.vox_mimi_decode_chunk(self.h, N.stream(), codes[b0:b0 + nb].data_ptr(), stride, sl[b0:b0 + nb].data_ptr(),
+                                                 nb, t, out[b0:b0 + nb].data_ptr()))
         return out
 
     def close(self):
