@@ -1449,18 +1449,22 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
     const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
     const bool own_last = FUSED && (t0 + nt == L);   // this chunk holds the row's newest token (index L-1)
 
-    for (int i = tid; i < VOX_TC * LPT; i += 256) {
-        const int t = i / LPT, j = i % LPT;
-        uint4 kx = make_uint4(0, 0, 0, 0), vx = kx;
-        if (t < nt && !(own_last && t == nt - 1)) {
+    // the K/V tile is requested first and parked in LDS only after the q prologue below: its HBM/L2 latency overlaps the
+    // prologue's own dependent loads (q row, norm weight, RoPE table) instead of preceding them
+    constexpr int KVL = (VOX_TC * LPT + 255) / 256;
+    uint4 kreg[KVL], vreg[KVL];
+#pragma unroll
+    for (int u = 0; u < KVL; ++u) {
+        const int i = tid + 256 * u, t = i / LPT, j = i % LPT;
+        kreg[u] = make_uint4(0, 0, 0, 0);
+        vreg[u] = kreg[u];
+        if (i < VOX_TC * LPT && t < nt && !(own_last && t == nt - 1)) {
             const int tok = t0 + t;
             const int pgi = pages ? pages[tok / a.page_size] : row;
             const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
-            kx = reinterpret_cast<const uint4*>(base)[j];
-            vx = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
+            kreg[u] = reinterpret_cast<const uint4*>(base)[j];
+            vreg[u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
         }
-        Ks[i] = kx;
-        Vs[i] = vx;
     }
     if (!FUSED) {
         for (int i = tid; i < G * LPT; i += 256) {
@@ -1481,6 +1485,11 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
             bf16_t* dst = isk ? Knew : reinterpret_cast<bf16_t*>(Qs) + (size_t)h * D;
             prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, Sh + wave * D, dst, lane);
         }
+    }
+#pragma unroll
+    for (int u = 0; u < KVL; ++u) {
+        const int i = tid + 256 * u;
+        if (i < VOX_TC * LPT) { Ks[i] = kreg[u]; Vs[i] = vreg[u]; }
     }
     __syncthreads();
     if (own_last) {
