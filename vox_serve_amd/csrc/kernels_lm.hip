@@ -1389,15 +1389,22 @@ template <int D>
 __device__ __forceinline__ void prep_head(const bf16_t* src, const bf16_t* nw, float eps, const float* cs_row,
                                           int rot, int interleave, float* sh, bf16_t* out, int lane) {
     constexpr int LPT = D / 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (lane < LPT) v = reinterpret_cast<const uint4*>(src)[lane];
+    // the three operands (head row, norm weight, this lane's RoPE table entry) are requested together: one exposed L2
+    // latency instead of three dependent ones
+    uint4 v = make_uint4(0, 0, 0, 0), g = v;
+    if (lane < LPT) {
+        v = reinterpret_cast<const uint4*>(src)[lane];
+        if (nw) g = reinterpret_cast<const uint4*>(nw)[lane];
+    }
+    const int half = rot >> 1;
+    float2 cs0 = make_float2(1.0f, 0.0f);
+    if (cs_row && lane < half) cs0 = *reinterpret_cast<const float2*>(cs_row + 2 * lane);
     float e[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
     if (nw) {
         float s = sq8(v, 0.0f);
         s = butterfly<64>(s);
         const float rinv = 1.0f / sqrtf(s / (float)D + eps);
         if (lane < LPT) {
-            const uint4 g = reinterpret_cast<const uint4*>(nw)[lane];
             const float gw[8] = {bflo(g.x), bfhi(g.x), bflo(g.y), bfhi(g.y), bflo(g.z), bfhi(g.z), bflo(g.w), bfhi(g.w)};
 #pragma unroll
             for (int i = 0; i < 8; ++i) e[i] = bfround((e[i] * rinv) * gw[i]);
@@ -1413,10 +1420,9 @@ __device__ __forceinline__ void prep_head(const bf16_t* src, const bf16_t* nw, f
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     if (cs_row) {
-        const int half = rot >> 1;
         for (int i = lane; i < half; i += 64) {
             const int ia = interleave ? 2 * i : i, ib = interleave ? 2 * i + 1 : i + half;
-            const float x = sh[ia], y = sh[ib], c = cs_row[2 * i], sn = cs_row[2 * i + 1];
+            const float x = sh[ia], y = sh[ib], c = i == lane ? cs0.x : cs_row[2 * i], sn = i == lane ? cs0.y : cs_row[2 * i + 1];
             const float xc = x * c, yc = y * c;
             out[ia] = f2bf(__fmaf_rn(-y, sn, xc));
             out[ib] = f2bf(__fmaf_rn(x, sn, yc));
