@@ -1851,14 +1851,31 @@ __global__ __launch_bounds__(256) void k_attn_merge(const float* part_o, const f
     const int HD = Hq * D;
     const int row = e / HD, h = (e % HD) / D, d = e % D;
     const int nc = (kvlen[row] + VOX_TC - 1) / VOX_TC;
-    const float* ml = part_ml + ((size_t)row * Hq + h) * max_chunks * 2;
+    const float2* ml = reinterpret_cast<const float2*>(part_ml + ((size_t)row * Hq + h) * max_chunks * 2);
     const float* po = part_o + ((size_t)row * Hq + h) * max_chunks * D + d;
-    float M = -INFINITY;
-    for (int c = 0; c < nc; ++c) M = fmaxf(M, ml[2 * c]);
-    float L = 0.0f, O = 0.0f;
-    for (int c = 0; c < nc; ++c) {
-        const float w = exp2_c((ml[2 * c] - M) * VOX_LOG2E);
-        L = __fmaf_rn(ml[2 * c + 1], w, L);
+    // all operands of up to 8 chunks are requested before the first is used (the max pass needs every (m, l) anyway)
+    float M = -INFINITY, L = 0.0f, O = 0.0f;
+    float2 mv[8];
+    float ov[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mv[j] = j < nc ? ml[j] : make_float2(-INFINITY, 0.0f);
+        ov[j] = j < nc ? po[(size_t)j * D] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) M = fmaxf(M, mv[j].x);
+    for (int c = 8; c < nc; ++c) M = fmaxf(M, ml[c].x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < nc) {
+            const float w = exp2_c((mv[j].x - M) * VOX_LOG2E);
+            L = __fmaf_rn(mv[j].y, w, L);
+            O = __fmaf_rn(ov[j], w, O);
+        }
+    }
+    for (int c = 8; c < nc; ++c) {
+        const float w = exp2_c((ml[c].x - M) * VOX_LOG2E);
+        L = __fmaf_rn(ml[c].y, w, L);
         O = __fmaf_rn(po[(size_t)c * D], w, O);
     }
     out[e] = f2bf(O / L);
