@@ -9,10 +9,13 @@ from collections import defaultdict
 path = sys.argv[1]
 counter = sys.argv[2] if len(sys.argv) > 2 else "FETCH_SIZE"
 rows = list(csv.DictReader(open(path)))
+# engine-creation kernels (fragment-major weight copies, depth-loop projection tables) run before the first embedding
+# kernel of the first prefill: they are not part of any frame
+first = min((int(r["Dispatch_Id"]) for r in rows if "k_qwen3_mix" in r["Kernel_Name"] or "k_frame_init" in r["Kernel_Name"]), default=0)
 by = defaultdict(float)
 cnt = defaultdict(int)
 for r in rows:
-    if r["Counter_Name"] != counter:
+    if r["Counter_Name"] != counter or int(r["Dispatch_Id"]) < first:
         continue
     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
     by[name] += float(r["Counter_Value"])
