@@ -286,7 +286,7 @@ def main():
                          "launch": "one hipGraph replay = one LM frame (talker + 15 depth steps + sampling)",
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": frame_gpu_s * 1e3},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N=1 only (other ranks would idle in RCCL)
             try:
                 out["cpu_baseline"] = cpu_baseline(loop)
             except Exception as ex:  # the baseline is a reported extra; never let it hide the GPU number
