@@ -60,7 +60,20 @@ struct ConvGemmArgs {
     float* out;            // [M, N]
     int M, N, Cin, L, P, n_taps, bias_mod, gelu;
     int off[CG_MAXTAPS];   // row look-back of each tap
+    // fused SnakeBeta of the NEXT layer's input: out2[m][n] = v + inv_beta[c] * sin(v * alpha[c])^2, c = n % sn_mod, beside
+    // (out != NULL) or instead of (out == NULL) the plain output — the arithmetic of k_snake, one elementwise pass less
+    float* out2;
+    const float *sn_alpha, *sn_invb;
+    int sn_mod;
 };
+// sin for the fused epilogues: explicit reduction to revolutions + the hardware v_sin_f32 (absolute error ~1e-6 on [-1, 1]:
+// far inside the 1e-4 waveform bar, and sin^2 enters scaled by 1/beta ~ 1).  The libm sinf (argument-reduction table,
+// private array) cannot be inlined into a GEMM epilogue without spilling the accumulators to scratch.
+__device__ __forceinline__ float snake_f(float v, float alpha, float invb) {
+    const float r = (v * alpha) * 0.15915494309189535f;
+    const float s_ = __builtin_amdgcn_sinf(r - floorf(r));
+    return v + invb * (s_ * s_);
+}
 
 // WM x WN 16x16 MFMA tiles per wave, 2 x 2 waves: block tile (32 WM) x (32 WN).  Smaller tiles are used when the
 // 64 x 64 grid would leave most of the 256 CUs idle (the mid-size decoder stages are MFMA-bound per CU).
@@ -181,7 +194,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
                 const size_t o = (size_t)m * a.N + n;
                 if (a.res) v = a.res[o] + sv * v;
                 else if (a.scale) v = sv * v;
-                a.out[o] = v;
+                if (a.out) a.out[o] = v;
+                if (a.out2) a.out2[o] = snake_f(v, a.sn_alpha[n % a.sn_mod], a.sn_invb[n % a.sn_mod]);
             }
         }
 }
@@ -279,7 +293,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
         const size_t o = (size_t)m * a.N + n;
         if (a.res) v = a.res[o] + sv * v;
         else if (a.scale) v = sv * v;
-        a.out[o] = v;
+        if (a.out) a.out[o] = v;
+        if (a.out2) a.out2[o] = snake_f(v, a.sn_alpha[n % a.sn_mod], a.sn_invb[n % a.sn_mod]);
     }
 }
 
@@ -526,13 +541,15 @@ struct vox_codec {
 };
 
 static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const float* state, const int* slots, int n,
-                     int L, int P, const int* offs, float* out, const float* res, const float* scale, int gelu) {
+                     int L, int P, const int* offs, float* out, const float* res, const float* scale, int gelu,
+                     float* out2 = nullptr, const vox_snake_w* sn = nullptr, int sn_mod = 0) {
     if (w.cin % CG_BK) return vox_fail(VOX_ERR_INVALID, "codec gemm: Cin %d %% %d != 0", w.cin, CG_BK);
     if (w.n_taps > CG_MAXTAPS) return vox_fail(VOX_ERR_INVALID, "codec gemm: too many taps");
     ConvGemmArgs a{};
     a.x = x; a.state = state; a.slots = slots; a.w = (const bf16_t*)w.w; a.bias = w.bias; a.res = res; a.scale = scale;
     a.out = out; a.M = n * L; a.N = w.n; a.Cin = w.cin; a.L = L; a.P = P; a.n_taps = w.n_taps;
     a.bias_mod = w.bias_mod > 0 ? w.bias_mod : w.n; a.gelu = gelu;
+    if (out2 && sn) { a.out2 = out2; a.sn_alpha = sn->alpha; a.sn_invb = sn->inv_beta; a.sn_mod = sn_mod > 0 ? sn_mod : w.n; }
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
     if (a.M <= 48) {
         const dim3 g((w.n + 63) / 64, (a.M + 15) / 16);
@@ -714,32 +731,37 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
     const int off7[7] = {6, 5, 4, 3, 2, 1, 0};
     VOX_TRY(conv_gemm(st, w.dec0, A, m->st_dec0, slots, n, L, 6, off7, B, nullptr, nullptr, 0));          // B [nL, decoder_dim]
     state_update(st, m->st_dec0, slots, A, n, L, 6, LD);
+    // SnakeBeta is fused into the epilogue of the conv that produces its input: a conv whose output is only ever consumed
+    // through a snake (conv1 of a residual unit) writes just the activated tensor, the others write both (the plain tensor
+    // is the residual branch).  t1 always holds the activated input of the next conv.
     float* h = B;      // current activations
     float* t1 = A;
     float* t2 = C;
     float* t3 = D;
+    snake(st, h, w.blocks[0].snake0, t1, (size_t)n * L, c.decoder_dim);      // (dec0's input A is t1: no room for a fused second output)
     for (int b = 0; b < 4; ++b) {
         const vox_codec_block_w& bw = w.blocks[b];
         const int cin = c.decoder_dim >> b, cout = c.decoder_dim >> (b + 1), r = c.rates[b];
-        snake(st, h, bw.snake0, t1, (size_t)n * L, cin);
         const int offt[2] = {0, 1};
-        VOX_TRY(conv_gemm(st, bw.tconv, t1, m->st_tc[b], slots, n, L, 1, offt, t2, nullptr, nullptr, 0)); // t2 [n*L*r, cout]
+        // t2 [n*L*r, cout] = tconv(t1); t3 = act1 of unit 0 applied to it (t1 is still being read by other blocks)
+        VOX_TRY(conv_gemm(st, bw.tconv, t1, m->st_tc[b], slots, n, L, 1, offt, t2, nullptr, nullptr, 0, t3, &bw.res[0].act1, cout));
         state_update(st, m->st_tc[b], slots, t1, n, L, 1, cin);
         L *= r;
         { float* x = h; h = t2; t2 = x; }
+        { float* x = t1; t1 = t3; t3 = x; }             // t1 = act1(h)
         for (int u = 0; u < 3; ++u) {
             const vox_codec_res_w& rw = bw.res[u];
             const int d = u == 0 ? 1 : (u == 1 ? 3 : 9);
             const int offd[7] = {6 * d, 5 * d, 4 * d, 3 * d, 2 * d, d, 0};
-            snake(st, h, rw.act1, t1, (size_t)n * L, cout);
-            VOX_TRY(conv_gemm(st, rw.conv1, t1, m->st_ru[b][u], slots, n, L, 6 * d, offd, t3, nullptr, nullptr, 0));
+            // t3 = act2(conv1(t1))   (the plain conv1 output has no other consumer)
+            VOX_TRY(conv_gemm(st, rw.conv1, t1, m->st_ru[b][u], slots, n, L, 6 * d, offd, nullptr, nullptr, nullptr, 0, t3, &rw.act2, cout));
             state_update(st, m->st_ru[b][u], slots, t1, n, L, 6 * d, cout);
-            snake(st, t3, rw.act2, t1, (size_t)n * L, cout);
-            VOX_TRY(conv_gemm(st, rw.conv2, t1, nullptr, slots, n, L, 0, off0, h, h, nullptr, 0));        // h += conv2(...)
+            // h += conv2(t3); t1 = the next consumer's activation of the new h
+            const vox_snake_w* nx = u < 2 ? &bw.res[u + 1].act1 : (b < 3 ? &w.blocks[b + 1].snake0 : &w.final_snake);
+            VOX_TRY(conv_gemm(st, rw.conv2, t3, nullptr, slots, n, L, 0, off0, h, h, nullptr, 0, t1, nx, cout));
         }
     }
     const int cl = c.decoder_dim >> 4;
-    snake(st, h, w.final_snake, t1, (size_t)n * L, cl);
     hipLaunchKernelGGL(k_final_conv, dim3((L + 3) / 4, n), dim3(256), 0, st, t1, m->st_final, slots, w.final_w, w.final_b, out,
                        L, cl);
     state_update(st, m->st_final, slots, t1, n, L, 6, cl);
