@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="concurrent requests per GPU (BASELINE configs: 1 and 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttfa-requests", type=int, default=5)
+    ap.add_argument("--exact-rows", type=int, default=8, help="rows up to which linears use the fixed-order (oracle-bit-exact) "
+                    "kernels; default 8 = the parity-tested configuration, lower = opt-in fast mode (bf16-rounding parity)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -220,6 +222,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)         # RCCL; used only for the barrier + max-reduce
 
     B = args.batch
+    if args.exact_rows != 8:
+        from vox_serve_amd import _native as N
+        N.set_exact_rows(args.exact_rows)
     loop = Loop(B, args.steps + args.warmup + 64, dev)
 
     # ---- TTFA (p50): request start -> first PCM chunk on the host, batch-1 streaming, outside the timed steps ----
@@ -276,7 +281,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Qwen3-TTS-1.7B bf16, batch={B}/GPU streaming, greedy, {PROMPT_TOKENS}-token prompt, "
-                                   f"detokenize_interval {INTERVAL}, page_size 128", "batch_per_gpu": B,
+                                   f"detokenize_interval {INTERVAL}, page_size 128"
+                                   + ("" if args.exact_rows == 8 else f", exact_rows {args.exact_rows} (fast mode)"), "batch_per_gpu": B,
                        "frames_per_request": args.steps, "parallelism": f"dp{world} (independent replicas, no collective on the data path)"},
             "realtime_factor": samples_total / dt / 24000.0 / (world * B),
             "ttfa_ms_p50": float(np.median(ttfa)) if ttfa else None,

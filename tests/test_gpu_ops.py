@@ -397,3 +397,16 @@ def test_stack_forward_batched_rows_paths(dev, n_rows):
     check(64, 0, False)      # prefill-style rows: head_prepare + single-chunk attention
     check(64, 40, True)      # decode rows, 41-token context: fused chunked attention + merge
     check(16, 2, True)       # decode rows on a short-context stack: one-wave attention (heads == 2 * kv heads)
+
+
+@pytest.mark.parametrize("n_rows", [3, 4, 8])
+def test_stack_forward_fast_mode_small_batches(dev, n_rows):
+    """vox_ctx_set_exact_rows(2): 3..8 rows leave the fixed-order kernels for the bf16 MFMA GEMMs (an opt-in trade of the
+    small-batch bit-exact guarantee for speed) — same bf16-rounding bar against the oracle as the 9+ row paths; the
+    default (8) is restored afterwards and is what every other test runs under."""
+    from vox_serve_amd import _native as N
+    N.set_exact_rows(2)
+    try:
+        test_stack_forward_batched_rows_paths(dev, n_rows)
+    finally:
+        N.set_exact_rows(8)

@@ -9,6 +9,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 use_graph = (sys.argv[3] != "eager") if len(sys.argv) > 3 else True
 dev = torch.device("cuda")
+if os.environ.get("VOX_EXACT_ROWS"):
+    from vox_serve_amd import _native as _N
+    _N.set_exact_rows(int(os.environ["VOX_EXACT_ROWS"]))
 cfg = Qwen3Cfg()
 W = synth_qwen3_weights(cfg, dev, seed=0)
 eng = Qwen3Engine(cfg, W, max_batch=B, page_size=128, max_pages=max(64, 4 * B), max_seq_len=2304, max_prefill_rows=128)

@@ -142,6 +142,15 @@ def ctx():
     return _ctx
 
 
+def set_exact_rows(rows: int):
+    """Linears with at most `rows` rows (1..8, default 8) keep the fixed-order kernels that are bit-identical to the oracle;
+    more rows take the bf16 MFMA kernels (see include/voxhip.h).  Call before the first frame of an engine is captured."""
+    L = lib()
+    L.vox_ctx_set_exact_rows.restype = ctypes.c_int
+    L.vox_ctx_set_exact_rows.argtypes = [c_void_p, ctypes.c_int]
+    check(L.vox_ctx_set_exact_rows(ctx(), int(rows)))
+
+
 def stream():
     import torch
     return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -51,6 +51,11 @@ void vox_ctx_destroy(vox_ctx* ctx) {
     (void)hipFree(ctx->samp_ws);
     delete ctx;
 }
+int vox_ctx_set_exact_rows(vox_ctx* ctx, int rows) {
+    if (!ctx || rows < 1 || rows > 8) return vox_fail(VOX_ERR_INVALID, "ctx_set_exact_rows: rows must be 1..8");
+    ctx->exact_rows = rows;
+    return VOX_OK;
+}
 int vox_ctx_props(vox_ctx* ctx, int64_t out[3]) {
     if (!ctx || !out) return vox_fail(VOX_ERR_INVALID, "ctx_props: NULL");
     out[0] = ctx->n_cu; out[1] = ctx->lds_bytes; out[2] = ctx->hbm_bytes;
@@ -257,7 +262,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         LinearCall a;  // input_layernorm + fused q/k/v projection
         a.W = w.wqkv; a.bias = w.bqkv; a.x = x; a.norm_w = w.ln1; a.eps = c.eps; a.y = s->qkv;
         a.B = n; a.N = nqkv; a.K = c.hidden; a.pro = VOX_PRO_RMSNORM; a.epi = VOX_EPI_STORE;
-        a.fixed_order = fixed_order; a.keep_weights = s->keep_weights; a.splitk_ws = s->skws; a.splitk_ws_bytes = s->skws_bytes; a.norm_scratch = s->xn;
+        a.fixed_order = fixed_order; a.exact_rows = s->ctx->exact_rows; a.keep_weights = s->keep_weights; a.splitk_ws = s->skws; a.splitk_ws_bytes = s->skws_bytes; a.norm_scratch = s->xn;
         if (xn_ready) a.x_prenormed = s->xn;
         const vox_stack::FragW fwl = s->fw.empty() ? vox_stack::FragW{} : s->fw[l];
         a.W_frag = fwl.qkv;
@@ -287,17 +292,17 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         LinearCall o;  // o_proj + residual
         o.W = w.wo; o.x = s->attn_out; o.residual = x; o.y = x; o.B = n; o.N = c.hidden; o.K = nq;
         o.pro = VOX_PRO_COPY; o.epi = VOX_EPI_STORE;
-        o.fixed_order = fixed_order; o.keep_weights = s->keep_weights; o.splitk_ws = s->skws; o.splitk_ws_bytes = s->skws_bytes;
+        o.fixed_order = fixed_order; o.exact_rows = s->ctx->exact_rows; o.keep_weights = s->keep_weights; o.splitk_ws = s->skws; o.splitk_ws_bytes = s->skws_bytes;
         xn_ready = vox_linear_is_rows_gemm(o);      // its reduce also writes post_attention_layernorm(x) for gate/up
         if (xn_ready) { o.post_norm_w = w.ln2; o.post_norm_out = s->xn; }
         LinearCall g;  // post_attention_layernorm + gate/up + SiLU*up
         g.W = w.wgate; g.W2 = w.wup; g.x = x; g.norm_w = w.ln2; g.eps = c.eps; g.y = s->h;
         g.B = n; g.N = c.ffn; g.K = c.hidden; g.pro = VOX_PRO_RMSNORM; g.epi = VOX_EPI_SILU_MUL;
-        g.fixed_order = fixed_order; g.keep_weights = s->keep_weights; g.splitk_ws = s->skws; g.splitk_ws_bytes = s->skws_bytes; g.norm_scratch = s->xn;
+        g.fixed_order = fixed_order; g.exact_rows = s->ctx->exact_rows; g.keep_weights = s->keep_weights; g.splitk_ws = s->skws; g.splitk_ws_bytes = s->skws_bytes; g.norm_scratch = s->xn;
         LinearCall d;  // down + residual
         d.W = w.wdown; d.x = s->h; d.residual = x; d.y = x; d.B = n; d.N = c.hidden; d.K = c.ffn;
         d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE;
-        d.fixed_order = fixed_order; d.keep_weights = s->keep_weights; d.splitk_ws = s->skws; d.splitk_ws_bytes = s->skws_bytes;
+        d.fixed_order = fixed_order; d.exact_rows = s->ctx->exact_rows; d.keep_weights = s->keep_weights; d.splitk_ws = s->skws; d.splitk_ws_bytes = s->skws_bytes;
         // fragment-major hand-offs between consecutive full-K GEMMs (o -> gate/up -> down -> next layer's qkv)
         const bool o_fk = s->xfrag && vox_linear_is_fullk(o), g_fk = s->xfrag && vox_linear_is_fullk(g), d_fk = s->xfrag && vox_linear_is_fullk(d);
         o.W_frag = fwl.o; g.W_frag = fwl.gate; g.W2_frag = fwl.up; d.W_frag = fwl.down;
@@ -402,7 +407,7 @@ int vox_stack_forward(vox_stack* s, void* stream, void* x, void* y, void* kv, in
     hipStream_t st = (hipStream_t)stream;
     // the decode-row hints promise one new token per request: take the fused (norm + RoPE + append in-kernel) path
     const bool decode_rows = rows->fixed_kvlen > 0 || rows->page_table != nullptr || rows->identity_pages;
-    VOX_TRY(stack_layers(s, st, x, kv, kv_layer_stride, rows, decode_rows, rows->n_rows <= 8));
+    VOX_TRY(stack_layers(s, st, x, kv, kv_layer_stride, rows, decode_rows, rows->n_rows <= s->ctx->exact_rows));
     if (y && s->final_norm)
         VOX_TRY(vox_launch_rmsnorm(st, x, s->final_norm, y, rows->n_rows, s->cfg.hidden, s->cfg.eps));
     return VOX_OK;
@@ -478,7 +483,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         if (i == 1 || !m->proj_tab) {     // (steps >= 2: the previous step's sampler gathered the tabulated projection into dx)
             LinearCall p;  // small_to_mtp_projection
             p.W = m->w.mtp_w; p.bias = m->w.mtp_b; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
-            p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8; p.keep_weights = m->depth->keep_weights;
+            p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= m->ctx->exact_rows; p.exact_rows = m->ctx->exact_rows; p.keep_weights = m->depth->keep_weights;
             p.splitk_ws = m->depth->skws; p.splitk_ws_bytes = m->depth->skws_bytes;
             VOX_TRY(vox_launch_linear(m->ctx, st, p));
         }
@@ -493,7 +498,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         r.n_rows = rows;
         r.max_kvlen = i + 1;
         if (i > 1) { r.fixed_kvlen = i + 1; r.fixed_pos = i; r.identity_pages = 1; }
-        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= 8));
+        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= m->ctx->exact_rows));
         void* dl = io->out_depth_logits ? (void*)((bf16_t*)io->out_depth_logits + (size_t)(i - 1) * c.max_batch * c.depth_vocab)
                                         : m->dlogits;
         LinearCall h;  // depth final norm + lm_head[i-1]
@@ -767,7 +772,7 @@ static int csm_tail(vox_csm* m, hipStream_t st, const vox_csm_io* io, int B, con
         if (i == 1 || !m->proj_tab) {     // (steps >= 2: the previous step's sampler gathered the tabulated projection into dx)
             LinearCall p;  // inputs_embeds_projector (no bias)
             p.W = m->w.depth_proj; p.x = m->depth_x; p.y = m->dx; p.B = rows; p.N = Hd; p.K = H;
-            p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= 8; p.keep_weights = m->depth->keep_weights;
+            p.pro = VOX_PRO_COPY; p.epi = VOX_EPI_STORE; p.fixed_order = B <= m->ctx->exact_rows; p.exact_rows = m->ctx->exact_rows; p.keep_weights = m->depth->keep_weights;
             p.splitk_ws = m->depth->skws; p.splitk_ws_bytes = m->depth->skws_bytes;
             VOX_TRY(vox_launch_linear(m->ctx, st, p));
         }
@@ -782,7 +787,7 @@ static int csm_tail(vox_csm* m, hipStream_t st, const vox_csm_io* io, int B, con
         r.n_rows = rows;
         r.max_kvlen = i + 1;
         if (i > 1) { r.fixed_kvlen = i + 1; r.fixed_pos = i; r.identity_pages = 1; }
-        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= 8));
+        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= m->ctx->exact_rows));
         void* dl = io->out_depth_logits ? (void*)((bf16_t*)io->out_depth_logits + (size_t)(i - 1) * c.max_batch * V) : m->dlogits;
         LinearCall h;  // depth final norm + codebooks_head[i-1]
         h.W = (const bf16_t*)m->w.depth_heads + (size_t)(i - 1) * V * Hd;
@@ -899,7 +904,7 @@ int vox_csm_frame(vox_csm* m, void* stream, const vox_csm_io* io, int B, int max
     r.pos = io->pos; r.q_req = m->iota; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
     r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = B; r.max_kvlen = max_kvlen;
     r.page_table = io->page_table; r.pt_stride = (int32_t)io->pt_stride;
-    VOX_TRY(stack_layers(m->backbone, st, m->x, io->kv, io->kv_layer_stride, &r, true, B <= 8));
+    VOX_TRY(stack_layers(m->backbone, st, m->x, io->kv, io->kv_layer_stride, &r, true, B <= m->ctx->exact_rows));
     VOX_TRY(csm_head(m, st, io, B, nullptr));
     return csm_tail(m, st, io, B, sc, seed, feedback);
 }
@@ -914,7 +919,7 @@ int vox_csm_prefill(vox_csm* m, void* stream, const vox_csm_io* io, const int32_
     vox_rows r{};
     r.pos = io->pos; r.q_req = q_req; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
     r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = n_rows; r.max_kvlen = max_kvlen;
-    VOX_TRY(stack_layers(m->backbone, st, m->x, io->kv, io->kv_layer_stride, &r, false, n_rows <= 8));
+    VOX_TRY(stack_layers(m->backbone, st, m->x, io->kv, io->kv_layer_stride, &r, false, n_rows <= m->ctx->exact_rows));
     if (n_req == 0) return VOX_OK;      // context chunk of a long prompt
     VOX_TRY(csm_head(m, st, io, n_req, last_rows));
     return csm_tail(m, st, io, n_req, sc, seed, feedback);
@@ -958,12 +963,12 @@ static int lm_run(vox_lm* m, hipStream_t st, const vox_lm_io* io, const int32_t*
     VOX_TRY(vox_launch_gather(st, m->w.embedding, ids, c.ids_stride, 0, m->x, H, n, H, c.vocab_in));
     if (c.input_mode == 1 && masks && feats)
         hipLaunchKernelGGL(k_where_rows, dim3((H + 255) / 256, n), dim3(256), 0, st, (bf16_t*)m->x, masks, (const bf16_t*)feats, H);
-    VOX_TRY(stack_layers(m->stack, st, m->x, io->kv, io->kv_layer_stride, &r, decode_rows, n <= 8));
+    VOX_TRY(stack_layers(m->stack, st, m->x, io->kv, io->kv_layer_stride, &r, decode_rows, n <= m->ctx->exact_rows));
     if (n_req == 0) return VOX_OK;      // context chunk of a long prompt
     LinearCall h;   // final norm + output head
     h.W = m->w.head_w; h.bias = m->w.head_b; h.x = m->x; h.x_rows = last_rows; h.norm_w = m->w.final_norm; h.eps = c.stack.eps;
     h.y = io->out_logits; h.B = n_req; h.N = c.vocab_out; h.K = H; h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
-    h.fixed_order = n_req <= 8;
+    h.fixed_order = n_req <= m->ctx->exact_rows; h.exact_rows = m->ctx->exact_rows;
     VOX_TRY(vox_launch_linear(m->ctx, st, h));
     SampleCall s;
     s.logits = io->out_logits; s.B = n_req; s.V = c.vocab_out; s.cfg = *sc; s.seed = seed; s.offset = 0;

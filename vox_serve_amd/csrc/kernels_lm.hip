@@ -1102,8 +1102,8 @@ int vox_launch_swizzle_frag(hipStream_t st, const void* src, void* dst, int rows
     return VOX_OK;
 }
 
-static bool fullk_shape_ok(int B, int N, int K, int pro, int epi) {
-    if (B < 9 || B > 64 || N % 16 || K % 256) return false;
+static bool fullk_shape_ok(int B, int N, int K, int pro, int epi, int exact_rows = 8) {
+    if (B <= exact_rows || B < 2 || B > 64 || N % 16 || K % 256) return false;
     if (B > 32 && N % 128) return false;          // 33..64 rows: two 32-row tiles per column tile (block ids 8 apart)
     const int ks = K / 256;
     if (pro == PRO_RMSNORM && (epi == EPI_STORE || epi == EPI_SILU_MUL)) return ks == 4 || ks == 8;
@@ -1143,7 +1143,7 @@ static int launch_gemm_fullk(hipStream_t st, const LinArgs& a) {
 }
 // true when this call takes the one-launch full-K path (9..32 rows, K a supported multiple of 256)
 static bool linear_is_fullk(const LinearCall& c) {
-    return !c.fixed_order && !c.x_out && fullk_shape_ok(c.B, c.N, c.K, c.pro, c.epi);
+    return !c.fixed_order && !c.x_out && fullk_shape_ok(c.B, c.N, c.K, c.pro, c.epi, c.exact_rows);
 }
 bool vox_linear_is_fullk(const LinearCall& c) { return linear_is_fullk(c); }
 bool vox_fullk_weight_ok(int N, int K) {
@@ -1166,7 +1166,9 @@ bool vox_linear_is_rows_gemm(const LinearCall& c) {
            (c.pro == PRO_COPY || (c.pro == PRO_RMSNORM && (c.x_prenormed || (c.norm_scratch && !c.x_rows && (c.x_stride == 0 || c.x_stride == c.K)))));
 }
 
-int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
+int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& call) {
+    LinearCall c = call;
+    c.exact_rows = ctx->exact_rows;       // the context's setting is authoritative (callers that plan hand-offs copy it too)
     if (c.K % 8 != 0 || c.B <= 0 || c.N <= 0) return vox_fail(VOX_ERR_INVALID, "linear: K%8!=0 or empty");
     LinArgs a{};
     a.W = (const bf16_t*)c.W; a.W2 = (const bf16_t*)c.W2; a.bias = (const bf16_t*)c.bias;
@@ -1217,7 +1219,7 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c) {
         if (epi == EPI_SILU) return launch_gemm_splitk<EPI_SILU>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
         if (epi == EPI_SILU_MUL) return launch_gemm_splitk<EPI_SILU_MUL>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
     }
-    if (c.B > 8 && !c.fixed_order && c.pro != PRO_ATTN && c.K % 32 == 0) {   // > 8 rows: MFMA path (weights streamed once per 32-row tile)
+    if (c.B > c.exact_rows && !c.fixed_order && c.pro != PRO_ATTN && c.K % 32 == 0) {   // above exact_rows: MFMA path (weights streamed once per 32-row tile)
 #define VOX_PM(P, E) if (c.pro == P && c.epi == E) return launch_linear_mfma_pe<P, E>(st, a);
         VOX_PM(PRO_COPY, EPI_STORE) VOX_PM(PRO_COPY, EPI_SILU) VOX_PM(PRO_COPY, EPI_SILU_MUL)
         VOX_PM(PRO_RMSNORM, EPI_STORE) VOX_PM(PRO_RMSNORM, EPI_SILU_MUL)

@@ -27,6 +27,7 @@ struct vox_ctx {
     int n_cu;
     int64_t lds_bytes, hbm_bytes;
     void* samp_ws;   // sampler scratch: SAMP_WS_ROWS x (65536 u32 histogram, all-zero between launches) + keys
+    int exact_rows = 8;   // linears with at most this many rows use the fixed-order kernels (vox_ctx_set_exact_rows)
 };
 // sampler scratch geometry (sampler.hip): one LM stream per context uses it at a time
 #define SAMP_WS_ROWS 64
@@ -65,7 +66,8 @@ struct LinearCall {
     void* y_frag = nullptr;                              // also write the output fragment-major (the next linear's x_frag)
     int y_rowmajor = 1;                                  // 0: skip the row-major y (only y_frag is consumed)
     int pro = 0, epi = 0;  // PRO_* / EPI_*
-    int fixed_order = 0;   // 1: keep the fixed-order VALU kernel even above 8 rows (depth step 1 of a <= 8 request frame)
+    int fixed_order = 0;   // 1: keep the fixed-order VALU kernel even above exact_rows rows (depth step 1 of a small-batch frame)
+    int exact_rows = 8;    // rows up to which the fixed-order kernels are used (the context's setting; vox_launch_linear fills it)
 };
 enum { VOX_PRO_COPY = 0, VOX_PRO_RMSNORM = 1, VOX_PRO_ATTN = 2 };
 enum { VOX_EPI_STORE = 0, VOX_EPI_SILU = 1, VOX_EPI_SILU_MUL = 2 };
