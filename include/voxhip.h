@@ -51,7 +51,8 @@ int vox_ctx_props(vox_ctx* ctx, int64_t out[3]);
 /* Linears with at most `rows` rows (1..8, default 8) run the fixed-order kernels, whose outputs are bit-identical to the CPU
  * oracle; above that the bf16 MFMA kernels (bf16-rounding parity: fp32 accumulation in MFMA order).  Lowering it trades the
  * bit-exact guarantee of small batches for speed (Qwen3-TTS B=8 frame 6.2 -> 4.9 ms); the reference gives no cross-batch-size
- * reproducibility either (cuBLAS picks kernels by shape).  Set before the first frame is captured into a graph. */
+ * reproducibility either (cuBLAS picks kernels by shape).  Set before the engines are created (they size their fragment-major
+ * weight copies by it) and before the first frame is captured into a graph. */
 int vox_ctx_set_exact_rows(vox_ctx* ctx, int rows);
 
 /* ---- hipGraph capture (replaces torch.cuda.graph in worker/cuda_graph_worker.py:189-805) ---------- */

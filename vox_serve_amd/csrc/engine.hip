@@ -366,7 +366,7 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
         delete s;
         return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc failed");
     }
-    if (R > 8) {
+    if (R > (size_t)ctx->exact_rows) {
         // fragment-major weight copies for the 9..32 rows GEMM (rows * 2 bytes each: doubles the stack's weight footprint;
         // the 1..8 rows GEMV and the 33+ rows split-K GEMM keep reading the caller's row-major tensors)
         auto mk = [&](const void* src, int rows, int K, void** dst) -> bool {
