@@ -319,7 +319,7 @@ def test_stack_forward_abi_bit_exact(dev):
 
 
 @pytest.mark.parametrize("n_rows", [12, 16, 24, 32, 48, 64, 75])
-def test_stack_forward_batched_rows_paths(dev, n_rows):
+def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072)):
     """9..32 rows take the one-launch full-K MFMA GEMM (norm prologue, SiLU*up / residual epilogues, fragment-major
     weights and activation hand-offs), 33+ the split-K pair: two decoder layers at depth-transformer widths vs the oracle's
     RefStack, through the three attention routes that feed o_proj (single-chunk prefill rows; decode rows at a 41-token
@@ -330,7 +330,7 @@ def test_stack_forward_batched_rows_paths(dev, n_rows):
     from vox_serve_amd import _native as N
     from vox_serve_amd.engine import StackCfg, _stack_config, rope_table
     L, ctx = N.lib(), N.ctx()
-    H, heads, kvh, D, F, NL = 1024, 8, 4, 128, 3072, 2
+    (H, heads, kvh, F), D, NL = dims, 128, 2
     oc = QR.StackCfg(H, NL, heads, kvh, D, F, eps=1e-6, rope_theta=1e6, qk_norm=True, qkv_bias=False)
     rng = np.random.default_rng(n_rows)
     w = lambda *s_, sd=0.03: vr.f2bf(rng.standard_normal(s_, dtype=np.float32) * np.float32(sd))
@@ -410,3 +410,10 @@ def test_stack_forward_fast_mode_small_batches(dev, n_rows):
         test_stack_forward_batched_rows_paths(dev, n_rows)
     finally:
         N.set_exact_rows(8)
+
+
+@pytest.mark.parametrize("n_rows", [12, 32])
+def test_stack_forward_batched_rows_k4096(dev, n_rows):
+    """The same three attention routes at GLM-4-Voice width (hidden 4096 = 16 k-steps per wave): copy-prologue linears on the
+    full-K kernel directly, norm-prologue ones through the normalise-once-into-scratch route."""
+    test_stack_forward_batched_rows_paths(dev, n_rows, dims=(4096, 32, 16, 4096))

@@ -14,8 +14,12 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--greedy", action="store_true")
+ap.add_argument("--exact-rows", type=int, default=8)
 args = ap.parse_args()
 B, dev = args.batch, torch.device("cuda")
+if args.exact_rows != 8:
+    from vox_serve_amd import _native as _N
+    _N.set_exact_rows(args.exact_rows)
 gc = GLMVoiceConfig()
 layers, norm, emb, head = pack_glm_weights(synth_glm_weights(gc, dev), gc)
 eng = LMEngine(gc.lm_cfg(4096), layers, norm, emb, head, None, max_batch=B, page_size=128, max_pages=4 * B + 1, max_seq_len=1024, max_prefill_rows=64)

@@ -1107,8 +1107,15 @@ static bool fullk_shape_ok(int B, int N, int K, int pro, int epi, int exact_rows
     if (B > 32 && N % 128) return false;          // 33..64 rows: two 32-row tiles per column tile (block ids 8 apart)
     const int ks = K / 256;
     if (pro == PRO_RMSNORM && (epi == EPI_STORE || epi == EPI_SILU_MUL)) return ks == 4 || ks == 8;
-    if (pro == PRO_COPY && epi == EPI_STORE) return ks == 4 || ks == 8 || ks == 12 || ks == 24 || ks == 32;
+    if (pro == PRO_COPY && epi == EPI_STORE) return ks == 4 || ks == 8 || ks == 12 || ks == 16 || ks == 24 || ks == 32;
+    if (pro == PRO_COPY && epi == EPI_SILU_MUL) return ks == 16;
     return false;
+}
+// K = 4096 with a norm prologue (GLM-4-Voice width): the operand registers of a whole row slice do not fit next to the weights,
+// so the row is normalised once into the caller's scratch and the copy-prologue kernel runs on that
+static bool fullk_prenorm_ok(const LinearCall& c) {
+    return !c.fixed_order && !c.x_out && !c.x_rows && c.norm_scratch && c.pro == PRO_RMSNORM && c.K == 4096 &&
+           (c.epi == EPI_STORE || c.epi == EPI_SILU_MUL) && fullk_shape_ok(c.B, c.N, c.K, PRO_COPY, c.epi == EPI_SILU_MUL ? EPI_SILU_MUL : EPI_STORE, c.exact_rows);
 }
 template <int MT, int KSTEPS, int PRO, int EPI>
 static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a0) {
@@ -1136,19 +1143,20 @@ template <int PRO, int EPI>
 static int launch_gemm_fullk(hipStream_t st, const LinArgs& a) {
     const int ks = a.K / 256;
 #define VOX_FK(KS) if (ks == KS) return a.B <= 16 ? launch_gemm_fullk_t<1, KS, PRO, EPI>(st, a) : launch_gemm_fullk_t<2, KS, PRO, EPI>(st, a);
-    VOX_FK(4) VOX_FK(8)
-    if constexpr (PRO == PRO_COPY) { VOX_FK(12) VOX_FK(24) VOX_FK(32) }
+    if constexpr (!(PRO == PRO_COPY && EPI == EPI_SILU_MUL)) { VOX_FK(4) VOX_FK(8) }
+    if constexpr (PRO == PRO_COPY && EPI == EPI_STORE) { VOX_FK(12) VOX_FK(16) VOX_FK(24) VOX_FK(32) }
+    if constexpr (PRO == PRO_COPY && EPI == EPI_SILU_MUL) { VOX_FK(16) }
 #undef VOX_FK
     return vox_fail(VOX_ERR_INVALID, "linear(full-K): unsupported K");
 }
 // true when this call takes the one-launch full-K path (9..32 rows, K a supported multiple of 256)
 static bool linear_is_fullk(const LinearCall& c) {
-    return !c.fixed_order && !c.x_out && fullk_shape_ok(c.B, c.N, c.K, c.pro, c.epi, c.exact_rows);
+    return (!c.fixed_order && !c.x_out && fullk_shape_ok(c.B, c.N, c.K, c.pro, c.epi, c.exact_rows)) || fullk_prenorm_ok(c);
 }
 bool vox_linear_is_fullk(const LinearCall& c) { return linear_is_fullk(c); }
 bool vox_fullk_weight_ok(int N, int K) {
     const int ks = K / 256;
-    return N % 16 == 0 && K % 256 == 0 && (ks == 4 || ks == 8 || ks == 12 || ks == 24 || ks == 32);
+    return N % 16 == 0 && K % 256 == 0 && (ks == 4 || ks == 8 || ks == 12 || ks == 16 || ks == 24 || ks == 32);
 }
 
 static int rows_gemm_min() {
@@ -1198,6 +1206,12 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& call) {
     if ((dev & 4) && epi == EPI_SILU_MUL) epi = EPI_STORE;
     if (dev & 8) a.bias = nullptr;
 #endif
+    if (fullk_prenorm_ok(c) && pro == PRO_RMSNORM) {
+        hipLaunchKernelGGL(k_rmsnorm, dim3((c.B + 3) / 4), dim3(256), 0, st, a.x, a.nw, (bf16_t*)c.norm_scratch, c.B, c.K, c.eps);
+        a.x = (const bf16_t*)c.norm_scratch; a.x_stride = c.K; a.x_frag = nullptr;
+        if (epi == EPI_SILU_MUL) return launch_gemm_fullk<PRO_COPY, EPI_SILU_MUL>(st, a);
+        return launch_gemm_fullk<PRO_COPY, EPI_STORE>(st, a);
+    }
     if (linear_is_fullk(c)) {
         if (pro == PRO_RMSNORM && epi == EPI_STORE) return launch_gemm_fullk<PRO_RMSNORM, EPI_STORE>(st, a);
         if (pro == PRO_RMSNORM && epi == EPI_SILU_MUL) return launch_gemm_fullk<PRO_RMSNORM, EPI_SILU_MUL>(st, a);
