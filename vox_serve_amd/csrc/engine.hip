@@ -969,6 +969,7 @@ static int lm_run(vox_lm* m, hipStream_t st, const vox_lm_io* io, const int32_t*
     h.W = m->w.head_w; h.bias = m->w.head_b; h.x = m->x; h.x_rows = last_rows; h.norm_w = m->w.final_norm; h.eps = c.stack.eps;
     h.y = io->out_logits; h.B = n_req; h.N = c.vocab_out; h.K = H; h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
     h.fixed_order = n_req <= m->ctx->exact_rows; h.exact_rows = m->ctx->exact_rows;
+    h.norm_scratch = m->stack->xn;       // (wide models: the head's norm prologue may be normalised once into the stack's scratch)
     VOX_TRY(vox_launch_linear(m->ctx, st, h));
     SampleCall s;
     s.logits = io->out_logits; s.B = n_req; s.V = c.vocab_out; s.cfg = *sc; s.seed = seed; s.offset = 0;
