@@ -29,7 +29,12 @@ class ModelWorker:
                  max_tokens: int = None, repetition_penalty: float = None, repetition_window: int = None,
                  cfg_scale: float = None, greedy: bool = False, enable_nvtx: bool = False,
                  enable_torch_compile: bool = False, detokenizer_device: Optional[str] = None, dp_rank: int = 0,
-                 dp_size: int = 1, detokenize_interval: int = None, model=None, device: str = "cuda:0", seed: int = 0):
+                 dp_size: int = 1, detokenize_interval: int = None, model=None, device: str = "cuda:0", seed: int = 0,
+                 exact_rows: Optional[int] = None):
+        if exact_rows is not None:
+            # opt-in fast mode (include/voxhip.h: vox_ctx_set_exact_rows): must precede the engines' creation
+            from .. import _native as _N
+            _N.set_exact_rows(exact_rows)
         if model is None:
             from ..model import load_model
             model = load_model(model_name, device=device, top_p=top_p, top_k=top_k, min_p=min_p, temperature=temperature,
