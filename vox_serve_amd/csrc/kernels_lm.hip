@@ -1844,7 +1844,9 @@ int vox_launch_attn_short(hipStream_t st, const AttnCall& c) {
 }
 // true when the fused short-attention + o_proj kernel covers this call (else the caller launches the two kernels)
 bool vox_attn1_linear_supported(const AttnCall& c, const LinearCall& l) {
-    return vox_attn_short_supported(c) && c.Nq <= 2 && l.K == c.Hq * c.D && l.K == 2048 && l.pro == PRO_COPY &&
+    // one row only: with two rows each wave runs two attention passes back to back — the separate one-wave-per-(row, head)
+    // kernel + a 2-row GEMV is faster there (B=2 frame 4.30 -> 4.05 ms)
+    return vox_attn_short_supported(c) && c.Nq == 1 && l.K == c.Hq * c.D && l.K == 2048 && l.pro == PRO_COPY &&
            l.epi == EPI_STORE && !l.x_rows && l.B == c.Nq;
 }
 int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const LinearCall& l) {
@@ -1855,8 +1857,7 @@ int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const LinearCall&
     a.W = (const bf16_t*)l.W; a.bias = (const bf16_t*)l.bias; a.residual = (const bf16_t*)l.residual; a.y = (bf16_t*)l.y;
     a.B = l.B; a.N = l.N; a.K = l.K;
     const dim3 grid((l.N + 7) / 8);
-    if (l.B == 1) hipLaunchKernelGGL((k_attn1_linear<1, 4, 1>), grid, dim3(512), 0, st, at, a);
-    else hipLaunchKernelGGL((k_attn1_linear<2, 4, 1>), grid, dim3(512), 0, st, at, a);
+    hipLaunchKernelGGL((k_attn1_linear<1, 4, 1>), grid, dim3(512), 0, st, at, a);
     return VOX_OK;
 }
 // merge partials -> bf16 out [Nq,Hq,D] (standalone op path; the engine merges inside the o_proj prologue)
