@@ -318,7 +318,7 @@ def test_stack_forward_abi_bit_exact(dev):
     L.vox_stack_destroy(h)
 
 
-@pytest.mark.parametrize("n_rows", [12, 16, 24, 32, 48, 64, 75])
+@pytest.mark.parametrize("n_rows", [12, 16, 24, 32, 48, 64, 75, 100, 128, 140])
 def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072)):
     """9..32 rows take the one-launch full-K MFMA GEMM (norm prologue, SiLU*up / residual epilogues, fragment-major
     weights and activation hand-offs), 33+ the split-K pair: two decoder layers at depth-transformer widths vs the oracle's
@@ -364,7 +364,7 @@ def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072)):
 
     def check(max_kvlen, kv_tokens, hints):
         """every row = the newest token of its own request, which already holds kv_tokens tokens of random K/V"""
-        sc = _stack_config(ec, page, 80, max_kvlen)
+        sc = _stack_config(ec, page, 144, max_kvlen)
         h = ctypes.c_void_p()
         N.check(L.vox_stack_create(ctx, ctypes.byref(sc), arr, fn.data_ptr(), rope.data_ptr(), 64, ctypes.byref(h)))
         kv_ref = [np.zeros((P, 2, page, kvh, D), np.uint16) for _ in range(NL)]

@@ -376,9 +376,9 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
             return vox_launch_swizzle_frag(nullptr, src, *dst, rows, K) == VOX_OK;
         };
         s->fw.resize(cfg->layers);
-        bool ok = hipMalloc(&s->xfrag, (size_t)64 * cfg->hidden * 2) == hipSuccess && hipMalloc(&s->hfrag, (size_t)64 * cfg->ffn * 2) == hipSuccess &&
-                  hipMalloc(&s->afrag, (size_t)64 * nq * 2) == hipSuccess;
-        if (ok) { (void)hipMemset(s->afrag, 0, (size_t)64 * nq * 2); (void)hipMemset(s->xfrag, 0, (size_t)64 * cfg->hidden * 2); (void)hipMemset(s->hfrag, 0, (size_t)64 * cfg->ffn * 2); }
+        bool ok = hipMalloc(&s->xfrag, (size_t)128 * cfg->hidden * 2) == hipSuccess && hipMalloc(&s->hfrag, (size_t)128 * cfg->ffn * 2) == hipSuccess &&
+                  hipMalloc(&s->afrag, (size_t)128 * nq * 2) == hipSuccess;
+        if (ok) { (void)hipMemset(s->afrag, 0, (size_t)128 * nq * 2); (void)hipMemset(s->xfrag, 0, (size_t)128 * cfg->hidden * 2); (void)hipMemset(s->hfrag, 0, (size_t)128 * cfg->ffn * 2); }
         for (int l = 0; ok && l < cfg->layers; ++l) {
             const vox_layer_weights& w = s->layers[l];
             ok = mk(w.wqkv, (int)(nq + 2 * nkv), cfg->hidden, &s->fw[l].qkv) && mk(w.wo, cfg->hidden, (int)nq, &s->fw[l].o) &&

@@ -1103,8 +1103,8 @@ int vox_launch_swizzle_frag(hipStream_t st, const void* src, void* dst, int rows
 }
 
 static bool fullk_shape_ok(int B, int N, int K, int pro, int epi, int exact_rows = 8) {
-    if (B <= exact_rows || B < 2 || B > 64 || N % 16 || K % 256) return false;
-    if (B > 32 && N % 128) return false;          // 33..64 rows: two 32-row tiles per column tile (block ids 8 apart)
+    if (B <= exact_rows || B < 2 || B > 128 || N % 16 || K % 256) return false;
+    if (B > 32 && N % 128) return false;          // 33..128 rows: 2..4 32-row tiles per column tile (block ids 8 apart)
     const int ks = K / 256;
     if (pro == PRO_RMSNORM && (epi == EPI_STORE || epi == EPI_SILU_MUL)) return ks == 4 || ks == 8;
     if (pro == PRO_COPY && epi == EPI_STORE) return ks == 4 || ks == 8 || ks == 12 || ks == 16 || ks == 24 || ks == 32;
@@ -1122,9 +1122,9 @@ static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a0) {
     LinArgs a = a0;
     a.row_tiles = 1;
     if constexpr (MT == 2) {
-        if (a.B > 32) {            // 33..64 rows: two 32-row blocks per column tile
-            a.row_tiles = 2;
-            hipLaunchKernelGGL((k_gemm_fullk<2, KSTEPS, PRO, EPI, true>), dim3(a.N / 16 * 2), dim3(512), 0, st, a);
+        if (a.B > 32) {            // 33..128 rows (short prefills, depth step 1 of 17+ requests): 32-row blocks side by side
+            a.row_tiles = (a.B + 31) / 32;
+            hipLaunchKernelGGL((k_gemm_fullk<2, KSTEPS, PRO, EPI, true>), dim3(a.N / 16 * a.row_tiles), dim3(512), 0, st, a);
             return VOX_OK;
         }
         if constexpr (PRO == PRO_COPY) {
