@@ -36,7 +36,7 @@ def rnd(rng, *shape, s=1.0):
 @pytest.mark.parametrize("B,N_,K", [(1, 64, 256), (1, 2048, 2048), (2, 1030, 1024), (3, 512, 6144), (4, 4096, 2048),
                                     (5, 96, 512), (8, 3072, 1024), (9, 128, 2048), (19, 256, 768), (1, 7, 64),
                                     (16, 2048, 2048), (32, 4096, 2048), (32, 2048, 6144), (75, 1000, 1024), (33, 64, 96),
-                                    (8, 256, 13696), (7, 64, 13696), (6, 100, 13696), (1, 128, 13696), (2, 256, 13696), (3, 4096, 13696)])
+                                    (8, 256, 13696), (7, 64, 13696), (6, 100, 13696), (1, 128, 13696), (2, 256, 13696), (3, 4096, 13696), (12, 2051, 1024), (16, 1000, 2048), (31, 2051, 1024)])
 def test_linear_bit_exact(dev, B, N_, K):
     from vox_serve_amd import _native as N
     rng = np.random.default_rng(B * 1000 + N_ + K)

@@ -976,7 +976,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
         const bool wf = a.W_frag != nullptr;
         const int wstep = wf ? 64 : 4;
         const uint4* w0 = wf ? reinterpret_cast<const uint4*>(a.W_frag) + (size_t)ctile * (a.K >> 5) * 64 + fbase
-                             : reinterpret_cast<const uint4*>(a.W + (size_t)(n0 + fr) * a.K + kbase);
+                             : reinterpret_cast<const uint4*>(a.W + (size_t)((n0 + fr) < a.N ? (n0 + fr) : a.N - 1) * a.K + kbase);   // (N % 16 tail: clamped, not stored)
         const uint4* w1 = !SM ? nullptr
                           : wf ? reinterpret_cast<const uint4*>(a.W2_frag) + (size_t)ctile * (a.K >> 5) * 64 + fbase
                                : reinterpret_cast<const uint4*>(a.W2 + (size_t)(n0 + fr) * a.K + kbase);
@@ -1063,6 +1063,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
         if (SM) u += red[w][NB - 1][m][lane];
     }
     const int n = n0 + fr;
+    if (n >= a.N) return;           // tail columns of an N that is not a multiple of 16 (vocabulary heads)
     const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1103,7 +1104,8 @@ int vox_launch_swizzle_frag(hipStream_t st, const void* src, void* dst, int rows
 }
 
 static bool fullk_shape_ok(int B, int N, int K, int pro, int epi, int exact_rows = 8) {
-    if (B <= exact_rows || B < 2 || B > 128 || N % 16 || K % 256) return false;
+    if (B <= exact_rows || B < 2 || B > 128 || K % 256) return false;
+    if (N % 16 && (B > 32 || epi == EPI_SILU_MUL)) return false;    // a column tail only for plain outputs of <= 32 rows (row-major weights)
     if (B > 32 && N % 128) return false;          // 33..128 rows: 2..4 32-row tiles per column tile (block ids 8 apart)
     const int ks = K / 256;
     if (pro == PRO_RMSNORM && (epi == EPI_STORE || epi == EPI_SILU_MUL)) return ks == 4 || ks == 8;
@@ -1129,14 +1131,14 @@ static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a0) {
         }
         if constexpr (PRO == PRO_COPY) {
             // few column tiles: per-CU load rate is the limit, so use twice the CUs (two 16-row blocks per column tile)
-            if (a.N / 16 <= 128 && (a.N / 16) % 8 == 0) {
+            if (a.N % 16 == 0 && a.N / 16 <= 128 && (a.N / 16) % 8 == 0) {
                 a.row_tiles = 2;
                 hipLaunchKernelGGL((k_gemm_fullk<1, KSTEPS, PRO, EPI, true>), dim3(a.N / 8), dim3(512), 0, st, a);
                 return VOX_OK;
             }
         }
     }
-    hipLaunchKernelGGL((k_gemm_fullk<MT, KSTEPS, PRO, EPI, false>), dim3(a.N / 16), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((k_gemm_fullk<MT, KSTEPS, PRO, EPI, false>), dim3((a.N + 15) / 16), dim3(512), 0, st, a);
     return VOX_OK;
 }
 template <int PRO, int EPI>
