@@ -26,16 +26,18 @@ def plan(eng, kvlen):
     pages = [[b * 3 + j for j in range((kvlen + ps - 1) // ps)] for b in range(B)]
     indptr = np.cumsum([0] + [len(p) for p in pages]); indices = sum(pages, [])
     eng.upload_plan(pos=[kvlen] * B, kvlen=[kvlen] * B, page=[p[-1] for p in pages], slot=[(kvlen - 1) % ps] * B, indptr=indptr, indices=indices)
+cs = [torch.cuda.Stream(device=dev) for _ in engs]      # one caller stream per engine: the engines' entry/exit fences must not chain through a common stream
 for w in range(5):
-    for eng in engs:
-        plan(eng, kv0 + w); eng.frame(B, kv0 + w, sc)
+    for eng, c in zip(engs, cs):
+        with torch.cuda.stream(c):
+            plan(eng, kv0 + w); eng.frame(B, kv0 + w, sc)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for f in range(frames):
-    for eng in engs:
-        plan(eng, kv0 + 5 + f)
-        eng.frame(B, kv0 + 5 + f, sc)
-        ids = None
+    for eng, c in zip(engs, cs):
+        with torch.cuda.stream(c):
+            plan(eng, kv0 + 5 + f)
+            eng.frame(B, kv0 + 5 + f, sc)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"{NE} engines x B={B}: {dt / frames * 1e3:.3f} ms per round of {NE * B} requests -> {NE * B * 1920 * frames / dt:.0f} samples/s")
