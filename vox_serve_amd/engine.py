@@ -147,6 +147,8 @@ class Qwen3Engine:
             off += n
         self.plan_dev = torch.zeros(off, **i32)
         self.plan_host = torch.zeros(off, dtype=torch.int32).pin_memory()
+        self._plan_np = self.plan_host.numpy()       # a view: numpy writes land in the pinned block
+        self._ptab_last = {}
         self.kv = torch.zeros(t.layers, max_pages, 2, page_size, t.kv_heads, t.head_dim, dtype=torch.bfloat16, device=dev)
         self.out_ids = torch.zeros(max_batch, G1, **i32)
         self.out_logits = torch.zeros(max_batch, cfg.vocab, dtype=torch.bfloat16, device=dev)
@@ -187,17 +189,26 @@ class Qwen3Engine:
         return self.plan_host[off:off + n]
 
     def upload_plan(self, **arrays):
-        """Host int lists/arrays -> the pinned block -> one async H2D copy (no synchronisation)."""
+        """Host int lists/arrays -> the pinned block -> one async H2D copy (no synchronisation).
+        Host cost matters (the GPU idles between frames while this runs): plain numpy writes into views of the pinned
+        block, and the per-row page table is rewritten only for rows whose page list changed since the last upload."""
         self.stream.synchronize()       # the previous frame may still read the pinned block's last upload
+        hv = self._plan_np
         for name, a in arrays.items():
             a = np.asarray(a, dtype=np.int32)
-            self._ph(name)[: len(a)] = torch.from_numpy(a)
+            off, _ = self._plan_layout[name]
+            hv[off: off + a.size] = a.ravel()
         if "indptr" in arrays and "indices" in arrays and len(arrays["indptr"]) - 1 <= self.max_batch:
             ip, ix = np.asarray(arrays["indptr"], dtype=np.int64), np.asarray(arrays["indices"], dtype=np.int32)
-            pt = self._ph("ptab").view(self.max_batch, self.pt_stride)      # per-row page table (decode frames)
+            off, _ = self._plan_layout["ptab"]
+            pt = hv[off: off + self.max_batch * self.pt_stride].reshape(self.max_batch, self.pt_stride)
+            last = self._ptab_last
             for b in range(len(ip) - 1):
-                n = min(int(ip[b + 1] - ip[b]), self.pt_stride)
-                pt[b, :n] = torch.from_numpy(ix[ip[b]: ip[b] + n])
+                row = ix[ip[b]: ip[b + 1]][: self.pt_stride]
+                prev = last.get(b)
+                if prev is None or prev.size != row.size or not np.array_equal(prev, row):
+                    pt[b, : row.size] = row
+                    last[b] = row.copy()
         with self._OnStream(self):
             self.plan_dev.copy_(self.plan_host, non_blocking=True)
 
@@ -369,6 +380,8 @@ class LMEngine(Qwen3Engine):
             off += n
         self.plan_dev = torch.zeros(off, **i32)
         self.plan_host = torch.zeros(off, dtype=torch.int32).pin_memory()
+        self._plan_np = self.plan_host.numpy()       # a view: numpy writes land in the pinned block
+        self._ptab_last = {}
         self.kv = torch.zeros(c.layers, max_pages, 2, page_size, c.kv_heads, c.head_dim, dtype=torch.bfloat16, device=dev)
         self.out_ids = torch.zeros(max_batch, **i32)
         self.out_logits = torch.zeros(max_batch, cfg.vocab_out, dtype=torch.bfloat16, device=dev)
@@ -499,6 +512,8 @@ class CSMEngine(Qwen3Engine):
             off += n
         self.plan_dev = torch.zeros(off, **i32)
         self.plan_host = torch.zeros(off, dtype=torch.int32).pin_memory()
+        self._plan_np = self.plan_host.numpy()       # a view: numpy writes land in the pinned block
+        self._ptab_last = {}
         self.kv = torch.zeros(b.layers, max_pages, 2, page_size, b.kv_heads, b.head_dim, dtype=torch.bfloat16, device=dev)
         self.out_ids = torch.zeros(max_batch, C1, **i32)
         self.out_logits = torch.zeros(max_batch, V, dtype=torch.bfloat16, device=dev)

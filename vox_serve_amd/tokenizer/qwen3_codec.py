@@ -257,6 +257,8 @@ class Qwen3TTSDecoder:
         self._free_slots = list(range(max_slots))
         self.hop = c.total_upsample
         self._out = torch.empty(max_batch, detokenize_interval * self.hop, dtype=torch.float32, device=dev)
+        self._graphs, self.use_graph = {}, True
+        self._stream = torch.cuda.Stream(device=dev)
 
     @property
     def state_bytes_per_request(self) -> int:
@@ -287,13 +289,57 @@ class Qwen3TTSDecoder:
         if stride < self.cfg.num_quantizers:
             raise ValueError(f"Expected {self.cfg.num_quantizers} layer of codes, got {stride}")
         slots = decoder_cache.slot.to(torch.int32).contiguous()
+        if self.use_graph:
+            return self._decode_chunk_graph(codes, slots, b, t, stride), decoder_cache
         out = self._out[:b, : t * self.hop]
         if not out.is_contiguous():
             out = torch.empty(b, t * self.hop, dtype=torch.float32, device=self.device)
         N.check(self.L.vox_codec_decode_chunk(self.h, N.stream(), N.ptr(codes), stride, N.ptr(slots), b, t, N.ptr(out)))
         return out[:, None, :], decoder_cache
 
+    def _decode_chunk_graph(self, codes, slots, b, t, stride):
+        """The ~150 launches of a chunk as one hipGraph per (rows, frames, code stride): the host is free again after one
+        launch (it has the next LM frame to submit).  Inputs are copied into graph-stable buffers; all streaming state lives on
+        the device and is indexed through the slot buffer, so a replay continues exactly where the last chunk stopped.  The
+        first chunk of a shape runs eagerly (kernel attributes are set outside capture), the second is captured and replayed.
+        The returned view is valid until the next chunk of the same shape."""
+        key = (b, t, stride)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = {"codes": torch.empty(b, t, stride, dtype=torch.int32, device=self.device),
+                                       "slots": torch.empty(b, dtype=torch.int32, device=self.device),
+                                       "out": torch.empty(b, t * self.hop, dtype=torch.float32, device=self.device), "g": None, "calls": 0}
+        # capture needs a non-default stream: the chunk runs on the decoder's own stream, fenced against the caller's
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            ent["codes"].copy_(codes, non_blocking=True)
+            ent["slots"].copy_(slots, non_blocking=True)
+            st = N.stream()
+            args = (self.h, st, N.ptr(ent["codes"]), stride, N.ptr(ent["slots"]), b, t, N.ptr(ent["out"]))
+            ent["calls"] += 1
+            if ent["calls"] == 1:
+                N.check(self.L.vox_codec_decode_chunk(*args))
+            else:
+                if ent["g"] is None:
+                    N.check(self.L.vox_graph_begin(N.ctx(), st))
+                    try:
+                        N.check(self.L.vox_codec_decode_chunk(*args))
+                    finally:
+                        gh = ctypes.c_void_p()
+                        N.check(self.L.vox_graph_end(N.ctx(), st, ctypes.byref(gh)))
+                    ent["g"] = gh
+                N.check(self.L.vox_graph_launch(ent["g"], st))
+        codes.record_stream(self._stream)
+        slots.record_stream(self._stream)
+        cur.wait_stream(self._stream)
+        return ent["out"][:, None, :]
+
     def close(self):
+        for ent in self._graphs.values():
+            if ent["g"] is not None:
+                self.L.vox_graph_destroy(ent["g"])
+        self._graphs.clear()
         if self.h:
             self.L.vox_codec_destroy(self.h)
             self.h = None
