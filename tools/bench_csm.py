@@ -59,15 +59,32 @@ def step(i, timed):
     ids = eng.out_ids[:B].cpu()
     pos = [p + 1 for p in pos]
     if i % 10 == 9:
-        wav = mimi.decode(ring, code_layout="BTQ")
-        return (wav[:, 0] * 32767).to(torch.int16).cpu().numpy()
+        # the chunk runs on its own stream beside the following frames (like bench.py); its PCM is fetched one chunk later
+        global pend
+        done = None
+        if pend is not None:
+            pend[1].synchronize(); done = pend[0].numpy().copy()
+        snap = ring.clone()
+        codec_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(codec_stream):
+            wav = mimi.decode(snap, code_layout="BTQ")
+            pcm_host.copy_((wav[:, 0] * 32767).to(torch.int16), non_blocking=True)
+            ev_ = torch.cuda.Event(); ev_.record(codec_stream)
+        snap.record_stream(codec_stream)
+        pend = (pcm_host, ev_)
+        return done
 
+codec_stream = torch.cuda.Stream(device=dev)
+pcm_host = torch.zeros(B, 19200, dtype=torch.int16).pin_memory()
+pend = None
 for i in range(args.warmup):
     step(i, False)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(args.steps):
     step(i, True)
+if pend is not None:
+    pend[1].synchronize()                 # the last chunk's audio is on the host inside the timed region
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 t1 = time.perf_counter(); mimi.decode(ring, code_layout="BTQ"); torch.cuda.synchronize(); t_codec = time.perf_counter() - t1

@@ -187,6 +187,8 @@ class MimiDecoder:
         h = ctypes.c_void_p()
         N.check(self.L.vox_mimi_create(N.ctx(), ctypes.byref(mc), ctypes.byref(mw), max_batch, max_frames, ctypes.byref(h)))
         self.h, self._mw = h, mw
+        self._graphs, self.use_graph = {}, True
+        self._stream = torch.cuda.Stream(device=self.device)
 
     sample_rate = property(lambda self: self.cfg.sample_rate)
     hop = property(lambda self: self.cfg.hop)
@@ -199,11 +201,45 @@ class MimiDecoder:
         b, t, stride = codes.shape
         if stride < self.cfg.n_q:
             raise ValueError(f"Expected {self.cfg.n_q} codebooks, got {stride}")
+        if self.use_graph and b <= self.max_batch:
+            return self._decode_graph(codes, b, t, stride)
         out = torch.empty(b, 1, t * self.hop, dtype=torch.float32, device=self.device)
         for b0 in range(0, b, self.max_batch):
             nb = min(self.max_batch, b - b0)
             N.check(self.L.vox_mimi_decode(self.h, N.stream(), codes[b0:b0 + nb].data_ptr(), stride, nb, t, out[b0:b0 + nb].data_ptr()))
         return out
+
+    def _decode_graph(self, codes, b, t, stride):
+        """One hipGraph per (rows, frames, code stride) on the decoder's own stream (the stateless chunk is a pure function of
+        the codes): one host launch instead of ~60.  First call of a shape eager, second captured, then replayed.  The
+        returned tensor is a fresh copy-free view valid until the next call of the same shape."""
+        key = (b, t, stride)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = {"codes": torch.empty(b, t, stride, dtype=torch.int32, device=self.device),
+                                       "out": torch.empty(b, 1, t * self.hop, dtype=torch.float32, device=self.device), "g": None, "calls": 0}
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            ent["codes"].copy_(codes, non_blocking=True)
+            st = N.stream()
+            args = (self.h, st, ent["codes"].data_ptr(), stride, b, t, ent["out"].data_ptr())
+            ent["calls"] += 1
+            if ent["calls"] == 1:
+                N.check(self.L.vox_mimi_decode(*args))
+            else:
+                if ent["g"] is None:
+                    N.check(self.L.vox_graph_begin(N.ctx(), st))
+                    try:
+                        N.check(self.L.vox_mimi_decode(*args))
+                    finally:
+                        gh = ctypes.c_void_p()
+                        N.check(self.L.vox_graph_end(N.ctx(), st, ctypes.byref(gh)))
+                    ent["g"] = gh
+                N.check(self.L.vox_graph_launch(ent["g"], st))
+        codes.record_stream(self._stream)
+        cur.wait_stream(self._stream)
+        return ent["out"]
 
     # ---- streaming option (not the reference's behaviour: it decodes every chunk from a fresh state, mimi.py:3085-3089) ----
     def enable_streaming(self, max_slots: int):
@@ -249,6 +285,10 @@ class MimiDecoder:
         return out
 
     def close(self):
+        for ent in self._graphs.values():
+            if ent["g"] is not None:
+                self.L.vox_graph_destroy(ent["g"])
+        self._graphs.clear()
         if self.h:
             self.L.vox_mimi_destroy(self.h)
             self.h = None
