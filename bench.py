@@ -55,6 +55,7 @@ class Loop:
         self.sc = self.eng.sampling_cfg(greedy=True)
         self.tok_ring = torch.zeros(B, INTERVAL, self.cfg.n_groups + 1, dtype=torch.int32, device=dev)
         self.pages = [[b * self.pages_per_req + j for j in range(self.pages_per_req)] for b in range(B)]
+        self._pages_np = np.asarray(self.pages, dtype=np.int64)
         self.kvlen = [0] * B
         self.nframe = 0
         self.samples = 0
@@ -96,15 +97,14 @@ class Loop:
     def step(self, timed_events=None, wait_pcm=False):
         """One frame for the whole batch."""
         e, B, ps = self.eng, self.B, self.ps
-        indptr, indices, page, slot = [0], [], [], []
-        for b in range(B):
-            self.kvlen[b] += 1
-            npg = (self.kvlen[b] + ps - 1) // ps
-            indptr.append(indptr[-1] + npg)
-            indices += self.pages[b][:npg]
-            page.append(self.pages[b][npg - 1])
-            slot.append((self.kvlen[b] - 1) % ps)
-        e.upload_plan(pos=self.pos, kvlen=self.kvlen, page=page, slot=slot, indptr=indptr, indices=indices)
+        kv = np.asarray(self.kvlen, dtype=np.int64) + 1            # the paged-KV plan of this frame, vectorised over the batch
+        self.kvlen = kv.tolist()
+        npg = (kv + ps - 1) // ps
+        indptr = np.concatenate([[0], np.cumsum(npg)])
+        pages = self._pages_np
+        indices = pages[np.arange(pages.shape[1])[None, :] < npg[:, None]]
+        page, slot = pages[np.arange(B), npg - 1], (kv - 1) % ps
+        e.upload_plan(pos=self.pos, kvlen=kv, page=page, slot=slot, indptr=indptr, indices=indices)
         if timed_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(e.stream)
