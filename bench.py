@@ -4,6 +4,10 @@ named architecture, synthetic fixed-length prompts), speech-token decode + token
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment) re-executes itself under
+torch.distributed.run with N ranks on 127.0.0.1; the JSON line reports the ranks that actually took part (`ranks_seen`).
+Without --batch the headline is batch 1 (BASELINE configs[1]) and the same line carries driver-timed sub-results for
+batch 8 and batch 32 (`batch8`, `batch32`: value, ms_per_step, roofline) — the metric is quoted at batch 1 / 8 / 32.
 
 A "step" is one audio frame (1920 samples at 24 kHz) for the whole batch of B concurrent requests: one hipGraph
 replay = talker decode step + codebook-0 sampling + the 15-step depth loop (+ feedback of the next inputs), the
@@ -39,18 +43,18 @@ def algorithmic_bytes_per_frame(B, kv_mean):
 class Loop:
     """B concurrent requests in lock-step on one GPU: the worker's decode + detokenize hot loop."""
 
-    def __init__(self, B, max_frames, dev):
+    def __init__(self, B, max_frames, dev, W=None, codec_W=None):
         from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
         from vox_serve_amd.synth import synth_qwen3_codec_weights, synth_qwen3_weights
         from vox_serve_amd.tokenizer.qwen3_codec import Qwen3TTSDecoder
         self.B, self.dev, self.cfg = B, dev, Qwen3Cfg()
         self.ps = 128
         self.pages_per_req = (PROMPT_TOKENS + max_frames + self.ps) // self.ps + 1
-        W = self.W = synth_qwen3_weights(self.cfg, dev, seed=0)
+        W = self.W = W if W is not None else synth_qwen3_weights(self.cfg, dev, seed=0)
         self.eng = Qwen3Engine(self.cfg, W, max_batch=B, page_size=self.ps, max_pages=B * self.pages_per_req + 1,
                                max_seq_len=2304, max_prefill_rows=128)
         self.eng.keep_hidden = False
-        self.codec = Qwen3TTSDecoder(synth_qwen3_codec_weights(seed=0), device=dev, max_batch=B, max_slots=B,
+        self.codec = Qwen3TTSDecoder(codec_W if codec_W is not None else synth_qwen3_codec_weights(seed=0), device=dev, max_batch=B, max_slots=B,
                                      detokenize_interval=INTERVAL)
         self.sc = self.eng.sampling_cfg(greedy=True)
         self.tok_ring = torch.zeros(B, INTERVAL, self.cfg.n_groups + 1, dtype=torch.int32, device=dev)
@@ -145,7 +149,7 @@ class Loop:
         return pcm
 
 
-def cpu_baseline(loop, budget_s=25.0):
+def cpu_baseline(W, budget_s=25.0):
     """The CPU oracle (oracle/voxref.c, OpenMP; oracle/qwen3_codec_ref.py, torch CPU) on the same workload:
     talker+depth decode frames at B=1 with kv=75, plus one codec chunk.  Reported, never the product path."""
     from oracle import qwen3_codec_ref as CR
@@ -153,7 +157,7 @@ def cpu_baseline(loop, budget_s=25.0):
     from oracle import voxref as vr
     cores = os.cpu_count() or 1
     ref_cfg = QR.Qwen3Cfg(max_pos=256)
-    src = {k: v.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16) for k, v in loop.W.items()}
+    src = {k: v.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16) for k, v in W.items()}
     m = QR.Qwen3Ref(ref_cfg, src, page_size=128, max_pages=2, max_batch=1)
     req = QR.RefRequest()
     rng = np.random.default_rng(1)
@@ -185,72 +189,47 @@ def cpu_baseline(loop, budget_s=25.0):
 
 
 def pmc_traffic(B):
-    """HBM bytes per LM graph launch from the committed rocprofv3 PMC passes of this same command (profiles/
-    round1_pmc_traffic.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py).  Counters cannot be read from inside the
-    timed run, so this is the recorded measurement for the same batch size, or null when none is committed."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
-    try:
-        rec = json.load(open(path)).get(f"batch_{B}")
-        return float(rec["fetch_corrected_bytes_per_launch"] + rec["write_raw_bytes_per_launch"]) if rec else None
-    except (OSError, ValueError, KeyError):
-        return None
+    """HBM bytes per LM graph launch as RECORDED by the committed rocprofv3 PMC passes of this same command
+    (profiles/round*_pmc_traffic.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py).  Hardware counters cannot be read from inside the
+    timed run, so the line labels this value `traffic_source: "recorded <file>"`; null when no pass is committed."""
+    pdir = os.path.join(ROOT, "profiles")
+    for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+        try:
+            rec = json.load(open(os.path.join(pdir, name))).get(f"batch_{B}")
+            if rec:
+                return float(rec["fetch_corrected_bytes_per_launch"] + rec["write_raw_bytes_per_launch"]), f"recorded profiles/{name}"
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1, help="concurrent requests per GPU (BASELINE configs: 1 and 32)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ttfa-requests", type=int, default=5)
-    ap.add_argument("--exact-rows", type=int, default=8, help="rows up to which linears use the fixed-order (oracle-bit-exact) "
-                    "kernels; default 8 = the parity-tested configuration, lower = opt-in fast mode (bf16-rounding parity)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)         # RCCL; used only for the barrier + max-reduce
-
-    B = args.batch
-    if args.exact_rows != 8:
-        from vox_serve_amd import _native as N
-        N.set_exact_rows(args.exact_rows)
-    loop = Loop(B, args.steps + args.warmup + 64, dev)
-
-    # ---- TTFA (p50): request start -> first PCM chunk on the host, batch-1 streaming, outside the timed steps ----
+def run_batch(B, args, dev, world, shared, ttfa_requests=0):
+    """The timed region for one batch size: W warm-up steps, a barrier, exactly K steps, barrier, max over ranks."""
+    import torch.distributed as dist
+    # requests are measured mid-stream: the KV length over the timed steps averages --kv-mean (SURVEY 8d: 200)
+    pre = max(0, int(args.kv_mean - PROMPT_TOKENS - args.warmup - args.steps / 2))
+    loop = Loop(B, pre + args.steps + args.warmup + 64, dev, shared["W"], shared["codec_W"])
     ttfa, ttfa2 = [], []
-    if rank == 0 and args.ttfa_requests > 0:
-        solo = loop if B == 1 else None
-        if solo is not None:
-            # (SURVEY 8d: the default detokenize_interval 10, and the TTFA-focused setting --detokenize-interval 2)
-            for interval, acc in ((INTERVAL, ttfa), (2, ttfa2)):
-                solo.interval = interval
-                for _ in range(args.ttfa_requests + 1):
-                    solo.kvlen, solo.samples = [0] * B, 0
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    solo.start_requests()
-                    pcm = None
-                    while pcm is None:
-                        _, pcm = solo.step(wait_pcm=True)
-                    acc.append((time.perf_counter() - t0) * 1e3)
-                    solo.codec.release_cache(solo.cache)
-                del acc[0]                      # (first request of a setting: graph capture for the new kv bucket / chunk shape)
-            solo.interval = INTERVAL
-
+    if ttfa_requests > 0 and B == 1:
+        # engine-level TTFA (request start -> first PCM chunk on the host), lock-step loop, outside the timed steps
+        for interval, acc in ((INTERVAL, ttfa), (2, ttfa2)):
+            loop.interval = interval
+            for _ in range(ttfa_requests + 1):
+                loop.kvlen, loop.samples = [0] * B, 0
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loop.start_requests()
+                pcm = None
+                while pcm is None:
+                    _, pcm = loop.step(wait_pcm=True)
+                acc.append((time.perf_counter() - t0) * 1e3)
+                loop.codec.release_cache(loop.cache)
+            del acc[0]                      # (first request of a setting: graph capture for the new kv bucket / chunk shape)
+        loop.interval = INTERVAL
     loop.kvlen, loop.samples = [0] * B, 0
     loop.start_requests()
-    for _ in range(args.warmup):
+    for _ in range(pre + args.warmup):
         loop.step()
     torch.cuda.synchronize()
     if world > 1:
@@ -270,31 +249,201 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     frame_gpu_s = float(np.mean([a.elapsed_time(b) for a, b in events])) * 1e-3
+    kv_mean = kv_start + args.steps / 2
+    alg = algorithmic_bytes_per_frame(B, kv_mean)
+    samples_total = world * B * 1920 * args.steps
+    traffic, src = pmc_traffic(B)
+    res = {
+        "value": samples_total / dt, "ms_per_step": dt / args.steps * 1e3, "batch_per_gpu": B,
+        "realtime_factor_per_request": samples_total / dt / 24000.0 / (world * B), "kv_mean": kv_mean,
+        "roofline": {"bound": "hbm", "achieved": alg / frame_gpu_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg / frame_gpu_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                     "launch": "one hipGraph replay = one LM frame (talker + 15 depth steps + sampling)",
+                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": frame_gpu_s * 1e3},
+    }
+    if ttfa:
+        res["ttfa_ms_p50_engine"] = float(np.median(ttfa))
+        res["ttfa_ms_p50_engine_detokenize_interval_2"] = float(np.median(ttfa2))
+    loop.eng.close()
+    loop.codec.close()
+    return res
+
+
+def serving_ttfa(dev, shared, n_requests, load, interval=INTERVAL, seed=0):
+    """TTFA through the serving path proper: `encode_request` on the scheduler's transport -> first
+    `id|AUDIO|` message on the result queue, via Scheduler -> ModelWorker -> engine -> codec.  p50 over `n_requests`
+    probe requests, each submitted while `load` other requests are decoding (load 0 = batch-1 streaming)."""
+    from vox_serve_amd.model.qwen3_tts import Qwen3TTSModel
+    from vox_serve_amd.sampling import SamplingConfig
+    from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
+    from vox_serve_amd.worker import ModelWorker
+    mb = max(8, load + 1)
+    m = Qwen3TTSModel("qwen3-tts", shared["W"], shared["codec_W"], device=str(dev), detokenize_interval=interval,
+                      max_batch_size=mb, page_size=128, max_num_pages=4 * mb + 8, max_seq_len=2304, max_prefill_tokens=128)
+    m.default_sampling_config = SamplingConfig(greedy=True, max_tokens=400, repetition_penalty=1.05, repetition_window=-1)
+    t = QueueTransport()
+    w = ModelWorker(model=m, max_batch_size=mb, max_num_pages=4 * mb + 8, page_size=128, device=str(dev))
+    s = Scheduler(w, max_batch_size=mb, transport=t)
+    rng = np.random.default_rng(seed)
+    counter = [0]
+
+    def submit(tag):
+        counter[0] += 1
+        rid = f"{tag}{counter[0]}"
+        ids = [1, 2, 3] + rng.integers(0, 151000, 64).tolist() + [4, 5, 6, 7, 8]      # 3 role + 64 text + 5 template tail
+        t.requests.put(encode_request(rid, "", model_kwargs={"prompt_token_ids": ids, "language": "english"}))
+        return rid
+
+    def drain(until_rid=None):
+        hit = False
+        while not t.results.empty():
+            msg = t.results.get()
+            rid, kind, _ = msg.split(b"|", 2)
+            if until_rid is not None and kind == b"AUDIO" and rid.decode() == until_rid:
+                hit = True
+        return hit
+
+    out = []
+    for i in range(n_requests + 1):
+        # keep `load` background requests decoding (a finished one is replaced before the probe goes in)
+        while sum(1 for r in s.active_requests if r.request_id.startswith("bg")) + t.requests.qsize() < load:
+            submit("bg")
+        for _ in range(4 * load + 2):
+            s._step()
+            drain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rid = submit("probe")
+        while True:
+            s._step()
+            if drain(rid):
+                break
+        out.append((time.perf_counter() - t0) * 1e3)
+        if load == 0:
+            s.run_until_idle(1000)       # let the probe finish so that the next one runs alone
+            drain()
+    del out[0]
+    m.engine.close()
+    m.audio_decoder.close()
+    return float(np.median(out))
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher: start N ranks of this script under torch.distributed.run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=None, help="concurrent requests per GPU of the headline value (default 1, with "
+                    "batch 8 and 32 as sub-results; an explicit --batch runs that batch size only)")
+    ap.add_argument("--sub-batches", type=str, default=None, help="comma list of extra batch sizes reported as batchN objects")
+    ap.add_argument("--kv-mean", type=float, default=200.0, help="mean KV length over the timed steps (SURVEY 8d: 200)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ttfa-requests", type=int, default=5, help="engine-level TTFA samples per setting (lock-step loop)")
+    ap.add_argument("--serving-ttfa-requests", type=int, default=100, help="TTFA samples through Scheduler + ModelWorker (0 = skip)")
+    ap.add_argument("--exact-rows", type=int, default=8, help="rows up to which linears use the fixed-order (oracle-bit-exact) "
+                    "kernels; default 8 = the parity-tested configuration, lower = opt-in fast mode (bf16-rounding parity)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPU(s) visible")
+    torch.cuda.set_device(local)                                # one process per GPU, bound before any allocation
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI; off the token path
+
+    if args.exact_rows != 8:
+        from vox_serve_amd import _native as N
+        N.set_exact_rows(args.exact_rows)
+    from vox_serve_amd.engine import Qwen3Cfg
+    from vox_serve_amd.synth import synth_qwen3_codec_weights, synth_qwen3_weights
+    shared = {"W": synth_qwen3_weights(Qwen3Cfg(), dev, seed=0 if rank == 0 else 1 + rank), "codec_W": synth_qwen3_codec_weights(seed=0)}
+    bcast = None
+    if world > 1:
+        # load-time weight distribution of the DP pool: rank 0's arena -> every replica over RCCL (worker/dp_pool.py);
+        # the other ranks start from different random weights, so a wrong broadcast would show in their outputs
+        from vox_serve_amd.worker.dp_pool import broadcast_weights
+        nbytes = sum(v.numel() * v.element_size() for v in shared["W"].values())
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        broadcast_weights(shared["W"])
+        torch.cuda.synchronize(); dist.barrier()
+        bdt = time.perf_counter() - t0
+        chk = torch.stack([shared["W"][k].float().sum() for k in sorted(shared["W"])[:8]]).to(torch.float64)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        bcast = {"bytes": nbytes, "seconds": bdt, "GBps": nbytes / bdt / 1e9, "replicas_identical": bool(torch.equal(lo, hi))}
+    ranks_seen = world
+    if world > 1:
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+
+    head_B = args.batch if args.batch is not None else 1
+    subs = [] if args.batch is not None else [8, 32]
+    if args.sub_batches is not None:
+        subs = [int(x) for x in args.sub_batches.split(",") if x.strip()]
+    head = run_batch(head_B, args, dev, world, shared, ttfa_requests=args.ttfa_requests if rank == 0 else 0)
+    sub_res = {b: run_batch(b, args, dev, world, shared) for b in subs}
+
+    serving = {}
+    if world == 1 and args.serving_ttfa_requests > 0 and args.batch is None:
+        n = args.serving_ttfa_requests
+        serving["ttfa_ms_p50"] = serving_ttfa(dev, shared, n, 0)
+        serving["ttfa_ms_p50_detokenize_interval_2"] = serving_ttfa(dev, shared, max(10, n // 2), 0, interval=2)
+        serving["ttfa_ms_p50_under_32way_load"] = serving_ttfa(dev, shared, max(10, n // 5), 31)
 
     if rank == 0:
-        kv_mean = kv_start + args.steps / 2
-        alg = algorithmic_bytes_per_frame(B, kv_mean)
-        samples_total = world * B * 1920 * args.steps
         out = {
             "metric": "audio samples/sec, Qwen3-TTS-1.7B streaming decode + codec",
-            "value": samples_total / dt, "unit": "audio samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": head["value"], "unit": "audio samples/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Qwen3-TTS-1.7B bf16, batch={B}/GPU streaming, greedy, {PROMPT_TOKENS}-token prompt, "
-                                   f"detokenize_interval {INTERVAL}, page_size 128"
-                                   + ("" if args.exact_rows == 8 else f", exact_rows {args.exact_rows} (fast mode)"), "batch_per_gpu": B,
+            "config": {"workload": f"Qwen3-TTS-1.7B bf16, batch={head_B}/GPU streaming, greedy, {PROMPT_TOKENS}-token prompt, "
+                                   f"detokenize_interval {INTERVAL}, page_size 128, mean kv {head['kv_mean']:.0f}"
+                                   + ("" if args.exact_rows == 8 else f", exact_rows {args.exact_rows} (fast mode)"), "batch_per_gpu": head_B,
                        "frames_per_request": args.steps, "parallelism": f"dp{world} (independent replicas, no collective on the data path)"},
-            "realtime_factor": samples_total / dt / 24000.0 / (world * B),
-            "ttfa_ms_p50": float(np.median(ttfa)) if ttfa else None,
-            "ttfa_ms_p50_detokenize_interval_2": float(np.median(ttfa2)) if ttfa2 else None,
-            "roofline": {"bound": "hbm", "achieved": alg / frame_gpu_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / frame_gpu_s / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(B),
-                         "launch": "one hipGraph replay = one LM frame (talker + 15 depth steps + sampling)",
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": frame_gpu_s * 1e3},
+            "realtime_factor": head["realtime_factor_per_request"],
+            "ttfa_ms_p50": serving.get("ttfa_ms_p50", head.get("ttfa_ms_p50_engine")),
+            "ttfa_ms_p50_detokenize_interval_2": serving.get("ttfa_ms_p50_detokenize_interval_2", head.get("ttfa_ms_p50_engine_detokenize_interval_2")),
+            "ttfa_path": ("encode_request -> Scheduler -> ModelWorker -> first id|AUDIO| on the result queue, p50" if serving
+                          else "engine lock-step loop (request start -> first PCM chunk on the host), p50"),
+            "roofline": head["roofline"],
         }
+        for k in ("ttfa_ms_p50_under_32way_load",):
+            if k in serving:
+                out[k] = serving[k]
+        for k in ("ttfa_ms_p50_engine", "ttfa_ms_p50_engine_detokenize_interval_2"):
+            if k in head:
+                out[k] = head[k]
+        for b, r in sub_res.items():
+            out[f"batch{b}"] = {k: r[k] for k in ("value", "ms_per_step", "batch_per_gpu", "realtime_factor_per_request", "kv_mean", "roofline")}
+        if bcast:
+            out["weight_broadcast_rccl"] = bcast
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N=1 only (other ranks would idle in RCCL)
             try:
-                out["cpu_baseline"] = cpu_baseline(loop)
+                out["cpu_baseline"] = cpu_baseline(shared["W"])
             except Exception as ex:  # the baseline is a reported extra; never let it hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)[:200]}
         print(json.dumps(out), flush=True)

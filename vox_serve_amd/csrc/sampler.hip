@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
     __shared__ u32 cand_key[SAMP_KMAX], srt_key[SAMP_KMAX];
     __shared__ int cand_idx[SAMP_KMAX], srt_idx[SAMP_KMAX];
     __shared__ float pe[SAMP_KMAX];
-    __shared__ int wcnt[4];
+    __shared__ int wcnt[8];     // per-wave tie counts, double-buffered by pass parity
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = a.V;
@@ -189,15 +189,19 @@ __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
                 }
             }
         } else {
-            for (int base = 0; base < V; base += 256) {
+            // the running tie count lives in a register of every thread (all threads add the same four wave counts), and the
+            // wave counts are double-buffered by iteration parity: one barrier per pass, and no wave can overwrite a count
+            // that a slower wave has yet to read
+            int seen = 0;
+            for (int base = 0, it = 0; base < V; base += 256, it ^= 1) {
                 const int v = base + tid;
                 const u32 ky = v < V ? keys[v] : 0;
                 const bool tie = v < V && ky == T;
                 const unsigned long long bal = __ballot(tie);
-                if (lane == 0) wcnt[wave] = __popcll(bal);
+                if (lane == 0) wcnt[it * 4 + wave] = __popcll(bal);
                 __syncthreads();
-                int before = sh_i[6];
-                for (int w = 0; w < wave; ++w) before += wcnt[w];
+                int before = seen;
+                for (int w = 0; w < wave; ++w) before += wcnt[it * 4 + w];
                 before += __popcll(bal & ((1ull << lane) - 1ull));
                 const bool sel = (v < V && ky > T) || (tie && before < r);
                 if (sel) {
@@ -205,8 +209,7 @@ __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
                     cand_key[s] = ky;
                     cand_idx[s] = v;
                 }
-                __syncthreads();
-                if (tid == 0) sh_i[6] += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+                seen += wcnt[it * 4 + 0] + wcnt[it * 4 + 1] + wcnt[it * 4 + 2] + wcnt[it * 4 + 3];
             }
         }
         __syncthreads();

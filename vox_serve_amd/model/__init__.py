@@ -11,12 +11,35 @@ from .base import BaseLM, BaseLMWithDepth, PreprocessOutput  # noqa: F401
 MODEL_REGISTRY: Dict[str, Callable] = {}
 
 
-def register_model(*names):
+def register_model(pattern, model_class=None, *more):
+    """`register_model(pattern, model_class)` — the reference's call (model/__init__.py:161-169; the pattern is stored
+    lower-cased).  Also usable as a decorator over several patterns (`@register_model("a", "b")`), which is how the
+    built-in families below register their loader functions."""
+    if model_class is not None and not isinstance(model_class, str):
+        MODEL_REGISTRY[pattern.lower()] = model_class
+        return None
+    names = (pattern,) + ((model_class,) if model_class is not None else ()) + more
+
     def deco(fn):
         for n in names:
-            MODEL_REGISTRY[n] = fn
+            MODEL_REGISTRY[n.lower()] = fn
         return fn
     return deco
+
+
+def get_model_class(model_name: str):
+    """Exact (case-insensitive) match first, then substring match of a registered pattern (model/__init__.py:44-70)."""
+    low = model_name.lower()
+    if low in MODEL_REGISTRY:
+        return MODEL_REGISTRY[low]
+    for pattern, cls in MODEL_REGISTRY.items():
+        if pattern in low:
+            return cls
+    raise ValueError(f"No model class found for '{model_name}'. Available model patterns: {list(MODEL_REGISTRY.keys())}")
+
+
+def list_supported_models() -> Dict[str, Callable]:
+    return MODEL_REGISTRY.copy()
 
 
 def _load_safetensors_dir(path, device):
@@ -98,14 +121,20 @@ def _csm(model_name, device="cuda:0", weights=None, checkpoint_dir=None, codec_c
 def load_model(model_name: str, device: str = "cuda", top_p=None, top_k=None, min_p=None, temperature=None,
                max_tokens=None, repetition_penalty=None, repetition_window=None, cfg_scale=None, greedy=False,
                enable_torch_compile=False, audio_decoder_device=None, detokenize_interval=None, **kw):
-    if model_name not in MODEL_REGISTRY:
-        raise ValueError(f"Model {model_name} not supported. Supported models are: {sorted(MODEL_REGISTRY)}")
-    m = MODEL_REGISTRY[model_name](model_name, device=device, audio_decoder_device=audio_decoder_device,
-                                   detokenize_interval=detokenize_interval, **kw)
+    loader = get_model_class(model_name)
+    if detokenize_interval is not None and loader is not _qwen3:      # model/__init__.py:124-126
+        raise ValueError(f"Detokenize interval is only supported for Qwen3TTS models, got {model_name}")
     overrides = dict(top_p=top_p, top_k=top_k, min_p=min_p, temperature=temperature, max_tokens=max_tokens,
                      repetition_penalty=repetition_penalty, repetition_window=repetition_window, cfg_scale=cfg_scale)
-    if greedy or any(v is not None for v in overrides.values()):      # per-field override (model/__init__.py:132-156)
-        cur = m.default_sampling_config
-        m.default_sampling_config = SamplingConfig(greedy=greedy, **{k: (v if v is not None else getattr(cur, k))
-                                                                     for k, v in overrides.items()})
+    has_overrides = greedy or any(v is not None for v in overrides.values())
+
+    def merged(cur):      # per-field override (model/__init__.py:132-156)
+        return SamplingConfig(greedy=greedy, **{k: (v if v is not None else getattr(cur, k)) for k, v in overrides.items()})
+    if has_overrides and loader in (_glm, _cosyvoice2):
+        # these plugins size the engine's persisted repetition cache from the sampling config: hand them the merged config
+        # BEFORE the engine exists (the reference swaps the config after construction; its cache is per-request)
+        kw["sampling_overrides"] = merged
+    m = loader(model_name, device=device, audio_decoder_device=audio_decoder_device, detokenize_interval=detokenize_interval, **kw)
+    if has_overrides:
+        m.default_sampling_config = merged(m.default_sampling_config)
     return m

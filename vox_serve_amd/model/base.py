@@ -25,6 +25,13 @@ class BaseLM(ABC):
         self.model_name, self.device, self.dtype = model_name, device, dtype
         self.enable_torch_compile = enable_torch_compile
         self.audio_decoder_device = audio_decoder_device or device
+        if torch.device(self.audio_decoder_device) != torch.device(device) and not (
+                torch.device(device).index is None or torch.device(self.audio_decoder_device).index is None):
+            # libvoxhip keeps ONE context per process (one process per GPU): codec state, workspace and streams would be
+            # created on the LM's device while the weights sit on the other one.  The reference's second-GPU detokenizer
+            # (worker/base.py:641-644) maps to a second worker process here, which is not wired up yet.
+            raise NotImplementedError(f"audio_decoder_device {self.audio_decoder_device} != device {device}: a detokenizer on a "
+                                      "second GPU needs its own worker process (one libvoxhip context per process)")
 
     # ---- architecture ----
     @property

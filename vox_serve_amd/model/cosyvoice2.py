@@ -56,11 +56,13 @@ class CosyVoice2Model(SingleStackLM):
 
     def __init__(self, model_name: str, weights: Dict[str, torch.Tensor], config: Optional[CosyVoice2Config] = None,
                  text_tokenizer=None, speaker_ref: Optional[dict] = None, device="cuda:0", dtype=torch.bfloat16,
-                 audio_decoder_device=None, sampling: Optional[SamplingConfig] = None, max_pos=8192, **engine_kw):
+                 audio_decoder_device=None, sampling: Optional[SamplingConfig] = None, max_pos=8192, sampling_overrides=None, **engine_kw):
         self.cv_config = config or CosyVoice2Config()
         layers, norm, emb, head, head_b = pack_cosyvoice2_weights(weights, self.cv_config)
         sampling = sampling or SamplingConfig(top_k=25, top_p=None, min_p=None, temperature=1.0, repetition_penalty=None,
                                               repetition_window=None, cfg_scale=None)
+        if sampling_overrides is not None:      # load_model's per-field overrides, applied before the engine sizes its caches
+            sampling = sampling_overrides(sampling)
         super().__init__(model_name, self.cv_config.lm_cfg(max_pos), layers, norm, emb, head, head_b, sampling,
                          device=device, dtype=dtype, audio_decoder_device=audio_decoder_device, **engine_kw)
         dev = torch.device(device)

@@ -61,11 +61,13 @@ def pack_glm_weights(S: Dict[str, torch.Tensor], c: GLMVoiceConfig):
 class GLMVoiceModel(SingleStackLM):
     def __init__(self, model_name: str, weights: Dict[str, torch.Tensor], config: Optional[GLMVoiceConfig] = None,
                  text_tokenizer=None, device="cuda:0", dtype=torch.bfloat16, audio_decoder_device=None,
-                 sampling: Optional[SamplingConfig] = None, max_pos=8192, **engine_kw):
+                 sampling: Optional[SamplingConfig] = None, max_pos=8192, sampling_overrides=None, **engine_kw):
         self.glm_config = config or GLMVoiceConfig()
         layers, norm, emb, head = pack_glm_weights(weights, self.glm_config)
         sampling = sampling or SamplingConfig(top_k=None, top_p=0.8, min_p=None, temperature=0.8, repetition_penalty=None,
                                               repetition_window=None, cfg_scale=None)
+        if sampling_overrides is not None:      # load_model's per-field overrides, applied before the engine sizes its caches
+            sampling = sampling_overrides(sampling)
         super().__init__(model_name, self.glm_config.lm_cfg(max_pos), layers, norm, emb, head, None, sampling,
                          device=device, dtype=dtype, audio_decoder_device=audio_decoder_device, **engine_kw)
         self.text_tokenizer = text_tokenizer

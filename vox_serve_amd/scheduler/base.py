@@ -71,13 +71,55 @@ class Scheduler:
         self._prepare_requests()
         detokenize_requests = self._select_detokenize_requests()
         lm_requests = self._select_lm_requests()
-        lm_inputs = self.model_worker.prepare_lm_inputs(lm_requests, detokenize_requests)
+        fresh = [r for r in lm_requests if not r.done_lm_prefill]
+        lm_inputs = None
+        for _attempt in range(len(lm_requests) + 2):
+            try:
+                lm_inputs = self.model_worker.prepare_lm_inputs(lm_requests, detokenize_requests)
+                break
+            except queue.Empty as ex:
+                # KV pages exhausted (worker.OutOfPages, raised before any state changed): the new prompt waits for a later
+                # step; if even the decode rows cannot grow, the youngest of them is dropped so that the others go on
+                if not getattr(self.model_worker, "defers_on_page_exhaustion", False):
+                    raise
+                if fresh:
+                    lm_requests = [r for r in lm_requests if r.done_lm_prefill]
+                    fresh = []
+                elif lm_requests:
+                    self._fail_requests(lm_requests[-1:], ex)
+                    lm_requests = lm_requests[:-1]
+                else:
+                    break
+            except Exception as ex:      # a request the worker cannot even stage (bad kwargs, missing tokenizer, ...)
+                self._fail_requests(fresh or lm_requests, ex)
+                for req in detokenize_requests:
+                    req.audio_decode_idx = req.next_audio_decode_idx.copy()
+                lm_requests, lm_inputs = [], None
+                break
         self.model_worker.run_detokenize(detokenize_requests)
         self._send_responses(detokenize_requests)
-        if lm_inputs is not None and lm_inputs["is_prefill"]:
-            self.model_worker.run_lm_prefill(lm_requests, lm_inputs)
-        else:
-            self.model_worker.run_lm_decode(lm_requests, lm_inputs)
+        try:
+            if lm_inputs is not None and lm_inputs["is_prefill"]:
+                self.model_worker.run_lm_prefill(lm_requests, lm_inputs)
+            else:
+                self.model_worker.run_lm_decode(lm_requests, lm_inputs)
+        except Exception as ex:
+            # one bad request must not take the serving loop down (the reference lets the exception escape run_forever):
+            # in a prefill step the new prompt is the suspect, in a decode step every row of the failed launch is dropped
+            self._fail_requests(fresh or lm_requests, ex)
+
+    def _fail_requests(self, requests, ex):
+        for req in requests:
+            self.logger.error(f"request {req.request_id} failed: {ex!r}")
+            req.done_lm_prefill = req.done_lm_generation = req.done_all = True
+            req.finish_reason = f"error: {type(ex).__name__}"
+            try:
+                self.model_worker.free_kv_cache(req)
+            except Exception:            # never mask the original failure
+                pass
+            msg = {"status": "error", "reason": req.finish_reason, "detail": str(ex)[:200]}
+            self.transport.send_result(req.request_id.encode("utf-8") + b"|COMPLETION|" + json.dumps(msg).encode("utf-8"))
+        self.active_requests = [r for r in self.active_requests if not r.done_all]
 
     def run_forever(self):
         while True:

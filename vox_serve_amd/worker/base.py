@@ -23,6 +23,12 @@ from ..sampling import native_config
 from ..tokenizer.base import DecoderCache
 
 
+class OutOfPages(queue.Empty):
+    """The step needs more KV pages than the free list holds.  Raised by prepare_lm_inputs BEFORE any request state is
+    touched, so the scheduler can defer the new prompt and retry (the reference lets `queue.Empty` escape from the
+    middle of the allocation, worker/base.py:283-287, and the server dies)."""
+
+
 class ModelWorker:
     def __init__(self, model_name: str = None, max_batch_size: int = 8, max_num_pages: int = 2048, page_size: int = 128,
                  top_p: float = None, top_k: int = None, min_p: float = None, temperature: float = None,
@@ -69,6 +75,8 @@ class ModelWorker:
         cap = int(getattr(e, "max_seq_len", 0)) - 2
         if cap > 1024:
             self.cuda_graph_seq_len_buckets = [1024, cap]
+        # the reference's prefill graphs hold 8 requests (cuda_graph_worker.py:62); a smaller engine holds fewer
+        self.prefill_graph_batch_size = min(8, max_batch_size, int(getattr(e, "max_batch", max_batch_size)))
 
     # ---- properties read by schedulers (scheduler/base.py:127, 243-245) ----
     detokenize_interval = property(lambda self: self.model.detokenize_interval)
@@ -79,6 +87,7 @@ class ModelWorker:
     def available_batch_sizes(self) -> Optional[List[int]]:
         return None
 
+    defers_on_page_exhaustion = True                  # prepare_lm_inputs raises OutOfPages before mutating anything
     prefill_graph_batch_size = 8                      # cuda_graph_worker.py:62
     cuda_graph_seq_len_buckets = [1024]               # cuda_graph_worker.py:61
 
@@ -91,27 +100,20 @@ class ModelWorker:
         qo_indptr, paged_kv_indptr, paged_kv_indices, paged_kv_last_page_len = [0], [0], [], []
         input_ids_list, position_ids_list, feats, masks, reps = [], [], [], [], []
         is_prefill = any(not req.done_lm_prefill for req in lm_requests)
+        prefill_flags = [not req.done_lm_prefill for req in lm_requests]
         ps = self.page_size
+        # admission: preprocess the new prompts (once) and count the pages this step takes before touching any KV state
+        need = 0
         for req in lm_requests:
             if not req.done_lm_prefill:
-                if req.is_input_streaming and not self.model.supports_input_streaming:
-                    raise ValueError(f"Input streaming is not supported by model {self.model.model_name}. "
-                                     f"Only Qwen3-TTS models support input streaming mode.")
-                kw = req.model_kwargs.copy()
-                if req.is_input_streaming:
-                    kw["is_input_streaming"] = True
-                pre = self.model.preprocess(prompt=req.prompt, audio_path=req.audio_path, **kw)
-                req.input_tokens = pre.input_tokens
-                if req.input_tokens is not None:
-                    req.input_length = req.input_tokens.shape[0]
-                if pre.input_features is not None:
-                    req.input_features = pre.input_features
-                if pre.input_masks is not None:
-                    req.input_masks = pre.input_masks
-                if pre.repetition_cache is not None:
-                    req.repetition_cache = pre.repetition_cache
-                if getattr(pre, "decoder_cache", None) is not None:
-                    req.decoder_cache = pre.decoder_cache
+                self._preprocess_request(req)
+                need += (len(req.input_tokens) + ps - 1) // ps
+            elif req.kv_last_page_len + 1 > ps:
+                need += 1
+        if need > self.empty_pages.qsize():
+            raise OutOfPages(f"step needs {need} KV pages, {self.empty_pages.qsize()} free")
+        for req in lm_requests:
+            if not req.done_lm_prefill:
                 n = len(req.input_tokens)
                 input_ids_list.append(req.input_tokens)
                 position_ids_list.extend(range(n))
@@ -156,7 +158,31 @@ class ModelWorker:
         return {"qo_indptr": qo_indptr, "paged_kv_indptr": paged_kv_indptr, "paged_kv_indices": paged_kv_indices,
                 "paged_kv_last_page_len": paged_kv_last_page_len, "input_ids": input_ids, "position_ids": position_ids,
                 "input_features": input_features, "input_masks": input_masks, "repetition_cache": repetition_cache,
-                "is_prefill": is_prefill}
+                "is_prefill": is_prefill, "prefill_flags": prefill_flags}
+
+    def _preprocess_request(self, req: Request) -> None:
+        """model.preprocess -> request fields (worker/base.py:246-270), once per request."""
+        if getattr(req, "_preprocessed", False):
+            return
+        if req.is_input_streaming and not self.model.supports_input_streaming:
+            raise ValueError(f"Input streaming is not supported by model {self.model.model_name}. "
+                             f"Only Qwen3-TTS models support input streaming mode.")
+        kw = req.model_kwargs.copy()
+        if req.is_input_streaming:
+            kw["is_input_streaming"] = True
+        pre = self.model.preprocess(prompt=req.prompt, audio_path=req.audio_path, **kw)
+        req.input_tokens = pre.input_tokens
+        if req.input_tokens is not None:
+            req.input_length = req.input_tokens.shape[0]
+        if pre.input_features is not None:
+            req.input_features = pre.input_features
+        if pre.input_masks is not None:
+            req.input_masks = pre.input_masks
+        if pre.repetition_cache is not None:
+            req.repetition_cache = pre.repetition_cache
+        if getattr(pre, "decoder_cache", None) is not None:
+            req.decoder_cache = pre.decoder_cache
+        req._preprocessed = True
 
     def _inject_streaming_text_token(self, req: Request) -> None:
         """worker/base.py:362-394: next queued text token, then tts_eos once, then tts_pad."""
@@ -201,9 +227,13 @@ class ModelWorker:
             return None
         e = self.model.engine
         n_rows, n_req = int(lm_inputs["input_ids"].shape[0]), len(requests)
-        if n_rows > e.max_rows:
-            if n_req != 1:      # (the scheduler admits one prefill per step; the reference raises for every overflow)
-                raise RuntimeError(f"No suitable prefill graph found for batch_size={n_req}, seq_len={n_rows}")
+        if n_rows > e.max_rows or n_req > e.max_batch:
+            if n_req != 1:
+                # a prompt (plus the decode rows piggy-backed onto its step) that does not fit the engine's row capacity:
+                # the reference never schedules one (one 1024-token bucket, scheduler/base.py:283-286) and raises for any
+                # overflow; here the step is split per request — each prefill alone (chunked when it is itself too long),
+                # then the decode rows as a normal decode step.  Per-request results are those of the unsplit step.
+                return self._run_split_prefill(requests, lm_inputs)
             return self._run_long_prefill(requests, lm_inputs)
         q_req, kvlen, page, slot = self._token_plan(lm_inputs)
         e.row_ids[:n_rows].copy_(lm_inputs["input_ids"].to(torch.int32))
@@ -219,6 +249,43 @@ class ModelWorker:
                       indices=lm_inputs["paged_kv_indices"])
         e.prefill(n_rows, n_req, max(kvlen), self._sampling(), seed=self.seed, feedback=True)
         self._after_frame(requests)
+        return None
+
+    @staticmethod
+    def _slice_inputs(lm_inputs: LMInputs, lo: int, hi: int) -> LMInputs:
+        """lm_inputs restricted to requests [lo, hi) of the step (rows qo_indptr[lo]..qo_indptr[hi])."""
+        qo, ip = lm_inputs["qo_indptr"], lm_inputs["paged_kv_indptr"]
+        r0, r1 = qo[lo], qo[hi]
+
+        def rows(t):
+            return None if t is None else t[r0:r1]
+        rep = lm_inputs.get("repetition_cache")
+        return {"qo_indptr": [q - r0 for q in qo[lo:hi + 1]], "paged_kv_indptr": [i - ip[lo] for i in ip[lo:hi + 1]],
+                "paged_kv_indices": lm_inputs["paged_kv_indices"][ip[lo]:ip[hi]],
+                "paged_kv_last_page_len": lm_inputs["paged_kv_last_page_len"][lo:hi],
+                "input_ids": rows(lm_inputs["input_ids"]), "position_ids": rows(lm_inputs["position_ids"]),
+                "input_features": rows(lm_inputs["input_features"]), "input_masks": rows(lm_inputs["input_masks"]),
+                "repetition_cache": None if rep is None else rep[lo:hi], "is_prefill": True}
+
+    def _run_split_prefill(self, requests: List[Request], lm_inputs: LMInputs):
+        qo = lm_inputs["qo_indptr"]
+        fresh = lm_inputs.get("prefill_flags") or [qo[i + 1] - qo[i] > 1 for i in range(len(requests))]
+        decode_idx = [i for i, f in enumerate(fresh) if not f]
+        for i, f in enumerate(fresh):
+            if f:
+                self.run_lm_prefill(requests[i:i + 1], self._slice_inputs(lm_inputs, i, i + 1))
+        # the decode rows are contiguous behind the prefill in every scheduler's selection; fall back to one call per row
+        if decode_idx:
+            lo, hi = decode_idx[0], decode_idx[-1] + 1
+            if decode_idx == list(range(lo, hi)):
+                sub = self._slice_inputs(lm_inputs, lo, hi)
+                sub["is_prefill"] = False
+                self.run_lm_decode(requests[lo:hi], sub)
+            else:
+                for i in decode_idx:
+                    sub = self._slice_inputs(lm_inputs, i, i + 1)
+                    sub["is_prefill"] = False
+                    self.run_lm_decode(requests[i:i + 1], sub)
         return None
 
     def _run_long_prefill(self, requests: List[Request], lm_inputs: LMInputs):
@@ -334,13 +401,28 @@ class ModelWorker:
                 token_ids.append(torch.cat(new, dim=0))
                 mapping.append((ri, ci))
         if token_ids:
-            batch = torch.stack(token_ids, dim=0)
             caches = [requests[ri].decoder_cache for ri, _ in mapping]
-            cache = DecoderCache.cat(caches) if all(c is not None for c in caches) else None
-            audio = self.model.postprocess(batch, decoder_cache=cache)
-            if self.needs_watermarking:
-                audio = self.run_watermark(audio)
-            audio_np = audio.detach().float().cpu().numpy()
+            stateful = all(c is not None for c in caches)
+            # A request's streaming codec state lives in ONE native slot that decode_chunk advances in place, so a slot may
+            # appear at most once per call: several windows of one request (offline / online policies hand them out
+            # together) are decoded in consecutive rounds, window k of every request in round k — each window continues
+            # from the state its predecessor left (seamless audio).  The reference decodes all of a request's windows from
+            # the same starting state and keeps the last one's (worker/base.py:641-656).
+            n_rounds = max(ci for _, ci in mapping) + 1 if stateful else 1
+            parts = [None] * len(mapping)
+            for rnd in range(n_rounds):
+                sel = [i for i, (_, ci) in enumerate(mapping) if not stateful or ci == rnd]
+                if not sel:
+                    continue
+                batch = torch.stack([token_ids[i] for i in sel], dim=0)
+                cache = DecoderCache.cat([caches[i] for i in sel]) if stateful else None
+                audio = self.model.postprocess(batch, decoder_cache=cache)
+                if self.needs_watermarking:
+                    audio = self.run_watermark(audio)
+                a = audio.detach().float().cpu().numpy()
+                for j, i in enumerate(sel):
+                    parts[i] = a[j]
+            audio_np = parts
             for i, (ri, ci) in enumerate(mapping):
                 req = requests[ri]
                 d = req.audio_decode_idx[ci]
