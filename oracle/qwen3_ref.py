@@ -14,6 +14,7 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import voxref as vr
+from .policy import EPI_SILU, EPI_SILU_MUL, NORM_ROWS1024, PRO_RMSNORM, Call, Policy
 
 
 @dataclass
@@ -106,33 +107,56 @@ def random_weights(cfg: Qwen3Cfg, seed: int = 0, std: float = 0.02) -> Dict[str,
 
 
 class RefStack:
-    """Decoder stack (qwen3_tts.py:611-739) over a paged KV cache [L][P,2,page,Hkv,D]."""
+    """Decoder stack (qwen3_tts.py:611-739) over a paged KV cache [L][P,2,page,Hkv,D].
 
-    def __init__(self, c: StackCfg, W, prefix, max_pos):
+    `policy` (oracle/policy.py) selects the summation order of every linear from the call's row count and shape: the
+    canonical order up to `exact_rows` rows, the matrix-core orders above."""
+
+    def __init__(self, c: StackCfg, W, prefix, max_pos, policy: Optional[Policy] = None):
         self.c, self.W, self.p = c, W, prefix
+        self.policy = policy or Policy()
         self.cs = vr.rope_table(max_pos, c.rope_dim or c.head_dim, c.rope_theta, c.rope_scale, c.rope_llama31)
 
-    def forward(self, x, pos, kv, q_req, q_kvlen, indptr, indices, page, slot, final_norm=True):
-        c, W = self.c, self.W
+    def forward(self, x, pos, kv, q_req, q_kvlen, indptr, indices, page, slot, final_norm=True, fixed_order=False):
+        c, W, P = self.c, self.W, self.policy
         N = x.shape[0]
+        nq, nkv = c.heads * c.head_dim, c.kv_heads * c.head_dim
+        st = dict(B=N, fixed_order=fixed_order, splitk_ws=True)
+        xn = None            # norm(x) written by the producing split-K linear's fused reduce (block order), if any
         for i in range(c.layers):
             p = f"{self.p}.layers.{i}."
-            h = vr.rmsnorm(x, W[p + "input_layernorm.weight"], c.eps)
-            q = vr.linear(W[p + "self_attn.q_proj.weight"], h, W.get(p + "self_attn.q_proj.bias"))
-            k = vr.linear(W[p + "self_attn.k_proj.weight"], h, W.get(p + "self_attn.k_proj.bias"))
-            v = vr.linear(W[p + "self_attn.v_proj.weight"], h, W.get(p + "self_attn.v_proj.bias"))
+            a = Call(N=nq + 2 * nkv, K=c.hidden, pro=PRO_RMSNORM, norm_scratch=True, x_prenormed=xn is not None, **st)
+            oa, na = P.route(a)
+            h = xn if (xn is not None and P.rows_gemm(a)) else vr.rmsnorm(x, W[p + "input_layernorm.weight"], c.eps, order=na)
+            q = vr.linear(W[p + "self_attn.q_proj.weight"], h, W.get(p + "self_attn.q_proj.bias"), order=oa)
+            k = vr.linear(W[p + "self_attn.k_proj.weight"], h, W.get(p + "self_attn.k_proj.bias"), order=oa)
+            v = vr.linear(W[p + "self_attn.v_proj.weight"], h, W.get(p + "self_attn.v_proj.bias"), order=oa)
             if c.qk_norm:
                 q = vr.rmsnorm(q.reshape(-1, c.head_dim), W[p + "self_attn.q_norm.weight"], c.eps)
                 k = vr.rmsnorm(k.reshape(-1, c.head_dim), W[p + "self_attn.k_norm.weight"], c.eps)
             q = vr.rope(q.reshape(N, c.heads, c.head_dim), pos, self.cs, c.rope_dim, c.rope_interleave)
             k = vr.rope(k.reshape(N, c.kv_heads, c.head_dim), pos, self.cs, c.rope_dim, c.rope_interleave)
             vr.kv_append(kv[i], k, v.reshape(N, c.kv_heads, c.head_dim), page, slot)
-            a = vr.paged_attention(q, kv[i], q_req, q_kvlen, indptr, indices)
-            x = vr.linear(W[p + "self_attn.o_proj.weight"], a.reshape(N, -1), residual=x)
-            h = vr.rmsnorm(x, W[p + "post_attention_layernorm.weight"], c.eps)
-            g = vr.linear_silu_mul(W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"], h)
-            x = vr.linear(W[p + "mlp.down_proj.weight"], g, residual=x)
+            at = vr.paged_attention(q, kv[i], q_req, q_kvlen, indptr, indices)
+            o = Call(N=c.hidden, K=nq, **st)
+            x = vr.linear(W[p + "self_attn.o_proj.weight"], at.reshape(N, -1), residual=x, order=P.route(o)[0])
+            xn = vr.rmsnorm(x, W[p + "post_attention_layernorm.weight"], c.eps, order=NORM_ROWS1024) if P.rows_gemm(o) else None
+            g = Call(N=c.ffn, K=c.hidden, pro=PRO_RMSNORM, epi=EPI_SILU_MUL, norm_scratch=True, x_prenormed=xn is not None, **st)
+            og, ng = P.route(g)
+            h = xn if (xn is not None and P.rows_gemm(g)) else vr.rmsnorm(x, W[p + "post_attention_layernorm.weight"], c.eps, order=ng)
+            gg = vr.linear_silu_mul(W[p + "mlp.gate_proj.weight"], W[p + "mlp.up_proj.weight"], h, order=og)
+            d = Call(N=c.hidden, K=c.ffn, **st)
+            x = vr.linear(W[p + "mlp.down_proj.weight"], gg, residual=x, order=P.route(d)[0])
+            xn = (vr.rmsnorm(x, W[f"{self.p}.layers.{i + 1}.input_layernorm.weight"], c.eps, order=NORM_ROWS1024)
+                  if i + 1 < c.layers and P.rows_gemm(d) else None)
         return vr.rmsnorm(x, W[self.p + ".norm.weight"], c.eps) if final_norm else x
+
+    def norm_head(self, x, head_w, head_b=None, x_out=False, x_rows=False):
+        """final norm fused into the head linear's prologue -> (normed rows, logits)."""
+        call = Call(B=x.shape[0], N=head_w.shape[0], K=head_w.shape[1], pro=PRO_RMSNORM, x_out=x_out, x_rows=x_rows)
+        od, nd = self.policy.route(call)
+        h = vr.rmsnorm(x, self.W[self.p + ".norm.weight"], self.c.eps, order=nd)
+        return h, vr.linear(head_w, h, head_b, order=od)
 
 
 @dataclass
@@ -149,11 +173,12 @@ class RefRequest:
 
 
 class Qwen3Ref:
-    def __init__(self, cfg: Qwen3Cfg, W, page_size=128, max_pages=64, max_batch=8):
+    def __init__(self, cfg: Qwen3Cfg, W, page_size=128, max_pages=64, max_batch=8, policy: Optional[Policy] = None):
         self.cfg, self.W, self.page_size = cfg, W, page_size
+        self.policy = policy or Policy()
         t, d = cfg.talker, cfg.depth
-        self.talker = RefStack(t, W, "talker.model", cfg.max_pos)
-        self.depth = RefStack(d, W, "talker.code_predictor.model", 64)
+        self.talker = RefStack(t, W, "talker.model", cfg.max_pos, self.policy)
+        self.depth = RefStack(d, W, "talker.code_predictor.model", 64, self.policy)
         self.kv = [np.zeros((max_pages, 2, page_size, t.kv_heads, t.head_dim), np.uint16) for _ in range(t.layers)]
         # depth KV: one page of n_groups slots per batch row (worker/base.py:196-205)
         self.dkv = [np.zeros((max_batch, 2, cfg.n_groups, d.kv_heads, d.head_dim), np.uint16)
@@ -164,9 +189,11 @@ class Qwen3Ref:
     def embed(self, input_ids, masks, feats):
         W = self.W
         te = vr.gather(W["talker.model.text_embedding.weight"], input_ids[:, -1])
-        h = vr.linear(W["talker.text_projection.linear_fc1.weight"], te, W["talker.text_projection.linear_fc1.bias"])
-        h = vr.silu(h)
-        text = vr.linear(W["talker.text_projection.linear_fc2.weight"], h, W["talker.text_projection.linear_fc2.bias"])
+        n, th = te.shape[0], self.cfg.text_hidden
+        o1 = self.policy.route(Call(B=n, N=th, K=th, epi=EPI_SILU))[0]
+        o2 = self.policy.route(Call(B=n, N=self.cfg.talker.hidden, K=th))[0]
+        h = vr.linear(W["talker.text_projection.linear_fc1.weight"], te, W["talker.text_projection.linear_fc1.bias"], order=o1, act=1)
+        text = vr.linear(W["talker.text_projection.linear_fc2.weight"], h, W["talker.text_projection.linear_fc2.bias"], order=o2)
         codec = vr.gather(W["talker.model.codec_embedding.weight"], input_ids[:, 0])
         return vr.qwen3_mix(text, codec, masks, feats)
 
@@ -184,10 +211,10 @@ class Qwen3Ref:
         indptr, indices = np.array([0, npg], np.int32), np.array(req.kv_pages, np.int32)
         page = np.array([req.kv_pages[t // ps] for t in range(n)], np.int32)
         slot = np.array([t % ps for t in range(n)], np.int32)
-        hid = self.talker.forward(x, pos, self.kv, np.zeros(n, np.int32), np.arange(1, n + 1, dtype=np.int32),
-                                  indptr, indices, page, slot)
-        logits = vr.linear(self.W["talker.codec_head.weight"], hid[-1:])
-        return logits, hid[-1:]
+        xs = self.talker.forward(x, pos, self.kv, np.zeros(n, np.int32), np.arange(1, n + 1, dtype=np.int32),
+                                 indptr, indices, page, slot, final_norm=False)
+        hid, logits = self.talker.norm_head(xs[-1:], self.W["talker.codec_head.weight"], x_out=True, x_rows=True)
+        return logits, hid
 
     # ---- one decode step for a batch (worker/base.py:302-325 + qwen3_tts.py:1805-1861) ----
     def decode(self, reqs: List[RefRequest]):
@@ -211,10 +238,10 @@ class Qwen3Ref:
         masks = np.array([r.input_mask for r in reqs], np.uint8)
         feats = np.concatenate([r.input_features for r in reqs], 0)
         x = self.embed(ids, masks, feats)
-        hid = self.talker.forward(x, np.array(pos, np.int32), self.kv, np.arange(B, dtype=np.int32),
-                                  np.array(kvlen, np.int32), np.array(indptr, np.int32),
-                                  np.array(indices, np.int32), np.array(page, np.int32), np.array(slot, np.int32))
-        logits = vr.linear(self.W["talker.codec_head.weight"], hid)
+        xs = self.talker.forward(x, np.array(pos, np.int32), self.kv, np.arange(B, dtype=np.int32),
+                                 np.array(kvlen, np.int32), np.array(indptr, np.int32),
+                                 np.array(indices, np.int32), np.array(page, np.int32), np.array(slot, np.int32), final_norm=False)
+        hid, logits = self.talker.norm_head(xs, self.W["talker.codec_head.weight"], x_out=True)
         return logits, hid
 
     # ---- sampling of codebook 0 (qwen3_tts.py:1863-1925) ----
@@ -249,12 +276,20 @@ class Qwen3Ref:
                 q_req = np.arange(B, dtype=np.int32)
                 q_kvlen = np.full(B, i + 1, np.int32)
                 slot = pos.copy()
+            # the engine pins the canonical kernels for the depth stack of a batch of <= exact_rows requests (step 1 has 2B
+            # rows); steps >= 2 gather small_to_mtp_projection(embedding[id]) from a table built with the canonical kernel
+            er = self.policy.exact_rows
+            pinned = er is None or B <= er
+            tabulated = i >= 2 and cfg.n_groups > 2
+            op = vr.ORD_CANON if tabulated else self.policy.route(
+                Call(B=x.shape[0], N=cfg.depth.hidden, K=cfg.talker.hidden, fixed_order=pinned, splitk_ws=True))[0]
             x = vr.linear(W["talker.code_predictor.small_to_mtp_projection.weight"], x,
-                          W["talker.code_predictor.small_to_mtp_projection.bias"])
-            h = self.depth.forward(x, pos, self.dkv, q_req, q_kvlen, indptr, indices, q_req.copy(), slot)
+                          W["talker.code_predictor.small_to_mtp_projection.bias"], order=op)
+            xs = self.depth.forward(x, pos, self.dkv, q_req, q_kvlen, indptr, indices, q_req.copy(), slot, final_norm=False,
+                                    fixed_order=pinned)
             if i == 1:
-                h = h[1::2]
-            logits = vr.linear(W[f"talker.code_predictor.lm_head.{i - 1}.weight"], h)
+                xs = xs[1::2]
+            h, logits = self.depth.norm_head(xs, W[f"talker.code_predictor.lm_head.{i - 1}.weight"], x_rows=(i == 1))
             all_logits.append(logits)
             ids = vr.argmax(logits) if sampler is None else sampler(logits, i)
             out[:, i] = ids

@@ -79,23 +79,43 @@ def to_torch(a):
 
 
 # ---- ops -----------------------------------------------------------------------------------------
-def linear(W, x, bias=None, residual=None):
+# summation orders of a linear (voxref.c): the canonical wave64 DOT of the <= exact_rows kernels, and the three MFMA
+# kernels that take calls with more rows
+ORD_CANON, ORD_FULLK, ORD_MFMA4, ORD_SPLITK = 0, 1, 2, 3
+
+
+def linear(W, x, bias=None, residual=None, order=ORD_CANON, act=0):
     W, x = u16(W), u16(x)
     N, K = W.shape
     B = x.shape[0]
     y = np.empty((B, N), np.uint16)
-    lib().vr_linear(_p(W, c_u16p), _p(None if bias is None else u16(bias), c_u16p), _p(x, c_u16p),
-                    _p(None if residual is None else u16(residual), c_u16p), _p(y, c_u16p), B, N, K)
+    if order == ORD_CANON and not act:
+        lib().vr_linear(_p(W, c_u16p), _p(None if bias is None else u16(bias), c_u16p), _p(x, c_u16p),
+                        _p(None if residual is None else u16(residual), c_u16p), _p(y, c_u16p), B, N, K)
+    else:
+        lib().vr_linear_ord(_p(W, c_u16p), _p(None if bias is None else u16(bias), c_u16p), _p(x, c_u16p),
+                            _p(None if residual is None else u16(residual), c_u16p), _p(y, c_u16p), B, N, K, int(order), int(act))
     return y
 
 
-def linear_silu_mul(Wg, Wu, x):
+def linear_silu_mul(Wg, Wu, x, order=ORD_CANON):
     Wg, Wu, x = u16(Wg), u16(Wu), u16(x)
     N, K = Wg.shape
     B = x.shape[0]
     h = np.empty((B, N), np.uint16)
-    lib().vr_linear_silu_mul(_p(Wg, c_u16p), _p(Wu, c_u16p), _p(x, c_u16p), _p(h, c_u16p), B, N, K)
+    if order == ORD_CANON:
+        lib().vr_linear_silu_mul(_p(Wg, c_u16p), _p(Wu, c_u16p), _p(x, c_u16p), _p(h, c_u16p), B, N, K)
+    else:
+        lib().vr_linear_silu_mul_ord(_p(Wg, c_u16p), _p(Wu, c_u16p), _p(x, c_u16p), _p(h, c_u16p), B, N, K, int(order))
     return h
+
+
+def mfma_cases(cases_u8, n, chain=1):
+    """Replay a tools/mfma_probe input file through the restated matrix-core arithmetic -> D [n,16,16] fp32."""
+    cases_u8 = np.ascontiguousarray(cases_u8, dtype=np.uint8)
+    out = np.zeros((n, 16, 16), np.float32)
+    lib().vr_mfma_cases(cases_u8.ctypes.data_as(ctypes.c_void_p), int(n), int(chain), _p(out, c_f32p))
+    return out
 
 
 def silu(x):
@@ -112,12 +132,14 @@ def add(a, b):
     return y
 
 
-def rmsnorm(x, w, eps=1e-6):
+def rmsnorm(x, w, eps=1e-6, order=ORD_CANON):
+    """order ORD_FULLK: the sum of squares in the order of k_gemm_fullk's fused norm prologue (H % 256 == 0)."""
     x, w = u16(x), u16(w)
     H = x.shape[-1]
     R = x.size // H
     y = np.empty_like(x)
-    lib().vr_rmsnorm(_p(x, c_u16p), _p(w, c_u16p), _p(y, c_u16p), R, H, ctypes.c_float(eps))
+    fn = {ORD_FULLK: lib().vr_rmsnorm_fullk, "fullk": lib().vr_rmsnorm_fullk, "rows1024": lib().vr_rmsnorm_rows1024}.get(order, lib().vr_rmsnorm)
+    fn(_p(x, c_u16p), _p(w, c_u16p), _p(y, c_u16p), R, H, ctypes.c_float(eps))
     return y
 
 

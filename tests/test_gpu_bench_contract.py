@@ -24,7 +24,7 @@ def _run(*extra):
 
 
 def test_bench_line_has_the_contract_keys():
-    d = _run("--ttfa-requests", "1", "--no-cpu-baseline")
+    d = _run("--ttfa-requests", "1", "--serving-ttfa-requests", "3", "--no-cpu-baseline")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in d, k
@@ -35,10 +35,17 @@ def test_bench_line_has_the_contract_keys():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["ttfa_ms_p50"] > 0 and d["ttfa_ms_p50_detokenize_interval_2"] > 0
+    assert "Scheduler" in d["ttfa_path"] and d["ttfa_ms_p50_under_32way_load"] > 0 and d["ttfa_ms_p50_engine"] > 0
+    assert d["ranks_seen"] == 1 and d["roofline"]["traffic_source"] is None or d["roofline"]["traffic_source"].startswith("recorded")
+    for b in (8, 32):      # the headline metric is quoted at batch 1 / 8 / 32: sub-results timed in the same run
+        sub = d[f"batch{b}"]
+        assert sub["batch_per_gpu"] == b and sub["value"] > d["value"] and 0 < sub["roofline"]["frac"] < 1
+        assert abs(sub["value"] - b * 1920 * 3 / (sub["ms_per_step"] * 3e-3)) / sub["value"] < 1e-6
     assert abs(d["value"] - 1920 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6      # samples of exactly K steps / their time
 
 
 def test_bench_batched_line_and_fast_mode_flag():
     d = _run("--batch", "8", "--ttfa-requests", "0", "--no-cpu-baseline", "--exact-rows", "2")
+    assert "batch32" not in d          # an explicit --batch runs that batch size only
     assert d["config"]["batch_per_gpu"] == 8 and "exact_rows 2" in d["config"]["workload"]
     assert abs(d["value"] - 8 * 1920 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6

@@ -12,6 +12,7 @@ Host bookkeeping follows the reference line by line where it is observable from 
                       one D2H copy of the sampled ids instead of >= 16*B `.item()` synchronisations.
 """
 import logging
+import os
 import queue
 from typing import List, Optional
 
@@ -48,6 +49,11 @@ class ModelWorker:
                                repetition_window=repetition_window, cfg_scale=cfg_scale, greedy=greedy,
                                audio_decoder_device=detokenizer_device, detokenize_interval=detokenize_interval,
                                max_batch_size=max_batch_size, max_num_pages=max_num_pages, page_size=page_size)
+        # One process per GPU whose host side only shuffles a few KB per step: intra-op CPU parallelism buys nothing, and on a
+        # 256-core host every multi-threaded torch CPU op (a 50 KB torch.stack!) wakes the whole OpenMP pool, whose spinning
+        # threads then starve the HIP runtime's own threads — measured: 35 ms per scheduler step instead of 4.
+        if os.environ.get("VOX_KEEP_TORCH_THREADS") != "1" and torch.get_num_threads() > 1:
+            torch.set_num_threads(1)
         self.model = model
         self.device = device
         self.detokenizer_device = detokenizer_device or device
@@ -88,6 +94,7 @@ class ModelWorker:
         return None
 
     defers_on_page_exhaustion = True                  # prepare_lm_inputs raises OutOfPages before mutating anything
+    materialize_repetition_cache = False              # lm_inputs["repetition_cache"] as the reference builds it (tests only)
     prefill_graph_batch_size = 8                      # cuda_graph_worker.py:62
     cuda_graph_seq_len_buckets = [1024]               # cuda_graph_worker.py:61
 
@@ -153,8 +160,12 @@ class ModelWorker:
             fl = [f for f in feats if f is not None]
             dev = next((f.device for f in fl if f.is_cuda), torch.device("cpu"))   # decode rows live on the GPU
             input_features = torch.cat([f.to(dev) for f in fl], dim=0)
-        repetition_cache = (torch.stack([c for c in reps if c is not None], dim=0)
-                            if self.model.use_repetition_penalty and reps and all(c is not None for c in reps) else None)
+        # The reference re-stacks every request's repetition cache into one [B,W,C,V] tensor each step (worker/base.py:344-347).
+        # Here the caches live in the engine's rows while a batch is resident (_stage_repetition reads req.repetition_cache
+        # directly), so the per-step host copy is only materialised on request (host-trace tests).
+        repetition_cache = None
+        if self.materialize_repetition_cache and self.model.use_repetition_penalty and reps and all(c is not None for c in reps):
+            repetition_cache = torch.stack(reps, dim=0)
         return {"qo_indptr": qo_indptr, "paged_kv_indptr": paged_kv_indptr, "paged_kv_indices": paged_kv_indices,
                 "paged_kv_last_page_len": paged_kv_last_page_len, "input_ids": input_ids, "position_ids": position_ids,
                 "input_features": input_features, "input_masks": input_masks, "repetition_cache": repetition_cache,
