@@ -13,6 +13,7 @@ from typing import Dict, List
 import numpy as np
 
 from . import voxref as vr
+from .policy import Call, Policy
 from .qwen3_ref import RefRequest, RefStack, StackCfg
 
 
@@ -68,16 +69,21 @@ def random_csm_state_dict(cfg: CSMCfg, seed=0, std=0.02) -> Dict[str, np.ndarray
 
 
 class CSMRef:
-    def __init__(self, cfg: CSMCfg, W, page_size=128, max_pages=64, max_batch=8):
+    def __init__(self, cfg: CSMCfg, W, page_size=128, max_pages=64, max_batch=8, policy=None):
         self.cfg, self.W, self.page_size = cfg, W, page_size
+        self.policy = policy or Policy()
         b, d = cfg.backbone, cfg.depth
-        self.backbone = RefStack(b, W, "backbone_model", cfg.max_pos)
-        self.depth = RefStack(d, W, "depth_decoder.model", 64)
+        self.backbone = RefStack(b, W, "backbone_model", cfg.max_pos, self.policy)
+        self.depth = RefStack(d, W, "depth_decoder.model", 64, self.policy)
         self.kv = [np.zeros((max_pages, 2, page_size, b.kv_heads, b.head_dim), np.uint16) for _ in range(b.layers)]
         self.dkv = [np.zeros((max_batch, 2, cfg.n_codebooks, d.kv_heads, d.head_dim), np.uint16) for _ in range(d.layers)]
         self.free_pages = list(range(max_pages))
         # codebooks_head.weight[i] is [Hd, V] (x @ W): as a linear, rows of W^T
         self.heads = [np.ascontiguousarray(W["depth_decoder.codebooks_head.weight"][i].T) for i in range(cfg.n_codebooks - 1)]
+
+    def _pinned(self, n):
+        er = self.policy.exact_rows
+        return er is None or n <= er
 
     def embed(self, ids, masks):
         """sum over the 33 masked embeddings in fp32, columns ascending, one rounding (csm.py:647-653)"""
@@ -101,10 +107,11 @@ class CSMRef:
         req.next_position_id = n + 1                       # quirk Q1 (worker/base.py:299)
         page = np.array([req.kv_pages[t // ps] for t in range(n)], np.int32)
         slot = np.array([t % ps for t in range(n)], np.int32)
-        hid = self.backbone.forward(self.embed(ids, masks), np.arange(n, dtype=np.int32), self.kv, np.zeros(n, np.int32),
-                                    np.arange(1, n + 1, dtype=np.int32), np.array([0, npg], np.int32),
-                                    np.array(req.kv_pages, np.int32), page, slot)
-        return vr.linear(self.W["lm_head.weight"], hid[-1:]), hid[-1:]
+        xs = self.backbone.forward(self.embed(ids, masks), np.arange(n, dtype=np.int32), self.kv, np.zeros(n, np.int32),
+                                   np.arange(1, n + 1, dtype=np.int32), np.array([0, npg], np.int32),
+                                   np.array(req.kv_pages, np.int32), page, slot, final_norm=False, fixed_order=self._pinned(n))
+        hid, logits = self.backbone.norm_head(xs[-1:], self.W["lm_head.weight"], x_out=True, x_rows=True)
+        return logits, hid
 
     def decode(self, reqs: List[RefRequest]):
         ps, B = self.page_size, len(reqs)
@@ -124,10 +131,11 @@ class CSMRef:
             r.next_position_id += 1
         ids = np.concatenate([r.input_ids for r in reqs], 0)
         masks = np.concatenate([r.input_mask for r in reqs], 0)
-        hid = self.backbone.forward(self.embed(ids, masks), np.array(pos, np.int32), self.kv, np.arange(B, dtype=np.int32),
-                                    np.array(kvlen, np.int32), np.array(indptr, np.int32), np.array(indices, np.int32),
-                                    np.array(page, np.int32), np.array(slot, np.int32))
-        return vr.linear(self.W["lm_head.weight"], hid), hid
+        xs = self.backbone.forward(self.embed(ids, masks), np.array(pos, np.int32), self.kv, np.arange(B, dtype=np.int32),
+                                   np.array(kvlen, np.int32), np.array(indptr, np.int32), np.array(indices, np.int32),
+                                   np.array(page, np.int32), np.array(slot, np.int32), final_norm=False, fixed_order=self._pinned(B))
+        hid, logits = self.backbone.norm_head(xs, self.W["lm_head.weight"], x_out=True)
+        return logits, hid
 
     def depth_loop(self, hid, c0, sampler=None):
         cfg, W = self.cfg, self.W
@@ -148,11 +156,18 @@ class CSMRef:
                 pos = np.full(B, i, np.int32)
                 q_req = np.arange(B, dtype=np.int32)
                 q_kvlen = np.full(B, i + 1, np.int32)
-            xp = vr.linear(W["depth_decoder.model.inputs_embeds_projector.weight"], x)
-            h = self.depth.forward(xp, pos, self.dkv, q_req, q_kvlen, indptr, indices, q_req.copy(), pos.copy())
+            # engine.hip csm_tail: canonical kernels pinned for a batch of <= exact_rows requests; steps >= 2 gather
+            # inputs_embeds_projector(embedding[id]) from a table built with the canonical kernel
+            pinned = self._pinned(B)
+            tabulated = i >= 2 and C > 2
+            op = vr.ORD_CANON if tabulated else self.policy.route(
+                Call(B=x.shape[0], N=cfg.depth.hidden, K=cfg.backbone.hidden, fixed_order=pinned, splitk_ws=True))[0]
+            xp = vr.linear(W["depth_decoder.model.inputs_embeds_projector.weight"], x, order=op)
+            xs = self.depth.forward(xp, pos, self.dkv, q_req, q_kvlen, indptr, indices, q_req.copy(), pos.copy(), final_norm=False,
+                                    fixed_order=pinned)
             if i == 1:
-                h = h[1::2]
-            logits = vr.linear(self.heads[i - 1], h)
+                xs = xs[1::2]
+            h, logits = self.depth.norm_head(xs, self.heads[i - 1], x_rows=(i == 1))
             all_logits.append(logits)
             ids = vr.argmax(logits) if sampler is None else sampler(logits, i)
             out[:, i] = ids

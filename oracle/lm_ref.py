@@ -16,6 +16,7 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from . import voxref as vr
+from .policy import PRO_RMSNORM, Call, Policy
 from .qwen3_ref import RefRequest, RefStack, StackCfg
 
 
@@ -133,10 +134,11 @@ class LMRequest(RefRequest):
 
 
 class LMRef:
-    def __init__(self, cfg: LMCfg, W, page_size=128, max_pages=64):
+    def __init__(self, cfg: LMCfg, W, page_size=128, max_pages=64, policy: Optional[Policy] = None):
         self.cfg, self.W, self.page_size = cfg, W, page_size
+        self.policy = policy or Policy()
         c = cfg.stack
-        self.stack = RefStack(c, W, "model", cfg.max_pos)
+        self.stack = RefStack(c, W, "model", cfg.max_pos, self.policy)
         self.kv = [np.zeros((max_pages, 2, page_size, c.kv_heads, c.head_dim), np.uint16) for _ in range(c.layers)]
         self.free_pages = list(range(max_pages))
 
@@ -147,8 +149,19 @@ class LMRef:
             x = np.where(np.asarray(masks, bool)[:, None], feats, x)            # cosyvoice2.py:1024
         return np.ascontiguousarray(x)
 
-    def head(self, hid):
-        return vr.linear(self.W["head_w"], hid, self.W.get("head_b"))
+    def _pinned(self, n):
+        er = self.policy.exact_rows
+        return er is None or n <= er
+
+    def head(self, xs, x_rows=False):
+        """final norm fused into the head linear (engine.hip lm_run): the canonical kernels for <= exact_rows requests, else the
+        matrix-core kernel the shape routes to (K = 4096 without row indirection: normalised once, then the full-K GEMM)."""
+        W, c = self.W, self.cfg.stack
+        call = Call(B=xs.shape[0], N=W["head_w"].shape[0], K=c.hidden, pro=PRO_RMSNORM, x_rows=x_rows,
+                    fixed_order=self._pinned(xs.shape[0]), norm_scratch=True)
+        od, nd = self.policy.route(call)
+        h = vr.rmsnorm(xs, W["model.norm.weight"], c.eps, order=nd)
+        return vr.linear(W["head_w"], h, W.get("head_b"), order=od)
 
     def prefill(self, req: LMRequest, ids, masks=None, feats=None):
         n, ps = len(ids), self.page_size
@@ -158,10 +171,10 @@ class LMRef:
         req.next_position_id = n + 1                                           # quirk Q1 (worker/base.py:299)
         page = np.array([req.kv_pages[t // ps] for t in range(n)], np.int32)
         slot = np.array([t % ps for t in range(n)], np.int32)
-        hid = self.stack.forward(self.embed(ids, masks, feats), np.arange(n, dtype=np.int32), self.kv, np.zeros(n, np.int32),
-                                 np.arange(1, n + 1, dtype=np.int32), np.array([0, npg], np.int32),
-                                 np.array(req.kv_pages, np.int32), page, slot)
-        return self.head(hid[-1:])
+        xs = self.stack.forward(self.embed(ids, masks, feats), np.arange(n, dtype=np.int32), self.kv, np.zeros(n, np.int32),
+                                np.arange(1, n + 1, dtype=np.int32), np.array([0, npg], np.int32),
+                                np.array(req.kv_pages, np.int32), page, slot, final_norm=False, fixed_order=self._pinned(n))
+        return self.head(xs[-1:], x_rows=True)
 
     def decode(self, reqs: List[LMRequest]):
         ps, B = self.page_size, len(reqs)
@@ -184,10 +197,10 @@ class LMRef:
         feats = None
         if self.cfg.input_mode == 1:
             feats = np.concatenate([r.input_features for r in reqs], 0)
-        hid = self.stack.forward(self.embed(ids, masks, feats), np.array(pos, np.int32), self.kv, np.arange(B, dtype=np.int32),
-                                 np.array(kvlen, np.int32), np.array(indptr, np.int32), np.array(indices, np.int32),
-                                 np.array(page, np.int32), np.array(slot, np.int32))
-        return self.head(hid)
+        xs = self.stack.forward(self.embed(ids, masks, feats), np.array(pos, np.int32), self.kv, np.arange(B, dtype=np.int32),
+                                np.array(kvlen, np.int32), np.array(indptr, np.int32), np.array(indices, np.int32),
+                                np.array(page, np.int32), np.array(slot, np.int32), final_norm=False, fixed_order=self._pinned(B))
+        return self.head(xs)
 
     def sample(self, logits, reqs: List[LMRequest], sampler=None, penalty=1.0, window=None):
         """{GLMVoice,CosyVoice2}Model.sampling: penalty -> draw -> cache update -> next inputs."""

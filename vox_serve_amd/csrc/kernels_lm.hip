@@ -1622,14 +1622,18 @@ __device__ __forceinline__ uint4 shfl4(uint4 v, int src) {
     return make_uint4(__shfl(v.x, src, VOX_WAVE), __shfl(v.y, src, VOX_WAVE), __shfl(v.z, src, VOX_WAVE),
                       __shfl(v.w, src, VOX_WAVE));
 }
+// NT > 0: the number of visible tokens is a compile-time constant (depth loop: step i sees exactly i + 1 tokens, known when
+// the frame graph is captured): every token loop has its exact trip count and no predicates — at one wave per (row, head)
+// instruction count is time.  NT == 0: read from the plan arrays (<= 16).
+template <int NT>
 __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int hk, int lane, bf16_t* out_row,
                                                 bool do_append) {
-    constexpr int D = 128, LPT = 16, TMAX = 16;
+    constexpr int D = 128, LPT = 16, TMAX = NT > 0 ? NT : 16, UMAX = (TMAX + 3) / 4;
     const int grp = lane >> 4, j = lane & 15;
     const int nqkv = (at.Hq + 2 * at.Hkv) * D;
     const size_t ps = (size_t)2 * at.page_size * at.Hkv * D;
-    const int L = at.fixed_kvlen > 0 ? at.fixed_kvlen : at.q_kvlen[row];
-    const int nt = L < TMAX ? L : TMAX;
+    const int L = NT > 0 ? NT : (at.fixed_kvlen > 0 ? at.fixed_kvlen : at.q_kvlen[row]);
+    const int nt = NT > 0 ? NT : (L < TMAX ? L : TMAX);
     const int* pages = at.identity_pages ? nullptr
                        : (at.ptab ? at.ptab + (size_t)row * at.pt_stride : at.indices + at.indptr[at.q_req[row]]);
     const bf16_t* raw = at.qkv + (size_t)row * nqkv;
@@ -1650,9 +1654,9 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
         for (int k = 0; k < 4; ++k) cs4[k] = cp[k];
     }
     // cached K (token-major) and V (chunk-major); token nt-1 is the new one
-    uint4 kr[4], vr[TMAX];
+    uint4 kr[UMAX], vr[TMAX];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UMAX; ++u) {
         const int t = u * 4 + grp;
         kr[u] = make_uint4(0, 0, 0, 0);
         if (t < nt - 1) {
@@ -1707,9 +1711,9 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
         }
     }
     // scores of token 4u+grp for both q heads, then the global max
-    float sc[2][4], m0 = -INFINITY, m1 = -INFINITY;
+    float sc[2][UMAX], m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UMAX; ++u) {
         const int t = u * 4 + grp;
         const uint4 kx = (t == nt - 1) ? knc : kr[u];
         const float d0 = butterfly<16>(dot8(q0c, kx, 0.0f)) * at.scale;
@@ -1721,9 +1725,9 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
     }
     m0 = fmaxf(m0, __shfl_xor(m0, 16, VOX_WAVE)); m0 = fmaxf(m0, __shfl_xor(m0, 32, VOX_WAVE));
     m1 = fmaxf(m1, __shfl_xor(m1, 16, VOX_WAVE)); m1 = fmaxf(m1, __shfl_xor(m1, 32, VOX_WAVE));
-    float pp[2][4];
+    float pp[2][UMAX];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UMAX; ++u) {
         const int t = u * 4 + grp;
         pp[0][u] = t < nt ? exp2_c((sc[0][u] - m0) * VOX_LOG2E) : 0.0f;
         pp[1][u] = t < nt ? exp2_c((sc[1][u] - m1) * VOX_LOG2E) : 0.0f;
@@ -1759,12 +1763,12 @@ __global__ __launch_bounds__(256) void k_attn_short(AttnArgs at, int n_pairs) {
     const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pi >= n_pairs) return;
     const int row = pi / at.Hkv, hk = pi % at.Hkv;
-    attn_short_wave(at, row, hk, threadIdx.x & 63, at.out + (size_t)row * at.Hq * 128, true);
+    attn_short_wave<0>(at, row, hk, threadIdx.x & 63, at.out + (size_t)row * at.Hq * 128, true);
 }
 
 // Fused into the o_proj GEMV: every o_proj block recomputes the row's attention (8 waves: one (row, kv head) pair
 // each per round) into LDS while its weight rows are in flight, block 0 appends the new K/V to the cache.
-template <int BT, int KC, int R>
+template <int BT, int KC, int R, int NT>
 __global__ __launch_bounds__(512) void k_attn1_linear(AttnArgs at, LinArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 xs[BT * KC * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1788,7 +1792,7 @@ __global__ __launch_bounds__(512) void k_attn1_linear(AttnArgs at, LinArgs a) {
     }
     for (int pi = wave; pi < a.B * at.Hkv; pi += 8) {
         const int row = pi / at.Hkv, hk = pi % at.Hkv;
-        attn_short_wave(at, row, hk, lane, reinterpret_cast<bf16_t*>(xs) + (size_t)row * a.K, blockIdx.x == 0);
+        attn_short_wave<NT>(at, row, hk, lane, reinterpret_cast<bf16_t*>(xs) + (size_t)row * a.K, blockIdx.x == 0);
     }
     __syncthreads();
     if (n0 >= a.N) return;
@@ -1859,7 +1863,14 @@ int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const LinearCall&
     a.W = (const bf16_t*)l.W; a.bias = (const bf16_t*)l.bias; a.residual = (const bf16_t*)l.residual; a.y = (bf16_t*)l.y;
     a.B = l.B; a.N = l.N; a.K = l.K;
     const dim3 grid((l.N + 7) / 8);
-    hipLaunchKernelGGL((k_attn1_linear<1, 4, 1>), grid, dim3(512), 0, st, at, a);
+    switch (at.fixed_kvlen) {      // depth loop: the visible length is part of the captured graph
+#define VOX_A1(NT_) case NT_: hipLaunchKernelGGL((k_attn1_linear<1, 4, 1, NT_>), grid, dim3(512), 0, st, at, a); return VOX_OK;
+        VOX_A1(2) VOX_A1(3) VOX_A1(4) VOX_A1(5) VOX_A1(6) VOX_A1(7) VOX_A1(8) VOX_A1(9) VOX_A1(10) VOX_A1(11) VOX_A1(12)
+        VOX_A1(13) VOX_A1(14) VOX_A1(15) VOX_A1(16)
+#undef VOX_A1
+        default: break;
+    }
+    hipLaunchKernelGGL((k_attn1_linear<1, 4, 1, 0>), grid, dim3(512), 0, st, at, a);
     return VOX_OK;
 }
 // merge partials -> bf16 out [Nq,Hq,D] (standalone op path; the engine merges inside the o_proj prologue)

@@ -48,12 +48,57 @@ __device__ __forceinline__ float sq8(uint4 x, float a) { return dot8(x, x, a); }
 
 // xor-butterfly over `width` lanes (width power of two <= 64): s = s + s_partner, offsets width/2 .. 1.
 // Every participating lane ends with the same value.
+#ifndef VOX_DPP_BUTTERFLY
+#define VOX_DPP_BUTTERFLY 1
+#endif
+#if VOX_DPP_BUTTERFLY
+// The same partner pairs without the LDS crossbar (__shfl_xor lowers to ds_bpermute_b32, ~2 LDS latencies per level, six levels
+// per DOT): lane ^ 32 / ^ 16 via gfx950's v_permlane32_swap / v_permlane16_swap (one swap hands every lane its own and its
+// partner's value in the two results; the add is commutative, so no select), lane ^ 8 / ^ 2 / ^ 1 via one DPP move, lane ^ 4 via
+// two bank-masked DPP moves.  Bit-identical sums (tools/dpp_check.hip).
+typedef u32 vox_u2 __attribute__((ext_vector_type(2)));
+template <int CTRL, int BANK>
+__device__ __forceinline__ float vox_dpp(float old, float s) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(old), __float_as_uint(s), CTRL, 0xF, BANK, false));
+}
+template <int OFF>
+__device__ __forceinline__ float xor_add(float s) {
+    if constexpr (OFF == 32) {
+        const vox_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+        return __uint_as_float(r.x) + __uint_as_float(r.y);
+    } else if constexpr (OFF == 16) {
+        const vox_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+        return __uint_as_float(r.x) + __uint_as_float(r.y);
+    } else if constexpr (OFF == 8) {
+        return s + vox_dpp<0x128, 0xF>(s, s);                  // row_ror:8
+    } else if constexpr (OFF == 4) {
+        float t = vox_dpp<0x104, 0x5>(s, s);                   // banks 0, 2 <- lane + 4
+        t = vox_dpp<0x114, 0xA>(t, s);                         // banks 1, 3 <- lane - 4
+        return s + t;
+    } else if constexpr (OFF == 2) {
+        return s + vox_dpp<0x4E, 0xF>(s, s);                   // quad_perm [2,3,0,1]
+    } else {
+        return s + vox_dpp<0xB1, 0xF>(s, s);                   // quad_perm [1,0,3,2]
+    }
+}
+template <int WIDTH>
+__device__ __forceinline__ float butterfly(float s) {
+    if constexpr (WIDTH >= 64) s = xor_add<32>(s);
+    if constexpr (WIDTH >= 32) s = xor_add<16>(s);
+    if constexpr (WIDTH >= 16) s = xor_add<8>(s);
+    if constexpr (WIDTH >= 8) s = xor_add<4>(s);
+    if constexpr (WIDTH >= 4) s = xor_add<2>(s);
+    if constexpr (WIDTH >= 2) s = xor_add<1>(s);
+    return s;
+}
+#else
 template <int WIDTH>
 __device__ __forceinline__ float butterfly(float s) {
 #pragma unroll
     for (int off = WIDTH / 2; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, VOX_WAVE);
     return s;
 }
+#endif
 
 __device__ __forceinline__ float exp2_c(float x) {
     if (!(x > -125.0f)) return 0.0f;
