@@ -391,6 +391,48 @@ int vox_mimi_reset_slot(vox_mimi* m, void* stream, int slot);
 int vox_mimi_decode_chunk(vox_mimi* m, void* stream, const int32_t* codes, int code_stride, const int32_t* slots, int n, int T,
                           float* out);
 
+/* ---- SNAC decoder (token -> waveform of the Orpheus family) ---------------------------------------------------------
+ * Replaces SNAC.decode (/root/reference/vox_serve/tokenizer/snac.py:438-441: ResidualVectorQuantize.from_codes :350-357 +
+ * Decoder :119-158 with DecoderBlock :215-241, ResidualUnit :160-176, NoiseBlock :201-212, Snake1d :253-267) as
+ * OrpheusModel.postprocess calls it (model/orpheus.py:483-507), for the depthwise / no-local-attention variant (snac_24khz).
+ * Stateless per window, fp32 activations, convolutions as implicit GEMMs on the matrix cores with exact products (fp32
+ * activations split into three bf16 terms, fp32 weights carried as two bf16 planes = 16 significand bits).
+ * Weights: weight-norm already folded (w = g * v / ||v||).  tab[i]: out_proj_i(codebook_i) + bias, tabulated [codebook_size][latent].
+ * Conv weights as vox_conv_w with 2 * taps planes (taps of the high plane, then the same taps of the residual plane).
+ * NoiseBlock: x + noise[b, t] * conv1x1(x); noise is either given (fp32, per stage i the block [n][T_i], stages concatenated) or
+ * generated on the device: Philox4x32-10 keyed by `seed`, counter (t, stream, 0, 0), stream = stream_base[b] + stage
+ * (stream_base NULL: b * n_stages), Box-Muller of words 0 and 1 — the stream oracle/snac_ref.py::philox_noise restates. */
+typedef struct {
+    vox_snake_w act1, act2;
+    const float *dw_w, *dw_b;      /* depthwise conv: [C][7], [C] */
+    vox_conv_w pw;                 /* 1x1 conv + bias */
+} vox_snac_res_w;
+typedef struct {
+    vox_snake_w snake0;
+    vox_conv_w tconv;              /* ConvTranspose1d(k = 2r, stride r, padding r/2): 2 taps x 2 planes, N = r * Cout, bias_mod = Cout */
+    vox_conv_w noise;              /* NoiseBlock 1x1 conv (no bias); n_taps == 0: no noise block */
+    vox_snac_res_w res[3];         /* dilations 1, 3, 9 */
+} vox_snac_block_w;
+typedef struct {
+    const float* tab[4];           /* per VQ level: [codebook_size][latent_dim] */
+    const float *dw0_w, *dw0_b;    /* depthwise k7 on the latent: [latent][7], [latent] */
+    vox_conv_w pw0;                /* 1x1 latent -> decoder_dim */
+    vox_snac_block_w blocks[4];
+    vox_snake_w final_snake;
+    const float* final_w;          /* [C_last][7] */
+    float final_b;
+} vox_snac_weights;
+typedef struct {
+    int32_t latent_dim, decoder_dim, codebook_size, n_levels, vq_strides[4], rates[4], noise;
+} vox_snac_config;
+typedef struct vox_snac vox_snac;
+int vox_snac_create(vox_ctx* ctx, const vox_snac_config* cfg, const vox_snac_weights* w, int max_batch, int max_T, vox_snac** out);
+void vox_snac_destroy(vox_snac* m);
+/* codes: device int32 [n][sum_i T / vq_strides[i]], level-major per request (all of level 0, then level 1, ...), clamped to the
+ * codebook; T % vq_strides[0] == 0, T <= max_T.  out: fp32 [n][out_len] = samples [out_off, out_off + out_len) of the T * hop decoded. */
+int vox_snac_decode(vox_snac* m, void* stream, const int32_t* codes, int n, int T, const float* noise, uint64_t seed,
+                    const uint32_t* stream_base, float* out, int out_off, int out_len);
+
 #ifdef __cplusplus
 }
 #endif

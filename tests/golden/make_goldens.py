@@ -9,6 +9,7 @@ import json
 import os
 import queue
 import sys
+import types
 
 import numpy as np
 import torch
@@ -791,8 +792,64 @@ def g5_mimi(ns):
         print("g5", tag, tuple(wav.shape), "rms", float(wav.pow(2).mean().sqrt()))
     np.savez_compressed(os.path.join(HERE, "g5_mimi.npz"), **out)
 
+# --------------------------------------------------------------------------------------------------
+def g10_snac(ns):
+    """SNAC decode through the reference SNAC module (tokenizer/snac.py:438-441), tiny and snac_24khz size, fp32, with
+    NoiseBlock's torch.randn replaced by the seeded Philox stream of oracle/snac_ref.py (the noise contract); plus
+    OrpheusModel.postprocess (model/orpheus.py:479-507) on LM token ids."""
+    import importlib
+    from oracle import snac_ref as SR
+    S = importlib.import_module("vox_serve.tokenizer.snac")
+    out = {}
+    for tag, cfg, kw in (("tiny", SR.tiny_snac_cfg(), dict(encoder_dim=4, encoder_rates=[2, 2, 2, 2])),
+                         ("full", SR.SnacCfg(), dict(encoder_dim=48, encoder_rates=[2, 4, 8, 8]))):
+        W = SR.random_snac_weights(cfg, seed=1)
+        m = S.SNAC(sampling_rate=24000, latent_dim=cfg.latent_dim, decoder_dim=cfg.decoder_dim, decoder_rates=list(cfg.rates),
+                   attn_window_size=None, codebook_size=cfg.codebook_size, codebook_dim=cfg.codebook_dim,
+                   vq_strides=list(cfg.vq_strides), noise=True, depthwise=True, **kw).eval()
+        missing, unexpected = m.load_state_dict(W, strict=False)
+        assert not unexpected and all(k.startswith("encoder.") or "in_proj" in k for k in missing), (missing, unexpected)
+        B, T = 2, 16
+        g = torch.Generator().manual_seed(3)
+        codes = [torch.randint(0, cfg.codebook_size, (B, T // s), generator=g) for s in cfg.vq_strides]
+        noise = SR.make_noise(cfg, B, T, seed=77)
+        it = iter(noise)
+        real_randn = torch.randn
+
+        def fake_randn(shape, **kwargs):
+            n = next(it)
+            assert tuple(shape) == tuple(n.shape), (shape, n.shape)
+            return n
+        torch.randn = fake_randn
+        try:
+            wav = m.decode(codes)
+        finally:
+            torch.randn = real_randn
+        for i, c in enumerate(codes):
+            out[f"{tag}_codes{i}"] = c.numpy().astype(np.int16)
+        out[f"{tag}_wav"] = wav.numpy().astype(np.float32)
+        print("g10", tag, tuple(wav.shape), "rms", float(wav.pow(2).mean().sqrt()), "max", float(wav.abs().max()))
+        if tag == "full":
+            # OrpheusModel.postprocess on raw LM ids (7 per frame, 4 frames), unbound: the constructor downloads weights
+            OM = importlib.import_module("vox_serve.model.orpheus").OrpheusModel
+            stub = types.SimpleNamespace(audio_decoder=m, idx_14=torch.tensor([1, 4]), idx_2356=torch.tensor([2, 3, 5, 6]))
+            stub._turn_token_into_id = lambda ids: OM._turn_token_into_id(stub, ids)
+            tok = 128256 + 10 + torch.randint(0, 7 * 4096, (B, 28), generator=g)
+            it = iter(noise)
+            torch.randn = fake_randn
+            try:
+                audio = OM.postprocess(stub, tok)
+            finally:
+                torch.randn = real_randn
+            out["orpheus_tokens"] = tok.numpy().astype(np.int32)
+            out["orpheus_audio"] = audio.numpy().astype(np.float32)
+            print("g10 orpheus", tuple(audio.shape), "rms", float(audio.pow(2).mean().sqrt()))
+    out["noise_seed"] = np.int64(77)
+    np.savez_compressed(os.path.join(HERE, "g10_snac.npz"), **out)
+
+
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac}
 
 if __name__ == "__main__":
     ns = H.boot()

@@ -43,11 +43,11 @@ def make_prompt(rng, cfg, n):
     return ids, masks, feats
 
 
-def run_parity(dev, cfg, W, prompt_lens, n_frames, page, sampler_kw=None, max_pages=64):
+def run_parity(dev, cfg, W, prompt_lens, n_frames, page, sampler_kw=None, max_pages=64, policy=None):
     from vox_serve_amd.engine import Qwen3Engine
     rng = np.random.default_rng(3)
     B = len(prompt_lens)
-    ref = QR.Qwen3Ref(cfg, W, page_size=page, max_pages=max_pages, max_batch=B)
+    ref = QR.Qwen3Ref(cfg, W, page_size=page, max_pages=max_pages, max_batch=B, policy=policy)
     Wt = {k: vr.to_torch(v).to(dev) for k, v in W.items()}
     eng = Qwen3Engine(to_engine_cfg(cfg), Wt, max_batch=B, page_size=page, max_pages=max_pages, max_seq_len=512,
                       max_prefill_rows=128, keep_depth_logits=True, device=dev)
@@ -161,6 +161,20 @@ def test_tiny_b20_topk_sampling_mfma(dev):
     cfg = QR.tiny_cfg()
     run_parity(dev, cfg, QR.random_weights(cfg, 9, 0.08), [5 + i for i in range(20)], 10, page=16, max_pages=160,
                sampler_kw=dict(top_k=50, top_p=1.0, temperature=0.9))
+
+
+def test_fast_mode_b8_bit_exact_under_its_own_policy(dev):
+    """`exact_rows 2` (bench.py --exact-rows 2): calls of 3..8 rows run on the matrix cores too.  The oracle follows the same
+    policy, so the fast mode is bit-exact as well — tiny config, 8 requests, 20 free-running frames."""
+    from oracle.policy import Policy
+    from vox_serve_amd import _native as N
+    cfg = QR.tiny_cfg()
+    N.set_exact_rows(2)
+    try:
+        run_parity(dev, cfg, QR.random_weights(cfg, 4, 0.08), [9, 5, 12, 6, 8, 10, 7, 11], 20, page=16, max_pages=96,
+                   policy=Policy(exact_rows=2))
+    finally:
+        N.set_exact_rows(8)
 
 
 def test_full_size_qwen3_1p7b_one_frame(dev):

@@ -318,3 +318,43 @@ def test_mimi_oracle_against_reference_module(golden):
         assert wav.shape == ref.shape == (2, 1, 10 * cfg.hop)
         rms = float(np.sqrt(np.mean((wav - ref) ** 2)))
         assert rms < tol and np.sqrt(np.mean(ref ** 2)) > 0.1, (tag, rms)
+
+
+# ---------------------------------------------------------------- g10: SNAC decoder / Orpheus postprocess ----------
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_snac_oracle_matches_the_reference_module(golden, tag):
+    """oracle/snac_ref.py (weight-norm folded, explicit noise) vs the reference SNAC module run with the same seeded noise:
+    fp32 both sides, only the conv summation order differs -> max-abs 5e-5, RMS 1e-5 on an O(0.15) waveform."""
+    import torch
+    from oracle import snac_ref as SR
+    g = golden("g10_snac")
+    cfg = SR.tiny_snac_cfg() if tag == "tiny" else SR.SnacCfg()
+    ref = SR.SnacRef(cfg, SR.random_snac_weights(cfg, seed=1))
+    codes = [torch.from_numpy(g[f"{tag}_codes{i}"].astype(np.int64)) for i in range(3)]
+    noise = SR.make_noise(cfg, 2, 16, seed=int(g["noise_seed"]))
+    wav = ref.decode(codes, noise).numpy()
+    want = g[f"{tag}_wav"]
+    assert wav.shape == want.shape
+    assert np.abs(wav - want).max() < 5e-5 and np.sqrt(np.mean((wav - want) ** 2)) < 1e-5
+    # the noise branch is live: without it the waveform differs well above the tolerance
+    assert np.abs(ref.decode(codes, None).numpy() - want).max() > 1e-3
+
+
+def test_orpheus_postprocess_token_layout(golden):
+    """7 LM tokens per frame -> SNAC levels (1 + 2 + 4 codes), 4-frame window, samples [2048:4096] (orpheus.py:479-507)."""
+    import torch
+    from oracle import snac_ref as SR
+    g = golden("g10_snac")
+    cfg = SR.SnacCfg()
+    ref = SR.SnacRef(cfg, SR.random_snac_weights(cfg, seed=1))
+    tok = torch.from_numpy(g["orpheus_tokens"].astype(np.int64))
+    audio = SR.orpheus_postprocess(ref, tok, SR.make_noise(cfg, 2, 16, seed=int(g["noise_seed"]))).numpy()
+    assert audio.shape == (2, 1, 2048)
+    assert np.abs(audio - g["orpheus_audio"]).max() < 5e-5
+
+
+def test_philox_noise_is_standard_normal_and_stream_separated():
+    from oracle import snac_ref as SR
+    a, b = SR.philox_noise(5, 0, 1 << 16), SR.philox_noise(5, 1, 1 << 16)
+    assert abs(a.mean()) < 0.02 and abs(a.std() - 1) < 0.02 and abs(np.corrcoef(a, b)[0, 1]) < 0.02
+    assert np.array_equal(a[:100], SR.philox_noise(5, 0, 100))          # counter-based: prefix-stable

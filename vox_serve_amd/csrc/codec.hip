@@ -57,6 +57,7 @@ struct ConvGemmArgs {
     const float* bias;     // [bias_mod] or NULL
     const float* res;      // [M, N] residual or NULL
     const float* scale;    // [N] multiplier applied before the residual add, or NULL
+    const float* rscale;   // [M] per-row multiplier applied before the residual add, or NULL (SNAC NoiseBlock: x + noise[t] * Wx)
     float* out;            // [M, N]
     int M, N, Cin, L, P, n_taps, bias_mod, gelu;
     int off[CG_MAXTAPS];   // row look-back of each tap
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
                 if (m >= a.M) continue;
                 float v = acc[i][j][r] + bv;
                 if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                if (a.rscale) v = a.rscale[m] * v;
                 const size_t o = (size_t)m * a.N + n;
                 if (a.res) v = a.res[o] + sv * v;
                 else if (a.scale) v = sv * v;
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
         if (m >= a.M) continue;
         float v = acc[r] + bvv;
         if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (a.rscale) v = a.rscale[m] * v;
         const size_t o = (size_t)m * a.N + n;
         if (a.res) v = a.res[o] + sv * v;
         else if (a.scale) v = sv * v;
@@ -542,12 +545,12 @@ struct vox_codec {
 
 static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const float* state, const int* slots, int n,
                      int L, int P, const int* offs, float* out, const float* res, const float* scale, int gelu,
-                     float* out2 = nullptr, const vox_snake_w* sn = nullptr, int sn_mod = 0) {
+                     float* out2 = nullptr, const vox_snake_w* sn = nullptr, int sn_mod = 0, const float* rscale = nullptr) {
     if (w.cin % CG_BK) return vox_fail(VOX_ERR_INVALID, "codec gemm: Cin %d %% %d != 0", w.cin, CG_BK);
     if (w.n_taps > CG_MAXTAPS) return vox_fail(VOX_ERR_INVALID, "codec gemm: too many taps");
     ConvGemmArgs a{};
     a.x = x; a.state = state; a.slots = slots; a.w = (const bf16_t*)w.w; a.bias = w.bias; a.res = res; a.scale = scale;
-    a.out = out; a.M = n * L; a.N = w.n; a.Cin = w.cin; a.L = L; a.P = P; a.n_taps = w.n_taps;
+    a.out = out; a.M = n * L; a.N = w.n; a.Cin = w.cin; a.L = L; a.P = P; a.n_taps = w.n_taps; a.rscale = rscale;
     a.bias_mod = w.bias_mod > 0 ? w.bias_mod : w.n; a.gelu = gelu;
     if (out2 && sn) { a.out2 = out2; a.sn_alpha = sn->alpha; a.sn_invb = sn->inv_beta; a.sn_mod = sn_mod > 0 ? sn_mod : w.n; }
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
@@ -1146,6 +1149,237 @@ int vox_mimi_decode_chunk(vox_mimi* m, void* stream, const int32_t* codes, int c
     if (!m->max_slots) return vox_fail(VOX_ERR_INVALID, "mimi_decode_chunk: call vox_mimi_stream_enable first");
     if (n < 1 || n > m->max_batch || T < 1 || T > m->max_frames) return vox_fail(VOX_ERR_INVALID, "mimi_decode_chunk: n=%d T=%d out of range", n, T);
     return mimi_run(m, (hipStream_t)stream, codes, code_stride, slots, n, T, out);
+}
+
+}  // extern "C"
+
+
+// ====================================================================================================================
+// SNAC decoder (Orpheus): SNAC.decode of /root/reference/vox_serve/tokenizer/snac.py:438-441, stateless per window.
+// Layout as above (fp32, time-major rows).  A transposed conv with stride r, kernel 2r, padding r/2 is the 2-tap GEMM
+//   G[q][j*Cout + co] = x[q] . W[:, co, j] + x[q-1] . W[:, co, j + r],   q = 0..Tin  (x[-1] = x[Tin] = 0),
+// and the conv's output row o is row o + r/2 of G seen as [(Tin + 1) * r][Cout].  Instead of copying, every later kernel
+// of the block works on that padded block (Lb = (Tin + 1) r rows per request, valid rows [v0, v0 + Lv)): the 1x1 GEMMs run
+// on all rows (rows never mix), the depthwise convs read zeros outside the valid range, and the next block's Snake
+// compacts the valid rows again (plus the zero row x[Tin]).
+// ====================================================================================================================
+struct SnacGeo { int B, Lb, v0, Lv, C; };
+
+__device__ __forceinline__ float snake_a(float v, float alpha, float invb) { return snake_f(v, alpha, invb); }
+
+// z[b][t][c] = sum_i tab_i[code_i[b][t / stride_i]][c]  (sequential in i; from_codes: snac.py:350-357)
+__global__ __launch_bounds__(256) void k_snac_embed(const int* codes, int code_row, const float* t0, const float* t1, const float* t2,
+                                                     const float* t3, int n_levels, int s0, int s1, int s2, int s3, int bins, int T,
+                                                     int C, float* z) {
+    const int b = blockIdx.z, t = blockIdx.y;
+    const float* tabs[4] = {t0, t1, t2, t3};
+    const int st[4] = {s0, s1, s2, s3};
+    const int* cr = codes + (size_t)b * code_row;
+    int id[4], off = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        int v = cr[off + t / st[i]];
+        id[i] = v < 0 ? 0 : (v >= bins ? bins - 1 : v);
+        off += T / st[i];
+    }
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        float acc = tabs[0][(size_t)id[0] * C + c];
+        for (int i = 1; i < n_levels; ++i) acc = acc + tabs[i][(size_t)id[i] * C + c];
+        z[((size_t)b * T + t) * C + c] = acc;
+    }
+}
+
+// depthwise conv k = 7, dilation d, "same" zero padding inside the valid rows, optional Snake on the input taps and on
+// the output:  y[t][c] = post( bias[c] + sum_j w[c][j] * pre(x[t + (j - 3) d][c]) )      (ResidualUnit: snac.py:160-176)
+__global__ __launch_bounds__(256) void k_snac_dw(const float* x, const float* w, const float* bias, const float* pa, const float* pib,
+                                                  const float* qa, const float* qib, float* y, SnacGeo g, int dil) {
+    const size_t total = (size_t)g.B * g.Lb * g.C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % g.C);
+        const size_t row = i / g.C;
+        const int t = (int)(row % g.Lb) - g.v0;
+        float v = 0.0f;
+        if (t >= 0 && t < g.Lv) {
+            const float a = pa ? pa[c] : 0.0f, ib = pa ? pib[c] : 0.0f;
+            v = bias[c];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int tt = t + (j - 3) * dil;
+                if (tt >= 0 && tt < g.Lv) {
+                    float xv = x[(row + (size_t)((j - 3) * dil)) * g.C + c];
+                    if (pa) xv = snake_a(xv, a, ib);
+                    v = fmaf(w[c * 7 + j], xv, v);
+                }
+            }
+            if (qa) v = snake_a(v, qa[c], qib[c]);
+        }
+        y[i] = v;
+    }
+}
+
+// Snake of the valid rows -> compact [B][Lv + 1][C] with a trailing zero row (the x[Tin] = 0 of the transposed conv)
+__global__ __launch_bounds__(256) void k_snac_snake_pack(const float* x, const float* alpha, const float* invb, float* y, SnacGeo g) {
+    const size_t total = (size_t)g.B * (g.Lv + 1) * g.C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % g.C);
+        const size_t row = i / g.C;
+        const int b = (int)(row / (g.Lv + 1)), t = (int)(row % (g.Lv + 1));
+        y[i] = t < g.Lv ? snake_a(x[((size_t)b * g.Lb + g.v0 + t) * g.C + c], alpha[c], invb[c]) : 0.0f;
+    }
+}
+
+__device__ __forceinline__ void philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* o0,
+                                        uint32_t* o1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    *o0 = c0; *o1 = c1;
+}
+// per-row NoiseBlock multiplier in the padded geometry (junk rows 0): given noise [B][Lv] or the seeded Philox stream
+__global__ __launch_bounds__(256) void k_snac_noise(const float* noise, uint64_t seed, const uint32_t* stream_base, int stage, int n_stages,
+                                                     float* rs, SnacGeo g) {
+    const size_t total = (size_t)g.B * g.Lb;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / g.Lb), t = (int)(i % g.Lb) - g.v0;
+        float v = 0.0f;
+        if (t >= 0 && t < g.Lv) {
+            if (noise) v = noise[(size_t)b * g.Lv + t];
+            else {
+                const uint32_t stream = (stream_base ? stream_base[b] : (uint32_t)(b * n_stages)) + (uint32_t)stage;
+                uint32_t w0, w1;
+                philox4((uint32_t)t, stream, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), &w0, &w1);
+                const float u1 = ((float)(w0 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+                v = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+            }
+        }
+        rs[i] = v;
+    }
+}
+
+// final Snake -> conv k7 (C -> 1) -> tanh, samples [out_off, out_off + out_len) of the valid rows; one wave per sample
+__global__ __launch_bounds__(256) void k_snac_final(const float* x, const float* alpha, const float* invb, const float* w, float bias,
+                                                     float* out, SnacGeo g, int out_off, int out_len) {
+    const int lane = threadIdx.x & 63;
+    const size_t s = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= (size_t)g.B * out_len) return;
+    const int b = (int)(s / out_len), t = out_off + (int)(s % out_len);
+    float acc = 0.0f;
+    for (int c = lane; c < g.C; c += 64) {
+        const float a = alpha[c], ib = invb[c];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int tt = t + j - 3;
+            if (tt >= 0 && tt < g.Lv) acc = fmaf(w[c * 7 + j], snake_a(x[((size_t)b * g.Lb + g.v0 + tt) * g.C + c], a, ib), acc);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) out[s] = tanhf(acc + bias);
+}
+
+struct vox_snac {
+    vox_ctx* ctx;
+    vox_snac_config cfg;
+    vox_snac_weights w;
+    int max_batch, max_T, n_stages;
+    float *buf[4], *rs;
+    size_t buf_floats;
+};
+
+static inline int ew_grid(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+extern "C" {
+
+int vox_snac_create(vox_ctx* ctx, const vox_snac_config* cfg, const vox_snac_weights* w, int max_batch, int max_T, vox_snac** out) {
+    if (!ctx || !cfg || !w || !out) return vox_fail(VOX_ERR_INVALID, "snac_create: NULL");
+    if (cfg->n_levels < 1 || cfg->n_levels > 4 || max_batch < 1 || max_T < 1) return vox_fail(VOX_ERR_INVALID, "snac_create: bad config");
+    vox_snac* m = new vox_snac();
+    m->ctx = ctx; m->cfg = *cfg; m->w = *w; m->max_batch = max_batch; m->max_T = max_T;
+    m->n_stages = 0;
+    int ch = cfg->decoder_dim;
+    size_t worst = (size_t)max_T * (cfg->latent_dim > cfg->decoder_dim ? cfg->latent_dim : cfg->decoder_dim);
+    size_t T = max_T, rs_rows = 0;
+    for (int i = 0; i < 4 && cfg->rates[i] > 0; ++i) {
+        const int r = cfg->rates[i];
+        if (r % 2 || ch % 2) { delete m; return vox_fail(VOX_ERR_INVALID, "snac_create: rates must be even"); }
+        const size_t Lb = (T + 1) * r;
+        if (Lb * (ch / 2) > worst) worst = Lb * (ch / 2);
+        if ((T + 1) * ch > worst) worst = (T + 1) * ch;
+        if (Lb > rs_rows) rs_rows = Lb;
+        T *= r; ch /= 2;
+        ++m->n_stages;
+    }
+    m->buf_floats = worst * max_batch;
+    bool ok = hipMalloc((void**)&m->rs, rs_rows * max_batch * 4) == hipSuccess;
+    for (int i = 0; i < 4; ++i) ok = ok && hipMalloc((void**)&m->buf[i], m->buf_floats * 4) == hipSuccess;
+    if (!ok) { vox_snac_destroy(m); return vox_fail(VOX_ERR_NOMEM, "snac_create: hipMalloc failed"); }
+    *out = m;
+    return VOX_OK;
+}
+
+void vox_snac_destroy(vox_snac* m) {
+    if (!m) return;
+    for (int i = 0; i < 4; ++i) (void)hipFree(m->buf[i]);
+    (void)hipFree(m->rs);
+    delete m;
+}
+
+int vox_snac_decode(vox_snac* m, void* stream, const int32_t* codes, int n, int T, const float* noise, uint64_t seed,
+                    const uint32_t* stream_base, float* out, int out_off, int out_len) {
+    if (!m || !codes || !out) return vox_fail(VOX_ERR_INVALID, "snac_decode: NULL");
+    const vox_snac_config& c = m->cfg;
+    if (n < 1 || n > m->max_batch || T < 1 || T > m->max_T || T % c.vq_strides[0])
+        return vox_fail(VOX_ERR_INVALID, "snac_decode: n %d / T %d out of range", n, T);
+    hipStream_t st = (hipStream_t)stream;
+    int code_row = 0;
+    for (int i = 0; i < c.n_levels; ++i) code_row += T / c.vq_strides[i];
+    float *x = m->buf[0], *y = m->buf[1], *u = m->buf[2], *pk = m->buf[3];
+    const vox_snac_weights& w = m->w;
+    // latent: from_codes -> depthwise k7 -> 1x1
+    hipLaunchKernelGGL(k_snac_embed, dim3((c.latent_dim + 255) / 256, T, n), dim3(256), 0, st, codes, code_row, w.tab[0], w.tab[1], w.tab[2],
+                       w.tab[3], c.n_levels, c.vq_strides[0], c.vq_strides[1] ? c.vq_strides[1] : 1, c.vq_strides[2] ? c.vq_strides[2] : 1,
+                       c.vq_strides[3] ? c.vq_strides[3] : 1, c.codebook_size, T, c.latent_dim, x);
+    SnacGeo g{n, T, 0, T, c.latent_dim};
+    hipLaunchKernelGGL(k_snac_dw, dim3(ew_grid((size_t)n * T * c.latent_dim)), dim3(256), 0, st, x, w.dw0_w, w.dw0_b, nullptr, nullptr, nullptr,
+                       nullptr, y, g, 1);
+    static const int off1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, off2[8] = {0, 1, 0, 1, 0, 0, 0, 0};
+    VOX_TRY(conv_gemm(st, w.pw0, y, nullptr, nullptr, n, T, 0, off1, x, nullptr, nullptr, 0));
+    g.C = c.decoder_dim;
+    size_t noise_off = 0;
+    for (int bi = 0; bi < m->n_stages; ++bi) {
+        const vox_snac_block_w& b = w.blocks[bi];
+        const int r = c.rates[bi], cout = g.C / 2, Tin = g.Lv;
+        // Snake -> compact rows + zero row; transposed conv as the 2-tap GEMM
+        hipLaunchKernelGGL(k_snac_snake_pack, dim3(ew_grid((size_t)n * (Tin + 1) * g.C)), dim3(256), 0, st, x, b.snake0.alpha, b.snake0.inv_beta, pk, g);
+        VOX_TRY(conv_gemm(st, b.tconv, pk, nullptr, nullptr, n, Tin + 1, 0, off2, x, nullptr, nullptr, 0));
+        g = SnacGeo{n, (Tin + 1) * r, r / 2, Tin * r, cout};
+        if (b.noise.n_taps > 0) {
+            hipLaunchKernelGGL(k_snac_noise, dim3(ew_grid((size_t)n * g.Lb)), dim3(256), 0, st, noise ? noise + noise_off : nullptr, seed, stream_base, bi,
+                               m->n_stages, m->rs, g);
+            VOX_TRY(conv_gemm(st, b.noise, x, nullptr, nullptr, n, g.Lb, 0, off1, y, x, nullptr, 0, nullptr, nullptr, 0, m->rs));
+            float* t = x; x = y; y = t;
+            noise_off += (size_t)n * g.Lv;
+        }
+        static const int dils[3] = {1, 3, 9};
+        for (int k = 0; k < 3; ++k) {
+            const vox_snac_res_w& ru = b.res[k];
+            hipLaunchKernelGGL(k_snac_dw, dim3(ew_grid((size_t)n * g.Lb * g.C)), dim3(256), 0, st, x, ru.dw_w, ru.dw_b, ru.act1.alpha, ru.act1.inv_beta,
+                               ru.act2.alpha, ru.act2.inv_beta, u, g, dils[k]);
+            VOX_TRY(conv_gemm(st, ru.pw, u, nullptr, nullptr, n, g.Lb, 0, off1, y, x, nullptr, 0));
+            float* t = x; x = y; y = t;
+        }
+    }
+    const int total_len = g.Lv;
+    if (out_off < 0 || out_len < 1 || out_off + out_len > total_len) return vox_fail(VOX_ERR_INVALID, "snac_decode: output window out of range");
+    hipLaunchKernelGGL(k_snac_final, dim3(((size_t)n * out_len + 3) / 4), dim3(256), 0, st, x, w.final_snake.alpha, w.final_snake.inv_beta, w.final_w,
+                       w.final_b, out, g, out_off, out_len);
+    return VOX_OK;
 }
 
 }  // extern "C"

@@ -291,7 +291,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         ac.out = s->attn_out;
         LinearCall o;  // o_proj + residual
         o.W = w.wo; o.x = s->attn_out; o.residual = x; o.y = x; o.B = n; o.N = c.hidden; o.K = nq;
-        o.pro = VOX_PRO_COPY; o.epi = VOX_EPI_STORE;
+        o.pro = VOX_PRO_COPY; o.epi = VOX_EPI_STORE; o.eps = c.eps;      // (eps of the fused post-norm the split-K reduce may run)
         o.fixed_order = fixed_order; o.exact_rows = s->ctx->exact_rows; o.keep_weights = s->keep_weights; o.splitk_ws = s->skws; o.splitk_ws_bytes = s->skws_bytes;
         xn_ready = vox_linear_is_rows_gemm(o);      // its reduce also writes post_attention_layernorm(x) for gate/up
         if (xn_ready) { o.post_norm_w = w.ln2; o.post_norm_out = s->xn; }
@@ -301,7 +301,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         g.fixed_order = fixed_order; g.exact_rows = s->ctx->exact_rows; g.keep_weights = s->keep_weights; g.splitk_ws = s->skws; g.splitk_ws_bytes = s->skws_bytes; g.norm_scratch = s->xn;
         LinearCall d;  // down + residual
         d.W = w.wdown; d.x = s->h; d.residual = x; d.y = x; d.B = n; d.N = c.hidden; d.K = c.ffn;
-        d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE;
+        d.pro = VOX_PRO_COPY; d.epi = VOX_EPI_STORE; d.eps = c.eps;
         d.fixed_order = fixed_order; d.exact_rows = s->ctx->exact_rows; d.keep_weights = s->keep_weights; d.splitk_ws = s->skws; d.splitk_ws_bytes = s->skws_bytes;
         // fragment-major hand-offs between consecutive full-K GEMMs (o -> gate/up -> down -> next layer's qkv)
         const bool o_fk = s->xfrag && vox_linear_is_fullk(o), g_fk = s->xfrag && vox_linear_is_fullk(g), d_fk = s->xfrag && vox_linear_is_fullk(d);
