@@ -353,8 +353,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttfa-requests", type=int, default=5, help="engine-level TTFA samples per setting (lock-step loop)")
     ap.add_argument("--serving-ttfa-requests", type=int, default=100, help="TTFA samples through Scheduler + ModelWorker (0 = skip)")
-    ap.add_argument("--exact-rows", type=int, default=8, help="rows up to which linears use the fixed-order (oracle-bit-exact) "
-                    "kernels; default 8 = the parity-tested configuration, lower = opt-in fast mode (bf16-rounding parity)")
+    ap.add_argument("--exact-rows", type=int, default=None, help="rows up to which linears use the wave64 VALU kernels instead of the "
+                    "matrix cores (library default 2; 1..8).  Every setting is bit-exact against the oracle under the same policy")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -373,7 +373,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI; off the token path
 
-    if args.exact_rows != 8:
+    if args.exact_rows is not None:
         from vox_serve_amd import _native as N
         N.set_exact_rows(args.exact_rows)
     from vox_serve_amd.engine import Qwen3Cfg
@@ -422,7 +422,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"Qwen3-TTS-1.7B bf16, batch={head_B}/GPU streaming, greedy, {PROMPT_TOKENS}-token prompt, "
                                    f"detokenize_interval {INTERVAL}, page_size 128, mean kv {head['kv_mean']:.0f}"
-                                   + ("" if args.exact_rows == 8 else f", exact_rows {args.exact_rows} (fast mode)"), "batch_per_gpu": head_B,
+                                   + ("" if args.exact_rows is None else f", exact_rows {args.exact_rows}"), "batch_per_gpu": head_B,
                        "frames_per_request": args.steps, "parallelism": f"dp{world} (independent replicas, no collective on the data path)"},
             "realtime_factor": head["realtime_factor_per_request"],
             "ttfa_ms_p50": serving.get("ttfa_ms_p50", head.get("ttfa_ms_p50_engine")),

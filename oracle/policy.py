@@ -1,7 +1,8 @@
 """Which summation order does a linear of the hot path use?  (TEST INFRASTRUCTURE — see oracle/voxref.c.)
 
 The numeric contract has two regimes:
-  * calls of at most `exact_rows` rows (default 8): the canonical wave64 order (oracle/voxref.c: DOT, RMSNorm);
+  * calls of at most `exact_rows` rows (default 2; vox_ctx_set_exact_rows accepts 1..8): the canonical wave64 order
+    (oracle/voxref.c: DOT, RMSNorm);
   * calls with more rows run on the matrix cores: the order is the MFMA's own arithmetic (voxref.c: vr_mfma_step8)
     composed with how the kernel that takes the call splits K.  Which kernel takes a call is a pure function of its
     shape and fusion flags — restated here from the contract in include/voxhip.h ("Summation order of a linear").
@@ -19,7 +20,7 @@ EPI_STORE, EPI_SILU, EPI_SILU_MUL = 0, 1, 2
 NORM_NONE, NORM_CANON, NORM_FULLK, NORM_ROWS1024 = None, "canon", "fullk", "rows1024"
 
 
-def fullk_shape_ok(B, N, K, pro, epi, exact_rows=8):
+def fullk_shape_ok(B, N, K, pro, epi, exact_rows=2):
     if B <= exact_rows or B < 2 or B > 128 or K % 256:
         return False
     if N % 16 and (B > 32 or epi == EPI_SILU_MUL):
@@ -51,22 +52,22 @@ class Call:
     x_prenormed: bool = False    # the producing linear already wrote norm(x)
 
 
-def fullk_prenorm_ok(c: Call, exact_rows=8):
+def fullk_prenorm_ok(c: Call, exact_rows=2):
     return (not c.fixed_order and not c.x_out and not c.x_rows and c.norm_scratch and c.pro == PRO_RMSNORM and c.K == 4096
             and c.epi in (EPI_STORE, EPI_SILU_MUL)
             and fullk_shape_ok(c.B, c.N, c.K, PRO_COPY, EPI_SILU_MUL if c.epi == EPI_SILU_MUL else EPI_STORE, exact_rows))
 
 
-def is_fullk(c: Call, exact_rows=8):
+def is_fullk(c: Call, exact_rows=2):
     return (not c.fixed_order and not c.x_out and fullk_shape_ok(c.B, c.N, c.K, c.pro, c.epi, exact_rows)) or fullk_prenorm_ok(c, exact_rows)
 
 
-def is_rows_gemm(c: Call, exact_rows=8):
+def is_rows_gemm(c: Call, exact_rows=2):
     return (not is_fullk(c, exact_rows) and c.B >= 17 and not c.fixed_order and c.K % 32 == 0 and c.splitk_ws and not c.x_out
             and (c.pro == PRO_COPY or (c.pro == PRO_RMSNORM and (c.x_prenormed or (c.norm_scratch and not c.x_rows)))))
 
 
-def route(c: Call, exact_rows=8):
+def route(c: Call, exact_rows=2):
     """-> (dot order, norm order of the prologue or None).  norm order NORM_ROWS1024 never comes from here: it is the
     order of the PREVIOUS linear's fused post-norm (x_prenormed), which the caller tracks."""
     norm = NORM_CANON if c.pro == PRO_RMSNORM else NORM_NONE
@@ -86,9 +87,9 @@ def route(c: Call, exact_rows=8):
 
 @dataclass
 class Policy:
-    """exact_rows: rows up to which the canonical kernels are used (vox_ctx_set_exact_rows; 8 by default).
-    exact_rows=None: everything canonical (the <= 8-row contract at any batch size — what the reference fixtures pin)."""
-    exact_rows: Optional[int] = 8
+    """exact_rows: rows up to which the canonical wave64 kernels are used (vox_ctx_set_exact_rows; 2 by default).
+    exact_rows=None: everything canonical at any row count (no kernel does that above 8 rows; reference-fixture comparisons)."""
+    exact_rows: Optional[int] = 2
 
     def route(self, c: Call):
         if self.exact_rows is None:

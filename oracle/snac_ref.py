@@ -40,7 +40,8 @@ class SnacCfg:
 
 
 def tiny_snac_cfg() -> SnacCfg:
-    return SnacCfg(latent_dim=64, decoder_dim=128, rates=(4, 2, 2, 2), codebook_size=64, codebook_dim=8, vq_strides=(4, 2, 1))
+    # (channels 256 / 128 / 64 / 32: the implicit-GEMM kernels take input channels in multiples of 32)
+    return SnacCfg(latent_dim=64, decoder_dim=512, rates=(4, 2, 2, 2), codebook_size=64, codebook_dim=8, vq_strides=(4, 2, 1))
 
 
 def param_shapes(cfg: SnacCfg) -> Dict[str, tuple]:

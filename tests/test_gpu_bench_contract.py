@@ -44,8 +44,8 @@ def test_bench_line_has_the_contract_keys():
     assert abs(d["value"] - 1920 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6      # samples of exactly K steps / their time
 
 
-def test_bench_batched_line_and_fast_mode_flag():
-    d = _run("--batch", "8", "--ttfa-requests", "0", "--no-cpu-baseline", "--exact-rows", "2")
+def test_bench_batched_line_and_exact_rows_flag():
+    d = _run("--batch", "8", "--ttfa-requests", "0", "--no-cpu-baseline", "--exact-rows", "8")
     assert "batch32" not in d          # an explicit --batch runs that batch size only
-    assert d["config"]["batch_per_gpu"] == 8 and "exact_rows 2" in d["config"]["workload"]
+    assert d["config"]["batch_per_gpu"] == 8 and "exact_rows 8" in d["config"]["workload"]
     assert abs(d["value"] - 8 * 1920 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6

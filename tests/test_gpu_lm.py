@@ -225,22 +225,22 @@ def test_glm_full_width_two_layers(dev):
 
 
 @pytest.mark.slow
-def test_glm_full_width_b8_default_and_fast_mode(dev):
+def test_glm_full_width_b8_both_settings(dev):
     """BASELINE config 4's per-GPU share — 8 concurrent requests — at GLM-4-Voice-9B layer shapes (2 of 40 layers, full
-    168960-entry vocabulary).  (a) default: 8 rows stay on the canonical kernels; (b) fast mode (`exact_rows 2`): every call
-    with more than 2 rows runs on the matrix cores (K = 4096: normalise-once + full-K GEMM; down_proj K = 13696: 4-wave GEMM).
-    Both are bit-exact against the oracle under the same policy, prefills included."""
+    168960-entry vocabulary).  (a) default (`exact_rows 2`): every call with more than 2 rows runs on the matrix cores
+    (K = 4096: normalise-once + full-K GEMM; down_proj K = 13696: 4-wave GEMM); (b) `exact_rows 8`: 8 rows stay on the wave64
+    VALU kernels.  Both are bit-exact against the oracle under the same policy, prefills included."""
     from oracle.policy import Policy
     from vox_serve_amd import _native as N
     cfg = LR.glm_cfg(layers=2, max_pos=512)
     S = LR.random_glm_state_dict(cfg, seed=1, std=0.02)
     lens = [4, 6, 3, 5, 7, 2, 8, 5]
     run_parity(dev, "glm", cfg, S, lens, 4, page=128, max_pages=16)
-    N.set_exact_rows(2)
+    N.set_exact_rows(8)
     try:
-        run_parity(dev, "glm", cfg, S, lens, 4, page=128, max_pages=16, policy=Policy(exact_rows=2))
+        run_parity(dev, "glm", cfg, S, lens, 4, page=128, max_pages=16, policy=Policy(exact_rows=8))
     finally:
-        N.set_exact_rows(8)
+        N.set_exact_rows(2)
 
 
 @pytest.mark.slow

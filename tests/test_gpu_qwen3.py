@@ -2,7 +2,7 @@
 oracle: ragged prefill, then free-running batched decode under greedy AND seeded top-k sampling.
 
 Bar: BIT-EXACT token ids, logits, hidden states and KV cache contents, free-running over many frames, at every batch
-size.  Calls of <= 8 rows run the fixed-order wave64 kernels (canonical order of oracle/voxref.c); calls with more rows
+size.  Calls of <= 2 rows (`exact_rows`, settable 1..8) run the wave64 VALU kernels (canonical order of oracle/voxref.c); calls with more rows
 (longer prompts, batches > 8) run on the matrix cores, whose accumulation arithmetic the oracle restates bit for bit
 (voxref.c: vr_mfma_step8, measured on the MI355X with tools/mfma_probe) together with each GEMM kernel's K split
 (oracle/policy.py).
@@ -135,7 +135,7 @@ def test_tiny_topk_sampling_b2(dev):
 
 def test_tiny_short_prompts_bit_exact_through_prefill(dev):
     cfg = QR.tiny_cfg()
-    run_parity(dev, cfg, QR.random_weights(cfg, 5, 0.08), [8, 3, 5, 1], 12, page=16)   # every call <= 8 rows
+    run_parity(dev, cfg, QR.random_weights(cfg, 5, 0.08), [8, 3, 5, 1], 12, page=16)
 
 
 def test_tiny_b8_batch(dev):
@@ -163,18 +163,19 @@ def test_tiny_b20_topk_sampling_mfma(dev):
                sampler_kw=dict(top_k=50, top_p=1.0, temperature=0.9))
 
 
-def test_fast_mode_b8_bit_exact_under_its_own_policy(dev):
-    """`exact_rows 2` (bench.py --exact-rows 2): calls of 3..8 rows run on the matrix cores too.  The oracle follows the same
-    policy, so the fast mode is bit-exact as well — tiny config, 8 requests, 20 free-running frames."""
+def test_exact_rows_8_setting_bit_exact_under_its_own_policy(dev):
+    """`vox_ctx_set_exact_rows(8)` (bench.py --exact-rows 8): calls of up to 8 rows stay on the wave64 VALU kernels instead of
+    the matrix cores.  The oracle follows the same policy — tiny config, 8 requests, 20 free-running frames, bit-exact
+    (the default setting, 2, runs in every other test of this file)."""
     from oracle.policy import Policy
     from vox_serve_amd import _native as N
     cfg = QR.tiny_cfg()
-    N.set_exact_rows(2)
+    N.set_exact_rows(8)
     try:
         run_parity(dev, cfg, QR.random_weights(cfg, 4, 0.08), [9, 5, 12, 6, 8, 10, 7, 11], 20, page=16, max_pages=96,
-                   policy=Policy(exact_rows=2))
+                   policy=Policy(exact_rows=8))
     finally:
-        N.set_exact_rows(8)
+        N.set_exact_rows(2)
 
 
 def test_full_size_qwen3_1p7b_one_frame(dev):

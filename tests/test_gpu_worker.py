@@ -320,3 +320,55 @@ def test_csm_stateful_mimi_option_streams_without_seams():
     a_s, a_l = (np.frombuffer(pcm[k]["a"], dtype=np.int16) for k in (True, False))
     n = min(len(a_s), len(a_l))
     assert np.array_equal(a_s[:100], a_l[:100]) and not np.array_equal(a_s[:n], a_l[:n])
+
+
+def test_orpheus_served_end_to_end_with_snac_windows():
+    """Orpheus plugin (single-stack LM engine + SNAC decoder) through Scheduler -> ModelWorker: 28-token detokenizer windows
+    advancing by 7 (detokenize_overlap 21), 2048 samples per window, EOS dropped from the audio tokens, resources released,
+    byte-identical audio on a repeat (seeded device noise)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    from oracle import snac_ref as SR
+    from vox_serve_amd.model.orpheus import OrpheusConfig, OrpheusModel
+    from vox_serve_amd.sampling import SamplingConfig
+    from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
+    from vox_serve_amd.synth import synth_orpheus_weights
+    from vox_serve_amd.tokenizer.snac import SNACConfig
+    from vox_serve_amd.worker import ModelWorker
+    oc = OrpheusConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                       head_dim=64, vocab_size=10 + 7 * 64, audio_token_base=10, stop_token_id=2)
+    sc = SR.tiny_snac_cfg()
+    pc = SNACConfig(latent_dim=sc.latent_dim, decoder_dim=sc.decoder_dim, decoder_rates=list(sc.rates), codebook_size=sc.codebook_size,
+                    codebook_dim=sc.codebook_dim, vq_strides=list(sc.vq_strides))
+
+    def serve():
+        m = OrpheusModel("tiny-orpheus", synth_orpheus_weights(oc, dev, seed=3, std=0.08), SR.random_snac_weights(sc, 1), config=oc,
+                         codec_config=pc, device=str(dev), max_batch_size=4, page_size=16, max_num_pages=64, max_seq_len=512,
+                         max_prefill_tokens=64, max_pos=512, noise_seed=5)
+        m.default_sampling_config = SamplingConfig(greedy=True, max_tokens=70, repetition_penalty=1.3, repetition_window=-1)
+        t = QueueTransport()
+        w = ModelWorker(model=m, max_batch_size=4, max_num_pages=64, page_size=16, device=str(dev))
+        s = Scheduler(w, max_batch_size=4, transport=t)
+        for rid, ids in (("a", [5, 9, 200, 31, 7]), ("b", [6, 8, 300, 12])):
+            t.requests.put(encode_request(rid, "", model_kwargs={"prompt_token_ids": ids, "voice": "tara"}))
+        s.run_until_idle(3000)
+        out = {"a": b"", "b": b""}
+        done = {}
+        while not t.results.empty():
+            rid, kind, body = t.results.get().split(b"|", 2)
+            if kind == b"AUDIO":
+                out[rid.decode()] += body
+            else:
+                done[rid.decode()] = json.loads(body)
+        free = w.empty_pages.qsize()
+        m.engine.close(); m.audio_decoder.close()
+        return out, done, free
+
+    out, done, free = serve()
+    assert free == 64 and set(done) == {"a", "b"} and all(d["status"] == "completed" for d in done.values())
+    for rid, pcm in out.items():
+        assert len(pcm) % 2 == 0 and len(pcm) >= 2 * 128            # at least one window (tiny SNAC: hop 32 -> 128 samples per window)
+        assert np.abs(np.frombuffer(pcm, np.int16)).max() > 50
+    out2, _, _ = serve()
+    assert out == out2

@@ -143,8 +143,8 @@ def ctx():
 
 
 def set_exact_rows(rows: int):
-    """Linears with at most `rows` rows (1..8, default 8) keep the fixed-order kernels that are bit-identical to the oracle;
-    more rows take the bf16 MFMA kernels (see include/voxhip.h).  Call before the first frame of an engine is captured."""
+    """Linears with at most `rows` rows (1..8, default 2) run the wave64 VALU kernels, more rows the matrix cores; every setting
+    is bit-exact against the oracle under the same policy (see include/voxhip.h).  Call before the engines are created."""
     L = lib()
     L.vox_ctx_set_exact_rows.restype = ctypes.c_int
     L.vox_ctx_set_exact_rows.argtypes = [c_void_p, ctypes.c_int]

@@ -27,7 +27,7 @@ struct vox_ctx {
     int n_cu;
     int64_t lds_bytes, hbm_bytes;
     void* samp_ws;   // sampler scratch: SAMP_WS_ROWS x (65536 u32 histogram, all-zero between launches) + keys
-    int exact_rows = 8;   // linears with at most this many rows use the fixed-order kernels (vox_ctx_set_exact_rows)
+    int exact_rows = 2;   // linears with at most this many rows use the wave64 VALU kernels, more rows the matrix cores (vox_ctx_set_exact_rows)
 };
 // sampler scratch geometry (sampler.hip): one LM stream per context uses it at a time
 #define SAMP_WS_ROWS 64
@@ -67,7 +67,7 @@ struct LinearCall {
     int y_rowmajor = 1;                                  // 0: skip the row-major y (only y_frag is consumed)
     int pro = 0, epi = 0;  // PRO_* / EPI_*
     int fixed_order = 0;   // 1: keep the fixed-order VALU kernel even above exact_rows rows (depth step 1 of a small-batch frame)
-    int exact_rows = 8;    // rows up to which the fixed-order kernels are used (the context's setting; vox_launch_linear fills it)
+    int exact_rows = 2;    // rows up to which the wave64 VALU kernels are used (the context's setting; vox_launch_linear fills it)
 };
 enum { VOX_PRO_COPY = 0, VOX_PRO_RMSNORM = 1, VOX_PRO_ATTN = 2 };
 enum { VOX_EPI_STORE = 0, VOX_EPI_SILU = 1, VOX_EPI_SILU_MUL = 2 };
@@ -109,6 +109,8 @@ struct AttnCall {
 };
 int vox_launch_attn_partial(hipStream_t st, const AttnCall& c);
 bool vox_attn_short_supported(const AttnCall& c);
+bool vox_attn_row_supported(const AttnCall& c);
+int vox_launch_attn_row(hipStream_t st, const AttnCall& c);
 int vox_launch_attn_short(hipStream_t st, const AttnCall& c);
 bool vox_attn1_linear_supported(const AttnCall& c, const struct LinearCall& l);
 int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const struct LinearCall& l);

@@ -118,6 +118,25 @@ def _csm(model_name, device="cuda:0", weights=None, checkpoint_dir=None, codec_c
     return CSMModel(model_name, weights, config=config, device=device, **kw)
 
 
+@register_model("orpheus", "canopylabs/orpheus-3b-0.1-ft")
+def _orpheus(model_name, device="cuda:0", weights=None, codec_weights=None, checkpoint_dir=None, codec_checkpoint_dir=None,
+             synthetic=False, **kw):
+    from .orpheus import OrpheusConfig, OrpheusModel
+    config = kw.pop("config", None) or OrpheusConfig()
+    kw.pop("detokenize_interval", None)
+    if weights is None:
+        if checkpoint_dir is not None:
+            weights = _load_safetensors_dir(checkpoint_dir, device)
+            if codec_weights is None:                                      # hubertsiuzdak/snac_24khz checkpoint directory
+                codec_weights = _load_safetensors_dir(codec_checkpoint_dir or checkpoint_dir, "cpu")
+        elif synthetic:
+            from ..synth import synth_orpheus_weights, synth_snac_weights
+            weights, codec_weights = synth_orpheus_weights(config, device), synth_snac_weights()
+        else:
+            raise FileNotFoundError("no checkpoint_dir given (offline box): pass checkpoint_dir=... or synthetic=True")
+    return OrpheusModel(model_name, weights, codec_weights, config=config, device=device, **kw)
+
+
 def load_model(model_name: str, device: str = "cuda", top_p=None, top_k=None, min_p=None, temperature=None,
                max_tokens=None, repetition_penalty=None, repetition_window=None, cfg_scale=None, greedy=False,
                enable_torch_compile=False, audio_decoder_device=None, detokenize_interval=None, **kw):
@@ -130,7 +149,7 @@ def load_model(model_name: str, device: str = "cuda", top_p=None, top_k=None, mi
 
     def merged(cur):      # per-field override (model/__init__.py:132-156)
         return SamplingConfig(greedy=greedy, **{k: (v if v is not None else getattr(cur, k)) for k, v in overrides.items()})
-    if has_overrides and loader in (_glm, _cosyvoice2):
+    if has_overrides and loader in (_glm, _cosyvoice2, _orpheus):
         # these plugins size the engine's persisted repetition cache from the sampling config: hand them the merged config
         # BEFORE the engine exists (the reference swaps the config after construction; its cache is per-request)
         kw["sampling_overrides"] = merged

@@ -197,3 +197,71 @@ def synth_mimi_weights(cfg=None, seed=0):
             t = t * 0.01
         W[k] = t.to(torch.bfloat16).to(torch.float32)
     return W
+
+
+def synth_orpheus_weights(c, device, seed=0, std=0.02):
+    """Random-init Orpheus / Llama-3.2 state_dict (reference names, orpheus.py:36-200; tied lm_head omitted); c: OrpheusConfig."""
+    w, ones = _gen(device, seed, std)
+    H, d = c.hidden_size, c.head_dim
+    W = {"model.embed_tokens.weight": w(c.vocab_size, H), "model.norm.weight": ones(H)}
+    for i in range(c.num_hidden_layers):
+        p = f"model.layers.{i}."
+        for n, rows in (("q", c.num_attention_heads), ("k", c.num_key_value_heads), ("v", c.num_key_value_heads)):
+            W[p + f"self_attn.{n}_proj.weight"] = w(rows * d, H)
+        W[p + "self_attn.o_proj.weight"] = w(H, c.num_attention_heads * d)
+        W[p + "mlp.gate_proj.weight"] = w(c.intermediate_size, H)
+        W[p + "mlp.up_proj.weight"] = w(c.intermediate_size, H)
+        W[p + "mlp.down_proj.weight"] = w(H, c.intermediate_size)
+        W[p + "input_layernorm.weight"] = ones(H)
+        W[p + "post_attention_layernorm.weight"] = ones(H)
+    return W
+
+
+def synth_snac_weights(cfg=None, seed=0):
+    """Random-init SNAC decoder-side state_dict (reference names with weight-norm parametrizations; CPU fp32 tensors), gains
+    chosen so that the waveform stays O(0.1) through the 12 residual units."""
+    import math
+    from .tokenizer.snac import SNACConfig
+    c = cfg or SNACConfig()
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+
+    def wn(name, shape, gain=1.0):
+        W[name + ".parametrizations.weight.original0"] = gain * (0.7 + 0.6 * torch.rand(shape[0], 1, 1, generator=g))
+        W[name + ".parametrizations.weight.original1"] = torch.randn(shape, generator=g)
+
+    for i in range(len(c.vq_strides)):
+        q = f"quantizer.quantizers.{i}."
+        W[q + "codebook.weight"] = torch.randn(c.codebook_size, c.codebook_dim, generator=g)
+        wn(q + "out_proj", (c.latent_dim, c.codebook_dim, 1))
+        W[q + "out_proj.bias"] = 0.02 * torch.randn(c.latent_dim, generator=g)
+    d = "decoder.model."
+    wn(d + "0", (c.latent_dim, 1, 7))
+    W[d + "0.bias"] = 0.02 * torch.randn(c.latent_dim, generator=g)
+    wn(d + "1", (c.decoder_dim, c.latent_dim, 1))
+    W[d + "1.bias"] = 0.02 * torch.randn(c.decoder_dim, generator=g)
+    ch = c.decoder_dim
+    for bi, r in enumerate(c.decoder_rates):
+        b = f"{d}{2 + bi}.block."
+        cin, cout = ch, ch // 2
+        W[b + "0.alpha"] = 0.5 + torch.rand(1, cin, 1, generator=g)
+        wn(b + "1", (cin, cout, 2 * r))
+        W[b + "1.bias"] = 0.02 * torch.randn(cout, generator=g)
+        j = 2
+        if c.noise:
+            wn(b + "2.linear", (cout, cout, 1), 0.3)
+            j = 3
+        for u in range(3):
+            ru = f"{b}{j + u}.block."
+            W[ru + "0.alpha"] = 0.5 + torch.rand(1, cout, 1, generator=g)
+            wn(ru + "1", (cout, 1, 7))
+            W[ru + "1.bias"] = 0.02 * torch.randn(cout, generator=g)
+            W[ru + "2.alpha"] = 0.5 + torch.rand(1, cout, 1, generator=g)
+            wn(ru + "3", (cout, cout, 1), 0.35)
+            W[ru + "3.bias"] = 0.02 * torch.randn(cout, generator=g)
+        ch = cout
+    n = 2 + len(c.decoder_rates)
+    W[f"{d}{n}.alpha"] = 0.5 + torch.rand(1, ch, 1, generator=g)
+    wn(f"{d}{n + 1}", (1, ch, 7), 0.12)
+    W[f"{d}{n + 1}.bias"] = 0.02 * torch.randn(1, generator=g)
+    return W

@@ -39,7 +39,7 @@ class ModelWorker:
                  dp_size: int = 1, detokenize_interval: int = None, model=None, device: str = "cuda:0", seed: int = 0,
                  exact_rows: Optional[int] = None):
         if exact_rows is not None:
-            # opt-in fast mode (include/voxhip.h: vox_ctx_set_exact_rows): must precede the engines' creation
+            # rows up to which the wave64 VALU kernels are used (include/voxhip.h: vox_ctx_set_exact_rows): must precede the engines' creation
             from .. import _native as _N
             _N.set_exact_rows(exact_rows)
         if model is None:
