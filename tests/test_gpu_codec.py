@@ -27,10 +27,10 @@ def small_cfg():
                        sliding_window=12, upsample_rates=[4, 2, 2, 2], upsampling_ratios=[2, 2])
 
 
-def engine(cfg, W, dev, max_batch, interval):
+def engine(cfg, W, dev, max_batch, interval, **kw):
     from vox_serve_amd.tokenizer.qwen3_codec import Qwen3CodecConfig, Qwen3TTSDecoder
     pc = Qwen3CodecConfig(**{k: getattr(cfg, k) for k in Qwen3CodecConfig.__dataclass_fields__})
-    return Qwen3TTSDecoder(W, pc, device=dev, max_batch=max_batch, max_slots=8, detokenize_interval=interval)
+    return Qwen3TTSDecoder(W, pc, device=dev, max_batch=max_batch, max_slots=8, detokenize_interval=interval, **kw)
 
 
 def oracle_exact(cfg, W, codes, chunk):
@@ -229,3 +229,24 @@ def test_mimi_streaming_full_size(dev):
     got, ref = _mimi_stream_case(dev, MR.MimiCfg(), 1, 2, [10, 10, 10])
     assert got.shape == (2, 1, 57600)
     assert np.sqrt(np.mean((got - ref) ** 2)) < 1e-4
+
+
+
+def test_full_size_codec_bf16_operand_mode(dev, golden):
+    """operand_precision="bf16": activations rounded to bf16 when they enter the matrix cores (one MFMA per product instead of
+    three).  The reference serves this decoder in bf16 (every tensor, qwen3_tts.py:1061-1064); its own bf16 output sits
+    `spread` = rms(ref_fp32 - ref_bf16) ~ 1.1e-2 from its fp32 output.  The bf16-operand mode must land INSIDE that spread on
+    both sides: closer to the fp32 module than the reference's bf16 run is, and no further from the reference's bf16 run than
+    the fp32 module is."""
+    g = golden("g4_qwen3_codec")
+    cfg = CR.CodecCfg()
+    W = CR.random_codec_weights(cfg, seed=0)
+    codes = torch.from_numpy(g["full_codes"].astype(np.int64))
+    dec = engine(cfg, W, dev, 2, 10, operand_precision="bf16")
+    cache = dec.init_cache(2)
+    got = torch.cat([dec.decode_chunk(codes[:, :, t:t + 10], cache)[0].cpu().clone() for t in range(0, 30, 10)], -1).numpy()
+    ref32, ref16 = g["full_fp32_c10"].astype(np.float32), g["full_bf16_c10"].astype(np.float32)
+    e32, e16, spread = rms(got - ref32), rms(got - ref16), rms(ref32 - ref16)
+    print(f"bf16-operand mode: rms vs fp32 module {e32:.3e}, vs the reference's bf16 run {e16:.3e}, reference fp32<->bf16 spread {spread:.3e}")
+    assert e32 < spread and e16 < 1.5 * spread, (e32, e16, spread)
+    dec.close()

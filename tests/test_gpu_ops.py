@@ -337,7 +337,7 @@ def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072), 
                   p + "self_attn.q_norm.weight": g(D), p + "self_attn.k_norm.weight": g(D),
                   p + "mlp.gate_proj.weight": w(F, H), p + "mlp.up_proj.weight": w(F, H), p + "mlp.down_proj.weight": w(H, F),
                   p + "input_layernorm.weight": g(H), p + "post_attention_layernorm.weight": g(H)})
-    ref = QR.RefStack(oc, W, "m", 64, policy)
+    ref = QR.RefStack(oc, W, "m", 512, policy)
     page, ppr = 8, (64 if n_rows in (3, 12) else 6)        # pages of 8 slots per request (long-context checks: 64)
     ec = StackCfg(H, NL, heads, kvh, D, F, 1e-6, 1e6, 1.0, None, False, None, True, False)
     arr, keep = (N.LayerWeights * NL)(), []
@@ -351,7 +351,7 @@ def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072), 
             t = T(v, dev)
             keep.append(t)
             setattr(arr[l], k, t.data_ptr())
-    fn, rope = T(W["m.norm.weight"], dev), rope_table(64, ec, dev)
+    fn, rope = T(W["m.norm.weight"], dev), rope_table(512, ec, dev)
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
     A = lambda v: np.array(v, np.int32)
     P = n_rows * ppr
@@ -360,7 +360,7 @@ def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072), 
         """every row = the newest token of its own request, which already holds kv_tokens tokens of random K/V"""
         sc = _stack_config(ec, page, 144, max_kvlen)
         h = ctypes.c_void_p()
-        N.check(L.vox_stack_create(ctx, ctypes.byref(sc), arr, fn.data_ptr(), rope.data_ptr(), 64, ctypes.byref(h)))
+        N.check(L.vox_stack_create(ctx, ctypes.byref(sc), arr, fn.data_ptr(), rope.data_ptr(), 512, ctypes.byref(h)))
         kv_ref = [np.zeros((P, 2, page, kvh, D), np.uint16) for _ in range(NL)]
         for l in range(NL):
             for r in range(n_rows):
@@ -388,10 +388,9 @@ def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072), 
     check(64, 0, False)      # prefill-style rows: head_prepare + single-chunk attention
     check(64, 40, True)      # decode rows, 41-token context: fused chunked attention + merge
     check(16, 2, True)       # decode rows on a short-context stack: one-wave attention (heads == 2 * kv heads)
-    if ppr == 64:            # 131 / 450-token contexts (5 / 15 chunks, ragged last chunk, many pages): the one-launch row attention
+    if ppr == 64:            # 131 / 450-token contexts (5 / 15 chunks of 32 tokens, ragged last chunk, 57 pages per request)
         check(256, 130, True)
         check(512, 449, True)
-        check(1024, 449, True)   # same context under a 1024 bucket: the chunked partial + merge pair
 
 
 @pytest.mark.parametrize("n_rows", [3, 4, 8])

@@ -1,0 +1,21 @@
+# Round-2 profile refresh (run on the GPU box through gpurun; outputs under gpurun_out/p2, copied into profiles/ by hand).
+# Counters are collected in their own rocprofv3 passes (--pmc with --kernel-trace only), one counter per pass.
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/p2; mkdir -p $O
+Q="--no-cpu-baseline --ttfa-requests 0 --serving-ttfa-requests 0"
+for b in 1 8 32; do
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b$b -o b$b -- python bench.py --batch $b --steps 40 --warmup 10 $Q > $O/bench_b${b}_prof.json 2> $O/bench_b${b}_prof.err
+  cp $(find $O/prof_b$b -name "*kernel_stats.csv" | head -1) $O/kernel_stats_b$b.csv
+  python tools/trace_summary.py $(find $O/prof_b$b -name "*kernel_trace.csv" | head -1) 60000 > $O/trace_summary_b$b.txt 2>&1
+  rm -rf $O/prof_b$b
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${b}_$c -o p -- python bench.py --batch $b --steps 30 --warmup 5 $Q > $O/pmc_${b}_$c.log 2>&1
+    python tools/pmc_summary.py $(find $O/pmc_${b}_$c -name "*counter_collection.csv" | head -1) $c > $O/pmc_${b}_$c.json 2>&1
+    rm -rf $O/pmc_${b}_$c
+  done
+done
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python bench.py --batch 32 --steps 20 --warmup 5 $Q > $O/pmc_mfma.log 2>&1
+python tools/mfma_summary.py $(find $O/pmc_mfma -name "*counter_collection.csv") $(find $O/pmc_mfma -name "*kernel_trace.csv") > $O/mfma_b32.json 2>&1
+rm -rf $O/pmc_mfma
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+tail -c 600 $O/bench_default.json

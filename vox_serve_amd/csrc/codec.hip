@@ -58,6 +58,8 @@ struct ConvGemmArgs {
     const float* res;      // [M, N] residual or NULL
     const float* scale;    // [N] multiplier applied before the residual add, or NULL
     const float* rscale;   // [M] per-row multiplier applied before the residual add, or NULL (SNAC NoiseBlock: x + noise[t] * Wx)
+    int planes;            // 3: exact products (fp32 activation = three bf16 terms); 1: activations rounded to bf16 (the reference's
+                           // own serving precision: its decoder runs in bf16, qwen3_tts.py:1061-1064) at a third of the MFMA issue
     float* out;            // [M, N]
     int M, N, Cin, L, P, n_taps, bias_mod, gelu;
     int off[CG_MAXTAPS];   // row look-back of each tap
@@ -165,8 +167,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
             uint4 bfr[WN];
 #pragma unroll
             for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(&Bs[(wn + j * 16 + fr) * LD + kb + fk]);
-#pragma unroll
-            for (int t = 2; t >= 0; --t) {      // smallest term first
+            for (int t = a.planes - 1; t >= 0; --t) {      // smallest term first
 #pragma unroll
                 for (int i = 0; i < WM; ++i) {
                     const uint4 afr = *reinterpret_cast<const uint4*>(&As[t][(wm + i * 16 + fr) * LD + kb + fk]);
@@ -275,8 +276,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
 #pragma unroll
         for (int kb = 0; kb < BK; kb += 32) {
             const uint4 bfr = *reinterpret_cast<const uint4*>(&Bs[(wave * 16 + fr) * LD + kb + fk]);
-#pragma unroll
-            for (int t = 2; t >= 0; --t) {
+            for (int t = a.planes - 1; t >= 0; --t) {
                 const uint4 afr = *reinterpret_cast<const uint4*>(&As[t][fr * LD + kb + fk]);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(afr), as_cbf8(bfr), acc, 0, 0, 0);
             }
@@ -533,6 +533,7 @@ struct vox_codec {
     vox_codec_config cfg;
     vox_codec_weights w;
     int max_batch, max_slots, T;
+    int planes = 3;     // operand planes of the conv GEMMs (vox_codec_set_operand_planes)
     // state (per slot)
     float *st_pre, *st_dw[2], *st_dec0, *st_tc[4], *st_ru[4][3], *st_final;
     bf16_t* ring;   // [layers][slots][Wn][2][HD]
@@ -543,6 +544,8 @@ struct vox_codec {
     float *q0, *qr;
 };
 
+// operand planes of the conv GEMMs launched by the current decode call (set by the entry points from their object's setting)
+static thread_local int g_conv_planes = 3;
 static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const float* state, const int* slots, int n,
                      int L, int P, const int* offs, float* out, const float* res, const float* scale, int gelu,
                      float* out2 = nullptr, const vox_snake_w* sn = nullptr, int sn_mod = 0, const float* rscale = nullptr) {
@@ -551,6 +554,7 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     ConvGemmArgs a{};
     a.x = x; a.state = state; a.slots = slots; a.w = (const bf16_t*)w.w; a.bias = w.bias; a.res = res; a.scale = scale;
     a.out = out; a.M = n * L; a.N = w.n; a.Cin = w.cin; a.L = L; a.P = P; a.n_taps = w.n_taps; a.rscale = rscale;
+    a.planes = g_conv_planes;
     a.bias_mod = w.bias_mod > 0 ? w.bias_mod : w.n; a.gelu = gelu;
     if (out2 && sn) { a.out2 = out2; a.sn_alpha = sn->alpha; a.sn_invb = sn->inv_beta; a.sn_mod = sn_mod > 0 ? sn_mod : w.n; }
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
@@ -634,6 +638,11 @@ int vox_codec_create(vox_ctx* ctx, const vox_codec_config* cfg, const vox_codec_
     return VOX_OK;
 }
 
+int vox_codec_set_operand_planes(vox_codec* m, int planes) {
+    if (!m || (planes != 1 && planes != 3)) return vox_fail(VOX_ERR_INVALID, "codec_set_operand_planes: 1 or 3");
+    m->planes = planes;
+    return VOX_OK;
+}
 void vox_codec_destroy(vox_codec* m) {
     if (!m) return;
     (void)hipFree(m->st_pre); (void)hipFree(m->st_dec0); (void)hipFree(m->st_final); (void)hipFree(m->ring);
@@ -683,6 +692,7 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
     if (!m || !codes || !slots || !out) return vox_fail(VOX_ERR_INVALID, "codec_decode_chunk: NULL");
     if (n < 1 || n > m->max_batch || T < 1 || T > m->T) return vox_fail(VOX_ERR_INVALID, "codec_decode_chunk: n=%d T=%d out of range", n, T);
     hipStream_t st = (hipStream_t)stream;
+    struct PlanesGuard { int saved; explicit PlanesGuard(int p) : saved(g_conv_planes) { g_conv_planes = p; } ~PlanesGuard() { g_conv_planes = saved; } } pg(m->planes);
     const vox_codec_config& c = m->cfg;
     const vox_codec_weights& w = m->w;
     const int HD = c.num_heads * c.head_dim, H = c.hidden, LD = c.latent_dim;

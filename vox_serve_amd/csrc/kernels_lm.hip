@@ -1737,8 +1737,10 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l = 0.0f;
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
-        const int srcl = (t & 3) * 16 + j;
-        const float p0 = __shfl(pp[0][t >> 2], srcl, VOX_WAVE), p1 = __shfl(pp[1][t >> 2], srcl, VOX_WAVE);
+        // p of token t lives (identically) in the 16 lanes of group t & 3, register t >> 2: a wave-uniform value, fetched with
+        // v_readlane (scalar broadcast) instead of a ds_bpermute round trip per token and head
+        const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pp[0][t >> 2]), (t & 3) * 16));
+        const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pp[1][t >> 2]), (t & 3) * 16));
         if (t < nt) {
             const float pt = g ? p1 : p0;
             const uint4 vx = (t == nt - 1) ? vnc : vr[t];
@@ -1758,191 +1760,13 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
     }
 }
 
-// ================================================================================================
-// Decode attention for contexts of up to a few hundred tokens as ONE launch (talker, B = 1..32): one block per (row, kv head),
-// wave w owns the 32-token chunks w, w + 8, ...; each chunk is processed by a single wave in registers exactly like
-// attn_short_wave (lane = 16*grp + j: q head 0 / q head 1 / new k / new v chunks for the prologue, K token-major, V
-// chunk-major), the per-chunk (m, l, o) meet in LDS and are merged in chunk order.  Same arithmetic, bit for bit, as
-// k_attn_partial<128, true> + k_attn_merge (the oracle's chunked attention), in one kernel instead of two: the partial
-// kernel's 56 blocks x 3 barriers and the merge launch were 12 us per talker layer at B = 1, 17 us at B = 32.
-// ================================================================================================
-#define VOX_AROW_MAXC 16      // chunks per (row, head): contexts up to 512 tokens
-__global__ __launch_bounds__(512) void k_attn_row(AttnArgs at) {
-    constexpr int D = 128, TC = VOX_TC;
-    __shared__ float sm_ml[VOX_AROW_MAXC][2][2];
-    __shared__ float sm_o[VOX_AROW_MAXC][2][D];
-    const int hk = blockIdx.x, row = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = lane >> 4, j = lane & 15;
-    const int L = at.fixed_kvlen > 0 ? at.fixed_kvlen : at.q_kvlen[row];
-    const int nc = (L + TC - 1) / TC;
-    const int nqkv = (at.Hq + 2 * at.Hkv) * D;
-    const size_t ps = (size_t)2 * at.page_size * at.Hkv * D;
-    const int* pages = at.identity_pages ? nullptr
-                       : (at.ptab ? at.ptab + (size_t)row * at.pt_stride : at.indices + at.indptr[at.q_req[row]]);
-    if (wave < nc) {
-        // ---- prologue (every chunk wave): per-head norm + RoPE of q0 / q1 / new k, raw new v ----
-        const bf16_t* raw = at.qkv + (size_t)row * nqkv;
-        const bf16_t* src = grp == 0 ? raw + (size_t)(hk * 2) * D
-                          : grp == 1 ? raw + (size_t)(hk * 2 + 1) * D
-                          : grp == 2 ? raw + (size_t)at.Hq * D + (size_t)hk * D
-                                     : raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D;
-        const uint4 v = reinterpret_cast<const uint4*>(src)[j];
-        const bf16_t* nwp = grp < 2 ? at.qn : (grp == 2 ? at.kn : nullptr);
-        uint4 gw4 = make_uint4(0, 0, 0, 0);
-        if (nwp) gw4 = reinterpret_cast<const uint4*>(nwp)[j];
-        int p = at.fixed_pos >= 0 ? at.fixed_pos : at.pos[row];
-        p = p < 0 ? 0 : (p >= at.table_max_pos ? at.table_max_pos - 1 : p);
-        float4 cs4[4];
-        {
-            const float4* cp = reinterpret_cast<const float4*>(at.cs + (size_t)p * D) + (j & 7) * 4;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cs4[k] = cp[k];
-        }
-        float e[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
-        {
-            float s = sq8(v, 0.0f);
-            s = butterfly<16>(s);
-            const float rinv = 1.0f / sqrtf(s / (float)D + at.eps);
-            if (nwp) {
-                const float gw[8] = {bflo(gw4.x), bfhi(gw4.x), bflo(gw4.y), bfhi(gw4.y), bflo(gw4.z), bfhi(gw4.z), bflo(gw4.w), bfhi(gw4.w)};
-#pragma unroll
-                for (int i = 0; i < 8; ++i) e[i] = bfround((e[i] * rinv) * gw[i]);
-            }
-        }
-        uint4 hq;
-        {
-            const float cc[8] = {cs4[0].x, cs4[0].z, cs4[1].x, cs4[1].z, cs4[2].x, cs4[2].z, cs4[3].x, cs4[3].z};
-            const float sn[8] = {cs4[0].y, cs4[0].w, cs4[1].y, cs4[1].w, cs4[2].y, cs4[2].w, cs4[3].y, cs4[3].w};
-            float r[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float o = __shfl_xor(e[i], 8, VOX_WAVE);
-                const float mc = e[i] * cc[i];
-                r[i] = (j < 8) ? __fmaf_rn(-o, sn[i], mc) : __fmaf_rn(o, sn[i], mc);
-            }
-            hq.x = pack_bf2(r[0], r[1]); hq.y = pack_bf2(r[2], r[3]); hq.z = pack_bf2(r[4], r[5]); hq.w = pack_bf2(r[6], r[7]);
-            if (grp == 3) hq = v;
-        }
-        const uint4 q0c = shfl4(hq, j), q1c = shfl4(hq, 16 + j), knc = shfl4(hq, 32 + j), vnc = shfl4(hq, 48 + j);
-        for (int c = wave; c < nc; c += 8) {
-            const int t0 = c * TC;
-            const int nt = (L - t0) < TC ? (L - t0) : TC;
-            const bool own_last = t0 + nt == L;          // this chunk holds the row's newest token (index L - 1)
-            if (own_last) {                              // append it to the paged cache (page < 0: graph padding row)
-                const int pg = at.identity_pages ? row : at.page[row];
-                const int sl = at.identity_pages ? (L - 1) : at.slot[row];
-                if (pg >= 0 && grp >= 2) {
-                    bf16_t* base = at.kv_w + (size_t)pg * ps + ((size_t)sl * at.Hkv + hk) * D;
-                    if (grp == 3) base += (size_t)at.page_size * at.Hkv * D;
-                    reinterpret_cast<uint4*>(base)[j] = hq;
-                }
-            }
-            // K token-major (token 4u + grp in pass u), V chunk-major (every lane: chunk j of every token)
-            uint4 kr[8], vr[TC];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = u * 4 + grp, tok = t0 + t;
-                kr[u] = make_uint4(0, 0, 0, 0);
-                if (t < nt && !(own_last && t == nt - 1)) {
-                    const int pgi = pages ? pages[tok / at.page_size] : row;
-                    kr[u] = reinterpret_cast<const uint4*>(at.kv + (size_t)pgi * ps + ((size_t)(tok % at.page_size) * at.Hkv + hk) * D)[j];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < TC; ++t) {
-                const int tok = t0 + t;
-                vr[t] = make_uint4(0, 0, 0, 0);
-                if (t < nt && !(own_last && t == nt - 1)) {
-                    const int pgi = pages ? pages[tok / at.page_size] : row;
-                    vr[t] = reinterpret_cast<const uint4*>(at.kv + (size_t)pgi * ps + (size_t)at.page_size * at.Hkv * D +
-                                                           ((size_t)(tok % at.page_size) * at.Hkv + hk) * D)[j];
-                }
-            }
-            float sc[2][8], m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = u * 4 + grp;
-                const uint4 kx = (own_last && t == nt - 1) ? knc : kr[u];
-                const float d0 = butterfly<16>(dot8(q0c, kx, 0.0f)) * at.scale;
-                const float d1 = butterfly<16>(dot8(q1c, kx, 0.0f)) * at.scale;
-                sc[0][u] = t < nt ? d0 : -INFINITY;
-                sc[1][u] = t < nt ? d1 : -INFINITY;
-                m0 = fmaxf(m0, sc[0][u]);
-                m1 = fmaxf(m1, sc[1][u]);
-            }
-            m0 = fmaxf(m0, __shfl_xor(m0, 16, VOX_WAVE)); m0 = fmaxf(m0, __shfl_xor(m0, 32, VOX_WAVE));
-            m1 = fmaxf(m1, __shfl_xor(m1, 16, VOX_WAVE)); m1 = fmaxf(m1, __shfl_xor(m1, 32, VOX_WAVE));
-            float pp[2][8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = u * 4 + grp;
-                pp[0][u] = t < nt ? exp2_c((sc[0][u] - m0) * VOX_LOG2E) : 0.0f;
-                pp[1][u] = t < nt ? exp2_c((sc[1][u] - m1) * VOX_LOG2E) : 0.0f;
-            }
-            const int g = grp & 1;
-            float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l = 0.0f;
-#pragma unroll
-            for (int t = 0; t < TC; ++t) {
-                const int srcl = (t & 3) * 16 + j;
-                const float p0 = __shfl(pp[0][t >> 2], srcl, VOX_WAVE), p1 = __shfl(pp[1][t >> 2], srcl, VOX_WAVE);
-                if (t < nt) {
-                    const float pt = g ? p1 : p0;
-                    const uint4 vx = (own_last && t == nt - 1) ? vnc : vr[t];
-                    l = l + pt;
-                    o[0] = __fmaf_rn(pt, bflo(vx.x), o[0]); o[1] = __fmaf_rn(pt, bfhi(vx.x), o[1]);
-                    o[2] = __fmaf_rn(pt, bflo(vx.y), o[2]); o[3] = __fmaf_rn(pt, bfhi(vx.y), o[3]);
-                    o[4] = __fmaf_rn(pt, bflo(vx.z), o[4]); o[5] = __fmaf_rn(pt, bfhi(vx.z), o[5]);
-                    o[6] = __fmaf_rn(pt, bflo(vx.w), o[6]); o[7] = __fmaf_rn(pt, bfhi(vx.w), o[7]);
-                }
-            }
-            if (grp < 2) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sm_o[c][g][j * 8 + i] = o[i];
-                if (j == 0) { sm_ml[c][g][0] = g ? m1 : m0; sm_ml[c][g][1] = l; }
-            }
-        }
-    }
-    __syncthreads();
-    // merge in chunk order against the global max (k_attn_merge), one thread per (q head, dim)
-    const int tid = threadIdx.x;
-    if (tid < 2 * D) {
-        const int g = tid / D, d = tid % D;
-        float M = -INFINITY;
-        for (int c = 0; c < nc; ++c) M = fmaxf(M, sm_ml[c][g][0]);
-        float Ls = 0.0f, O = 0.0f;
-        for (int c = 0; c < nc; ++c) {
-            const float w = exp2_c((sm_ml[c][g][0] - M) * VOX_LOG2E);
-            Ls = __fmaf_rn(sm_ml[c][g][1], w, Ls);
-            O = __fmaf_rn(sm_o[c][g][d], w, O);
-        }
-        const bf16_t r = f2bf(O / Ls);
-        const int col = (hk * 2 + g) * D + d;
-        at.out[(size_t)row * at.Hq * D + col] = r;
-        if (at.out_frag) at.out_frag[frag_off(row, col, at.Hq * D)] = r;
-    }
-}
-bool vox_attn_row_supported(const AttnCall& c) {
-    return c.qkv && c.out && c.D == 128 && c.Hkv > 0 && c.Hq == 2 * c.Hkv && c.rot == 128 && !c.interleave && c.cs &&
-           c.max_kvlen > 16 && c.max_kvlen <= VOX_TC * VOX_AROW_MAXC;
-}
-static void fill_attn_args(AttnArgs& a, const AttnCall& c);
-int vox_launch_attn_row(hipStream_t st, const AttnCall& c) {
-    if (!vox_attn_row_supported(c)) return vox_fail(VOX_ERR_INVALID, "attn_row: unsupported shape");
-    AttnArgs at{};
-    fill_attn_args(at, c);
-    at.out = (bf16_t*)c.out;
-    at.out_frag = (bf16_t*)c.out_frag;
-    hipLaunchKernelGGL(k_attn_row, dim3(c.Hkv, c.Nq), dim3(512), 0, st, at);
-    return VOX_OK;
-}
-
-// standalone: one wave per (row, kv head), four pairs per block
+// standalone: one wave per (row, kv head), four pairs per block (NT as in attn_short_wave)
+template <int NT>
 __global__ __launch_bounds__(256) void k_attn_short(AttnArgs at, int n_pairs) {
     const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pi >= n_pairs) return;
     const int row = pi / at.Hkv, hk = pi % at.Hkv;
-    attn_short_wave<0>(at, row, hk, threadIdx.x & 63, at.out + (size_t)row * at.Hq * 128, true);
+    attn_short_wave<NT>(at, row, hk, threadIdx.x & 63, at.out + (size_t)row * at.Hq * 128, true);
 }
 
 // Fused into the o_proj GEMV: every o_proj block recomputes the row's attention (8 waves: one (row, kv head) pair
@@ -2024,7 +1848,14 @@ int vox_launch_attn_short(hipStream_t st, const AttnCall& c) {
     at.out = (bf16_t*)c.out;
     at.out_frag = (bf16_t*)c.out_frag;
     const int n_pairs = c.Nq * c.Hkv;
-    hipLaunchKernelGGL(k_attn_short, dim3((n_pairs + 3) / 4), dim3(256), 0, st, at, n_pairs);
+    switch (at.fixed_kvlen) {      // depth loop: the visible length is part of the captured graph
+#define VOX_AS(NT_) case NT_: hipLaunchKernelGGL(k_attn_short<NT_>, dim3((n_pairs + 3) / 4), dim3(256), 0, st, at, n_pairs); return VOX_OK;
+        VOX_AS(2) VOX_AS(3) VOX_AS(4) VOX_AS(5) VOX_AS(6) VOX_AS(7) VOX_AS(8) VOX_AS(9) VOX_AS(10) VOX_AS(11) VOX_AS(12)
+        VOX_AS(13) VOX_AS(14) VOX_AS(15) VOX_AS(16)
+#undef VOX_AS
+        default: break;
+    }
+    hipLaunchKernelGGL(k_attn_short<0>, dim3((n_pairs + 3) / 4), dim3(256), 0, st, at, n_pairs);
     return VOX_OK;
 }
 // true when the fused short-attention + o_proj kernel covers this call (else the caller launches the two kernels)

@@ -109,8 +109,6 @@ struct AttnCall {
 };
 int vox_launch_attn_partial(hipStream_t st, const AttnCall& c);
 bool vox_attn_short_supported(const AttnCall& c);
-bool vox_attn_row_supported(const AttnCall& c);
-int vox_launch_attn_row(hipStream_t st, const AttnCall& c);
 int vox_launch_attn_short(hipStream_t st, const AttnCall& c);
 bool vox_attn1_linear_supported(const AttnCall& c, const struct LinearCall& l);
 int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const struct LinearCall& l);

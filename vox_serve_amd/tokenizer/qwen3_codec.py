@@ -143,6 +143,7 @@ def _bind(L):
                                                                   ci, ci, ci, ctypes.POINTER(vp)]
     L.vox_codec_destroy.restype, L.vox_codec_destroy.argtypes = None, [vp]
     L.vox_codec_state_bytes.restype, L.vox_codec_state_bytes.argtypes = ctypes.c_int64, [vp]
+    L.vox_codec_set_operand_planes.restype, L.vox_codec_set_operand_planes.argtypes = ctypes.c_int, [vp, ctypes.c_int]
     L.vox_codec_reset_slot.restype, L.vox_codec_reset_slot.argtypes = ci, [vp, vp, ci]
     L.vox_codec_decode_chunk.restype, L.vox_codec_decode_chunk.argtypes = ci, [vp, vp, vp, ci, vp, ci, ci, vp]
     L._codec_bound = True
@@ -159,8 +160,14 @@ class Qwen3TTSDecoder:
     """decode_chunk / init_cache surface of the reference's Qwen3TTSDecoder (qwen3_codec.py:1789-1903)."""
 
     def __init__(self, weights: Dict[str, torch.Tensor], config: Optional[Qwen3CodecConfig] = None, device="cuda",
-                 max_batch=8, max_slots=64, detokenize_interval=10):
+                 max_batch=8, max_slots=64, detokenize_interval=10, operand_precision: str = "fp32"):
+        """operand_precision: "fp32" (default) keeps every GEMM product exact — waveform within 1e-4 RMS of the reference
+        decoder evaluated in fp32; "bf16" rounds the activations to bf16 when they enter the matrix cores, the precision the
+        reference itself serves at (it runs this decoder in bf16), for a third of the MFMA issue."""
         self.cfg = c = config or Qwen3CodecConfig()
+        if operand_precision not in ("fp32", "bf16"):
+            raise ValueError("operand_precision must be 'fp32' or 'bf16'")
+        self.operand_precision = operand_precision
         self.device = torch.device(device)
         self.max_batch, self.max_slots, self.interval = max_batch, max_slots, detokenize_interval
         self.L = N.lib()
@@ -254,6 +261,8 @@ class Qwen3TTSDecoder:
         N.check(self.L.vox_codec_create(N.ctx(), ctypes.byref(cc), ctypes.byref(cw), max_batch, max_slots,
                                         detokenize_interval, ctypes.byref(h)))
         self.h = h
+        if operand_precision == "bf16":
+            N.check(self.L.vox_codec_set_operand_planes(h, 1))
         self._free_slots = list(range(max_slots))
         self.hop = c.total_upsample
         self._out = torch.empty(max_batch, detokenize_interval * self.hop, dtype=torch.float32, device=dev)
