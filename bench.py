@@ -328,6 +328,58 @@ def serving_ttfa(dev, shared, n_requests, load, interval=INTERVAL, seed=0):
     return float(np.median(out))
 
 
+def serving_throughput(dev, shared, n_req, frames, kind="base"):
+    """A batch job through the serving path proper: `n_req` requests submitted at once on the scheduler's transport, each
+    generating `frames` frames (greedy, max_tokens bounds the length), served by Scheduler / DisaggregationScheduler ->
+    ModelWorker -> engine -> codec until every COMPLETION is on the result queue.  value = PCM samples received / wall time
+    (prefills, one per step, included).  The hot loop of bench.py's headline (`Loop`) is the same engine + codec calls
+    without the scheduler / worker bookkeeping; this is the number with it."""
+    from vox_serve_amd.model.qwen3_tts import Qwen3TTSModel
+    from vox_serve_amd.sampling import SamplingConfig
+    from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
+    from vox_serve_amd.scheduler.disaggregation import DisaggregationScheduler
+    from vox_serve_amd.worker import ModelWorker
+    mb = max(8, n_req)
+    m = Qwen3TTSModel("qwen3-tts", shared["W"], shared["codec_W"], device=str(dev), detokenize_interval=INTERVAL,
+                      max_batch_size=mb, page_size=128, max_num_pages=4 * mb + 8, max_seq_len=2304, max_prefill_tokens=128)
+    m.default_sampling_config = SamplingConfig(greedy=True, max_tokens=PROMPT_TOKENS + frames, repetition_penalty=1.05, repetition_window=-1)
+    t = QueueTransport()
+    w = ModelWorker(model=m, max_batch_size=mb, max_num_pages=4 * mb + 8, page_size=128, device=str(dev))
+    s = (DisaggregationScheduler(w, max_batch_size=mb, transport=t) if kind == "disaggregation"
+         else Scheduler(w, max_batch_size=mb, transport=t, async_scheduling=(kind == "async")))
+    rng = np.random.default_rng(3)
+
+    def submit(tag, n):
+        for i in range(n):
+            ids = [1, 2, 3] + rng.integers(0, 151000, 64).tolist() + [4, 5, 6, 7, 8]
+            t.requests.put(encode_request(f"{tag}{i}", "", model_kwargs={"prompt_token_ids": ids, "language": "english"}))
+
+    def run():
+        if kind == "disaggregation":
+            s.run_until_idle(600.0)
+        else:
+            s.run_until_idle(1000000)
+        n = 0
+        while not t.results.empty():
+            msg = t.results.get()
+            rid, k, body = msg.split(b"|", 2)
+            if k == b"AUDIO":
+                n += len(body) // 2
+        return n
+    submit("warm", min(2, n_req))          # graph capture for the shapes of this run
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    submit("r", n_req)
+    samples = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    m.engine.close()
+    m.audio_decoder.close()
+    return {"value": samples / dt, "unit": "audio samples/s", "requests": n_req, "frames_per_request": frames, "seconds": dt,
+            "scheduler": kind, "ms_per_frame_step_equiv": dt / frames * 1e3}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher: start N ranks of this script under torch.distributed.run."""
     import socket
@@ -413,6 +465,8 @@ def main():
         serving["ttfa_ms_p50"] = serving_ttfa(dev, shared, n, 0)
         serving["ttfa_ms_p50_detokenize_interval_2"] = serving_ttfa(dev, shared, max(10, n // 2), 0, interval=2)
         serving["ttfa_ms_p50_under_32way_load"] = serving_ttfa(dev, shared, max(10, n // 5), 31)
+        serving["throughput"] = {k: serving_throughput(dev, shared, 32, 120, k) for k in ("base", "async", "disaggregation")}
+        serving["throughput"]["batch1_base"] = serving_throughput(dev, shared, 1, 120, "base")
 
     if rank == 0:
         out = {
@@ -434,6 +488,8 @@ def main():
         for k in ("ttfa_ms_p50_under_32way_load",):
             if k in serving:
                 out[k] = serving[k]
+        if "throughput" in serving:
+            out["serving_path_throughput"] = serving["throughput"]
         for k in ("ttfa_ms_p50_engine", "ttfa_ms_p50_engine_detokenize_interval_2"):
             if k in head:
                 out[k] = head[k]

@@ -33,12 +33,12 @@ def build(dev, max_tokens=None, max_prefill_tokens=64):
     return m, cfg
 
 
-def serve(m, prompts):
+def serve(m, prompts, async_scheduling=False):
     from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
     from vox_serve_amd.worker import ModelWorker
     t = QueueTransport()
     w = ModelWorker(model=m, max_batch_size=4, max_num_pages=64, page_size=16, device=m.device)
-    s = Scheduler(w, max_batch_size=4, transport=t)
+    s = Scheduler(w, max_batch_size=4, transport=t, async_scheduling=async_scheduling)
     for rid, ids in prompts.items():
         t.requests.put(encode_request(rid, "", model_kwargs={"prompt_token_ids": ids, "speaker": "a"}))
     s.run_until_idle(2000)
@@ -372,3 +372,31 @@ def test_orpheus_served_end_to_end_with_snac_windows():
         assert np.abs(np.frombuffer(pcm, np.int16)).max() > 50
     out2, _, _ = serve()
     assert out == out2
+
+
+def test_async_scheduling_gives_the_same_audio():
+    """Scheduler(async_scheduling=True): the worker's run_lm_* return the request-state update as a coroutine and the next
+    step is launched before the previous one's tokens reach the host (scheduler/base.py:166-221 of the reference).  EOS /
+    max_tokens are seen one step late (a surplus row, dropped): the audio is byte-identical to the synchronous loop's."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    from vox_serve_amd import _native as N
+    # The one-step lag changes which rows share a launch around a request's last frame, and a row's bits depend on the row
+    # count of its launch once calls of 3+ rows run on the matrix cores (default).  With exact_rows 8 every call of this
+    # test (<= 4 rows) uses the row-count-invariant wave64 kernels, so the two schedules must agree byte for byte.
+    N.set_exact_rows(8)
+    try:
+        m, cfg = build(dev, max_tokens=34)
+        prompt = [1, 2, 3, 40, 41, 42, 43, 7, 8, 9, 10, 11]
+        prompts = {"r1": prompt, "r2": prompt[:3] + [50, 51] + prompt[-5:], "r3": prompt[:3] + [60] + prompt[-5:]}
+        sync, w1 = serve(m, prompts)
+        asy, w2 = serve(m, prompts, async_scheduling=True)
+        assert w2.async_scheduling is False and w2._pending is None            # loop left the worker drained and synchronous
+        for rid in prompts:
+            assert asy[rid]["done"] == sync[rid]["done"], rid
+            assert asy[rid]["pcm"] == sync[rid]["pcm"] and len(asy[rid]["pcm"]) > 0, rid
+        assert w2.empty_pages.qsize() == 64
+        m.engine.close(); m.audio_decoder.close()
+    finally:
+        N.set_exact_rows(2)

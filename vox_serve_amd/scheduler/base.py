@@ -65,6 +65,10 @@ class Scheduler:
         self.logger = logging.getLogger(__name__)
         self.available_batch_sizes = model_worker.available_batch_sizes
         self.sample_rate, self.bytes_per_sample, self.channels = 24000, 2, 1
+        # in-process counters (the reference measures these from the client side: benchmark/goodput.py:250-262,
+        # benchmark/throughput.py:312-318): time to first audio per request, audio samples sent, completions
+        self._arrival = {}
+        self.stats = {"started": time.time(), "requests": 0, "completed": 0, "failed": 0, "samples": 0, "ttfa_s": []}
 
     # ---- one iteration of the hot loop ----
     def _step(self):
@@ -113,6 +117,8 @@ class Scheduler:
             self.logger.error(f"request {req.request_id} failed: {ex!r}")
             req.done_lm_prefill = req.done_lm_generation = req.done_all = True
             req.finish_reason = f"error: {type(ex).__name__}"
+            self.stats["failed"] += 1
+            self._arrival.pop(req.request_id, None)
             try:
                 self.model_worker.free_kv_cache(req)
             except Exception:            # never mask the original failure
@@ -121,11 +127,74 @@ class Scheduler:
             self.transport.send_result(req.request_id.encode("utf-8") + b"|COMPLETION|" + json.dumps(msg).encode("utf-8"))
         self.active_requests = [r for r in self.active_requests if not r.done_all]
 
+    # ---- async scheduling: the reference's pipelined loop (scheduler/base.py:166-221) ----
+    async def _step_async(self, task, lm_requests, detokenize_requests):
+        """Launch the step selected LAST iteration, then (while it runs on the GPU) finish the previous step's request-state
+        update and select the next step.  A request's EOS / max_tokens is therefore seen one step late (one surplus row,
+        dropped by the worker), exactly as in the reference."""
+        self._prepare_requests()
+        fresh = [r for r in lm_requests if not r.done_lm_prefill]
+        lm_inputs = None
+        try:
+            lm_inputs = self.model_worker.prepare_lm_inputs(lm_requests, detokenize_requests)
+        except queue.Empty as ex:              # no KV pages: drop the new prompt from this step (it stays queued)
+            if not getattr(self.model_worker, "defers_on_page_exhaustion", False):
+                raise
+            lm_requests = [r for r in lm_requests if r.done_lm_prefill]
+            lm_inputs = self.model_worker.prepare_lm_inputs(lm_requests, detokenize_requests) if lm_requests else None
+        except Exception as ex:
+            self._fail_requests(fresh or lm_requests, ex)
+            lm_requests = []
+        self.model_worker.run_detokenize(detokenize_requests)
+        self._send_responses(detokenize_requests)
+        next_task = None
+        try:
+            if lm_inputs is not None and lm_inputs["is_prefill"]:
+                next_task = self.model_worker.run_lm_prefill(lm_requests, lm_inputs)
+            else:
+                next_task = self.model_worker.run_lm_decode(lm_requests, lm_inputs)
+        except Exception as ex:
+            self._fail_requests(fresh or lm_requests, ex)
+        if task is not None:
+            await task                          # step N-1's tokens -> request objects, while step N runs
+        if next_task is not None and lm_inputs is not None and lm_inputs["is_prefill"]:
+            await next_task                     # a prefill's first frame decides the request's next inputs: not pipelined
+            next_task = None
+        # requests completed by this iteration's detokenize / send must not be selected again (the synchronous loop prunes
+        # them in _prepare_requests before it selects)
+        self.active_requests = [r for r in self.active_requests if not r.done_all]
+        detok = self._select_detokenize_requests()
+        return next_task, self._select_lm_requests(), detok
+
+    async def _run_async_loop(self, until_idle: bool = False, max_steps: int = 1 << 62):
+        import asyncio
+        task, lm_requests, detokenize_requests = None, [], []
+        self.model_worker.async_scheduling = True       # run_lm_* now hand back the request-state update as a coroutine
+        try:
+            for _ in range(max_steps):
+                task, lm_requests, detokenize_requests = await self._step_async(task, lm_requests, detokenize_requests)
+                await asyncio.sleep(0)
+                if until_idle and not self.active_requests and self.transport.requests.empty() and not lm_requests:
+                    break
+            if task is not None:
+                await task
+        finally:
+            if hasattr(self.model_worker, "drain"):
+                self.model_worker.drain()
+            self.model_worker.async_scheduling = False
+
     def run_forever(self):
+        if self.async_scheduling:
+            import asyncio
+            asyncio.run(self._run_async_loop())
         while True:
             self._step()
 
     def run_until_idle(self, max_steps: int = 100000):
+        if self.async_scheduling:
+            import asyncio
+            asyncio.run(self._run_async_loop(until_idle=True, max_steps=max_steps))
+            return
         for _ in range(max_steps):
             self._step()
             if not self.active_requests and self.transport.requests.empty():
@@ -199,10 +268,26 @@ class Scheduler:
                     req.chunk_send_timestamps.append(time.time())
                     req.chunk_durations.append(self._calculate_chunk_duration(chunk))
                 self.transport.send_result(req.request_id.encode("utf-8") + b"|AUDIO|" + chunk)
+                t0 = self._arrival.pop(req.request_id, None)
+                if t0 is not None:
+                    self.stats["ttfa_s"].append(time.time() - t0)
+                self.stats["samples"] += len(chunk) // (self.channels * self.bytes_per_sample)
             if req.done_all:
+                self.stats["completed"] += 1
+                self._arrival.pop(req.request_id, None)
                 self.model_worker.free_kv_cache(req)
                 msg = {"status": "completed", "reason": req.finish_reason or "unknown"}
                 self.transport.send_result(req.request_id.encode("utf-8") + b"|COMPLETION|" + json.dumps(msg).encode("utf-8"))
+
+    def metrics(self) -> dict:
+        """p50 / p95 time to first audio (request received -> first AUDIO message sent), audio samples/s and real-time factor
+        since the scheduler started."""
+        tt = sorted(self.stats["ttfa_s"])
+        dt = max(time.time() - self.stats["started"], 1e-9)
+        pick = lambda q: (tt[min(len(tt) - 1, int(q * len(tt)))] * 1e3 if tt else None)
+        return {"requests": self.stats["requests"], "completed": self.stats["completed"], "failed": self.stats["failed"],
+                "ttfa_ms_p50": pick(0.5), "ttfa_ms_p95": pick(0.95), "audio_samples_per_s": self.stats["samples"] / dt,
+                "realtime_factor": self.stats["samples"] / self.sample_rate / dt}
 
     def _calculate_chunk_duration(self, audio_chunk: bytes) -> float:
         return len(audio_chunk) // (self.channels * self.bytes_per_sample) / self.sample_rate
@@ -227,6 +312,8 @@ class Scheduler:
                 req = self._handle_request_payload(payload)
                 if req:
                     self.active_requests.append(req)
+                    self._arrival[req.request_id] = time.time()
+                    self.stats["requests"] += 1
             except Exception as e:          # malformed request: log and keep serving (scheduler/base.py:444-449)
                 self.logger.error(f"Error receiving requests: {e}")
         self.active_requests = [r for r in self.active_requests if not r.done_all]

@@ -66,6 +66,8 @@ class DisaggregationScheduler(Scheduler):
                 req = self._handle_request_payload(payload)
                 if req:
                     self.active_requests.append(req)
+                    self._arrival[req.request_id] = time.time()
+                    self.stats["requests"] += 1
             except Exception as e:
                 self.logger.error(f"Error receiving requests: {e}")
 
@@ -99,7 +101,12 @@ class DisaggregationScheduler(Scheduler):
                     req.chunk_send_timestamps.append(time.time())
                     req.chunk_durations.append(self._calculate_chunk_duration(chunk))
                 self.transport.send_result(req.request_id.encode("utf-8") + b"|AUDIO|" + chunk)
+                t0 = self._arrival.pop(req.request_id, None)
+                if t0 is not None:
+                    self.stats["ttfa_s"].append(time.time() - t0)
+                self.stats["samples"] += len(chunk) // (self.channels * self.bytes_per_sample)
             if req.done_all:
+                self.stats["completed"] += 1
                 with self.requests_lock:
                     self.model_worker.free_kv_cache(req)
                     if req in self.active_requests:

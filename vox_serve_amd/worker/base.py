@@ -70,6 +70,9 @@ class ModelWorker:
             self.empty_pages.put(i)
         self.needs_watermarking = getattr(model, "needs_watermarking", False)
         self.has_depth_transformer = getattr(model, "has_depth_transformer", False)
+        self.async_scheduling = False   # set by a scheduler running the reference's async loop (scheduler/base.py:166-221)
+        self._pending = None         # the deferred request-state update of the last launched step (async scheduling)
+        self._snap, self._snap_i = None, 0
         self._resident = None        # request ids whose next inputs already sit in the engine's rows (feedback path)
         self._resident_reqs = []     # ... and the requests themselves (their repetition-cache rows live in the engine)
         self._next_feats = None
@@ -108,6 +111,8 @@ class ModelWorker:
         input_ids_list, position_ids_list, feats, masks, reps = [], [], [], [], []
         is_prefill = any(not req.done_lm_prefill for req in lm_requests)
         prefill_flags = [not req.done_lm_prefill for req in lm_requests]
+        if self._pending is not None and (is_prefill or [r.request_id for r in lm_requests] != self._resident):
+            self.drain()             # this step reads per-request host state (restaging): finish the deferred update first
         ps = self.page_size
         # admission: preprocess the new prompts (once) and count the pages this step takes before touching any KV state
         need = 0
@@ -246,6 +251,7 @@ class ModelWorker:
                 # then the decode rows as a normal decode step.  Per-request results are those of the unsplit step.
                 return self._run_split_prefill(requests, lm_inputs)
             return self._run_long_prefill(requests, lm_inputs)
+        self.nvtx_range_push(f"lm_prefill_bs{n_req}")            # range names of cuda_graph_worker.py:813-1228
         q_req, kvlen, page, slot = self._token_plan(lm_inputs)
         e.row_ids[:n_rows].copy_(lm_inputs["input_ids"].to(torch.int32))
         if lm_inputs["input_masks"] is not None:     # Qwen3 consumes the text column's mask, CSM every column's
@@ -258,9 +264,14 @@ class ModelWorker:
         e.upload_plan(pos=lm_inputs["position_ids"].numpy(), kvlen=kvlen, page=page, slot=slot, q_req=q_req,
                       last_rows=[q - 1 for q in qo[1:]], indptr=lm_inputs["paged_kv_indptr"],
                       indices=lm_inputs["paged_kv_indices"])
+        self.nvtx_range_push("cuda_graph_replay")                # (here: the eager prefill launches)
         e.prefill(n_rows, n_req, max(kvlen), self._sampling(), seed=self.seed, feedback=True)
-        self._after_frame(requests)
-        return None
+        self.nvtx_range_pop()
+        self.nvtx_range_push("sampling")                         # request-state half of sampling (+ depth loop results)
+        task = self._finish_launch(requests)
+        self.nvtx_range_pop()
+        self.nvtx_range_pop()
+        return task
 
     @staticmethod
     def _slice_inputs(lm_inputs: LMInputs, lo: int, hi: int) -> LMInputs:
@@ -323,14 +334,14 @@ class ModelWorker:
             e.upload_plan(pos=pos[a:b], kvlen=kvlen[a:b], page=page[a:b], slot=slot[a:b], q_req=[0] * m, last_rows=[m - 1],
                           indptr=lm_inputs["paged_kv_indptr"], indices=lm_inputs["paged_kv_indices"])
             e.prefill(m, 1 if last else 0, max(kvlen[a:b]), self._sampling(), seed=self.seed, feedback=True)
-        self._after_frame(requests)
-        return None
+        return self._finish_launch(requests)
 
     def run_lm_decode(self, requests: List[Request], lm_inputs: LMInputs):
         if len(requests) == 0:
             return None
         e = self.model.engine
         B = len(requests)
+        self.nvtx_range_push(f"lm_decode_bs{B}")
         ids = [r.request_id for r in requests]
         if self._resident != ids:        # batch composition changed: restage the per-request inputs
             e.input_ids[:B].copy_(lm_inputs["input_ids"].to(torch.int32))
@@ -343,9 +354,62 @@ class ModelWorker:
         e.upload_plan(pos=lm_inputs["position_ids"].numpy(), kvlen=[r.kv_token_len for r in requests],
                       page=[r.kv_pages[-1] for r in requests], slot=[r.kv_last_page_len - 1 for r in requests],
                       indptr=lm_inputs["paged_kv_indptr"], indices=lm_inputs["paged_kv_indices"])
+        self.nvtx_range_push("cuda_graph_replay")                # one hipGraph: talker + sampling + the whole depth loop
         e.frame(B, max(r.kv_token_len for r in requests), self._sampling(), seed=self.seed, feedback=True)
-        self._after_frame(requests)
-        return None
+        self.nvtx_range_pop()
+        self.nvtx_range_push("sampling")
+        task = self._finish_launch(requests)
+        self.nvtx_range_pop()
+        self.nvtx_range_pop()
+        return task
+
+    # ---- async scheduling (scheduler/base.py:163-221 of the reference: `sampling` hands back a coroutine that updates the
+    # request objects; the scheduler awaits it while the next step already runs) ----
+    def _finish_launch(self, requests: List[Request]):
+        """After a frame / prefill was enqueued: update the requests now (synchronous scheduling, returns None) or hand back
+        a coroutine that does it later.  The deferred form snapshots the sampled ids (pinned host buffer) and the next-step
+        features in STREAM ORDER right behind the frame, so the following frame may overwrite the engine's buffers while the
+        host is still reading this one's."""
+        if not self.async_scheduling:
+            self._after_frame(requests)
+            return None
+        e, B = self.model.engine, len(requests)
+        self.drain()                                   # at most one step in flight behind the one being launched
+        if self._snap is None:
+            mk = lambda: {"ids": torch.zeros_like(e.out_ids, device="cpu").pin_memory(),
+                          "feats": torch.zeros_like(e.next_features) if getattr(e, "next_features", None) is not None else None,
+                          "event": torch.cuda.Event()}
+            self._snap = [mk(), mk()]
+        snap = self._snap[self._snap_i]
+        self._snap_i ^= 1
+        with e._OnStream(e):
+            snap["ids"][:B].copy_(e.out_ids[:B], non_blocking=True)
+            if snap["feats"] is not None:
+                snap["feats"][:B].copy_(e.next_features[:B])
+            snap["event"].record()
+        self._resident = [r.request_id for r in requests]
+        self._resident_reqs = list(requests)
+        positions = [r.next_position_id for r in requests]      # as of this step (the next step's prepare advances them)
+        state = {"done": False}
+
+        def finish():
+            if state["done"]:
+                return
+            state["done"] = True
+            snap["event"].synchronize()
+            self._after_frame(requests, out=snap["ids"][:B].to(torch.long), feats=snap["feats"], positions=positions)
+            if self._pending is finish:
+                self._pending = None
+        self._pending = finish
+
+        async def task():
+            finish()
+        return task()
+
+    def drain(self):
+        """Run the deferred request-state update of the last launched step now (idempotent)."""
+        if self._pending is not None:
+            self._pending()
 
     def _stage_repetition(self, requests: List[Request], e):
         """Per-request repetition caches live in the engine's rows while a batch is resident; when the batch changes the
@@ -362,18 +426,40 @@ class ModelWorker:
                 rc[i].copy_(req.repetition_cache.to(rc.device, torch.uint8))
         self._resident_reqs = []
 
-    def _after_frame(self, requests: List[Request]):
-        """The request-state half of the plugin's `sampling` (+ `depth_sampling`), once per frame on one D2H copy."""
+    def _after_frame(self, requests: List[Request], out=None, feats=None, positions=None):
+        """The request-state half of the plugin's `sampling` (+ `depth_sampling`), once per frame on one D2H copy.
+        out / feats: stream-ordered snapshots of the step (async scheduling); default: read the engine's buffers now."""
         e, m = self.model.engine, self.model
         B = len(requests)
-        out = e.out_ids[:B].cpu().to(torch.long)                      # the one synchronisation of the step
-        self._resident = [r.request_id for r in requests]
-        self._resident_reqs = list(requests)
+        if out is None:
+            out = e.out_ids[:B].cpu().to(torch.long)                  # the one synchronisation of the step
+            self._resident = [r.request_id for r in requests]
+            self._resident_reqs = list(requests)
+        # async scheduling launches step N+1 before step N's tokens are seen: a request that finished at N has one surplus
+        # row in N+1, whose output is dropped here (the reference's async loop has the same one-step lag)
+        if positions is None:
+            positions = [r.next_position_id for r in requests]
+        live = [i for i, r in enumerate(requests) if not r.done_lm_generation]
+        if len(live) != B:
+            requests, positions = [requests[i] for i in live], [positions[i] for i in live]
+            out = out[live]
+            if feats is not None:
+                feats = feats[live]
+            B = len(requests)
+            if B == 0:
+                return
         if hasattr(m, "update_requests"):                              # single-stack families
-            m.update_requests(requests, out.view(B, -1))
+            saved = [r.next_position_id for r in requests]             # (the plugin's max_tokens rule reads next_position_id)
+            for r, p_ in zip(requests, positions):
+                r.next_position_id = p_
+            try:
+                m.update_requests(requests, out.view(B, -1))
+            finally:
+                for r, p_ in zip(requests, saved):
+                    r.next_position_id = p_
             return
         # Qwen3-TTS: qwen3_tts.py:1931-1962, 1995-2002
-        feats = e.next_features[:B].clone()
+        feats = (e.next_features if feats is None else feats)[:B].clone()
         C = m.n_codebooks
         pad = m.config.tts_pad_id
         for i, req in enumerate(requests):
@@ -390,8 +476,8 @@ class ModelWorker:
             else:
                 req.done_lm_generation = True
                 req.finish_reason = "stop_id_encountered"
-        for req in requests:
-            if req.next_position_id > m.max_tokens:
+        for req, p_ in zip(requests, positions):
+            if p_ > m.max_tokens:
                 req.done_lm_generation = True
                 req.finish_reason = "max_tokens_reached"
 
@@ -401,6 +487,7 @@ class ModelWorker:
             return
         interval = self.detokenize_interval
         token_ids, mapping = [], []
+        self.nvtx_range_push(f"detokenize_bs{len(requests)}")
         for ri, req in enumerate(requests):
             for ci in range(len(req.audio_decode_idx)):
                 d = req.audio_decode_idx[ci]
@@ -427,7 +514,9 @@ class ModelWorker:
                     continue
                 batch = torch.stack([token_ids[i] for i in sel], dim=0)
                 cache = DecoderCache.cat([caches[i] for i in sel]) if stateful else None
+                self.nvtx_range_push("detokenize_replay")
                 audio = self.model.postprocess(batch, decoder_cache=cache)
+                self.nvtx_range_pop()
                 if self.needs_watermarking:
                     audio = self.run_watermark(audio)
                 a = audio.detach().float().cpu().numpy()
@@ -446,14 +535,16 @@ class ModelWorker:
             if req.done_lm_generation and req.audio_decode_idx and (
                     req.audio_decode_idx[-1] + interval >= len(req.lm_output_audio_tokens)):
                 req.done_all = True
+        self.nvtx_range_pop()
 
     def run_watermark(self, audio):
         return audio          # hook kept (worker/base.py:104-121); Qwen3 needs none
 
     def nvtx_range_push(self, name: str):
+        """worker/base.py:736-747 — torch.cuda.nvtx is roctx on ROCm builds of torch (rocprofv3 --marker-trace shows the ranges)."""
         if self.nvtx_enabled:
             torch.cuda.synchronize()
-            torch.cuda.nvtx.range_push(name)      # roctx on ROCm builds of torch
+            torch.cuda.nvtx.range_push(name)
 
     def nvtx_range_pop(self):
         if self.nvtx_enabled:
