@@ -161,6 +161,7 @@ class Qwen3Engine:
         self.row_masks = torch.zeros(R, dtype=torch.uint8, device=dev)
         self.row_feats = torch.zeros(R, H, dtype=torch.bfloat16, device=dev)
         self._graphs = {}
+        self.max_graphs = 512          # frame graphs (batch x kv bucket) + prefill graphs (exact shapes seen twice)
         self.keep_hidden = True
         # hipGraph capture needs a non-default stream; all engine work runs on this one, fenced against the
         # caller's current stream on entry and exit.
@@ -264,11 +265,32 @@ class Qwen3Engine:
             g = self._graphs[key] = gh
         N.check(self.L.vox_graph_launch(g, N.stream()))
 
-    def prefill(self, n_rows, n_req, max_kvlen, sampling=None, seed=0, feedback=True):
-        """Ragged prefill of rows staged in row_ids/row_masks/row_feats + plan arrays (eager, not captured)."""
+    def prefill(self, n_rows, n_req, max_kvlen, sampling=None, seed=0, feedback=True, use_graph=True):
+        """Ragged prefill of rows staged in row_ids/row_masks/row_feats + plan arrays.  A shape (rows, requests, kv bound) seen
+        for the second time is captured into a hipGraph and replayed from then on (the reference captures padded prefill
+        buckets up front, cuda_graph_worker.py:206-352; here every buffer of the call sits at a fixed address, so the exact
+        shape can be captured without padding and without changing which kernels — hence which bits — a prompt gets)."""
         sampling = sampling or self.sampling_cfg()
         with self._OnStream(self):
-            self._prefill_on_stream(n_rows, n_req, max_kvlen, sampling, seed, feedback)
+            if not use_graph:
+                return self._prefill_on_stream(n_rows, n_req, max_kvlen, sampling, seed, feedback)
+            key = ("prefill", n_rows, n_req, min(max(32, int(max_kvlen)), self.max_seq_len), bytes(sampling), seed, bool(feedback),
+                   self.keep_hidden)
+            ent = self._graphs.get(key)
+            if ent is None:                                   # first sighting: eager (also sets kernel attributes)
+                if len(self._graphs) < getattr(self, "max_graphs", 512):
+                    self._graphs[key] = False
+                return self._prefill_on_stream(n_rows, n_req, max_kvlen, sampling, seed, feedback)
+            if ent is False:                                  # second: capture (capture does not execute), then fall through to replay
+                st = N.stream()
+                N.check(self.L.vox_graph_begin(self.ctx, st))
+                try:
+                    self._prefill_on_stream(n_rows, n_req, max_kvlen, sampling, seed, feedback)
+                finally:
+                    gh = ctypes.c_void_p()
+                    N.check(self.L.vox_graph_end(self.ctx, st, ctypes.byref(gh)))
+                ent = self._graphs[key] = gh
+            N.check(self.L.vox_graph_launch(ent, N.stream()))
 
     def _mutable_state(self):
         return [self.input_ids, self.input_masks, self.input_features, self.rng_offset]
@@ -293,7 +315,8 @@ class Qwen3Engine:
 
     def close(self):
         for g in self._graphs.values():
-            self.L.vox_graph_destroy(g)
+            if g:
+                self.L.vox_graph_destroy(g)
         self._graphs.clear()
         if self.h:
             self._native_destroy()
