@@ -34,6 +34,16 @@ INTERVAL = 10              # detokenize_interval default (qwen3_tts.py:965)
 KV_BYTES_PER_TOKEN = 28 * 2 * 8 * 128 * 2
 
 
+_T0 = [time.perf_counter()]
+
+
+def _phase(label):
+    """wall time of each bench phase on stderr (the JSON line on stdout stays the only stdout output)"""
+    now = time.perf_counter()
+    print(f"[bench] {label}: {now - _T0[0]:.1f} s", file=sys.stderr, flush=True)
+    _T0[0] = now
+
+
 def algorithmic_bytes_per_frame(B, kv_mean):
     talker = 28 * 50.33e6 * 2 + 3072 * 2048 * 2 + (2048 * 2048 * 2 + 4096) * 2     # layers + codec_head + text_projection
     depth = (5 * 15.73e6 + 2048 * 1024 + 1024) * 2 + 15 * 2048 * 1024 * 2          # read once per frame (SURVEY §8d)
@@ -161,17 +171,21 @@ def cpu_baseline(W, budget_s=25.0):
     m = QR.Qwen3Ref(ref_cfg, src, page_size=128, max_pages=2, max_batch=1)
     req = QR.RefRequest()
     rng = np.random.default_rng(1)
-    n = 8                                         # short prefill just to have a live request (not timed)
+    n = 2                                         # short prefill just to have a live request (not timed; > 2 rows would take the
+                                                  # oracle's restated matrix-core datapath: a minute per prefill)
     ids = np.zeros((n, 17), np.int32)
     ids[:, -1] = rng.integers(0, 151000, n)
+    _phase("cpu baseline: oracle set-up")
     lg, hid = m.prefill(req, ids, np.ones(n, np.uint8), np.zeros((n, 2048), np.uint16))
     m.frame([req], lg, hid)
+    _phase("cpu baseline: prefill + first frame (untimed)")
     t0 = time.perf_counter()
     nf = 0
-    while nf < 1 or (time.perf_counter() - t0 < budget_s * 0.6 and nf < 8):
+    while nf < 1 or (time.perf_counter() - t0 < budget_s * 0.4 and nf < 6):
         m.frame([req])
         nf += 1
     t_lm = (time.perf_counter() - t0) / nf
+    _phase("cpu baseline: LM frames")
     tthreads = min(cores, 16)                     # torch-CPU conv stops scaling (and collapses) far below 256 threads
     torch.set_num_threads(tthreads)
     ccfg = CR.CodecCfg()
@@ -280,7 +294,9 @@ def serving_ttfa(dev, shared, n_requests, load, interval=INTERVAL, seed=0):
     mb = max(8, load + 1)
     m = Qwen3TTSModel("qwen3-tts", shared["W"], shared["codec_W"], device=str(dev), detokenize_interval=interval,
                       max_batch_size=mb, page_size=128, max_num_pages=4 * mb + 8, max_seq_len=2304, max_prefill_tokens=128)
-    m.default_sampling_config = SamplingConfig(greedy=True, max_tokens=400, repetition_penalty=1.05, repetition_window=-1)
+    # alone (load 0) a probe only has to reach its first chunk: a short request keeps the default run within minutes
+    m.default_sampling_config = SamplingConfig(greedy=True, max_tokens=(400 if load else PROMPT_TOKENS + interval + 6),
+                                               repetition_penalty=1.05, repetition_window=-1)
     t = QueueTransport()
     w = ModelWorker(model=m, max_batch_size=mb, max_num_pages=4 * mb + 8, page_size=128, device=str(dev))
     s = Scheduler(w, max_batch_size=mb, transport=t)
@@ -345,8 +361,11 @@ def serving_throughput(dev, shared, n_req, frames, kind="base"):
     m.default_sampling_config = SamplingConfig(greedy=True, max_tokens=PROMPT_TOKENS + frames, repetition_penalty=1.05, repetition_window=-1)
     t = QueueTransport()
     w = ModelWorker(model=m, max_batch_size=mb, max_num_pages=4 * mb + 8, page_size=128, device=str(dev))
+    from vox_serve_amd.scheduler.offline import OfflineScheduler
     s = (DisaggregationScheduler(w, max_batch_size=mb, transport=t) if kind == "disaggregation"
-         else Scheduler(w, max_batch_size=mb, transport=t, async_scheduling=(kind == "async")))
+         else OfflineScheduler(w, max_batch_size=mb, transport=t) if kind == "offline"
+         else Scheduler(w, max_batch_size=mb, transport=t, async_scheduling=(kind == "async"),
+                        detokenize_min_batch=(mb // 2 if kind == "batched_detokenize" else 0)))
     rng = np.random.default_rng(3)
 
     def submit(tag, n):
@@ -456,17 +475,29 @@ def main():
     subs = [] if args.batch is not None else [8, 32]
     if args.sub_batches is not None:
         subs = [int(x) for x in args.sub_batches.split(",") if x.strip()]
+    _phase("weights")
     head = run_batch(head_B, args, dev, world, shared, ttfa_requests=args.ttfa_requests if rank == 0 else 0)
-    sub_res = {b: run_batch(b, args, dev, world, shared) for b in subs}
+    _phase(f"batch {head_B}")
+    sub_res = {}
+    for b in subs:
+        sub_res[b] = run_batch(b, args, dev, world, shared)
+        _phase(f"batch {b}")
 
     serving = {}
     if world == 1 and args.serving_ttfa_requests > 0 and args.batch is None:
         n = args.serving_ttfa_requests
         serving["ttfa_ms_p50"] = serving_ttfa(dev, shared, n, 0)
+        _phase("serving ttfa")
         serving["ttfa_ms_p50_detokenize_interval_2"] = serving_ttfa(dev, shared, max(10, n // 2), 0, interval=2)
+        _phase("serving ttfa interval 2")
         serving["ttfa_ms_p50_under_32way_load"] = serving_ttfa(dev, shared, max(10, n // 5), 31)
-        serving["throughput"] = {k: serving_throughput(dev, shared, 32, 120, k) for k in ("base", "async", "disaggregation")}
+        _phase("serving ttfa under load")
+        serving["throughput"] = {}
+        for k in ("base", "async", "disaggregation", "offline", "batched_detokenize"):
+            serving["throughput"][k] = serving_throughput(dev, shared, 32, 120, k)
+            _phase(f"serving throughput {k}")
         serving["throughput"]["batch1_base"] = serving_throughput(dev, shared, 1, 120, "base")
+        _phase("serving throughput batch 1")
 
     if rank == 0:
         out = {
@@ -500,6 +531,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N=1 only (other ranks would idle in RCCL)
             try:
                 out["cpu_baseline"] = cpu_baseline(shared["W"])
+                _phase("cpu baseline")
             except Exception as ex:  # the baseline is a reported extra; never let it hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)[:200]}
         print(json.dumps(out), flush=True)

@@ -424,7 +424,7 @@ def g4_qwen3_codec(ns):
                     wav, cache = m.forward_chunk(codes[:, :, t0:t0 + ch], cache)
                     wavs.append(wav.float().clone())
                 wav = torch.cat(wavs, -1)
-                out[f"{tag}_{dt_name}_c{ch}"] = wav.numpy().astype(np.float32 if tag == "tiny" else np.float16)
+                out[f"{tag}_{dt_name}_c{ch}"] = wav.numpy().astype(np.float32 if (tag == "tiny" or dt_name == "fp32") else np.float16)
                 print(tag, dt_name, ch, tuple(wav.shape), "rms", float(wav.pow(2).mean().sqrt()), "max", float(wav.abs().max()))
     np.savez_compressed(os.path.join(HERE, "g4_qwen3_codec.npz"), **out)
     print("g4 ok")
@@ -788,7 +788,7 @@ def g5_mimi(ns):
         codes[1, :, 7:] = codes[1, :, 6:7]                       # a run of repeated frames (the worker's tail padding)
         wav = model.decode(codes)
         out[f"{tag}_codes"] = codes.numpy().astype(np.int16)
-        out[f"{tag}_wav"] = wav.numpy().astype(np.float32 if tag == "tiny" else np.float16)
+        out[f"{tag}_wav"] = wav.numpy().astype(np.float32 if (tag == "tiny" or dt_name == "fp32") else np.float16)
         print("g5", tag, tuple(wav.shape), "rms", float(wav.pow(2).mean().sqrt()))
     np.savez_compressed(os.path.join(HERE, "g5_mimi.npz"), **out)
 

@@ -33,12 +33,13 @@ def build(dev, max_tokens=None, max_prefill_tokens=64):
     return m, cfg
 
 
-def serve(m, prompts, async_scheduling=False):
+def serve(m, prompts, async_scheduling=False, overlap_detokenize=True, detokenize_min_batch=0):
     from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
     from vox_serve_amd.worker import ModelWorker
     t = QueueTransport()
     w = ModelWorker(model=m, max_batch_size=4, max_num_pages=64, page_size=16, device=m.device)
-    s = Scheduler(w, max_batch_size=4, transport=t, async_scheduling=async_scheduling)
+    s = Scheduler(w, max_batch_size=4, transport=t, async_scheduling=async_scheduling, detokenize_min_batch=detokenize_min_batch)
+    s.overlap_detokenize = overlap_detokenize
     for rid, ids in prompts.items():
         t.requests.put(encode_request(rid, "", model_kwargs={"prompt_token_ids": ids, "speaker": "a"}))
     s.run_until_idle(2000)
@@ -400,3 +401,25 @@ def test_async_scheduling_gives_the_same_audio():
         m.engine.close(); m.audio_decoder.close()
     finally:
         N.set_exact_rows(2)
+
+
+def test_detokenize_beside_the_lm_frame_gives_the_same_audio():
+    """The scheduler enqueues the codec chunk on the worker's detokenize stream, launches the LM step behind it and collects the
+    audio afterwards (first chunks are still sent at once); the reference's order (decode, send, then the LM step) and the
+    opt-in batching window (`detokenize_min_batch`) must give every request the same bytes — the streaming codec state and
+    the token windows do not depend on when the host waits or on which requests share a codec call."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    dev = torch.device("cuda:0")
+    m, cfg = build(dev, max_tokens=40)
+    prompt = [1, 2, 3, 40, 41, 42, 43, 7, 8, 9, 10, 11]
+    prompts = {"r1": prompt, "r2": prompt[:3] + [50, 51] + prompt[-5:], "r3": prompt[:3] + [60] + prompt[-5:],
+               "r4": prompt[:3] + [70, 71, 72] + prompt[-5:]}
+    ref, w0 = serve(m, prompts, overlap_detokenize=False)
+    for kw in ({}, {"detokenize_min_batch": 3}, {"detokenize_min_batch": 3, "async_scheduling": False, "overlap_detokenize": False}):
+        got, w = serve(m, prompts, **kw)
+        for rid in prompts:
+            assert got[rid]["done"] == ref[rid]["done"], (kw, rid)
+            assert got[rid]["pcm"] == ref[rid]["pcm"] and len(got[rid]["pcm"]) > 0, (kw, rid)
+        assert w.empty_pages.qsize() == 64
+    m.engine.close(); m.audio_decoder.close()

@@ -288,6 +288,43 @@ def test_scheduler_policies_match_reference():
                 assert [bool(r.done_all) for r in sch.active_requests] == want["done_all"], (ci, name)
 
 
+def test_detokenize_batching_window():
+    """Opt-in `detokenize_min_batch`: a ready window waits for company unless it is a first chunk, a tail, or a second window."""
+    import types
+    from vox_serve_amd.requests import Request
+    from vox_serve_amd.scheduler import Scheduler
+
+    def mk(i, n_tokens, next_idx, done=False):
+        r = Request(request_id=f"r{i}", prompt="x")
+        r.done_lm_prefill, r.done_lm_generation = True, done
+        r.lm_output_audio_tokens = [None] * n_tokens
+        r.next_audio_decode_idx = list(next_idx)
+        return r
+    w = types.SimpleNamespace(detokenize_interval=10, detokenize_overlap=0, available_batch_sizes=None, supports_audio_input=False)
+    sel = lambda s: [r.request_id for r in s._select_detokenize_requests()]
+    ref = Scheduler(w, max_batch_size=8)
+    bat = Scheduler(w, max_batch_size=8, detokenize_min_batch=4)
+    # two of six generating requests have their second window ready: the reference policy takes them, the window waits
+    states = lambda: [mk(0, 20, [0]), mk(1, 21, [0]), mk(2, 15, [0]), mk(3, 13, [0]), mk(4, 12, [0]), mk(5, 11, [0])]
+    ref.active_requests, bat.active_requests = states(), states()
+    assert sel(ref) == ["r0", "r1"] and sel(bat) == []
+    assert [r.next_audio_decode_idx for r in bat.active_requests] == [[0]] * 6          # nothing was advanced
+    # ... until four are ready
+    st = states(); st[2], st[3] = mk(2, 20, [0]), mk(3, 22, [0])
+    bat.active_requests = st
+    assert sel(bat) == ["r0", "r1", "r2", "r3"]
+    # a first chunk, a tail, or a piled-up second window go at once (with everything else that is ready)
+    bat.active_requests = [mk(0, 10, []), mk(1, 20, [0])] + states()[2:]
+    assert sel(bat) == ["r0", "r1"]
+    bat.active_requests = [mk(0, 14, [0], done=True)] + states()[1:]
+    assert sel(bat) == ["r0", "r1"]
+    bat.active_requests = [mk(0, 30, [0])] + states()[2:]
+    assert sel(bat) == ["r0"]
+    # fewer generating requests than the window: all of them ready is enough
+    bat.active_requests = [mk(0, 20, [0]), mk(1, 20, [0])]
+    assert sel(bat) == ["r0", "r1"]
+
+
 def test_input_streaming_messages_match_reference():
     import json
     import types

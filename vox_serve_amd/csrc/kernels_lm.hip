@@ -986,6 +986,15 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
             if (SM) wv[1][s] = a.keep ? w1[s * wstep] : ldg_nt(w1 + s * wstep);
         }
     }
+    // residual of the outputs this thread will finish (threads < MT*64), requested with the operands instead of after the reduce
+    float res_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!SM && a.residual && tid < MT * 64 && n0 + fr < a.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = (tid >> 6) * 16 + (lane >> 4) * 4 + r;
+            if (b < bt) res_pre[r] = bf2f(a.residual[(size_t)(r0 + b) * a.N + n0 + fr]);
+        }
+    }
     const uint4* xr[MT];
     const int xstep = a.x_frag ? 64 : 4;
 #pragma unroll
@@ -1078,7 +1087,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
             if (a.bias) f = f + bv;
             o = f2bf(f);
             if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
-            if (a.residual) o = f2bf(bf2f(a.residual[oi]) + bf2f(o));
+            if (a.residual) o = f2bf(res_pre[r] + bf2f(o));
         }
         if (a.y_rowmajor) a.y[oi] = o;
         if (a.y_frag) a.y_frag[frag_off(r0 + b, n, a.N)] = o;

@@ -61,6 +61,7 @@ class Scheduler:
         self.max_batch_size = max_batch_size
         self.transport = transport or QueueTransport()
         self.async_scheduling = async_scheduling
+        self.detokenize_min_batch = int(kwargs.get("detokenize_min_batch", self.detokenize_min_batch))
         self.active_requests: List[Request] = []
         self.logger = logging.getLogger(__name__)
         self.available_batch_sizes = model_worker.available_batch_sizes
@@ -100,8 +101,7 @@ class Scheduler:
                     req.audio_decode_idx = req.next_audio_decode_idx.copy()
                 lm_requests, lm_inputs = [], None
                 break
-        self.model_worker.run_detokenize(detokenize_requests)
-        self._send_responses(detokenize_requests)
+        pending_audio = self._launch_detokenize(detokenize_requests)
         try:
             if lm_inputs is not None and lm_inputs["is_prefill"]:
                 self.model_worker.run_lm_prefill(lm_requests, lm_inputs)
@@ -111,6 +111,35 @@ class Scheduler:
             # one bad request must not take the serving loop down (the reference lets the exception escape run_forever):
             # in a prefill step the new prompt is the suspect, in a decode step every row of the failed launch is dropped
             self._fail_requests(fresh or lm_requests, ex)
+        self._finish_detokenize(pending_audio, detokenize_requests)
+
+    # ---- detokenize beside the LM frame ----
+    overlap_detokenize = True       # False: the reference's order (decode the audio, send it, then launch the LM step)
+
+    def _launch_detokenize(self, detokenize_requests):
+        """Enqueue the codec chunk of this step.  The reference decodes and sends the audio before it launches the LM step
+        (scheduler/base.py:125-160), i.e. the GPU runs the two one after the other; here the chunk is enqueued on the
+        worker's detokenize stream, the LM step is launched right behind it and the audio is collected after the step, so
+        both share the GPU.  A chunk that carries a request's FIRST audio (time to first audio) is still collected and sent
+        at once.  Returns the handle for `_finish_detokenize`, or None when everything was already sent."""
+        w = self.model_worker
+        if not detokenize_requests:
+            return None
+        if not (self.overlap_detokenize and hasattr(w, "launch_detokenize")):
+            w.run_detokenize(detokenize_requests)
+            self._send_responses(detokenize_requests)
+            return None
+        pending = w.launch_detokenize(detokenize_requests)
+        if any(r.audio_decode_idx and r.audio_decode_idx[0] == 0 for r in detokenize_requests):
+            w.finish_detokenize(pending)
+            self._send_responses(detokenize_requests)
+            return None
+        return pending
+
+    def _finish_detokenize(self, pending, detokenize_requests):
+        if pending is not None:
+            self.model_worker.finish_detokenize(pending)
+            self._send_responses(detokenize_requests)
 
     def _fail_requests(self, requests, ex):
         for req in requests:
@@ -145,8 +174,7 @@ class Scheduler:
         except Exception as ex:
             self._fail_requests(fresh or lm_requests, ex)
             lm_requests = []
-        self.model_worker.run_detokenize(detokenize_requests)
-        self._send_responses(detokenize_requests)
+        pending_audio = self._launch_detokenize(detokenize_requests)
         next_task = None
         try:
             if lm_inputs is not None and lm_inputs["is_prefill"]:
@@ -155,6 +183,7 @@ class Scheduler:
                 next_task = self.model_worker.run_lm_decode(lm_requests, lm_inputs)
         except Exception as ex:
             self._fail_requests(fresh or lm_requests, ex)
+        self._finish_detokenize(pending_audio, detokenize_requests)
         if task is not None:
             await task                          # step N-1's tokens -> request objects, while step N runs
         if next_task is not None and lm_inputs is not None and lm_inputs["is_prefill"]:
@@ -240,23 +269,41 @@ class Scheduler:
     def _lm_batch_cap(self, prefill_cycle: bool, max_prefill_batch_size: int) -> int:
         return self.max_batch_size
 
+    # Opt-in (0 = the reference's policy: every request with a full window is decoded in the step it becomes ready).  With n > 1 a
+    # ready window waits until n requests (or all that are still generating) have one, or until it is a request's first
+    # audio / its tail / a second window has piled up: requests that started in different steps reach their window
+    # boundaries in different steps, and a codec call for 3 rows costs a quarter of one for 32 (bench.py: serving_path_throughput).
+    detokenize_min_batch = 0
+
     def _select_detokenize_requests(self):
-        out = []
         interval = self.model_worker.detokenize_interval
         step = interval - self.model_worker.detokenize_overlap
+        cand, urgent = [], False
         for req in self.active_requests:
-            if len(out) >= self.max_batch_size:
+            if len(cand) >= self.max_batch_size:
                 break
             nxt = req.next_audio_decode_idx[-1] + step if req.next_audio_decode_idx else 0
+            n_tok = len(req.lm_output_audio_tokens)
             if req.done_lm_generation:
+                cand.append((req, nxt, True))
+                urgent = True
+            elif nxt + interval <= n_tok:
+                cand.append((req, nxt, False))
+                urgent = urgent or nxt == 0 or nxt + step + interval <= n_tok
+        if self.detokenize_min_batch > 1 and not urgent:
+            generating = sum(1 for r in self.active_requests if not r.done_lm_generation)
+            if len(cand) < min(self.detokenize_min_batch, generating):
+                return []
+        out = []
+        for req, nxt, tail in cand:
+            if tail:
                 if nxt < len(req.lm_output_audio_tokens):
                     req.next_audio_decode_idx = [nxt]
                 else:
                     req.done_all = True
-                out.append(req)
-            elif nxt + interval <= len(req.lm_output_audio_tokens):
+            else:
                 req.next_audio_decode_idx = [nxt]
-                out.append(req)
+            out.append(req)
         return out
 
     # ---- wire format ----

@@ -11,6 +11,7 @@ Host bookkeeping follows the reference line by line where it is observable from 
                       Qwen3TTSModel.sampling / depth_sampling (qwen3_tts.py:1931-1962, 1995-2002) run once per frame on
                       one D2H copy of the sampled ids instead of >= 16*B `.item()` synchronisations.
 """
+import contextlib
 import logging
 import os
 import queue
@@ -72,6 +73,7 @@ class ModelWorker:
         self.has_depth_transformer = getattr(model, "has_depth_transformer", False)
         self.async_scheduling = False   # set by a scheduler running the reference's async loop (scheduler/base.py:166-221)
         self._pending = None         # the deferred request-state update of the last launched step (async scheduling)
+        self._detok_stream = None    # launch_detokenize: the codec chunk + its D2H copy run here, beside the LM frame
         self._snap, self._snap_i = None, 0
         self._resident = None        # request ids whose next inputs already sit in the engine's rows (feedback path)
         self._resident_reqs = []     # ... and the requests themselves (their repetition-cache rows live in the engine)
@@ -483,8 +485,16 @@ class ModelWorker:
 
     # -------------------------------------------------------------------------------------------------
     def run_detokenize(self, requests: List[Request]):
+        """worker/base.py:616-690 of the reference: decode the selected windows, PCM16 into each request's output queue."""
+        self.finish_detokenize(self.launch_detokenize(requests))
+
+    def launch_detokenize(self, requests: List[Request]):
+        """First half of `run_detokenize`: stage the windows and ENQUEUE the codec chunk(s) plus the D2H copy of their audio on
+        the worker's detokenize stream, without waiting.  The scheduler launches the LM frame next, so the chunk and the frame
+        share the GPU (the engine and the codec run on their own streams), and collects the audio with `finish_detokenize`.
+        Same calls on the same data as the one-shot form; only the point where the host waits moves."""
         if len(requests) == 0:
-            return
+            return None
         interval = self.detokenize_interval
         token_ids, mapping = [], []
         self.nvtx_range_push(f"detokenize_bs{len(requests)}")
@@ -498,6 +508,7 @@ class ModelWorker:
                     new.extend([new[-1]] * (interval - len(new)))      # pad by repeating the final token
                 token_ids.append(torch.cat(new, dim=0))
                 mapping.append((ri, ci))
+        parts, event, n_last = [None] * len(mapping), None, []
         if token_ids:
             caches = [requests[ri].decoder_cache for ri, _ in mapping]
             stateful = all(c is not None for c in caches)
@@ -507,35 +518,61 @@ class ModelWorker:
             # from the state its predecessor left (seamless audio).  The reference decodes all of a request's windows from
             # the same starting state and keeps the last one's (worker/base.py:641-656).
             n_rounds = max(ci for _, ci in mapping) + 1 if stateful else 1
-            parts = [None] * len(mapping)
-            for rnd in range(n_rounds):
-                sel = [i for i, (_, ci) in enumerate(mapping) if not stateful or ci == rnd]
-                if not sel:
-                    continue
-                batch = torch.stack([token_ids[i] for i in sel], dim=0)
-                cache = DecoderCache.cat([caches[i] for i in sel]) if stateful else None
-                self.nvtx_range_push("detokenize_replay")
-                audio = self.model.postprocess(batch, decoder_cache=cache)
-                self.nvtx_range_pop()
-                if self.needs_watermarking:
-                    audio = self.run_watermark(audio)
-                a = audio.detach().float().cpu().numpy()
-                for j, i in enumerate(sel):
-                    parts[i] = a[j]
-            audio_np = parts
-            for i, (ri, ci) in enumerate(mapping):
+            on_gpu = torch.cuda.is_available() and str(self.device).startswith("cuda")
+            if on_gpu and self._detok_stream is None:
+                self._detok_stream = torch.cuda.Stream(device=self.device)
+            if on_gpu:
+                self._detok_stream.wait_stream(torch.cuda.current_stream())
+            ctx = torch.cuda.stream(self._detok_stream) if on_gpu else contextlib.nullcontext()
+            with ctx:
+                for rnd in range(n_rounds):
+                    sel = [i for i, (_, ci) in enumerate(mapping) if not stateful or ci == rnd]
+                    if not sel:
+                        continue
+                    batch = torch.stack([token_ids[i] for i in sel], dim=0)
+                    cache = DecoderCache.cat([caches[i] for i in sel]) if stateful else None
+                    self.nvtx_range_push("detokenize_replay")
+                    audio = self.model.postprocess(batch, decoder_cache=cache)
+                    self.nvtx_range_pop()
+                    if self.needs_watermarking:
+                        audio = self.run_watermark(audio)
+                    audio = audio.detach().float()
+                    if audio.is_cuda:
+                        host = torch.empty(audio.shape, dtype=torch.float32, pin_memory=True)
+                        host.copy_(audio, non_blocking=True)       # stream-ordered right behind the chunk
+                    else:
+                        host = audio
+                    for j, i in enumerate(sel):
+                        parts[i] = (host, j)
+                if on_gpu:
+                    event = torch.cuda.Event()
+                    event.record(self._detok_stream)
+            for ri, ci in mapping:
                 req = requests[ri]
                 d = req.audio_decode_idx[ci]
-                a16 = (audio_np[i] * 32767).astype(np.int16)
-                n_last = len(req.lm_output_audio_tokens[d: d + interval])
-                if n_last < interval:
-                    a16 = a16[:, : int(a16.shape[1] * (n_last - 0.5) / interval)]
-                req.output_audio.put(a16.tobytes())
+                n_last.append(len(req.lm_output_audio_tokens[d: d + interval]))
+        self.nvtx_range_pop()
+        return {"requests": requests, "mapping": mapping, "parts": parts, "event": event, "n_last": n_last}
+
+    def finish_detokenize(self, pending):
+        """Second half of `run_detokenize`: wait for the audio of `launch_detokenize`, PCM16 -> the requests' output queues."""
+        if pending is None:
+            return
+        requests, interval = pending["requests"], self.detokenize_interval
+        if pending["event"] is not None:
+            pending["event"].synchronize()
+        for i, (ri, ci) in enumerate(pending["mapping"]):
+            req = requests[ri]
+            host, j = pending["parts"][i]
+            a16 = (host[j].numpy() * 32767).astype(np.int16)
+            n_last = pending["n_last"][i]
+            if n_last < interval:
+                a16 = a16[:, : int(a16.shape[1] * (n_last - 0.5) / interval)]
+            req.output_audio.put(a16.tobytes())
         for req in requests:
             if req.done_lm_generation and req.audio_decode_idx and (
                     req.audio_decode_idx[-1] + interval >= len(req.lm_output_audio_tokens)):
                 req.done_all = True
-        self.nvtx_range_pop()
 
     def run_watermark(self, audio):
         return audio          # hook kept (worker/base.py:104-121); Qwen3 needs none
