@@ -15,7 +15,14 @@ ap.add_argument("--warmup", type=int, default=20)
 args = ap.parse_args()
 B, dev = args.batch, torch.device("cuda")
 cfg = CSMCfg()
-eng = CSMEngine(cfg, synth_csm_weights(cfg, dev), max_batch=B, page_size=128, max_pages=4 * B + 1, max_seq_len=2304, max_prefill_rows=128)
+W = synth_csm_weights(cfg, dev)
+# algorithmic bytes of one frame: the backbone's weights once, the depth decoder's 31 times (one pass per codebook 1..31), the
+# heads once, K/V of the visible context; activations are negligible
+nb = lambda pred: sum(v.numel() * v.element_size() for k, v in W.items() if pred(k) and "embed" not in k)
+bytes_backbone = nb(lambda k: k.startswith("backbone_model.") or k == "lm_head.weight")
+bytes_depth = nb(lambda k: k.startswith("depth_decoder.model.layers.") or k.startswith("depth_decoder.model.norm") or "inputs_embeds_projector" in k)
+bytes_heads = nb(lambda k: k.startswith("depth_decoder.codebooks_head"))
+eng = CSMEngine(cfg, W, max_batch=B, page_size=128, max_pages=4 * B + 1, max_seq_len=2304, max_prefill_rows=128)
 eng.keep_hidden = False
 # Mimi with random-init weights of the reference configuration
 from vox_serve_amd.synth import synth_mimi_weights
@@ -91,4 +98,9 @@ t1 = time.perf_counter(); mimi.decode(ring, code_layout="BTQ"); torch.cuda.synch
 frame_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 print(json.dumps({"workload": f"CSM-1B bf16 + Mimi, batch={B}, greedy, 64-token prompt, detokenize_interval 10",
                   "audio_samples_per_s": B * 1920 * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                  "lm_frame_graph_ms": frame_ms, "mimi_chunk_ms": t_codec * 1e3, "realtime_factor_per_request": 1920 * args.steps / dt / 24000}))
+                  "lm_frame_graph_ms": frame_ms, "mimi_chunk_ms": t_codec * 1e3, "realtime_factor_per_request": 1920 * args.steps / dt / 24000,
+                  "roofline": (lambda alg: {"bound": "hbm", "achieved": alg / (frame_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                            "frac": alg / (frame_ms * 1e-3) / 8e12, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                                            "launch": "one hipGraph replay = one frame (backbone + 31 depth passes + samplers)"})(
+                      bytes_backbone + (cfg.n_codebooks - 1) * bytes_depth + bytes_heads
+                      + B * (n0 + args.warmup + args.steps / 2) * cfg.backbone.layers * 2 * cfg.backbone.kv_heads * cfg.backbone.head_dim * 2)}))

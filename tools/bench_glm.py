@@ -14,10 +14,10 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--greedy", action="store_true")
-ap.add_argument("--exact-rows", type=int, default=8)
+ap.add_argument("--exact-rows", type=int, default=2)
 args = ap.parse_args()
 B, dev = args.batch, torch.device("cuda")
-if args.exact_rows != 8:
+if args.exact_rows != 2:
     from vox_serve_amd import _native as _N
     _N.set_exact_rows(args.exact_rows)
 gc = GLMVoiceConfig()
@@ -61,4 +61,7 @@ frame_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 wbytes = sum(t.numel() * 2 for l in layers for t in l.values()) + head.numel() * 2
 print(json.dumps({"workload": f"GLM-4-Voice-9B bf16 LM, batch={B}/GPU, {'greedy' if args.greedy else 'top-p 0.8 T 0.8 over 168960 ids'}, 64-token context",
                   "lm_tokens_per_s": B * args.steps / dt, "audio_seconds_per_s": B * args.steps / dt / 12.5, "ms_per_step": dt / args.steps * 1e3,
-                  "lm_graph_ms": frame_ms, "weight_bytes_streamed": wbytes, "hbm_frac_of_8TBps": wbytes / (frame_ms * 1e-3) / 8e12}))
+                  "lm_graph_ms": frame_ms, "weight_bytes_streamed": wbytes, "exact_rows": args.exact_rows,
+                  "roofline": {"bound": "hbm", "achieved": wbytes / (frame_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": wbytes / (frame_ms * 1e-3) / 8e12, "traffic": None, "algorithmic_bytes_per_launch": wbytes,
+                               "launch": "one hipGraph replay = one token step (40 layers + head + sampler)"}}))

@@ -19,3 +19,11 @@ python tools/mfma_summary.py $(find $O/pmc_mfma -name "*counter_collection.csv")
 rm -rf $O/pmc_mfma
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 600 $O/bench_default.json
+# BASELINE configs 3 and 4 (development benches; one JSON line each with a roofline block) + their kernel summaries
+for b in 1 16; do timeout 600 python tools/bench_csm.py --batch $b > $O/csm_b$b.json 2> $O/csm_b$b.err; done
+for b in 1 8; do timeout 600 python tools/bench_glm.py --batch $b --greedy > $O/glm_b$b.json 2> $O/glm_b$b.err; done
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_csm -o csm -- python tools/bench_csm.py --batch 16 --steps 40 --warmup 10 > $O/csm_b16_prof.json 2> $O/csm_b16_prof.err
+cp $(find $O/prof_csm -name "*kernel_stats.csv" | head -1) $O/kernel_stats_csm_b16.csv; rm -rf $O/prof_csm
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_glm -o glm -- python tools/bench_glm.py --batch 8 --greedy --steps 40 --warmup 10 > $O/glm_b8_prof.json 2> $O/glm_b8_prof.err
+cp $(find $O/prof_glm -name "*kernel_stats.csv" | head -1) $O/kernel_stats_glm_b8.csv; rm -rf $O/prof_glm
+cat $O/csm_b16.json $O/glm_b8.json
