@@ -848,8 +848,67 @@ def g10_snac(ns):
     np.savez_compressed(os.path.join(HERE, "g10_snac.npz"), **out)
 
 
+def g11_hift(ns):
+    """HiFT vocoder through the reference HiFTGenerator.forward_chunk (tokenizer/hifigan.py:641-665), tiny and CosyVoice2 size,
+    fp32, with SineGen2's torch.rand / torch.randn_like replaced by the seeded streams of oracle/hift_ref.py (the noise contract);
+    plus cosyvoice2.fade_in_out."""
+    import importlib
+    from oracle import hift_ref as HR
+    Hm = importlib.import_module("vox_serve.tokenizer.hifigan")
+    out = {}
+    for tag, cfg, B, T in (("tiny", HR.tiny_hift_cfg(), 2, 6), ("full", HR.HiftCfg(), 2, 12)):
+        W = HR.random_hift_weights(cfg, seed=2)
+        m = Hm.HiFTGenerator(in_channels=cfg.in_channels, base_channels=cfg.base_channels, nb_harmonics=cfg.nb_harmonics,
+                             sampling_rate=cfg.sampling_rate, nsf_alpha=cfg.nsf_alpha, nsf_sigma=cfg.nsf_sigma,
+                             nsf_voiced_threshold=cfg.voiced_threshold, upsample_rates=list(cfg.upsample_rates),
+                             upsample_kernel_sizes=list(cfg.upsample_kernel_sizes),
+                             istft_params={"n_fft": cfg.n_fft, "hop_len": cfg.hop_len},
+                             resblock_kernel_sizes=list(cfg.resblock_kernel_sizes),
+                             resblock_dilation_sizes=[list(cfg.resblock_dilations)] * len(cfg.resblock_kernel_sizes),
+                             source_resblock_kernel_sizes=list(cfg.source_resblock_kernel_sizes),
+                             source_resblock_dilation_sizes=[list(cfg.resblock_dilations)] * len(cfg.source_resblock_kernel_sizes),
+                             lrelu_slope=cfg.lrelu_slope, audio_limit=cfg.audio_limit,
+                             f0_predictor=Hm.ConvRNNF0Predictor(in_channels=cfg.in_channels, cond_channels=cfg.f0_channels),
+                             device=torch.device("cpu")).eval()
+        m.load_state_dict(W, strict=True)
+        g = torch.Generator().manual_seed(11)
+        mel = (0.8 * torch.randn(B, cfg.in_channels, T, generator=g)).to(torch.bfloat16).float()
+        ini, nz = HR.make_noise(cfg, B, T, seed=91)
+        real_rand, real_randn_like = torch.rand, torch.randn_like
+        calls = {"rand": 0, "randn_like": 0}
+
+        def fake_rand(*shape, **kw):
+            calls["rand"] += 1
+            assert tuple(shape) == tuple(ini.shape), (shape, ini.shape)
+            return ini.clone()
+
+        def fake_randn_like(t, **kw):
+            calls["randn_like"] += 1
+            if tuple(t.shape) == tuple(nz.shape):
+                return nz.clone()
+            return torch.zeros_like(t)                      # SourceModuleHnNSF2's second draw: its `noise` output is not used
+        torch.rand, torch.randn_like = fake_rand, fake_randn_like
+        try:
+            wav, src = m.forward_chunk(mel)
+        finally:
+            torch.rand, torch.randn_like = real_rand, real_randn_like
+        assert calls == {"rand": 1, "randn_like": 2}, calls
+        f0 = m.f0_predictor(mel)
+        out[f"{tag}_mel"], out[f"{tag}_wav"], out[f"{tag}_source"] = mel.numpy(), wav.numpy().astype(np.float32), src.numpy().astype(np.float32)
+        out[f"{tag}_f0"] = f0.detach().numpy().astype(np.float32)
+        print("g11", tag, tuple(wav.shape), "rms", float(wav.pow(2).mean().sqrt()), "max", float(wav.abs().max()),
+              "voiced frac", float((f0 > cfg.voiced_threshold).float().mean()), "f0 mean", float(f0.mean()))
+    C2 = importlib.import_module("vox_serve.tokenizer.cosyvoice2")
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(2, 400, generator=g), torch.randn(2, 120, generator=g)
+    win = torch.from_numpy(np.hamming(2 * 96)).float()
+    out["fade_new"], out["fade_old"], out["fade_out"] = a.numpy(), b.numpy(), C2.fade_in_out(a, b, win).numpy()
+    out["noise_seed"] = np.int64(91)
+    np.savez_compressed(os.path.join(HERE, "g11_hift.npz"), **out)
+
+
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift}
 
 if __name__ == "__main__":
     ns = H.boot()

@@ -358,3 +358,39 @@ def test_philox_noise_is_standard_normal_and_stream_separated():
     a, b = SR.philox_noise(5, 0, 1 << 16), SR.philox_noise(5, 1, 1 << 16)
     assert abs(a.mean()) < 0.02 and abs(a.std() - 1) < 0.02 and abs(np.corrcoef(a, b)[0, 1]) < 0.02
     assert np.array_equal(a[:100], SR.philox_noise(5, 0, 100))          # counter-based: prefix-stable
+
+
+def test_hift_oracle_matches_reference_module(golden):
+    """oracle/hift_ref.py vs the reference HiFTGenerator.forward_chunk (g11): f0, harmonic source, waveform — tiny and CosyVoice2 size,
+    with the seeded phases / noise injected on both sides."""
+    import torch
+    from oracle import hift_ref as HR
+    g = golden("g11_hift")
+    for tag, cfg in (("tiny", HR.tiny_hift_cfg()), ("full", HR.HiftCfg())):
+        ref = HR.HiftRef(cfg, HR.random_hift_weights(cfg, seed=2))
+        mel = torch.from_numpy(g[f"{tag}_mel"])
+        B, _, T = mel.shape
+        ini, nz = HR.make_noise(cfg, B, T, seed=int(g["noise_seed"]))
+        f0 = ref.f0_predict(mel)
+        assert np.abs(f0.numpy() - g[f"{tag}_f0"]).max() < 1e-3 * max(1.0, float(np.abs(g[f"{tag}_f0"]).max()))
+        wav, src = ref.forward_chunk(mel, ini, nz)
+        assert wav.shape == (B, T * cfg.upsample_scale) and src.shape == (B, 1, T * cfg.upsample_scale)
+        es = float(np.sqrt(np.mean((src.numpy() - g[f"{tag}_source"]) ** 2)))
+        ew = float(np.sqrt(np.mean((wav.numpy() - g[f"{tag}_wav"]) ** 2)))
+        rw = float(np.sqrt(np.mean(g[f"{tag}_wav"] ** 2)))
+        assert es < 2e-5 and ew < 2e-5 and rw > 0.03, (tag, es, ew, rw)
+
+
+def test_hift_noise_contract_and_fade(golden):
+    import torch
+    from oracle import hift_ref as HR
+    g = golden("g11_hift")
+    cfg = HR.tiny_hift_cfg()
+    ini, nz = HR.make_noise(cfg, 3, 4, seed=5)
+    assert ini.shape == (3, 9) and nz.shape == (3, 4 * 96, 9) and float(ini[:, 0].abs().max()) == 0.0
+    assert 0.0 <= float(ini.min()) and float(ini.max()) < 1.0 and abs(float(nz.mean())) < 0.05 and abs(float(nz.std()) - 1.0) < 0.05
+    ini2, nz2 = HR.make_noise(cfg, 2, 4, seed=5, first_stream=2)              # request b of a batch == request 0 of a later call
+    assert torch.equal(ini2[0], ini[1]) and torch.equal(nz2[0], nz[1])
+    win = torch.from_numpy(np.hamming(2 * 96)).float()
+    out = HR.fade_in_out(torch.from_numpy(g["fade_new"]), torch.from_numpy(g["fade_old"]), win)
+    assert np.array_equal(out.numpy(), g["fade_out"])

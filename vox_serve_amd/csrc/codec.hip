@@ -47,7 +47,7 @@ __device__ __forceinline__ void split3(const float4 lo4, const float4 hi4, uint4
 #define CG_BM 64
 #define CG_BN 64
 #define CG_BK 32            // smallest K chunk (Cin granularity); 64-wide chunks are used where Cin allows
-#define CG_MAXTAPS 8
+#define CG_MAXTAPS 24          // (HiFT: 11-tap dilated convs with fp32 weights carried as two bf16 planes)
 
 struct ConvGemmArgs {
     const float* x;        // [n*L, Cin] current-chunk input rows
@@ -62,7 +62,7 @@ struct ConvGemmArgs {
                            // own serving precision: its decoder runs in bf16, qwen3_tts.py:1061-1064) at a third of the MFMA issue
     float* out;            // [M, N]
     int M, N, Cin, L, P, n_taps, bias_mod, gelu;
-    int off[CG_MAXTAPS];   // row look-back of each tap
+    int off[CG_MAXTAPS];   // row look-back of each tap (negative: look-ahead)
     // fused SnakeBeta of the NEXT layer's input: out2[m][n] = v + inv_beta[c] * sin(v * alpha[c])^2, c = n % sn_mod, beside
     // (out != NULL) or instead of (out == NULL) the plain output — the arithmetic of k_snake, one elementwise pass less
     float* out2;
@@ -120,9 +120,10 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
             v0[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             v1[i] = v0[i];
             if (a_ok[i]) {
-                const int st = a_t[i] - a.off[tap];
+                const int st = a_t[i] - a.off[tap];      // (off < 0: the tap looks ahead; rows past the request's end read as zero)
                 const float* arow = nullptr;
-                if (st >= 0) arow = a.x + ((size_t)a_b[i] * a.L + st) * a.Cin;
+                if (st >= a.L) arow = nullptr;
+                else if (st >= 0) arow = a.x + ((size_t)a_b[i] * a.L + st) * a.Cin;
                 else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[a_b[i]] * a.P + (a.P + st)) * a.Cin;
                 if (arow) {
                     v0[i] = *reinterpret_cast<const float4*>(arow + c0 + seg * 8);
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
             if (idx < 16 * SEGA && am < a.M) {
                 const int ab = am / a.L, st = am % a.L - a.off[tap];
                 const float* arow = nullptr;
-                if (st >= 0) arow = a.x + ((size_t)ab * a.L + st) * a.Cin;
+                if (st >= a.L) arow = nullptr;
+                else if (st >= 0) arow = a.x + ((size_t)ab * a.L + st) * a.Cin;
                 else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[ab] * a.P + (a.P + st)) * a.Cin;
                 if (arow) av[i] = *reinterpret_cast<const float4*>(arow + c0 + seg * 4);
             }
