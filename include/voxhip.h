@@ -443,6 +443,51 @@ void vox_snac_destroy(vox_snac* m);
 int vox_snac_decode(vox_snac* m, void* stream, const int32_t* codes, int n, int T, const float* noise, uint64_t seed,
                     const uint32_t* stream_base, float* out, int out_off, int out_len);
 
+/* ---- HiFT vocoder (mel -> waveform of the CosyVoice2 / GLM-4-Voice detokenizers) ----------------------------------------
+ * Replaces HiFTGenerator.forward_chunk (/root/reference/vox_serve/tokenizer/hifigan.py:641-665: ConvRNNF0Predictor :394-426,
+ * SourceModuleHnNSF2 / SineGen2 :251-391, _stft :542-552, decode :596-628 with ResBlock :98-141 and Snake :45-95,
+ * _istft_graph_safe :566-594) as CosyVoice2Decoder.decode_chunk calls it (tokenizer/cosyvoice2.py:1043-1046: no source cache).
+ * Stateless per chunk, fp32 activations time-major [request * t][C]; every conv / transposed conv is an implicit GEMM on the
+ * matrix cores with exact products (fp32 activations = three bf16 terms, fp32 weights = two bf16 planes).
+ * Weights: weight norm already folded.  A conv of kernel k (dilation d, "same" padding) is a vox_conv_w of 2k taps: the k taps of
+ * the high plane [j][Cout][Cin] (tap j reads row t + (j - (k-1)/2) d), then the k taps of the residual plane.  Cin is padded to a
+ * multiple of 32 with zero columns (conv_pre / f0 conv 0: mel channels).  ConvTranspose1d(k, stride u, padding (k-u)/2) is the
+ * taps d = dmin..dmax (dmin = ceil((-(k-u)/2 - (u-1)) / u), dmax = floor((k-1-(k-u)/2) / u)) of an N = u * Cout GEMM:
+ * W_d[phi * Cout + co][ci] = w[ci][co][d u + phi + (k-u)/2] (0 outside the kernel), tap d reads row t - d; bias_mod = Cout.
+ * source_downs are plain fp32 [Cout][n_fft + 2][k] (strided convs over the 18-row STFT of the source; direct kernel).
+ * Harmonic source: SineGen2's torch.rand initial phases never reach the output (the 1/scale linear resampling reads samples
+ * scale*j + scale/2 - 1 and scale*j + scale/2 only, the phases are added to sample 0), so only its additive noise is part of
+ * the contract: given (fp32 [n][T * scale][H + 1]) or generated on the device: Philox4x32-10 keyed by `seed`, counter
+ * (l * (H + 1) + h, stream, 0, 0), stream = stream_base[b] + 1 (stream_base NULL: 2 b + 1), Box-Muller of words 0 and 1 — the
+ * stream oracle/hift_ref.py::make_noise restates. */
+typedef struct { vox_conv_w c1[3], c2[3]; vox_snake_w a1[3], a2[3]; } vox_hift_resblock_w;
+typedef struct {
+    vox_conv_w f0_conv[5];             /* k3 convs of the f0 predictor (ELU after each); THREE weight planes (9 taps): the harmonic
+                                          source multiplies an f0 error by 2 pi scale T */
+    const float* f0_cls_w;             /* [f0_channels] */
+    float f0_cls_b;
+    const float* src_lin_w;            /* [H + 1] */
+    float src_lin_b;
+    vox_conv_w conv_pre;               /* k7 */
+    vox_conv_w ups[4];
+    const float *sd_w[4], *sd_b[4];    /* source_downs[i]: fp32 [Cout_i][n_fft + 2][k_i], [Cout_i] */
+    vox_hift_resblock_w src_rb[4];     /* source_resblocks[i] */
+    vox_hift_resblock_w rb[12];        /* resblocks[i * n_kernels + j] */
+    vox_conv_w conv_post;              /* k7, N = n_fft + 2 */
+} vox_hift_weights;
+typedef struct {
+    int32_t in_channels, in_channels_padded, base_channels, nb_harmonics, sampling_rate, n_stages, upsample_rates[4],
+        upsample_kernels[4], n_fft, hop_len, n_kernels, resblock_kernels[4], dilations[3], source_resblock_kernels[4], f0_channels;
+    float nsf_alpha, nsf_sigma, voiced_threshold, lrelu_slope, audio_limit;
+} vox_hift_config;
+typedef struct vox_hift vox_hift;
+int vox_hift_create(vox_ctx* ctx, const vox_hift_config* cfg, const vox_hift_weights* w, int max_batch, int max_T, vox_hift** out);
+void vox_hift_destroy(vox_hift* m);
+/* mel: device fp32 [n][in_channels][T] (the reference's layout); wav: fp32 [n][T * scale], scale = prod(upsample_rates) * hop_len;
+ * source (optional): fp32 [n][T * scale], the merged harmonic source (the reference returns it for its cache). */
+int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, const float* noise, uint64_t seed,
+                    const uint32_t* stream_base, float* wav, float* source);
+
 #ifdef __cplusplus
 }
 #endif

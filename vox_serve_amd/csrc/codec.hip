@@ -1395,3 +1395,356 @@ int vox_snac_decode(vox_snac* m, void* stream, const int32_t* codes, int n, int 
 }
 
 }  // extern "C"
+
+// ====================================================================================================================
+// HiFT vocoder (mel -> waveform; CosyVoice2 / GLM-4-Voice detokenizers).  See include/voxhip.h for the contract.
+// Layout: fp32 time-major [request][t][C].  Every conv / transposed conv runs on conv_gemm (look-ahead taps, two weight planes);
+// the harmonic source, the 16-point STFT / iSTFT and the strided source convs (Cin = 18) are direct kernels.
+// ====================================================================================================================
+// mel [n][Cm][T] -> x [n*T][Cp] (channels >= Cm zero)
+__global__ __launch_bounds__(256) void k_hift_mel_in(const float* mel, float* x, int n, int Cm, int Cp, int T) {
+    const size_t total = (size_t)n * T * Cp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % Cp);
+        const size_t row = i / Cp;
+        const int b = (int)(row / T), t = (int)(row % T);
+        x[i] = c < Cm ? mel[((size_t)b * Cm + c) * T + t] : 0.0f;
+    }
+}
+// f0[row] = |w . x[row] + b|: one wave per row (hifigan.py:423-426)
+__global__ __launch_bounds__(256) void k_hift_f0cls(const float* x, const float* w, float bias, float* f0, int rows, int C) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.0f;
+    for (int c = lane; c < C; c += 64) s = fmaf(x[(size_t)row * C + c], w[c], s);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) f0[row] = fabsf(s + bias);
+}
+// phase at the frame rate (hifigan.py:296-313): rad = (f0 h / sr) mod 1 (what the 1/scale linear resampling of the sample-rate
+// track returns exactly), cumulative sum over the frames (accumulated in double like torch.cumsum on the CPU), * 2 * pi * scale
+__global__ void k_hift_phase(const float* f0, float* ph, int n, int T, int H1, float sr, float scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * H1) return;
+    const int b = i / H1, h = i % H1;
+    double cum = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const float fn = f0[(size_t)b * T + t] * (float)(h + 1);
+        float r = fn / sr;
+        r = r - floorf(r);
+        cum += (double)r;
+        ph[((size_t)b * T + t) * H1 + h] = (((float)cum * 2.0f) * 3.14159274101257324f) * scale;
+    }
+}
+// merged harmonic source s[b][l] (hifigan.py:314-316, 334-343, 386-388): linear interpolation of the frame-rate phase back to the
+// sample rate (torch upsample_linear1d, align_corners = False), sin, voiced / unvoiced noise, tanh(linear)
+__global__ __launch_bounds__(256) void k_hift_source(const float* f0, const float* ph, const float* noise, uint64_t seed,
+                                                      const uint32_t* stream_base, const float* lw, float lb, float* s, int n, int T,
+                                                      int H1, int scale, float rscale, float alpha, float sigma, float vth) {
+    const size_t L = (size_t)T * scale, total = (size_t)n * L;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / L);
+        const size_t l = i % L;
+        const float uv = f0[(size_t)b * T + l / scale] > vth ? 1.0f : 0.0f;
+        const float amp = uv * sigma + (1.0f - uv) * alpha / 3.0f;
+        float src = rscale * ((float)l + 0.5f) - 0.5f;
+        src = src < 0.0f ? 0.0f : src;
+        const int i0 = (int)src, i1 = i0 + (i0 < T - 1 ? 1 : 0);
+        float l1 = src - (float)i0;
+        l1 = l1 < 0.0f ? 0.0f : (l1 > 1.0f ? 1.0f : l1);
+        const float l0 = 1.0f - l1;
+        const uint32_t stream = stream_base ? stream_base[b] + 1u : (uint32_t)(2 * b + 1);
+        float acc = 0.0f;
+        for (int h = 0; h < H1; ++h) {
+            const float p = l0 * ph[((size_t)b * T + i0) * H1 + h] + l1 * ph[((size_t)b * T + i1) * H1 + h];
+            float nz;
+            if (noise) nz = noise[i * H1 + h];
+            else {
+                uint32_t w0, w1;
+                philox4((uint32_t)(l * H1 + h), stream, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), &w0, &w1);
+                const float u1 = ((float)(w0 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+                nz = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+            }
+            const float sw = (sinf(p) * alpha) * uv + amp * nz;
+            acc = fmaf(sw, lw[h], acc);
+        }
+        s[i] = tanhf(acc + lb);
+    }
+}
+// STFT of the source (torch.stft: n_fft 16, hop 4, periodic Hann, center = True with reflect padding): S[b][f][k] real rows
+// 0..nb-1, imaginary rows nb..2nb-1; one thread per (b, frame, bin)
+__global__ __launch_bounds__(256) void k_hift_stft(const float* s, float* S, int n, int L, int F, int nfft, int hop) {
+    const int nb = nfft / 2 + 1;
+    const size_t total = (size_t)n * F * nb;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % nb);
+        const size_t bf = i / nb;
+        const int b = (int)(bf / F), f = (int)(bf % F);
+        float re = 0.0f, im = 0.0f;
+        for (int j = 0; j < nfft; ++j) {
+            int q = f * hop + j - nfft / 2;
+            q = q < 0 ? -q : (q >= L ? 2 * (L - 1) - q : q);
+            const float win = 0.5f - 0.5f * cospif(2.0f * (float)j / (float)nfft);
+            const float v = s[(size_t)b * L + q] * win;
+            const float ang = 2.0f * (float)((k * j) % nfft) / (float)nfft;      // in units of pi
+            re = fmaf(v, cospif(ang), re);
+            im = fmaf(-v, sinpif(ang), im);
+        }
+        S[bf * (2 * nb) + k] = re;
+        S[bf * (2 * nb) + nb + k] = im;
+    }
+}
+// source_downs[i]: strided conv over the STFT frames, Cin = 2 nb (hifigan.py:497-510): out[b][t][co]
+__global__ __launch_bounds__(256) void k_hift_sd(const float* S, const float* w, const float* bias, float* out, int n, int F, int Cin,
+                                                  int Lo, int Cout, int k, int stride, int pad) {
+    const size_t total = (size_t)n * Lo * Cout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i % Cout);
+        const size_t row = i / Cout;
+        const int b = (int)(row / Lo), t = (int)(row % Lo);
+        float acc = bias[co];
+        for (int j = 0; j < k; ++j) {
+            const int f = t * stride - pad + j;
+            if (f < 0 || f >= F) continue;
+            const float* sr = S + ((size_t)b * F + f) * Cin;
+            for (int ci = 0; ci < Cin; ++ci) acc = fmaf(sr[ci], w[((size_t)co * Cin + ci) * k + j], acc);
+        }
+        out[i] = acc;
+    }
+}
+// x = pad(y) + si (ReflectionPad1d((1, 0)) on the last stage: row 0 = row 1 of y) and the first Snake of the three resblocks
+__global__ __launch_bounds__(256) void k_hift_add_snake3(const float* y, const float* si, float* x, float* a0, float* a1, float* a2,
+                                                          const float* al0, const float* ib0, const float* al1, const float* ib1,
+                                                          const float* al2, const float* ib2, int n, int Ly, int Lx, int C) {
+    const size_t total = (size_t)n * Lx * C;
+    const int padl = Lx - Ly;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t row = i / C;
+        const int b = (int)(row / Lx), t = (int)(row % Lx);
+        int ty = t - padl;
+        ty = ty < 0 ? -ty : ty;
+        const float v = y[((size_t)b * Ly + ty) * C + c] + si[i];
+        x[i] = v;
+        float s_;
+        s_ = sinf(v * al0[c]); a0[i] = v + ib0[c] * (s_ * s_);
+        if (a1) { s_ = sinf(v * al1[c]); a1[i] = v + ib1[c] * (s_ * s_); }
+        if (a2) { s_ = sinf(v * al2[c]); a2[i] = v + ib2[c] * (s_ * s_); }
+    }
+}
+// x = leaky_relu(((r0 + r1) + r2) / nk, slope)   (hifigan.py:613-621; r1 / r2 NULL when fewer kernels)
+__global__ __launch_bounds__(256) void k_hift_avg_lrelu(const float* r0, const float* r1, const float* r2, float* x, size_t total, float nk,
+                                                         float slope) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float v = r0[i];
+        if (r1) v = v + r1[i];
+        if (r2) v = v + r2[i];
+        if (nk != 1.0f) v = v / nk;
+        x[i] = v > 0.0f ? v : v * slope;
+    }
+}
+// magnitude / phase heads -> irfft per frame -> window -> overlap-add / window^2 -> trim n_fft/2 -> clamp  (hifigan.py:554-594, 623-628)
+// one thread per output sample; P[b][f][0..nb-1] = log-magnitude rows, [nb..2nb-1] = phase rows
+__global__ __launch_bounds__(256) void k_hift_istft(const float* P, float* wav, int n, int F, int nfft, int hop, int Lout, float limit) {
+    const int nb = nfft / 2 + 1;
+    const size_t total = (size_t)n * Lout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / Lout), l = (int)(i % Lout);
+        const int q = l + nfft / 2;                        // position in the untrimmed signal
+        float acc = 0.0f, den = 0.0f;
+        int f_hi = q / hop;
+        f_hi = f_hi > F - 1 ? F - 1 : f_hi;
+        int f_lo = (q - nfft) / hop + 1;
+        f_lo = (q - nfft) < 0 ? 0 : f_lo;
+        for (int f = f_lo; f <= f_hi; ++f) {               // ascending frame order, like F.fold's accumulation
+            const int j = q - f * hop;
+            if (j < 0 || j >= nfft) continue;
+            const float* pf = P + ((size_t)b * F + f) * (2 * nb);
+            float v = 0.0f;
+            for (int k = 0; k < nb; ++k) {
+                float mag = expf(pf[k]);
+                mag = mag > 1e2f ? 1e2f : mag;
+                const float ph = sinf(pf[nb + k]);
+                const float re = mag * cosf(ph), im = mag * sinf(ph);
+                const float ang = 2.0f * (float)((k * j) % nfft) / (float)nfft;
+                if (k == 0 || k == nb - 1) v += re * cospif(ang);                       // irfft ignores the imaginary part of DC / Nyquist
+                else v += 2.0f * (re * cospif(ang) - im * sinpif(ang));
+            }
+            const float win = 0.5f - 0.5f * cospif(2.0f * (float)j / (float)nfft);
+            acc += (v / (float)nfft) * win;
+            den += win * win;
+        }
+        den = den > 1e-8f ? den : 1.0f;
+        float o = acc / den;
+        o = o < -limit ? -limit : (o > limit ? limit : o);
+        wav[i] = o;
+    }
+}
+
+struct vox_hift {
+    vox_ctx* ctx;
+    vox_hift_config cfg;
+    vox_hift_weights w;
+    int max_batch, max_T, scale;
+    float* buf[9];
+    size_t buf_floats;
+    float *f0, *ph, *src, *stft, *post;
+};
+
+static int hift_conv_offsets(int k, int dil, int* off, int planes = 2) {   // "same" conv: tap j reads row t + (j - (k-1)/2) dil
+    const int pad = (k - 1) * dil / 2;
+    for (int p = 0; p < planes; ++p)
+        for (int j = 0; j < k; ++j) off[p * k + j] = pad - j * dil;
+    return planes * k;
+}
+static int hift_tconv_offsets(int k, int u, int* off) {           // ConvTranspose1d(k, stride u, padding (k-u)/2): taps d = dmin..dmax, two planes
+    const int p = (k - u) / 2;
+    int dmin = -((p + (u - 1)) / u), dmax = (k - 1 - p) / u;
+    while (dmin * u + (u - 1) + p < 0) ++dmin;
+    const int nd = dmax - dmin + 1;
+    for (int pl = 0; pl < 2; ++pl)
+        for (int d = 0; d < nd; ++d) off[pl * nd + d] = dmin + d;
+    return 2 * nd;
+}
+
+extern "C" {
+
+void vox_hift_destroy(vox_hift* m) {
+    if (!m) return;
+    for (int i = 0; i < 9; ++i) (void)hipFree(m->buf[i]);
+    (void)hipFree(m->f0); (void)hipFree(m->ph); (void)hipFree(m->src); (void)hipFree(m->stft); (void)hipFree(m->post);
+    delete m;
+}
+
+int vox_hift_create(vox_ctx* ctx, const vox_hift_config* cfg, const vox_hift_weights* w, int max_batch, int max_T, vox_hift** out) {
+    if (!ctx || !cfg || !w || !out) return vox_fail(VOX_ERR_INVALID, "hift_create: NULL");
+    if (cfg->n_stages < 1 || cfg->n_stages > 4 || cfg->n_kernels < 1 || cfg->n_kernels > 3 || max_batch < 1 || max_T < 1 ||
+        cfg->in_channels_padded % 32 || cfg->in_channels > cfg->in_channels_padded || cfg->n_fft % 2 || cfg->nb_harmonics > 15)
+        return vox_fail(VOX_ERR_INVALID, "hift_create: bad config");
+    vox_hift* m = new vox_hift();
+    m->ctx = ctx; m->cfg = *cfg; m->w = *w; m->max_batch = max_batch; m->max_T = max_T;
+    m->scale = cfg->hop_len;
+    size_t rows = max_T, worst = (size_t)max_T * cfg->base_channels;
+    int ch = cfg->base_channels;
+    if ((size_t)max_T * cfg->f0_channels > worst) worst = (size_t)max_T * cfg->f0_channels;
+    if ((size_t)max_T * cfg->in_channels_padded > worst) worst = (size_t)max_T * cfg->in_channels_padded;
+    for (int i = 0; i < cfg->n_stages; ++i) {
+        if ((cfg->upsample_kernels[i] - cfg->upsample_rates[i]) < 0) { delete m; return vox_fail(VOX_ERR_INVALID, "hift_create: kernel < stride"); }
+        rows *= cfg->upsample_rates[i]; ch /= 2; m->scale *= cfg->upsample_rates[i];
+        if ((rows + 1) * ch > worst) worst = (rows + 1) * ch;
+        if (ch % 32) { delete m; return vox_fail(VOX_ERR_INVALID, "hift_create: stage channels must be multiples of 32"); }
+    }
+    m->buf_floats = worst * max_batch;
+    const size_t L = (size_t)max_T * m->scale, F = rows + 1;
+    bool ok = true;
+    for (int i = 0; i < 9; ++i) ok = ok && hipMalloc((void**)&m->buf[i], m->buf_floats * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&m->f0, (size_t)max_batch * max_T * 4) == hipSuccess &&
+         hipMalloc((void**)&m->ph, (size_t)max_batch * max_T * (cfg->nb_harmonics + 1) * 4) == hipSuccess &&
+         hipMalloc((void**)&m->src, (size_t)max_batch * L * 4) == hipSuccess &&
+         hipMalloc((void**)&m->stft, (size_t)max_batch * F * (cfg->n_fft + 2) * 4) == hipSuccess &&
+         hipMalloc((void**)&m->post, (size_t)max_batch * F * (cfg->n_fft + 2) * 4) == hipSuccess;
+    if (!ok) { vox_hift_destroy(m); return vox_fail(VOX_ERR_NOMEM, "hift_create: hipMalloc failed"); }
+    *out = m;
+    return VOX_OK;
+}
+
+// one ResBlock (hifigan.py:134-141) on rows L per request: a = snake1_0(x) is given; result in `r` (x itself is left untouched);
+// t1 scratch.  The next iteration's first Snake and this iteration's second Snake are fused into the producing conv's epilogue.
+static int hift_resblock(hipStream_t st, const vox_hift_resblock_w& rb, const vox_hift_config& c, int k, const float* x, float* a, float* t1,
+                         float* r, int n, int L) {
+    int off1[CG_MAXTAPS], off2[CG_MAXTAPS];
+    hift_conv_offsets(k, 1, off2);
+    for (int j = 0; j < 3; ++j) {
+        hift_conv_offsets(k, c.dilations[j], off1);
+        VOX_TRY(conv_gemm(st, rb.c1[j], a, nullptr, nullptr, n, L, 0, off1, nullptr, nullptr, nullptr, 0, t1, &rb.a2[j]));
+        VOX_TRY(conv_gemm(st, rb.c2[j], t1, nullptr, nullptr, n, L, 0, off2, r, j == 0 ? x : r, nullptr, 0, j < 2 ? a : nullptr,
+                          j < 2 ? &rb.a1[j + 1] : nullptr));
+    }
+    return VOX_OK;
+}
+
+int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, const float* noise, uint64_t seed,
+                    const uint32_t* stream_base, float* wav, float* source) {
+    if (!m || !mel || !wav) return vox_fail(VOX_ERR_INVALID, "hift_decode: NULL");
+    if (n < 1 || n > m->max_batch || T < 1 || T > m->max_T) return vox_fail(VOX_ERR_INVALID, "hift_decode: n %d / T %d out of range", n, T);
+    const vox_hift_config& c = m->cfg;
+    const vox_hift_weights& w = m->w;
+    hipStream_t st = (hipStream_t)stream;
+    g_conv_planes = 3;
+    const int H1 = c.nb_harmonics + 1, nb2 = c.n_fft + 2;
+    const size_t L = (size_t)T * m->scale;
+    float** B = m->buf;
+    int off[CG_MAXTAPS];
+    // ---- f0 predictor: 5 x (conv k3 + ELU), linear, abs ----
+    hipLaunchKernelGGL(k_hift_mel_in, dim3(ew_grid((size_t)n * T * c.in_channels_padded)), dim3(256), 0, st, mel, B[0], n, c.in_channels,
+                       c.in_channels_padded, T);
+    hift_conv_offsets(3, 1, off, 3);          // (three weight planes: the source's phase multiplies an f0 error by 2 pi scale T)
+    {
+        const float* in = B[0];
+        for (int i = 0; i < 5; ++i) {
+            float* o = (i & 1) ? B[2] : B[1];
+            VOX_TRY(conv_gemm(st, w.f0_conv[i], in, nullptr, nullptr, n, T, 0, off, o, nullptr, nullptr, 0));
+            elu(st, o, o, (size_t)n * T * c.f0_channels);
+            in = o;
+        }
+        hipLaunchKernelGGL(k_hift_f0cls, dim3((n * T + 3) / 4), dim3(256), 0, st, in, w.f0_cls_w, w.f0_cls_b, m->f0, n * T, c.f0_channels);
+    }
+    // ---- harmonic source + its STFT ----
+    hipLaunchKernelGGL(k_hift_phase, dim3((n * H1 + 63) / 64), dim3(64), 0, st, m->f0, m->ph, n, T, H1, (float)c.sampling_rate, (float)m->scale);
+    hipLaunchKernelGGL(k_hift_source, dim3(ew_grid((size_t)n * L)), dim3(256), 0, st, m->f0, m->ph, noise, seed, stream_base, w.src_lin_w,
+                       w.src_lin_b, m->src, n, T, H1, m->scale, (float)(1.0 / (double)m->scale), c.nsf_alpha, c.nsf_sigma, c.voiced_threshold);
+    if (source) (void)hipMemcpyAsync(source, m->src, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st);
+    const int F = (int)(L / c.hop_len) + 1;
+    hipLaunchKernelGGL(k_hift_stft, dim3(ew_grid((size_t)n * F * (c.n_fft / 2 + 1))), dim3(256), 0, st, m->src, m->stft, n, (int)L, F, c.n_fft,
+                       c.hop_len);
+    // ---- conv_pre ----
+    hift_conv_offsets(7, 1, off);
+    VOX_TRY(conv_gemm(st, w.conv_pre, B[0], nullptr, nullptr, n, T, 0, off, B[1], nullptr, nullptr, 0));
+    hipLaunchKernelGGL(k_hift_avg_lrelu, dim3(ew_grid((size_t)n * T * c.base_channels)), dim3(256), 0, st, B[1], nullptr, nullptr, B[1],
+                       (size_t)n * T * c.base_channels, 1.0f, c.lrelu_slope);
+    float* cur = B[1];                     // leaky_relu'ed stage input
+    int Lc = T, ch = c.base_channels;
+    // strides of source_downs: cumulative products of the LATER stages' rates (hifigan.py:497-500)
+    for (int i = 0; i < c.n_stages; ++i) {
+        const int u = c.upsample_rates[i], k = c.upsample_kernels[i], cout = ch / 2;
+        const bool last = i == c.n_stages - 1;
+        const int Ly = Lc * u, Lx = last ? Ly + 1 : Ly;
+        // pick working buffers distinct from `cur`
+        float* pool[8];
+        int np = 0;
+        for (int q = 0; q < 9; ++q) if (B[q] != cur) pool[np++] = B[q];
+        float *Y = pool[0], *S = pool[1], *A = pool[2], *T1 = pool[3], *X = pool[4], *A1 = pool[5], *A2 = pool[6], *R2 = pool[7];
+        hift_tconv_offsets(k, u, off);
+        VOX_TRY(conv_gemm(st, w.ups[i], cur, nullptr, nullptr, n, Lc, 0, off, Y, nullptr, nullptr, 0));
+        int sstride = 1;
+        for (int q = i + 1; q < c.n_stages; ++q) sstride *= c.upsample_rates[q];
+        const int sk = sstride == 1 ? 1 : 2 * sstride, spad = sstride == 1 ? 0 : sstride / 2;
+        if ((F + 2 * spad - sk) / sstride + 1 != Lx) return vox_fail(VOX_ERR_INVALID, "hift_decode: source / stage length mismatch at stage %d", i);
+        hipLaunchKernelGGL(k_hift_sd, dim3(ew_grid((size_t)n * Lx * cout)), dim3(256), 0, st, m->stft, w.sd_w[i], w.sd_b[i], S, n, F, nb2, Lx, cout,
+                           sk, sstride, spad);
+        // source resblock: S <- resblock(S)
+        snake(st, S, w.src_rb[i].a1[0], A, (size_t)n * Lx, cout);
+        VOX_TRY(hift_resblock(st, w.src_rb[i], c, c.source_resblock_kernels[i], S, A, T1, X, n, Lx));       // result in X (scratch here)
+        // x = pad(Y) + si, first Snakes of the stage's resblocks
+        const vox_hift_resblock_w* rb = &w.rb[i * c.n_kernels];
+        float* Si = X;                      // source branch output
+        float* Xs = S;                      // stage tensor (S is free now)
+        hipLaunchKernelGGL(k_hift_add_snake3, dim3(ew_grid((size_t)n * Lx * cout)), dim3(256), 0, st, Y, Si, Xs, A, c.n_kernels > 1 ? A1 : nullptr,
+                           c.n_kernels > 2 ? A2 : nullptr, rb[0].a1[0].alpha, rb[0].a1[0].inv_beta, c.n_kernels > 1 ? rb[1].a1[0].alpha : nullptr,
+                           c.n_kernels > 1 ? rb[1].a1[0].inv_beta : nullptr, c.n_kernels > 2 ? rb[2].a1[0].alpha : nullptr,
+                           c.n_kernels > 2 ? rb[2].a1[0].inv_beta : nullptr, n, Ly, Lx, cout);
+        float* Rs[3] = {Y, Si, R2};         // Y and the source output are free after the add
+        float* As[3] = {A, A1, A2};
+        for (int r = 0; r < c.n_kernels; ++r) VOX_TRY(hift_resblock(st, rb[r], c, c.resblock_kernels[r], Xs, As[r], T1, Rs[r], n, Lx));
+        // average + the next stage's leaky_relu (slope 0.01 before conv_post: F.leaky_relu's default)
+        hipLaunchKernelGGL(k_hift_avg_lrelu, dim3(ew_grid((size_t)n * Lx * cout)), dim3(256), 0, st, Rs[0], c.n_kernels > 1 ? Rs[1] : nullptr,
+                           c.n_kernels > 2 ? Rs[2] : nullptr, Xs, (size_t)n * Lx * cout, (float)c.n_kernels, last ? 0.01f : c.lrelu_slope);
+        cur = Xs; Lc = Lx; ch = cout;
+    }
+    if (Lc != F) return vox_fail(VOX_ERR_INVALID, "hift_decode: frame count mismatch");
+    hift_conv_offsets(7, 1, off);
+    VOX_TRY(conv_gemm(st, w.conv_post, cur, nullptr, nullptr, n, Lc, 0, off, m->post, nullptr, nullptr, 0));
+    hipLaunchKernelGGL(k_hift_istft, dim3(ew_grid((size_t)n * L)), dim3(256), 0, st, m->post, wav, n, F, c.n_fft, c.hop_len, (int)L, c.audio_limit);
+    return VOX_OK;
+}
+
+}  // extern "C"
