@@ -907,8 +907,105 @@ def g11_hift(ns):
     np.savez_compressed(os.path.join(HERE, "g11_hift.npz"), **out)
 
 
+def _ref_cosyvoice2_decoder(ns, fc, hc, Wf, Wh):
+    """The reference CosyVoice2Decoder's modules (flow + hift) with the given weights, fp32, on a stub object: its constructor
+    downloads checkpoints, its methods only need these attributes (tokenizer/cosyvoice2.py:774-860)."""
+    import importlib
+    Fm = importlib.import_module("vox_serve.tokenizer.cosyvoice_flow")
+    Hm = importlib.import_module("vox_serve.tokenizer.hifigan")
+    C2 = importlib.import_module("vox_serve.tokenizer.cosyvoice2")
+    enc = Fm.UpsampleConformerEncoder(output_size=fc.dim, attention_heads=fc.enc_heads, linear_units=fc.enc_ffn, num_blocks=fc.enc_layers,
+                                      input_size=fc.dim)
+    est = Fm.CausalConditionalDecoder(in_channels=fc.est_in, out_channels=fc.mel, channels=[fc.est_ch], dropout=0.0,
+                                      attention_head_dim=fc.est_head_dim, n_blocks=fc.est_blocks, num_mid_blocks=fc.est_mid,
+                                      num_heads=fc.est_heads, act_fn="gelu")
+    cfm = Fm.CausalConditionalCFM(in_channels=3 * fc.mel, spk_emb_dim=fc.mel, estimator=est)
+    flow = Fm.CausalMaskedDiffWithXvec(input_size=fc.dim, output_size=fc.mel, spk_embed_dim=fc.spk_dim, vocab_size=fc.vocab,
+                                       encoder=enc, decoder=cfm)
+    flow.load_state_dict(Wf, strict=True)
+    flow.eval()
+    hift = Hm.HiFTGenerator(in_channels=hc.in_channels, base_channels=hc.base_channels, sampling_rate=hc.sampling_rate,
+                            upsample_rates=list(hc.upsample_rates), upsample_kernel_sizes=list(hc.upsample_kernel_sizes),
+                            source_resblock_kernel_sizes=list(hc.source_resblock_kernel_sizes),
+                            source_resblock_dilation_sizes=[list(hc.resblock_dilations)] * 3,
+                            f0_predictor=Hm.ConvRNNF0Predictor(in_channels=hc.in_channels, cond_channels=hc.f0_channels),
+                            device=torch.device("cpu")).eval()
+    hift.load_state_dict(Wh, strict=True)
+    stub = types.SimpleNamespace(flow=flow, hift=hift, device=torch.device("cpu"), shared_prompt_cache_mode=True, mel_cache_len=6,
+                                 source_cache_len=6 * 480, speech_window=torch.from_numpy(np.hamming(2 * 6 * 480)),
+                                 MAX_CACHE_LEN=128, PREFIX_LEN=16)
+    return stub, C2, flow
+
+
+def g12_flow(ns):
+    """CosyVoice2 detokenizer through the reference: CosyVoice2Decoder.init_cache on a synthetic prompt, then decode_chunk in the
+    (default) shared-prompt mode — flow.forward_chunk (conformer encoder + 10-step CFM with classifier-free guidance, static prompt
+    caches) -> HiFT -> fade / trim — fp32, tiny and CosyVoice2 size, with every torch.randn / rand / randn_like replaced by the seeded
+    streams of oracle/flow_ref.py / oracle/hift_ref.py (the noise contract)."""
+    from oracle import flow_ref as FR, hift_ref as HR
+    import contextlib
+    out = {}
+    for tag, fc, hc, Np in (("tiny", FR.tiny_flow_cfg(), HR.HiftCfg(base_channels=256, f0_channels=64), 9),
+                            ("full", FR.FlowCfg(), HR.HiftCfg(), 40)):
+        Wf, Wh = FR.random_flow_weights(fc, seed=3), HR.random_hift_weights(hc, seed=2)
+        stub, C2, flow = _ref_cosyvoice2_decoder(ns, fc, hc, Wf, Wh)
+        g = torch.Generator().manual_seed(21)
+        B, T = 2, 28
+        ptok = torch.randint(0, fc.vocab, (1, Np), generator=g)
+        pfeat = (0.7 * torch.randn(1, 2 * Np, fc.mel, generator=g)).to(torch.bfloat16).float()
+        spk = torch.randn(1, fc.spk_dim, generator=g).to(torch.bfloat16).float()
+        tok = torch.randint(0, fc.vocab, (B, T), generator=g)
+        seed = 33
+        ini, nz = HR.make_noise(hc, B, 2 * T, seed=seed, first_stream=16)
+        queue = []
+        real = (torch.randn, torch.rand, torch.randn_like)
+
+        def fake_randn(*shape, **kw):
+            shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+            z = queue.pop(0)
+            assert tuple(z.shape) == shape, (z.shape, shape)
+            return z.clone()
+
+        def fake_rand(*shape, **kw):
+            return ini.clone()
+
+        def fake_randn_like(t, **kw):
+            return nz.clone() if tuple(t.shape) == tuple(nz.shape) else torch.zeros_like(t)
+        ref_dict = {"prompt_speech_token": ptok, "prompt_speech_token_len": Np, "prompt_feat": pfeat, "prompt_feat_len": 2 * Np,
+                    "embedding": spk}
+        torch.randn, torch.rand, torch.randn_like = fake_randn, fake_rand, fake_randn_like
+        try:
+            with contextlib.redirect_stdout(open(os.devnull, "w")), torch.no_grad():
+                queue.append(FR.cfm_noise(seed, 0, fc.mel, 2 * (Np + 3)))
+                cache = C2.CosyVoice2Decoder.init_cache(stub, ref_dict)
+                # the mels of the chunk (decode_chunk does not return them): the same call it makes
+                queue.append(FR.cfm_noise(seed, 1, fc.mel, 2 * T))
+                ec, dc = cache.flow_encoder_cache, cache.flow_decoder_cache
+                mels, _, _ = flow.forward_chunk(token=tok, token_len=torch.full((B,), T), prompt_feat=torch.zeros(1, 0, fc.mel), prompt_feat_len=0,
+                                                embedding=spk, encoder_cache=type(ec)(conformer_att_cache=ec.conformer_att_cache.expand(B, -1, -1, -1, -1),
+                                                                                      up_conformer_att_cache=ec.up_conformer_att_cache.expand(B, -1, -1, -1, -1)),
+                                                decoder_cache=type(dc)(cnn_cache=[[k.expand(B, -1, -1, -1) for k in st] for st in dc.cnn_cache],
+                                                                       att_cache=dc.att_cache.expand(B, -1, -1, -1, -1, -1, -1)),
+                                                last_chunk=False, return_cache=False)
+                queue.append(FR.cfm_noise(seed, 1, fc.mel, 2 * T))
+                audio, _ = C2.CosyVoice2Decoder.decode_chunk(stub, tok, T, cache, ref_dict=ref_dict)
+        finally:
+            torch.randn, torch.rand, torch.randn_like = real
+        assert not queue
+        out[f"{tag}_prompt_token"], out[f"{tag}_prompt_feat"], out[f"{tag}_spk"] = ptok.numpy().astype(np.int32), pfeat.numpy(), spk.numpy()
+        out[f"{tag}_token"] = tok.numpy().astype(np.int32)
+        out[f"{tag}_mel"], out[f"{tag}_audio"] = mels.numpy().astype(np.float32), audio.float().numpy().astype(np.float32)
+        out[f"{tag}_cache_lens"] = np.array([ec.conformer_att_cache.shape[3], ec.up_conformer_att_cache.shape[3], dc.att_cache.shape[5]], np.int32)
+        out[f"{tag}_att_cache_sum"] = np.float64(dc.att_cache.double().sum().item())
+        out[f"{tag}_up_cache_last"] = ec.up_conformer_att_cache[0, -1, 0, -1].numpy().astype(np.float32)
+        print("g12", tag, "mel", tuple(mels.shape), "rms", float(mels.pow(2).mean().sqrt()), "audio", tuple(audio.shape), "rms",
+              float(audio.float().pow(2).mean().sqrt()), "cache lens", out[f"{tag}_cache_lens"])
+    out["noise_seed"] = np.int64(33)
+    np.savez_compressed(os.path.join(HERE, "g12_flow.npz"), **out)
+
+
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow}
 
 if __name__ == "__main__":
     ns = H.boot()

@@ -394,3 +394,31 @@ def test_hift_noise_contract_and_fade(golden):
     win = torch.from_numpy(np.hamming(2 * 96)).float()
     out = HR.fade_in_out(torch.from_numpy(g["fade_new"]), torch.from_numpy(g["fade_old"]), win)
     assert np.array_equal(out.numpy(), g["fade_out"])
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_flow_oracle_matches_reference_decoder(golden, tag):
+    """oracle/flow_ref.py vs the reference CosyVoice2Decoder.init_cache + decode_chunk (g12, shared-prompt mode): cache lengths after the
+    sliding-window truncation, cache contents (checksums), the chunk's mels and the final audio, with the seeded noise on both sides."""
+    import torch
+    from oracle import flow_ref as FR, hift_ref as HR
+    g = golden("g12_flow")
+    fc, hc = (FR.tiny_flow_cfg(), HR.HiftCfg(base_channels=256, f0_channels=64)) if tag == "tiny" else (FR.FlowCfg(), HR.HiftCfg())
+    fr, hr = FR.FlowRef(fc, FR.random_flow_weights(fc, seed=3)), HR.HiftRef(hc, HR.random_hift_weights(hc, seed=2))
+    seed = int(g["noise_seed"])
+    ptok, pfeat, spk = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("prompt_token", "prompt_feat", "spk"))
+    tok = torch.from_numpy(g[f"{tag}_token"]).long()
+    Np, (B, T) = ptok.shape[1], tok.shape
+    with torch.no_grad():
+        _, cache = fr.init_cache(ptok.long(), pfeat, spk, FR.cfm_noise(seed, 0, fc.mel, 2 * (Np + 3)))
+        lens = [cache["enc"].shape[3], cache["up"].shape[3], cache["att"].shape[5]]
+        assert lens == g[f"{tag}_cache_lens"].tolist()
+        assert abs(float(cache["att"].double().sum()) - float(g[f"{tag}_att_cache_sum"])) < 1e-3 * max(1.0, abs(float(g[f"{tag}_att_cache_sum"])))
+        assert np.abs(cache["up"][0, -1, 0, -1].numpy() - g[f"{tag}_up_cache_last"]).max() < 1e-4
+        ini, nz = HR.make_noise(hc, B, 2 * T, seed=seed, first_stream=16)
+        audio, mel = FR.decode_chunk_shared(fr, hr, tok, spk, cache, FR.cfm_noise(seed, 1, fc.mel, 2 * T), ini, nz)
+    em = float(np.sqrt(np.mean((mel.numpy() - g[f"{tag}_mel"]) ** 2)))
+    ea = float(np.sqrt(np.mean((audio.numpy() - g[f"{tag}_audio"]) ** 2)))
+    assert mel.shape == (B, fc.mel, 2 * T) and audio.shape == (B, 24000)
+    assert em < 2e-5 * max(1.0, float(np.sqrt(np.mean(g[f"{tag}_mel"] ** 2)))), em
+    assert ea < 5e-5, ea
