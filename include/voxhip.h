@@ -488,6 +488,66 @@ void vox_hift_destroy(vox_hift* m);
 int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, const float* noise, uint64_t seed,
                     const uint32_t* stream_base, float* wav, float* source);
 
+/* ---- CosyVoice2 flow: speech tokens -> mel (conformer encoder + 10-step conditional flow matching) -----------------------
+ * Replaces CausalMaskedDiffWithXvec.forward_chunk (/root/reference/vox_serve/tokenizer/cosyvoice_flow.py:2909-2980:
+ * UpsampleConformerEncoder.forward_chunk :1185-1358 with RelPositionMultiHeadedAttention :742-860, CausalConditionalCFM
+ * .solve_euler_with_cache :2700-2793, CausalConditionalDecoder.forward_chunk :2440-2586) and the flow half of
+ * CosyVoice2Decoder.init_cache / decode_chunk (tokenizer/cosyvoice2.py:862-1046) in the plugin's default shared-prompt mode
+ * (model/cosyvoice2.py:325,1093-1103: every chunk of every request is decoded against the static caches of the prompt).
+ * fp32 activations time-major [request * t][C]; linears / convs are implicit GEMMs with exact products against bf16 weights
+ * (one plane: the reference casts this module to bf16, cosyvoice2.py:837); attention, LayerNorm, Mish / SiLU / GELU in fp32.
+ * vox_flow_set_prompt runs init_cache natively (prompt tokens + the first 3 again, prompt mel as the condition, empty caches) and
+ * keeps the truncated caches (16-entry prefix + suffix, 128 entries; 64 for the first encoder stack) on the device.
+ * The CFM start noise [mel][frames] (one draw per call, shared by the batch, as the reference): given, or the seeded Philox stream
+ * (counter (c * frames + t, stream, 0, 0), Box-Muller) that oracle/flow_ref.py::cfm_noise restates. */
+typedef struct {
+    vox_conv_w qkv, out, pos;            /* linear_q | linear_k | linear_v fused (N = 3 D), linear_out, linear_pos (no bias) */
+    const float *bias_u, *bias_v;        /* [heads][d_k] */
+    vox_conv_w w1, w2;                   /* feed_forward (SiLU between) */
+    const float *ln_mha_w, *ln_mha_b, *ln_ff_w, *ln_ff_b;
+} vox_flow_conformer_w;
+typedef struct {
+    vox_conv_w conv1, conv2, res;        /* CausalBlock1D convs k3 (taps t-2, t-1, t), res_conv k1 */
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    vox_conv_w mlp;                      /* Mish -> Linear(time_embed -> C) */
+} vox_flow_resnet_w;
+typedef struct {
+    const float *ln1_w, *ln1_b, *ln3_w, *ln3_b;
+    vox_conv_w qkv, out, ff1, ff2;       /* to_q | to_k | to_v fused (no bias), to_out.0, GELU proj, ff out */
+} vox_flow_tblock_w;
+typedef struct {
+    const float* embedding;              /* input_embedding [vocab][D] fp32 */
+    vox_conv_w spk;                      /* spk_embed_affine_layer */
+    vox_conv_w embed_lin, up_embed_lin;  /* LinearNoSubsampling.out.0 */
+    const float *embed_ln_w, *embed_ln_b, *up_embed_ln_w, *up_embed_ln_b, *after_w, *after_b;
+    vox_conv_w pre1, pre2, up_conv;      /* PreLookaheadLayer conv1 (taps t .. t+3), conv2 (t-2 .. t), Upsample1D conv (t-4 .. t) */
+    const vox_flow_conformer_w* enc;     /* [enc_layers] then [up_layers] */
+    vox_conv_w enc_proj;
+    vox_conv_w time1, time2;             /* TimestepEmbedding */
+    const vox_flow_resnet_w* resnets;    /* [1 + mid + 1]: down, mid..., up */
+    const vox_flow_tblock_w* tblocks;    /* [(1 + mid + 1) * n_blocks] in the same order */
+    vox_conv_w down_conv, up_conv2, final_conv, final_proj;
+    const float *final_ln_w, *final_ln_b;
+} vox_flow_weights;
+typedef struct {
+    int32_t vocab, dim, mel, spk_dim, enc_layers, up_layers, enc_heads, enc_ffn, pre_lookahead, est_ch, est_heads, est_head_dim,
+        est_blocks, est_mid, n_steps, max_cache, prefix;
+    float cfg_rate;
+} vox_flow_config;
+typedef struct vox_flow vox_flow;
+/* time_emb: host fp32 [n_steps][4 mel], the sinusoidal embedding of every Euler step's t (SinusoidalPosEmb, scale 1000); dt: host fp32
+ * [n_steps], the step sizes of the cosine schedule — both computed by the caller exactly as the reference computes them */
+int vox_flow_create(vox_ctx* ctx, const vox_flow_config* cfg, const vox_flow_weights* w, int max_batch, int max_T, int max_prompt_T,
+                    const float* time_emb, const float* dt, vox_flow** out);
+void vox_flow_destroy(vox_flow* m);
+/* prompt_tokens: device int32 [n_prompt]; prompt_feat: device fp32 [2 n_prompt][mel]; embedding: device fp32 [spk_dim];
+ * noise: device fp32 [mel][2 (n_prompt + 3)] or NULL (seeded stream `stream`); prompt_mel (optional): fp32 [mel][2 (n_prompt + 3)] */
+int vox_flow_set_prompt(vox_flow* m, void* stream, const int32_t* prompt_tokens, int n_prompt, const float* prompt_feat,
+                        const float* embedding, const float* noise, uint64_t seed, uint32_t noise_stream, float* prompt_mel);
+/* tokens: device int32 [n][T]; mel: fp32 [n][mel][2T] (the reference's layout); mu (optional, debugging): the encoder output [n][2T][mel] */
+int vox_flow_decode_chunk(vox_flow* m, void* stream, const int32_t* tokens, int n, int T, const float* noise, uint64_t seed,
+                          uint32_t noise_stream, float* mel, float* mu);
+
 #ifdef __cplusplus
 }
 #endif

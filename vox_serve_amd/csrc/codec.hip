@@ -1748,3 +1748,501 @@ int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, c
 }
 
 }  // extern "C"
+
+// ====================================================================================================================
+// CosyVoice2 flow (speech tokens -> mel): conformer encoder + conditional flow matching.  See include/voxhip.h for the contract.
+// ====================================================================================================================
+__device__ __forceinline__ float mish_f(float v) { return v * tanhf(v > 20.0f ? v : log1pf(expf(v))); }
+
+// x[row] = embedding[max(id, 0)]
+__global__ __launch_bounds__(256) void k_flow_embed(const int* ids, const float* emb, float* x, size_t rows, int D) {
+    const size_t total = rows * D;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int id = ids[i / D];
+        x[i] = emb[(size_t)(id < 0 ? 0 : id) * D + i % D];
+    }
+}
+// y = act(LayerNorm(x) * w + b) * post + add[row / rows_per_req]      (act 0 none, 1 Mish)
+__global__ __launch_bounds__(256) void k_flow_ln(const float* x, const float* w, const float* b, float* y, int C, float eps, float post, int act,
+                                                  const float* add, int rows_per_req) {
+    __shared__ float red[8];
+    const float* xr = x + (size_t)blockIdx.x * C;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < C; i += 256) s += xr[i];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < C; i += 256) { const float d = xr[i] - mean; v += d * d; }
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + eps);
+    const float* ad = add ? add + (size_t)(blockIdx.x / rows_per_req) * C : nullptr;
+    for (int i = threadIdx.x; i < C; i += 256) {
+        float o = (xr[i] - mean) * rstd * w[i] + b[i];
+        if (act == 1) o = mish_f(o);
+        o *= post;
+        if (ad) o += ad[i];
+        y[(size_t)blockIdx.x * C + i] = o;
+    }
+}
+// in-place activation: 1 Mish, 2 SiLU, 3 leaky_relu(0.01)
+__global__ __launch_bounds__(256) void k_flow_act(float* x, size_t total, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float v = x[i];
+        x[i] = act == 1 ? mish_f(v) : act == 2 ? v / (1.0f + expf(-v)) : (v > 0.0f ? v : 0.01f * v);
+    }
+}
+// nearest x2 along time: y[b][2t + j] = x[b][t]
+__global__ __launch_bounds__(256) void k_flow_repeat2(const float* x, float* y, size_t rows, int C) {
+    const size_t total = rows * 2 * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) y[i] = x[(i / C / 2) * C + i % C];
+}
+// EspnetRelPositionalEncoding.position_encoding(0, S): pe[j] = encoding of position S - 1 - j   (cosyvoice_flow.py:427-447, 483-486)
+__global__ __launch_bounds__(256) void k_flow_relpos(float* pe, int S, int D) {
+    const size_t total = (size_t)(2 * S - 1) * D;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int j = (int)(i / D), c = (int)(i % D);
+        const float pos = (float)(S - 1 - j);
+        const float div = expf((float)(c & ~1) * (float)(-(9.210340371976184 / (double)D)));
+        pe[i] = (c & 1) ? cosf(pos * div) : sinf(pos * div);
+    }
+}
+// Attention over [cached keys ; this chunk's keys], no mask.  One wave per (request n, head h, query i).
+// qkv [N * T][3 HD] (q | k | v); cache [chalf][H][Tcap][2 dk] (K | V), Tc valid; output [N * T][HD].
+// P != NULL: the relative-position term of RelPositionMultiHeadedAttention with its literal rel_shift (cosyvoice_flow.py:772-786, 830-857).
+struct FlowAttn {
+    const float *qkv, *cache, *P, *bu, *bv;
+    float* out;
+    int T, H, dk, Tc, Tcap, B;          // B: requests per classifier-free-guidance half (cache half = n / B); B <= 0: one shared cache
+    size_t cache_half_stride;
+    float scale;
+};
+#define FLOW_MAXKEYS 1024
+__global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
+    __shared__ float ps[4][FLOW_MAXKEYS];
+    __shared__ float qs[4][2][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave, h = blockIdx.y, n = blockIdx.z;
+    if (i >= a.T) return;
+    const int HD = a.H * a.dk, ld = 3 * HD, S = a.Tc + a.T;
+    const float* cache = a.cache ? a.cache + (a.B > 0 ? (size_t)(n / a.B) * a.cache_half_stride : 0) + (size_t)h * a.Tcap * 2 * a.dk : nullptr;
+    const float* qrow = a.qkv + ((size_t)n * a.T + i) * ld + h * a.dk;
+    for (int d = lane; d < a.dk; d += 64) {
+        qs[wave][0][d] = qrow[d] + (a.bu ? a.bu[h * a.dk + d] : 0.0f);
+        qs[wave][1][d] = a.bv ? a.bv[h * a.dk + d] : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float mx = -INFINITY;
+    for (int j = lane; j < S; j += 64) {
+        const float* kr = j < a.Tc ? cache + (size_t)j * 2 * a.dk : a.qkv + ((size_t)n * a.T + (j - a.Tc)) * ld + HD + h * a.dk;
+        float ac = 0.0f;
+        for (int d = 0; d < a.dk; ++d) ac = fmaf(qs[wave][0][d], kr[d], ac);
+        if (a.P) {
+            const long f = (long)i * (2 * S - 1) + j + a.T;
+            const int r = (int)(f / (2 * S)), ci = (int)(f % (2 * S));
+            if (ci > 0) {
+                const float* qr = a.qkv + ((size_t)n * a.T + r) * ld + h * a.dk;
+                const float* pr = a.P + (size_t)(ci - 1) * HD + h * a.dk;
+                float bd = 0.0f;
+                for (int d = 0; d < a.dk; ++d) bd = fmaf(qr[d] + qs[wave][1][d], pr[d], bd);
+                ac += bd;
+            }
+        }
+        ac *= a.scale;
+        ps[wave][j] = ac;
+        mx = fmaxf(mx, ac);
+    }
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.0f;
+    for (int j = lane; j < S; j += 64) {
+        const float p = expf(ps[wave][j] - mx);
+        ps[wave][j] = p;
+        sum += p;
+    }
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.0f / sum;
+    for (int d = lane; d < a.dk; d += 64) {
+        float o = 0.0f;
+        for (int j = 0; j < S; ++j) {
+            const float* vr = j < a.Tc ? cache + (size_t)j * 2 * a.dk + a.dk : a.qkv + ((size_t)n * a.T + (j - a.Tc)) * ld + 2 * HD + h * a.dk;
+            o = fmaf(ps[wave][j] * inv, vr[d], o);
+        }
+        a.out[((size_t)n * a.T + i) * HD + h * a.dk + d] = o;
+    }
+}
+// new K | V rows of request n -> cache [half = n][H][Tcap][2 dk], keeping the first `prefix` and the last Tcap - prefix of the T rows
+__global__ __launch_bounds__(256) void k_flow_cache_store(const float* qkv, float* cache, int T, int H, int dk, int Tcap, int prefix,
+                                                           size_t cache_half_stride, int N) {
+    const int keep = T < Tcap ? T : Tcap;
+    const size_t total = (size_t)N * H * keep * 2 * dk;
+    const int HD = H * dk;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int e = (int)(i % (2 * dk));
+        size_t r = i / (2 * dk);
+        const int j = (int)(r % keep); r /= keep;
+        const int h = (int)(r % H), n = (int)(r / H);
+        const int src = (T <= Tcap || j < prefix) ? j : T - (Tcap - j);
+        const float v = qkv[((size_t)n * T + src) * 3 * HD + (e < dk ? HD : 2 * HD) + h * dk + (e < dk ? e : e - dk)];
+        cache[(size_t)n * cache_half_stride + ((size_t)h * Tcap + j) * 2 * dk + e] = v;
+    }
+}
+// last two rows of every request -> conv state [n][2][C]
+__global__ __launch_bounds__(256) void k_flow_tail2(const float* x, float* st, int N, int T, int C) {
+    const size_t total = (size_t)N * 2 * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C), p = (int)((i / C) % 2), n = (int)(i / (2 * C));
+        const int t = T - 2 + p;
+        st[i] = t >= 0 ? x[((size_t)n * T + t) * C + c] : 0.0f;
+    }
+}
+// estimator input [2B * T][4 mel] = x | mu | spk | cond, the second (unconditional) half with mu = spk = cond = 0   (cosyvoice_flow.py:2737-2745)
+__global__ __launch_bounds__(256) void k_flow_pack(const float* x, const float* mu, const float* spk, const float* cond, float* y, int B, int T,
+                                                    int M) {
+    const size_t total = (size_t)2 * B * T * 4 * M;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % (4 * M));
+        const size_t row = i / (4 * M);
+        const int n = (int)(row / T), t = (int)(row % T), b = n % B;
+        const bool un = n >= B;
+        const int part = c / M, cc = c % M;
+        float v;
+        if (part == 0) v = x[((size_t)b * T + t) * M + cc];
+        else if (un) v = 0.0f;
+        else if (part == 1) v = mu[((size_t)b * T + t) * M + cc];
+        else if (part == 2) v = spk[cc];
+        else v = cond ? cond[((size_t)b * T + t) * M + cc] : 0.0f;
+        y[i] = v;
+    }
+}
+// x <- x + dt * ((1 + r) d[b] - r d[B + b])   (classifier-free guidance + Euler step, cosyvoice_flow.py:2774-2778)
+__global__ __launch_bounds__(256) void k_flow_euler(float* x, const float* d, int B, int T, int M, float dt, float rate) {
+    const size_t total = (size_t)B * T * M;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const float g = (1.0f + rate) * d[i] - rate * d[total + i];
+        x[i] = x[i] + dt * g;
+    }
+}
+// start noise z [M][T] (given, or the seeded stream) -> x [B][T][M]
+__global__ __launch_bounds__(256) void k_flow_noise(const float* z, uint64_t seed, uint32_t stream, float* x, int B, int T, int M) {
+    const size_t total = (size_t)B * T * M;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % M), t = (int)((i / M) % T);
+        float v;
+        if (z) v = z[(size_t)c * T + t];
+        else {
+            uint32_t w0, w1;
+            philox4((uint32_t)(c * T + t), stream, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), &w0, &w1);
+            const float u1 = ((float)(w0 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+            v = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+        }
+        x[i] = v;
+    }
+}
+// [B][T][M] -> [B][M][T]
+__global__ __launch_bounds__(256) void k_flow_to_bct(const float* x, float* y, int B, int T, int M) {
+    const size_t total = (size_t)B * T * M;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int t = (int)(i % T), c = (int)((i / T) % M), b = (int)(i / ((size_t)T * M));
+        y[i] = x[((size_t)b * T + t) * M + c];
+    }
+}
+// L2-normalise the speaker embedding (F.normalize, eps 1e-12): one block
+__global__ __launch_bounds__(256) void k_flow_l2norm(const float* x, float* y, int C) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < C; i += 256) s += x[i] * x[i];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+    for (int i = threadIdx.x; i < C; i += 256) y[i] = x[i] / nrm;
+}
+// cond [rows][M]: the first n_feat rows = prompt_feat, the rest 0
+__global__ __launch_bounds__(256) void k_flow_cond(const float* feat, float* cond, int rows, int n_feat, int M) {
+    const size_t total = (size_t)rows * M;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) cond[i] = (int)(i / M) < n_feat ? feat[i] : 0.0f;
+}
+
+// y[row] = a[row] | b[row]
+__global__ __launch_bounds__(256) void k_flow_concat2(const float* a, const float* b, float* y, size_t rows, int C) {
+    const size_t total = rows * 2 * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % (2 * C));
+        const size_t r = i / (2 * C);
+        y[i] = c < C ? a[r * C + c] : b[r * C + c - C];
+    }
+}
+__global__ void k_flow_slots(int* slots, int N, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) slots[i] = i / B;
+}
+
+struct vox_flow {
+    vox_ctx* ctx;
+    vox_flow_config cfg;
+    vox_flow_weights w;
+    std::vector<vox_flow_conformer_w> enc;
+    std::vector<vox_flow_resnet_w> resnets;
+    std::vector<vox_flow_tblock_w> tblocks;
+    int max_batch, max_T, max_prompt_T, n_res, n_att;
+    std::vector<float> dt;                  // host: Euler step sizes
+    float* tb = nullptr;                    // [n_steps][n_res][C]: mlp_r(Mish(time_mlp(emb_s)))
+    float* buf[10] = {};
+    size_t buf_floats = 0;
+    float *spk = nullptr, *pe = nullptr, *pp = nullptr;
+    int* slots = nullptr;                   // [2 * max_batch]: conv-state slot (= guidance half) of every estimator request row
+    // static prompt caches
+    float *enc_kv = nullptr, *up_kv = nullptr, *att_kv = nullptr, *cnn1 = nullptr, *cnn2 = nullptr;
+    int enc_len = 0, up_len = 0, att_len = 0, cnn1_w = 0;
+    bool have_prompt = false;
+};
+
+static inline int flow_res_cin(const vox_flow_config& c, int r) { return r == 0 ? 4 * c.mel : (r == 1 + c.est_mid ? 2 * c.est_ch : c.est_ch); }
+
+extern "C" {
+
+void vox_flow_destroy(vox_flow* m) {
+    if (!m) return;
+    for (int i = 0; i < 10; ++i) (void)hipFree(m->buf[i]);
+    (void)hipFree(m->tb); (void)hipFree(m->spk); (void)hipFree(m->pe); (void)hipFree(m->pp); (void)hipFree(m->slots);
+    (void)hipFree(m->enc_kv); (void)hipFree(m->up_kv); (void)hipFree(m->att_kv); (void)hipFree(m->cnn1); (void)hipFree(m->cnn2);
+    delete m;
+}
+
+}  // extern "C"
+
+static const int FLOW_OFF0[4] = {0, 0, 0, 0};
+static const int FLOW_OFF_C3[3] = {2, 1, 0};            // causal k3
+static const int FLOW_OFF_C5[5] = {4, 3, 2, 1, 0};      // causal k5 (Upsample1D after its left pad of 4)
+static const int FLOW_OFF_LA[8] = {0, -1, -2, -3, -4, -5, -6, -7};   // look-ahead k (PreLookaheadLayer.conv1)
+
+// one conformer layer (norm_mha -> rel-pos attention -> residual; norm_ff -> SiLU FFN -> residual) on x [n * T][D] in place
+static int flow_conformer(vox_flow* m, hipStream_t st, const vox_flow_conformer_w& w, float* x, int n, int T, const float* cache, int Tc, int Tcap,
+                          float* store_cache, int store_cap, int store_prefix, float** B) {
+    const vox_flow_config& c = m->cfg;
+    const int D = c.dim, H = c.enc_heads, dk = D / H, S = Tc + T;
+    if (S > FLOW_MAXKEYS) return vox_fail(VOX_ERR_INVALID, "flow: %d keys > %d", S, FLOW_MAXKEYS);
+    float *nrm = B[0], *qkv = B[1], *att = B[2];
+    hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, w.ln_mha_w, w.ln_mha_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1);
+    VOX_TRY(conv_gemm(st, w.qkv, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
+    VOX_TRY(conv_gemm(st, w.pos, m->pe, nullptr, nullptr, 1, 2 * S - 1, 0, FLOW_OFF0, m->pp, nullptr, nullptr, 0));
+    FlowAttn a{qkv, cache, m->pp, w.bias_u, w.bias_v, att, T, H, dk, Tc, Tcap, 0, 0, 1.0f / sqrtf((float)dk)};
+    hipLaunchKernelGGL(k_flow_attn, dim3((T + 3) / 4, H, n), dim3(256), 0, st, a);
+    if (store_cache)
+        hipLaunchKernelGGL(k_flow_cache_store, dim3(ew_grid((size_t)H * store_cap * 2 * dk)), dim3(256), 0, st, qkv, store_cache, T, H, dk, store_cap,
+                           store_prefix, (size_t)0, 1);
+    VOX_TRY(conv_gemm(st, w.out, att, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
+    hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, w.ln_ff_w, w.ln_ff_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1);
+    VOX_TRY(conv_gemm(st, w.w1, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
+    hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)n * T * c.enc_ffn)), dim3(256), 0, st, qkv, (size_t)n * T * c.enc_ffn, 2);
+    VOX_TRY(conv_gemm(st, w.w2, qkv, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
+    return VOX_OK;
+}
+
+// tokens [B][T] -> mel frames x [B][2T][mel] (time-major, in m->buf[9]); init: B == 1, caches are written instead of read
+static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, int T, bool init, const float* prompt_feat, int n_feat,
+                    const float* noise, uint64_t seed, uint32_t nstream, float* mu_out) {
+    const vox_flow_config& c = m->cfg;
+    const vox_flow_weights& w = m->w;
+    const int D = c.dim, M = c.mel, C = c.est_ch, T2 = 2 * T, H = c.enc_heads, dk = D / H, inner = c.est_heads * c.est_head_dim;
+    float** Bf = m->buf;
+    g_conv_planes = 3;
+    // ---- encoder ----
+    float* x = Bf[3];
+    hipLaunchKernelGGL(k_flow_embed, dim3(ew_grid((size_t)B * T * D)), dim3(256), 0, st, tokens, w.embedding, Bf[0], (size_t)B * T, D);
+    VOX_TRY(conv_gemm(st, w.embed_lin, Bf[0], nullptr, nullptr, B, T, 0, FLOW_OFF0, Bf[1], nullptr, nullptr, 0));
+    hipLaunchKernelGGL(k_flow_ln, dim3(B * T), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1);
+    // PreLookaheadLayer (empty context): conv k(pre+1) looking ahead, leaky_relu, causal conv k3, residual
+    VOX_TRY(conv_gemm(st, w.pre1, x, nullptr, nullptr, B, T, 0, FLOW_OFF_LA, Bf[0], nullptr, nullptr, 0));
+    hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)B * T * D)), dim3(256), 0, st, Bf[0], (size_t)B * T * D, 3);
+    VOX_TRY(conv_gemm(st, w.pre2, Bf[0], nullptr, nullptr, B, T, 0, FLOW_OFF_C3, x, x, nullptr, 0));
+    {
+        const int Tc = init ? 0 : m->enc_len, S = Tc + T, cap = c.max_cache / 2;
+        hipLaunchKernelGGL(k_flow_relpos, dim3(ew_grid((size_t)(2 * S - 1) * D)), dim3(256), 0, st, m->pe, S, D);
+        for (int l = 0; l < c.enc_layers; ++l) {
+            float* kv = m->enc_kv + (size_t)l * H * cap * 2 * dk;
+            VOX_TRY(flow_conformer(m, st, m->enc[l], x, B, T, init ? nullptr : kv, Tc, cap, init ? kv : nullptr, cap, c.prefix / 2, Bf));
+        }
+        if (init) m->enc_len = T < cap ? T : cap;
+    }
+    // Upsample1D (nearest x2, causal conv k5), up_embed, the second conformer stack, after_norm, encoder_proj
+    hipLaunchKernelGGL(k_flow_repeat2, dim3(ew_grid((size_t)B * T2 * D)), dim3(256), 0, st, x, Bf[0], (size_t)B * T, D);
+    VOX_TRY(conv_gemm(st, w.up_conv, Bf[0], nullptr, nullptr, B, T2, 0, FLOW_OFF_C5, Bf[1], nullptr, nullptr, 0));
+    VOX_TRY(conv_gemm(st, w.up_embed_lin, Bf[1], nullptr, nullptr, B, T2, 0, FLOW_OFF0, Bf[0], nullptr, nullptr, 0));
+    hipLaunchKernelGGL(k_flow_ln, dim3(B * T2), dim3(256), 0, st, Bf[0], w.up_embed_ln_w, w.up_embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1);
+    {
+        const int Tc = init ? 0 : m->up_len, S = Tc + T2, cap = c.max_cache;
+        hipLaunchKernelGGL(k_flow_relpos, dim3(ew_grid((size_t)(2 * S - 1) * D)), dim3(256), 0, st, m->pe, S, D);
+        for (int l = 0; l < c.up_layers; ++l) {
+            float* kv = m->up_kv + (size_t)l * H * cap * 2 * dk;
+            VOX_TRY(flow_conformer(m, st, m->enc[c.enc_layers + l], x, B, T2, init ? nullptr : kv, Tc, cap, init ? kv : nullptr, cap, c.prefix, Bf));
+        }
+        if (init) m->up_len = T2 < cap ? T2 : cap;
+    }
+    hipLaunchKernelGGL(k_flow_ln, dim3(B * T2), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1);
+    float* mu = Bf[8];
+    VOX_TRY(conv_gemm(st, w.enc_proj, Bf[0], nullptr, nullptr, B, T2, 0, FLOW_OFF0, mu, nullptr, nullptr, 0));
+    if (mu_out) (void)hipMemcpyAsync(mu_out, mu, (size_t)B * T2 * M * 4, hipMemcpyDeviceToDevice, st);
+    // ---- conditional flow matching: n_steps Euler steps of the estimator on the doubled (guidance) batch ----
+    float *xs = Bf[9], *cond = Bf[7];
+    if (init) hipLaunchKernelGGL(k_flow_cond, dim3(ew_grid((size_t)T2 * M)), dim3(256), 0, st, prompt_feat, cond, T2, n_feat, M);
+    hipLaunchKernelGGL(k_flow_noise, dim3(ew_grid((size_t)B * T2 * M)), dim3(256), 0, st, noise, seed, nstream, xs, B, T2, M);
+    const int N = 2 * B, capA = c.max_cache, hd = c.est_head_dim, HE = c.est_heads;
+    const size_t att_layer = (size_t)HE * capA * 2 * hd, att_half = (size_t)c.n_steps * m->n_att * att_layer;
+    const int Tc = init ? 0 : m->att_len;
+    if (Tc + T2 > FLOW_MAXKEYS) return vox_fail(VOX_ERR_INVALID, "flow: chunk too long");
+    hipLaunchKernelGGL(k_flow_slots, dim3((N + 63) / 64), dim3(64), 0, st, m->slots, N, B);
+    for (int s = 0; s < c.n_steps; ++s) {
+        float *hA = Bf[0], *a1 = Bf[1], *a2 = Bf[2], *a3 = Bf[3], *skip = Bf[4], *cat = Bf[5], *hB = Bf[6];
+        hipLaunchKernelGGL(k_flow_pack, dim3(ew_grid((size_t)N * T2 * 4 * M)), dim3(256), 0, st, xs, mu, m->spk, init ? cond : nullptr, cat, B, T2, M);
+        const float* in = cat;
+        float* h = hA;
+        int li = 0;
+        for (int r = 0; r < m->n_res; ++r) {
+            const vox_flow_resnet_w& rw = m->resnets[r];
+            const int cin = flow_res_cin(c, r);
+            if (r == m->n_res - 1) {      // up block: pack([x, skip]) along channels
+                hipLaunchKernelGGL(k_flow_concat2, dim3(ew_grid((size_t)N * T2 * 2 * C)), dim3(256), 0, st, in, skip, cat, (size_t)N * T2, C);
+                in = cat;
+            }
+            h = (in == hA) ? hB : hA;
+            float* st1 = m->cnn1 + ((size_t)s * m->n_res + r) * 4 * m->cnn1_w;
+            float* st2 = m->cnn2 + ((size_t)s * m->n_res + r) * 4 * C;
+            if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * cin)), dim3(256), 0, st, in, st1, N, T2, cin);
+            // block1: (cached) causal conv k3 -> LayerNorm -> Mish, + the time projection; block2 likewise; + res_conv(x)
+            VOX_TRY(conv_gemm(st, rw.conv1, in, init ? nullptr : st1, m->slots, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
+            hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, a1, rw.ln1_w, rw.ln1_b, a2, C, 1e-5f, 1.0f, 1,
+                               m->tb + ((size_t)s * m->n_res + r) * C, N * T2);
+            if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * C)), dim3(256), 0, st, a2, st2, N, T2, C);
+            VOX_TRY(conv_gemm(st, rw.conv2, a2, init ? nullptr : st2, m->slots, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
+            hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, a1, rw.ln2_w, rw.ln2_b, a2, C, 1e-5f, 1.0f, 1, nullptr, 1);
+            VOX_TRY(conv_gemm(st, rw.res, in, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, a2, nullptr, 0));       // h = block2 + res_conv(in)
+            for (int j = 0; j < c.est_blocks; ++j, ++li) {
+                const vox_flow_tblock_w& tw = m->tblocks[li];
+                float* kv = m->att_kv + ((size_t)s * m->n_att + li) * att_layer;
+                hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, h, tw.ln1_w, tw.ln1_b, a1, C, 1e-5f, 1.0f, 0, nullptr, 1);
+                VOX_TRY(conv_gemm(st, tw.qkv, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF0, a2, nullptr, nullptr, 0));
+                FlowAttn a{a2, init ? nullptr : kv, nullptr, nullptr, nullptr, a3, T2, HE, hd, Tc, capA, B, att_half, 1.0f / sqrtf((float)hd)};
+                hipLaunchKernelGGL(k_flow_attn, dim3((T2 + 3) / 4, HE, N), dim3(256), 0, st, a);
+                if (init)
+                    hipLaunchKernelGGL(k_flow_cache_store, dim3(ew_grid((size_t)N * HE * capA * 2 * hd)), dim3(256), 0, st, a2, kv, T2, HE, hd, capA,
+                                       c.prefix, att_half, N);
+                VOX_TRY(conv_gemm(st, tw.out, a3, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, h, nullptr, 0));
+                hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, h, tw.ln3_w, tw.ln3_b, a1, C, 1e-5f, 1.0f, 0, nullptr, 1);
+                VOX_TRY(conv_gemm(st, tw.ff1, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF0, a2, nullptr, nullptr, 1));
+                VOX_TRY(conv_gemm(st, tw.ff2, a2, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, h, nullptr, 0));
+            }
+            in = h;
+            if (r == 0) {                  // down block: keep the skip, then its (uncached) causal conv
+                (void)hipMemcpyAsync(skip, h, (size_t)N * T2 * C * 4, hipMemcpyDeviceToDevice, st);
+                float* o = (h == hA) ? hB : hA;
+                VOX_TRY(conv_gemm(st, w.down_conv, skip, nullptr, nullptr, N, T2, 0, FLOW_OFF_C3, o, nullptr, nullptr, 0));
+                in = o;
+            }
+        }
+        VOX_TRY(conv_gemm(st, w.up_conv2, in, nullptr, nullptr, N, T2, 0, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
+        VOX_TRY(conv_gemm(st, w.final_conv, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF_C3, a2, nullptr, nullptr, 0));
+        hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, a2, w.final_ln_w, w.final_ln_b, a1, C, 1e-5f, 1.0f, 1, nullptr, 1);
+        VOX_TRY(conv_gemm(st, w.final_proj, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF0, a2, nullptr, nullptr, 0));
+        hipLaunchKernelGGL(k_flow_euler, dim3(ew_grid((size_t)B * T2 * M)), dim3(256), 0, st, xs, a2, B, T2, M, m->dt[s], c.cfg_rate);
+    }
+    if (init) m->att_len = T2 < capA ? T2 : capA;
+    return VOX_OK;
+}
+
+extern "C" {
+
+int vox_flow_create(vox_ctx* ctx, const vox_flow_config* cfg, const vox_flow_weights* w, int max_batch, int max_T, int max_prompt_T,
+                    const float* time_emb, const float* dt, vox_flow** out) {
+    if (!ctx || !cfg || !w || !out || !time_emb || !dt) return vox_fail(VOX_ERR_INVALID, "flow_create: NULL");
+    const vox_flow_config& c = *cfg;
+    if (c.dim % c.enc_heads || c.dim / c.enc_heads > 128 || c.est_head_dim > 128 || c.dim % 32 || c.est_ch % 32 || (4 * c.mel) % 32 ||
+        (c.est_heads * c.est_head_dim) % 32 || c.enc_ffn % 32 || c.spk_dim % 32 || c.pre_lookahead + 1 > 8 || max_batch < 1 || max_T < 1 ||
+        max_prompt_T < 1 || c.n_steps < 1)
+        return vox_fail(VOX_ERR_INVALID, "flow_create: bad config");
+    vox_flow* m = new vox_flow();
+    m->ctx = ctx; m->cfg = c; m->w = *w; m->max_batch = max_batch; m->max_T = max_T; m->max_prompt_T = max_prompt_T;
+    m->n_res = 2 + c.est_mid; m->n_att = m->n_res * c.est_blocks;
+    m->enc.assign(w->enc, w->enc + c.enc_layers + c.up_layers);
+    m->resnets.assign(w->resnets, w->resnets + m->n_res);
+    m->tblocks.assign(w->tblocks, w->tblocks + m->n_att);
+    m->dt.assign(dt, dt + c.n_steps);
+    const int D = c.dim, C = c.est_ch, TE = 4 * C, inner = c.est_heads * c.est_head_dim, dk = D / c.enc_heads;
+    size_t rows = (size_t)2 * max_batch * 2 * max_T;
+    if ((size_t)2 * 2 * (max_prompt_T + 3) > rows) rows = (size_t)2 * 2 * (max_prompt_T + 3);
+    size_t wmax = 3 * (size_t)D;
+    for (size_t v : {(size_t)c.enc_ffn, (size_t)4 * C, (size_t)3 * inner, (size_t)4 * c.mel, (size_t)TE}) wmax = v > wmax ? v : wmax;
+    m->buf_floats = rows * wmax;
+    m->cnn1_w = 4 * c.mel > 2 * C ? 4 * c.mel : 2 * C;
+    const size_t capE = c.max_cache / 2, capU = c.max_cache;
+    bool ok = true;
+    auto alloc = [&](float** p, size_t n) { ok = ok && hipMalloc((void**)p, n * 4) == hipSuccess; };
+    for (int i = 0; i < 10; ++i) alloc(&m->buf[i], m->buf_floats);
+    alloc(&m->tb, (size_t)c.n_steps * m->n_res * C);
+    alloc(&m->spk, c.mel);
+    alloc(&m->pe, (size_t)2 * FLOW_MAXKEYS * D);
+    alloc(&m->pp, (size_t)2 * FLOW_MAXKEYS * D);
+    alloc(&m->enc_kv, (size_t)c.enc_layers * c.enc_heads * capE * 2 * dk);
+    alloc(&m->up_kv, (size_t)c.up_layers * c.enc_heads * capU * 2 * dk);
+    alloc(&m->att_kv, (size_t)2 * c.n_steps * m->n_att * c.est_heads * c.max_cache * 2 * c.est_head_dim);
+    alloc(&m->cnn1, (size_t)c.n_steps * m->n_res * 4 * m->cnn1_w);
+    alloc(&m->cnn2, (size_t)c.n_steps * m->n_res * 4 * C);
+    ok = ok && hipMalloc((void**)&m->slots, (size_t)2 * (max_batch > 1 ? max_batch : 1) * 4) == hipSuccess;
+    if (!ok) { vox_flow_destroy(m); return vox_fail(VOX_ERR_NOMEM, "flow_create: hipMalloc failed"); }
+    // time projections of every Euler step and resnet, once: tb[s][r] = mlp_r(Mish(linear_2(SiLU(linear_1(emb_s)))))
+    hipStream_t st = nullptr;
+    g_conv_planes = 3;
+    int rc = VOX_OK;
+    (void)hipMemcpy(m->buf[0], time_emb, (size_t)c.n_steps * 4 * c.mel * 4, hipMemcpyHostToDevice);
+    rc = conv_gemm(st, w->time1, m->buf[0], nullptr, nullptr, 1, c.n_steps, 0, FLOW_OFF0, m->buf[1], nullptr, nullptr, 0);
+    hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)c.n_steps * TE)), dim3(256), 0, st, m->buf[1], (size_t)c.n_steps * TE, 2);
+    if (rc == VOX_OK) rc = conv_gemm(st, w->time2, m->buf[1], nullptr, nullptr, 1, c.n_steps, 0, FLOW_OFF0, m->buf[2], nullptr, nullptr, 0);
+    hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)c.n_steps * TE)), dim3(256), 0, st, m->buf[2], (size_t)c.n_steps * TE, 1);
+    for (int r = 0; r < m->n_res && rc == VOX_OK; ++r) {
+        rc = conv_gemm(st, m->resnets[r].mlp, m->buf[2], nullptr, nullptr, 1, c.n_steps, 0, FLOW_OFF0, m->buf[3], nullptr, nullptr, 0);
+        (void)hipMemcpy2DAsync(m->tb + (size_t)r * C, (size_t)m->n_res * C * 4, m->buf[3], (size_t)C * 4, (size_t)C * 4, c.n_steps,
+                               hipMemcpyDeviceToDevice, st);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess || rc != VOX_OK) { vox_flow_destroy(m); return rc != VOX_OK ? rc : vox_fail(VOX_ERR_HIP, "flow_create: time MLP failed"); }
+    *out = m;
+    return VOX_OK;
+}
+
+int vox_flow_set_prompt(vox_flow* m, void* stream, const int32_t* prompt_tokens, int n_prompt, const float* prompt_feat,
+                        const float* embedding, const float* noise, uint64_t seed, uint32_t noise_stream, float* prompt_mel) {
+    if (!m || !prompt_tokens || !prompt_feat || !embedding) return vox_fail(VOX_ERR_INVALID, "flow_set_prompt: NULL");
+    if (n_prompt < 3 || n_prompt > m->max_prompt_T) return vox_fail(VOX_ERR_INVALID, "flow_set_prompt: %d prompt tokens out of range", n_prompt);
+    hipStream_t st = (hipStream_t)stream;
+    const vox_flow_config& c = m->cfg;
+    const int T = n_prompt + 3;
+    // speaker vector: spk_embed_affine_layer(normalize(embedding))
+    hipLaunchKernelGGL(k_flow_l2norm, dim3(1), dim3(256), 0, st, embedding, m->buf[0], c.spk_dim);
+    g_conv_planes = 3;
+    VOX_TRY(conv_gemm(st, m->w.spk, m->buf[0], nullptr, nullptr, 1, 1, 0, FLOW_OFF0, m->spk, nullptr, nullptr, 0));
+    // tokens = prompt + its first three again (cosyvoice2.py:864-867)
+    int* tok = reinterpret_cast<int*>(m->buf[6]);
+    (void)hipMemcpyAsync(tok, prompt_tokens, (size_t)n_prompt * 4, hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(tok + n_prompt, prompt_tokens, (size_t)3 * 4, hipMemcpyDeviceToDevice, st);
+    m->have_prompt = false;
+    VOX_TRY(flow_run(m, st, tok, 1, T, true, prompt_feat, 2 * n_prompt, noise, seed, noise_stream, nullptr));
+    if (prompt_mel) hipLaunchKernelGGL(k_flow_to_bct, dim3(ew_grid((size_t)2 * T * c.mel)), dim3(256), 0, st, m->buf[9], prompt_mel, 1, 2 * T, c.mel);
+    m->have_prompt = true;
+    return VOX_OK;
+}
+
+int vox_flow_decode_chunk(vox_flow* m, void* stream, const int32_t* tokens, int n, int T, const float* noise, uint64_t seed,
+                          uint32_t noise_stream, float* mel, float* mu) {
+    if (!m || !tokens || !mel) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk: NULL");
+    if (!m->have_prompt) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk: no prompt set (vox_flow_set_prompt)");
+    if (n < 1 || n > m->max_batch || T < 1 || T > m->max_T) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk: n %d / T %d out of range", n, T);
+    hipStream_t st = (hipStream_t)stream;
+    VOX_TRY(flow_run(m, st, tokens, n, T, false, nullptr, 0, noise, seed, noise_stream, mu));
+    hipLaunchKernelGGL(k_flow_to_bct, dim3(ew_grid((size_t)n * 2 * T * m->cfg.mel)), dim3(256), 0, st, m->buf[9], mel, n, 2 * T, m->cfg.mel);
+    return VOX_OK;
+}
+
+}  // extern "C"
