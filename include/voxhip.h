@@ -548,6 +548,10 @@ int vox_flow_set_prompt(vox_flow* m, void* stream, const int32_t* prompt_tokens,
 int vox_flow_decode_chunk(vox_flow* m, void* stream, const int32_t* tokens, int n, int T, const float* noise, uint64_t seed,
                           uint32_t noise_stream, float* mel, float* mu);
 
+/* fade_in_out (tokenizer/cosyvoice2.py:46-54): wav [n][L] (in place): the first `fade` samples of every row become
+ * wav * window[:fade] + prev_tail * window[fade:] (prev_tail [n][fade] or NULL = silence; window: device double [2 fade]) */
+int vox_fade_in_out(void* stream, float* wav, int n, int L, const float* prev_tail, const double* window, int fade);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2246,3 +2246,19 @@ int vox_flow_decode_chunk(vox_flow* m, void* stream, const int32_t* tokens, int 
 }
 
 }  // extern "C"
+
+// fade_in_out (tokenizer/cosyvoice2.py:46-54): the first `fade` samples of every row cross-fade with the tail of the previous chunk
+// (prev NULL = silence), computed in double like the reference's float64 Hamming window
+__global__ __launch_bounds__(256) void k_fade_in(float* wav, const float* prev, const double* win, int n, int L, int fade) {
+    const size_t total = (size_t)n * fade;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / fade), t = (int)(i % fade);
+        const double v = (double)wav[(size_t)b * L + t] * win[t] + (prev ? (double)prev[(size_t)b * fade + t] : 0.0) * win[fade + t];
+        wav[(size_t)b * L + t] = (float)v;
+    }
+}
+extern "C" int vox_fade_in_out(void* stream, float* wav, int n, int L, const float* prev_tail, const double* window, int fade) {
+    if (!wav || !window || n < 1 || fade < 1 || fade > L) return vox_fail(VOX_ERR_INVALID, "fade_in_out: bad arguments");
+    hipLaunchKernelGGL(k_fade_in, dim3(ew_grid((size_t)n * fade)), dim3(256), 0, (hipStream_t)stream, wav, prev_tail, window, n, L, fade);
+    return VOX_OK;
+}

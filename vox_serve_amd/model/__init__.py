@@ -95,6 +95,12 @@ def _glm(model_name, device="cuda:0", weights=None, checkpoint_dir=None, synthet
 
 @register_model("cosyvoice2", "FunAudioLLM/CosyVoice2-0.5B")
 def _cosyvoice2(model_name, device="cuda:0", weights=None, checkpoint_dir=None, synthetic=False, **kw):
+    if synthetic and kw.get("codec_weights") is None and "speaker_ref" not in kw:
+        # random-init detokenizer (flow + HiFT) with a synthetic speaker prompt, like the LM weights
+        from .. import synth
+        cw, prompt = synth.synth_cosyvoice2_codec_weights()
+        kw["codec_weights"] = cw
+        kw["speaker_ref"] = dict(prompt, ref_text_ids=__import__("torch").zeros(0, dtype=__import__("torch").long))
     return _single_stack(model_name, (".cosyvoice2", "CosyVoice2Model"), "CosyVoice2Config", "synth_cosyvoice2_weights",
                          device, weights, checkpoint_dir, synthetic, kw)
 

@@ -56,7 +56,9 @@ class CosyVoice2Model(SingleStackLM):
 
     def __init__(self, model_name: str, weights: Dict[str, torch.Tensor], config: Optional[CosyVoice2Config] = None,
                  text_tokenizer=None, speaker_ref: Optional[dict] = None, device="cuda:0", dtype=torch.bfloat16,
-                 audio_decoder_device=None, sampling: Optional[SamplingConfig] = None, max_pos=8192, sampling_overrides=None, **engine_kw):
+                 audio_decoder_device=None, sampling: Optional[SamplingConfig] = None, max_pos=8192, sampling_overrides=None,
+                 codec_weights: Optional[dict] = None, codec_config: Optional[dict] = None, use_detokenizer_cache: bool = False,
+                 codec_seed: int = 0, **engine_kw):
         self.cv_config = config or CosyVoice2Config()
         layers, norm, emb, head, head_b = pack_cosyvoice2_weights(weights, self.cv_config)
         sampling = sampling or SamplingConfig(top_k=25, top_p=None, min_p=None, temperature=1.0, repetition_penalty=None,
@@ -75,6 +77,35 @@ class CosyVoice2Model(SingleStackLM):
         self.speaker_ref = speaker_ref or {"ref_text_ids": torch.zeros(0, dtype=torch.long),
                                            "prompt_speech_token": torch.zeros(0, dtype=torch.long)}
         self.stop_token_ids = [self.cv_config.speech_token_size + i for i in range(3)]
+        # detokenizer (cosyvoice2.py:377-418): flow + HiFT; the plugin's default is the shared prompt cache — the speaker prompt is run
+        # through the flow once here and every chunk of every request is decoded against its caches
+        if use_detokenizer_cache:
+            raise NotImplementedError("CosyVoice2Model: use_detokenizer_cache=True (per-request evolving detokenizer cache) is not built")
+        self.use_detokenizer_cache = False
+        self.audio_decoder = None
+        if codec_weights is not None:
+            from ..tokenizer.cosyvoice2 import CosyVoice2Decoder
+            cc = codec_config or {}
+            need = [k for k in ("prompt_speech_token", "prompt_feat", "embedding") if k not in self.speaker_ref]
+            if need:
+                raise ValueError(f"CosyVoice2Model: speaker_ref lacks {need} (the detokenizer's prompt: speech tokens, mel, x-vector)")
+            self.audio_decoder = CosyVoice2Decoder(codec_weights["flow"], codec_weights["hift"], device=self.audio_decoder_device or device,
+                                                   flow_config=cc.get("flow"), hift_config=cc.get("hift"),
+                                                   max_batch=engine_kw.get("max_batch_size", 8), max_tokens_per_chunk=self.detokenize_interval,
+                                                   max_prompt_tokens=max(64, int(self.speaker_ref["prompt_speech_token"].numel()) + 8),
+                                                   seed=codec_seed)
+            self._shared_prompt_cache = self.audio_decoder.init_cache(self.speaker_ref)
+
+    def audio_decoder_initial_cache(self, batch_size: int):
+        return None         # shared prompt cache mode: nothing per request (cosyvoice2.py:521-524)
+
+    def postprocess(self, token_ids: torch.Tensor, decoder_cache=None, **kwargs) -> torch.Tensor:
+        """token_ids [B, 28, 1] -> audio [B, 1, 24000]   (cosyvoice2.py:1093-1103)"""
+        if self.audio_decoder is None:
+            raise NotImplementedError("CosyVoice2Model: no detokenizer weights were given (codec_weights={'flow': ..., 'hift': ...})")
+        audio, _ = self.audio_decoder.decode_chunk(token_ids[:, :, 0], speech_token_lens=self.detokenize_interval,
+                                                   decoder_cache=self._shared_prompt_cache, ref_dict=self.speaker_ref)
+        return audio[:, None, :]
 
     supports_audio_input = property(lambda self: True)
     needs_input_features = property(lambda self: True)

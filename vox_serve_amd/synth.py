@@ -265,3 +265,130 @@ def synth_snac_weights(cfg=None, seed=0):
     wn(f"{d}{n + 1}", (1, ch, 7), 0.12)
     W[f"{d}{n + 1}.bias"] = 0.02 * torch.randn(1, generator=g)
     return W
+
+
+def synth_cosyvoice2_codec_weights(flow_cfg=None, hift_cfg=None, seed=0):
+    """Random-init CosyVoice2 detokenizer weights (flow.pt / hift.pt names; CPU fp32 tensors holding bf16-representable values, fan-in
+    scaled) + a synthetic speaker prompt {prompt_speech_token [1, Np], prompt_feat [1, 2 Np, 80], embedding [1, 192]}."""
+    import math
+    from .tokenizer.cosyvoice_flow import FlowConfig
+    from .tokenizer.hifigan import HiFTConfig
+    fc, hc = flow_cfg or FlowConfig(), hift_cfg or HiFTConfig()
+    g = torch.Generator().manual_seed(seed)
+    F, H = {}, {}
+
+    def w(d, name, shape, gain=1.0):
+        fan = 1
+        for v in shape[1:]:
+            fan *= v
+        d[name] = (gain * torch.randn(shape, generator=g) / math.sqrt(max(fan, 1))).to(torch.bfloat16).float()
+
+    def lin(d, n, o, i, bias=True, gain=1.0):
+        w(d, n + ".weight", (o, i), gain)
+        if bias:
+            d[n + ".bias"] = (0.05 * torch.randn(o, generator=g)).to(torch.bfloat16).float()
+
+    def ln(d, n, c):
+        d[n + ".weight"] = (1.0 + 0.1 * torch.randn(c, generator=g)).to(torch.bfloat16).float()
+        d[n + ".bias"] = (0.05 * torch.randn(c, generator=g)).to(torch.bfloat16).float()
+
+    def conv(d, n, o, i, k, gain=1.0):
+        w(d, n + ".weight", (o, i, k), gain)
+        d[n + ".bias"] = (0.05 * torch.randn(o, generator=g)).to(torch.bfloat16).float()
+
+    D = fc.dim
+    F["input_embedding.weight"] = torch.randn(fc.vocab_size, D, generator=g).to(torch.bfloat16).float()
+    lin(F, "spk_embed_affine_layer", fc.mel, fc.spk_embed_dim)
+    lin(F, "encoder_proj", fc.mel, D)
+    for e in ("encoder.embed", "encoder.up_embed"):
+        lin(F, e + ".out.0", D, D)
+        ln(F, e + ".out.1", D)
+    ln(F, "encoder.after_norm", D)
+    conv(F, "encoder.pre_lookahead_layer.conv1", D, D, fc.pre_lookahead_len + 1)
+    conv(F, "encoder.pre_lookahead_layer.conv2", D, D, 3)
+    conv(F, "encoder.up_layer.conv", D, D, 5)
+    for grp, nl in (("encoder.encoders", fc.enc_layers), ("encoder.up_encoders", fc.up_layers)):
+        for i in range(nl):
+            p = f"{grp}.{i}."
+            for q in ("linear_q", "linear_k", "linear_v"):
+                lin(F, p + "self_attn." + q, D, D)
+            lin(F, p + "self_attn.linear_out", D, D, gain=0.5)
+            lin(F, p + "self_attn.linear_pos", D, D, bias=False)
+            for b in ("pos_bias_u", "pos_bias_v"):
+                F[p + "self_attn." + b] = (0.3 * torch.randn(fc.enc_heads, D // fc.enc_heads, generator=g)).to(torch.bfloat16).float()
+            lin(F, p + "feed_forward.w_1", fc.enc_ffn, D)
+            lin(F, p + "feed_forward.w_2", D, fc.enc_ffn, gain=0.5)
+            ln(F, p + "norm_ff", D)
+            ln(F, p + "norm_mha", D)
+    es, C = "decoder.estimator.", fc.est_channels
+    TE, inner = 4 * C, fc.est_heads * fc.est_head_dim
+    lin(F, es + "time_mlp.linear_1", TE, 4 * fc.mel)
+    lin(F, es + "time_mlp.linear_2", TE, TE)
+    groups = [(es + "down_blocks.0.", 4 * fc.mel)] + [(f"{es}mid_blocks.{i}.", C) for i in range(fc.est_mid_blocks)] + [(es + "up_blocks.0.", 2 * C)]
+    for gp, cin in groups:
+        p = gp + "0."
+        lin(F, p + "mlp.1", C, TE)
+        conv(F, p + "block1.block.0", C, cin, 3)
+        ln(F, p + "block1.block.2", C)
+        conv(F, p + "block2.block.0", C, C, 3)
+        ln(F, p + "block2.block.2", C)
+        conv(F, p + "res_conv", C, cin, 1)
+        for j in range(fc.est_blocks):
+            p = f"{gp}1.{j}."
+            ln(F, p + "norm1", C)
+            for q in ("to_q", "to_k", "to_v"):
+                lin(F, p + "attn1." + q, inner, C, bias=False)
+            lin(F, p + "attn1.to_out.0", C, inner, gain=0.5)
+            ln(F, p + "norm3", C)
+            lin(F, p + "ff.net.0.proj", 4 * C, C)
+            lin(F, p + "ff.net.2", C, 4 * C, gain=0.5)
+    for n in ("down_blocks.0.2", "up_blocks.0.2", "final_block.block.0"):
+        conv(F, es + n, C, C, 3)
+    ln(F, es + "final_block.block.2", C)
+    conv(F, es + "final_proj", fc.mel, C, 1)
+
+    # HiFT (weight-norm parametrizations like the checkpoint)
+    def wn(name, shape, gain=1.0):
+        H[name + ".parametrizations.weight.original0"] = (gain * (0.7 + 0.6 * torch.rand(shape[0], 1, 1, generator=g))).to(torch.bfloat16).float()
+        H[name + ".parametrizations.weight.original1"] = torch.randn(shape, generator=g).to(torch.bfloat16).float()
+
+    def wnb(name, shape, gain=1.0, nb=None):
+        wn(name, shape, gain)
+        H[name + ".bias"] = (0.02 * torch.randn(shape[0] if nb is None else nb, generator=g)).to(torch.bfloat16).float()
+
+    H1, nst, nk = hc.nb_harmonics + 1, len(hc.upsample_rates), len(hc.resblock_kernel_sizes)
+    H["m_source.l_linear.weight"] = (0.6 * torch.randn(1, H1, generator=g)).to(torch.bfloat16).float()
+    H["m_source.l_linear.bias"] = torch.zeros(1)
+    wnb("conv_pre", (hc.base_channels, hc.in_channels, 7))
+
+    def resblock(p, ch, k):
+        for j in range(3):
+            wnb(f"{p}.convs1.{j}", (ch, ch, k))
+            wnb(f"{p}.convs2.{j}", (ch, ch, k), gain=0.25)
+            for a in ("activations1", "activations2"):
+                H[f"{p}.{a}.{j}.alpha"] = (0.5 + torch.rand(ch, generator=g)).to(torch.bfloat16).float()
+
+    down = [1] + list(hc.upsample_rates[::-1][:-1])
+    cum = [int(v) for v in torch.tensor(down).cumprod(0).tolist()][::-1]
+    for i, (u, k) in enumerate(zip(hc.upsample_rates, hc.upsample_kernel_sizes)):
+        cin, cout = hc.base_channels // 2 ** i, hc.base_channels // 2 ** (i + 1)
+        wnb(f"ups.{i}", (cin, cout, k), nb=cout)
+        sk = 1 if cum[i] == 1 else 2 * cum[i]
+        H[f"source_downs.{i}.weight"] = (torch.randn(cout, hc.istft_n_fft + 2, sk, generator=g) / math.sqrt((hc.istft_n_fft + 2) * sk)).to(torch.bfloat16).float()
+        H[f"source_downs.{i}.bias"] = (0.02 * torch.randn(cout, generator=g)).to(torch.bfloat16).float()
+        resblock(f"source_resblocks.{i}", cout, hc.source_resblock_kernel_sizes[i])
+        for j, k2 in enumerate(hc.resblock_kernel_sizes):
+            resblock(f"resblocks.{i * nk + j}", cout, k2)
+    wnb("conv_post", (hc.istft_n_fft + 2, hc.base_channels // 2 ** nst, 7), gain=0.35)
+    H["conv_post.bias"][: hc.istft_n_fft // 2 + 1] += 1.5
+    cin = hc.in_channels
+    for li in range(5):
+        wnb(f"f0_predictor.condnet.{2 * li}", (hc.f0_channels, cin, 3), gain=1.2)
+        cin = hc.f0_channels
+    H["f0_predictor.classifier.weight"] = (torch.randn(1, hc.f0_channels, generator=g) * (120.0 / math.sqrt(hc.f0_channels))).to(torch.bfloat16).float()
+    H["f0_predictor.classifier.bias"] = torch.full((1,), 60.0)
+    Np = 40
+    prompt = {"prompt_speech_token": torch.randint(0, fc.vocab_size, (1, Np), generator=g),
+              "prompt_feat": (0.7 * torch.randn(1, 2 * Np, fc.mel, generator=g)).to(torch.bfloat16).float(),
+              "embedding": torch.randn(1, fc.spk_embed_dim, generator=g).to(torch.bfloat16).float()}
+    return {"flow": F, "hift": H}, prompt
