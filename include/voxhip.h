@@ -551,6 +551,8 @@ int vox_flow_decode_chunk(vox_flow* m, void* stream, const int32_t* tokens, int 
 /* fade_in_out (tokenizer/cosyvoice2.py:46-54): wav [n][L] (in place): the first `fade` samples of every row become
  * wav * window[:fade] + prev_tail * window[fade:] (prev_tail [n][fade] or NULL = silence; window: device double [2 fade]) */
 int vox_fade_in_out(void* stream, float* wav, int n, int L, const float* prev_tail, const double* window, int fade);
+/* z [mel][frames] = the seeded CFM start noise vox_flow_* draw when `noise` is NULL (for callers that replay captured graphs) */
+int vox_flow_fill_noise(void* stream, uint64_t seed, uint32_t noise_stream, int mel, int frames, float* z);
 
 #ifdef __cplusplus
 }

@@ -548,6 +548,9 @@ struct vox_codec {
 
 // operand planes of the conv GEMMs launched by the current decode call (set by the entry points from their object's setting)
 static thread_local int g_conv_planes = 3;
+// rows up to which the few-row GEMM variant (16-row tiles, wide K steps) is used: the flow's GEMMs have 56..450 rows and K <= 2048, their
+// time is the number of dependent K steps, not MFMA issue
+static thread_local int g_conv_skinny_rows = 48;
 static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const float* state, const int* slots, int n,
                      int L, int P, const int* offs, float* out, const float* res, const float* scale, int gelu,
                      float* out2 = nullptr, const vox_snake_w* sn = nullptr, int sn_mod = 0, const float* rscale = nullptr) {
@@ -560,7 +563,7 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     a.bias_mod = w.bias_mod > 0 ? w.bias_mod : w.n; a.gelu = gelu;
     if (out2 && sn) { a.out2 = out2; a.sn_alpha = sn->alpha; a.sn_invb = sn->inv_beta; a.sn_mod = sn_mod > 0 ? sn_mod : w.n; }
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
-    if (a.M <= 48) {
+    if (a.M <= g_conv_skinny_rows) {
         const dim3 g((w.n + 63) / 64, (a.M + 15) / 16);
         if (w.cin % 128 == 0) hipLaunchKernelGGL(k_conv_gemm_skinny<128>, g, dim3(256), 0, st, a);
         else if (w.cin % 64 == 0) hipLaunchKernelGGL(k_conv_gemm_skinny<64>, g, dim3(256), 0, st, a);
@@ -1823,7 +1826,7 @@ struct FlowAttn {
 #define FLOW_MAXKEYS 1024
 __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
     __shared__ float ps[4][FLOW_MAXKEYS];
-    __shared__ float qs[4][2][128];
+    __shared__ __attribute__((aligned(16))) float qs[4][2][128];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave, h = blockIdx.y, n = blockIdx.z;
     if (i >= a.T) return;
@@ -1836,18 +1839,30 @@ __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
     }
     __builtin_amdgcn_wave_barrier();
     float mx = -INFINITY;
+    const int dk4 = a.dk >> 2;
+    const float4* q4 = reinterpret_cast<const float4*>(qs[wave][0]);
+    const float4* v4 = reinterpret_cast<const float4*>(qs[wave][1]);
     for (int j = lane; j < S; j += 64) {
-        const float* kr = j < a.Tc ? cache + (size_t)j * 2 * a.dk : a.qkv + ((size_t)n * a.T + (j - a.Tc)) * ld + HD + h * a.dk;
+        const float4* kr = reinterpret_cast<const float4*>(j < a.Tc ? cache + (size_t)j * 2 * a.dk
+                                                                    : a.qkv + ((size_t)n * a.T + (j - a.Tc)) * ld + HD + h * a.dk);
         float ac = 0.0f;
-        for (int d = 0; d < a.dk; ++d) ac = fmaf(qs[wave][0][d], kr[d], ac);
+#pragma unroll 4
+        for (int d = 0; d < dk4; ++d) {
+            const float4 k = kr[d], q = q4[d];
+            ac = fmaf(q.x, k.x, ac); ac = fmaf(q.y, k.y, ac); ac = fmaf(q.z, k.z, ac); ac = fmaf(q.w, k.w, ac);
+        }
         if (a.P) {
             const long f = (long)i * (2 * S - 1) + j + a.T;
             const int r = (int)(f / (2 * S)), ci = (int)(f % (2 * S));
             if (ci > 0) {
-                const float* qr = a.qkv + ((size_t)n * a.T + r) * ld + h * a.dk;
-                const float* pr = a.P + (size_t)(ci - 1) * HD + h * a.dk;
+                const float4* qr = reinterpret_cast<const float4*>(a.qkv + ((size_t)n * a.T + r) * ld + h * a.dk);
+                const float4* pr = reinterpret_cast<const float4*>(a.P + (size_t)(ci - 1) * HD + h * a.dk);
                 float bd = 0.0f;
-                for (int d = 0; d < a.dk; ++d) bd = fmaf(qr[d] + qs[wave][1][d], pr[d], bd);
+#pragma unroll 4
+                for (int d = 0; d < dk4; ++d) {
+                    const float4 q = qr[d], bv = v4[d], p = pr[d];
+                    bd = fmaf(q.x + bv.x, p.x, bd); bd = fmaf(q.y + bv.y, p.y, bd); bd = fmaf(q.z + bv.z, p.z, bd); bd = fmaf(q.w + bv.w, p.w, bd);
+                }
                 ac += bd;
             }
         }
@@ -1865,13 +1880,28 @@ __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
     __builtin_amdgcn_wave_barrier();
     const float inv = 1.0f / sum;
+    // PV: lane = output dim; four independent partial sums over interleaved keys (the loads of a group are in flight together)
     for (int d = lane; d < a.dk; d += 64) {
-        float o = 0.0f;
-        for (int j = 0; j < S; ++j) {
-            const float* vr = j < a.Tc ? cache + (size_t)j * 2 * a.dk + a.dk : a.qkv + ((size_t)n * a.T + (j - a.Tc)) * ld + 2 * HD + h * a.dk;
-            o = fmaf(ps[wave][j] * inv, vr[d], o);
+        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
+        const float* vc = cache ? cache + a.dk + d : nullptr;
+        const float* vn = a.qkv + (size_t)n * a.T * ld + 2 * HD + h * a.dk + d;
+        int j = 0;
+        for (; j + 4 <= a.Tc; j += 4) {
+            o0 = fmaf(ps[wave][j], vc[(size_t)j * 2 * a.dk], o0);
+            o1 = fmaf(ps[wave][j + 1], vc[(size_t)(j + 1) * 2 * a.dk], o1);
+            o2 = fmaf(ps[wave][j + 2], vc[(size_t)(j + 2) * 2 * a.dk], o2);
+            o3 = fmaf(ps[wave][j + 3], vc[(size_t)(j + 3) * 2 * a.dk], o3);
         }
-        a.out[((size_t)n * a.T + i) * HD + h * a.dk + d] = o;
+        for (; j < a.Tc; ++j) o0 = fmaf(ps[wave][j], vc[(size_t)j * 2 * a.dk], o0);
+        int t = 0;
+        for (; t + 4 <= a.T; t += 4) {
+            o0 = fmaf(ps[wave][a.Tc + t], vn[(size_t)t * ld], o0);
+            o1 = fmaf(ps[wave][a.Tc + t + 1], vn[(size_t)(t + 1) * ld], o1);
+            o2 = fmaf(ps[wave][a.Tc + t + 2], vn[(size_t)(t + 2) * ld], o2);
+            o3 = fmaf(ps[wave][a.Tc + t + 3], vn[(size_t)(t + 3) * ld], o3);
+        }
+        for (; t < a.T; ++t) o0 = fmaf(ps[wave][a.Tc + t], vn[(size_t)t * ld], o0);
+        a.out[((size_t)n * a.T + i) * HD + h * a.dk + d] = ((o0 + o1) + (o2 + o3)) * inv;
     }
 }
 // new K | V rows of request n -> cache [half = n][H][Tcap][2 dk], keeping the first `prefix` and the last Tcap - prefix of the T rows
@@ -2015,6 +2045,9 @@ void vox_flow_destroy(vox_flow* m) {
 
 }  // extern "C"
 
+#ifndef FLOW_SKINNY_ROWS
+#define FLOW_SKINNY_ROWS 512
+#endif
 static const int FLOW_OFF0[4] = {0, 0, 0, 0};
 static const int FLOW_OFF_C3[3] = {2, 1, 0};            // causal k3
 static const int FLOW_OFF_C5[5] = {4, 3, 2, 1, 0};      // causal k5 (Upsample1D after its left pad of 4)
@@ -2051,6 +2084,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
     const int D = c.dim, M = c.mel, C = c.est_ch, T2 = 2 * T, H = c.enc_heads, dk = D / H, inner = c.est_heads * c.est_head_dim;
     float** Bf = m->buf;
     g_conv_planes = 3;
+    g_conv_skinny_rows = FLOW_SKINNY_ROWS;
     // ---- encoder ----
     float* x = Bf[3];
     hipLaunchKernelGGL(k_flow_embed, dim3(ew_grid((size_t)B * T * D)), dim3(256), 0, st, tokens, w.embedding, Bf[0], (size_t)B * T, D);
@@ -2151,6 +2185,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
         hipLaunchKernelGGL(k_flow_euler, dim3(ew_grid((size_t)B * T2 * M)), dim3(256), 0, st, xs, a2, B, T2, M, m->dt[s], c.cfg_rate);
     }
     if (init) m->att_len = T2 < capA ? T2 : capA;
+    g_conv_skinny_rows = 48;
     return VOX_OK;
 }
 
@@ -2260,5 +2295,21 @@ __global__ __launch_bounds__(256) void k_fade_in(float* wav, const float* prev, 
 extern "C" int vox_fade_in_out(void* stream, float* wav, int n, int L, const float* prev_tail, const double* window, int fade) {
     if (!wav || !window || n < 1 || fade < 1 || fade > L) return vox_fail(VOX_ERR_INVALID, "fade_in_out: bad arguments");
     hipLaunchKernelGGL(k_fade_in, dim3(ew_grid((size_t)n * fade)), dim3(256), 0, (hipStream_t)stream, wav, prev_tail, window, n, L, fade);
+    return VOX_OK;
+}
+
+// the seeded CFM start noise as a tensor [mel][frames] (what vox_flow_* draw when `noise` is NULL): lets a caller that replays a captured
+// graph keep the draw outside it (a graph freezes scalar arguments such as the stream id)
+__global__ __launch_bounds__(256) void k_flow_noise_z(uint64_t seed, uint32_t stream, float* z, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        uint32_t w0, w1;
+        philox4((uint32_t)i, stream, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), &w0, &w1);
+        const float u1 = ((float)(w0 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+        z[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    }
+}
+extern "C" int vox_flow_fill_noise(void* stream, uint64_t seed, uint32_t noise_stream, int mel, int frames, float* z) {
+    if (!z || mel < 1 || frames < 1) return vox_fail(VOX_ERR_INVALID, "flow_fill_noise: bad arguments");
+    hipLaunchKernelGGL(k_flow_noise_z, dim3(ew_grid((size_t)mel * frames)), dim3(256), 0, (hipStream_t)stream, seed, noise_stream, z, (size_t)mel * frames);
     return VOX_OK;
 }

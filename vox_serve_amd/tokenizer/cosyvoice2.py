@@ -42,7 +42,11 @@ class CosyVoice2Decoder:
         self.mel_cache_len = 6
         self.source_cache_len = int(self.mel_cache_len * 480)
         self.speech_window = torch.from_numpy(np.hamming(2 * self.source_cache_len)).to(self.device)      # float64, like the reference
+        self.seed, self.use_graph, self._graphs, self._chunk = seed, True, {}, 0
+        self._stream = torch.cuda.Stream(device=self.device)
         L = N.lib()
+        L.vox_flow_fill_noise.restype = ctypes.c_int
+        L.vox_flow_fill_noise.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         L.vox_fade_in_out.restype = ctypes.c_int
         L.vox_fade_in_out.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         self.L = L
@@ -62,11 +66,62 @@ class CosyVoice2Decoder:
         """speech_tokens [B, T] -> (audio fp32 [B, 2 T * 480 - 2880], the same cache)   (cosyvoice2.py:944-1063, shared mode)"""
         if speech_tokens.dim() == 1:
             speech_tokens = speech_tokens.unsqueeze(0)
+        if (self.use_graph and flow_noise is None and hift_noise is None and hift_stream_base is None and flow_noise_stream is None
+                and speech_tokens.shape[0] <= self.flow.max_batch):
+            return self._decode_chunk_graph(speech_tokens), decoder_cache
         mels = self.flow.forward_chunk(speech_tokens, noise=flow_noise, noise_stream=flow_noise_stream)
         wav, _ = self.hift.forward_chunk(mels, noise=hift_noise, stream_base=hift_stream_base)
         B, Lw = wav.shape
         N.check(self.L.vox_fade_in_out(N.stream(), wav.data_ptr(), B, Lw, None, self.speech_window.data_ptr(), self.source_cache_len))
         return wav[:, : Lw - self.source_cache_len], decoder_cache
+
+    def _decode_chunk_graph(self, speech_tokens: torch.Tensor) -> torch.Tensor:
+        """The ~7 000 launches of a chunk (flow: 10 estimator passes of 70 blocks; HiFT) as one hipGraph per (requests, tokens): inputs go
+        into graph-stable buffers, the CFM start noise is drawn into one before the replay (a graph would freeze its stream id), the
+        vocoder's noise streams are read from a device array.  The first chunk of a shape runs eagerly, the second is captured.  The
+        returned tensor is a fresh copy."""
+        B, T = speech_tokens.shape
+        c, L = self.flow.cfg, self.L
+        key = (B, T)
+        ent = self._graphs.get(key)
+        if ent is None:
+            Lw = 2 * T * self.hift.upsample_scale
+            ent = self._graphs[key] = {"tok": torch.empty(B, T, dtype=torch.int32, device=self.device),
+                                       "z": torch.empty(c.mel, 2 * T, dtype=torch.float32, device=self.device),
+                                       "sb": torch.empty(B, dtype=torch.int32, device=self.device),
+                                       "mel": torch.empty(B, c.mel, 2 * T, dtype=torch.float32, device=self.device),
+                                       "wav": torch.empty(B, Lw, dtype=torch.float32, device=self.device), "g": None, "calls": 0}
+        self._chunk += 1
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            st = N.stream()
+            ent["tok"].copy_(speech_tokens.to(self.device, torch.int32), non_blocking=True)
+            ent["sb"].copy_(((torch.arange(B, dtype=torch.int64) + self._chunk * 65536) * 2).to(torch.int32), non_blocking=True)
+            N.check(L.vox_flow_fill_noise(st, ctypes.c_uint64(self.seed), self._chunk, c.mel, 2 * T, ent["z"].data_ptr()))
+
+            def body():
+                N.check(self.flow.L.vox_flow_decode_chunk(self.flow.h, st, ent["tok"].data_ptr(), B, T, ent["z"].data_ptr(), ctypes.c_uint64(self.seed), 0,
+                                                          ent["mel"].data_ptr(), None))
+                N.check(self.hift.L.vox_hift_decode(self.hift.h, st, ent["mel"].data_ptr(), B, 2 * T, None, ctypes.c_uint64(self.seed),
+                                                    ent["sb"].data_ptr(), ent["wav"].data_ptr(), None))
+                N.check(L.vox_fade_in_out(st, ent["wav"].data_ptr(), B, ent["wav"].shape[1], None, self.speech_window.data_ptr(), self.source_cache_len))
+            ent["calls"] += 1
+            if ent["calls"] == 1:
+                body()
+            else:
+                if ent["g"] is None:
+                    N.check(L.vox_graph_begin(N.ctx(), st))
+                    try:
+                        body()
+                    finally:
+                        gh = ctypes.c_void_p()
+                        N.check(L.vox_graph_end(N.ctx(), st, ctypes.byref(gh)))
+                    ent["g"] = gh
+                N.check(L.vox_graph_launch(ent["g"], st))
+            out = ent["wav"][:, : ent["wav"].shape[1] - self.source_cache_len].clone()
+        cur.wait_stream(self._stream)
+        return out
 
     def close(self):
         self.flow.close()
