@@ -213,7 +213,7 @@ class FlowRef:
         """LinearNoSubsampling + the positional encoding's x * sqrt(d)"""
         return self._ln(self._lin(x, n + ".out.0"), n + ".out.1", 1e-5) * math.sqrt(self.c.dim)
 
-    def _conformer(self, x, p, pos_emb, cache):
+    def _conformer(self, x, p, pos_emb, cache, mask=None):
         """x [B, T, D]; cache [Bc, H, Tc, 2 dk] or None -> (x, new_cache [B, H, Tc + T, 2 dk])"""
         c = self.c
         H, dk = c.enc_heads, c.dim // c.enc_heads
@@ -234,7 +234,12 @@ class FlowRef:
         bd = torch.matmul(qv, pe.transpose(-2, -1))
         if ac.shape != bd.shape:
             bd = rel_shift(bd)
-        att = torch.softmax((ac + bd) / math.sqrt(dk), dim=-1)
+        sc = (ac + bd) / math.sqrt(dk)
+        if mask is not None:                 # MultiHeadedAttention.forward_attention: -inf before the softmax, 0 after
+            sc = sc.masked_fill(~mask, -float("inf"))
+        att = torch.softmax(sc, dim=-1)
+        if mask is not None:
+            att = att.masked_fill(~mask, 0.0)
         o = torch.matmul(att, v).transpose(1, 2).contiguous().view(B, T, H * dk)
         x = r + self._lin(o, p + "self_attn.linear_out")
         n = self._ln(x, p + "norm_ff", 1e-12)

@@ -197,6 +197,41 @@ def _fake_permissive(name):
 _BOOTED = None
 
 
+def _build_diffusers_standin():
+    """diffusers==0.34.0 (pyproject.toml:34; not installed here) is used by tokenizer/glm.py:1563 for ONE class,
+    `diffusers.models.attention_processor.Attention`, as a bias-free self-attention of the GLM estimator's transformer blocks.  The
+    stand-in is OUR restatement of its published default path (AttnProcessor2_0): to_q / to_k / to_v (bias as given), heads split,
+    torch scaled_dot_product_attention, to_out = [Linear(inner, query_dim), Dropout] — same parameter names as the checkpoint."""
+    import torch
+    import torch.nn.functional as F
+    from torch import nn
+
+    class Attention(nn.Module):
+        def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False, upcast_attention=False, **kw):
+            super().__init__()
+            inner = dim_head * heads
+            kv_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+            self.heads = heads
+            self.to_q = nn.Linear(query_dim, inner, bias=bias)
+            self.to_k = nn.Linear(kv_dim, inner, bias=bias)
+            self.to_v = nn.Linear(kv_dim, inner, bias=bias)
+            self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+
+        def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+            B, T, _ = hidden_states.shape
+            ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+            q, k, v = self.to_q(hidden_states), self.to_k(ctx), self.to_v(ctx)
+            hd = q.shape[-1] // self.heads
+            q, k, v = (t.view(B, -1, self.heads, hd).transpose(1, 2) for t in (q, k, v))
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask, dropout_p=0.0, is_causal=False)
+            o = o.transpose(1, 2).reshape(B, -1, self.heads * hd).to(q.dtype)
+            return self.to_out[1](self.to_out[0](o))
+
+    _fake("diffusers")
+    _fake("diffusers.models")
+    _fake("diffusers.models.attention_processor", Attention=Attention)
+
+
 def boot():
     """Import the reference's hot-path modules on CPU.  Returns a namespace of modules."""
     global _BOOTED
@@ -216,6 +251,7 @@ def boot():
 
     # 2. stand-ins
     _build_flashinfer_standin()
+    _build_diffusers_standin()
     for n in ("librosa", "librosa.filters", "torchaudio", "torchaudio.functional", "torchaudio.transforms",
               "torchaudio.compliance", "torchaudio.compliance.kaldi", "onnxruntime", "onnx", "zmq",
               "zmq.asyncio", "inflect", "tiktoken"):

@@ -1004,8 +1004,66 @@ def g12_flow(ns):
     np.savez_compressed(os.path.join(HERE, "g12_flow.npz"), **out)
 
 
+def g13_glm_decoder(ns):
+    """GLM-4-Voice detokenizer through the reference modules (tokenizer/glm.py): GLMFlowModel.inference (block conformer encoder, length
+    regulator, 10-step CFM with a non-causal U-Net) and GLMHiFTModel (two x8 stages, SineGen v1), as GLMAudioDecoder.forward chains them
+    (:2640-2651), fp32, tiny and GLM-4-Voice size, with the random draws replaced by the seeded streams (oracle/glm_dec_ref.py)."""
+    import importlib
+    from oracle import glm_dec_ref as GR, hift_ref as HR
+    Gm = importlib.import_module("vox_serve.tokenizer.glm")
+    out = {}
+    for tag, fc, hc in (("tiny", GR.tiny_glm_flow_cfg(), GR.glm_hift_cfg(base_channels=128, f0_channels=64)), ("full", GR.GlmFlowCfg(), GR.glm_hift_cfg())):
+        Wf, Wh = GR.random_glm_flow_weights(fc, seed=5), HR.random_hift_weights(hc, seed=6)
+        flow = Gm.GLMFlowModel(vocab_size=fc.vocab,
+                               encoder=Gm.BlockConformerEncoder(attention_heads=fc.enc_heads, linear_units=fc.enc_ffn, num_blocks=fc.enc_layers,
+                                                                block_size=fc.block_size),
+                               length_regulator=Gm.InterpolateRegulator(),
+                               decoder=Gm.ConditionalCFM(estimator=Gm.ConditionalDecoder(channels=(fc.est_ch, fc.est_ch), attention_head_dim=fc.est_head_dim,
+                                                                                         n_blocks=fc.est_blocks, num_mid_blocks=fc.est_mid,
+                                                                                         num_heads=fc.est_heads))).eval()
+        flow.load_state_dict(Wf, strict=True)
+        hift = Gm.GLMHiFTModel(base_channels=hc.base_channels,
+                               f0_predictor=Gm.ConvRNNF0Predictor(cond_channels=hc.f0_channels)).eval()
+        Wh_old = {k.replace(".parametrizations.weight.original0", ".weight_g").replace(".parametrizations.weight.original1", ".weight_v"): v
+                  for k, v in Wh.items()}
+        hift.load_state_dict(Wh_old, strict=True)
+        g = torch.Generator().manual_seed(8)
+        B, T = 2, 25
+        tok = torch.randint(0, fc.vocab, (B, T), generator=g)
+        Tm = fc.mel_len(T)
+        seed = 47
+        z = GR.glm_cfm_noise(seed, 0, B, fc.mel, Tm)
+        ini, nz = HR.make_noise(hc, B, Tm, seed=seed, first_stream=8)
+        real_randn_like = torch.randn_like
+
+        def fake_randn_like(t, **kw):
+            if tuple(t.shape) == tuple(z.shape):
+                return z.clone()
+            if tuple(t.shape) == (B, hc.nb_harmonics + 1, Tm * hc.upsample_scale):
+                return nz.transpose(1, 2).clone()
+            return torch.zeros_like(t)
+
+        class FakeU:
+            def sample(self, sample_shape):
+                assert tuple(sample_shape) == (B, hc.nb_harmonics + 1, 1), sample_shape
+                return (-np.pi + 2 * np.pi * ini).unsqueeze(-1).float()
+        hift.m_source.l_sin_gen._u_dist = FakeU()
+        torch.randn_like = fake_randn_like
+        try:
+            with torch.no_grad():
+                mel = flow.inference(token=tok, token_len=torch.tensor([T], dtype=torch.int32), embedding=torch.zeros(B, 192))
+                wav, src = hift.inference(mel=mel)
+        finally:
+            torch.randn_like = real_randn_like
+        out[f"{tag}_token"], out[f"{tag}_mel"] = tok.numpy().astype(np.int32), mel.numpy().astype(np.float32)
+        out[f"{tag}_wav"], out[f"{tag}_source"] = wav.numpy().astype(np.float32), src.numpy().astype(np.float32)
+        print("g13", tag, "mel", tuple(mel.shape), "rms", float(mel.pow(2).mean().sqrt()), "wav", tuple(wav.shape), "rms", float(wav.pow(2).mean().sqrt()))
+    out["noise_seed"] = np.int64(47)
+    np.savez_compressed(os.path.join(HERE, "g13_glm_decoder.npz"), **out)
+
+
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder}
 
 if __name__ == "__main__":
     ns = H.boot()

@@ -422,3 +422,27 @@ def test_flow_oracle_matches_reference_decoder(golden, tag):
     assert mel.shape == (B, fc.mel, 2 * T) and audio.shape == (B, 24000)
     assert em < 2e-5 * max(1.0, float(np.sqrt(np.mean(g[f"{tag}_mel"] ** 2)))), em
     assert ea < 5e-5, ea
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_glm_decoder_oracle_matches_reference_modules(golden, tag):
+    """oracle/glm_dec_ref.py vs the reference GLMFlowModel.inference + GLMHiFTModel (g13): mels, harmonic source, waveform, with the
+    seeded noise on both sides (diffusers' Attention is stood in by its published SDPA path in the generator: tests/golden/_ref_harness.py)."""
+    import torch
+    from oracle import glm_dec_ref as GR, hift_ref as HR
+    g = golden("g13_glm_decoder")
+    fc, hc = (GR.tiny_glm_flow_cfg(), GR.glm_hift_cfg(base_channels=128, f0_channels=64)) if tag == "tiny" else (GR.GlmFlowCfg(), GR.glm_hift_cfg())
+    fr, hr = GR.GlmFlowRef(fc, GR.random_glm_flow_weights(fc, seed=5)), GR.GlmHiftRef(hc, HR.random_hift_weights(hc, seed=6))
+    seed = int(g["noise_seed"])
+    tok = torch.from_numpy(g[f"{tag}_token"]).long()
+    B, T = tok.shape
+    Tm = fc.mel_len(T)
+    assert Tm == 172
+    with torch.no_grad():
+        mel = fr.inference(tok, GR.glm_cfm_noise(seed, 0, B, fc.mel, Tm))
+        ini, nz = HR.make_noise(hc, B, Tm, seed=seed, first_stream=8)
+        wav, src = hr.forward_chunk(mel, ini, nz)
+    rms = lambda x: float(np.sqrt(np.mean(np.asarray(x, np.float64) ** 2)))
+    em, es, ew = rms(mel.numpy() - g[f"{tag}_mel"]), rms(src.numpy() - g[f"{tag}_source"]), rms(wav.numpy() - g[f"{tag}_wav"])
+    assert wav.shape == (B, 44032)
+    assert em < 2e-5 and es < 1e-4 and ew < 1e-4, (em, es, ew)
