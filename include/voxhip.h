@@ -479,14 +479,17 @@ typedef struct {
     int32_t in_channels, in_channels_padded, base_channels, nb_harmonics, sampling_rate, n_stages, upsample_rates[4],
         upsample_kernels[4], n_fft, hop_len, n_kernels, resblock_kernels[4], dilations[3], source_resblock_kernels[4], f0_channels;
     float nsf_alpha, nsf_sigma, voiced_threshold, lrelu_slope, audio_limit;
+    int32_t sine_gen_v1;   /* 1: GLM-4-Voice's SineGen (tokenizer/glm.py:2254-2331): phase accumulated per SAMPLE, theta = 2 pi (cumsum(f0 h / sr) mod 1)
+                              + a random initial phase per harmonic (uniform stream stream_base[b], element h; or rand_ini), which does matter */
 } vox_hift_config;
 typedef struct vox_hift vox_hift;
 int vox_hift_create(vox_ctx* ctx, const vox_hift_config* cfg, const vox_hift_weights* w, int max_batch, int max_T, vox_hift** out);
 void vox_hift_destroy(vox_hift* m);
 /* mel: device fp32 [n][in_channels][T] (the reference's layout); wav: fp32 [n][T * scale], scale = prod(upsample_rates) * hop_len;
  * source (optional): fp32 [n][T * scale], the merged harmonic source (the reference returns it for its cache). */
+/* rand_ini (sine_gen_v1 only, optional): fp32 [n][H + 1] uniforms in [0, 1) for the initial phases (NULL: the seeded stream) */
 int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, const float* noise, uint64_t seed,
-                    const uint32_t* stream_base, float* wav, float* source);
+                    const uint32_t* stream_base, float* wav, float* source, const float* rand_ini);
 
 /* ---- CosyVoice2 flow: speech tokens -> mel (conformer encoder + 10-step conditional flow matching) -----------------------
  * Replaces CausalMaskedDiffWithXvec.forward_chunk (/root/reference/vox_serve/tokenizer/cosyvoice_flow.py:2909-2980:

@@ -1473,6 +1473,62 @@ __global__ __launch_bounds__(256) void k_hift_source(const float* f0, const floa
         s[i] = tanhf(acc + lb);
     }
 }
+// SineGen v1 (GLM-4-Voice's vocoder, tokenizer/glm.py:2298-2316): theta[b][l][h] = 2 pi ((cumulative sum over samples of f0 (h+1) / sr) mod 1),
+// the sum accumulated in double like torch.cumsum on the CPU; one thread per (request, harmonic)
+__global__ void k_hift_theta_v1(const float* f0, float* theta, int n, int T, int H1, int scale, float sr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * H1) return;
+    const int b = i / H1, h = i % H1;
+    double cum = 0.0;
+    const size_t L = (size_t)T * scale;
+    for (int t = 0; t < T; ++t) {
+        const float F = (f0[(size_t)b * T + t] * (float)(h + 1)) / sr;
+        for (int q = 0; q < scale; ++q) {
+            cum += (double)F;
+            const float v = (float)cum;
+            theta[((size_t)b * L + (size_t)t * scale + q) * H1 + h] = 6.28318548202514648f * (v - floorf(v));
+        }
+    }
+}
+// merged source for SineGen v1: sin(theta + initial phase), voiced / unvoiced noise, tanh(linear).  Initial phases: -pi + 2 pi u with u
+// given (rand_ini [n][H1], column 0 ignored) or word 0 of the seeded uniform stream stream_base[b] (element h); phase of the fundamental = 0
+__global__ __launch_bounds__(256) void k_hift_source_v1(const float* f0, const float* theta, const float* rand_ini, const float* noise, uint64_t seed,
+                                                         const uint32_t* stream_base, const float* lw, float lb, float* s, int n, int T, int H1,
+                                                         int scale, float alpha, float sigma, float vth) {
+    const size_t L = (size_t)T * scale, total = (size_t)n * L;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / L);
+        const size_t l = i % L;
+        const float uv = f0[(size_t)b * T + l / scale] > vth ? 1.0f : 0.0f;
+        const float amp = uv * sigma + (1.0f - uv) * alpha / 3.0f;
+        const uint32_t sb = stream_base ? stream_base[b] : (uint32_t)(2 * b);
+        float acc = 0.0f;
+        for (int h = 0; h < H1; ++h) {
+            float ph = 0.0f;
+            if (h > 0) {
+                float u;
+                if (rand_ini) u = rand_ini[(size_t)b * H1 + h];
+                else {
+                    uint32_t w0, w1;
+                    philox4((uint32_t)h, sb, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), &w0, &w1);
+                    u = (float)(w0 >> 8) * (1.0f / 16777216.0f);
+                }
+                ph = -3.14159274101257324f + 6.28318548202514648f * u;
+            }
+            float nz;
+            if (noise) nz = noise[i * H1 + h];
+            else {
+                uint32_t w0, w1;
+                philox4((uint32_t)(l * H1 + h), sb + 1u, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), &w0, &w1);
+                const float u1 = ((float)(w0 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+                nz = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+            }
+            const float sw = (alpha * sinf(theta[i * H1 + h] + ph)) * uv + amp * nz;
+            acc = fmaf(sw, lw[h], acc);
+        }
+        s[i] = tanhf(acc + lb);
+    }
+}
 // STFT of the source (torch.stft: n_fft 16, hop 4, periodic Hann, center = True with reflect padding): S[b][f][k] real rows
 // 0..nb-1, imaginary rows nb..2nb-1; one thread per (b, frame, bin)
 __global__ __launch_bounds__(256) void k_hift_stft(const float* s, float* S, int n, int L, int F, int nfft, int hop) {
@@ -1590,7 +1646,8 @@ struct vox_hift {
     int max_batch, max_T, scale;
     float* buf[9];
     size_t buf_floats;
-    float *f0, *ph, *src, *stft, *post;
+    float *f0, *ph, *src, *stft, *post, *theta = nullptr;
+    int sine_v1 = 0;
 };
 
 static int hift_conv_offsets(int k, int dil, int* off, int planes = 2) {   // "same" conv: tap j reads row t + (j - (k-1)/2) dil
@@ -1614,7 +1671,7 @@ extern "C" {
 void vox_hift_destroy(vox_hift* m) {
     if (!m) return;
     for (int i = 0; i < 9; ++i) (void)hipFree(m->buf[i]);
-    (void)hipFree(m->f0); (void)hipFree(m->ph); (void)hipFree(m->src); (void)hipFree(m->stft); (void)hipFree(m->post);
+    (void)hipFree(m->f0); (void)hipFree(m->ph); (void)hipFree(m->src); (void)hipFree(m->stft); (void)hipFree(m->post); (void)hipFree(m->theta);
     delete m;
 }
 
@@ -1645,6 +1702,8 @@ int vox_hift_create(vox_ctx* ctx, const vox_hift_config* cfg, const vox_hift_wei
          hipMalloc((void**)&m->src, (size_t)max_batch * L * 4) == hipSuccess &&
          hipMalloc((void**)&m->stft, (size_t)max_batch * F * (cfg->n_fft + 2) * 4) == hipSuccess &&
          hipMalloc((void**)&m->post, (size_t)max_batch * F * (cfg->n_fft + 2) * 4) == hipSuccess;
+    m->sine_v1 = cfg->sine_gen_v1;
+    if (m->sine_v1) ok = ok && hipMalloc((void**)&m->theta, (size_t)max_batch * L * (cfg->nb_harmonics + 1) * 4) == hipSuccess;
     if (!ok) { vox_hift_destroy(m); return vox_fail(VOX_ERR_NOMEM, "hift_create: hipMalloc failed"); }
     *out = m;
     return VOX_OK;
@@ -1666,7 +1725,7 @@ static int hift_resblock(hipStream_t st, const vox_hift_resblock_w& rb, const vo
 }
 
 int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, const float* noise, uint64_t seed,
-                    const uint32_t* stream_base, float* wav, float* source) {
+                    const uint32_t* stream_base, float* wav, float* source, const float* rand_ini) {
     if (!m || !mel || !wav) return vox_fail(VOX_ERR_INVALID, "hift_decode: NULL");
     if (n < 1 || n > m->max_batch || T < 1 || T > m->max_T) return vox_fail(VOX_ERR_INVALID, "hift_decode: n %d / T %d out of range", n, T);
     const vox_hift_config& c = m->cfg;
@@ -1692,9 +1751,15 @@ int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, c
         hipLaunchKernelGGL(k_hift_f0cls, dim3((n * T + 3) / 4), dim3(256), 0, st, in, w.f0_cls_w, w.f0_cls_b, m->f0, n * T, c.f0_channels);
     }
     // ---- harmonic source + its STFT ----
-    hipLaunchKernelGGL(k_hift_phase, dim3((n * H1 + 63) / 64), dim3(64), 0, st, m->f0, m->ph, n, T, H1, (float)c.sampling_rate, (float)m->scale);
-    hipLaunchKernelGGL(k_hift_source, dim3(ew_grid((size_t)n * L)), dim3(256), 0, st, m->f0, m->ph, noise, seed, stream_base, w.src_lin_w,
-                       w.src_lin_b, m->src, n, T, H1, m->scale, (float)(1.0 / (double)m->scale), c.nsf_alpha, c.nsf_sigma, c.voiced_threshold);
+    if (m->sine_v1) {
+        hipLaunchKernelGGL(k_hift_theta_v1, dim3((n * H1 + 63) / 64), dim3(64), 0, st, m->f0, m->theta, n, T, H1, m->scale, (float)c.sampling_rate);
+        hipLaunchKernelGGL(k_hift_source_v1, dim3(ew_grid((size_t)n * L)), dim3(256), 0, st, m->f0, m->theta, rand_ini, noise, seed, stream_base,
+                           w.src_lin_w, w.src_lin_b, m->src, n, T, H1, m->scale, c.nsf_alpha, c.nsf_sigma, c.voiced_threshold);
+    } else {
+        hipLaunchKernelGGL(k_hift_phase, dim3((n * H1 + 63) / 64), dim3(64), 0, st, m->f0, m->ph, n, T, H1, (float)c.sampling_rate, (float)m->scale);
+        hipLaunchKernelGGL(k_hift_source, dim3(ew_grid((size_t)n * L)), dim3(256), 0, st, m->f0, m->ph, noise, seed, stream_base, w.src_lin_w,
+                           w.src_lin_b, m->src, n, T, H1, m->scale, (float)(1.0 / (double)m->scale), c.nsf_alpha, c.nsf_sigma, c.voiced_threshold);
+    }
     if (source) (void)hipMemcpyAsync(source, m->src, (size_t)n * L * 4, hipMemcpyDeviceToDevice, st);
     const int F = (int)(L / c.hop_len) + 1;
     hipLaunchKernelGGL(k_hift_stft, dim3(ew_grid((size_t)n * F * (c.n_fft / 2 + 1))), dim3(256), 0, st, m->src, m->stft, n, (int)L, F, c.n_fft,

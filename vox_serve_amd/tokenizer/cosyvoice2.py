@@ -104,7 +104,7 @@ class CosyVoice2Decoder:
                 N.check(self.flow.L.vox_flow_decode_chunk(self.flow.h, st, ent["tok"].data_ptr(), B, T, ent["z"].data_ptr(), ctypes.c_uint64(self.seed), 0,
                                                           ent["mel"].data_ptr(), None))
                 N.check(self.hift.L.vox_hift_decode(self.hift.h, st, ent["mel"].data_ptr(), B, 2 * T, None, ctypes.c_uint64(self.seed),
-                                                    ent["sb"].data_ptr(), ent["wav"].data_ptr(), None))
+                                                    ent["sb"].data_ptr(), ent["wav"].data_ptr(), None, None))
                 N.check(L.vox_fade_in_out(st, ent["wav"].data_ptr(), B, ent["wav"].shape[1], None, self.speech_window.data_ptr(), self.source_cache_len))
             ent["calls"] += 1
             if ent["calls"] == 1:

@@ -44,6 +44,7 @@ class HiFTConfig:
     lrelu_slope: float = 0.1
     audio_limit: float = 0.99
     f0_channels: int = 512
+    sine_gen_v1: bool = False          # GLM-4-Voice's GLMHiFTModel (tokenizer/glm.py:2385-2594): SineGen v1, two x8 stages, 22.05 kHz
 
     @property
     def upsample_scale(self) -> int:
@@ -65,7 +66,8 @@ class HiftConfigC(ctypes.Structure):
                [("upsample_rates", ctypes.c_int32 * 4), ("upsample_kernels", ctypes.c_int32 * 4), ("n_fft", ctypes.c_int32),
                 ("hop_len", ctypes.c_int32), ("n_kernels", ctypes.c_int32), ("resblock_kernels", ctypes.c_int32 * 4),
                 ("dilations", ctypes.c_int32 * 3), ("source_resblock_kernels", ctypes.c_int32 * 4), ("f0_channels", ctypes.c_int32)] + \
-               [(n, ctypes.c_float) for n in ("nsf_alpha", "nsf_sigma", "voiced_threshold", "lrelu_slope", "audio_limit")]
+               [(n, ctypes.c_float) for n in ("nsf_alpha", "nsf_sigma", "voiced_threshold", "lrelu_slope", "audio_limit")] + \
+               [("sine_gen_v1", ctypes.c_int32)]
 
 
 def _bind(L):
@@ -76,7 +78,7 @@ def _bind(L):
                                                                 ctypes.POINTER(vp)]
     L.vox_hift_destroy.restype, L.vox_hift_destroy.argtypes = None, [vp]
     L.vox_hift_decode.restype = ci
-    L.vox_hift_decode.argtypes = [vp, vp, vp, ci, ci, vp, ctypes.c_uint64, vp, vp, vp]
+    L.vox_hift_decode.argtypes = [vp, vp, vp, ci, ci, vp, ctypes.c_uint64, vp, vp, vp, vp]
     L._hift_bound = True
 
 
@@ -176,7 +178,7 @@ class HiFTGenerator:
         hc = HiftConfigC(c.in_channels, c.in_channels + (-c.in_channels) % 32, c.base_channels, c.nb_harmonics, c.sampling_rate, nst,
                          i4(c.upsample_rates), i4(c.upsample_kernel_sizes), c.istft_n_fft, c.istft_hop_len, nk, i4(c.resblock_kernel_sizes),
                          (ctypes.c_int32 * 3)(*c.resblock_dilation_sizes), i4(c.source_resblock_kernel_sizes), c.f0_channels,
-                         c.nsf_alpha, c.nsf_sigma, c.nsf_voiced_threshold, c.lrelu_slope, c.audio_limit)
+                         c.nsf_alpha, c.nsf_sigma, c.nsf_voiced_threshold, c.lrelu_slope, c.audio_limit, int(c.sine_gen_v1))
         h = ctypes.c_void_p()
         N.check(self.L.vox_hift_create(N.ctx(), ctypes.byref(hc), ctypes.byref(hw), max_batch, max_T, ctypes.byref(h)))
         self.h, self._hw = h, hw
@@ -186,7 +188,7 @@ class HiFTGenerator:
     upsample_scale = property(lambda self: self.cfg.upsample_scale)
 
     def forward_chunk(self, speech_feat: torch.Tensor, cache_source: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
-                      stream_base: Optional[torch.Tensor] = None):
+                      stream_base: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None):
         """speech_feat fp32 [B, in_channels, T] -> (audio fp32 [B, T * scale], source fp32 [B, 1, T * scale]).
         noise: optional [B, T * scale, H + 1] (else the seeded device stream).  cache_source must be None / empty, as the reference's
         streaming path calls it (decode_chunk passes the mels only)."""
@@ -200,6 +202,7 @@ class HiFTGenerator:
         for b0 in range(0, B, self.max_batch):
             nb = min(self.max_batch, B - b0)
             nz = noise[b0:b0 + nb].to(self.device, torch.float32).contiguous() if noise is not None else None
+            ri = rand_ini[b0:b0 + nb].to(self.device, torch.float32).contiguous() if rand_ini is not None else None
             sb = stream_base
             if sb is None and noise is None:
                 sb = ((torch.arange(b0, b0 + nb, device=self.device, dtype=torch.int64) + self._chunk * 65536) * 2).to(torch.int32)
@@ -207,7 +210,7 @@ class HiFTGenerator:
                 sb = sb[b0:b0 + nb].to(self.device, torch.int32).contiguous()
             N.check(self.L.vox_hift_decode(self.h, N.stream(), mel[b0:b0 + nb].data_ptr(), nb, T, nz.data_ptr() if nz is not None else None,
                                            ctypes.c_uint64(self.seed), sb.data_ptr() if sb is not None else None, wav[b0:b0 + nb].data_ptr(),
-                                           src[b0:b0 + nb].data_ptr()))
+                                           src[b0:b0 + nb].data_ptr(), ri.data_ptr() if ri is not None else None))
         if noise is None and stream_base is None:
             self._chunk += 1
         return wav, src
