@@ -557,6 +557,46 @@ int vox_fade_in_out(void* stream, float* wav, int n, int L, const float* prev_ta
 /* z [mel][frames] = the seeded CFM start noise vox_flow_* draw when `noise` is NULL (for callers that replay captured graphs) */
 int vox_flow_fill_noise(void* stream, uint64_t seed, uint32_t noise_stream, int mel, int frames, float* z);
 
+/* ---- GLM-4-Voice flow: speech tokens -> mel ---------------------------------------------------------------------------
+ * Replaces GLMFlowModel.inference (/root/reference/vox_serve/tokenizer/glm.py:2065-2112: BlockConformerEncoder :1005-1112 with
+ * BlockRelPositionMultiHeadedAttention :434-599, InterpolateRegulator :1114-1148, ConditionalCFM.solve_euler :1951-1990 with
+ * ConditionalDecoder.forward :1812-1895) as GLMAudioDecoder.forward calls it (:2640-2651).  Stateless per call.  Same arithmetic
+ * conventions as vox_flow_* (fp32 activations, bf16 weights as the GEMM B operand, one plane).  The two estimator calls per Euler
+ * step (conditional / unconditional) run as one doubled batch.  GroupNorm weights ride in the ln*_w / ln*_b fields of
+ * vox_flow_resnet_w.  mel rows of the regulator are kept mel_padded wide (a multiple of 32; pad columns zero).
+ * Start noise: per request [mel][frames] (the reference draws randn_like(mu)): given, or Philox stream first_stream + b. */
+typedef struct {
+    const float* embedding;              /* input_embedding [vocab][D] */
+    vox_conv_w spk, embed_lin;
+    const float *embed_ln_w, *embed_ln_b, *after_w, *after_b;
+    const vox_flow_conformer_w* enc;     /* [enc_layers] */
+    vox_conv_w enc_proj;                 /* N = mel_padded (rows >= mel zero) */
+    vox_conv_w reg_conv[4];              /* k3 "same" convs mel_padded -> mel_padded */
+    const float *reg_gn_w[4], *reg_gn_b[4];
+    vox_conv_w reg_out;                  /* k1, mel_padded -> mel */
+    vox_conv_w time1, time2;
+    const vox_flow_resnet_w* resnets;    /* [2 + mid + 2]: down 0, down 1, mid..., up 0, up 1; convs k3 "same" (taps t-1, t, t+1) */
+    const vox_flow_tblock_w* tblocks;    /* [(4 + mid) * n_blocks] */
+    vox_conv_w down_s2;                  /* Downsample1D conv (k3, stride 2, pad 1) as ONE tap over [x[2t-1] | x[2t] | x[2t+1]] (Cin = 3 C) */
+    vox_conv_w down_conv1;               /* k3 "same" */
+    vox_conv_w up_tconv;                 /* ConvTranspose1d(4, 2, 1): taps d = -1, 0, 1, N = 2 C, bias_mod = C */
+    vox_conv_w up_conv1, final_conv, final_proj;
+    const float *final_gn_w, *final_gn_b;
+} vox_glmflow_weights;
+typedef struct {
+    int32_t vocab, dim, mel, mel_padded, spk_dim, enc_layers, enc_heads, enc_ffn, block_size, est_ch, est_heads, est_head_dim, est_blocks,
+        est_mid, n_steps, reg_layers, groups;
+    float cfg_rate;
+} vox_glmflow_config;
+typedef struct vox_glmflow vox_glmflow;
+int vox_glmflow_create(vox_ctx* ctx, const vox_glmflow_config* cfg, const vox_glmflow_weights* w, int max_batch, int max_T, int max_mel,
+                       const float* time_emb, const float* dt, vox_glmflow** out);
+void vox_glmflow_destroy(vox_glmflow* m);
+/* tokens: device int32 [n][T]; Tm: mel frames per request ((T / 12.5 * 22050 / 256).int() in the reference); embedding: device fp32
+ * [n][spk_dim] or NULL (zeros, as GLMAudioDecoder passes); noise: device fp32 [n][mel][Tm] or NULL; mel: fp32 [n][mel][Tm] */
+int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int n, int T, int Tm, const float* embedding, const float* noise,
+                       uint64_t seed, uint32_t first_stream, float* mel);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1887,6 +1887,7 @@ struct FlowAttn {
     int T, H, dk, Tc, Tcap, B;          // B: requests per classifier-free-guidance half (cache half = n / B); B <= 0: one shared cache
     size_t cache_half_stride;
     float scale;
+    int mask_block;                     // > 0: key j is visible to query i iff j <= i or j / mask_block == i / mask_block (glm.py:452-470)
 };
 #define FLOW_MAXKEYS 1024
 __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
@@ -1932,6 +1933,7 @@ __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
             }
         }
         ac *= a.scale;
+        if (a.mask_block > 0 && j > i && j / a.mask_block != i / a.mask_block) ac = -INFINITY;
         ps[wave][j] = ac;
         mx = fmaxf(mx, ac);
     }
@@ -1996,7 +1998,7 @@ __global__ __launch_bounds__(256) void k_flow_tail2(const float* x, float* st, i
 }
 // estimator input [2B * T][4 mel] = x | mu | spk | cond, the second (unconditional) half with mu = spk = cond = 0   (cosyvoice_flow.py:2737-2745)
 __global__ __launch_bounds__(256) void k_flow_pack(const float* x, const float* mu, const float* spk, const float* cond, float* y, int B, int T,
-                                                    int M) {
+                                                    int M, int spk_stride = 0) {
     const size_t total = (size_t)2 * B * T * 4 * M;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % (4 * M));
@@ -2008,7 +2010,7 @@ __global__ __launch_bounds__(256) void k_flow_pack(const float* x, const float* 
         if (part == 0) v = x[((size_t)b * T + t) * M + cc];
         else if (un) v = 0.0f;
         else if (part == 1) v = mu[((size_t)b * T + t) * M + cc];
-        else if (part == 2) v = spk[cc];
+        else if (part == 2) v = spk[(size_t)b * spk_stride + cc];
         else v = cond ? cond[((size_t)b * T + t) * M + cc] : 0.0f;
         y[i] = v;
     }
@@ -2378,3 +2380,274 @@ extern "C" int vox_flow_fill_noise(void* stream, uint64_t seed, uint32_t noise_s
     hipLaunchKernelGGL(k_flow_noise_z, dim3(ew_grid((size_t)mel * frames)), dim3(256), 0, (hipStream_t)stream, seed, noise_stream, z, (size_t)mel * frames);
     return VOX_OK;
 }
+
+// ====================================================================================================================
+// GLM-4-Voice flow (speech tokens -> mel): block conformer encoder, length regulator, non-causal U-Net CFM.  include/voxhip.h has the contract.
+// ====================================================================================================================
+// GroupNorm over (channels of a group) x (all rows of a request) + Mish + optional per-channel addend; x [N][T][ld], C real channels
+// (columns >= C are written 0); one block per (group, request)
+__global__ __launch_bounds__(256) void k_flow_groupnorm(const float* x, const float* w, const float* b, float* y, int T, int C, int ld, int G,
+                                                         float eps, const float* add) {
+    __shared__ float red[8];
+    const int g = blockIdx.x, n = blockIdx.y, cg = C / G;
+    const float* xb = x + (size_t)n * T * ld;
+    float* yb = y + (size_t)n * T * ld;
+    const int cnt = T * cg;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < cnt; i += 256) s += xb[(size_t)(i / cg) * ld + g * cg + i % cg];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)cnt;
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < cnt; i += 256) { const float d = xb[(size_t)(i / cg) * ld + g * cg + i % cg] - mean; v += d * d; }
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)cnt + eps);
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int c = g * cg + i % cg;
+        const size_t o = (size_t)(i / cg) * ld + c;
+        float r = mish_f((xb[o] - mean) * rstd * w[c] + b[c]);
+        if (add) r += add[c];
+        yb[o] = r;
+    }
+    if (g == G - 1 && ld > C)
+        for (int i = threadIdx.x; i < T * (ld - C); i += 256) yb[(size_t)(i / (ld - C)) * ld + C + i % (ld - C)] = 0.0f;
+}
+// F.interpolate(mode="nearest") along time: y[b][t] = x[b][min(floor(t * T / To), T - 1)]
+__global__ __launch_bounds__(256) void k_flow_interp(const float* x, float* y, int B, int T, int To, int ld) {
+    const size_t total = (size_t)B * To * ld;
+    const float sc = (float)T / (float)To;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % ld), t = (int)((i / ld) % To), b = (int)(i / ((size_t)ld * To));
+        int src = (int)floorf((float)t * sc);
+        src = src > T - 1 ? T - 1 : src;
+        y[i] = x[((size_t)b * T + src) * ld + c];
+    }
+}
+// Conv1d(k 3, stride 2, padding 1) as a 1-tap GEMM: y[n][t] = x[n][2t - 1] | x[n][2t] | x[n][2t + 1]  (zeros outside)
+__global__ __launch_bounds__(256) void k_flow_stride2(const float* x, float* y, int N, int T, int To, int C) {
+    const size_t total = (size_t)N * To * 3 * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C), j = (int)((i / C) % 3), t = (int)((i / (3 * (size_t)C)) % To), n = (int)(i / (3 * (size_t)C * To));
+        const int ts = 2 * t - 1 + j;
+        y[i] = (ts >= 0 && ts < T) ? x[((size_t)n * T + ts) * C + c] : 0.0f;
+    }
+}
+// per-request start noise z [B][M][T] (given, or stream first + b) -> x [B][T][M]
+__global__ __launch_bounds__(256) void k_flow_noise_req(const float* z, uint64_t seed, uint32_t first, float* x, int B, int T, int M) {
+    const size_t total = (size_t)B * T * M;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % M), t = (int)((i / M) % T), b = (int)(i / ((size_t)M * T));
+        float v;
+        if (z) v = z[((size_t)b * M + c) * T + t];
+        else {
+            uint32_t w0, w1;
+            philox4((uint32_t)(c * T + t), first + (uint32_t)b, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), &w0, &w1);
+            const float u1 = ((float)(w0 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
+            v = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+        }
+        x[i] = v;
+    }
+}
+// rows of x [n][C] L2-normalised (F.normalize, eps 1e-12): one block per row; x NULL = zeros
+__global__ __launch_bounds__(256) void k_flow_l2norm_rows(const float* x, float* y, int C) {
+    __shared__ float red[4];
+    const float* xr = x ? x + (size_t)blockIdx.x * C : nullptr;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < C; i += 256) { const float v = xr ? xr[i] : 0.0f; s += v * v; }
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+    for (int i = threadIdx.x; i < C; i += 256) y[(size_t)blockIdx.x * C + i] = (xr ? xr[i] : 0.0f) / nrm;
+}
+
+struct vox_glmflow {
+    vox_ctx* ctx;
+    vox_glmflow_config cfg;
+    vox_glmflow_weights w;
+    std::vector<vox_flow_conformer_w> enc;
+    std::vector<vox_flow_resnet_w> resnets;
+    std::vector<vox_flow_tblock_w> tblocks;
+    int max_batch, max_T, max_mel, n_res, n_att;
+    std::vector<float> dt;
+    float* tb = nullptr;
+    float* buf[10] = {};
+    size_t buf_floats = 0;
+    float *spk = nullptr, *pe = nullptr, *pp = nullptr;
+};
+static const int FLOW_OFF_S3[3] = {1, 0, -1};           // "same" k3
+static const int FLOW_OFF_T3[3] = {-1, 0, 1};           // ConvTranspose1d(4, 2, 1): taps d = -1, 0, 1 (tap d reads row t - d)
+
+extern "C" {
+
+void vox_glmflow_destroy(vox_glmflow* m) {
+    if (!m) return;
+    for (int i = 0; i < 10; ++i) (void)hipFree(m->buf[i]);
+    (void)hipFree(m->tb); (void)hipFree(m->spk); (void)hipFree(m->pe); (void)hipFree(m->pp);
+    delete m;
+}
+
+int vox_glmflow_create(vox_ctx* ctx, const vox_glmflow_config* cfg, const vox_glmflow_weights* w, int max_batch, int max_T, int max_mel,
+                       const float* time_emb, const float* dt, vox_glmflow** out) {
+    if (!ctx || !cfg || !w || !out || !time_emb || !dt) return vox_fail(VOX_ERR_INVALID, "glmflow_create: NULL");
+    const vox_glmflow_config& c = *cfg;
+    if (c.dim % c.enc_heads || c.dim / c.enc_heads > 128 || c.est_head_dim > 128 || c.dim % 32 || c.est_ch % 32 || (4 * c.mel) % 32 ||
+        c.mel_padded % 32 || c.mel_padded < c.mel || (c.est_heads * c.est_head_dim) % 32 || c.enc_ffn % 32 || c.spk_dim % 32 ||
+        c.est_ch % c.groups || max_batch < 1 || max_T < 1 || max_mel < 2 || c.n_steps < 1 || c.reg_layers > 4 || max_mel > FLOW_MAXKEYS ||
+        max_T > FLOW_MAXKEYS)
+        return vox_fail(VOX_ERR_INVALID, "glmflow_create: bad config");
+    vox_glmflow* m = new vox_glmflow();
+    m->ctx = ctx; m->cfg = c; m->w = *w; m->max_batch = max_batch; m->max_T = max_T; m->max_mel = max_mel;
+    m->n_res = 4 + c.est_mid; m->n_att = m->n_res * c.est_blocks;
+    m->enc.assign(w->enc, w->enc + c.enc_layers);
+    m->resnets.assign(w->resnets, w->resnets + m->n_res);
+    m->tblocks.assign(w->tblocks, w->tblocks + m->n_att);
+    m->dt.assign(dt, dt + c.n_steps);
+    const int D = c.dim, C = c.est_ch, TE = 4 * C, inner = c.est_heads * c.est_head_dim;
+    size_t rows = (size_t)2 * max_batch * max_mel;
+    if ((size_t)max_batch * max_T > rows) rows = (size_t)max_batch * max_T;
+    size_t wmax = 3 * (size_t)D;
+    for (size_t v : {(size_t)c.enc_ffn, (size_t)4 * C, (size_t)3 * inner, (size_t)4 * c.mel, (size_t)TE, (size_t)3 * C}) wmax = v > wmax ? v : wmax;
+    m->buf_floats = rows * wmax;
+    bool ok = true;
+    auto alloc = [&](float** p, size_t n) { ok = ok && hipMalloc((void**)p, n * 4) == hipSuccess; };
+    for (int i = 0; i < 10; ++i) alloc(&m->buf[i], m->buf_floats);
+    alloc(&m->tb, (size_t)c.n_steps * m->n_res * C);
+    alloc(&m->spk, (size_t)max_batch * c.mel);
+    alloc(&m->pe, (size_t)2 * FLOW_MAXKEYS * D);
+    alloc(&m->pp, (size_t)2 * FLOW_MAXKEYS * D);
+    if (!ok) { vox_glmflow_destroy(m); return vox_fail(VOX_ERR_NOMEM, "glmflow_create: hipMalloc failed"); }
+    hipStream_t st = nullptr;
+    g_conv_planes = 3;
+    g_conv_skinny_rows = 48;
+    int rc = VOX_OK;
+    (void)hipMemcpy(m->buf[0], time_emb, (size_t)c.n_steps * 4 * c.mel * 4, hipMemcpyHostToDevice);
+    rc = conv_gemm(st, w->time1, m->buf[0], nullptr, nullptr, 1, c.n_steps, 0, FLOW_OFF0, m->buf[1], nullptr, nullptr, 0);
+    hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)c.n_steps * TE)), dim3(256), 0, st, m->buf[1], (size_t)c.n_steps * TE, 2);
+    if (rc == VOX_OK) rc = conv_gemm(st, w->time2, m->buf[1], nullptr, nullptr, 1, c.n_steps, 0, FLOW_OFF0, m->buf[2], nullptr, nullptr, 0);
+    hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)c.n_steps * TE)), dim3(256), 0, st, m->buf[2], (size_t)c.n_steps * TE, 1);
+    for (int r = 0; r < m->n_res && rc == VOX_OK; ++r) {
+        rc = conv_gemm(st, m->resnets[r].mlp, m->buf[2], nullptr, nullptr, 1, c.n_steps, 0, FLOW_OFF0, m->buf[3], nullptr, nullptr, 0);
+        (void)hipMemcpy2DAsync(m->tb + (size_t)r * C, (size_t)m->n_res * C * 4, m->buf[3], (size_t)C * 4, (size_t)C * 4, c.n_steps,
+                               hipMemcpyDeviceToDevice, st);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess || rc != VOX_OK) { vox_glmflow_destroy(m); return rc != VOX_OK ? rc : vox_fail(VOX_ERR_HIP, "glmflow_create: time MLP failed"); }
+    *out = m;
+    return VOX_OK;
+}
+
+int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int n, int T, int Tm, const float* embedding, const float* noise,
+                       uint64_t seed, uint32_t first_stream, float* mel) {
+    if (!m || !tokens || !mel) return vox_fail(VOX_ERR_INVALID, "glmflow_decode: NULL");
+    if (n < 1 || n > m->max_batch || T < 1 || T > m->max_T || Tm < 2 || Tm > m->max_mel)
+        return vox_fail(VOX_ERR_INVALID, "glmflow_decode: n %d / T %d / mel frames %d out of range", n, T, Tm);
+    hipStream_t st = (hipStream_t)stream;
+    const vox_glmflow_config& c = m->cfg;
+    const vox_glmflow_weights& w = m->w;
+    const int D = c.dim, M = c.mel, MP = c.mel_padded, C = c.est_ch, H = c.enc_heads, dk = D / H, HE = c.est_heads, hd = c.est_head_dim;
+    float** Bf = m->buf;
+    g_conv_planes = 3;
+    g_conv_skinny_rows = FLOW_SKINNY_ROWS;
+    // speaker vector per request: spk_embed_affine_layer(normalize(embedding)); GLM-4-Voice passes zeros (glm.py:2647)
+    hipLaunchKernelGGL(k_flow_l2norm_rows, dim3(n), dim3(256), 0, st, embedding, Bf[0], c.spk_dim);
+    VOX_TRY(conv_gemm(st, w.spk, Bf[0], nullptr, nullptr, n, 1, 0, FLOW_OFF0, m->spk, nullptr, nullptr, 0));
+    // ---- encoder: embed, LinearNoSubsampling, block-masked relative-position conformer layers, after_norm, encoder_proj ----
+    float* x = Bf[3];
+    hipLaunchKernelGGL(k_flow_embed, dim3(ew_grid((size_t)n * T * D)), dim3(256), 0, st, tokens, w.embedding, Bf[0], (size_t)n * T, D);
+    VOX_TRY(conv_gemm(st, w.embed_lin, Bf[0], nullptr, nullptr, n, T, 0, FLOW_OFF0, Bf[1], nullptr, nullptr, 0));
+    hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1);
+    hipLaunchKernelGGL(k_flow_relpos, dim3(ew_grid((size_t)(2 * T - 1) * D)), dim3(256), 0, st, m->pe, T, D);
+    for (int l = 0; l < c.enc_layers; ++l) {
+        const vox_flow_conformer_w& cw = m->enc[l];
+        float *nrm = Bf[0], *qkv = Bf[1], *att = Bf[2];
+        hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, cw.ln_mha_w, cw.ln_mha_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1);
+        VOX_TRY(conv_gemm(st, cw.qkv, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
+        VOX_TRY(conv_gemm(st, cw.pos, m->pe, nullptr, nullptr, 1, 2 * T - 1, 0, FLOW_OFF0, m->pp, nullptr, nullptr, 0));
+        FlowAttn a{qkv, nullptr, m->pp, cw.bias_u, cw.bias_v, att, T, H, dk, 0, 0, 0, 0, 1.0f / sqrtf((float)dk), c.block_size};
+        hipLaunchKernelGGL(k_flow_attn, dim3((T + 3) / 4, H, n), dim3(256), 0, st, a);
+        VOX_TRY(conv_gemm(st, cw.out, att, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
+        hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, cw.ln_ff_w, cw.ln_ff_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1);
+        VOX_TRY(conv_gemm(st, cw.w1, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
+        hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)n * T * c.enc_ffn)), dim3(256), 0, st, qkv, (size_t)n * T * c.enc_ffn, 2);
+        VOX_TRY(conv_gemm(st, cw.w2, qkv, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
+    }
+    hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1);
+    VOX_TRY(conv_gemm(st, w.enc_proj, Bf[0], nullptr, nullptr, n, T, 0, FLOW_OFF0, Bf[1], nullptr, nullptr, 0));       // [n*T][MP] (pad columns 0)
+    // ---- length regulator: nearest resampling to Tm frames, (conv k3, GroupNorm(1), Mish) x reg_layers, conv k1 ----
+    hipLaunchKernelGGL(k_flow_interp, dim3(ew_grid((size_t)n * Tm * MP)), dim3(256), 0, st, Bf[1], Bf[0], n, T, Tm, MP);
+    for (int i = 0; i < c.reg_layers; ++i) {
+        VOX_TRY(conv_gemm(st, w.reg_conv[i], Bf[0], nullptr, nullptr, n, Tm, 0, FLOW_OFF_S3, Bf[1], nullptr, nullptr, 0));
+        hipLaunchKernelGGL(k_flow_groupnorm, dim3(1, n), dim3(256), 0, st, Bf[1], w.reg_gn_w[i], w.reg_gn_b[i], Bf[0], Tm, M, MP, 1, 1e-5f, nullptr);
+    }
+    float* mu = Bf[8];
+    VOX_TRY(conv_gemm(st, w.reg_out, Bf[0], nullptr, nullptr, n, Tm, 0, FLOW_OFF0, mu, nullptr, nullptr, 0));           // [n*Tm][M]
+    // ---- CFM: n_steps Euler steps of the U-Net on the doubled (classifier-free guidance) batch ----
+    float* xs = Bf[9];
+    hipLaunchKernelGGL(k_flow_noise_req, dim3(ew_grid((size_t)n * Tm * M)), dim3(256), 0, st, noise, seed, first_stream, xs, n, Tm, M);
+    const int N = 2 * n, Th = (Tm - 1) / 2 + 1;
+    auto tblocks = [&](float* h, int rows_T, int& li, float* a1, float* a2, float* a3) -> int {
+        for (int j = 0; j < c.est_blocks; ++j, ++li) {
+            const vox_flow_tblock_w& tw = m->tblocks[li];
+            hipLaunchKernelGGL(k_flow_ln, dim3(N * rows_T), dim3(256), 0, st, h, tw.ln1_w, tw.ln1_b, a1, C, 1e-5f, 1.0f, 0, nullptr, 1);
+            VOX_TRY(conv_gemm(st, tw.qkv, a1, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, a2, nullptr, nullptr, 0));
+            FlowAttn a{a2, nullptr, nullptr, nullptr, nullptr, a3, rows_T, HE, hd, 0, 0, 0, 0, 1.0f / sqrtf((float)hd), 0};
+            hipLaunchKernelGGL(k_flow_attn, dim3((rows_T + 3) / 4, HE, N), dim3(256), 0, st, a);
+            VOX_TRY(conv_gemm(st, tw.out, a3, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, h, h, nullptr, 0));
+            hipLaunchKernelGGL(k_flow_ln, dim3(N * rows_T), dim3(256), 0, st, h, tw.ln3_w, tw.ln3_b, a1, C, 1e-5f, 1.0f, 0, nullptr, 1);
+            VOX_TRY(conv_gemm(st, tw.ff1, a1, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, a2, nullptr, nullptr, 1));
+            VOX_TRY(conv_gemm(st, tw.ff2, a2, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, h, h, nullptr, 0));
+        }
+        return VOX_OK;
+    };
+    for (int s = 0; s < c.n_steps; ++s) {
+        float *hA = Bf[0], *a1 = Bf[1], *a2 = Bf[2], *a3 = Bf[3], *skip0 = Bf[4], *cat = Bf[5], *hB = Bf[6], *skip1 = Bf[7];
+        hipLaunchKernelGGL(k_flow_pack, dim3(ew_grid((size_t)N * Tm * 4 * M)), dim3(256), 0, st, xs, mu, m->spk, nullptr, cat, n, Tm, M, M);
+        int li = 0, r = 0;
+        // ResnetBlock1D (conv k3, GroupNorm(groups), Mish; + time projection; again; + res_conv) then the transformer blocks, in -> out
+        auto group = [&](const float* in, float* o, int rows_T) -> int {
+            const vox_flow_resnet_w& rw = m->resnets[r];
+            VOX_TRY(conv_gemm(st, rw.conv1, in, nullptr, nullptr, N, rows_T, 0, FLOW_OFF_S3, a1, nullptr, nullptr, 0));
+            hipLaunchKernelGGL(k_flow_groupnorm, dim3(c.groups, N), dim3(256), 0, st, a1, rw.ln1_w, rw.ln1_b, a2, rows_T, C, C, c.groups, 1e-5f,
+                               m->tb + ((size_t)s * m->n_res + r) * C);
+            VOX_TRY(conv_gemm(st, rw.conv2, a2, nullptr, nullptr, N, rows_T, 0, FLOW_OFF_S3, a1, nullptr, nullptr, 0));
+            hipLaunchKernelGGL(k_flow_groupnorm, dim3(c.groups, N), dim3(256), 0, st, a1, rw.ln2_w, rw.ln2_b, a2, rows_T, C, C, c.groups, 1e-5f, nullptr);
+            VOX_TRY(conv_gemm(st, rw.res, in, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, o, a2, nullptr, 0));
+            ++r;
+            return tblocks(o, rows_T, li, a1, a2, a3);
+        };
+        VOX_TRY(group(cat, skip0, Tm));                                                       // down 0 (its output is the outer skip)
+        hipLaunchKernelGGL(k_flow_stride2, dim3(ew_grid((size_t)N * Th * 3 * C)), dim3(256), 0, st, skip0, cat, N, Tm, Th, C);
+        VOX_TRY(conv_gemm(st, w.down_s2, cat, nullptr, nullptr, N, Th, 0, FLOW_OFF0, hA, nullptr, nullptr, 0));
+        VOX_TRY(group(hA, skip1, Th));                                                        // down 1
+        VOX_TRY(conv_gemm(st, w.down_conv1, skip1, nullptr, nullptr, N, Th, 0, FLOW_OFF_S3, hA, nullptr, nullptr, 0));
+        float *cur = hA, *nxt = hB;
+        for (int i = 0; i < c.est_mid; ++i) {
+            VOX_TRY(group(cur, nxt, Th));
+            float* t = cur; cur = nxt; nxt = t;
+        }
+        hipLaunchKernelGGL(k_flow_concat2, dim3(ew_grid((size_t)N * Th * 2 * C)), dim3(256), 0, st, cur, skip1, cat, (size_t)N * Th, C);
+        VOX_TRY(group(cat, nxt, Th));                                                         // up 0
+        VOX_TRY(conv_gemm(st, w.up_tconv, nxt, nullptr, nullptr, N, Th, 0, FLOW_OFF_T3, cur, nullptr, nullptr, 0));      // [N][2 Th][C]
+        // x[:, :, :skip.shape[-1]]: the transposed conv gives 2 Th rows per request, the skip has Tm (<= 2 Th)
+        if (2 * Th != Tm) {
+            for (int q = 0; q < N; ++q)
+                (void)hipMemcpyAsync(nxt + (size_t)q * Tm * C, cur + (size_t)q * 2 * Th * C, (size_t)Tm * C * 4, hipMemcpyDeviceToDevice, st);
+            float* t = cur; cur = nxt; nxt = t;
+        }
+        hipLaunchKernelGGL(k_flow_concat2, dim3(ew_grid((size_t)N * Tm * 2 * C)), dim3(256), 0, st, cur, skip0, cat, (size_t)N * Tm, C);
+        VOX_TRY(group(cat, nxt, Tm));                                                         // up 1
+        VOX_TRY(conv_gemm(st, w.up_conv1, nxt, nullptr, nullptr, N, Tm, 0, FLOW_OFF_S3, a1, nullptr, nullptr, 0));
+        VOX_TRY(conv_gemm(st, w.final_conv, a1, nullptr, nullptr, N, Tm, 0, FLOW_OFF_S3, a2, nullptr, nullptr, 0));
+        hipLaunchKernelGGL(k_flow_groupnorm, dim3(c.groups, N), dim3(256), 0, st, a2, w.final_gn_w, w.final_gn_b, a1, Tm, C, C, c.groups, 1e-5f, nullptr);
+        VOX_TRY(conv_gemm(st, w.final_proj, a1, nullptr, nullptr, N, Tm, 0, FLOW_OFF0, a2, nullptr, nullptr, 0));
+        hipLaunchKernelGGL(k_flow_euler, dim3(ew_grid((size_t)n * Tm * M)), dim3(256), 0, st, xs, a2, n, Tm, M, m->dt[s], c.cfg_rate);
+    }
+    g_conv_skinny_rows = 48;
+    hipLaunchKernelGGL(k_flow_to_bct, dim3(ew_grid((size_t)n * Tm * M)), dim3(256), 0, st, xs, mel, n, Tm, M);
+    return VOX_OK;
+}
+
+}  // extern "C"
