@@ -89,6 +89,9 @@ def _single_stack(model_name, cls_path, cfg_path, synth_name, device, weights, c
 
 @register_model("glm", "zai-org/glm-4-voice-9b")
 def _glm(model_name, device="cuda:0", weights=None, checkpoint_dir=None, synthetic=False, **kw):
+    if synthetic and kw.get("codec_weights") is None:
+        from .. import synth
+        kw["codec_weights"] = synth.synth_glm_codec_weights()        # random-init detokenizer (flow + HiFT), like the LM weights
     return _single_stack(model_name, (".glm_voice", "GLMVoiceModel"), "GLMVoiceConfig", "synth_glm_weights", device,
                          weights, checkpoint_dir, synthetic, kw)
 

@@ -61,7 +61,8 @@ def pack_glm_weights(S: Dict[str, torch.Tensor], c: GLMVoiceConfig):
 class GLMVoiceModel(SingleStackLM):
     def __init__(self, model_name: str, weights: Dict[str, torch.Tensor], config: Optional[GLMVoiceConfig] = None,
                  text_tokenizer=None, device="cuda:0", dtype=torch.bfloat16, audio_decoder_device=None,
-                 sampling: Optional[SamplingConfig] = None, max_pos=8192, sampling_overrides=None, **engine_kw):
+                 sampling: Optional[SamplingConfig] = None, max_pos=8192, sampling_overrides=None, codec_weights: Optional[dict] = None,
+                 codec_config: Optional[dict] = None, codec_seed: int = 0, **engine_kw):
         self.glm_config = config or GLMVoiceConfig()
         layers, norm, emb, head = pack_glm_weights(weights, self.glm_config)
         sampling = sampling or SamplingConfig(top_k=None, top_p=0.8, min_p=None, temperature=0.8, repetition_penalty=None,
@@ -74,6 +75,21 @@ class GLMVoiceModel(SingleStackLM):
         self.stop_token_ids = list(self.glm_config.eos_token_id)
         self.audio_offset = (text_tokenizer.convert_tokens_to_ids("<|audio_0|>") if text_tokenizer is not None
                              else self.glm_config.audio_offset)
+        # detokenizer (glm_voice.py:355-369: GLMAudioDecoder = flow + HiFT, stateless per 25-token window)
+        self.audio_decoder = None
+        if codec_weights is not None:
+            from ..tokenizer.glm import GLMAudioDecoder
+            cc = codec_config or {}
+            self.audio_decoder = GLMAudioDecoder(codec_weights["flow"], codec_weights["hift"], device=self.audio_decoder_device or device,
+                                                 flow_config=cc.get("flow"), hift_config=cc.get("hift"),
+                                                 max_batch=engine_kw.get("max_batch_size", 8), max_tokens=self.detokenize_interval, seed=codec_seed)
+
+    def postprocess(self, token_ids: torch.Tensor, **kwargs) -> torch.Tensor:
+        """token_ids [B, 25, 1] (LM ids of audio tokens) -> audio [B, 1, 44032]   (glm_voice.py:594-596)"""
+        if self.audio_decoder is None:
+            raise NotImplementedError("GLMVoiceModel: no detokenizer weights were given (codec_weights={'flow': ..., 'hift': ...})")
+        audio = self.audio_decoder(token_ids[:, :, 0] - self.audio_offset, None)
+        return audio[:, None, :]
 
     supports_audio_input = property(lambda self: True)
     detokenize_interval = property(lambda self: 25)

@@ -392,3 +392,93 @@ def synth_cosyvoice2_codec_weights(flow_cfg=None, hift_cfg=None, seed=0):
               "prompt_feat": (0.7 * torch.randn(1, 2 * Np, fc.mel, generator=g)).to(torch.bfloat16).float(),
               "embedding": torch.randn(1, fc.spk_embed_dim, generator=g).to(torch.bfloat16).float()}
     return {"flow": F, "hift": H}, prompt
+
+
+def synth_glm_codec_weights(flow_cfg=None, hift_cfg=None, seed=0):
+    """Random-init GLM-4-Voice detokenizer weights (flow / hift checkpoint names; CPU fp32 tensors holding bf16-representable values)."""
+    import math
+    from .tokenizer.glm import GLMFlowConfig, glm_hift_config
+    fc, hc = flow_cfg or GLMFlowConfig(), hift_cfg or glm_hift_config()
+    g = torch.Generator().manual_seed(seed)
+    F = {}
+
+    def w(name, shape, gain=1.0):
+        fan = 1
+        for v in shape[1:]:
+            fan *= v
+        F[name] = (gain * torch.randn(shape, generator=g) / math.sqrt(max(fan, 1))).to(torch.bfloat16).float()
+
+    def vec(name, n, mean=0.0, std=0.05):
+        F[name] = (mean + std * torch.randn(n, generator=g)).to(torch.bfloat16).float()
+
+    def lin(n, o, i, bias=True, gain=1.0):
+        w(n + ".weight", (o, i), gain)
+        if bias:
+            vec(n + ".bias", o)
+
+    def nrm(n, c):
+        vec(n + ".weight", c, 1.0, 0.1)
+        vec(n + ".bias", c)
+
+    def conv(n, o, i, k, gain=1.0):
+        w(n + ".weight", (o, i, k), gain)
+        vec(n + ".bias", o)
+
+    D, C = fc.dim, fc.est_channels
+    F["input_embedding.weight"] = torch.randn(fc.vocab_size, D, generator=g).to(torch.bfloat16).float()
+    lin("spk_embed_affine_layer", fc.mel, fc.spk_embed_dim)
+    lin("encoder_proj", fc.mel, D)
+    lin("encoder.embed.out.0", D, D)
+    nrm("encoder.embed.out.1", D)
+    nrm("encoder.after_norm", D)
+    for i in range(fc.enc_layers):
+        p = f"encoder.encoders.{i}."
+        for q in ("linear_q", "linear_k", "linear_v"):
+            lin(p + "self_attn." + q, D, D)
+        lin(p + "self_attn.linear_out", D, D, gain=0.5)
+        lin(p + "self_attn.linear_pos", D, D, bias=False)
+        for b in ("pos_bias_u", "pos_bias_v"):
+            F[p + "self_attn." + b] = (0.3 * torch.randn(fc.enc_heads, D // fc.enc_heads, generator=g)).to(torch.bfloat16).float()
+        lin(p + "feed_forward.w_1", fc.enc_ffn, D)
+        lin(p + "feed_forward.w_2", D, fc.enc_ffn, gain=0.5)
+        nrm(p + "norm_ff", D)
+        nrm(p + "norm_mha", D)
+    for i in range(fc.reg_layers):
+        conv(f"length_regulator.model.{3 * i}", fc.mel, fc.mel, 3)
+        nrm(f"length_regulator.model.{3 * i + 1}", fc.mel)
+    conv(f"length_regulator.model.{3 * fc.reg_layers}", fc.mel, fc.mel, 1)
+    es, TE, inner = "decoder.estimator.", 4 * C, fc.est_heads * fc.est_head_dim
+    lin(es + "time_mlp.linear_1", TE, 4 * fc.mel)
+    lin(es + "time_mlp.linear_2", TE, TE)
+    groups = [(es + "down_blocks.0.", 4 * fc.mel), (es + "down_blocks.1.", C)] + [(f"{es}mid_blocks.{i}.", C) for i in range(fc.est_mid_blocks)] + \
+             [(es + "up_blocks.0.", 2 * C), (es + "up_blocks.1.", 2 * C)]
+    for gp, cin in groups:
+        p = gp + "0."
+        lin(p + "mlp.1", C, TE)
+        conv(p + "block1.block.0", C, cin, 3)
+        nrm(p + "block1.block.1", C)
+        conv(p + "block2.block.0", C, C, 3)
+        nrm(p + "block2.block.1", C)
+        conv(p + "res_conv", C, cin, 1)
+        for j in range(fc.est_blocks):
+            p = f"{gp}1.{j}."
+            nrm(p + "norm1", C)
+            for q in ("to_q", "to_k", "to_v"):
+                lin(p + "attn1." + q, inner, C, bias=False)
+            lin(p + "attn1.to_out.0", C, inner, gain=0.5)
+            nrm(p + "norm3", C)
+            lin(p + "ff.net.0.proj", 4 * C, C)
+            lin(p + "ff.net.2", C, 4 * C, gain=0.5)
+    conv(es + "down_blocks.0.2.conv", C, C, 3)
+    conv(es + "down_blocks.1.2", C, C, 3)
+    conv(es + "up_blocks.0.2.conv", C, C, 4)                    # ConvTranspose1d weight [Cin, Cout, 4]
+    conv(es + "up_blocks.1.2", C, C, 3)
+    conv(es + "final_block.block.0", C, C, 3)
+    nrm(es + "final_block.block.1", C)
+    conv(es + "final_proj", fc.mel, C, 1)
+    # the vocoder: the CosyVoice2 recipe with GLM's stage layout, weight_g / weight_v names
+    from .tokenizer.hifigan import HiFTConfig
+    cw, _ = synth_cosyvoice2_codec_weights(hift_cfg=hc, seed=seed + 1)
+    H = {k.replace(".parametrizations.weight.original0", ".weight_g").replace(".parametrizations.weight.original1", ".weight_v"): v
+         for k, v in cw["hift"].items()}
+    return {"flow": F, "hift": H}
