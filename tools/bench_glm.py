@@ -1,7 +1,9 @@
 """BASELINE config 4, one GPU's share: GLM-4-Voice-9B (random-init weights of the named architecture), B = 8 of the 64
 data-parallel requests, the model's default top-p 0.8 / T 0.8 sampling over the 168 960-entry vocabulary.  One step = one
 LM token for the batch (GLM emits 12.5 audio tokens/s; 25 tokens -> 44 032 samples at 22.05 kHz through the flow + HiFT
-detokenizer, which is not built: LM tokens/s is what this measures).  Development measurement; prints one JSON line."""
+detokenizer).  GLM interleaves 13 text tokens with 26 audio tokens: 2/3 of the LM steps yield audio tokens, so one 25-token window (one
+hipGraph: block conformer encoder, length regulator, 10-step CFM, HiFT) is decoded every 37.5 steps.  Development measurement; prints one
+JSON line with the LM roofline block and the end-to-end audio rate."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -31,7 +33,12 @@ for b in range(B):                       # 64-token prompt per request
     eng.kv[:, pages[b][0], :, :n0].normal_(0, 0.5)
 eng.input_ids[:B, 0] = torch.from_numpy(rng.integers(152353, 168000, B).astype(np.int32)).to(dev)
 kv, pos = [n0] * B, [n0 + 1] * B
-ev = []
+from vox_serve_amd.synth import synth_glm_codec_weights
+from vox_serve_amd.tokenizer.glm import GLMAudioDecoder
+cw = synth_glm_codec_weights()
+dec = GLMAudioDecoder(cw["flow"], cw["hift"], device=dev, max_batch=B)
+ev, chunk_ms, samples, audio_tok = [], [], [0], [0.0]
+win = torch.randint(0, 16384, (B, 25))
 
 def step(timed):
     global kv, pos
@@ -48,8 +55,15 @@ def step(timed):
         e1.record(eng.stream); ev.append((e0, e1))
     ids = eng.out_ids[:B].cpu()
     pos = [p + 1 for p in pos]
+    audio_tok[0] += 26.0 / 39.0                      # audio tokens per LM step in the interleaved stream
+    if audio_tok[0] >= 25.0:
+        audio_tok[0] -= 25.0
+        t0_ = time.perf_counter()
+        pcm = (dec(win) * 32767).to(torch.int16).cpu()
+        if timed:
+            chunk_ms.append((time.perf_counter() - t0_) * 1e3); samples[0] += pcm.numel()
 
-for i in range(args.warmup):
+for i in range(max(args.warmup, 80)):
     step(False)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -62,6 +76,7 @@ wbytes = sum(t.numel() * 2 for l in layers for t in l.values()) + head.numel() *
 print(json.dumps({"workload": f"GLM-4-Voice-9B bf16 LM, batch={B}/GPU, {'greedy' if args.greedy else 'top-p 0.8 T 0.8 over 168960 ids'}, 64-token context",
                   "lm_tokens_per_s": B * args.steps / dt, "audio_seconds_per_s": B * args.steps / dt / 12.5, "ms_per_step": dt / args.steps * 1e3,
                   "lm_graph_ms": frame_ms, "weight_bytes_streamed": wbytes, "exact_rows": args.exact_rows,
+                  "audio_samples_per_s": samples[0] / dt, "detokenizer_window_ms": float(np.mean(chunk_ms)) if chunk_ms else None,
                   "roofline": {"bound": "hbm", "achieved": wbytes / (frame_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                "frac": wbytes / (frame_ms * 1e-3) / 8e12, "traffic": None, "algorithmic_bytes_per_launch": wbytes,
                                "launch": "one hipGraph replay = one token step (40 layers + head + sampler)"}}))

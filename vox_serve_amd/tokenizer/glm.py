@@ -202,16 +202,71 @@ class GLMAudioDecoder:
         self.flow = GLMFlow(flow_weights, flow_config, device=device, max_batch=max_batch, max_T=max_tokens, seed=seed)
         self.hift = HiFTGenerator(hift_weights, hift_config or glm_hift_config(), device=device, max_batch=max_batch,
                                   max_T=self.flow.cfg.mel_len(max_tokens) + 2, seed=seed)
+        self.seed, self.use_graph, self._graphs, self._call = seed, True, {}, 0
+        self._stream = torch.cuda.Stream(device=self.device)
+        L = self.flow.L
+        L.vox_flow_fill_noise.restype = ctypes.c_int
+        L.vox_flow_fill_noise.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 
     @torch.inference_mode()
     def forward(self, audio_ids: torch.Tensor, token_len=None, flow_noise=None, hift_noise=None, hift_rand_ini=None, first_stream=None,
                 hift_stream_base=None) -> torch.Tensor:
         """audio_ids [B, T] -> speech fp32 [B, Tm * 256]   (glm.py:2640-2651)"""
+        if (self.use_graph and flow_noise is None and hift_noise is None and hift_rand_ini is None and first_stream is None
+                and hift_stream_base is None and audio_ids.shape[0] <= self.flow.max_batch):
+            return self._forward_graph(audio_ids)
         mel = self.flow.inference(audio_ids, token_len, None, noise=flow_noise, first_stream=first_stream)
         speech, _ = self.hift.forward_chunk(mel, noise=hift_noise, rand_ini=hift_rand_ini, stream_base=hift_stream_base)
         return speech
 
     __call__ = forward
+
+    def _forward_graph(self, audio_ids: torch.Tensor) -> torch.Tensor:
+        """The ~8 000 launches of a window as one hipGraph per (requests, tokens): inputs in graph-stable buffers, the per-request CFM start
+        noise drawn into one before the replay (a graph would freeze the stream ids), the vocoder's streams read from a device array.  The
+        first window of a shape runs eagerly, the second is captured."""
+        B, T = audio_ids.shape
+        c, L = self.flow.cfg, self.flow.L
+        Tm = c.mel_len(T)
+        ent = self._graphs.get((B, T))
+        if ent is None:
+            ent = self._graphs[(B, T)] = {"tok": torch.empty(B, T, dtype=torch.int32, device=self.device),
+                                          "z": torch.empty(B, c.mel, Tm, dtype=torch.float32, device=self.device),
+                                          "sb": torch.empty(B, dtype=torch.int32, device=self.device),
+                                          "mel": torch.empty(B, c.mel, Tm, dtype=torch.float32, device=self.device),
+                                          "wav": torch.empty(B, Tm * self.hift.upsample_scale, dtype=torch.float32, device=self.device),
+                                          "g": None, "calls": 0}
+        self._call += 1
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            st = N.stream()
+            ent["tok"].copy_(audio_ids.to(self.device, torch.int32), non_blocking=True)
+            ent["sb"].copy_(((torch.arange(B, dtype=torch.int64) + self._call * 65536) * 2).to(torch.int32), non_blocking=True)
+            for b in range(B):
+                N.check(L.vox_flow_fill_noise(st, ctypes.c_uint64(self.seed), self._call * 65536 + b, c.mel, Tm, ent["z"][b].data_ptr()))
+
+            def body():
+                N.check(L.vox_glmflow_decode(self.flow.h, st, ent["tok"].data_ptr(), B, T, Tm, None, ent["z"].data_ptr(), ctypes.c_uint64(self.seed), 0,
+                                             ent["mel"].data_ptr()))
+                N.check(self.hift.L.vox_hift_decode(self.hift.h, st, ent["mel"].data_ptr(), B, Tm, None, ctypes.c_uint64(self.seed ^ 0x5A5A),
+                                                    ent["sb"].data_ptr(), ent["wav"].data_ptr(), None, None))
+            ent["calls"] += 1
+            if ent["calls"] == 1:
+                body()
+            else:
+                if ent["g"] is None:
+                    N.check(L.vox_graph_begin(N.ctx(), st))
+                    try:
+                        body()
+                    finally:
+                        gh = ctypes.c_void_p()
+                        N.check(L.vox_graph_end(N.ctx(), st, ctypes.byref(gh)))
+                    ent["g"] = gh
+                N.check(L.vox_graph_launch(ent["g"], st))
+            out = ent["wav"].clone()
+        cur.wait_stream(self._stream)
+        return out
 
     def close(self):
         self.flow.close()
