@@ -399,6 +399,24 @@ def serving_throughput(dev, shared, n_req, frames, kind="base"):
             "scheduler": kind, "ms_per_frame_step_equiv": dt / frames * 1e3}
 
 
+def other_configs():
+    """The other BASELINE.json configs, one GPU each, as sub-results of the same driver-timed command: every tool prints one JSON line
+    (LM step + detokenizer in its loop, synthetic weights of the named architecture) and runs in its own process."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for name, cmd in (("cosyvoice2_0.5b_flow_hift_b8", ["tools/bench_cosyvoice2.py", "--batch", "8", "--steps", "75"]),
+                      ("csm_1b_mimi_b16", ["tools/bench_csm.py", "--batch", "16", "--steps", "60"]),
+                      ("glm_4_voice_9b_flow_hift_b8_per_gpu", ["tools/bench_glm.py", "--batch", "8", "--greedy", "--steps", "80"])):
+        try:
+            p = subprocess.run([sys.executable, os.path.join(here, cmd[0])] + cmd[1:], capture_output=True, text=True, timeout=300, cwd=here)
+            line = [ln for ln in p.stdout.strip().split("\n") if ln.startswith("{")]
+            res[name] = json.loads(line[-1]) if line else {"error": (p.stderr or "no output")[-200:]}
+        except Exception as ex:          # a sub-result must never hide the headline
+            res[name] = {"error": repr(ex)[:200]}
+    return res
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher: start N ranks of this script under torch.distributed.run."""
     import socket
@@ -424,6 +442,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttfa-requests", type=int, default=5, help="engine-level TTFA samples per setting (lock-step loop)")
     ap.add_argument("--serving-ttfa-requests", type=int, default=100, help="TTFA samples through Scheduler + ModelWorker (0 = skip)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs 1, 3, 4 sub-results (CosyVoice2, CSM-1B, GLM-4-Voice)")
     ap.add_argument("--exact-rows", type=int, default=None, help="rows up to which linears use the wave64 VALU kernels instead of the "
                     "matrix cores (library default 2; 1..8).  Every setting is bit-exact against the oracle under the same policy")
     args = ap.parse_args()
@@ -528,6 +547,9 @@ def main():
             out[f"batch{b}"] = {k: r[k] for k in ("value", "ms_per_step", "batch_per_gpu", "realtime_factor_per_request", "kv_mean", "roofline")}
         if bcast:
             out["weight_broadcast_rccl"] = bcast
+        if world == 1 and args.batch is None and not args.no_other_configs:
+            out["other_configs"] = other_configs()
+            _phase("other configs")
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N=1 only (other ranks would idle in RCCL)
             try:
                 out["cpu_baseline"] = cpu_baseline(shared["W"])

@@ -24,7 +24,7 @@ def _run(*extra):
 
 
 def test_bench_line_has_the_contract_keys():
-    d = _run("--ttfa-requests", "1", "--serving-ttfa-requests", "3", "--no-cpu-baseline")
+    d = _run("--ttfa-requests", "1", "--serving-ttfa-requests", "3", "--no-cpu-baseline", "--no-other-configs")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"):
         assert k in d, k

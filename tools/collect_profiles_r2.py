@@ -19,8 +19,9 @@ json.dump(traffic, open(os.path.join(D, "round2_pmc_traffic.json"), "w"), indent
 shutil.copy(os.path.join(S, "mfma_b32.json"), os.path.join(D, "round2_mfma_util_b32.json"))
 shutil.copy(os.path.join(S, "bench_default.json"), os.path.join(D, "round2_bench_default.json"))
 shutil.copy(os.path.join(S, "bench_default.err"), os.path.join(D, "round2_bench_default_phases.txt"))
-for name in ("csm_b1", "csm_b16", "glm_b1", "glm_b8"):
+for name in ("csm_b1", "csm_b16", "glm_b1", "glm_b8", "cosyvoice2_b1", "cosyvoice2_b8"):
     shutil.copy(os.path.join(S, name + ".json"), os.path.join(D, f"round2_{name}.json"))
 shutil.copy(os.path.join(S, "kernel_stats_csm_b16.csv"), os.path.join(D, "round2_csm_b16_kernel_stats.csv"))
 shutil.copy(os.path.join(S, "kernel_stats_glm_b8.csv"), os.path.join(D, "round2_glm_b8_kernel_stats.csv"))
+shutil.copy(os.path.join(S, "kernel_stats_cosyvoice2_b1.csv"), os.path.join(D, "round2_cosyvoice2_b1_kernel_stats.csv"))
 print({k: round(v["fetch_corrected_bytes_per_launch"] / 1e9, 3) for k, v in traffic.items()})

@@ -2,7 +2,7 @@
 # Counters are collected in their own rocprofv3 passes (--pmc with --kernel-trace only), one counter per pass.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/p2; mkdir -p $O
-Q="--no-cpu-baseline --ttfa-requests 0 --serving-ttfa-requests 0"
+Q="--no-cpu-baseline --ttfa-requests 0 --serving-ttfa-requests 0 --no-other-configs"
 for b in 1 8 32; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b$b -o b$b -- python bench.py --batch $b --steps 40 --warmup 10 $Q > $O/bench_b${b}_prof.json 2> $O/bench_b${b}_prof.err
   cp $(find $O/prof_b$b -name "*kernel_stats.csv" | head -1) $O/kernel_stats_b$b.csv
@@ -21,7 +21,10 @@ timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 600 $O/bench_default.json
 # BASELINE configs 3 and 4 (development benches; one JSON line each with a roofline block) + their kernel summaries
 for b in 1 16; do timeout 600 python tools/bench_csm.py --batch $b > $O/csm_b$b.json 2> $O/csm_b$b.err; done
-for b in 1 8; do timeout 600 python tools/bench_glm.py --batch $b --greedy > $O/glm_b$b.json 2> $O/glm_b$b.err; done
+for b in 1 8; do timeout 600 python tools/bench_glm.py --batch $b --greedy --steps 150 > $O/glm_b$b.json 2> $O/glm_b$b.err; done
+for b in 1 8; do timeout 600 python tools/bench_cosyvoice2.py --batch $b > $O/cosyvoice2_b$b.json 2> $O/cosyvoice2_b$b.err; done
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cv -o cv -- python tools/bench_cosyvoice2.py --batch 1 --steps 50 --warmup 0 > $O/cv_prof.json 2> $O/cv_prof.err
+cp $(find $O/prof_cv -name "*kernel_stats.csv" | head -1) $O/kernel_stats_cosyvoice2_b1.csv; rm -rf $O/prof_cv
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_csm -o csm -- python tools/bench_csm.py --batch 16 --steps 40 --warmup 10 > $O/csm_b16_prof.json 2> $O/csm_b16_prof.err
 cp $(find $O/prof_csm -name "*kernel_stats.csv" | head -1) $O/kernel_stats_csm_b16.csv; rm -rf $O/prof_csm
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_glm -o glm -- python tools/bench_glm.py --batch 8 --greedy --steps 40 --warmup 10 > $O/glm_b8_prof.json 2> $O/glm_b8_prof.err
