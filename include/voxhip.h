@@ -219,6 +219,13 @@ int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const 
                       const int32_t* last_rows, int n_req, int max_kvlen, const vox_sampling_config* sampling,
                       uint64_t seed, int feedback);
 
+/* Voice-clone prompt features of Qwen3TTSModel.preprocess (model/qwen3_tts.py:1657-1672 speaker position,
+ * :1733-1744 ICL rows): spk_out[H] = bf16(speaker_embedding - codec_embedding[codec_pad_id]) when speaker_embedding != NULL;
+ * icl_out[t][H] = bf16 running sum over codebooks 1..n_groups-1 of code_predictor.codec_embedding[cb-1][ref_codes[t][cb]]
+ * (ref_codes int32 [n_frames][n_groups]; each add rounded to bf16 in codebook order, as the reference's bf16 `+=`). */
+int vox_qwen3_prompt_features(vox_qwen3* m, void* stream, const int32_t* ref_codes, int n_frames, const void* speaker_embedding,
+                              int codec_pad_id, void* spk_out, void* icl_out);
+
 /* ---- CSM-1B frame engine: backbone decode + on-device sampling + 31-step depth loop --------------------
  * replaces CSMModel.forward / sampling / depth_forward / depth_sampling (model/csm.py:637-770) and the depth loop of
  * ModelWorker.run_lm_depth (worker/base.py:546-614).  Backbone input = sum over the 33 masked per-column embeddings
@@ -596,6 +603,64 @@ void vox_glmflow_destroy(vox_glmflow* m);
  * [n][spk_dim] or NULL (zeros, as GLMAudioDecoder passes); noise: device fp32 [n][mel][Tm] or NULL; mel: fp32 [n][mel][Tm] */
 int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int n, int T, int Tm, const float* embedding, const float* noise,
                        uint64_t seed, uint32_t first_stream, float* mel);
+
+/* ---- Qwen3-TTS speaker encoder (voice cloning, prompt side) -------------------------------------------------
+ * replaces mel_spectrogram + Qwen3TTSSpeakerEncoder.forward as called by Qwen3TTSModel._extract_speaker_embedding
+ * (model/qwen3_tts.py:21-88, 835-891, 1288-1328): 24 kHz clip -> reflect-padded Hann STFT (DFT accumulated in fp64) -> log-mel
+ * -> ECAPA-TDNN (TDNN, SE-Res2Net blocks with reflect "same" padding, multi-layer aggregation, attentive statistics pooling, fc)
+ * -> x-vector.  fp32 activations over the checkpoint's bf16 weights (one weight plane per conv, exact products).           */
+typedef struct vox_spkenc vox_spkenc;
+typedef struct {
+    int32_t n_mels, n_mels_padded, n_fft, hop;   /* n_fft a power of two <= 2048 */
+    int32_t n_blocks;                            /* SE-Res2Net blocks (3) */
+    int32_t channels, scale, se_channels;        /* 512, 8, 128 */
+    int32_t mfa_channels, att_channels, enc_dim; /* 1536 (= n_blocks * channels), 128, 1024 | 2048 */
+    int32_t kernel0, dilation0;                  /* first TDNN (5, 1) */
+    int32_t kernels[4], dilations[4];            /* Res2Net convs of each block (3; 2, 3, 4) */
+} vox_spkenc_config;
+typedef struct { vox_conv_w tdnn1, res2[7], tdnn2, se1, se2; } vox_spkenc_block_w;
+typedef struct {
+    const float* mel_basis; /* [n_mels][n_fft/2 + 1]  (librosa.filters.mel, Slaney) */
+    const float* window;    /* [n_fft] periodic Hann */
+    vox_conv_w conv0;
+    vox_spkenc_block_w blocks[4];
+    vox_conv_w mfa, asp_tdnn, asp_conv, fc;
+} vox_spkenc_weights;
+int vox_spkenc_create(vox_ctx* ctx, const vox_spkenc_config* cfg, const vox_spkenc_weights* w, int max_samples, vox_spkenc** out);
+void vox_spkenc_destroy(vox_spkenc* m);
+/* audio: device fp32 [n_samples]; mel_out: device fp32 [T][n_mels] or NULL (T = n_samples / hop frames, returned through n_frames);
+ * emb_out: device fp32 [enc_dim] */
+int vox_spkenc_embed(vox_spkenc* m, void* stream, const float* audio, int n_samples, float* mel_out, int32_t* n_frames, float* emb_out);
+
+/* ---- Qwen3-TTS speech-tokenizer encoder (ICL voice cloning, prompt side) ---------------------------------------
+ * replaces Qwen3TTSTokenizerV2Model.encode (tokenizer/qwen3_codec.py:1743-1773: MimiModel.encode of `transformers` behind
+ * Qwen3TTSTokenizerV2Encoder, :1669-1679) as called by Qwen3TTSModel._encode_audio_to_codes (model/qwen3_tts.py:1330-1371):
+ * 24 kHz clip -> SEANet encoder (causal convs, strided convs as two-tap GEMMs over r-frame rows) -> 8-layer sliding-window
+ * transformer -> stride-2 downsample (replicate padding) -> split RVQ encode (nearest centroid per layer) -> codes
+ * [ceil(n / 1920)][16].  fp32 activations, one bf16 weight plane (the reference serves the tokenizer in bf16).             */
+typedef struct vox_codecenc vox_codecenc;
+typedef struct {
+    int32_t num_filters, ratios[4], kernel_size, residual_kernel_size, last_kernel_size, compress;
+    int32_t hidden, num_heads, head_dim, num_layers, ffn, window;
+    int32_t codebook_size, codebook_dim, n_semantic, n_acoustic; /* RVQ layers used: 1 + 15 */
+    float ln_eps;
+} vox_codecenc_config;
+typedef struct { vox_conv_w conv1, conv2, down; } vox_codecenc_stage_w; /* ResnetBlock convs (k3, k1), strided conv as 2 taps over [L/r][r C] */
+typedef struct {
+    const float *in_w, *in_b;      /* first conv: [num_filters][kernel_size], [num_filters] */
+    vox_codecenc_stage_w stage[4];
+    vox_conv_w last;
+    vox_mimi_layer_w layers[16];   /* qkv = [q; k; v] rows, o, fc1, fc2; LayerNorm + LayerScale vectors */
+    const float* inv_freq;         /* [head_dim / 2] */
+    vox_conv_w downsample;         /* 2 taps over frame pairs [T/2][2 hidden] */
+    vox_conv_w sem_proj, ac_proj;  /* 1x1 input projections hidden -> codebook_dim */
+    const float *sem_emb, *ac_emb; /* [layers][codebook_size][codebook_dim] = embed_sum / clamp(cluster_usage, 1e-5) */
+} vox_codecenc_weights;
+int vox_codecenc_create(vox_ctx* ctx, const vox_codecenc_config* cfg, const vox_codecenc_weights* w, int max_samples, vox_codecenc** out);
+void vox_codecenc_destroy(vox_codecenc* m);
+/* audio: device fp32 [n_samples]; codes: device int32 [T][n_semantic + n_acoustic], T = ceil(n_samples / hop) (returned through
+ * n_frames); latents_out: device fp32 [T][hidden] (the frames that were quantised) or NULL */
+int vox_codecenc_encode(vox_codecenc* m, void* stream, const float* audio, int n_samples, int32_t* codes, int32_t* n_frames, float* latents_out);
 
 #ifdef __cplusplus
 }

@@ -312,3 +312,24 @@ class Qwen3Ref:
             r.input_ids, r.input_mask, r.input_features = ids, True, feats[b:b + 1].copy()
             r.frames.append(out[b].copy())
         return out, masked, hid, dl
+
+
+def prompt_features(W: Dict[str, np.ndarray], cfg: Qwen3Cfg, n_rows: int, speaker_row, spk_bits, icl_row, ref_codes,
+                    codec_pad_id: int) -> np.ndarray:
+    """input_features (bf16 bits [n_rows, H]) of a voice-clone prompt, as Qwen3TTSModel.preprocess builds them
+    (/root/reference/vox_serve/model/qwen3_tts.py:1657-1672 speaker position, :1733-1744 reference-code rows): the
+    speaker row holds bf16(speaker_embedding - codec_embedding[codec_pad]); each reference frame's row is the in-place
+    bf16 `+=` of code_predictor.codec_embedding[cb-1][code] over codebooks 1..G-1, i.e. rounded to bf16 after every add."""
+    H = cfg.talker.hidden
+    out = np.zeros((n_rows, H), np.uint16)
+    if speaker_row is not None:
+        pad = vr.bf2f(W["talker.model.codec_embedding.weight"][codec_pad_id])
+        out[speaker_row] = vr.f2bf(vr.bf2f(spk_bits) - pad)
+    if icl_row is not None:
+        T = ref_codes.shape[0]
+        acc = np.zeros((T, H), np.float32)
+        for cb in range(1, cfg.n_groups):
+            tab = W[f"talker.code_predictor.model.codec_embedding.{cb - 1}.weight"]
+            acc = vr.bf2f(vr.f2bf(acc + vr.bf2f(tab[ref_codes[:, cb]])))
+        out[icl_row:icl_row + T] = vr.f2bf(acc)
+    return out

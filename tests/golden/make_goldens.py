@@ -1062,8 +1062,164 @@ def g13_glm_decoder(ns):
     np.savez_compressed(os.path.join(HERE, "g13_glm_decoder.npz"), **out)
 
 
+class _TplTok:
+    """Stand-in for the Qwen text tokenizer inside Qwen3TTSModel.preprocess: the chat-template pieces map to their
+    real ids, every other run of text to one token per 3 characters (ids 1000..5999)."""
+    SPECIAL = {"<|im_start|>": 151644, "<|im_end|>": 151645, "\n": 198, "assistant": 77091, "user": 872}
+
+    def ids(self, text):
+        out, i = [], 0
+        while i < len(text):
+            for k, v in self.SPECIAL.items():
+                if text.startswith(k, i):
+                    out.append(v)
+                    i += len(k)
+                    break
+            else:
+                j = i
+                while j < len(text) and j - i < 3 and not any(text.startswith(k, j) for k in self.SPECIAL):
+                    j += 1
+                out.append(1000 + sum(map(ord, text[i:j])) % 5000)
+                i = j
+        return out
+
+    def encode(self, text, return_tensors=None):
+        return torch.tensor([self.ids(text)], dtype=torch.long)
+
+
+def g14_qwen3_preprocess(ns):
+    """Qwen3TTSModel.preprocess of the reference (qwen3_tts.py:1373-1803) in every mode: custom voice (language id,
+    dialect speaker, instruct), voice design, x-vector-only cloning, ICL cloning, and the input-streaming variants.
+    The two prompt-side encoders are replaced by given outputs (speaker embedding / reference codes) here; they have
+    their own fixtures (g15, g16)."""
+    import logging
+    cfg = QR.tiny_cfg()
+    W = QR.random_weights(cfg, seed=0, std=0.08)
+    m = _ref_qwen3(ns, cfg, W)
+    tc = m.config.talker_config
+    # special ids inside the tiny vocabulary (1280 codec ids)
+    tc.codec_pad_id, tc.codec_bos_id, tc.codec_think_id, tc.codec_nothink_id = 1148, 1149, 1154, 1155
+    tc.codec_think_bos_id, tc.codec_think_eos_id = 1156, 1157
+    m.config.tts_bos_token_id, m.config.tts_eos_token_id = 151672, 151673
+    tc.spk_id = {"vivian": 1101, "dylan": 1102}
+    tc.spk_is_dialect = {"vivian": False, "dylan": "beijing_dialect"}
+    tc.codec_language_id = {"chinese": 1055, "english": 1050, "german": 1053, "beijing_dialect": 1074}
+    out_ids = dict(tts_bos=151672, tts_eos=151673, tts_pad=int(m.config.tts_pad_token_id), codec_pad=1148, codec_bos=1149,
+                   codec_think=1154, codec_nothink=1155, codec_think_bos=1156, codec_think_eos=1157)
+    tok = _TplTok()
+    m.text_tokenizer, m.logger, m.tts_model_size, m.speaker_encoder_sample_rate = tok, logging.getLogger("g14"), "1b7", 24000
+    m.audio_decoder_initial_cache = lambda batch_size: None
+    H_ = cfg.talker.hidden
+    g = torch.Generator().manual_seed(14)
+    spk = (torch.randn(H_, generator=g) * 0.5).to(torch.bfloat16)
+    ref_codes = torch.randint(0, cfg.depth_vocab, (7, cfg.n_groups), generator=g)
+    m._load_audio_to_np = lambda x: (np.zeros(2400, np.float32), 24000)
+    m._extract_speaker_embedding = lambda audio, sr: spk
+    m._encode_audio_to_codes = lambda audio, sr: ref_codes
+    out = {"spk_embedding": bits(spk), "ref_codes": ref_codes.numpy().astype(np.int32),
+           "special_ids": np.array(json.dumps(dict(out_ids, spk_id=tc.spk_id, spk_is_dialect=tc.spk_is_dialect,
+                                                   codec_language_id=tc.codec_language_id)))}
+    cases = [
+        ("cv_english", "custom_voice", dict(prompt="Hello there, world.", language="english", speaker="Vivian")),
+        ("cv_auto_dialect", "custom_voice", dict(prompt="ni hao", language="auto", speaker="dylan")),
+        ("cv_instruct", "custom_voice", dict(prompt="Read this slowly.", language="german", speaker="vivian", instruct="Speak calmly")),
+        ("cv_stream", "custom_voice", dict(prompt="Streaming text", language="english", speaker="vivian", is_input_streaming=True)),
+        ("vd_instruct", "voice_design", dict(prompt="A designed voice.", language="auto", instruct="A deep male voice")),
+        ("vd_stream", "voice_design", dict(prompt="Design stream", language="english", instruct="bright", is_input_streaming=True)),
+        ("xvec", "base", dict(prompt="Clone by x-vector.", audio_path="ref.wav", ref_text="ignored", language="english", x_vector_only_mode=True)),
+        ("xvec_stream", "base", dict(prompt="Clone stream", audio_path="ref.wav", ref_text="r", language="auto", x_vector_only_mode=True, is_input_streaming=True)),
+        ("icl", "base", dict(prompt="Say this in the cloned voice.", audio_path="ref.wav", ref_text="The reference transcript.", language="english")),
+        ("icl_auto_instruct", "base", dict(prompt="Second one", audio_path="ref.wav", ref_text="Ref", language="auto", instruct="whisper")),
+    ]
+    for tag, kind, kw in cases:
+        m.tts_model_type = kind
+        m.config.tts_model_type = kind
+        po = m.preprocess(**kw)
+        out[f"{tag}_tokens"] = po.input_tokens.numpy().astype(np.int64)
+        out[f"{tag}_masks"] = po.input_masks.numpy()
+        out[f"{tag}_features"] = bits(po.input_features)
+        tpl = "<|im_start|>assistant\n{prompt}" if kw.get("is_input_streaming") else "<|im_start|>assistant\n{prompt}<|im_end|>\n<|im_start|>assistant\n"
+        out[f"{tag}_prompt_ids"] = np.array(tok.ids(tpl.format(prompt=kw["prompt"])), np.int64)
+        if kw.get("instruct"):
+            out[f"{tag}_instruct_ids"] = np.array(tok.ids("<|im_start|>user\n{}<|im_end|>\n".format(kw["instruct"])), np.int64)
+        if kw.get("ref_text") and not kw.get("x_vector_only_mode"):
+            out[f"{tag}_ref_text_ids"] = np.array(tok.ids("<|im_start|>assistant\n{}<|im_end|>\n".format(kw["ref_text"])), np.int64)
+        print("g14", tag, tuple(po.input_tokens.shape), "feature rows nonzero", int((po.input_features.float().abs().sum(1) > 0).sum()))
+    out["cases"] = np.array(json.dumps([(t, k, {a: b for a, b in kw.items()}) for t, k, kw in cases]))
+    np.savez_compressed(os.path.join(HERE, "g14_qwen3_preprocess.npz"), **out)
+
+
+def g15_speaker_encoder(ns):
+    """Qwen3TTSSpeakerEncoder + mel_spectrogram of the reference (qwen3_tts.py:21-88, 835-891), run in fp32 over bf16-valued
+    weights, tiny and full size (mel 128 -> 2048, the 1.7B base checkpoint's shape).  librosa is absent: its mel filterbank is
+    the restatement in oracle/spk_ref.py (the one third-party piece of this path; see that file's header)."""
+    from oracle import spk_ref as SR
+    Q = ns.qwen3_tts
+    out = {}
+    for tag, cfg, n, seed in (("tiny", SR.tiny_spk_cfg(), 9000, 3), ("full", SR.SpkCfg(), 60000, 4)):
+        Q.librosa_mel_fn = lambda sr, n_fft, n_mels, fmin, fmax: SR.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+        rc = Q.Qwen3TTSSpeakerEncoderConfig(enc_dim=cfg.enc_dim, sample_rate=cfg.sample_rate, mel_dim=cfg.mel_dim,
+                                            enc_channels=cfg.enc_channels, enc_kernel_sizes=cfg.enc_kernel_sizes,
+                                            enc_dilations=cfg.enc_dilations, enc_res2net_scale=cfg.enc_res2net_scale,
+                                            enc_se_channels=cfg.enc_se_channels, enc_attention_channels=cfg.enc_attention_channels)
+        net = Q.Qwen3TTSSpeakerEncoder(rc).float().eval()
+        W = SR.random_spk_weights(cfg, seed=seed)
+        missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+        audio = SR.test_audio(seed, n)
+        mels = Q.mel_spectrogram(torch.from_numpy(audio)[None], n_fft=1024, num_mels=cfg.mel_dim, sampling_rate=24000, hop_size=256,
+                                 win_size=1024, fmin=0, fmax=12000).transpose(1, 2)
+        emb = net(mels)[0]
+        emb_bf16 = net.to(torch.bfloat16)(mels.to(torch.bfloat16))[0]
+        out[f"{tag}_mel"], out[f"{tag}_emb"] = mels[0].numpy().astype(np.float32), emb.numpy().astype(np.float32)
+        out[f"{tag}_emb_bf16"] = emb_bf16.float().numpy()
+        out[f"{tag}_seed"], out[f"{tag}_n"] = np.int64(seed), np.int64(n)
+        print("g15", tag, "mel", tuple(mels.shape), "emb rms", float(emb.pow(2).mean().sqrt()),
+              "bf16 run rel", float((emb_bf16.float() - emb).pow(2).mean().sqrt() / emb.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(HERE, "g15_speaker_encoder.npz"), **out)
+
+
+def g16_codec_encoder(ns):
+    """The speech tokenizer's encoder as the reference wires it (Qwen3TTSTokenizerV2Encoder(MimiModel) behind
+    Qwen3TTSTokenizerV2Model.encode, qwen3_codec.py:1669-1773), fp32, tiny and full size: pre-quantisation latents and codes."""
+    import transformers
+    from transformers import MimiConfig
+    from oracle import codec_enc_ref as ER, spk_ref as SR
+    C = ns.qwen3_codec
+    out = {"transformers_version": np.array(transformers.__version__)}
+    for tag, cfg, n, seed in (("tiny", ER.tiny_codec_enc_cfg(), 1000, 5), ("full", ER.CodecEncCfg(), 52000, 6)):
+        mc = MimiConfig(audio_channels=1, codebook_dim=cfg.codebook_dim, codebook_size=cfg.codebook_size, compress=cfg.compress,
+                        dilation_growth_rate=2, head_dim=cfg.head_dim, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                        kernel_size=cfg.kernel_size, last_kernel_size=cfg.last_kernel_size, num_filters=cfg.num_filters,
+                        num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_heads,
+                        num_quantizers=cfg.num_quantizers, num_residual_layers=1, pad_mode="constant",
+                        residual_kernel_size=cfg.residual_kernel_size, rope_theta=cfg.rope_theta, sampling_rate=24000,
+                        sliding_window=cfg.sliding_window, trim_right_ratio=1.0, upsample_groups=cfg.hidden_size,
+                        upsampling_ratios=list(reversed(cfg.ratios)), use_cache=False, use_conv_shortcut=False,
+                        vector_quantization_hidden_dimension=cfg.codebook_dim, num_semantic_quantizers=cfg.num_semantic_quantizers,
+                        norm_eps=cfg.norm_eps)
+        enc = C.Qwen3TTSTokenizerV2Encoder(mc).float().eval()
+        W = ER.random_codec_enc_weights(cfg, seed=seed)
+        missing, unexpected = enc.load_state_dict(W, strict=False)
+        assert not unexpected, unexpected
+        assert all(("initialized" in k) or ("output_proj" in k) or ("inv_freq" in k) for k in missing), missing
+        for m_ in enc.modules():                      # the codebook property caches embed_sum / cluster_usage
+            if hasattr(m_, "_embed"):
+                m_._embed = None
+        stub = types.SimpleNamespace(encoder=enc, encoder_valid_num_quantizers=cfg.valid_quantizers, encode_downsample_rate=cfg.hop)
+        wav = torch.from_numpy(SR.test_audio(seed, n))
+        codes = C.Qwen3TTSTokenizerV2Model.encode(stub, wav[None], torch.ones(1, n, dtype=torch.long))[0]
+        emb = enc.encoder(wav.view(1, 1, -1))
+        lat = enc.downsample(enc.encoder_transformer(emb.transpose(1, 2))[0].transpose(1, 2))[0].transpose(0, 1)
+        out[f"{tag}_codes"], out[f"{tag}_latents"] = codes.numpy().astype(np.int32), lat.numpy().astype(np.float32)
+        out[f"{tag}_seanet"] = emb[0].transpose(0, 1).numpy().astype(np.float32)[:: max(1, emb.shape[-1] // 16)]
+        out[f"{tag}_seed"], out[f"{tag}_n"] = np.int64(seed), np.int64(n)
+        print("g16", tag, "codes", tuple(codes.shape), "latent rms", float(lat.pow(2).mean().sqrt()), "distinct codes per layer",
+              [int(codes[:, q].unique().numel()) for q in range(codes.shape[1])][:6])
+    np.savez_compressed(os.path.join(HERE, "g16_codec_encoder.npz"), **out)
+
+
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder}
 
 if __name__ == "__main__":
     ns = H.boot()

@@ -200,6 +200,36 @@ def test_qwen3_prompt_layout_matches_reference_rules():
     assert toks2.shape[0] == P + 10 and toks2[3:6, 0].tolist() == [t.codec_nothink, t.codec_think_bos, t.codec_think_eos]
 
 
+def test_qwen3_preprocess_layout_equals_reference(golden):
+    """Every mode of the reference's Qwen3TTSModel.preprocess (g14: custom voice with language id / dialect speaker /
+    instruct, voice design, x-vector-only and ICL cloning, input streaming): tokens and masks equal, row for row."""
+    import json
+    from vox_serve_amd.engine import Qwen3Cfg
+    from vox_serve_amd.model.qwen3_tts import Qwen3TTSModel, Qwen3TTSTokens
+    g = golden("g14_qwen3_preprocess")
+    ids = json.loads(str(g["special_ids"]))
+    spk_id, dialect, lang = ids.pop("spk_id"), ids.pop("spk_is_dialect"), ids.pop("codec_language_id")
+    for tag, kind, kw in json.loads(str(g["cases"])):
+        m = Qwen3TTSModel.__new__(Qwen3TTSModel)
+        m.tokens = Qwen3TTSTokens(**ids, codec_eos=300, codec_language_id=lang, spk_id=spk_id, spk_is_dialect=dialect)
+        m.tts_model_type, m.config = kind, Qwen3Cfg(n_groups=4)
+        icl = kind == "base" and not kw.get("x_vector_only_mode")
+        toks, masks, info = m.layout(
+            g[f"{tag}_prompt_ids"].tolist(), kw.get("language", "english"), kw.get("speaker", "ryan"),
+            g[f"{tag}_instruct_ids"].tolist() if f"{tag}_instruct_ids" in g else None, bool(kw.get("is_input_streaming")),
+            ref_text_ids=g[f"{tag}_ref_text_ids"].tolist() if icl else None,
+            ref_codes0=g["ref_codes"][:, 0].tolist() if icl else None, return_info=True)
+        assert torch.equal(toks, torch.from_numpy(g[f"{tag}_tokens"])), tag
+        assert torch.equal(masks, torch.from_numpy(g[f"{tag}_masks"])), tag
+        feat_rows = np.nonzero(g[f"{tag}_features"].any(axis=1))[0].tolist()
+        want = ([info["speaker_row"]] if info["speaker_row"] is not None else []) + \
+            (list(range(info["icl_row"], toks.shape[0])) if info["icl_row"] is not None else [])
+        assert feat_rows == want, tag
+    m.tts_model_type = "base"
+    with pytest.raises(ValueError):
+        m.layout([1, 2, 3, 4], "auto", None, None, True, ref_text_ids=[1, 2, 3, 4, 5, 6], ref_codes0=[1, 2])
+
+
 def test_registry_errors():
     from vox_serve_amd.model import load_model
     with pytest.raises(ValueError):

@@ -446,3 +446,62 @@ def test_glm_decoder_oracle_matches_reference_modules(golden, tag):
     em, es, ew = rms(mel.numpy() - g[f"{tag}_mel"]), rms(src.numpy() - g[f"{tag}_source"]), rms(wav.numpy() - g[f"{tag}_wav"])
     assert wav.shape == (B, 44032)
     assert em < 2e-5 and es < 1e-4 and ew < 1e-4, (em, es, ew)
+
+
+def test_qwen3_prompt_features_pin(golden):
+    """oracle prompt_features == the reference preprocess's input_features (x-vector-only and ICL cloning, g14), bit for bit."""
+    import json
+    from oracle import qwen3_ref as QR
+    g = golden("g14_qwen3_preprocess")
+    ids = json.loads(str(g["special_ids"]))
+    cfg = QR.tiny_cfg()
+    W = QR.random_weights(cfg, seed=0, std=0.08)
+    for tag, kind, kw in json.loads(str(g["cases"])):
+        toks, want = g[f"{tag}_tokens"], g[f"{tag}_features"]
+        if kind != "base":
+            assert not want.any()
+            continue
+        icl = not kw.get("x_vector_only_mode")
+        T = g["ref_codes"].shape[0]
+        n_pre = (len(g[f"{tag}_instruct_ids"]) if f"{tag}_instruct_ids" in g else 0) + 3 + (3 if kw["language"] == "auto" else 4)
+        got = QR.prompt_features(W, cfg, toks.shape[0], n_pre, g["spk_embedding"], toks.shape[0] - T if icl else None,
+                                 g["ref_codes"], ids["codec_pad"])
+        assert np.array_equal(got, want), tag
+
+
+def test_speaker_encoder_pin(golden):
+    """oracle mel_spectrogram + ECAPA encoder == the reference's mel_spectrogram + Qwen3TTSSpeakerEncoder (fp32 run, g15), tiny and
+    full size; the reference's own bf16 serving run sits ~1e-2 away from its fp32 run (recorded in the fixture)."""
+    from oracle import spk_ref as SR
+    g = golden("g15_speaker_encoder")
+    for tag, cfg in (("tiny", SR.tiny_spk_cfg()), ("full", SR.SpkCfg())):
+        audio = SR.test_audio(int(g[f"{tag}_seed"]), int(g[f"{tag}_n"]))
+        mel = SR.mel_spectrogram(audio, cfg)
+        assert mel.shape == g[f"{tag}_mel"].shape
+        assert np.abs(mel - g[f"{tag}_mel"]).max() < 2e-3, np.abs(mel - g[f"{tag}_mel"]).max()     # log of fp32-FFT magnitudes in quiet bins
+        ref = SR.SpkRef(cfg, SR.random_spk_weights(cfg, seed=int(g[f"{tag}_seed"])))
+        want = g[f"{tag}_emb"]
+        rms = np.sqrt((want ** 2).mean())
+        e_net = np.sqrt(((ref.forward(g[f"{tag}_mel"]) - want) ** 2).mean()) / rms          # the network alone, on the reference's mels
+        e_all = np.sqrt(((ref.forward(mel) - want) ** 2).mean()) / rms
+        assert e_net < 2e-6 and e_all < 1e-4, (tag, e_net, e_all)
+
+
+def test_codec_encoder_pin(golden):
+    """oracle SEANet encoder + transformer + downsample + RVQ encode == the reference's Qwen3TTSTokenizerV2Model.encode over
+    transformers' MimiModel (fp32, g16): latents within 1e-5 relative, every code equal; the sliding window (tiny: 5 < T) and the
+    ragged tail (n % hop != 0) are inside the fixture."""
+    import torch
+    from oracle import codec_enc_ref as ER, spk_ref as SR
+    g = golden("g16_codec_encoder")
+    for tag, cfg in (("tiny", ER.tiny_codec_enc_cfg()), ("full", ER.CodecEncCfg())):
+        seed, n = int(g[f"{tag}_seed"]), int(g[f"{tag}_n"])
+        ref = ER.CodecEncRef(cfg, ER.random_codec_enc_weights(cfg, seed=seed))
+        wav = torch.from_numpy(SR.test_audio(seed, n))
+        lat = ref.latents(wav).numpy()
+        want = g[f"{tag}_latents"]
+        assert lat.shape == want.shape
+        assert np.sqrt(((lat - want) ** 2).mean()) / np.sqrt((want ** 2).mean()) < 1e-5
+        codes = ref.encode(wav).numpy()
+        assert codes.shape == g[f"{tag}_codes"].shape == (-(-n // cfg.hop), cfg.valid_quantizers)
+        assert np.array_equal(codes, g[f"{tag}_codes"]), (tag, int((codes != g[f"{tag}_codes"]).sum()))

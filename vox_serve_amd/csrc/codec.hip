@@ -2651,3 +2651,454 @@ int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int 
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// Prompt-side encoders of a voice-clone request (run once per request, before prefill)
+// ================================================================================================
+// ---- speaker encoder: log-mel front end + ECAPA-TDNN  (model/qwen3_tts.py:21-88, 317-532, 835-891) ----
+// Layout: fp32 time-major [t][C].  A reflect-padded "same" conv is a centred-tap conv_gemm over a reflect-padded copy of its input
+// ([T + 2p][C]); rows p .. p+T-1 of the result are the conv's output (contiguous, so later stages just offset the pointer).
+#define ENC_MAX_FFT 2048
+__global__ __launch_bounds__(256) void k_enc_logmel(const float* audio, int N, const float* window, const float* basis, int n_fft, int hop,
+                                                     int n_mels, int MP, float* mel) {
+    __shared__ double xs[ENC_MAX_FFT], tw[ENC_MAX_FFT];
+    __shared__ float mag[ENC_MAX_FFT / 2 + 1];
+    const int t = blockIdx.x, pad = (n_fft - hop) / 2, mask = n_fft - 1, nb = n_fft / 2 + 1;
+    for (int j = threadIdx.x; j < n_fft; j += 256) {
+        int i = t * hop + j - pad;                       // F.pad(..., mode="reflect"): no edge repeat
+        i = i < 0 ? -i : (i >= N ? 2 * (N - 1) - i : i);
+        xs[j] = (double)(audio[i] * window[j]);
+        tw[j] = cospi(2.0 * j / n_fft);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += 256) {
+        double re = 0.0, im = 0.0;
+        const int q = 3 * n_fft / 4;                     // sin(a) = cos(a - pi/2)
+        for (int n = 0; n < n_fft; ++n) {
+            const int idx = (k * n) & mask;
+            re += xs[n] * tw[idx];
+            im += xs[n] * tw[(idx + q) & mask];
+        }
+        mag[k] = sqrtf((float)(re * re + im * im) + 1e-9f);
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < MP; m += 256) {
+        float v = 0.f;
+        if (m < n_mels) {
+            const float* b = basis + (size_t)m * nb;
+            float acc = 0.f;
+            for (int k = 0; k < nb; ++k) acc += b[k] * mag[k];
+            v = logf(fmaxf(acc, 1e-5f));
+        }
+        mel[(size_t)t * MP + m] = v;
+    }
+}
+// dst [T + 2p][C]: dst[r][c] = s1[refl(r - p)][c] (+ s2[refl(r - p)][c]), reflect without edge repeat
+__global__ __launch_bounds__(256) void k_enc_gather(float* dst, int T, int p, int C, const float* s1, int ld1, const float* s2, int ld2) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)(T + 2 * p) * C) return;
+    const int r = (int)(i / C), c = (int)(i % C);
+    int t = r - p;
+    t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
+    float v = s1[(size_t)t * ld1 + c];
+    if (s2) v += s2[(size_t)t * ld2 + c];
+    dst[i] = v;
+}
+__global__ __launch_bounds__(256) void k_enc_copy_cols(float* dst, int ldd, const float* src, int lds, int T, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * C) return;
+    const int t = (int)(i / C), c = (int)(i % C);
+    dst[(size_t)t * ldd + c] = src[(size_t)t * lds + c];
+}
+// mode 2: ReLU; 3: tanh(ReLU); 4: sigmoid
+__global__ __launch_bounds__(256) void k_enc_act(float* x, size_t n, int mode) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i];
+    if (mode == 2) v = fmaxf(v, 0.f);
+    else if (mode == 3) v = tanhf(fmaxf(v, 0.f));
+    else if (mode == 4) v = 1.0f / (1.0f + expf(-v));
+    x[i] = v;
+}
+// Per-channel weighted statistics over time (AttentiveStatisticsPooling._compute_statistics): weights 1/T (att == NULL) or the softmax over
+// time of att[:, c].  mean[c] = sum w x, std[c] = sqrt(max(sum w (x - mean)^2, 1e-12)).  Block = 64 channels x 4 time lanes.
+__global__ __launch_bounds__(256) void k_enc_colstats(const float* x, int T, int C, const float* att, float* mean, float* stdv) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const bool ok = c < C;
+    auto reduce = [&](float v, bool is_max) {
+        red[tl][cl] = v;
+        __syncthreads();
+        float r = red[0][cl];
+        for (int k = 1; k < 4; ++k) r = is_max ? fmaxf(r, red[k][cl]) : r + red[k][cl];
+        __syncthreads();
+        return r;
+    };
+    float amax = 0.f, inv = 1.0f / (float)T;
+    if (att) {
+        float mx = -INFINITY;
+        if (ok) for (int t = tl; t < T; t += 4) mx = fmaxf(mx, att[(size_t)t * C + c]);
+        amax = reduce(mx, true);
+        float se = 0.f;
+        if (ok) for (int t = tl; t < T; t += 4) se += expf(att[(size_t)t * C + c] - amax);
+        inv = 1.0f / reduce(se, false);
+    }
+    float sm = 0.f;
+    if (ok) for (int t = tl; t < T; t += 4) {
+        const float w = att ? expf(att[(size_t)t * C + c] - amax) * inv : inv;
+        sm += w * x[(size_t)t * C + c];
+    }
+    const float mu = reduce(sm, false);
+    float sv = 0.f;
+    if (ok) for (int t = tl; t < T; t += 4) {
+        const float w = att ? expf(att[(size_t)t * C + c] - amax) * inv : inv;
+        const float d = x[(size_t)t * C + c] - mu;
+        sv += w * d * d;
+    }
+    const float var = reduce(sv, false);
+    if (ok && tl == 0) {
+        mean[c] = mu;
+        if (stdv) stdv[c] = sqrtf(fmaxf(var, 1e-12f));
+    }
+}
+// SE scale + residual (qwen3_tts.py:378, 532): out[t][c] = h[t][c] * s[c] + res[t][c]; a second copy goes into the aggregation buffer
+__global__ __launch_bounds__(256) void k_enc_se_apply(const float* h, const float* s, const float* res, float* out, float* out2, int ld2, int T, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * C) return;
+    const int t = (int)(i / C), c = (int)(i % C);
+    const float v = h[i] * s[c] + res[i];
+    out[i] = v;
+    out2[(size_t)t * ld2 + c] = v;
+}
+// [x, mean, std] along channels (qwen3_tts.py:452-454): out [T][3C]
+__global__ __launch_bounds__(256) void k_enc_asp_cat(const float* x, const float* mean, const float* stdv, float* out, int T, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * 3 * C) return;
+    const int t = (int)(i / (3 * C)), c = (int)(i % (3 * C));
+    out[i] = c < C ? x[(size_t)t * C + c] : (c < 2 * C ? mean[c - C] : stdv[c - 2 * C]);
+}
+
+struct vox_spkenc {
+    vox_ctx* ctx;
+    vox_spkenc_config cfg;
+    vox_spkenc_weights w;
+    int max_T, max_pad;
+    float *mel = nullptr, *g = nullptr, *c0 = nullptr, *a = nullptr, *cat = nullptr, *h2 = nullptr, *hA = nullptr, *hB = nullptr,
+          *co[8] = {}, *mfa_in = nullptr, *x = nullptr, *att_in = nullptr, *att_h = nullptr, *logits = nullptr, *vec = nullptr;
+};
+static inline unsigned enc_grid(size_t n) { return (unsigned)((n + 255) / 256); }
+static inline void enc_act(hipStream_t st, float* x, size_t n, int mode) { hipLaunchKernelGGL(k_enc_act, dim3(enc_grid(n)), dim3(256), 0, st, x, n, mode); }
+
+extern "C" {
+
+void vox_spkenc_destroy(vox_spkenc* m) {
+    if (!m) return;
+    float* all[] = {m->mel, m->g, m->c0, m->a, m->cat, m->h2, m->hA, m->hB, m->mfa_in, m->x, m->att_in, m->att_h, m->logits, m->vec};
+    for (float* p : all) if (p) (void)hipFree(p);
+    for (float* p : m->co) if (p) (void)hipFree(p);
+    delete m;
+}
+
+int vox_spkenc_create(vox_ctx* ctx, const vox_spkenc_config* cfg, const vox_spkenc_weights* w, int max_samples, vox_spkenc** out) {
+    if (!ctx || !cfg || !w || !out) return vox_fail(VOX_ERR_INVALID, "spkenc_create: NULL");
+    const vox_spkenc_config& c = *cfg;
+    if (c.n_fft < 64 || c.n_fft > ENC_MAX_FFT || (c.n_fft & (c.n_fft - 1)) || c.hop < 1 || c.hop > c.n_fft || c.n_mels > c.n_mels_padded ||
+        c.n_mels_padded % 32 || c.n_blocks < 1 || c.n_blocks > 4 || c.scale < 2 || c.scale > 8 || c.channels % (32 * c.scale) ||
+        c.mfa_channels != c.n_blocks * c.channels || c.se_channels % 32 || c.att_channels % 32 || !(c.kernel0 & 1) || max_samples < c.n_fft)
+        return vox_fail(VOX_ERR_INVALID, "spkenc_create: bad config");
+    vox_spkenc* m = new vox_spkenc();
+    m->ctx = ctx; m->cfg = c; m->w = *w;
+    m->max_T = (max_samples + 2 * ((c.n_fft - c.hop) / 2) - c.n_fft) / c.hop + 1;
+    int pad = c.dilation0 * (c.kernel0 - 1) / 2;
+    for (int b = 0; b < c.n_blocks; ++b) {
+        if (!(c.kernels[b] & 1)) { delete m; return vox_fail(VOX_ERR_INVALID, "spkenc_create: even kernel"); }
+        pad = max(pad, c.dilations[b] * (c.kernels[b] - 1) / 2);
+    }
+    m->max_pad = pad;
+    const size_t Tp = (size_t)m->max_T + 2 * pad, T = m->max_T, C = c.channels, M = c.mfa_channels, cw = C / c.scale;
+    auto A = [&](float** p, size_t n) { return hipMalloc((void**)p, n * 4) == hipSuccess; };
+    bool ok = A(&m->mel, T * c.n_mels_padded) && A(&m->g, Tp * (size_t)max(c.n_mels_padded, (int)cw)) && A(&m->c0, Tp * C) && A(&m->a, T * C) &&
+              A(&m->cat, T * C) && A(&m->h2, T * C) && A(&m->hA, T * C) && A(&m->hB, T * C) && A(&m->mfa_in, T * M) && A(&m->x, T * M) &&
+              A(&m->att_in, T * 3 * M) && A(&m->att_h, T * c.att_channels) && A(&m->logits, T * M) &&
+              A(&m->vec, (size_t)(4 * M + 2 * C + c.se_channels + 64));
+    for (int i = 1; i < c.scale && ok; ++i) ok = A(&m->co[i], Tp * cw);
+    if (!ok) { vox_spkenc_destroy(m); return vox_fail(VOX_ERR_NOMEM, "spkenc_create: hipMalloc failed"); }
+    *out = m;
+    return VOX_OK;
+}
+
+int vox_spkenc_embed(vox_spkenc* m, void* stream, const float* audio, int n_samples, float* mel_out, int32_t* n_frames, float* emb_out) {
+    if (!m || !audio || !emb_out) return vox_fail(VOX_ERR_INVALID, "spkenc_embed: NULL");
+    const vox_spkenc_config& c = m->cfg;
+    const vox_spkenc_weights& w = m->w;
+    const int padw = (c.n_fft - c.hop) / 2;
+    if (n_samples <= padw) return vox_fail(VOX_ERR_INVALID, "spkenc_embed: clip of %d samples is shorter than the STFT padding", n_samples);
+    const int T = (n_samples + 2 * padw - c.n_fft) / c.hop + 1;
+    if (T < 1 || T > m->max_T) return vox_fail(VOX_ERR_INVALID, "spkenc_embed: %d frames (capacity %d)", T, m->max_T);
+    if (T <= m->max_pad) return vox_fail(VOX_ERR_INVALID, "spkenc_embed: %d frames, reflect padding needs more than %d", T, m->max_pad);
+    if (n_frames) *n_frames = T;
+    hipStream_t st = (hipStream_t)stream;
+    const int saved_planes = g_conv_planes, saved_skinny = g_conv_skinny_rows;
+    g_conv_planes = 3; g_conv_skinny_rows = 48;
+    const int MP = c.n_mels_padded, C = c.channels, M = c.mfa_channels, cw = C / c.scale;
+    int off[CG_MAXTAPS];
+    static const int off0[1] = {0};
+    hipLaunchKernelGGL(k_enc_logmel, dim3(T), dim3(256), 0, st, audio, n_samples, w.window, w.mel_basis, c.n_fft, c.hop, c.n_mels, MP, m->mel);
+    if (mel_out) hipLaunchKernelGGL(k_enc_copy_cols, dim3(enc_grid((size_t)T * c.n_mels)), dim3(256), 0, st, mel_out, c.n_mels, m->mel, MP, T, c.n_mels);
+    // blocks[0]: TDNN(mel -> C, k0, reflect)
+    int p = c.dilation0 * (c.kernel0 - 1) / 2;
+    hipLaunchKernelGGL(k_enc_gather, dim3(enc_grid((size_t)(T + 2 * p) * MP)), dim3(256), 0, st, m->g, T, p, MP, m->mel, MP, (const float*)nullptr, 0);
+    hift_conv_offsets(c.kernel0, c.dilation0, off, 1);
+    VOX_TRY(conv_gemm(st, w.conv0, m->g, nullptr, nullptr, 1, T + 2 * p, 0, off, m->c0, nullptr, nullptr, 0));
+    enc_act(st, m->c0, (size_t)(T + 2 * p) * C, 2);
+    const float* h = m->c0 + (size_t)p * C;
+    float* hn = m->hA;
+    float *vmean = m->vec, *vs1 = m->vec + C, *vs2 = vs1 + c.se_channels;       // SE vectors
+    for (int b = 0; b < c.n_blocks; ++b) {
+        const vox_spkenc_block_w& bw = w.blocks[b];
+        VOX_TRY(conv_gemm(st, bw.tdnn1, h, nullptr, nullptr, 1, T, 0, off0, m->a, nullptr, nullptr, 0));
+        enc_act(st, m->a, (size_t)T * C, 2);
+        p = c.dilations[b] * (c.kernels[b] - 1) / 2;
+        hift_conv_offsets(c.kernels[b], c.dilations[b], off, 1);
+        for (int i = 1; i < c.scale; ++i) {                                       // Res2Net: chunk i sees chunk i + the previous output
+            hipLaunchKernelGGL(k_enc_gather, dim3(enc_grid((size_t)(T + 2 * p) * cw)), dim3(256), 0, st, m->g, T, p, cw, m->a + i * cw, C,
+                               i > 1 ? m->co[i - 1] + (size_t)p * cw : (const float*)nullptr, cw);
+            VOX_TRY(conv_gemm(st, bw.res2[i - 1], m->g, nullptr, nullptr, 1, T + 2 * p, 0, off, m->co[i], nullptr, nullptr, 0));
+            enc_act(st, m->co[i], (size_t)(T + 2 * p) * cw, 2);
+        }
+        hipLaunchKernelGGL(k_enc_copy_cols, dim3(enc_grid((size_t)T * cw)), dim3(256), 0, st, m->cat, C, m->a, C, T, cw);
+        for (int i = 1; i < c.scale; ++i)
+            hipLaunchKernelGGL(k_enc_copy_cols, dim3(enc_grid((size_t)T * cw)), dim3(256), 0, st, m->cat + i * cw, C, m->co[i] + (size_t)p * cw, cw, T, cw);
+        VOX_TRY(conv_gemm(st, bw.tdnn2, m->cat, nullptr, nullptr, 1, T, 0, off0, m->h2, nullptr, nullptr, 0));
+        enc_act(st, m->h2, (size_t)T * C, 2);
+        hipLaunchKernelGGL(k_enc_colstats, dim3((C + 63) / 64), dim3(256), 0, st, m->h2, T, C, (const float*)nullptr, vmean, (float*)nullptr);
+        VOX_TRY(conv_gemm(st, bw.se1, vmean, nullptr, nullptr, 1, 1, 0, off0, vs1, nullptr, nullptr, 0));
+        enc_act(st, vs1, c.se_channels, 2);
+        VOX_TRY(conv_gemm(st, bw.se2, vs1, nullptr, nullptr, 1, 1, 0, off0, vs2, nullptr, nullptr, 0));
+        enc_act(st, vs2, C, 4);
+        hipLaunchKernelGGL(k_enc_se_apply, dim3(enc_grid((size_t)T * C)), dim3(256), 0, st, m->h2, vs2, h, hn, m->mfa_in + (size_t)b * C, M, T, C);
+        h = hn;
+        hn = hn == m->hA ? m->hB : m->hA;
+    }
+    VOX_TRY(conv_gemm(st, w.mfa, m->mfa_in, nullptr, nullptr, 1, T, 0, off0, m->x, nullptr, nullptr, 0));
+    enc_act(st, m->x, (size_t)T * M, 2);
+    float *amean = m->vec + 2 * C + c.se_channels, *astd = amean + M, *pooled = astd + M;   // pooled = [mean | std], 2M
+    hipLaunchKernelGGL(k_enc_colstats, dim3((M + 63) / 64), dim3(256), 0, st, m->x, T, M, (const float*)nullptr, amean, astd);
+    hipLaunchKernelGGL(k_enc_asp_cat, dim3(enc_grid((size_t)T * 3 * M)), dim3(256), 0, st, m->x, amean, astd, m->att_in, T, M);
+    VOX_TRY(conv_gemm(st, w.asp_tdnn, m->att_in, nullptr, nullptr, 1, T, 0, off0, m->att_h, nullptr, nullptr, 0));
+    enc_act(st, m->att_h, (size_t)T * c.att_channels, 3);
+    VOX_TRY(conv_gemm(st, w.asp_conv, m->att_h, nullptr, nullptr, 1, T, 0, off0, m->logits, nullptr, nullptr, 0));
+    hipLaunchKernelGGL(k_enc_colstats, dim3((M + 63) / 64), dim3(256), 0, st, m->x, T, M, m->logits, pooled, pooled + M);
+    VOX_TRY(conv_gemm(st, w.fc, pooled, nullptr, nullptr, 1, 1, 0, off0, emb_out, nullptr, nullptr, 0));
+    g_conv_planes = saved_planes; g_conv_skinny_rows = saved_skinny;
+    VOX_HIP(hipGetLastError());
+    return VOX_OK;
+}
+
+}  // extern "C"
+
+// ---- speech-tokenizer encoder: SEANet encoder + sliding-window transformer + downsample + split RVQ encode ----
+// (tokenizer/qwen3_codec.py:1669-1773 over transformers' MimiModel; see include/voxhip.h).  Layout: fp32 time-major [t][C].
+// A stride-r conv (kernel 2r, causal left pad r, zero right pad to a whole stride) is a two-tap conv_gemm over the same buffer
+// viewed as [ceil(L/r)][r C]: output o reads view rows o-1 (kernel taps 0..r-1) and o (taps r..2r-1); row -1 reads as zero.
+__global__ __launch_bounds__(256) void k_cenc_conv_in(const float* audio, int N, const float* w, const float* b, float* out, int nf, int k) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)N * nf) return;
+    const int t = (int)(i / nf), co = (int)(i % nf);
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int s = t - (k - 1) + j;
+        if (s >= 0) acc += w[co * k + j] * audio[s];
+    }
+    out[i] = acc + b[co];
+}
+// rotate-half RoPE in place on the q and k thirds of qkv [T][3 A], A = H D
+__global__ __launch_bounds__(256) void k_cenc_rope(float* qkv, int T, int H, int D, const float* inv_freq) {
+    const int half = D / 2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * 2 * H * half) return;
+    const int d = (int)(i % half), h = (int)((i / half) % H), which = (int)((i / ((size_t)half * H)) % 2), t = (int)(i / ((size_t)half * H * 2));
+    const float ang = (float)t * inv_freq[d], cs = cosf(ang), sn = sinf(ang);
+    float* p = qkv + (size_t)t * 3 * H * D + (size_t)which * H * D + (size_t)h * D;
+    const float x1 = p[d], x2 = p[d + half];
+    p[d] = x1 * cs - x2 * sn;
+    p[d + half] = x2 * cs + x1 * sn;
+}
+// causal attention over the last `window` keys; one wave per query row, lane = head dim (D <= 64); online softmax
+__global__ __launch_bounds__(256) void k_cenc_attn(const float* qkv, float* out, int T, int H, int D, int window, float scale) {
+    const int h = blockIdx.x, i = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= T) return;
+    const int A = H * D, ld = 3 * A;
+    const bool on = lane < D;
+    const float q = on ? qkv[(size_t)i * ld + h * D + lane] * scale : 0.f;
+    float mx = -INFINITY, l = 0.f, acc = 0.f;
+    const int j0 = i - window + 1 > 0 ? i - window + 1 : 0;
+    for (int j = j0; j <= i; ++j) {
+        float s = on ? q * qkv[(size_t)j * ld + A + h * D + lane] : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float nm = fmaxf(mx, s), c = expf(mx - nm), p = expf(s - nm);
+        l = l * c + p;
+        acc = acc * c + (on ? p * qkv[(size_t)j * ld + 2 * A + h * D + lane] : 0.f);
+        mx = nm;
+    }
+    if (on) out[(size_t)i * A + h * D + lane] = acc / l;
+}
+// frame pairs for the stride-2 downsample conv (kernel 4, replicate padding): dst [To][2 H] = [x[2o] | x[2o+1]] (the last frame
+// repeated when T is odd); hist [2 H] = [x[0] | x[0]] (the replicate left padding, read as the conv's look-back row)
+__global__ __launch_bounds__(256) void k_cenc_pairs(const float* x, int T, int Hd, float* dst, float* hist) {
+    const int To = (T + 1) / 2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)(To + 1) * 2 * Hd) return;
+    const int o = (int)(i / (2 * Hd)), c = (int)(i % (2 * Hd));
+    if (o == To) { hist[c] = x[c % Hd]; return; }
+    int t = 2 * o + c / Hd;
+    t = t < T ? t : T - 1;
+    dst[i] = x[(size_t)t * Hd + c % Hd];
+}
+// residual vector quantisation of one frame per block (MimiResidualVectorQuantizer.encode): per layer the nearest centroid by squared
+// distance (lowest index on an exact tie), residual -= centroid.  One wave per centroid at a time, lanes over the dimension.
+__global__ __launch_bounds__(256) void k_cenc_rvq(const float* x, const float* emb, int n_layers, int bins, int dim, int32_t* codes, int ld_codes) {
+    __shared__ float r[512];
+    __shared__ float bd[4];
+    __shared__ int bi[4];
+    const int t = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int d = threadIdx.x; d < dim; d += 256) r[d] = x[(size_t)t * dim + d];
+    __syncthreads();
+    for (int q = 0; q < n_layers; ++q) {
+        const float* E = emb + (size_t)q * bins * dim;
+        float best = INFINITY;
+        int besti = 0x7fffffff;
+        for (int c = wave; c < bins; c += 4) {
+            float s = 0.f;
+            for (int d = lane; d < dim; d += 64) {
+                const float df = r[d] - E[(size_t)c * dim + d];
+                s += df * df;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (s < best) { best = s; besti = c; }
+        }
+        if (lane == 0) { bd[wave] = best; bi[wave] = besti; }
+        __syncthreads();
+        float b = bd[0];
+        int k = bi[0];
+        for (int w = 1; w < 4; ++w)
+            if (bd[w] < b || (bd[w] == b && bi[w] < k)) { b = bd[w]; k = bi[w]; }
+        if (threadIdx.x == 0) codes[(size_t)t * ld_codes + q] = k;
+        __syncthreads();
+        for (int d = threadIdx.x; d < dim; d += 256) r[d] -= E[(size_t)k * dim + d];
+        __syncthreads();
+    }
+}
+
+struct vox_codecenc {
+    vox_ctx* ctx;
+    vox_codecenc_config cfg;
+    vox_codecenc_weights w;
+    int max_samples, hop25, max_T25;
+    size_t big;
+    float *A = nullptr, *B = nullptr, *C = nullptr, *tr[4] = {nullptr, nullptr, nullptr, nullptr}, *hist = nullptr, *proj = nullptr;
+    int32_t* zero_slot = nullptr;
+};
+
+extern "C" {
+
+void vox_codecenc_destroy(vox_codecenc* m) {
+    if (!m) return;
+    (void)hipFree(m->A); (void)hipFree(m->B); (void)hipFree(m->C); (void)hipFree(m->hist); (void)hipFree(m->proj); (void)hipFree(m->zero_slot);
+    for (float* p : m->tr) (void)hipFree(p);
+    delete m;
+}
+
+int vox_codecenc_create(vox_ctx* ctx, const vox_codecenc_config* cfg, const vox_codecenc_weights* w, int max_samples, vox_codecenc** out) {
+    if (!ctx || !cfg || !w || !out) return vox_fail(VOX_ERR_INVALID, "codecenc_create: NULL");
+    const vox_codecenc_config& c = *cfg;
+    if (c.num_filters % (32 * c.compress) || c.compress < 1 || c.hidden % 32 || c.head_dim > 64 || c.head_dim % 2 || c.num_layers > 16 ||
+        c.num_heads * c.head_dim % 32 || c.ffn % 32 || c.codebook_dim % 32 || c.codebook_dim > 512 || c.residual_kernel_size != 3 ||
+        c.last_kernel_size != 3 || c.kernel_size > 16 || c.n_semantic < 1 || c.n_acoustic < 0 || max_samples < 1)
+        return vox_fail(VOX_ERR_INVALID, "codecenc_create: bad config");
+    vox_codecenc* m = new vox_codecenc();
+    m->ctx = ctx; m->cfg = c; m->w = *w; m->max_samples = max_samples;
+    // rows x channels shrinks by 2/r per stage, so the first stage bounds every SEANet buffer; + one padded stride of slack per stage
+    size_t L = max_samples, ch = c.num_filters, big = (L + 64) * ch;
+    m->hop25 = 1;
+    for (int s = 0; s < 4; ++s) {
+        if (c.ratios[s] < 1) { delete m; return vox_fail(VOX_ERR_INVALID, "codecenc_create: bad ratio"); }
+        L = (L + c.ratios[s] - 1) / c.ratios[s];
+        ch *= 2;
+        m->hop25 *= c.ratios[s];
+        big = big > (L + 64) * ch ? big : (L + 64) * ch;
+    }
+    m->max_T25 = (int)L;
+    m->big = big;
+    const size_t T = L + 2, A3 = (size_t)3 * c.num_heads * c.head_dim, wide = A3 > (size_t)c.ffn ? A3 : (size_t)c.ffn;
+    bool ok = hipMalloc((void**)&m->A, big * 4) == hipSuccess && hipMalloc((void**)&m->B, big * 4) == hipSuccess &&
+              hipMalloc((void**)&m->C, big * 4) == hipSuccess && hipMalloc((void**)&m->hist, (size_t)2 * c.hidden * 4) == hipSuccess &&
+              hipMalloc((void**)&m->proj, T * c.codebook_dim * 4) == hipSuccess && hipMalloc((void**)&m->zero_slot, 4) == hipSuccess;
+    for (int i = 0; i < 4 && ok; ++i) ok = hipMalloc((void**)&m->tr[i], T * (i < 2 ? (size_t)c.hidden * 2 : wide) * 4) == hipSuccess;
+    if (!ok) { vox_codecenc_destroy(m); return vox_fail(VOX_ERR_NOMEM, "codecenc_create: hipMalloc failed"); }
+    (void)hipMemset(m->zero_slot, 0, 4);
+    *out = m;
+    return VOX_OK;
+}
+
+int vox_codecenc_encode(vox_codecenc* m, void* stream, const float* audio, int n_samples, int32_t* codes, int32_t* n_frames, float* latents_out) {
+    if (!m || !audio || !codes) return vox_fail(VOX_ERR_INVALID, "codecenc_encode: NULL");
+    if (n_samples < 1 || n_samples > m->max_samples) return vox_fail(VOX_ERR_INVALID, "codecenc_encode: %d samples (capacity %d)", n_samples, m->max_samples);
+    const vox_codecenc_config& c = m->cfg;
+    const vox_codecenc_weights& w = m->w;
+    hipStream_t st = (hipStream_t)stream;
+    const int saved_planes = g_conv_planes, saved_skinny = g_conv_skinny_rows;
+    g_conv_planes = 3; g_conv_skinny_rows = 48;
+    static const int off0[1] = {0}, off3[3] = {2, 1, 0}, off2[2] = {1, 0};
+    float *x = m->A, *t1 = m->B, *t2 = m->C;
+    int L = n_samples, ch = c.num_filters;
+    hipLaunchKernelGGL(k_cenc_conv_in, dim3(enc_grid((size_t)L * ch)), dim3(256), 0, st, audio, L, w.in_w, w.in_b, x, ch, c.kernel_size);
+    for (int s = 0; s < 4; ++s) {
+        const vox_codecenc_stage_w& sw = w.stage[s];
+        const int r = c.ratios[s], Lo = (L + r - 1) / r;
+        elu(st, x, t1, (size_t)L * ch);
+        VOX_TRY(conv_gemm(st, sw.conv1, t1, nullptr, nullptr, 1, L, 0, off3, t2, nullptr, nullptr, 0));            // [L][ch / compress]
+        elu(st, t2, t2, (size_t)L * (ch / c.compress));
+        VOX_TRY(conv_gemm(st, sw.conv2, t2, nullptr, nullptr, 1, L, 0, off0, x, x, nullptr, 0));                   // x += conv2(...)
+        elu(st, x, t1, (size_t)L * ch);
+        if (Lo * r > L) VOX_HIP(hipMemsetAsync(t1 + (size_t)L * ch, 0, (size_t)(Lo * r - L) * ch * 4, st));      // zero right padding
+        VOX_TRY(conv_gemm(st, sw.down, t1, nullptr, nullptr, 1, Lo, 0, off2, t2, nullptr, nullptr, 0));            // [Lo][2 ch]
+        float* sw_ = x; x = t2; t2 = sw_;
+        L = Lo; ch *= 2;
+    }
+    const int T = L, Hd = c.hidden, nh = c.num_heads, D = c.head_dim, A = nh * D;
+    float *h = m->tr[0], *nrm = m->tr[1], *qkv = m->tr[2], *att = m->tr[3];
+    elu(st, x, t1, (size_t)T * ch);
+    VOX_TRY(conv_gemm(st, w.last, t1, nullptr, nullptr, 1, T, 0, off3, h, nullptr, nullptr, 0));                   // h [T][hidden]
+    for (int l = 0; l < c.num_layers; ++l) {
+        const vox_mimi_layer_w& lw = w.layers[l];
+        hipLaunchKernelGGL(k_layernorm_f32, dim3(T), dim3(256), 0, st, h, lw.ln1_w, lw.ln1_b, nrm, Hd, c.ln_eps);
+        VOX_TRY(conv_gemm(st, lw.qkv, nrm, nullptr, nullptr, 1, T, 0, off0, qkv, nullptr, nullptr, 0));            // [T][3A]
+        hipLaunchKernelGGL(k_cenc_rope, dim3(enc_grid((size_t)T * nh * D)), dim3(256), 0, st, qkv, T, nh, D, w.inv_freq);
+        hipLaunchKernelGGL(k_cenc_attn, dim3(nh, (T + 3) / 4), dim3(256), 0, st, qkv, att, T, nh, D, c.window, 1.0f / sqrtf((float)D));
+        VOX_TRY(conv_gemm(st, lw.o, att, nullptr, nullptr, 1, T, 0, off0, h, h, lw.scale1, 0));
+        hipLaunchKernelGGL(k_layernorm_f32, dim3(T), dim3(256), 0, st, h, lw.ln2_w, lw.ln2_b, nrm, Hd, c.ln_eps);
+        VOX_TRY(conv_gemm(st, lw.fc1, nrm, nullptr, nullptr, 1, T, 0, off0, qkv, nullptr, nullptr, 1));            // GELU
+        VOX_TRY(conv_gemm(st, lw.fc2, qkv, nullptr, nullptr, 1, T, 0, off0, h, h, lw.scale2, 0));
+    }
+    const int To = (T + 1) / 2;
+    hipLaunchKernelGGL(k_cenc_pairs, dim3(enc_grid((size_t)(To + 1) * 2 * Hd)), dim3(256), 0, st, h, T, Hd, nrm, m->hist);
+    float* lat = latents_out ? latents_out : att;
+    VOX_TRY(conv_gemm(st, w.downsample, nrm, m->hist, m->zero_slot, 1, To, 1, off2, lat, nullptr, nullptr, 0));    // [To][hidden]
+    const int nq = c.n_semantic + c.n_acoustic;
+    VOX_TRY(conv_gemm(st, w.sem_proj, lat, nullptr, nullptr, 1, To, 0, off0, m->proj, nullptr, nullptr, 0));
+    hipLaunchKernelGGL(k_cenc_rvq, dim3(To), dim3(256), 0, st, m->proj, w.sem_emb, c.n_semantic, c.codebook_size, c.codebook_dim, codes, nq);
+    if (c.n_acoustic > 0) {
+        VOX_TRY(conv_gemm(st, w.ac_proj, lat, nullptr, nullptr, 1, To, 0, off0, m->proj, nullptr, nullptr, 0));
+        hipLaunchKernelGGL(k_cenc_rvq, dim3(To), dim3(256), 0, st, m->proj, w.ac_emb, c.n_acoustic, c.codebook_size, c.codebook_dim,
+                           codes + c.n_semantic, nq);
+    }
+    if (n_frames) *n_frames = To;
+    g_conv_planes = saved_planes; g_conv_skinny_rows = saved_skinny;
+    VOX_HIP(hipGetLastError());
+    return VOX_OK;
+}
+
+}  // extern "C"

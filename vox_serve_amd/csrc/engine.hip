@@ -548,6 +548,31 @@ static int qwen3_embed(vox_qwen3* m, hipStream_t st, const int32_t* ids, const u
     return vox_launch_qwen3_mix(st, m->text, m->w.codec_embedding, ids, G1, masks, feats, m->x, n, H, c.vocab);
 }
 
+
+// Voice-clone prompt features (qwen3_tts.py:1657-1672, 1733-1744): row 0..T-1 = the bf16 running sum over codebooks
+// 1..G-1 of code_predictor.codec_embedding[cb-1][ref_codes[t][cb]] (each add rounded to bf16, in codebook order, as the
+// reference's in-place `+=` on a bf16 tensor does); spk_out = bf16(speaker_embedding - codec_embedding[codec_pad]).
+struct IclTabs { const bf16_t* emb[31]; };
+__global__ __launch_bounds__(256) void k_qwen3_prompt_features(IclTabs tabs, const int32_t* codes, int T, int G, int H, int dvocab,
+                                                                const bf16_t* spk, const bf16_t* codec_emb, int pad_id,
+                                                                bf16_t* spk_out, bf16_t* icl_out) {
+    int t = blockIdx.x;
+    if (t == T) {
+        if (spk)
+            for (int i = threadIdx.x; i < H; i += 256) spk_out[i] = f2bf(bf2f(spk[i]) - bf2f(codec_emb[(size_t)pad_id * H + i]));
+        return;
+    }
+    for (int i = threadIdx.x; i < H; i += 256) {
+        float acc = 0.f;
+        for (int cb = 1; cb < G; ++cb) {
+            int c = codes[(size_t)t * G + cb];
+            c = c < 0 ? 0 : (c >= dvocab ? dvocab - 1 : c);
+            acc = bfround(acc + bf2f(tabs.emb[cb - 1][(size_t)c * H + i]));
+        }
+        icl_out[(size_t)t * H + i] = f2bf(acc);
+    }
+}
+
 extern "C" {
 
 int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_weights* w, vox_qwen3** out) {
@@ -681,6 +706,22 @@ int vox_qwen3_prefill(vox_qwen3* m, void* stream, const vox_qwen3_io* io, const 
     if (n_req == 0) return VOX_OK;      // context chunk of a long prompt: K/V appended, nothing sampled
     VOX_TRY(qwen3_head(m, st, io, n_req, last_rows));
     return qwen3_tail(m, st, io, n_req, sc, seed, feedback);
+}
+
+int vox_qwen3_prompt_features(vox_qwen3* m, void* stream, const int32_t* ref_codes, int n_frames, const void* speaker_embedding,
+                              int codec_pad_id, void* spk_out, void* icl_out) {
+    if (!m) return vox_fail(VOX_ERR_INVALID, "qwen3_prompt_features: NULL");
+    const vox_qwen3_config& c = m->cfg;
+    if (n_frames < 0 || (n_frames && (!ref_codes || !icl_out)) || (speaker_embedding && !spk_out) || c.n_groups > 32 ||
+        codec_pad_id < 0 || codec_pad_id >= c.vocab)
+        return vox_fail(VOX_ERR_INVALID, "qwen3_prompt_features: bad arguments");
+    IclTabs tabs{};
+    for (int i = 0; i < c.n_groups - 1; ++i) tabs.emb[i] = (const bf16_t*)m->depth_emb[i];
+    hipLaunchKernelGGL(k_qwen3_prompt_features, dim3(n_frames + 1), dim3(256), 0, (hipStream_t)stream, tabs, ref_codes, n_frames,
+                       c.n_groups, c.talker.hidden, c.depth_vocab, (const bf16_t*)speaker_embedding,
+                       (const bf16_t*)m->w.codec_embedding, codec_pad_id, (bf16_t*)spk_out, (bf16_t*)icl_out);
+    VOX_HIP(hipGetLastError());
+    return VOX_OK;
 }
 
 }  // extern "C"
