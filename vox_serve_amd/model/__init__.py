@@ -51,7 +51,7 @@ def _load_safetensors_dir(path, device):
 
 
 @register_model("qwen3-tts", "Qwen/Qwen3-TTS-12Hz-1.7B-CustomVoice", "qwen3-tts-voice-design",
-                "Qwen/Qwen3-TTS-12Hz-1.7B-VoiceDesign")
+                "Qwen/Qwen3-TTS-12Hz-1.7B-VoiceDesign", "qwen3-tts-base", "Qwen/Qwen3-TTS-12Hz-1.7B-Base")
 def _qwen3(model_name, device="cuda:0", weights=None, codec_weights=None, checkpoint_dir=None, codec_checkpoint_dir=None,
            synthetic=False, **kw):
     from .qwen3_tts import Qwen3TTSModel
@@ -66,7 +66,20 @@ def _qwen3(model_name, device="cuda:0", weights=None, codec_weights=None, checkp
             weights = _load_safetensors_dir(checkpoint_dir, device)
             codec_weights = {k.removeprefix("decoder."): v for k, v in
                              _load_safetensors_dir(codec_checkpoint_dir or checkpoint_dir, "cpu").items()}
-    mtype = "voice_design" if "design" in model_name.lower() else "custom_voice"
+    name = model_name.lower()
+    mtype = "voice_design" if "design" in name else ("base" if name.endswith("base") else "custom_voice")
+    if mtype == "base" and "speaker_encoder_weights" not in kw:
+        # voice cloning: the speaker encoder ships inside the LM checkpoint (speaker_encoder.*), the codec encoder inside the speech
+        # tokenizer's (encoder.*)
+        if synthetic or checkpoint_dir is None:
+            from ..synth import synth_qwen3_codec_encoder_weights, synth_qwen3_speaker_encoder_weights
+            kw["speaker_encoder_weights"] = synth_qwen3_speaker_encoder_weights()
+            kw["audio_encoder_weights"] = synth_qwen3_codec_encoder_weights()
+        else:
+            spk = {k.removeprefix("speaker_encoder."): v for k, v in weights.items() if k.startswith("speaker_encoder.")}
+            enc = {k.removeprefix("encoder."): v for k, v in
+                   _load_safetensors_dir(codec_checkpoint_dir or checkpoint_dir, "cpu").items() if k.startswith("encoder.")}
+            kw["speaker_encoder_weights"], kw["audio_encoder_weights"] = spk or None, enc or None
     return Qwen3TTSModel(model_name, weights, codec_weights, device=device, tts_model_type=mtype, **kw)
 
 

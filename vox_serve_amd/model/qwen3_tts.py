@@ -42,12 +42,16 @@ class Qwen3TTSModel(BaseLMWithDepth):
                  config: Optional[Qwen3Cfg] = None, codec_config: Optional[Qwen3CodecConfig] = None,
                  tokens: Optional[Qwen3TTSTokens] = None, text_tokenizer=None, dtype=torch.bfloat16, device="cuda:0",
                  audio_decoder_device=None, detokenize_interval=None, tts_model_type="custom_voice", max_batch_size=8,
-                 page_size=128, max_num_pages=2048, max_seq_len=2304, max_prefill_tokens=1024):
+                 page_size=128, max_num_pages=2048, max_seq_len=2304, max_prefill_tokens=1024, tts_model_size="1b7",
+                 speaker_encoder_weights: Optional[Dict[str, torch.Tensor]] = None, speaker_encoder_config=None,
+                 audio_encoder_weights: Optional[Dict[str, torch.Tensor]] = None, audio_encoder_config=None,
+                 max_reference_seconds: float = 30.0):
         super().__init__(model_name, device, dtype, False, audio_decoder_device)
         self._detokenize_interval = detokenize_interval if detokenize_interval is not None else 10
         self.config = config or Qwen3Cfg()
         self.tokens = tokens or Qwen3TTSTokens(tts_pad=self.config.tts_pad_id, codec_eos=self.config.eos_id)
         self.tts_model_type = tts_model_type
+        self.tts_model_size = tts_model_size
         self.text_tokenizer = text_tokenizer
         self.stop_token_id = self.config.eos_id
         self.suppress_tokens = [i for i in range(self.config.vocab - 1024, self.config.vocab) if i != self.config.eos_id]
@@ -59,6 +63,19 @@ class Qwen3TTSModel(BaseLMWithDepth):
         self.audio_decoder = Qwen3TTSDecoder(codec_weights, codec_config, device=self.audio_decoder_device,
                                              max_batch=max_batch_size, max_slots=max(64, 2 * max_batch_size),
                                              detokenize_interval=self._detokenize_interval)
+        # prompt-side encoders of the "base" (voice clone) checkpoints: speaker_encoder.* of the LM checkpoint (qwen3_tts.py:897-901)
+        # and the encoder half of the speech tokenizer (qwen3_codec.py:1681-1741)
+        self.speaker_encoder = self.audio_encoder = None
+        if speaker_encoder_weights is not None:
+            from .qwen3_tts_speaker import Qwen3TTSSpeakerEncoder
+            self.speaker_encoder = Qwen3TTSSpeakerEncoder(speaker_encoder_weights, speaker_encoder_config, device=device,
+                                                          max_seconds=max_reference_seconds)
+            if self.speaker_encoder.cfg.enc_dim != self.config.talker.hidden:
+                raise ValueError("speaker encoder enc_dim must equal the talker hidden size")
+        if audio_encoder_weights is not None:
+            from ..tokenizer.qwen3_codec_encoder import Qwen3TTSTokenizerV2Encoder
+            self.audio_encoder = Qwen3TTSTokenizerV2Encoder(audio_encoder_weights, audio_encoder_config, device=self.audio_decoder_device,
+                                                            max_seconds=max_reference_seconds)
 
     # ---- properties (qwen3_tts.py:1098-1240) ----
     n_codebooks = property(lambda self: self.config.n_groups + 1)
@@ -209,7 +226,7 @@ class Qwen3TTSModel(BaseLMWithDepth):
         language = "auto" if language is None else language
         if language.lower() != "auto" and language.lower() not in self.tokens.codec_language_id:
             language = "auto"
-        if instruct == "":
+        if instruct == "" or self.tts_model_size == "0b6":        # the 0.6B checkpoints take no instruct (qwen3_tts.py:1463-1466)
             instruct = None
         if prompt_token_ids is None:
             if self.text_tokenizer is None:
@@ -281,14 +298,14 @@ class Qwen3TTSModel(BaseLMWithDepth):
             raise NotImplementedError("no speaker encoder weights loaded: pass speaker_embedding=")
         if sr != 24000:
             raise ValueError("the speaker encoder takes 24 kHz audio (qwen3_tts.py:1299); resample the reference clip")
-        return self.speaker_encoder(torch.as_tensor(audio, dtype=torch.float32))
+        return self.speaker_encoder(torch.as_tensor(audio, dtype=torch.float32)).to(self.dtype)      # the reference's encoder output dtype
 
     def _encode_audio_to_codes(self, audio, sr: int) -> torch.Tensor:
         if getattr(self, "audio_encoder", None) is None:
             raise NotImplementedError("no codec encoder weights loaded: pass ref_codes=")
         if sr != 24000:
             raise ValueError("the codec encoder takes 24 kHz audio (qwen3_tts.py:1350-1357); resample the reference clip")
-        return self.audio_encoder(torch.as_tensor(audio, dtype=torch.float32))
+        return self.audio_encoder(torch.as_tensor(audio, dtype=torch.float32)).to(self.device)
 
     def postprocess(self, token_ids: torch.Tensor, decoder_cache: Optional[Qwen3TTSDecoderCache] = None, **kwargs):
         """token_ids [B, interval, n_codebooks] (last column = text token, dropped) -> audio [B,1,interval*1920]

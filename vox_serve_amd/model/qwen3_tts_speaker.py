@@ -62,6 +62,30 @@ def _bind(L):
     L._spk_bound = True
 
 
+def param_shapes(c: Qwen3TTSSpeakerEncoderConfig) -> Dict[str, tuple]:
+    """state_dict names and shapes of Qwen3TTSSpeakerEncoder (qwen3_tts.py:835-878)."""
+    S: Dict[str, tuple] = {}
+
+    def conv(name, cout, cin, k):
+        S[name + ".weight"], S[name + ".bias"] = (cout, cin, k), (cout,)
+
+    ch, ks = c.enc_channels, c.enc_kernel_sizes
+    conv("blocks.0.conv", ch[0], c.mel_dim, ks[0])
+    for i in range(1, len(ch) - 1):
+        p = f"blocks.{i}"
+        conv(p + ".tdnn1.conv", ch[i], ch[i - 1], 1)
+        for j in range(c.enc_res2net_scale - 1):
+            conv(f"{p}.res2net_block.blocks.{j}.conv", ch[i] // c.enc_res2net_scale, ch[i] // c.enc_res2net_scale, ks[i])
+        conv(p + ".tdnn2.conv", ch[i], ch[i], 1)
+        conv(p + ".se_block.conv1", c.enc_se_channels, ch[i], 1)
+        conv(p + ".se_block.conv2", ch[i], c.enc_se_channels, 1)
+    conv("mfa.conv", ch[-1], ch[-1], ks[-1])
+    conv("asp.tdnn.conv", c.enc_attention_channels, ch[-1] * 3, 1)
+    conv("asp.conv", ch[-1], c.enc_attention_channels, 1)
+    conv("fc", c.enc_dim, ch[-1] * 2, 1)
+    return S
+
+
 def slaney_mel_filterbank(sr: int, n_fft: int, n_mels: int, fmin: float, fmax: float) -> np.ndarray:
     """librosa.filters.mel(sr=, n_fft=, n_mels=, fmin=, fmax=) with its defaults (htk=False, norm="slaney"): [n_mels, n_fft/2+1] float32."""
     f_sp, min_log_hz = 200.0 / 3, 1000.0

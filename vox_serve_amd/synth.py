@@ -482,3 +482,38 @@ def synth_glm_codec_weights(flow_cfg=None, hift_cfg=None, seed=0):
     H = {k.replace(".parametrizations.weight.original0", ".weight_g").replace(".parametrizations.weight.original1", ".weight_v"): v
          for k, v in cw["hift"].items()}
     return {"flow": F, "hift": H}
+
+
+def _fan_in_weights(shapes, seed, gain):
+    """Random-init conv / linear stacks: bf16-representable fp32 values, N(0, gain^2 / fan_in); small biases; unit norms."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    for k, s in shapes.items():
+        if k.endswith("cluster_usage"):
+            t = 1.0 + torch.rand(s, generator=g)
+        elif k.endswith("embed_sum"):
+            t = torch.randn(s, generator=g)
+        elif k.endswith("layernorm.weight"):
+            t = 1.0 + 0.1 * torch.randn(s, generator=g)
+        elif k.endswith(".scale"):
+            t = torch.full(s, 0.3)
+        elif k.endswith(".bias"):
+            t = 0.05 * torch.randn(s, generator=g)
+        else:
+            fan = s[1] * (s[2] if len(s) == 3 else 1)
+            t = torch.randn(s, generator=g) * (gain / math.sqrt(fan))
+        W[k] = t.to(torch.bfloat16).float() if t.dim() > 1 and not k.endswith("embed_sum") else t.float()
+    return W
+
+
+def synth_qwen3_speaker_encoder_weights(cfg=None, seed=0):
+    """Random-init ECAPA speaker encoder weights under the reference state_dict names (model/qwen3_tts_speaker.py)."""
+    from .model.qwen3_tts_speaker import Qwen3TTSSpeakerEncoderConfig, param_shapes
+    return _fan_in_weights(param_shapes(cfg or Qwen3TTSSpeakerEncoderConfig()), seed, 1.2)
+
+
+def synth_qwen3_codec_encoder_weights(cfg=None, seed=0):
+    """Random-init speech-tokenizer encoder weights under the MimiModel state_dict names (tokenizer/qwen3_codec_encoder.py)."""
+    from .tokenizer.qwen3_codec_encoder import Qwen3TTSTokenizerV2EncoderConfig, param_shapes
+    return _fan_in_weights(param_shapes(cfg or Qwen3TTSTokenizerV2EncoderConfig()), seed, 1.4)
