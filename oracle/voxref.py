@@ -56,11 +56,12 @@ def i32(a):
 # ---- bf16 helpers (numpy only) -------------------------------------------------------------------
 def f2bf(x):
     """fp32 ndarray -> bf16 bits (uint16), round-to-nearest-even."""
-    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
-    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    # uint32 arithmetic: the rounding add can only wrap for NaN patterns, which are replaced below
+    r = ((u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))) >> np.uint32(16)).astype(np.uint16)
+    nan = (u & np.uint32(0x7FFFFFFF)) > np.uint32(0x7F800000)
     if nan.any():
-        r = np.where(nan, ((u >> 16) | 0x40).astype(np.uint16), r)
+        r = np.where(nan, ((u >> np.uint32(16)) | np.uint32(0x40)).astype(np.uint16), r)
     return r
 
 

@@ -11,7 +11,28 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _cpu_budget() -> int:
+    """CPUs this process may really use: affinity mask and cgroup quota, capped at 64.  The oracles are OpenMP / torch-CPU code; on a
+    shared box the default (one thread per logical CPU of the host) oversubscribes the container's share and runs many times slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_budget()))
+
+
 def pytest_configure(config):
+    try:
+        import torch
+        torch.set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: CPU test taking tens of seconds")
 

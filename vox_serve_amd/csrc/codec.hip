@@ -68,6 +68,9 @@ struct ConvGemmArgs {
     float* out2;
     const float *sn_alpha, *sn_invb;
     int sn_mod;
+    // LayerNorm of the input rows fused into the A-operand staging (few-row kernel, one tap): x <- (x - mean) * rstd * ln_w + ln_b
+    const float *ln_w, *ln_b;
+    float ln_eps;
 };
 // sin for the fused epilogues: explicit reduction to revolutions + the hardware v_sin_f32 (absolute error ~1e-6 on [-1, 1]:
 // far inside the 1e-4 waveform bar, and sin^2 enters scaled by 1/beta ~ 1).  The libm sinf (argument-reduction table,
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
 // Few-row variant (M <= 48: the transformer and the first upsampling stages of a single request's chunk): tile
 // 16(M) x 64(N), one n-tile per wave, K walked in BK-wide chunks (128 where Cin allows) with the same one-step
 // register prefetch.  These stages run a handful of blocks: time = number of dependent K steps, so the steps are wide.
-template <int BK>
+template <int BK, bool LN = false>
 __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
     constexpr int LD = BK + 8;                      // bf16 elements
     constexpr int NA = (16 * BK / 4 + 255) / 256;   // float4 per thread (activations)
@@ -246,13 +249,43 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
         }
     };
     fetch(0);
+    __shared__ float ln_stat[LN ? 32 : 1];
+    if (LN) {      // row statistics of the block's 16 rows (two passes, 16 lanes per row), while the first operands are in flight
+        const int r = tid >> 4, l16 = tid & 15, am = m0 + r;
+        float mean = 0.0f, rstd = 0.0f;
+        if (am < a.M) {
+            const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)am * a.Cin);
+            float sm = 0.0f;
+            for (int c = l16; c < a.Cin / 4; c += 16) { const float4 v = xr[c]; sm += (v.x + v.y) + (v.z + v.w); }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) sm += __shfl_xor(sm, off, 64);
+            mean = sm / (float)a.Cin;
+            float vs = 0.0f;
+            for (int c = l16; c < a.Cin / 4; c += 16) {
+                const float4 v = xr[c];
+                const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+                vs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) vs += __shfl_xor(vs, off, 64);
+            rstd = rsqrtf(vs / (float)a.Cin + a.ln_eps);
+        }
+        if (l16 == 0) { ln_stat[2 * r] = mean; ln_stat[2 * r + 1] = rstd; }
+    }
     for (int it = 0; it < nit; ++it) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int idx = tid + 256 * i;
             if (idx < 16 * SEGA) {      // 4 fp32 -> 4 bf16 per plane (8 bytes)
-                const float x4[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+                float x4[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+                if (LN) {
+                    const int r = idx / SEGA, c = (it % nck) * BK + (idx % SEGA) * 4;
+                    const float mean = ln_stat[2 * r], rstd = ln_stat[2 * r + 1];
+                    const float4 w4 = *reinterpret_cast<const float4*>(a.ln_w + c), b4 = *reinterpret_cast<const float4*>(a.ln_b + c);
+                    x4[0] = (x4[0] - mean) * rstd * w4.x + b4.x; x4[1] = (x4[1] - mean) * rstd * w4.y + b4.y;
+                    x4[2] = (x4[2] - mean) * rstd * w4.z + b4.z; x4[3] = (x4[3] - mean) * rstd * w4.w + b4.w;
+                }
                 unsigned short hb[4], mb[4], lb[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -551,9 +584,16 @@ static thread_local int g_conv_planes = 3;
 // rows up to which the few-row GEMM variant (16-row tiles, wide K steps) is used: the flow's GEMMs have 56..450 rows and K <= 2048, their
 // time is the number of dependent K steps, not MFMA issue
 static thread_local int g_conv_skinny_rows = 48;
+// few-row GEMMs walk K in 256-wide steps where Cin allows (half the dependent steps of the 128-wide walk; same accumulation order, so
+// the results are bit-identical).  VOX_SKINNY_BK256=0 keeps the 128-wide walk (A/B timing).
+static bool skinny_wide() {
+    static const bool on = [] { const char* e = getenv("VOX_SKINNY_BK256"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const float* state, const int* slots, int n,
                      int L, int P, const int* offs, float* out, const float* res, const float* scale, int gelu,
-                     float* out2 = nullptr, const vox_snake_w* sn = nullptr, int sn_mod = 0, const float* rscale = nullptr) {
+                     float* out2 = nullptr, const vox_snake_w* sn = nullptr, int sn_mod = 0, const float* rscale = nullptr,
+                     const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 0.0f) {
     if (w.cin % CG_BK) return vox_fail(VOX_ERR_INVALID, "codec gemm: Cin %d %% %d != 0", w.cin, CG_BK);
     if (w.n_taps > CG_MAXTAPS) return vox_fail(VOX_ERR_INVALID, "codec gemm: too many taps");
     ConvGemmArgs a{};
@@ -563,9 +603,21 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     a.bias_mod = w.bias_mod > 0 ? w.bias_mod : w.n; a.gelu = gelu;
     if (out2 && sn) { a.out2 = out2; a.sn_alpha = sn->alpha; a.sn_invb = sn->inv_beta; a.sn_mod = sn_mod > 0 ? sn_mod : w.n; }
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
+    if (ln_w) {      // fused input LayerNorm: few-row kernel, one plain tap, the row statistics need the whole row in one K walk
+        if (a.M > g_conv_skinny_rows || a.planes * 0 + w.n_taps != 1 || a.off[0] != 0)
+            return vox_fail(VOX_ERR_INVALID, "codec gemm: fused LayerNorm needs the few-row one-tap path");
+        a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps;
+        const dim3 g((w.n + 63) / 64, (a.M + 15) / 16);
+        if (w.cin % 256 == 0 && skinny_wide()) hipLaunchKernelGGL((k_conv_gemm_skinny<256, true>), g, dim3(256), 0, st, a);
+        else if (w.cin % 128 == 0) hipLaunchKernelGGL((k_conv_gemm_skinny<128, true>), g, dim3(256), 0, st, a);
+        else if (w.cin % 64 == 0) hipLaunchKernelGGL((k_conv_gemm_skinny<64, true>), g, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_conv_gemm_skinny<32, true>), g, dim3(256), 0, st, a);
+        return VOX_OK;
+    }
     if (a.M <= g_conv_skinny_rows) {
         const dim3 g((w.n + 63) / 64, (a.M + 15) / 16);
-        if (w.cin % 128 == 0) hipLaunchKernelGGL(k_conv_gemm_skinny<128>, g, dim3(256), 0, st, a);
+        if (w.cin % 256 == 0 && skinny_wide()) hipLaunchKernelGGL(k_conv_gemm_skinny<256>, g, dim3(256), 0, st, a);
+        else if (w.cin % 128 == 0) hipLaunchKernelGGL(k_conv_gemm_skinny<128>, g, dim3(256), 0, st, a);
         else if (w.cin % 64 == 0) hipLaunchKernelGGL(k_conv_gemm_skinny<64>, g, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_conv_gemm_skinny<32>, g, dim3(256), 0, st, a);
         return VOX_OK;
@@ -1947,28 +1999,45 @@ __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
     __builtin_amdgcn_wave_barrier();
     const float inv = 1.0f / sum;
-    // PV: lane = output dim; four independent partial sums over interleaved keys (the loads of a group are in flight together)
-    for (int d = lane; d < a.dk; d += 64) {
-        float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;
-        const float* vc = cache ? cache + a.dk + d : nullptr;
-        const float* vn = a.qkv + (size_t)n * a.T * ld + 2 * HD + h * a.dk + d;
-        int j = 0;
-        for (; j + 4 <= a.Tc; j += 4) {
-            o0 = fmaf(ps[wave][j], vc[(size_t)j * 2 * a.dk], o0);
-            o1 = fmaf(ps[wave][j + 1], vc[(size_t)(j + 1) * 2 * a.dk], o1);
-            o2 = fmaf(ps[wave][j + 2], vc[(size_t)(j + 2) * 2 * a.dk], o2);
-            o3 = fmaf(ps[wave][j + 3], vc[(size_t)(j + 3) * 2 * a.dk], o3);
+    // PV: lane = (key group g = lane / 16, float4 chunk c = lane % 16 of the output dims); a pass reads four whole V rows (coalesced
+    // 256-byte segments), four passes are in flight together; the four key groups are summed by two butterfly steps at the end.
+    // (chunk c covers dims 4c .. 4c+3 of each 64-dim slab; lanes past dk idle)
+    for (int c4 = (lane & 15) * 4, slab = 0; slab < a.dk; slab += 64, c4 += 64) {
+        const int g = lane >> 4;
+        const bool on = c4 < a.dk;
+        float4 o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* vc = cache ? cache + a.dk + c4 : nullptr;
+        const float* vn = a.qkv + (size_t)n * a.T * ld + 2 * HD + h * a.dk + c4;
+        auto vrow = [&](int j) { return reinterpret_cast<const float4*>(j < a.Tc ? vc + (size_t)j * 2 * a.dk : vn + (size_t)(j - a.Tc) * ld); };
+        int j = g;
+        if (on) {
+            for (; j + 12 < S; j += 16) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *vrow(j + 4 * u);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float p = ps[wave][j + 4 * u];
+                    o[u].x = fmaf(p, v[u].x, o[u].x); o[u].y = fmaf(p, v[u].y, o[u].y);
+                    o[u].z = fmaf(p, v[u].z, o[u].z); o[u].w = fmaf(p, v[u].w, o[u].w);
+                }
+            }
+            for (; j < S; j += 4) {
+                const float4 v = *vrow(j);
+                const float p = ps[wave][j];
+                o[0].x = fmaf(p, v.x, o[0].x); o[0].y = fmaf(p, v.y, o[0].y); o[0].z = fmaf(p, v.z, o[0].z); o[0].w = fmaf(p, v.w, o[0].w);
+            }
         }
-        for (; j < a.Tc; ++j) o0 = fmaf(ps[wave][j], vc[(size_t)j * 2 * a.dk], o0);
-        int t = 0;
-        for (; t + 4 <= a.T; t += 4) {
-            o0 = fmaf(ps[wave][a.Tc + t], vn[(size_t)t * ld], o0);
-            o1 = fmaf(ps[wave][a.Tc + t + 1], vn[(size_t)(t + 1) * ld], o1);
-            o2 = fmaf(ps[wave][a.Tc + t + 2], vn[(size_t)(t + 2) * ld], o2);
-            o3 = fmaf(ps[wave][a.Tc + t + 3], vn[(size_t)(t + 3) * ld], o3);
+        float4 r = make_float4((o[0].x + o[1].x) + (o[2].x + o[3].x), (o[0].y + o[1].y) + (o[2].y + o[3].y),
+                               (o[0].z + o[1].z) + (o[2].z + o[3].z), (o[0].w + o[1].w) + (o[2].w + o[3].w));
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            r.x += __shfl_xor(r.x, off, 64); r.y += __shfl_xor(r.y, off, 64); r.z += __shfl_xor(r.z, off, 64); r.w += __shfl_xor(r.w, off, 64);
         }
-        for (; t < a.T; ++t) o0 = fmaf(ps[wave][a.Tc + t], vn[(size_t)t * ld], o0);
-        a.out[((size_t)n * a.T + i) * HD + h * a.dk + d] = ((o0 + o1) + (o2 + o3)) * inv;
+        if (on && g == 0)
+            *reinterpret_cast<float4*>(a.out + ((size_t)n * a.T + i) * HD + h * a.dk + c4) = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
     }
 }
 // new K | V rows of request n -> cache [half = n][H][Tcap][2 dk], keeping the first `prefix` and the last Tcap - prefix of the T rows
@@ -2121,14 +2190,22 @@ static const int FLOW_OFF_C5[5] = {4, 3, 2, 1, 0};      // causal k5 (Upsample1D
 static const int FLOW_OFF_LA[8] = {0, -1, -2, -3, -4, -5, -6, -7};   // look-ahead k (PreLookaheadLayer.conv1)
 
 // one conformer layer (norm_mha -> rel-pos attention -> residual; norm_ff -> SiLU FFN -> residual) on x [n * T][D] in place
+// LayerNorm(w, b, eps) followed by a one-tap GEMM of the normalised rows.  Calls that take the few-row GEMM normalise inside its operand
+// staging (one launch less per attention / feed-forward half); larger batches normalise into `scratch` first.
+static int ln_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const float* lw, const float* lb, float eps, float* scratch, int n, int L,
+                   float* out, int gelu) {
+    if (n * L <= g_conv_skinny_rows && w.n_taps == 1)
+        return conv_gemm(st, w, x, nullptr, nullptr, n, L, 0, FLOW_OFF0, out, nullptr, nullptr, gelu, nullptr, nullptr, 0, nullptr, lw, lb, eps);
+    hipLaunchKernelGGL(k_flow_ln, dim3(n * L), dim3(256), 0, st, x, lw, lb, scratch, w.cin, eps, 1.0f, 0, (const float*)nullptr, 1);
+    return conv_gemm(st, w, scratch, nullptr, nullptr, n, L, 0, FLOW_OFF0, out, nullptr, nullptr, gelu);
+}
 static int flow_conformer(vox_flow* m, hipStream_t st, const vox_flow_conformer_w& w, float* x, int n, int T, const float* cache, int Tc, int Tcap,
                           float* store_cache, int store_cap, int store_prefix, float** B) {
     const vox_flow_config& c = m->cfg;
     const int D = c.dim, H = c.enc_heads, dk = D / H, S = Tc + T;
     if (S > FLOW_MAXKEYS) return vox_fail(VOX_ERR_INVALID, "flow: %d keys > %d", S, FLOW_MAXKEYS);
     float *nrm = B[0], *qkv = B[1], *att = B[2];
-    hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, w.ln_mha_w, w.ln_mha_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1);
-    VOX_TRY(conv_gemm(st, w.qkv, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
+    VOX_TRY(ln_gemm(st, w.qkv, x, w.ln_mha_w, w.ln_mha_b, 1e-12f, nrm, n, T, qkv, 0));
     VOX_TRY(conv_gemm(st, w.pos, m->pe, nullptr, nullptr, 1, 2 * S - 1, 0, FLOW_OFF0, m->pp, nullptr, nullptr, 0));
     FlowAttn a{qkv, cache, m->pp, w.bias_u, w.bias_v, att, T, H, dk, Tc, Tcap, 0, 0, 1.0f / sqrtf((float)dk)};
     hipLaunchKernelGGL(k_flow_attn, dim3((T + 3) / 4, H, n), dim3(256), 0, st, a);
@@ -2136,8 +2213,7 @@ static int flow_conformer(vox_flow* m, hipStream_t st, const vox_flow_conformer_
         hipLaunchKernelGGL(k_flow_cache_store, dim3(ew_grid((size_t)H * store_cap * 2 * dk)), dim3(256), 0, st, qkv, store_cache, T, H, dk, store_cap,
                            store_prefix, (size_t)0, 1);
     VOX_TRY(conv_gemm(st, w.out, att, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
-    hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, w.ln_ff_w, w.ln_ff_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1);
-    VOX_TRY(conv_gemm(st, w.w1, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
+    VOX_TRY(ln_gemm(st, w.w1, x, w.ln_ff_w, w.ln_ff_b, 1e-12f, nrm, n, T, qkv, 0));
     hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)n * T * c.enc_ffn)), dim3(256), 0, st, qkv, (size_t)n * T * c.enc_ffn, 2);
     VOX_TRY(conv_gemm(st, w.w2, qkv, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
     return VOX_OK;
@@ -2225,16 +2301,14 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
             for (int j = 0; j < c.est_blocks; ++j, ++li) {
                 const vox_flow_tblock_w& tw = m->tblocks[li];
                 float* kv = m->att_kv + ((size_t)s * m->n_att + li) * att_layer;
-                hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, h, tw.ln1_w, tw.ln1_b, a1, C, 1e-5f, 1.0f, 0, nullptr, 1);
-                VOX_TRY(conv_gemm(st, tw.qkv, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF0, a2, nullptr, nullptr, 0));
+                VOX_TRY(ln_gemm(st, tw.qkv, h, tw.ln1_w, tw.ln1_b, 1e-5f, a1, N, T2, a2, 0));
                 FlowAttn a{a2, init ? nullptr : kv, nullptr, nullptr, nullptr, a3, T2, HE, hd, Tc, capA, B, att_half, 1.0f / sqrtf((float)hd)};
                 hipLaunchKernelGGL(k_flow_attn, dim3((T2 + 3) / 4, HE, N), dim3(256), 0, st, a);
                 if (init)
                     hipLaunchKernelGGL(k_flow_cache_store, dim3(ew_grid((size_t)N * HE * capA * 2 * hd)), dim3(256), 0, st, a2, kv, T2, HE, hd, capA,
                                        c.prefix, att_half, N);
                 VOX_TRY(conv_gemm(st, tw.out, a3, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, h, nullptr, 0));
-                hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, h, tw.ln3_w, tw.ln3_b, a1, C, 1e-5f, 1.0f, 0, nullptr, 1);
-                VOX_TRY(conv_gemm(st, tw.ff1, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF0, a2, nullptr, nullptr, 1));
+                VOX_TRY(ln_gemm(st, tw.ff1, h, tw.ln3_w, tw.ln3_b, 1e-5f, a1, N, T2, a2, 1));
                 VOX_TRY(conv_gemm(st, tw.ff2, a2, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, h, nullptr, 0));
             }
             in = h;
@@ -2591,13 +2665,11 @@ int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int 
     auto tblocks = [&](float* h, int rows_T, int& li, float* a1, float* a2, float* a3) -> int {
         for (int j = 0; j < c.est_blocks; ++j, ++li) {
             const vox_flow_tblock_w& tw = m->tblocks[li];
-            hipLaunchKernelGGL(k_flow_ln, dim3(N * rows_T), dim3(256), 0, st, h, tw.ln1_w, tw.ln1_b, a1, C, 1e-5f, 1.0f, 0, nullptr, 1);
-            VOX_TRY(conv_gemm(st, tw.qkv, a1, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, a2, nullptr, nullptr, 0));
+            VOX_TRY(ln_gemm(st, tw.qkv, h, tw.ln1_w, tw.ln1_b, 1e-5f, a1, N, rows_T, a2, 0));
             FlowAttn a{a2, nullptr, nullptr, nullptr, nullptr, a3, rows_T, HE, hd, 0, 0, 0, 0, 1.0f / sqrtf((float)hd), 0};
             hipLaunchKernelGGL(k_flow_attn, dim3((rows_T + 3) / 4, HE, N), dim3(256), 0, st, a);
             VOX_TRY(conv_gemm(st, tw.out, a3, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, h, h, nullptr, 0));
-            hipLaunchKernelGGL(k_flow_ln, dim3(N * rows_T), dim3(256), 0, st, h, tw.ln3_w, tw.ln3_b, a1, C, 1e-5f, 1.0f, 0, nullptr, 1);
-            VOX_TRY(conv_gemm(st, tw.ff1, a1, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, a2, nullptr, nullptr, 1));
+            VOX_TRY(ln_gemm(st, tw.ff1, h, tw.ln3_w, tw.ln3_b, 1e-5f, a1, N, rows_T, a2, 1));
             VOX_TRY(conv_gemm(st, tw.ff2, a2, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, h, h, nullptr, 0));
         }
         return VOX_OK;
