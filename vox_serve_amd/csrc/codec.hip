@@ -207,6 +207,27 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
         }
 }
 
+// LayerNorm row statistics by the 16 lanes l16 = 0..15 of a row group (two passes over float4 chunks, butterfly inside the group).
+// Shared by the GEMM with the fused LayerNorm and by k_flow_ln, so a row normalises to the same bits on either path (a request's output
+// must not depend on how many requests share its batch).
+__device__ __forceinline__ void ln_row_stats(const float* row, int C, int l16, float eps, float& mean, float& rstd) {
+    const float4* xr = reinterpret_cast<const float4*>(row);
+    float sm = 0.0f;
+    for (int c = l16; c < C / 4; c += 16) { const float4 v = xr[c]; sm += (v.x + v.y) + (v.z + v.w); }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) sm += __shfl_xor(sm, off, 64);
+    mean = sm / (float)C;
+    float vs = 0.0f;
+    for (int c = l16; c < C / 4; c += 16) {
+        const float4 v = xr[c];
+        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        vs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) vs += __shfl_xor(vs, off, 64);
+    rstd = rsqrtf(vs / (float)C + eps);
+}
+
 // Few-row variant (M <= 48: the transformer and the first upsampling stages of a single request's chunk): tile
 // 16(M) x 64(N), one n-tile per wave, K walked in BK-wide chunks (128 where Cin allows) with the same one-step
 // register prefetch.  These stages run a handful of blocks: time = number of dependent K steps, so the steps are wide.
@@ -253,23 +274,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
     if (LN) {      // row statistics of the block's 16 rows (two passes, 16 lanes per row), while the first operands are in flight
         const int r = tid >> 4, l16 = tid & 15, am = m0 + r;
         float mean = 0.0f, rstd = 0.0f;
-        if (am < a.M) {
-            const float4* xr = reinterpret_cast<const float4*>(a.x + (size_t)am * a.Cin);
-            float sm = 0.0f;
-            for (int c = l16; c < a.Cin / 4; c += 16) { const float4 v = xr[c]; sm += (v.x + v.y) + (v.z + v.w); }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) sm += __shfl_xor(sm, off, 64);
-            mean = sm / (float)a.Cin;
-            float vs = 0.0f;
-            for (int c = l16; c < a.Cin / 4; c += 16) {
-                const float4 v = xr[c];
-                const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-                vs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-            }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) vs += __shfl_xor(vs, off, 64);
-            rstd = rsqrtf(vs / (float)a.Cin + a.ln_eps);
-        }
+        if (am < a.M) ln_row_stats(a.x + (size_t)am * a.Cin, a.Cin, l16, a.ln_eps, mean, rstd);
         if (l16 == 0) { ln_stat[2 * r] = mean; ln_stat[2 * r + 1] = rstd; }
     }
     for (int it = 0; it < nit; ++it) {
@@ -1884,28 +1889,19 @@ __global__ __launch_bounds__(256) void k_flow_embed(const int* ids, const float*
 }
 // y = act(LayerNorm(x) * w + b) * post + add[row / rows_per_req]      (act 0 none, 1 Mish)
 __global__ __launch_bounds__(256) void k_flow_ln(const float* x, const float* w, const float* b, float* y, int C, float eps, float post, int act,
-                                                  const float* add, int rows_per_req) {
-    __shared__ float red[8];
-    const float* xr = x + (size_t)blockIdx.x * C;
-    float s = 0.0f;
-    for (int i = threadIdx.x; i < C; i += 256) s += xr[i];
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
-    float v = 0.0f;
-    for (int i = threadIdx.x; i < C; i += 256) { const float d = xr[i] - mean; v += d * d; }
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = v;
-    __syncthreads();
-    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + eps);
-    const float* ad = add ? add + (size_t)(blockIdx.x / rows_per_req) * C : nullptr;
-    for (int i = threadIdx.x; i < C; i += 256) {
+                                                  const float* add, int rows_per_req, int rows) {
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;      // 16 rows per block, 16 lanes per row
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float mean, rstd;
+    ln_row_stats(xr, C, l16, eps, mean, rstd);
+    const float* ad = add ? add + (size_t)(row / rows_per_req) * C : nullptr;
+    for (int i = l16; i < C; i += 16) {
         float o = (xr[i] - mean) * rstd * w[i] + b[i];
         if (act == 1) o = mish_f(o);
         o *= post;
         if (ad) o += ad[i];
-        y[(size_t)blockIdx.x * C + i] = o;
+        y[(size_t)row * C + i] = o;
     }
 }
 // in-place activation: 1 Mish, 2 SiLU, 3 leaky_relu(0.01)
@@ -2196,7 +2192,7 @@ static int ln_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const fl
                    float* out, int gelu) {
     if (n * L <= g_conv_skinny_rows && w.n_taps == 1)
         return conv_gemm(st, w, x, nullptr, nullptr, n, L, 0, FLOW_OFF0, out, nullptr, nullptr, gelu, nullptr, nullptr, 0, nullptr, lw, lb, eps);
-    hipLaunchKernelGGL(k_flow_ln, dim3(n * L), dim3(256), 0, st, x, lw, lb, scratch, w.cin, eps, 1.0f, 0, (const float*)nullptr, 1);
+    hipLaunchKernelGGL(k_flow_ln, dim3((n * L + 15) / 16), dim3(256), 0, st, x, lw, lb, scratch, w.cin, eps, 1.0f, 0, (const float*)nullptr, 1, n * L);
     return conv_gemm(st, w, scratch, nullptr, nullptr, n, L, 0, FLOW_OFF0, out, nullptr, nullptr, gelu);
 }
 static int flow_conformer(vox_flow* m, hipStream_t st, const vox_flow_conformer_w& w, float* x, int n, int T, const float* cache, int Tc, int Tcap,
@@ -2232,7 +2228,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
     float* x = Bf[3];
     hipLaunchKernelGGL(k_flow_embed, dim3(ew_grid((size_t)B * T * D)), dim3(256), 0, st, tokens, w.embedding, Bf[0], (size_t)B * T, D);
     VOX_TRY(conv_gemm(st, w.embed_lin, Bf[0], nullptr, nullptr, B, T, 0, FLOW_OFF0, Bf[1], nullptr, nullptr, 0));
-    hipLaunchKernelGGL(k_flow_ln, dim3(B * T), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1);
+    hipLaunchKernelGGL(k_flow_ln, dim3((B * T + 15) / 16), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, B * T);
     // PreLookaheadLayer (empty context): conv k(pre+1) looking ahead, leaky_relu, causal conv k3, residual
     VOX_TRY(conv_gemm(st, w.pre1, x, nullptr, nullptr, B, T, 0, FLOW_OFF_LA, Bf[0], nullptr, nullptr, 0));
     hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)B * T * D)), dim3(256), 0, st, Bf[0], (size_t)B * T * D, 3);
@@ -2250,7 +2246,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
     hipLaunchKernelGGL(k_flow_repeat2, dim3(ew_grid((size_t)B * T2 * D)), dim3(256), 0, st, x, Bf[0], (size_t)B * T, D);
     VOX_TRY(conv_gemm(st, w.up_conv, Bf[0], nullptr, nullptr, B, T2, 0, FLOW_OFF_C5, Bf[1], nullptr, nullptr, 0));
     VOX_TRY(conv_gemm(st, w.up_embed_lin, Bf[1], nullptr, nullptr, B, T2, 0, FLOW_OFF0, Bf[0], nullptr, nullptr, 0));
-    hipLaunchKernelGGL(k_flow_ln, dim3(B * T2), dim3(256), 0, st, Bf[0], w.up_embed_ln_w, w.up_embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1);
+    hipLaunchKernelGGL(k_flow_ln, dim3((B * T2 + 15) / 16), dim3(256), 0, st, Bf[0], w.up_embed_ln_w, w.up_embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, B * T2);
     {
         const int Tc = init ? 0 : m->up_len, S = Tc + T2, cap = c.max_cache;
         hipLaunchKernelGGL(k_flow_relpos, dim3(ew_grid((size_t)(2 * S - 1) * D)), dim3(256), 0, st, m->pe, S, D);
@@ -2260,7 +2256,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
         }
         if (init) m->up_len = T2 < cap ? T2 : cap;
     }
-    hipLaunchKernelGGL(k_flow_ln, dim3(B * T2), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1);
+    hipLaunchKernelGGL(k_flow_ln, dim3((B * T2 + 15) / 16), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1, B * T2);
     float* mu = Bf[8];
     VOX_TRY(conv_gemm(st, w.enc_proj, Bf[0], nullptr, nullptr, B, T2, 0, FLOW_OFF0, mu, nullptr, nullptr, 0));
     if (mu_out) (void)hipMemcpyAsync(mu_out, mu, (size_t)B * T2 * M * 4, hipMemcpyDeviceToDevice, st);
@@ -2292,11 +2288,11 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
             if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * cin)), dim3(256), 0, st, in, st1, N, T2, cin);
             // block1: (cached) causal conv k3 -> LayerNorm -> Mish, + the time projection; block2 likewise; + res_conv(x)
             VOX_TRY(conv_gemm(st, rw.conv1, in, init ? nullptr : st1, m->slots, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
-            hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, a1, rw.ln1_w, rw.ln1_b, a2, C, 1e-5f, 1.0f, 1,
-                               m->tb + ((size_t)s * m->n_res + r) * C, N * T2);
+            hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 15) / 16), dim3(256), 0, st, a1, rw.ln1_w, rw.ln1_b, a2, C, 1e-5f, 1.0f, 1,
+                               m->tb + ((size_t)s * m->n_res + r) * C, N * T2, N * T2);
             if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * C)), dim3(256), 0, st, a2, st2, N, T2, C);
             VOX_TRY(conv_gemm(st, rw.conv2, a2, init ? nullptr : st2, m->slots, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
-            hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, a1, rw.ln2_w, rw.ln2_b, a2, C, 1e-5f, 1.0f, 1, nullptr, 1);
+            hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 15) / 16), dim3(256), 0, st, a1, rw.ln2_w, rw.ln2_b, a2, C, 1e-5f, 1.0f, 1, nullptr, 1, N * T2);
             VOX_TRY(conv_gemm(st, rw.res, in, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, a2, nullptr, 0));       // h = block2 + res_conv(in)
             for (int j = 0; j < c.est_blocks; ++j, ++li) {
                 const vox_flow_tblock_w& tw = m->tblocks[li];
@@ -2321,7 +2317,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
         }
         VOX_TRY(conv_gemm(st, w.up_conv2, in, nullptr, nullptr, N, T2, 0, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
         VOX_TRY(conv_gemm(st, w.final_conv, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF_C3, a2, nullptr, nullptr, 0));
-        hipLaunchKernelGGL(k_flow_ln, dim3(N * T2), dim3(256), 0, st, a2, w.final_ln_w, w.final_ln_b, a1, C, 1e-5f, 1.0f, 1, nullptr, 1);
+        hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 15) / 16), dim3(256), 0, st, a2, w.final_ln_w, w.final_ln_b, a1, C, 1e-5f, 1.0f, 1, nullptr, 1, N * T2);
         VOX_TRY(conv_gemm(st, w.final_proj, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF0, a2, nullptr, nullptr, 0));
         hipLaunchKernelGGL(k_flow_euler, dim3(ew_grid((size_t)B * T2 * M)), dim3(256), 0, st, xs, a2, B, T2, M, m->dt[s], c.cfg_rate);
     }
@@ -2632,23 +2628,23 @@ int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int 
     float* x = Bf[3];
     hipLaunchKernelGGL(k_flow_embed, dim3(ew_grid((size_t)n * T * D)), dim3(256), 0, st, tokens, w.embedding, Bf[0], (size_t)n * T, D);
     VOX_TRY(conv_gemm(st, w.embed_lin, Bf[0], nullptr, nullptr, n, T, 0, FLOW_OFF0, Bf[1], nullptr, nullptr, 0));
-    hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1);
+    hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 15) / 16), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, n * T);
     hipLaunchKernelGGL(k_flow_relpos, dim3(ew_grid((size_t)(2 * T - 1) * D)), dim3(256), 0, st, m->pe, T, D);
     for (int l = 0; l < c.enc_layers; ++l) {
         const vox_flow_conformer_w& cw = m->enc[l];
         float *nrm = Bf[0], *qkv = Bf[1], *att = Bf[2];
-        hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, cw.ln_mha_w, cw.ln_mha_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1);
+        hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 15) / 16), dim3(256), 0, st, x, cw.ln_mha_w, cw.ln_mha_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1, n * T);
         VOX_TRY(conv_gemm(st, cw.qkv, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
         VOX_TRY(conv_gemm(st, cw.pos, m->pe, nullptr, nullptr, 1, 2 * T - 1, 0, FLOW_OFF0, m->pp, nullptr, nullptr, 0));
         FlowAttn a{qkv, nullptr, m->pp, cw.bias_u, cw.bias_v, att, T, H, dk, 0, 0, 0, 0, 1.0f / sqrtf((float)dk), c.block_size};
         hipLaunchKernelGGL(k_flow_attn, dim3((T + 3) / 4, H, n), dim3(256), 0, st, a);
         VOX_TRY(conv_gemm(st, cw.out, att, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
-        hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, cw.ln_ff_w, cw.ln_ff_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1);
+        hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 15) / 16), dim3(256), 0, st, x, cw.ln_ff_w, cw.ln_ff_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1, n * T);
         VOX_TRY(conv_gemm(st, cw.w1, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
         hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)n * T * c.enc_ffn)), dim3(256), 0, st, qkv, (size_t)n * T * c.enc_ffn, 2);
         VOX_TRY(conv_gemm(st, cw.w2, qkv, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
     }
-    hipLaunchKernelGGL(k_flow_ln, dim3(n * T), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1);
+    hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 15) / 16), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1, n * T);
     VOX_TRY(conv_gemm(st, w.enc_proj, Bf[0], nullptr, nullptr, n, T, 0, FLOW_OFF0, Bf[1], nullptr, nullptr, 0));       // [n*T][MP] (pad columns 0)
     // ---- length regulator: nearest resampling to Tm frames, (conv k3, GroupNorm(1), Mish) x reg_layers, conv k1 ----
     hipLaunchKernelGGL(k_flow_interp, dim3(ew_grid((size_t)n * Tm * MP)), dim3(256), 0, st, Bf[1], Bf[0], n, T, Tm, MP);
