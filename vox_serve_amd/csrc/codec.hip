@@ -3037,15 +3037,28 @@ __global__ __launch_bounds__(256) void k_cenc_rvq(const float* x, const float* e
         const float* E = emb + (size_t)q * bins * dim;
         float best = INFINITY;
         int besti = 0x7fffffff;
-        for (int c = wave; c < bins; c += 4) {
-            float s = 0.f;
+        // eight centroids per pass: their rows' loads are independent and in flight together (the search is load-latency bound)
+        for (int c0 = wave; c0 < bins; c0 += 32) {
+            float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int d = lane; d < dim; d += 64) {
-                const float df = r[d] - E[(size_t)c * dim + d];
-                s += df * df;
+                const float rd = r[d];
+                float e8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + 4 * u;
+                    e8[u] = E[(size_t)(c < bins ? c : bins - 1) * dim + d];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const float df = rd - e8[u]; s8[u] += df * df; }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (s < best) { best = s; besti = c; }
+            for (int u = 0; u < 8; ++u) {
+                float sv = s8[u];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o);
+                const int c = c0 + 4 * u;
+                if (c < bins && sv < best) { best = sv; besti = c; }
+            }
         }
         if (lane == 0) { bd[wave] = best; bi[wave] = besti; }
         __syncthreads();
