@@ -407,7 +407,8 @@ def other_configs():
     res = {}
     for name, cmd in (("cosyvoice2_0.5b_flow_hift_b8", ["tools/bench_cosyvoice2.py", "--batch", "8", "--steps", "75"]),
                       ("csm_1b_mimi_b16", ["tools/bench_csm.py", "--batch", "16", "--steps", "60"]),
-                      ("glm_4_voice_9b_flow_hift_b8_per_gpu", ["tools/bench_glm.py", "--batch", "8", "--greedy", "--steps", "80"])):
+                      ("glm_4_voice_9b_flow_hift_b8_per_gpu", ["tools/bench_glm.py", "--batch", "8", "--greedy", "--steps", "80"]),
+                      ("qwen3_tts_voice_clone_prompt_side", ["tools/bench_clone.py", "--reps", "10"])):
         try:
             p = subprocess.run([sys.executable, os.path.join(here, cmd[0])] + cmd[1:], capture_output=True, text=True, timeout=300, cwd=here)
             line = [ln for ln in p.stdout.strip().split("\n") if ln.startswith("{")]

@@ -29,4 +29,8 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_csm 
 cp $(find $O/prof_csm -name "*kernel_stats.csv" | head -1) $O/kernel_stats_csm_b16.csv; rm -rf $O/prof_csm
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_glm -o glm -- python tools/bench_glm.py --batch 8 --greedy --steps 40 --warmup 10 > $O/glm_b8_prof.json 2> $O/glm_b8_prof.err
 cp $(find $O/prof_glm -name "*kernel_stats.csv" | head -1) $O/kernel_stats_glm_b8.csv; rm -rf $O/prof_glm
-cat $O/csm_b16.json $O/glm_b8.json
+# voice-clone prompt side: timings + kernel summary
+timeout 300 python tools/bench_clone.py > $O/clone.json 2> $O/clone.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_clone -o clone -- python tools/bench_clone.py --reps 5 --seconds 5 > $O/clone_prof.json 2> $O/clone_prof.err
+cp $(find $O/prof_clone -name "*kernel_stats.csv" | head -1) $O/kernel_stats_clone.csv; rm -rf $O/prof_clone
+cat $O/csm_b16.json $O/glm_b8.json $O/clone.json
