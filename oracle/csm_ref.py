@@ -38,7 +38,7 @@ def tiny_csm_cfg() -> CSMCfg:
 
 def random_csm_state_dict(cfg: CSMCfg, seed=0, std=0.02) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
-    w = lambda *s: vr.f2bf(rng.standard_normal(s, dtype=np.float32) * np.float32(std))
+    w = lambda *s: vr.random_bf16(rng, s, std)
     ones = lambda n: vr.f2bf(np.ones(n, np.float32))
     W: Dict[str, np.ndarray] = {}
 

@@ -55,7 +55,7 @@ def tiny_cosyvoice2_cfg() -> LMCfg:
 def random_glm_state_dict(cfg: LMCfg, seed=0, std=0.02) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     c = cfg.stack
-    w = lambda *s: vr.f2bf(rng.standard_normal(s, dtype=np.float32) * np.float32(std))
+    w = lambda *s: vr.random_bf16(rng, s, std)
     ones = lambda n: vr.f2bf(np.ones(n, np.float32))
     qkv = (c.heads + 2 * c.kv_heads) * c.head_dim
     W = {"transformer.embedding.word_embeddings.weight": w(cfg.vocab_in, c.hidden),
@@ -76,7 +76,7 @@ def random_glm_state_dict(cfg: LMCfg, seed=0, std=0.02) -> Dict[str, np.ndarray]
 def random_cosyvoice2_state_dict(cfg: LMCfg, seed=0, std=0.02, text_vocab=640) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     c = cfg.stack
-    w = lambda *s: vr.f2bf(rng.standard_normal(s, dtype=np.float32) * np.float32(std))
+    w = lambda *s: vr.random_bf16(rng, s, std)
     ones = lambda n: vr.f2bf(np.ones(n, np.float32))
     W = {"llm.model.model.embed_tokens.weight": w(text_vocab, c.hidden), "llm.model.model.norm.weight": ones(c.hidden),
          "llm.model.lm_head.weight": w(text_vocab, c.hidden),        # unused by the path (cosyvoice2.py:247-248)

@@ -65,7 +65,7 @@ def random_weights(cfg: Qwen3Cfg, seed: int = 0, std: float = 0.02) -> Dict[str,
     rng = np.random.default_rng(seed)
 
     def w(*shape, s=std):
-        return vr.f2bf((rng.standard_normal(shape, dtype=np.float32) * np.float32(s)))
+        return vr.random_bf16(rng, shape, s)
 
     def ones(n):
         return vr.f2bf(np.ones(n, np.float32))

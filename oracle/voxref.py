@@ -65,6 +65,19 @@ def f2bf(x):
     return r
 
 
+def random_bf16(rng, shape, std):
+    """N(0, std^2) bf16 bits of the given shape.  Tensors above 2^21 elements (the vocabulary tables and wide projections of the
+    full-size test configurations; never the tiny configurations the goldens are generated from) are a 2^20-value normal block tiled
+    under an independent random sign per element: drawing and rounding 1.7 G normals costs minutes of single-threaded host time."""
+    n = int(np.prod(shape))
+    if n <= (1 << 21):
+        return f2bf(rng.standard_normal(shape, dtype=np.float32) * np.float32(std))
+    blk = f2bf(rng.standard_normal(1 << 20, dtype=np.float32) * np.float32(std))
+    out = np.tile(blk, -(-n // blk.size))[:n].copy()
+    out ^= rng.integers(0, 2, n, dtype=np.uint16) << np.uint16(15)
+    return out.reshape(shape)
+
+
 def bf2f(b):
     return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
 

@@ -215,12 +215,22 @@ def test_against_reference_goldens(dev, golden):
         eng.close()
 
 
+_GLM_FULL = {}
+
+
+def glm_full_width():
+    """GLM-4-Voice-9B layer shapes, 2 layers, built once per session (the two 168960 x 4096 tables are 1.4 G values)."""
+    if not _GLM_FULL:
+        cfg = LR.glm_cfg(layers=2, max_pos=512)
+        _GLM_FULL["cfg"], _GLM_FULL["S"] = cfg, LR.random_glm_state_dict(cfg, seed=1, std=0.02)
+    return _GLM_FULL["cfg"], _GLM_FULL["S"]
+
+
 @pytest.mark.slow
 def test_glm_full_width_two_layers(dev):
     """GLM-4-Voice-9B layer shapes (4096 hidden, 32/2 heads, FFN 13696, vocab 168960), 2 of the 40 layers: bit-exact
     decode under the model's default top-p-only sampling over the full 168960-entry vocabulary."""
-    cfg = LR.glm_cfg(layers=2, max_pos=512)
-    S = LR.random_glm_state_dict(cfg, seed=1, std=0.02)
+    cfg, S = glm_full_width()
     run_parity(dev, "glm", cfg, S, [4, 6], 6, page=128, max_pages=8, sampler_kw=dict(top_k=0, top_p=0.8, temperature=0.8))
 
 
@@ -232,8 +242,7 @@ def test_glm_full_width_b8_both_settings(dev):
     VALU kernels.  Both are bit-exact against the oracle under the same policy, prefills included."""
     from oracle.policy import Policy
     from vox_serve_amd import _native as N
-    cfg = LR.glm_cfg(layers=2, max_pos=512)
-    S = LR.random_glm_state_dict(cfg, seed=1, std=0.02)
+    cfg, S = glm_full_width()
     lens = [4, 6, 3, 5, 7, 2, 8, 5]
     run_parity(dev, "glm", cfg, S, lens, 4, page=128, max_pages=16)
     N.set_exact_rows(8)
