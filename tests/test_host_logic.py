@@ -230,6 +230,32 @@ def test_qwen3_preprocess_layout_equals_reference(golden):
         m.layout([1, 2, 3, 4], "auto", None, None, True, ref_text_ids=[1, 2, 3, 4, 5, 6], ref_codes0=[1, 2])
 
 
+def test_reference_clip_loading_and_resampling(tmp_path):
+    """Qwen3TTSModel._load_audio_to_np reads (waveform, sr) pairs, .npy and 16-bit wav (stereo averaged); clips at other rates are
+    brought to 24 kHz before the encoders (the reference resamples with librosa on the host, qwen3_tts.py:1513-1518)."""
+    import wave
+    from vox_serve_amd.model.qwen3_tts import Qwen3TTSModel
+    m = Qwen3TTSModel.__new__(Qwen3TTSModel)
+    t = np.arange(16000) / 16000.0
+    x = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    a, sr = m._load_audio_to_np((x, 16000))
+    assert sr == 16000 and np.array_equal(a, x)
+    np.save(tmp_path / "c.npy", x)
+    assert np.array_equal(m._load_audio_to_np(str(tmp_path / "c.npy"))[0], x)
+    pcm = (x * 32767).astype("<i2")
+    with wave.open(str(tmp_path / "s.wav"), "wb") as f:
+        f.setnchannels(2), f.setsampwidth(2), f.setframerate(16000), f.writeframes(np.stack([pcm, pcm], 1).tobytes())
+    a, sr = m._load_audio_to_np(str(tmp_path / "s.wav"))
+    assert sr == 16000 and a.shape == x.shape and np.abs(a - pcm / 32768.0).max() < 1e-7
+    y = Qwen3TTSModel._to_24k(a, sr)
+    assert y.shape == (24000,) and y.dtype == np.float32
+    spec = np.abs(np.fft.rfft(y * np.hanning(len(y))))
+    assert abs(int(np.argmax(spec)) - 440) <= 1 and abs(float(np.abs(y).max()) - 0.5) < 0.02
+    assert Qwen3TTSModel._to_24k(x, 24000) is not None and np.array_equal(Qwen3TTSModel._to_24k(x, 24000), x)
+    with pytest.raises(ValueError):
+        m._load_audio_to_np("clip.mp3")
+
+
 def test_registry_errors():
     from vox_serve_amd.model import load_model
     with pytest.raises(ValueError):

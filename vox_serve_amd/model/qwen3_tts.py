@@ -293,19 +293,30 @@ class Qwen3TTSModel(BaseLMWithDepth):
                 return a, f.getframerate()
         raise ValueError("audio_path: pass (waveform, sample_rate), a .npy or a 16-bit .wav path")
 
+    @staticmethod
+    def _to_24k(audio, sr: int):
+        """Reference clip at 24 kHz.  The reference resamples with librosa (soxr) on the host (qwen3_tts.py:1513-1518, 1350-1357); here a
+        polyphase FIR (scipy.signal.resample_poly) does — same band-limited signal, not the same filter taps, so a non-24 kHz clip gives
+        codes / an x-vector close to, not identical with, the reference's."""
+        import numpy as np
+        if int(sr) == 24000:
+            return np.asarray(audio, dtype=np.float32)
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(24000, int(sr))
+        return resample_poly(np.asarray(audio, dtype=np.float64), 24000 // g, int(sr) // g).astype(np.float32)
+
     def _extract_speaker_embedding(self, audio, sr: int) -> torch.Tensor:
         if getattr(self, "speaker_encoder", None) is None:
             raise NotImplementedError("no speaker encoder weights loaded: pass speaker_embedding=")
-        if sr != 24000:
-            raise ValueError("the speaker encoder takes 24 kHz audio (qwen3_tts.py:1299); resample the reference clip")
-        return self.speaker_encoder(torch.as_tensor(audio, dtype=torch.float32)).to(self.dtype)      # the reference's encoder output dtype
+        wav = torch.from_numpy(self._to_24k(audio, sr))
+        return self.speaker_encoder(wav).to(self.dtype)      # the reference's encoder output dtype
 
     def _encode_audio_to_codes(self, audio, sr: int) -> torch.Tensor:
         if getattr(self, "audio_encoder", None) is None:
             raise NotImplementedError("no codec encoder weights loaded: pass ref_codes=")
-        if sr != 24000:
-            raise ValueError("the codec encoder takes 24 kHz audio (qwen3_tts.py:1350-1357); resample the reference clip")
-        return self.audio_encoder(torch.as_tensor(audio, dtype=torch.float32)).to(self.device)
+        wav = torch.from_numpy(self._to_24k(audio, sr))
+        return self.audio_encoder(wav).to(self.device)
 
     def postprocess(self, token_ids: torch.Tensor, decoder_cache: Optional[Qwen3TTSDecoderCache] = None, **kwargs):
         """token_ids [B, interval, n_codebooks] (last column = text token, dropped) -> audio [B,1,interval*1920]
