@@ -231,7 +231,7 @@ def test_glm_full_width_two_layers(dev):
     """GLM-4-Voice-9B layer shapes (4096 hidden, 32/2 heads, FFN 13696, vocab 168960), 2 of the 40 layers: bit-exact
     decode under the model's default top-p-only sampling over the full 168960-entry vocabulary."""
     cfg, S = glm_full_width()
-    run_parity(dev, "glm", cfg, S, [4, 6], 6, page=128, max_pages=8, sampler_kw=dict(top_k=0, top_p=0.8, temperature=0.8))
+    run_parity(dev, "glm", cfg, S, [4, 6], 3, page=128, max_pages=8, sampler_kw=dict(top_k=0, top_p=0.8, temperature=0.8))
 
 
 @pytest.mark.slow
@@ -244,10 +244,10 @@ def test_glm_full_width_b8_both_settings(dev):
     from vox_serve_amd import _native as N
     cfg, S = glm_full_width()
     lens = [4, 6, 3, 5, 7, 2, 8, 5]
-    run_parity(dev, "glm", cfg, S, lens, 4, page=128, max_pages=16)
+    run_parity(dev, "glm", cfg, S, lens, 2, page=128, max_pages=16)
     N.set_exact_rows(8)
     try:
-        run_parity(dev, "glm", cfg, S, lens, 4, page=128, max_pages=16, policy=Policy(exact_rows=8))
+        run_parity(dev, "glm", cfg, S, lens, 2, page=128, max_pages=16, policy=Policy(exact_rows=8))
     finally:
         N.set_exact_rows(2)
 
