@@ -609,7 +609,7 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     if (out2 && sn) { a.out2 = out2; a.sn_alpha = sn->alpha; a.sn_invb = sn->inv_beta; a.sn_mod = sn_mod > 0 ? sn_mod : w.n; }
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
     if (ln_w) {      // fused input LayerNorm: few-row kernel, one plain tap, the row statistics need the whole row in one K walk
-        if (a.M > g_conv_skinny_rows || a.planes * 0 + w.n_taps != 1 || a.off[0] != 0)
+        if (a.M > g_conv_skinny_rows || w.n_taps != 1 || a.off[0] != 0)
             return vox_fail(VOX_ERR_INVALID, "codec gemm: fused LayerNorm needs the few-row one-tap path");
         a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps;
         const dim3 g((w.n + 63) / 64, (a.M + 15) / 16);
