@@ -3149,7 +3149,7 @@ int vox_codecenc_encode(vox_codecenc* m, void* stream, const float* audio, int n
         float* sw_ = x; x = t2; t2 = sw_;
         L = Lo; ch *= 2;
     }
-    const int T = L, Hd = c.hidden, nh = c.num_heads, D = c.head_dim, A = nh * D;
+    const int T = L, Hd = c.hidden, nh = c.num_heads, D = c.head_dim;
     float *h = m->tr[0], *nrm = m->tr[1], *qkv = m->tr[2], *att = m->tr[3];
     elu(st, x, t1, (size_t)T * ch);
     VOX_TRY(conv_gemm(st, w.last, t1, nullptr, nullptr, 1, T, 0, off3, h, nullptr, nullptr, 0));                   // h [T][hidden]
