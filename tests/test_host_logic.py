@@ -256,6 +256,27 @@ def test_reference_clip_loading_and_resampling(tmp_path):
         m._load_audio_to_np("clip.mp3")
 
 
+def test_strided_conv_as_two_taps_over_frame_rows():
+    """The speech-tokenizer encoder runs a causal stride-r conv (kernel 2r) as a two-tap GEMM over the input viewed as rows of r frames
+    (tokenizer/qwen3_codec_encoder.py::strided_taps); here the packing is checked against F.conv1d on the CPU, ragged tail included
+    (MimiConv1d pads the tail with zeros up to a whole stride)."""
+    import torch.nn.functional as F
+    from vox_serve_amd.tokenizer.qwen3_codec_encoder import strided_taps
+    g = torch.Generator().manual_seed(0)
+    for r, cin, cout, L in ((4, 8, 16, 40), (5, 6, 4, 43), (2, 16, 16, 7)):
+        w, b = torch.randn(cout, cin, 2 * r, generator=g), torch.randn(cout, generator=g)
+        x = torch.randn(L, cin, generator=g)                               # time-major [t][C]
+        Lo = -(-L // r)
+        want = F.conv1d(F.pad(x.t()[None], (r, Lo * r - L)), w, b, stride=r)[0].t()          # causal: left pad 2r - r, zero tail
+        rows = F.pad(x, (0, 0, 0, Lo * r - L)).reshape(Lo, r * cin)
+        taps = strided_taps(w, r)
+        prev = torch.cat([torch.zeros(1, r * cin), rows[:-1]])
+        got = prev @ taps[0].t() + rows @ taps[1].t() + b
+        assert got.shape == want.shape == (Lo, cout) and torch.allclose(got, want, atol=1e-4)
+    with pytest.raises(ValueError):
+        strided_taps(torch.zeros(2, 2, 7), 4)
+
+
 def test_registry_errors():
     from vox_serve_amd.model import load_model
     with pytest.raises(ValueError):

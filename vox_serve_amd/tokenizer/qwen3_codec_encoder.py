@@ -84,6 +84,15 @@ def param_shapes(c: Qwen3TTSTokenizerV2EncoderConfig) -> Dict[str, tuple]:
     return S
 
 
+def strided_taps(w: torch.Tensor, r: int) -> torch.Tensor:
+    """Conv1d weight [Cout, Cin, 2r] of a causal stride-r conv -> two GEMM taps [2][Cout][r * Cin] over the input viewed as rows of r
+    frames ([L / r][r * Cin], frame-major inside a row): output o = tap0 . row(o - 1) + tap1 . row(o), row(-1) = the causal zero padding."""
+    cout, cin, k = w.shape
+    if k != 2 * r:
+        raise ValueError(f"stride-{r} conv with kernel {k}: the two-tap form needs kernel = 2 * stride")
+    return torch.stack([w[:, :, j0:j0 + r].permute(0, 2, 1).reshape(cout, r * cin) for j0 in (0, r)], 0)
+
+
 class StageW(ctypes.Structure):
     _fields_ = [("conv1", ConvW), ("conv2", ConvW), ("down", ConvW)]
 
@@ -139,9 +148,7 @@ class Qwen3TTSTokenizerV2Encoder:
             return conv(W[name + ".conv.weight"].permute(2, 0, 1), W[name + ".conv.bias"])
 
         def strided(w, r, bias):                  # [Cout, Cin, 2r] -> two taps over rows of r frames: [2][Cout][r * Cin]
-            cout, cin, _ = w.shape
-            taps = [w[:, :, j0:j0 + r].permute(0, 2, 1).reshape(cout, r * cin) for j0 in (0, r)]
-            return conv(torch.stack(taps, 0), bias)
+            return conv(strided_taps(w, r), bias)
 
         def lin(*names):
             return conv(torch.cat([W[n].float().reshape(W[n].shape[0], -1) for n in names], 0)[None])
