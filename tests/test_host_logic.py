@@ -277,6 +277,20 @@ def test_strided_conv_as_two_taps_over_frame_rows():
         strided_taps(torch.zeros(2, 2, 7), 4)
 
 
+def test_mel_filterbank_table_equals_the_oracle_restatement():
+    """The speaker encoder's constant mel table (built on the host by the plugin) equals the oracle's restatement of librosa.filters.mel —
+    the table the reference-generated fixture g15 was computed with — for both checkpoint variants (128 and 80 mels); rows are
+    area-normalised triangles (Slaney): non-negative, each with one peak."""
+    from oracle import spk_ref as SR
+    from vox_serve_amd.model.qwen3_tts_speaker import slaney_mel_filterbank
+    for n_mels in (128, 80):
+        a, b = slaney_mel_filterbank(24000, 1024, n_mels, 0.0, 12000.0), SR.mel_filterbank(24000, 1024, n_mels, 0.0, 12000.0)
+        assert a.shape == (n_mels, 513) and a.dtype == np.float32 and np.array_equal(a, b)
+        assert (a >= 0).all() and (a.sum(axis=1) > 0).all()
+        peaks = a.argmax(axis=1)
+        assert (np.diff(peaks) > 0).all()
+
+
 def test_registry_errors():
     from vox_serve_amd.model import load_model
     with pytest.raises(ValueError):
