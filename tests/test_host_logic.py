@@ -291,6 +291,34 @@ def test_mel_filterbank_table_equals_the_oracle_restatement():
         assert (np.diff(peaks) > 0).all()
 
 
+def test_base_checkpoint_loader_wires_the_clone_encoders(monkeypatch):
+    """load_model's Qwen3 loader: a `...-Base` name selects the voice-clone model type and hands the plugin the speaker encoder
+    (speaker_encoder.* of the LM checkpoint) and the speech tokenizer's encoder half (encoder.* of the codec checkpoint); the other
+    names do not."""
+    import inspect
+    import vox_serve_amd.model as M
+    from vox_serve_amd.model import qwen3_tts as Q
+    accepted = set(inspect.signature(Q.Qwen3TTSModel.__init__).parameters)
+    seen = {}
+
+    class Capture:
+        def __init__(self, model_name, weights, codec_weights, **kw):
+            seen.clear()
+            seen.update(kw)
+
+    monkeypatch.setattr(Q, "Qwen3TTSModel", Capture)
+    monkeypatch.setattr(M, "_load_safetensors_dir", lambda path, device: {"encoder.layers.0.conv.weight": 1, "decoder.x": 2})
+    lm = {"speaker_encoder.fc.weight": 3, "talker.model.norm.weight": 4}
+    M.MODEL_REGISTRY["qwen/qwen3-tts-12hz-1.7b-base"]("Qwen/Qwen3-TTS-12Hz-1.7B-Base", device="cpu", weights=lm, codec_weights={},
+                                                      checkpoint_dir="/ckpt")
+    assert seen["tts_model_type"] == "base" and set(seen) <= accepted
+    assert seen["speaker_encoder_weights"] == {"fc.weight": 3} and seen["audio_encoder_weights"] == {"layers.0.conv.weight": 1}
+    M.MODEL_REGISTRY["qwen3-tts"]("qwen3-tts", device="cpu", weights=lm, codec_weights={}, checkpoint_dir="/ckpt")
+    assert seen["tts_model_type"] == "custom_voice" and "speaker_encoder_weights" not in seen
+    M.MODEL_REGISTRY["qwen3-tts-voice-design"]("qwen3-tts-voice-design", device="cpu", weights=lm, codec_weights={}, checkpoint_dir="/ckpt")
+    assert seen["tts_model_type"] == "voice_design"
+
+
 def test_registry_errors():
     from vox_serve_amd.model import load_model
     with pytest.raises(ValueError):
