@@ -426,3 +426,24 @@ def decode_chunk_shared(fr: "FlowRef", hr, token, embedding, cache, z, rand_ini,
     out = wav.clone()
     out[..., :n] = (wav[..., :n] * win[:n] + torch.zeros(1, n, dtype=torch.bfloat16) * win[n:]).to(wav.dtype)
     return out[:, :-n], mel
+
+
+# ---- CosyVoice2Decoder.decode_chunk, per-request evolving caches (use_detokenizer_cache=True: cosyvoice2.py:1010-1083) ----
+def decode_chunk_evolving(fr: "FlowRef", hr, token, embedding, cache, speech_cache, z, rand_ini, noise, mel_cache_len: int = 6):
+    """One chunk of a request that owns its caches (the reference's non-shared mode; not the plugin default, and not built in HIP yet —
+    this restatement and its fixture g17 are the pinned target).  token [B, T]; cache: dict(enc, up, cnn, att) with batch B (after
+    init_cache: the prompt's caches); speech_cache [B, mel_cache_len * scale]: the tail of the previous chunk's faded audio (zeros at
+    the start).  Returns (audio [B, (2T - mel_cache_len) scale], mel, new cache, new speech_cache): the flow runs against the request's
+    own caches, which then grow by this chunk's rows and are cut back to the sliding window (first `prefix` rows + the most recent
+    ones); HiFT as in the shared mode; the fade-in blends against the previous chunk's tail instead of zeros."""
+    c = fr.c
+    mel, new = fr.flow_chunk(token, torch.zeros(1, 0, c.mel), embedding, z, cache)
+    new["enc"] = truncate_cache(new["enc"], 3, c.max_cache // 2, c.prefix // 2)
+    new["up"] = truncate_cache(new["up"], 3, c.max_cache, c.prefix)
+    new["att"] = truncate_cache(new["att"], 5, c.max_cache, c.prefix)
+    wav, _ = hr.forward_chunk(mel, rand_ini, noise)
+    n = mel_cache_len * hr.cfg.upsample_scale
+    win = torch.from_numpy(np.hamming(2 * n))
+    out = wav.clone()
+    out[..., :n] = (wav[..., :n] * win[:n] + speech_cache * win[n:]).to(wav.dtype)       # fade_in_out (cosyvoice2.py:1060)
+    return out[:, :-n], mel, new, out[:, -n:]

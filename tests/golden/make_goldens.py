@@ -1218,8 +1218,65 @@ def g16_codec_encoder(ns):
     np.savez_compressed(os.path.join(HERE, "g16_codec_encoder.npz"), **out)
 
 
+def g17_flow_evolving(ns):
+    """CosyVoice2Decoder.decode_chunk in the per-request mode (shared_prompt_cache_mode=False, i.e. use_detokenizer_cache=True:
+    cosyvoice2.py:1010-1083) through the reference, tiny size, one request, three consecutive 28-token chunks: the caches grow and are
+    cut back to the sliding window (the third chunk runs against truncated caches), the fade-in blends against the previous chunk's tail.
+    Not built in HIP yet: this pins the oracle restatement (oracle/flow_ref.py::decode_chunk_evolving) the HIP path will be held to."""
+    from oracle import flow_ref as FR, hift_ref as HR
+    import contextlib
+    fc, hc, Np = FR.tiny_flow_cfg(), HR.HiftCfg(base_channels=256, f0_channels=64), 9
+    Wf, Wh = FR.random_flow_weights(fc, seed=3), HR.random_hift_weights(hc, seed=2)
+    stub, C2, flow = _ref_cosyvoice2_decoder(ns, fc, hc, Wf, Wh)
+    stub.shared_prompt_cache_mode = False
+    g = torch.Generator().manual_seed(23)
+    T, n_chunks, seed = 28, 3, 35
+    ptok = torch.randint(0, fc.vocab, (1, Np), generator=g)
+    pfeat = (0.7 * torch.randn(1, 2 * Np, fc.mel, generator=g)).to(torch.bfloat16).float()
+    spk = torch.randn(1, fc.spk_dim, generator=g).to(torch.bfloat16).float()
+    toks = torch.randint(0, fc.vocab, (n_chunks, 1, T), generator=g)
+    queue, cur = [], {}
+    real = (torch.randn, torch.rand, torch.randn_like)
+
+    def fake_randn(*shape, **kw):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        z = queue.pop(0)
+        assert tuple(z.shape) == shape, (z.shape, shape)
+        return z.clone()
+
+    def fake_rand(*shape, **kw):
+        return cur["ini"].clone()
+
+    def fake_randn_like(t, **kw):
+        return cur["nz"].clone() if tuple(t.shape) == tuple(cur["nz"].shape) else torch.zeros_like(t)
+    ref_dict = {"prompt_speech_token": ptok, "prompt_speech_token_len": Np, "prompt_feat": pfeat, "prompt_feat_len": 2 * Np, "embedding": spk}
+    out = {"prompt_token": ptok.numpy().astype(np.int32), "prompt_feat": pfeat.numpy(), "spk": spk.numpy(),
+           "tokens": toks.numpy().astype(np.int32), "noise_seed": np.int64(seed)}
+    torch.randn, torch.rand, torch.randn_like = fake_randn, fake_rand, fake_randn_like
+    try:
+        with contextlib.redirect_stdout(open(os.devnull, "w")), torch.no_grad():
+            queue.append(FR.cfm_noise(seed, 0, fc.mel, 2 * (Np + 3)))
+            cache = C2.CosyVoice2Decoder.init_cache(stub, ref_dict)
+            lens = []
+            for k in range(n_chunks):
+                cur["ini"], cur["nz"] = HR.make_noise(hc, 1, 2 * T, seed=seed, first_stream=16 + 2 * k)
+                queue.append(FR.cfm_noise(seed, 1 + k, fc.mel, 2 * T))
+                audio, cache = C2.CosyVoice2Decoder.decode_chunk(stub, toks[k], T, cache, ref_dict=ref_dict)
+                out[f"audio_{k}"] = audio.float().numpy().astype(np.float32)
+                ec, dc = cache.flow_encoder_cache, cache.flow_decoder_cache
+                lens.append([ec.conformer_att_cache.shape[3], ec.up_conformer_att_cache.shape[3], dc.att_cache.shape[5]])
+                out[f"att_cache_sum_{k}"] = np.float64(dc.att_cache.double().sum().item())
+                out[f"speech_cache_{k}"] = cache.hift_cache.speech_cache.float().numpy().astype(np.float32)
+    finally:
+        torch.randn, torch.rand, torch.randn_like = real
+    assert not queue
+    out["cache_lens"] = np.array(lens, np.int32)
+    print("g17 cache lens per chunk", lens, "audio rms", [float(np.sqrt((out[f"audio_{k}"] ** 2).mean())) for k in range(n_chunks)])
+    np.savez_compressed(os.path.join(HERE, "g17_flow_evolving.npz"), **out)
+
+
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder, "g17": g17_flow_evolving}
 
 if __name__ == "__main__":
     ns = H.boot()

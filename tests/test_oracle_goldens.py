@@ -505,3 +505,30 @@ def test_codec_encoder_pin(golden):
         codes = ref.encode(wav).numpy()
         assert codes.shape == g[f"{tag}_codes"].shape == (-(-n // cfg.hop), cfg.valid_quantizers)
         assert np.array_equal(codes, g[f"{tag}_codes"]), (tag, int((codes != g[f"{tag}_codes"]).sum()))
+
+
+def test_flow_evolving_cache_mode_pin(golden):
+    """oracle decode_chunk_evolving == the reference's CosyVoice2Decoder.decode_chunk with shared_prompt_cache_mode=False (g17): three
+    consecutive chunks of one request — audio within 3e-5 RMS (the level of g12; the chunk's last 6 frames, carried as the next fade's
+    tail, within 1e-4: the harmonic source's phase error grows along the chunk), cache lengths after each chunk (growth, then the sliding-window cut),
+    the attention-cache checksum and the carried speech tail."""
+    import torch
+    from oracle import flow_ref as FR, hift_ref as HR
+    g = golden("g17_flow_evolving")
+    fc, hc = FR.tiny_flow_cfg(), HR.HiftCfg(base_channels=256, f0_channels=64)
+    fr, hr = FR.FlowRef(fc, FR.random_flow_weights(fc, seed=3)), HR.HiftRef(hc, HR.random_hift_weights(hc, seed=2))
+    seed, T = int(g["noise_seed"]), g["tokens"].shape[2]
+    ptok, pfeat, spk = torch.from_numpy(g["prompt_token"]).long(), torch.from_numpy(g["prompt_feat"]), torch.from_numpy(g["spk"])
+    with torch.no_grad():
+        _, cache = fr.init_cache(ptok, pfeat, spk, FR.cfm_noise(seed, 0, fc.mel, 2 * (ptok.shape[1] + 3)))
+        speech = torch.zeros(1, 6 * hc.upsample_scale)
+        for k in range(g["tokens"].shape[0]):
+            ini, nz = HR.make_noise(hc, 1, 2 * T, seed=seed, first_stream=16 + 2 * k)
+            audio, _, cache, speech = FR.decode_chunk_evolving(fr, hr, torch.from_numpy(g["tokens"][k]).long(), spk, cache, speech,
+                                                               FR.cfm_noise(seed, 1 + k, fc.mel, 2 * T), ini, nz)
+            want = g[f"audio_{k}"]
+            assert audio.shape == want.shape
+            assert np.sqrt(((audio.numpy() - want) ** 2).mean()) < 3e-5, k
+            assert [cache["enc"].shape[3], cache["up"].shape[3], cache["att"].shape[5]] == g["cache_lens"][k].tolist(), k
+            assert abs(float(cache["att"].double().sum()) - float(g[f"att_cache_sum_{k}"])) < 1e-3 * (1 + abs(float(g[f"att_cache_sum_{k}"])))
+            assert np.sqrt(((speech.numpy() - g[f"speech_cache_{k}"]) ** 2).mean()) < 1e-4
