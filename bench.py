@@ -159,6 +159,18 @@ class Loop:
         return pcm
 
 
+def _host_cpu_share() -> int:
+    """CPUs this process may really use (affinity mask and cgroup quota): the GPU boxes show 256 logical CPUs to a 16-CPU share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(W, budget_s=25.0):
     """The CPU oracle (oracle/voxref.c, OpenMP; oracle/qwen3_codec_ref.py, torch CPU) on the same workload:
     talker+depth decode frames at B=1 with kv=75, plus one codec chunk.  Reported, never the product path."""
@@ -166,6 +178,13 @@ def cpu_baseline(W, budget_s=25.0):
     from oracle import qwen3_ref as QR
     from oracle import voxref as vr
     cores = os.cpu_count() or 1
+    try:      # one OpenMP thread per CPU of the container's share (the oracle links the system libgomp; torch carries its own copy)
+        import ctypes
+        share = _host_cpu_share()
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(share))
+        cores = share
+    except Exception:
+        pass
     ref_cfg = QR.Qwen3Cfg(max_pos=256)
     src = {k: v.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16) for k, v in W.items()}
     m = QR.Qwen3Ref(ref_cfg, src, page_size=128, max_pages=2, max_batch=1)
