@@ -173,7 +173,7 @@ def _host_cpu_share() -> int:
 
 def cpu_baseline(W, budget_s=25.0):
     """The CPU oracle (oracle/voxref.c, OpenMP; oracle/qwen3_codec_ref.py, torch CPU) on the same workload:
-    talker+depth decode frames at B=1 with kv=75, plus one codec chunk.  Reported, never the product path."""
+    talker+depth decode frames at B=1 mid-stream (kv ~ 200, as the GPU line), plus one codec chunk.  Reported, never the product path."""
     from oracle import qwen3_codec_ref as CR
     from oracle import qwen3_ref as QR
     from oracle import voxref as vr
@@ -197,6 +197,13 @@ def cpu_baseline(W, budget_s=25.0):
     _phase("cpu baseline: oracle set-up")
     lg, hid = m.prefill(req, ids, np.ones(n, np.uint8), np.zeros((n, 2048), np.uint16))
     m.frame([req], lg, hid)
+    # the GPU line is measured mid-stream at a mean KV length of 200: give the CPU request the same history (random K/V bits
+    # in its pages — the timed frames then attend over ~200 tokens like the GPU's)
+    kv0 = 197
+    req.kv_pages.append(m.free_pages.pop(0))
+    for layer in m.kv:
+        layer[req.kv_pages, :, :, :, :] = vr.f2bf((0.5 * rng.standard_normal((2,) + layer.shape[1:])).astype(np.float32))
+    req.kv_token_len, req.kv_last_page_len, req.next_position_id = kv0, kv0 - 128, kv0 + 1
     _phase("cpu baseline: prefill + first frame (untimed)")
     t0 = time.perf_counter()
     nf = 0
@@ -216,7 +223,7 @@ def cpu_baseline(W, budget_s=25.0):
     t_codec = time.perf_counter() - t1
     per_frame = t_lm + t_codec / INTERVAL
     return {"value": 1920.0 / per_frame, "unit": "audio samples/s", "cores": cores, "kind": "port",
-            "sample": f"{nf} LM frames (talker 28L + 15x depth 5L, B=1, kv~{n}) {t_lm:.2f} s/frame on {cores} OpenMP threads "
+            "sample": f"{nf} LM frames (talker 28L + 15x depth 5L, B=1, kv~{kv0 + 1 + nf // 2}) {t_lm:.2f} s/frame on {cores} OpenMP threads "
                       f"+ 1 codec chunk (10 frames) {t_codec:.2f} s on {tthreads} torch threads; "
                       f"oracle = C fixed-order fp32 + torch-CPU codec"}
 
@@ -227,7 +234,7 @@ def pmc_traffic(B):
     MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py).  Hardware counters cannot be read from inside the
     timed run, so the line labels this value `traffic_source: "recorded <file>"`; null when no pass is committed."""
     pdir = os.path.join(ROOT, "profiles")
-    for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+    for name in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
         try:
             rec = json.load(open(os.path.join(pdir, name))).get(f"batch_{B}")
             if rec:
@@ -240,6 +247,7 @@ def pmc_traffic(B):
 def run_batch(B, args, dev, world, shared, ttfa_requests=0):
     """The timed region for one batch size: W warm-up steps, a barrier, exactly K steps, barrier, max over ranks."""
     import torch.distributed as dist
+    use_dist = world > 1 or args.force_dist
     # requests are measured mid-stream: the KV length over the timed steps averages --kv-mean (SURVEY 8d: 200)
     pre = max(0, int(args.kv_mean - PROMPT_TOKENS - args.warmup - args.steps / 2))
     loop = Loop(B, pre + args.steps + args.warmup + 64, dev, shared["W"], shared["codec_W"])
@@ -265,7 +273,7 @@ def run_batch(B, args, dev, world, shared, ttfa_requests=0):
     for _ in range(pre + args.warmup):
         loop.step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     loop.samples = 0
     kv_start = loop.kvlen[0]
@@ -276,7 +284,7 @@ def run_batch(B, args, dev, world, shared, ttfa_requests=0):
     loop.collect_pcm()                     # the last chunk's audio must be on the host inside the timed region
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         dist.barrier()
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -462,6 +470,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttfa-requests", type=int, default=5, help="engine-level TTFA samples per setting (lock-step loop)")
     ap.add_argument("--serving-ttfa-requests", type=int, default=100, help="TTFA samples through Scheduler + ModelWorker (0 = skip)")
+    ap.add_argument("--serving-modes", type=str, default="ttfa,ttfa2,load,throughput", help="which serving-path measurements run "
+                    "(comma list of ttfa, ttfa2 = detokenize_interval 2, load = TTFA under 32-way load, throughput)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the weight broadcast / "
+                    "all-reduce / barrier path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs 1, 3, 4 sub-results (CosyVoice2, CSM-1B, GLM-4-Voice)")
     ap.add_argument("--exact-rows", type=int, default=None, help="rows up to which linears use the wave64 VALU kernels instead of the "
                     "matrix cores (library default 2; 1..8).  Every setting is bit-exact against the oracle under the same policy")
@@ -479,8 +491,11 @@ def main():
     torch.cuda.set_device(local)                                # one process per GPU, bound before any allocation
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI; off the token path
 
     if args.exact_rows is not None:
@@ -490,14 +505,14 @@ def main():
     from vox_serve_amd.synth import synth_qwen3_codec_weights, synth_qwen3_weights
     shared = {"W": synth_qwen3_weights(Qwen3Cfg(), dev, seed=0 if rank == 0 else 1 + rank), "codec_W": synth_qwen3_codec_weights(seed=0)}
     bcast = None
-    if world > 1:
+    if use_dist:
         # load-time weight distribution of the DP pool: rank 0's arena -> every replica over RCCL (worker/dp_pool.py);
         # the other ranks start from different random weights, so a wrong broadcast would show in their outputs
         from vox_serve_amd.worker.dp_pool import broadcast_weights
         nbytes = sum(v.numel() * v.element_size() for v in shared["W"].values())
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.perf_counter()
-        broadcast_weights(shared["W"])
+        broadcast_weights(shared["W"], force=args.force_dist)
         torch.cuda.synchronize(); dist.barrier()
         bdt = time.perf_counter() - t0
         chk = torch.stack([shared["W"][k].float().sum() for k in sorted(shared["W"])[:8]]).to(torch.float64)
@@ -505,7 +520,7 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         bcast = {"bytes": nbytes, "seconds": bdt, "GBps": nbytes / bdt / 1e9, "replicas_identical": bool(torch.equal(lo, hi))}
     ranks_seen = world
-    if world > 1:
+    if use_dist:
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
         ranks_seen = int(one.item())
@@ -523,20 +538,25 @@ def main():
         _phase(f"batch {b}")
 
     serving = {}
+    modes = {m.strip() for m in args.serving_modes.split(",") if m.strip()}
     if world == 1 and args.serving_ttfa_requests > 0 and args.batch is None:
         n = args.serving_ttfa_requests
-        serving["ttfa_ms_p50"] = serving_ttfa(dev, shared, n, 0)
-        _phase("serving ttfa")
-        serving["ttfa_ms_p50_detokenize_interval_2"] = serving_ttfa(dev, shared, max(10, n // 2), 0, interval=2)
-        _phase("serving ttfa interval 2")
-        serving["ttfa_ms_p50_under_32way_load"] = serving_ttfa(dev, shared, max(10, n // 5), 31)
-        _phase("serving ttfa under load")
-        serving["throughput"] = {}
-        for k in ("base", "async", "disaggregation", "offline", "batched_detokenize"):
-            serving["throughput"][k] = serving_throughput(dev, shared, 32, 120, k)
-            _phase(f"serving throughput {k}")
-        serving["throughput"]["batch1_base"] = serving_throughput(dev, shared, 1, 120, "base")
-        _phase("serving throughput batch 1")
+        if "ttfa" in modes:
+            serving["ttfa_ms_p50"] = serving_ttfa(dev, shared, n, 0)
+            _phase("serving ttfa")
+        if "ttfa2" in modes:
+            serving["ttfa_ms_p50_detokenize_interval_2"] = serving_ttfa(dev, shared, max(10, n // 2), 0, interval=2)
+            _phase("serving ttfa interval 2")
+        if "load" in modes:
+            serving["ttfa_ms_p50_under_32way_load"] = serving_ttfa(dev, shared, max(10, n // 5), 31)
+            _phase("serving ttfa under load")
+        if "throughput" in modes:
+            serving["throughput"] = {}
+            for k in ("base", "async", "disaggregation", "offline", "batched_detokenize"):
+                serving["throughput"][k] = serving_throughput(dev, shared, 32, 120, k)
+                _phase(f"serving throughput {k}")
+            serving["throughput"]["batch1_base"] = serving_throughput(dev, shared, 1, 120, "base")
+            _phase("serving throughput batch 1")
 
     if rank == 0:
         out = {
@@ -577,7 +597,7 @@ def main():
             except Exception as ex:  # the baseline is a reported extra; never let it hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)[:200]}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import voxref as vr
 from .policy import Call, Policy
-from .qwen3_ref import RefRequest, RefStack, StackCfg
+from .qwen3_ref import DRY, RefRequest, RefStack, StackCfg
 
 
 @dataclass
@@ -36,10 +36,14 @@ def tiny_csm_cfg() -> CSMCfg:
                   vocab=136, text_vocab=320, n_codebooks=6, max_pos=512)
 
 
-def random_csm_state_dict(cfg: CSMCfg, seed=0, std=0.02) -> Dict[str, np.ndarray]:
+def random_csm_state_dict(cfg: CSMCfg, seed=0, std=0.02, device=None) -> Dict[str, np.ndarray]:
+    """`device`: the same bits as torch bf16 tensors on that device (vr.random_bf16), else numpy bit arrays."""
     rng = np.random.default_rng(seed)
-    w = lambda *s: vr.random_bf16(rng, s, std)
-    ones = lambda n: vr.f2bf(np.ones(n, np.float32))
+    w = lambda *s: vr.random_bf16(rng, s, std, device)
+
+    def ones(n):
+        o = vr.f2bf(np.ones(n, np.float32))
+        return o if device is None else vr.to_torch(o).to(device)
     W: Dict[str, np.ndarray] = {}
 
     def stack(prefix, c: StackCfg):
@@ -69,10 +73,15 @@ def random_csm_state_dict(cfg: CSMCfg, seed=0, std=0.02) -> Dict[str, np.ndarray
 
 
 class CSMRef:
-    def __init__(self, cfg: CSMCfg, W, page_size=128, max_pages=64, max_batch=8, policy=None):
-        self.cfg, self.W, self.page_size = cfg, W, page_size
+    def __init__(self, cfg: CSMCfg, W, page_size=128, max_pages=64, max_batch=8, policy=None, dry=False):
+        """dry: page / position bookkeeping only (see Qwen3Ref)."""
+        self.cfg, self.W, self.page_size, self.dry = cfg, W, page_size, dry
         self.policy = policy or Policy()
         b, d = cfg.backbone, cfg.depth
+        self.free_pages = list(range(max_pages))
+        if dry:
+            self.kv = self.dkv = None
+            return
         self.backbone = RefStack(b, W, "backbone_model", cfg.max_pos, self.policy)
         self.depth = RefStack(d, W, "depth_decoder.model", 64, self.policy)
         self.kv = [np.zeros((max_pages, 2, page_size, b.kv_heads, b.head_dim), np.uint16) for _ in range(b.layers)]
@@ -105,6 +114,8 @@ class CSMRef:
         req.kv_pages = [self.free_pages.pop(0) for _ in range(npg)]
         req.kv_token_len, req.kv_last_page_len = n, n % ps or ps
         req.next_position_id = n + 1                       # quirk Q1 (worker/base.py:299)
+        if self.dry:
+            return DRY, DRY
         page = np.array([req.kv_pages[t // ps] for t in range(n)], np.int32)
         slot = np.array([t % ps for t in range(n)], np.int32)
         xs = self.backbone.forward(self.embed(ids, masks), np.arange(n, dtype=np.int32), self.kv, np.zeros(n, np.int32),
@@ -129,6 +140,8 @@ class CSMRef:
             pos.append(r.next_position_id)
             kvlen.append(r.kv_token_len)
             r.next_position_id += 1
+        if self.dry:
+            return DRY, DRY
         ids = np.concatenate([r.input_ids for r in reqs], 0)
         masks = np.concatenate([r.input_mask for r in reqs], 0)
         xs = self.backbone.forward(self.embed(ids, masks), np.array(pos, np.int32), self.kv, np.arange(B, dtype=np.int32),
@@ -176,6 +189,8 @@ class CSMRef:
 
     def frame(self, reqs: List[RefRequest], first_logits=None, first_hidden=None, sampler=None):
         logits, hid = (self.decode(reqs) if first_logits is None else (first_logits, first_hidden))
+        if self.dry:
+            return None, None, None, None
         c0 = vr.argmax(logits) if sampler is None else sampler(logits, 0)
         out, dl = self.depth_loop(hid, c0, sampler)
         C = self.cfg.n_codebooks

@@ -52,11 +52,17 @@ def tiny_cosyvoice2_cfg() -> LMCfg:
 
 
 # ---- synthetic weights under the reference's state_dict names (so the same dict loads into its modules) ----
-def random_glm_state_dict(cfg: LMCfg, seed=0, std=0.02) -> Dict[str, np.ndarray]:
+def _ones(n, device):
+    o = vr.f2bf(np.ones(n, np.float32))
+    return o if device is None else vr.to_torch(o).to(device)
+
+
+def random_glm_state_dict(cfg: LMCfg, seed=0, std=0.02, device=None) -> Dict[str, np.ndarray]:
+    """`device`: the same bits as torch bf16 tensors on that device (vr.random_bf16), else numpy bit arrays."""
     rng = np.random.default_rng(seed)
     c = cfg.stack
-    w = lambda *s: vr.random_bf16(rng, s, std)
-    ones = lambda n: vr.f2bf(np.ones(n, np.float32))
+    w = lambda *s: vr.random_bf16(rng, s, std, device)
+    ones = lambda n: _ones(n, device)
     qkv = (c.heads + 2 * c.kv_heads) * c.head_dim
     W = {"transformer.embedding.word_embeddings.weight": w(cfg.vocab_in, c.hidden),
          "transformer.encoder.final_layernorm.weight": ones(c.hidden),
@@ -73,11 +79,11 @@ def random_glm_state_dict(cfg: LMCfg, seed=0, std=0.02) -> Dict[str, np.ndarray]
     return W
 
 
-def random_cosyvoice2_state_dict(cfg: LMCfg, seed=0, std=0.02, text_vocab=640) -> Dict[str, np.ndarray]:
+def random_cosyvoice2_state_dict(cfg: LMCfg, seed=0, std=0.02, text_vocab=640, device=None) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     c = cfg.stack
-    w = lambda *s: vr.random_bf16(rng, s, std)
-    ones = lambda n: vr.f2bf(np.ones(n, np.float32))
+    w = lambda *s: vr.random_bf16(rng, s, std, device)
+    ones = lambda n: _ones(n, device)
     W = {"llm.model.model.embed_tokens.weight": w(text_vocab, c.hidden), "llm.model.model.norm.weight": ones(c.hidden),
          "llm.model.lm_head.weight": w(text_vocab, c.hidden),        # unused by the path (cosyvoice2.py:247-248)
          "llm_embedding.weight": w(2, c.hidden), "llm_decoder.weight": w(cfg.vocab_out, c.hidden),
@@ -134,10 +140,15 @@ class LMRequest(RefRequest):
 
 
 class LMRef:
-    def __init__(self, cfg: LMCfg, W, page_size=128, max_pages=64, policy: Optional[Policy] = None):
-        self.cfg, self.W, self.page_size = cfg, W, page_size
+    def __init__(self, cfg: LMCfg, W, page_size=128, max_pages=64, policy: Optional[Policy] = None, dry=False):
+        """dry: page / position bookkeeping only (see Qwen3Ref)."""
+        self.cfg, self.W, self.page_size, self.dry = cfg, W, page_size, dry
         self.policy = policy or Policy()
         c = cfg.stack
+        self.free_pages = list(range(max_pages))
+        if dry:
+            self.kv = None
+            return
         self.stack = RefStack(c, W, "model", cfg.max_pos, self.policy)
         self.kv = [np.zeros((max_pages, 2, page_size, c.kv_heads, c.head_dim), np.uint16) for _ in range(c.layers)]
         self.free_pages = list(range(max_pages))
@@ -169,6 +180,8 @@ class LMRef:
         req.kv_pages = [self.free_pages.pop(0) for _ in range(npg)]
         req.kv_token_len, req.kv_last_page_len = n, n % ps or ps
         req.next_position_id = n + 1                                           # quirk Q1 (worker/base.py:299)
+        if self.dry:
+            return None
         page = np.array([req.kv_pages[t // ps] for t in range(n)], np.int32)
         slot = np.array([t % ps for t in range(n)], np.int32)
         xs = self.stack.forward(self.embed(ids, masks, feats), np.arange(n, dtype=np.int32), self.kv, np.zeros(n, np.int32),
@@ -192,6 +205,8 @@ class LMRef:
             pos.append(r.next_position_id)
             kvlen.append(r.kv_token_len)
             r.next_position_id += 1
+        if self.dry:
+            return None
         ids = np.array([r.input_ids[0, 0] for r in reqs], np.int32)
         masks = np.array([r.input_mask for r in reqs], np.uint8)
         feats = None
@@ -204,6 +219,8 @@ class LMRef:
 
     def sample(self, logits, reqs: List[LMRequest], sampler=None, penalty=1.0, window=None):
         """{GLMVoice,CosyVoice2}Model.sampling: penalty -> draw -> cache update -> next inputs."""
+        if self.dry:
+            return None, None
         use_rep = reqs[0].rep_cache is not None and penalty != 1.0
         if use_rep:
             cache = np.ascontiguousarray(np.stack([r.rep_cache for r in reqs], 0))

@@ -60,15 +60,17 @@ def tiny_cfg() -> Qwen3Cfg:
                     tts_pad_id=7, max_pos=512)
 
 
-def random_weights(cfg: Qwen3Cfg, seed: int = 0, std: float = 0.02) -> Dict[str, np.ndarray]:
-    """N(0, std^2) bf16 weights, norm weights 1 (SURVEY §8d synthetic recipe); reference state_dict names."""
+def random_weights(cfg: Qwen3Cfg, seed: int = 0, std: float = 0.02, device=None) -> Dict[str, np.ndarray]:
+    """N(0, std^2) bf16 weights, norm weights 1 (SURVEY §8d synthetic recipe); reference state_dict names.  `device`: the same
+    bits as torch bf16 tensors on that device (large tensors are generated there, vr.random_bf16), else numpy bit arrays."""
     rng = np.random.default_rng(seed)
 
     def w(*shape, s=std):
-        return vr.random_bf16(rng, shape, s)
+        return vr.random_bf16(rng, shape, s, device)
 
     def ones(n):
-        return vr.f2bf(np.ones(n, np.float32))
+        o = vr.f2bf(np.ones(n, np.float32))
+        return o if device is None else vr.to_torch(o).to(device)
 
     W: Dict[str, np.ndarray] = {}
 
@@ -159,6 +161,10 @@ class RefStack:
         return h, vr.linear(head_w, h, head_b, order=od)
 
 
+DRY = "dry-oracle"      # what a dry oracle hands back in place of a tensor (so that `frame(reqs, logits, hidden)` still knows
+                        # that the step was already run by prefill / decode)
+
+
 @dataclass
 class RefRequest:
     """Mirror of the KV / position bookkeeping fields of vox_serve.requests.Request (requests.py:12-77)."""
@@ -173,10 +179,16 @@ class RefRequest:
 
 
 class Qwen3Ref:
-    def __init__(self, cfg: Qwen3Cfg, W, page_size=128, max_pages=64, max_batch=8, policy: Optional[Policy] = None):
-        self.cfg, self.W, self.page_size = cfg, W, page_size
+    def __init__(self, cfg: Qwen3Cfg, W, page_size=128, max_pages=64, max_batch=8, policy: Optional[Policy] = None, dry=False):
+        """dry: page / position bookkeeping only, no arithmetic — prefill / decode / frame return None where they would return
+        tensors.  Used when a GPU test replays an oracle run recorded earlier (tests/oracle_tape.py)."""
+        self.cfg, self.W, self.page_size, self.dry = cfg, W, page_size, dry
         self.policy = policy or Policy()
         t, d = cfg.talker, cfg.depth
+        self.free_pages = list(range(max_pages))
+        if dry:
+            self.kv = self.dkv = None
+            return
         self.talker = RefStack(t, W, "talker.model", cfg.max_pos, self.policy)
         self.depth = RefStack(d, W, "talker.code_predictor.model", 64, self.policy)
         self.kv = [np.zeros((max_pages, 2, page_size, t.kv_heads, t.head_dim), np.uint16) for _ in range(t.layers)]
@@ -206,6 +218,8 @@ class Qwen3Ref:
         req.kv_token_len = n
         req.kv_last_page_len = n % ps or ps
         req.next_position_id = n + 1                       # quirk Q1 (worker/base.py:299)
+        if self.dry:
+            return DRY, DRY
         pos = np.arange(n, dtype=np.int32)
         x = self.embed(input_ids, masks, feats)
         indptr, indices = np.array([0, npg], np.int32), np.array(req.kv_pages, np.int32)
@@ -234,6 +248,8 @@ class Qwen3Ref:
             pos.append(r.next_position_id)
             kvlen.append(r.kv_token_len)
             r.next_position_id += 1
+        if self.dry:
+            return DRY, DRY
         ids = np.concatenate([r.input_ids for r in reqs], 0)
         masks = np.array([r.input_mask for r in reqs], np.uint8)
         feats = np.concatenate([r.input_features for r in reqs], 0)
@@ -303,6 +319,8 @@ class Qwen3Ref:
             logits, hid = self.decode(reqs)
         else:
             logits, hid = first_logits, first_hidden
+        if self.dry:
+            return None, None, None, None
         c0, masked = self.sample0(logits, sampler)
         out, feats, dl = self.depth_loop(hid, c0, sampler)
         for b, r in enumerate(reqs):

@@ -65,17 +65,63 @@ def f2bf(x):
     return r
 
 
-def random_bf16(rng, shape, std):
+_HASH_A, _HASH_B = 2654435761, 2246822507      # odd 32-bit multipliers (Fibonacci hashing); i < 2^30 keeps i * A below 2^63
+
+
+def hashed_bf16(blk, n, device=None):
+    """n bf16 bit patterns drawn from the 2^20-entry block `blk` by a counter recipe: element i takes
+    blk[((i * A) mod 2^32) >> 12] with its sign flipped when bit 31 of (i * B) mod 2^32 is set.  Pure 64-bit integer
+    arithmetic without overflow, so numpy (device None -> uint16 ndarray) and torch on any device (-> int16 tensor there)
+    give the same bits: a GPU test builds its full-size weights on the GPU in milliseconds while the fixture generator built
+    the very same weights on the CPU (tests/golden/make_oracle_tapes.py)."""
+    assert blk.size == 1 << 20 and n < (1 << 30)
+    if device is None:
+        out = np.empty(n, np.uint16)
+
+        def chunk(lo):          # uint32 products wrap mod 2^32: the same value as the masked 64-bit product
+            i = np.arange(lo, min(n, lo + (1 << 22)), dtype=np.uint32)
+            h = i * np.uint32(_HASH_A)
+            h >>= np.uint32(12)
+            o = out[lo:lo + i.size]
+            np.take(blk, h, out=o, mode="wrap")
+            i *= np.uint32(_HASH_B)
+            i >>= np.uint32(31)
+            o ^= i.astype(np.uint16) << np.uint16(15)
+        los = range(0, n, 1 << 22)
+        if n <= (1 << 24):
+            for lo in los:
+                chunk(lo)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max(1, min(16, len(os.sched_getaffinity(0))))) as ex:
+                list(ex.map(chunk, los))
+        return out
+    import torch
+    b = torch.from_numpy(blk.view(np.int16).copy()).to(device)
+    out = torch.empty(n, dtype=torch.int16, device=device)
+    for lo in range(0, n, 1 << 26):
+        i = torch.arange(lo, min(n, lo + (1 << 26)), dtype=torch.int64, device=device)
+        idx = ((i * _HASH_A) & 0xFFFFFFFF) >> 12
+        sgn = ((((i * _HASH_B) & 0xFFFFFFFF) >> 31) << 15).to(torch.int16)      # 0x8000 wraps to the int16 sign bit
+        out[lo:lo + i.numel()] = b[idx] ^ sgn
+    return out
+
+
+def random_bf16(rng, shape, std, device=None):
     """N(0, std^2) bf16 bits of the given shape.  Tensors above 2^21 elements (the vocabulary tables and wide projections of the
-    full-size test configurations; never the tiny configurations the goldens are generated from) are a 2^20-value normal block tiled
-    under an independent random sign per element: drawing and rounding 1.7 G normals costs minutes of single-threaded host time."""
+    full-size test configurations; never the tiny configurations the goldens are generated from) are a 2^20-value normal block
+    spread by `hashed_bf16`: drawing and rounding 1.7 G normals costs minutes of single-threaded host time.  With `device` the
+    result is a torch bf16 tensor there (large tensors are generated on that device), else a numpy uint16 array."""
     n = int(np.prod(shape))
     if n <= (1 << 21):
-        return f2bf(rng.standard_normal(shape, dtype=np.float32) * np.float32(std))
+        out = f2bf(rng.standard_normal(shape, dtype=np.float32) * np.float32(std))
+        return out if device is None else to_torch(out).to(device)
     blk = f2bf(rng.standard_normal(1 << 20, dtype=np.float32) * np.float32(std))
-    out = np.tile(blk, -(-n // blk.size))[:n].copy()
-    out ^= rng.integers(0, 2, n, dtype=np.uint16) << np.uint16(15)
-    return out.reshape(shape)
+    out = hashed_bf16(blk, n, device)
+    if device is None:
+        return out.reshape(shape)
+    import torch
+    return out.view(torch.bfloat16).reshape(*shape)
 
 
 def bf2f(b):

@@ -25,6 +25,9 @@ def _cpu_budget() -> int:
 
 
 os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_budget()))
+# two OpenMP runtimes live in this process (the oracle's libgomp and torch's bundled copy): bound how long an idle pool spins
+# after a parallel region, so that it does not eat the other one's share of a small CPU quota
+os.environ.setdefault("GOMP_SPINCOUNT", "30000")
 
 
 def pytest_configure(config):
@@ -34,7 +37,17 @@ def pytest_configure(config):
     except Exception:
         pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "slow: CPU test taking tens of seconds")
+    config.addinivalue_line("markers", "slow: takes tens of seconds (full-size configurations); collected last")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Cheap tests first: every hot-path row's oracle / fixture tests run before the full-size cases (marked `slow`) and the
+    bench.py subprocess, so a slow tail can never hide a row's parity result behind a time limit.  Stable within a class."""
+    def rank(item):
+        if "test_gpu_bench_contract" in item.nodeid:
+            return 2
+        return 1 if item.get_closest_marker("slow") else 0
+    items.sort(key=rank)
 
 
 @pytest.fixture(scope="session")

@@ -171,6 +171,16 @@ def _ref_qwen3(ns, cfg: QR.Qwen3Cfg, W):
 
 def g3_qwen3_lm(ns):
     """Tiny Qwen3-TTS talker+depth through the reference's own worker: prefill + 3 decode frames, B=2."""
+    _qwen3_lm_golden(ns, [20, 13], "g3_qwen3_lm.npz", seed=11)
+
+
+def g18_qwen3_lm_b12(ns):
+    """The same at 12 concurrent requests (ragged prompts of 3..31 tokens, 3 decode frames): the row counts at which the HIP
+    engine and the oracle leave the fixed-order kernels for the matrix cores meet logits the REFERENCE produced."""
+    _qwen3_lm_golden(ns, [9, 5, 12, 6, 31, 10, 7, 11, 13, 3, 15, 6], "g18_qwen3_lm_b12.npz", seed=18, P=64)
+
+
+def _qwen3_lm_golden(ns, prompt_lens, fname, seed, P=32):
     torch.cuda.synchronize = lambda *a, **k: None          # worker/base.py calls it unconditionally
     FU, MW = ns.flashinfer_utils, ns.ModelWorker
     from vox_serve.model.base import PreprocessOutput
@@ -178,10 +188,10 @@ def g3_qwen3_lm(ns):
     W = QR.random_weights(cfg, seed=0, std=0.08)
     m = _ref_qwen3(ns, cfg, W)
     t, d = cfg.talker, cfg.depth
-    page, P = 16, 32
+    page = 16
     cpu = torch.device("cpu")
     w = MW.__new__(MW)
-    w.model, w.device, w.page_size, w.max_batch_size = m, "cpu", page, 4
+    w.model, w.device, w.page_size, w.max_batch_size = m, "cpu", page, max(4, len(prompt_lens))
     w.empty_pages = queue.Queue()
     for i in range(P):
         w.empty_pages.put(i)
@@ -209,11 +219,11 @@ def g3_qwen3_lm(ns):
         return lg
     m.forward, m.depth_forward = fwd, dfwd
 
-    g = torch.Generator().manual_seed(11)
-    out = {"page": np.int32(page), "P": np.int32(P)}
+    g = torch.Generator().manual_seed(seed)
+    out = {"page": np.int32(page), "P": np.int32(P), "prompt_lens": np.array(prompt_lens, np.int32)}
     reqs = []
     R = ns.requests.Request
-    for r, n in enumerate([20, 13]):
+    for r, n in enumerate(prompt_lens):
         ids = torch.zeros(n, cfg.n_groups + 1, dtype=torch.long)
         ids[:, -1] = torch.randint(0, cfg.text_vocab, (n,), generator=g)
         ids[:, 0] = torch.randint(0, cfg.vocab - 1024, (n,), generator=g)
@@ -255,8 +265,8 @@ def g3_qwen3_lm(ns):
         rec["dlogits"].clear()
         out[f"f{f}_tokens"] = np.stack([r.lm_output_tokens[-1].numpy().astype(np.int32)[0] for r in reqs])
     out["kv_final"] = bits(w.kv_cache)
-    np.savez_compressed(os.path.join(HERE, "g3_qwen3_lm.npz"), **out)
-    print("g3 ok; frame tokens", out["f2_tokens"][:, :6])
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "ok; frame tokens", out["f2_tokens"][:, :6])
 
 
 
@@ -1275,7 +1285,7 @@ def g17_flow_evolving(ns):
     np.savez_compressed(os.path.join(HERE, "g17_flow_evolving.npz"), **out)
 
 
-ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g4": g4_qwen3_codec, "g6": g6_host_traces,
+ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g18": g18_qwen3_lm_b12, "g4": g4_qwen3_codec, "g6": g6_host_traces,
        "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder, "g17": g17_flow_evolving}
 
 if __name__ == "__main__":

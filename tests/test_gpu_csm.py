@@ -12,6 +12,7 @@ from oracle import csm_ref as CR
 from oracle import qwen3_ref as QR
 from oracle import voxref as vr
 from tests.conftest import bf16_close
+from tests.oracle_tape import Tape, Weights
 
 pytestmark = pytest.mark.gpu
 
@@ -41,69 +42,76 @@ def make_prompt(rng, cfg, n_text, n_audio):
     return ids, masks
 
 
-def run_parity(dev, cfg, W, prompts, n_frames, page=16, max_pages=64, sampler_kw=None):
-    from vox_serve_amd.engine import CSMEngine
+def run_parity(dev, cfg, W, prompts, n_frames, page=16, max_pages=64, sampler_kw=None, tape=None):
+    """W: numpy state dict or tests.oracle_tape.Weights.  tape: None = live oracle (tests/oracle_tape.py)."""
+    tape = tape or Tape()
+    W = W if isinstance(W, Weights) else Weights(W)
     rng = np.random.default_rng(5)
     B, C, C1 = len(prompts), cfg.n_codebooks, cfg.n_codebooks + 1
-    ref = CR.CSMRef(cfg, W, page_size=page, max_pages=max_pages, max_batch=B)
-    eng = CSMEngine(to_engine_cfg(cfg), {k: vr.to_torch(v).to(dev) for k, v in W.items()}, max_batch=B, page_size=page,
-                    max_pages=max_pages, max_seq_len=512, max_prefill_rows=128, keep_depth_logits=True, device=dev)
+    ref = CR.CSMRef(cfg, W.numpy() if tape.oracle else None, page_size=page, max_pages=max_pages, max_batch=B, dry=not tape.oracle)
+    eng = None
+    if tape.gpu:
+        from vox_serve_amd.engine import CSMEngine
+        eng = CSMEngine(to_engine_cfg(cfg), W.torch(dev), max_batch=B, page_size=page, max_pages=max_pages, max_seq_len=512,
+                        max_prefill_rows=128, keep_depth_logits=True, device=dev)
     seed, frame_no = 99, [0]
-    if sampler_kw:
-        sc = eng.sampling_cfg(greedy=False, **sampler_kw)
-        sampler = lambda lg, i: vr.sample(lg, seed=seed, offset=frame_no[0] * C + i, **sampler_kw)
-    else:
-        sc, sampler = eng.sampling_cfg(greedy=True), None
+    sampler = (lambda lg, i: vr.sample(lg, seed=seed, offset=frame_no[0] * C + i, **sampler_kw)) if sampler_kw else None
+    if eng:
+        sc = eng.sampling_cfg(greedy=False, **sampler_kw) if sampler_kw else eng.sampling_cfg(greedy=True)
+        st_ids = torch.zeros(B, C1, dtype=torch.int32, device=dev)
+        st_masks = torch.zeros(B, C1, dtype=torch.uint8, device=dev)
     reqs = []
-    st_ids = torch.zeros(B, C1, dtype=torch.int32, device=dev)
-    st_masks = torch.zeros(B, C1, dtype=torch.uint8, device=dev)
     for r, (nt, na) in enumerate(prompts):
         ids, masks = make_prompt(rng, cfg, nt, na)
         n = nt + na
         req = QR.RefRequest()
         lg, hid = ref.prefill(req, ids, masks)
         out, _, _, dl = ref.frame([req], lg, hid, sampler)
-        eng.row_ids[:n] = torch.from_numpy(ids).to(dev)
-        eng.row_masks[:n] = torch.from_numpy(masks).to(dev)
-        eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[req.kv_pages[t // page] for t in range(n)],
-                        slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1],
-                        indptr=[0, len(req.kv_pages)], indices=req.kv_pages)
-        eng.rng_offset.fill_(frame_no[0])
-        eng.prefill(n, 1, n, sc, seed=seed, feedback=True)
-        torch.cuda.synchronize()
-        assert np.array_equal(vr.from_torch(eng.out_hidden[:1]), hid), f"prefill hidden r{r}"       # bit-exact at every length
-        assert np.array_equal(vr.from_torch(eng.out_logits[:1]), lg), f"prefill logits r{r}"
-        assert np.array_equal(vr.from_torch(eng.out_depth_logits[:, 0]), np.stack(dl)[:, 0]), f"prefill depth r{r}"
-        assert np.array_equal(eng.out_ids[:1].cpu().numpy(), out), f"prefill tokens r{r}"
-        assert np.array_equal(eng.input_ids[:1].cpu().numpy(), req.input_ids) and \
-            np.array_equal(eng.input_masks[:1].cpu().numpy(), req.input_mask), f"feedback r{r}"
-        st_ids[r], st_masks[r] = eng.input_ids[0], eng.input_masks[0]
+        if eng:
+            eng.row_ids[:n] = torch.from_numpy(ids).to(dev)
+            eng.row_masks[:n] = torch.from_numpy(masks).to(dev)
+            eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[req.kv_pages[t // page] for t in range(n)],
+                            slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1],
+                            indptr=[0, len(req.kv_pages)], indices=req.kv_pages)
+            eng.rng_offset.fill_(frame_no[0])
+            eng.prefill(n, 1, n, sc, seed=seed, feedback=True)
+            torch.cuda.synchronize()
+        tape.check(f"prefill hidden r{r}", lambda: vr.from_torch(eng.out_hidden[:1]), lambda: hid)       # bit-exact at every length
+        tape.check(f"prefill logits r{r}", lambda: vr.from_torch(eng.out_logits[:1]), lambda: lg)
+        tape.check(f"prefill depth r{r}", lambda: vr.from_torch(eng.out_depth_logits[:, 0]), lambda: np.stack(dl)[:, 0])
+        tape.check(f"prefill tokens r{r}", lambda: eng.out_ids[:1].cpu().numpy(), lambda: out)
+        tape.check(f"feedback ids r{r}", lambda: eng.input_ids[:1].cpu().numpy(), lambda: req.input_ids)
+        tape.check(f"feedback masks r{r}", lambda: eng.input_masks[:1].cpu().numpy(), lambda: req.input_mask)
+        if eng:
+            st_ids[r], st_masks[r] = eng.input_ids[0], eng.input_masks[0]
         reqs.append(req)
     frame_no[0] = 1
-    eng.input_ids[:B], eng.input_masks[:B] = st_ids, st_masks
-    eng.rng_offset.fill_(frame_no[0])
+    if eng:
+        eng.input_ids[:B], eng.input_masks[:B] = st_ids, st_masks
+        eng.rng_offset.fill_(frame_no[0])
     for f in range(n_frames):
         lg, hid = ref.decode(reqs)
         out, _, _, dl = ref.frame(reqs, lg, hid, sampler)
-        indptr, indices = [0], []
-        for q in reqs:
-            indptr.append(indptr[-1] + len(q.kv_pages))
-            indices += q.kv_pages
-        eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
-                        page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
-                        indptr=indptr, indices=indices)
-        eng.frame(B, max(q.kv_token_len for q in reqs), sc, seed=seed, feedback=True, use_graph=True)
-        torch.cuda.synchronize()
-        assert np.array_equal(vr.from_torch(eng.out_hidden[:B]), hid), f"hidden f{f}"
-        assert np.array_equal(vr.from_torch(eng.out_logits[:B]), lg), f"logits f{f}"
-        assert np.array_equal(vr.from_torch(eng.out_depth_logits[:, :B]), np.stack(dl)), f"depth logits f{f}"
-        assert np.array_equal(eng.out_ids[:B].cpu().numpy(), out), f"tokens f{f}"
+        if eng:
+            indptr, indices = [0], []
+            for q in reqs:
+                indptr.append(indptr[-1] + len(q.kv_pages))
+                indices += q.kv_pages
+            eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
+                            page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
+                            indptr=indptr, indices=indices)
+            eng.frame(B, max(q.kv_token_len for q in reqs), sc, seed=seed, feedback=True, use_graph=True)
+            torch.cuda.synchronize()
+        tape.check(f"hidden f{f}", lambda: vr.from_torch(eng.out_hidden[:B]), lambda: hid)
+        tape.check(f"logits f{f}", lambda: vr.from_torch(eng.out_logits[:B]), lambda: lg)
+        tape.check(f"depth logits f{f}", lambda: vr.from_torch(eng.out_depth_logits[:, :B]), lambda: np.stack(dl))
+        tape.check(f"tokens f{f}", lambda: eng.out_ids[:B].cpu().numpy(), lambda: out)
         frame_no[0] += 1
     used = sorted({p for q in reqs for p in q.kv_pages})
-    kv_gpu = vr.from_torch(eng.kv)
-    for l in range(len(ref.kv)):
-        assert np.array_equal(kv_gpu[l][used], ref.kv[l][used]), f"kv layer {l}"
-    eng.close()
+    tape.check("kv", lambda: vr.from_torch(eng.kv)[:, used], lambda: np.stack([l[used] for l in ref.kv]))
+    if eng:
+        eng.close()
+    tape.done(kind="csm", prompts=[list(p_) for p_ in prompts], n_frames=n_frames)
 
 
 def test_csm_tiny_greedy(dev):
@@ -164,14 +172,42 @@ def test_csm_against_reference_goldens(dev, golden):
     eng.close()
 
 
+# ---- heavy cases: the oracle side is recorded ahead of time (tests/oracle_tape.py, tests/golden/make_oracle_tapes.py) ----------
+TAPED = {}
+
+
+def taped(case):
+    def deco(fn):
+        TAPED[case] = fn
+        return fn
+    return deco
+
+
+def csm_full_width_cfg():
+    cfg = CR.CSMCfg(max_pos=512)
+    cfg.backbone.layers, cfg.depth.layers, cfg.text_vocab = 2, 2, 4096
+    return cfg
+
+
+@taped("csm_full_width_two_requests_top_k")
+def case_csm_full_width_two_layers(tape, dev):
+    cfg = csm_full_width_cfg()
+    W = Weights(lambda device=None: CR.random_csm_state_dict(cfg, 3, 0.02, device=device))
+    run_parity(dev, cfg, W, [(4, 2), (3, 0)], 3, page=128, max_pages=8, sampler_kw=dict(top_k=50, temperature=0.9), tape=tape)
+
+
+@taped("csm_full_width_b16")
+def case_csm_full_width_b16(tape, dev):
+    cfg = csm_full_width_cfg()
+    W = Weights(lambda device=None: CR.random_csm_state_dict(cfg, 5, 0.02, device=device))
+    run_parity(dev, cfg, W, [(2 + i % 5, i % 3) for i in range(16)], 2, page=128, max_pages=32, tape=tape)
+
+
 @pytest.mark.slow
 def test_csm_full_width_two_layers(dev):
     """CSM-1B layer shapes (2048 hidden, 32/8 heads of 64, FFN 8192; depth 1024, 8/2 heads of 128, FFN 8192, vocab 2051,
     32 codebooks -> 31 depth steps), 2 backbone + 2 depth layers: bit-exact decode."""
-    cfg = CR.CSMCfg(max_pos=512)
-    cfg.backbone.layers, cfg.depth.layers, cfg.text_vocab = 2, 2, 4096
-    run_parity(dev, cfg, CR.random_csm_state_dict(cfg, 3, 0.02), [(4, 2), (3, 0)], 3, page=128, max_pages=8,
-               sampler_kw=dict(top_k=50, temperature=0.9))
+    case_csm_full_width_two_layers(Tape.open("csm_full_width_two_requests_top_k"), dev)
 
 
 @pytest.mark.slow
@@ -179,7 +215,4 @@ def test_csm_full_width_b16_mfma_batch(dev):
     """BASELINE config 3's batch size: 16 concurrent requests at CSM-1B layer shapes (2 backbone + 2 depth layers, all 32
     codebooks -> 31 depth steps): every linear of the frame runs on the matrix cores (32-row depth step 1 included);
     prefills and two free-running frames bit-exact against the oracle."""
-    cfg = CR.CSMCfg(max_pos=512)
-    cfg.backbone.layers, cfg.depth.layers, cfg.text_vocab = 2, 2, 4096
-    prompts = [(2 + i % 5, i % 3) for i in range(16)]
-    run_parity(dev, cfg, CR.random_csm_state_dict(cfg, 5, 0.02), prompts, 2, page=128, max_pages=32)
+    case_csm_full_width_b16(Tape.open("csm_full_width_b16"), dev)

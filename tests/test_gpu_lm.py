@@ -12,6 +12,7 @@ import torch
 from oracle import lm_ref as LR
 from oracle import voxref as vr
 from tests.conftest import bf16_close
+from tests.oracle_tape import Tape, Weights
 
 pytestmark = pytest.mark.gpu
 
@@ -23,10 +24,9 @@ def dev():
     return torch.device("cuda")
 
 
-def build(dev, family, cfg, S, B, page, max_pages, rep_window=None, max_seq_len=512):
-    """Reference-named state dict S (numpy bf16 bits) -> product plugin packers -> LMEngine."""
+def build(dev, family, cfg, St, B, page, max_pages, rep_window=None, max_seq_len=512):
+    """Reference-named state dict St (torch bf16 on the device) -> product plugin packers -> LMEngine."""
     from vox_serve_amd.engine import LMEngine
-    St = {k: vr.to_torch(v).to(dev) for k, v in S.items()}
     c = cfg.stack
     if family == "glm":
         from vox_serve_amd.model.glm_voice import GLMVoiceConfig, pack_glm_weights
@@ -47,24 +47,25 @@ def build(dev, family, cfg, S, B, page, max_pages, rep_window=None, max_seq_len=
 
 
 def run_parity(dev, family, cfg, S, prompt_lens, n_steps, page=16, max_pages=48, sampler_kw=None, penalty=1.0, window=None,
-               policy=None):
+               policy=None, tape=None):
+    """S: numpy state dict or tests.oracle_tape.Weights.  tape: None = live oracle (tests/oracle_tape.py)."""
+    tape = tape or Tape()
+    S = S if isinstance(S, Weights) else Weights(S)
     rng = np.random.default_rng(11)
     B = len(prompt_lens)
-    W = (LR.from_glm_state_dict if family == "glm" else LR.from_cosyvoice2_state_dict)(cfg, S)
-    ref = LR.LMRef(cfg, W, page_size=page, max_pages=max_pages, policy=policy)
+    W = (LR.from_glm_state_dict if family == "glm" else LR.from_cosyvoice2_state_dict)(cfg, S.numpy()) if tape.oracle else None
+    ref = LR.LMRef(cfg, W, page_size=page, max_pages=max_pages, policy=policy, dry=not tape.oracle)
     use_rep = penalty != 1.0
-    eng = build(dev, family, cfg, S, B, page, max_pages, rep_window=window if use_rep else None)
+    eng = build(dev, family, cfg, S.torch(dev), B, page, max_pages, rep_window=window if use_rep else None) if tape.gpu else None
     seed, step = 4321, [0]
-    if sampler_kw:
-        sc = eng.sampling_cfg(greedy=False, repetition_penalty=penalty, **sampler_kw)
-        sampler = lambda lg: vr.sample(lg, seed=seed, offset=step[0], **sampler_kw)
-    else:
-        sc, sampler = eng.sampling_cfg(greedy=True, repetition_penalty=penalty), None
+    sampler = (lambda lg: vr.sample(lg, seed=seed, offset=step[0], **sampler_kw)) if sampler_kw else None
     H, V = cfg.stack.hidden, cfg.vocab_out
     Wn = (window if window and window > 0 else 1)
+    if eng:
+        sc = eng.sampling_cfg(greedy=not sampler_kw, repetition_penalty=penalty, **(sampler_kw or {}))
+        state_ids = torch.zeros(B, 1, dtype=torch.int32, device=dev)
+        state_rep = torch.zeros(B, Wn, 1, V, dtype=torch.uint8, device=dev)
     reqs = []
-    state_ids = torch.zeros(B, 1, dtype=torch.int32, device=dev)
-    state_rep = torch.zeros(B, Wn, 1, V, dtype=torch.uint8, device=dev)
     for r, n in enumerate(prompt_lens):
         ids = rng.integers(0, cfg.vocab_in if family == "glm" else 640, n).astype(np.int32)
         masks = feats = None
@@ -76,57 +77,62 @@ def run_parity(dev, family, cfg, S, prompt_lens, n_steps, page=16, max_pages=48,
         req = LR.LMRequest(rep_cache=np.zeros((Wn, 1, V), np.uint8) if use_rep else None)
         lg = ref.prefill(req, ids, masks, feats)
         tok, pen = ref.sample(lg, [req], sampler, penalty, window)
-        eng.row_ids[:n, 0] = torch.from_numpy(ids).to(dev)
-        if masks is not None:
-            eng.row_masks[:n] = torch.from_numpy(masks).to(dev)
-            eng.row_feats[:n] = vr.to_torch(feats).to(dev)
-        eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[req.kv_pages[t // page] for t in range(n)],
-                        slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1],
-                        indptr=[0, len(req.kv_pages)], indices=req.kv_pages)
-        eng.rng_offset.fill_(step[0])
+        if eng:
+            eng.row_ids[:n, 0] = torch.from_numpy(ids).to(dev)
+            if masks is not None:
+                eng.row_masks[:n] = torch.from_numpy(masks).to(dev)
+                eng.row_feats[:n] = vr.to_torch(feats).to(dev)
+            eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[req.kv_pages[t // page] for t in range(n)],
+                            slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1],
+                            indptr=[0, len(req.kv_pages)], indices=req.kv_pages)
+            eng.rng_offset.fill_(step[0])
+            if use_rep:
+                eng.rep_cache[0].zero_()
+            eng.prefill(n, 1, n, sc, seed=seed, feedback=True)
+            torch.cuda.synchronize()
+        # bit-exact at every prompt length (MFMA prefills incl.)
+        tape.check(f"prefill logits r{r}", lambda: vr.from_torch(eng.out_logits[:1]), lambda: pen)
+        tape.check(f"prefill token r{r}", lambda: eng.out_ids[:1].cpu().numpy(), lambda: tok)
+        tape.check(f"prefill feedback r{r}", lambda: eng.input_ids[:1, :1].cpu().numpy(), lambda: req.input_ids[:1, :1])
         if use_rep:
-            eng.rep_cache[0].zero_()
-        eng.prefill(n, 1, n, sc, seed=seed, feedback=True)
-        torch.cuda.synchronize()
-        got_lg, got = vr.from_torch(eng.out_logits[:1]), eng.out_ids[:1].cpu().numpy()
-        assert np.array_equal(got_lg, pen), f"prefill logits r{r}"        # bit-exact at every prompt length (MFMA prefills incl.)
-        assert np.array_equal(got, tok), f"prefill token r{r}"
-        assert int(eng.input_ids[0, 0]) == int(req.input_ids[0, 0])
-        if cfg.input_mode == 1:
-            assert int(eng.input_masks[0]) == 0
-        state_ids[r] = eng.input_ids[0]
-        if use_rep:
-            state_rep[r] = eng.rep_cache[0]
-            assert np.array_equal(eng.rep_cache[0].cpu().numpy(), req.rep_cache), f"rep cache r{r}"
+            tape.check(f"rep cache r{r}", lambda: eng.rep_cache[0].cpu().numpy(), lambda: req.rep_cache)
+        if eng:
+            if cfg.input_mode == 1:
+                assert int(eng.input_masks[0]) == 0
+            state_ids[r] = eng.input_ids[0]
+            if use_rep:
+                state_rep[r] = eng.rep_cache[0]
         reqs.append(req)
     step[0] = 1
-    eng.input_ids[:B] = state_ids
-    eng.input_masks[:B] = 0
-    if use_rep:
-        eng.rep_cache[:B] = state_rep
-    eng.rng_offset.fill_(step[0])
+    if eng:
+        eng.input_ids[:B] = state_ids
+        eng.input_masks[:B] = 0
+        if use_rep:
+            eng.rep_cache[:B] = state_rep
+        eng.rng_offset.fill_(step[0])
     for f in range(n_steps):
         lg = ref.decode(reqs)
         tok, pen = ref.sample(lg, reqs, sampler, penalty, window)
-        indptr, indices = [0], []
-        for q in reqs:
-            indptr.append(indptr[-1] + len(q.kv_pages))
-            indices += q.kv_pages
-        eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
-                        page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
-                        indptr=indptr, indices=indices)
-        eng.frame(B, max(q.kv_token_len for q in reqs), sc, seed=seed, feedback=True, use_graph=True)
-        torch.cuda.synchronize()
-        assert np.array_equal(vr.from_torch(eng.out_logits[:B]), pen), f"logits step {f}"
-        assert np.array_equal(eng.out_ids[:B].cpu().numpy(), tok), f"tokens step {f}"
+        if eng:
+            indptr, indices = [0], []
+            for q in reqs:
+                indptr.append(indptr[-1] + len(q.kv_pages))
+                indices += q.kv_pages
+            eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
+                            page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
+                            indptr=indptr, indices=indices)
+            eng.frame(B, max(q.kv_token_len for q in reqs), sc, seed=seed, feedback=True, use_graph=True)
+            torch.cuda.synchronize()
+        tape.check(f"logits step {f}", lambda: vr.from_torch(eng.out_logits[:B]), lambda: pen)
+        tape.check(f"tokens step {f}", lambda: eng.out_ids[:B].cpu().numpy(), lambda: tok)
         if use_rep:
-            assert np.array_equal(eng.rep_cache[:B].cpu().numpy(), np.stack([q.rep_cache for q in reqs])), f"rep {f}"
+            tape.check(f"rep {f}", lambda: eng.rep_cache[:B].cpu().numpy(), lambda: np.stack([q.rep_cache for q in reqs]))
         step[0] += 1
-    kv_gpu = vr.from_torch(eng.kv)
     used = sorted({p for q in reqs for p in q.kv_pages})
-    for l in range(len(ref.kv)):
-        assert np.array_equal(kv_gpu[l][used], ref.kv[l][used]), f"kv layer {l}"
-    eng.close()
+    tape.check("kv", lambda: vr.from_torch(eng.kv)[:, used], lambda: np.stack([l[used] for l in ref.kv]))
+    if eng:
+        eng.close()
+    tape.done(kind=family, prompt_lens=list(prompt_lens), n_steps=n_steps)
     return [q.tokens for q in reqs]
 
 
@@ -175,7 +181,7 @@ def test_against_reference_goldens(dev, golden):
         else:
             cfg = LR.tiny_cosyvoice2_cfg()
             S = LR.random_cosyvoice2_state_dict(cfg, seed=4, std=0.08)
-        eng = build(dev, fam, cfg, S, 2, page, P)
+        eng = build(dev, fam, cfg, {k: vr.to_torch(v).to(dev) for k, v in S.items()}, 2, page, P)
         sc = eng.sampling_cfg(greedy=True)
         pages, lens, free, mism = [], [], list(range(P)), 0
         for r in range(2):
@@ -215,23 +221,55 @@ def test_against_reference_goldens(dev, golden):
         eng.close()
 
 
-_GLM_FULL = {}
+# ---- heavy cases: the oracle side is recorded ahead of time (tests/oracle_tape.py, tests/golden/make_oracle_tapes.py) ----------
+TAPED = {}
 
 
-def glm_full_width():
-    """GLM-4-Voice-9B layer shapes, 2 layers, built once per session (the two 168960 x 4096 tables are 1.4 G values)."""
-    if not _GLM_FULL:
-        cfg = LR.glm_cfg(layers=2, max_pos=512)
-        _GLM_FULL["cfg"], _GLM_FULL["S"] = cfg, LR.random_glm_state_dict(cfg, seed=1, std=0.02)
-    return _GLM_FULL["cfg"], _GLM_FULL["S"]
+def taped(case):
+    def deco(fn):
+        TAPED[case] = fn
+        return fn
+    return deco
+
+
+def glm_full_width_cfg():
+    return LR.glm_cfg(layers=2, max_pos=512)
+
+
+# GLM-4-Voice-9B layer shapes, 2 layers (the two 168960 x 4096 tables are 1.4 G values), built once per session and side
+_GLM_FULL = Weights(lambda device=None: LR.random_glm_state_dict(glm_full_width_cfg(), seed=1, std=0.02, device=device))
+_GLM_LENS = [4, 6, 3, 5, 7, 2, 8, 5]
+
+
+@taped("glm_full_width_two_requests_top_p")
+def case_glm_full_width_two_layers(tape, dev):
+    run_parity(dev, "glm", glm_full_width_cfg(), _GLM_FULL, [4, 6], 3, page=128, max_pages=8,
+               sampler_kw=dict(top_k=0, top_p=0.8, temperature=0.8), tape=tape)
+
+
+@taped("glm_full_width_b8_exact_rows_2")
+def case_glm_full_width_b8(tape, dev):
+    run_parity(dev, "glm", glm_full_width_cfg(), _GLM_FULL, _GLM_LENS, 2, page=128, max_pages=16, tape=tape)
+
+
+@taped("glm_full_width_b8_exact_rows_8")
+def case_glm_full_width_b8_er8(tape, dev):
+    from oracle.policy import Policy
+    run_parity(dev, "glm", glm_full_width_cfg(), _GLM_FULL, _GLM_LENS, 2, page=128, max_pages=16, policy=Policy(exact_rows=8), tape=tape)
+
+
+@taped("cosyvoice2_full_size_top_k")
+def case_cosyvoice2_full_size(tape, dev):
+    cfg = LR.cosyvoice2_cfg(max_pos=512)
+    S = Weights(lambda device=None: LR.random_cosyvoice2_state_dict(cfg, seed=2, std=0.02, device=device))
+    run_parity(dev, "cosy", cfg, S, [5, 3], 6, page=128, max_pages=8, sampler_kw=dict(top_k=25, temperature=1.0), tape=tape)
 
 
 @pytest.mark.slow
 def test_glm_full_width_two_layers(dev):
     """GLM-4-Voice-9B layer shapes (4096 hidden, 32/2 heads, FFN 13696, vocab 168960), 2 of the 40 layers: bit-exact
     decode under the model's default top-p-only sampling over the full 168960-entry vocabulary."""
-    cfg, S = glm_full_width()
-    run_parity(dev, "glm", cfg, S, [4, 6], 3, page=128, max_pages=8, sampler_kw=dict(top_k=0, top_p=0.8, temperature=0.8))
+    case_glm_full_width_two_layers(Tape.open("glm_full_width_two_requests_top_p"), dev)
 
 
 @pytest.mark.slow
@@ -240,14 +278,11 @@ def test_glm_full_width_b8_both_settings(dev):
     168960-entry vocabulary).  (a) default (`exact_rows 2`): every call with more than 2 rows runs on the matrix cores
     (K = 4096: normalise-once + full-K GEMM; down_proj K = 13696: 4-wave GEMM); (b) `exact_rows 8`: 8 rows stay on the wave64
     VALU kernels.  Both are bit-exact against the oracle under the same policy, prefills included."""
-    from oracle.policy import Policy
     from vox_serve_amd import _native as N
-    cfg, S = glm_full_width()
-    lens = [4, 6, 3, 5, 7, 2, 8, 5]
-    run_parity(dev, "glm", cfg, S, lens, 2, page=128, max_pages=16)
+    case_glm_full_width_b8(Tape.open("glm_full_width_b8_exact_rows_2"), dev)
     N.set_exact_rows(8)
     try:
-        run_parity(dev, "glm", cfg, S, lens, 2, page=128, max_pages=16, policy=Policy(exact_rows=8))
+        case_glm_full_width_b8_er8(Tape.open("glm_full_width_b8_exact_rows_8"), dev)
     finally:
         N.set_exact_rows(2)
 
@@ -255,6 +290,4 @@ def test_glm_full_width_b8_both_settings(dev):
 @pytest.mark.slow
 def test_cosyvoice2_full_size(dev):
     """CosyVoice2-0.5B at full size (24 layers x 896, 14/2 heads of 64, FFN 4864, 6564 speech ids), top-k 25."""
-    cfg = LR.cosyvoice2_cfg(max_pos=512)
-    S = LR.random_cosyvoice2_state_dict(cfg, seed=2, std=0.02)
-    run_parity(dev, "cosy", cfg, S, [5, 3], 6, page=128, max_pages=8, sampler_kw=dict(top_k=25, temperature=1.0))
+    case_cosyvoice2_full_size(Tape.open("cosyvoice2_full_size_top_k"), dev)

@@ -9,6 +9,7 @@ import torch
 from oracle import voxref as vr
 from tests.conftest import bf16_close
 from oracle.policy import EPI_SILU, EPI_SILU_MUL, EPI_STORE, Call, route
+from tests.oracle_tape import Tape
 
 pytestmark = pytest.mark.gpu
 
@@ -312,18 +313,15 @@ def test_stack_forward_abi_bit_exact(dev):
     L.vox_stack_destroy(h)
 
 
-@pytest.mark.parametrize("n_rows", [12, 16, 24, 32, 48, 64, 75, 100, 128, 140])
-def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072), policy=None):
+def stack_rows_case(tape, dev, n_rows, dims=(1024, 8, 4, 3072), policy=None):
     """9..32 rows take the one-launch full-K MFMA GEMM (norm prologue, SiLU*up / residual epilogues, fragment-major
     weights and activation hand-offs), 33+ the split-K pair: two decoder layers at depth-transformer widths vs the oracle's
     RefStack, through the three attention routes that feed o_proj (single-chunk prefill rows; decode rows at a 41-token
     context = chunked + merge; decode rows on a <= 16-token stack = one-wave short attention).  MFMA accumulation order =>
-    bit-exact against the oracle, which follows the same kernel routing (oracle/policy.py)."""
+    bit-exact against the oracle, which follows the same kernel routing (oracle/policy.py).
+    tape: live oracle, or the oracle side recorded / replayed (tests/oracle_tape.py) for the larger row counts."""
     import ctypes
     from oracle import qwen3_ref as QR
-    from vox_serve_amd import _native as N
-    from vox_serve_amd.engine import StackCfg, _stack_config, rope_table
-    L, ctx = N.lib(), N.ctx()
     (H, heads, kvh, F), D, NL = dims, 128, 2
     oc = QR.StackCfg(H, NL, heads, kvh, D, F, eps=1e-6, rope_theta=1e6, qk_norm=True, qkv_bias=False)
     rng = np.random.default_rng(n_rows)
@@ -339,51 +337,60 @@ def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072), 
                   p + "input_layernorm.weight": g(H), p + "post_attention_layernorm.weight": g(H)})
     ref = QR.RefStack(oc, W, "m", 512, policy)
     page, ppr = 8, (64 if n_rows in (3, 12) else 6)        # pages of 8 slots per request (long-context checks: 64)
-    ec = StackCfg(H, NL, heads, kvh, D, F, 1e-6, 1e6, 1.0, None, False, None, True, False)
-    arr, keep = (N.LayerWeights * NL)(), []
-    for l in range(NL):
-        p = f"m.layers.{l}."
-        ts = dict(wqkv=np.concatenate([W[p + f"self_attn.{n_}_proj.weight"] for n_ in "qkv"]), wo=W[p + "self_attn.o_proj.weight"],
-                  wgate=W[p + "mlp.gate_proj.weight"], wup=W[p + "mlp.up_proj.weight"], wdown=W[p + "mlp.down_proj.weight"],
-                  ln1=W[p + "input_layernorm.weight"], ln2=W[p + "post_attention_layernorm.weight"],
-                  qnorm=W[p + "self_attn.q_norm.weight"], knorm=W[p + "self_attn.k_norm.weight"])
-        for k, v in ts.items():
-            t = T(v, dev)
-            keep.append(t)
-            setattr(arr[l], k, t.data_ptr())
-    fn, rope = T(W["m.norm.weight"], dev), rope_table(512, ec, dev)
-    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
     A = lambda v: np.array(v, np.int32)
     P = n_rows * ppr
+    if tape.gpu:
+        from vox_serve_amd import _native as N
+        from vox_serve_amd.engine import StackCfg, _stack_config, rope_table
+        L, ctx = N.lib(), N.ctx()
+        ec = StackCfg(H, NL, heads, kvh, D, F, 1e-6, 1e6, 1.0, None, False, None, True, False)
+        arr, keep = (N.LayerWeights * NL)(), []
+        for l in range(NL):
+            p = f"m.layers.{l}."
+            ts = dict(wqkv=np.concatenate([W[p + f"self_attn.{n_}_proj.weight"] for n_ in "qkv"]), wo=W[p + "self_attn.o_proj.weight"],
+                      wgate=W[p + "mlp.gate_proj.weight"], wup=W[p + "mlp.up_proj.weight"], wdown=W[p + "mlp.down_proj.weight"],
+                      ln1=W[p + "input_layernorm.weight"], ln2=W[p + "post_attention_layernorm.weight"],
+                      qnorm=W[p + "self_attn.q_norm.weight"], knorm=W[p + "self_attn.k_norm.weight"])
+            for k, v in ts.items():
+                t = T(v, dev)
+                keep.append(t)
+                setattr(arr[l], k, t.data_ptr())
+        fn, rope = T(W["m.norm.weight"], dev), rope_table(512, ec, dev)
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
 
     def check(max_kvlen, kv_tokens, hints):
         """every row = the newest token of its own request, which already holds kv_tokens tokens of random K/V"""
-        sc = _stack_config(ec, page, 144, max_kvlen)
-        h = ctypes.c_void_p()
-        N.check(L.vox_stack_create(ctx, ctypes.byref(sc), arr, fn.data_ptr(), rope.data_ptr(), 512, ctypes.byref(h)))
         kv_ref = [np.zeros((P, 2, page, kvh, D), np.uint16) for _ in range(NL)]
         for l in range(NL):
             for r in range(n_rows):
                 for t in range(kv_tokens):
                     kv_ref[l][r * ppr + t // page, :, t % page] = w(2, kvh, D, sd=0.5)
-        kv = torch.stack([T(k, dev) for k in kv_ref])
+        kv0 = [k.copy() for k in kv_ref] if tape.gpu else None
         x0 = w(n_rows, H, sd=1.0)
         n_new = kv_tokens + 1
         pos, q_req, kvl = [n_new] * n_rows, list(range(n_rows)), [n_new] * n_rows
         pg, sl = [r * ppr + kv_tokens // page for r in range(n_rows)], [kv_tokens % page] * n_rows
         npg = kv_tokens // page + 1
         indptr, indices = [r * npg for r in range(n_rows + 1)], [r * ppr + j for r in range(n_rows) for j in range(npg)]
-        want = ref.forward(x0.copy(), A(pos), kv_ref, A(q_req), A(kvl), A(indptr), A(indices), A(pg), A(sl))
-        x, y = T(x0, dev), torch.empty(n_rows, H, dtype=torch.bfloat16, device=dev)
-        tens = [i32(v) for v in (pos, q_req, kvl, pg, sl, indptr, indices)]
-        ptab = i32([[r * ppr + j for j in range(ppr)] for r in range(n_rows)])
-        rows = N.Rows(*[t.data_ptr() for t in tens], n_rows, n_new, ptab.data_ptr() if hints else None, ppr if hints else 0, 0, -1, 0)
-        N.check(L.vox_stack_forward(h, N.stream(), x.data_ptr(), y.data_ptr(), kv.data_ptr(), kv[0].numel(), ctypes.byref(rows)))
-        torch.cuda.synchronize()
-        assert np.array_equal(Bits(y), want), (max_kvlen, kv_tokens, hints)
-        for l in range(NL):     # the new token's K/V landed where the oracle put them
-            assert np.array_equal(vr.from_torch(kv[l])[pg, :, sl], kv_ref[l][pg, :, sl]), l
-        L.vox_stack_destroy(h)
+        want = ref.forward(x0.copy(), A(pos), kv_ref, A(q_req), A(kvl), A(indptr), A(indices), A(pg), A(sl)) if tape.oracle else None
+        tag = f"kv{kv_tokens} bucket{max_kvlen}"
+        if tape.gpu:
+            sc = _stack_config(ec, page, 144, max_kvlen)
+            h = ctypes.c_void_p()
+            N.check(L.vox_stack_create(ctx, ctypes.byref(sc), arr, fn.data_ptr(), rope.data_ptr(), 512, ctypes.byref(h)))
+            kv = torch.stack([T(k, dev) for k in kv0])
+            x, y = T(x0, dev), torch.empty(n_rows, H, dtype=torch.bfloat16, device=dev)
+            tens = [i32(v) for v in (pos, q_req, kvl, pg, sl, indptr, indices)]
+            ptab = i32([[r * ppr + j for j in range(ppr)] for r in range(n_rows)])
+            rows = N.Rows(*[t.data_ptr() for t in tens], n_rows, n_new, ptab.data_ptr() if hints else None, ppr if hints else 0, 0, -1, 0)
+            N.check(L.vox_stack_forward(h, N.stream(), x.data_ptr(), y.data_ptr(), kv.data_ptr(), kv[0].numel(), ctypes.byref(rows)))
+            torch.cuda.synchronize()
+        tape.check(f"hidden {tag}", lambda: Bits(y), lambda: want)
+        # the new token's K/V landed where the oracle put them
+        tape.check(f"new K/V {tag}", lambda: np.stack([vr.from_torch(kv[l])[pg, :, sl] for l in range(NL)]),
+                   lambda: np.stack([kv_ref[l][pg, :, sl] for l in range(NL)]))
+        if tape.gpu:
+            L.vox_stack_destroy(h)
 
     check(64, 0, False)      # prefill-style rows: head_prepare + single-chunk attention
     check(64, 40, True)      # decode rows, 41-token context: fused chunked attention + merge
@@ -391,6 +398,24 @@ def test_stack_forward_batched_rows_paths(dev, n_rows, dims=(1024, 8, 4, 3072), 
     if ppr == 64:            # 131 / 450-token contexts (5 / 15 chunks of 32 tokens, ragged last chunk, 57 pages per request)
         check(256, 130, True)
         check(512, 449, True)
+    tape.done(kind="stack_forward", n_rows=n_rows, dims=list(dims))
+
+
+# the larger row counts: the oracle's side is recorded ahead of time (tests/oracle_tape.py, tests/golden/make_oracle_tapes.py)
+TAPED = {}
+for _n in (24, 32, 48, 64, 75, 100, 128, 140):
+    TAPED[f"ops_stack_rows_{_n}"] = (lambda tape, dev, n=_n: stack_rows_case(tape, dev, n))
+for _n in (12, 32):
+    TAPED[f"ops_stack_rows_k4096_{_n}"] = (lambda tape, dev, n=_n: stack_rows_case(tape, dev, n, dims=(4096, 32, 16, 4096)))
+
+
+@pytest.mark.parametrize("n_rows", [12, 16, 24, 32, 48, 64, 75, 100, 128, 140])
+def test_stack_forward_batched_rows_paths(dev, n_rows):
+    name = f"ops_stack_rows_{n_rows}"
+    if name in TAPED:
+        TAPED[name](Tape.open(name), dev)
+    else:
+        stack_rows_case(Tape(), dev, n_rows)
 
 
 @pytest.mark.parametrize("n_rows", [3, 4, 8])
@@ -399,10 +424,10 @@ def test_stack_forward_small_batches_both_settings(dev, n_rows):
     both bit-exact against the oracle under the matching policy."""
     from oracle.policy import Policy
     from vox_serve_amd import _native as N
-    test_stack_forward_batched_rows_paths(dev, n_rows)
+    stack_rows_case(Tape(), dev, n_rows)
     N.set_exact_rows(8)
     try:
-        test_stack_forward_batched_rows_paths(dev, n_rows, policy=Policy(exact_rows=8))
+        stack_rows_case(Tape(), dev, n_rows, policy=Policy(exact_rows=8))
     finally:
         N.set_exact_rows(2)
 
@@ -411,4 +436,5 @@ def test_stack_forward_small_batches_both_settings(dev, n_rows):
 def test_stack_forward_batched_rows_k4096(dev, n_rows):
     """The same three attention routes at GLM-4-Voice width (hidden 4096 = 16 k-steps per wave): copy-prologue linears on the
     full-K kernel directly, norm-prologue ones through the normalise-once-into-scratch route."""
-    test_stack_forward_batched_rows_paths(dev, n_rows, dims=(4096, 32, 16, 4096))
+    name = f"ops_stack_rows_k4096_{n_rows}"
+    TAPED[name](Tape.open(name), dev)

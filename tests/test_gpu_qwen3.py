@@ -16,6 +16,7 @@ import torch
 
 from oracle import qwen3_ref as QR
 from oracle import voxref as vr
+from tests.oracle_tape import Tape, Weights
 
 pytestmark = pytest.mark.gpu
 
@@ -45,78 +46,84 @@ def make_prompt(rng, cfg, n):
     return ids, masks, feats
 
 
-def run_parity(dev, cfg, W, prompt_lens, n_frames, page, sampler_kw=None, max_pages=64, policy=None):
-    from vox_serve_amd.engine import Qwen3Engine
+def run_parity(dev, cfg, W, prompt_lens, n_frames, page, sampler_kw=None, max_pages=64, policy=None, tape=None):
+    """W: numpy state dict or tests.oracle_tape.Weights.  tape: None = live oracle; a recording tape runs the oracle side only
+    (no GPU), a replaying one the engine side only (tests/oracle_tape.py)."""
+    tape = tape or Tape()
+    W = W if isinstance(W, Weights) else Weights(W)
     rng = np.random.default_rng(3)
     B = len(prompt_lens)
-    ref = QR.Qwen3Ref(cfg, W, page_size=page, max_pages=max_pages, max_batch=B, policy=policy)
-    Wt = {k: vr.to_torch(v).to(dev) for k, v in W.items()}
-    eng = Qwen3Engine(to_engine_cfg(cfg), Wt, max_batch=B, page_size=page, max_pages=max_pages, max_seq_len=512,
-                      max_prefill_rows=128, keep_depth_logits=True, device=dev)
+    ref = QR.Qwen3Ref(cfg, W.numpy() if tape.oracle else None, page_size=page, max_pages=max_pages, max_batch=B, policy=policy,
+                      dry=not tape.oracle)
+    eng = None
+    if tape.gpu:
+        from vox_serve_amd.engine import Qwen3Engine
+        eng = Qwen3Engine(to_engine_cfg(cfg), W.torch(dev), max_batch=B, page_size=page, max_pages=max_pages, max_seq_len=512,
+                          max_prefill_rows=128, keep_depth_logits=True, device=dev)
     seed = 1234
+    frame_no = [0]
+    sampler = None
     if sampler_kw:
-        sc = eng.sampling_cfg(greedy=False, **sampler_kw)
-        frame_no = [0]
-
         def sampler(logits, i):
             return vr.sample(logits, seed=seed, offset=frame_no[0] * cfg.n_groups + i, **sampler_kw)
-    else:
-        sc, sampler, frame_no = eng.sampling_cfg(greedy=True), None, [0]
-
-    G1 = cfg.n_groups + 1
+    if eng:
+        sc = eng.sampling_cfg(greedy=False, **sampler_kw) if sampler_kw else eng.sampling_cfg(greedy=True)
+        state_ids = torch.zeros(B, cfg.n_groups + 1, dtype=torch.int32, device=dev)
+        state_feat = torch.zeros(B, cfg.talker.hidden, dtype=torch.bfloat16, device=dev)
     reqs = []
-    state_ids = torch.zeros(B, G1, dtype=torch.int32, device=dev)
-    state_feat = torch.zeros(B, cfg.talker.hidden, dtype=torch.bfloat16, device=dev)
     for r, n in enumerate(prompt_lens):
         ids, masks, feats = make_prompt(rng, cfg, n)
         req = QR.RefRequest()
         lg, hid = ref.prefill(req, ids, masks, feats)
         out, masked, _, dl = ref.frame([req], lg, hid, sampler)
-        # engine: stage rows + plan, prefill, compare
-        eng.row_ids[:n] = torch.from_numpy(ids).to(dev)
-        eng.row_masks[:n] = torch.from_numpy(masks).to(dev)
-        eng.row_feats[:n] = vr.to_torch(feats).to(dev)
-        eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[req.kv_pages[t // page] for t in range(n)],
-                        slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1],
-                        indptr=[0, len(req.kv_pages)], indices=req.kv_pages)
-        eng.rng_offset.fill_(frame_no[0])
-        eng.prefill(n, 1, n, sc, seed=seed, feedback=True)
-        torch.cuda.synchronize()
-        assert np.array_equal(vr.from_torch(eng.out_hidden[:1]), hid), f"prefill hidden r{r}"
-        assert np.array_equal(vr.from_torch(eng.out_logits[:1]), masked), f"prefill logits r{r}"
-        assert np.array_equal(vr.from_torch(eng.out_depth_logits[:, 0]), np.stack(dl)[:, 0]), f"prefill depth r{r}"
-        assert np.array_equal(eng.out_ids[:1].cpu().numpy(), out), f"prefill tokens r{r}"
-        state_ids[r] = eng.input_ids[0]
-        state_feat[r] = eng.input_features[0]
+        if eng:     # stage rows + plan, prefill
+            eng.row_ids[:n] = torch.from_numpy(ids).to(dev)
+            eng.row_masks[:n] = torch.from_numpy(masks).to(dev)
+            eng.row_feats[:n] = vr.to_torch(feats).to(dev)
+            eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[req.kv_pages[t // page] for t in range(n)],
+                            slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1],
+                            indptr=[0, len(req.kv_pages)], indices=req.kv_pages)
+            eng.rng_offset.fill_(frame_no[0])
+            eng.prefill(n, 1, n, sc, seed=seed, feedback=True)
+            torch.cuda.synchronize()
+        tape.check(f"prefill hidden r{r}", lambda: vr.from_torch(eng.out_hidden[:1]), lambda: hid)
+        tape.check(f"prefill logits r{r}", lambda: vr.from_torch(eng.out_logits[:1]), lambda: masked)
+        tape.check(f"prefill depth r{r}", lambda: vr.from_torch(eng.out_depth_logits[:, 0]), lambda: np.stack(dl)[:, 0])
+        tape.check(f"prefill tokens r{r}", lambda: eng.out_ids[:1].cpu().numpy(), lambda: out)
+        if eng:
+            state_ids[r] = eng.input_ids[0]
+            state_feat[r] = eng.input_features[0]
         reqs.append(req)
     frame_no[0] = 1
-    # batched free-running decode from the fed-back state
-    eng.input_ids[:B] = state_ids
-    eng.input_masks[:B] = 1
-    eng.input_features[:B] = state_feat
-    eng.rng_offset.fill_(frame_no[0])
+    if eng:     # batched free-running decode from the fed-back state
+        eng.input_ids[:B] = state_ids
+        eng.input_masks[:B] = 1
+        eng.input_features[:B] = state_feat
+        eng.rng_offset.fill_(frame_no[0])
     for f in range(n_frames):
         lg, hid = ref.decode(reqs)
         out, masked, _, dl = ref.frame(reqs, lg, hid, sampler)
-        indptr, indices = [0], []
-        for q in reqs:
-            indptr.append(indptr[-1] + len(q.kv_pages))
-            indices += q.kv_pages
-        eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
-                        page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
-                        indptr=indptr, indices=indices)
-        eng.frame(B, max(q.kv_token_len for q in reqs), sc, seed=seed, feedback=True, use_graph=True)
-        torch.cuda.synchronize()
-        assert np.array_equal(vr.from_torch(eng.out_hidden[:B]), hid), f"hidden f{f}"
-        assert np.array_equal(vr.from_torch(eng.out_logits[:B]), masked), f"logits f{f}"
-        assert np.array_equal(vr.from_torch(eng.out_depth_logits[:, :B]), np.stack(dl)), f"depth logits f{f}"
-        assert np.array_equal(eng.out_ids[:B].cpu().numpy(), out), f"tokens f{f}"
-        assert np.array_equal(vr.from_torch(eng.input_features[:B]),
-                              np.concatenate([q.input_features for q in reqs])), f"features f{f}"
+        if eng:
+            indptr, indices = [0], []
+            for q in reqs:
+                indptr.append(indptr[-1] + len(q.kv_pages))
+                indices += q.kv_pages
+            eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
+                            page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
+                            indptr=indptr, indices=indices)
+            eng.frame(B, max(q.kv_token_len for q in reqs), sc, seed=seed, feedback=True, use_graph=True)
+            torch.cuda.synchronize()
+        tape.check(f"hidden f{f}", lambda: vr.from_torch(eng.out_hidden[:B]), lambda: hid)
+        tape.check(f"logits f{f}", lambda: vr.from_torch(eng.out_logits[:B]), lambda: masked)
+        tape.check(f"depth logits f{f}", lambda: vr.from_torch(eng.out_depth_logits[:, :B]), lambda: np.stack(dl))
+        tape.check(f"tokens f{f}", lambda: eng.out_ids[:B].cpu().numpy(), lambda: out)
+        tape.check(f"features f{f}", lambda: vr.from_torch(eng.input_features[:B]),
+                   lambda: np.concatenate([q.input_features for q in reqs]))
         frame_no[0] += 1
-    kv_ref = np.stack(ref.kv)
-    assert np.array_equal(vr.from_torch(eng.kv), kv_ref), "KV cache"
-    eng.close()
+    tape.check("KV cache", lambda: vr.from_torch(eng.kv), lambda: np.stack(ref.kv))
+    if eng:
+        eng.close()
+    tape.done(kind="qwen3", prompt_lens=list(prompt_lens), n_frames=n_frames)
 
 
 def test_tiny_greedy_b1(dev):
@@ -151,14 +158,6 @@ def test_tiny_b12_mfma_batch(dev):
     run_parity(dev, cfg, QR.random_weights(cfg, 6, 0.08), [9, 5, 12, 6, 8, 10, 7, 11, 13, 4, 15, 6], 40, page=16, max_pages=128)
 
 
-def test_tiny_b32_mfma_batch_100_frames(dev):
-    """BASELINE config 2's batch size on the tiny config: 32 requests (prompts of 3..40 tokens, MFMA prefills included),
-    100 free-running frames with no re-synchronisation — every token of every codebook equals the oracle's."""
-    cfg = QR.tiny_cfg()
-    lens = [3 + (7 * i) % 38 for i in range(32)]
-    run_parity(dev, cfg, QR.random_weights(cfg, 8, 0.08), lens, 100, page=16, max_pages=32 * 10)
-
-
 def test_tiny_b20_topk_sampling_mfma(dev):
     cfg = QR.tiny_cfg()
     run_parity(dev, cfg, QR.random_weights(cfg, 9, 0.08), [5 + i for i in range(20)], 10, page=16, max_pages=160,
@@ -180,30 +179,130 @@ def test_exact_rows_8_setting_bit_exact_under_its_own_policy(dev):
         N.set_exact_rows(2)
 
 
-_FULL = {}
+# ---- heavy cases: the oracle side is recorded ahead of time (tests/oracle_tape.py, tests/golden/make_oracle_tapes.py) ----------
+TAPED = {}
 
 
-def full_size_cfg_and_weights():
-    """Qwen3-TTS-1.7B shapes with random weights, built once per session (1.7 G normals take a minute of host time)."""
-    if not _FULL:
-        cfg = QR.Qwen3Cfg(text_vocab=4096, tts_pad_id=4095, max_pos=1024)   # text table shrunk (gathered, not streamed)
-        _FULL["cfg"], _FULL["W"] = cfg, QR.random_weights(cfg, 0, 0.02)
-    return _FULL["cfg"], _FULL["W"]
+def taped(case):
+    def deco(fn):
+        TAPED[case] = fn
+        return fn
+    return deco
 
 
-def test_full_size_qwen3_1p7b_one_frame(dev):
-    """Qwen3-TTS-1.7B shapes (28+5 layers, random weights): 12-token prefill (matrix-core path through every layer) + 1 decode frame,
-    greedy."""
-    cfg, W = full_size_cfg_and_weights()
-    run_parity(dev, cfg, W, [12], 1, page=128, max_pages=8)
+def full_size_cfg():
+    return QR.Qwen3Cfg(text_vocab=4096, tts_pad_id=4095, max_pos=1024)      # text table shrunk (gathered, not streamed)
 
 
+_FULL_W = Weights(lambda device=None: QR.random_weights(full_size_cfg(), 0, 0.02, device=device))
+
+
+@taped("qwen3_tiny_b32_100_frames")
+def case_tiny_b32_100_frames(tape, dev):
+    cfg = QR.tiny_cfg()
+    lens = [3 + (7 * i) % 38 for i in range(32)]
+    run_parity(dev, cfg, QR.random_weights(cfg, 8, 0.08), lens, 100, page=16, max_pages=32 * 10, tape=tape)
+
+
+@taped("qwen3_full_size_one_request")
+def case_full_size_one_request(tape, dev):
+    run_parity(dev, full_size_cfg(), _FULL_W, [12], 2, page=128, max_pages=8, tape=tape)
+
+
+@taped("qwen3_full_size_b32_two_frames")
+def case_full_size_b32(tape, dev, frames=2):
+    cfg = full_size_cfg()
+    B, ps, kv0 = 32, 128, 40
+    rng = np.random.default_rng(11)
+    t = cfg.talker
+    ref = QR.Qwen3Ref(cfg, _FULL_W.numpy() if tape.oracle else None, page_size=ps, max_pages=B, max_batch=B, dry=not tape.oracle)
+    ids0 = np.zeros((B, cfg.n_groups + 1), np.int32)
+    ids0[:, 0] = rng.integers(0, cfg.vocab - 1024, B)
+    ids0[:, -1] = cfg.tts_pad_id
+    feats0 = vr.f2bf((0.05 * rng.standard_normal((B, t.hidden))).astype(np.float32))
+    kv_shape = (t.layers, B, 2, kv0, t.kv_heads, t.head_dim)
+    kv_rng = lambda: np.random.default_rng(12)
+    eng = None
+    if tape.oracle:
+        kv0_bits = vr.random_bf16(kv_rng(), kv_shape, 0.5)
+        for l in range(t.layers):
+            ref.kv[l][:, :, :kv0] = kv0_bits[l]
+    if tape.gpu:
+        from vox_serve_amd.engine import Qwen3Engine
+        eng = Qwen3Engine(to_engine_cfg(cfg), _FULL_W.torch(dev), max_batch=B, page_size=ps, max_pages=B, max_seq_len=512,
+                          max_prefill_rows=32, keep_depth_logits=True, device=dev)
+        eng.kv[:, :, :, :kv0] = vr.random_bf16(kv_rng(), kv_shape, 0.5, device=dev)
+        eng.input_ids[:B] = torch.from_numpy(ids0).to(dev)
+        eng.input_masks[:B] = 1
+        eng.input_features[:B] = vr.to_torch(feats0).to(dev)
+        sc = eng.sampling_cfg(greedy=True)
+    reqs = []
+    for b in range(B):
+        ref.free_pages.remove(b)
+        reqs.append(QR.RefRequest(kv_pages=[b], kv_token_len=kv0, kv_last_page_len=kv0, next_position_id=kv0 + 1,
+                                  input_ids=ids0[b:b + 1].copy(), input_mask=True, input_features=feats0[b:b + 1].copy()))
+    for f in range(frames):
+        lg, hid = ref.decode(reqs)
+        out, masked, _, dl = ref.frame(reqs, lg, hid, None)
+        if eng:
+            eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
+                            page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
+                            indptr=list(range(B + 1)), indices=list(range(B)))
+            eng.frame(B, max(q.kv_token_len for q in reqs), sc, feedback=True)
+            torch.cuda.synchronize()
+        tape.check(f"hidden f{f}", lambda: vr.from_torch(eng.out_hidden[:B]), lambda: hid)
+        tape.check(f"logits f{f}", lambda: vr.from_torch(eng.out_logits[:B]), lambda: masked)
+        tape.check(f"depth logits f{f}", lambda: vr.from_torch(eng.out_depth_logits[:, :B]), lambda: np.stack(dl))
+        tape.check(f"tokens f{f}", lambda: eng.out_ids[:B].cpu().numpy(), lambda: out)
+        tape.check(f"features f{f}", lambda: vr.from_torch(eng.input_features[:B]),
+                   lambda: np.concatenate([q.input_features for q in reqs]))
+    tape.check("KV cache", lambda: vr.from_torch(eng.kv), lambda: np.stack(ref.kv))
+    if eng:
+        eng.close()
+    tape.done(kind="qwen3", batch=B, frames=frames, layers=[t.layers, cfg.depth.layers])
+
+
+@pytest.mark.slow
+def test_tiny_b32_mfma_batch_100_frames(dev):
+    """BASELINE config 2's batch size on the tiny config: 32 requests (prompts of 3..40 tokens, MFMA prefills included),
+    100 free-running frames with no re-synchronisation — every token of every codebook equals the oracle's."""
+    case_tiny_b32_100_frames(Tape.open("qwen3_tiny_b32_100_frames"), dev)
+
+
+@pytest.mark.slow
+def test_full_size_qwen3_1p7b_one_request(dev):
+    """Qwen3-TTS-1.7B shapes (28+5 layers, seeded weights): 12-token prefill (matrix-core path through every layer) + 2 decode
+    frames on the fixed-order kernels, greedy — bit-exact against the oracle's recorded run."""
+    case_full_size_one_request(Tape.open("qwen3_full_size_one_request"), dev)
+
+
+@pytest.mark.slow
+def test_full_size_b32_free_running_bit_exact_vs_oracle(dev):
+    """BASELINE config 2 at full size: Qwen3-TTS-1.7B (all 28 talker + 5 depth layers), 32 concurrent requests, every linear of
+    the frame on the matrix cores (full-K GEMMs on fragment-major weights, 64-row depth step 1, 4-wave GEMM for codec_head and
+    the text projection).  Two free-running frames from an injected 40-token KV state: hidden states, masked logits, all 15
+    depth logits, all 16 codebook ids, the fed-back next-frame features and the whole K/V cache equal the oracle's bit for bit.
+    The oracle's side (about ten minutes of host time) is the recorded tape tests/golden/tapes/qwen3_full_size_b32_two_frames.json."""
+    case_full_size_b32(Tape.open("qwen3_full_size_b32_two_frames"), dev)
+
+
+# relative RMS of the 32-row (matrix-core) codec logits against the 1-row fixed-order path on the same inputs, Qwen3-TTS-1.7B full
+# size: observed maximum over 32 rows x 3 frames on an MI355X is recorded in profiles/round3_b32_vs_b1_logit_rms.json; the bar is
+# twice that (a wrong K split or a dropped k-step shows up as O(1e-1))
+B32_VS_B1_REL_RMS_BAR = 2e-2
+
+
+@pytest.mark.slow
 def test_full_size_b32_rows_independent_and_close_to_the_exact_path(dev):
     """BASELINE config 2 shapes (Qwen3-TTS-1.7B, 32 concurrent requests) through the batched path (full-K MFMA GEMMs on
     fragment-major weights, 64-row depth step 1, chunked talker attention): size-independent properties —
       (1) determinism: the same batch twice gives identical ids and logits;
       (2) row independence: a request's outputs do not depend on which rows its neighbours occupy (batch permuted);
-      (3) the batched logits sit within bf16 rounding of the 1-row fixed-order path (the one pinned bit-exactly to the oracle)."""
+      (3) every row of every frame sits within bf16 rounding of the 1-row fixed-order path (the one pinned bit-exactly to the
+          oracle on the canonical order) run on the same inputs: all 32 rows x 3 frames, the 1-row engine teacher-forced with
+          the batched run's fed-back ids and features."""
+    import json
+    import os
     from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
     from vox_serve_amd.synth import synth_qwen3_weights
     cfg = Qwen3Cfg()
@@ -216,7 +315,7 @@ def test_full_size_b32_rows_independent_and_close_to_the_exact_path(dev):
     feats0 = (torch.randn(B, cfg.talker.hidden, generator=g) * 0.05).to(torch.bfloat16)
 
     def run(order, max_batch):
-        """order[r] = request placed in row r"""
+        """order[r] = request placed in row r -> ids, logits, and the inputs every frame started from"""
         n = len(order)
         eng = Qwen3Engine(cfg, W, max_batch=max_batch, page_size=ps, max_pages=max(8, 2 * n), max_seq_len=512, max_prefill_rows=16)
         eng.keep_hidden = False
@@ -226,79 +325,111 @@ def test_full_size_b32_rows_independent_and_close_to_the_exact_path(dev):
             eng.input_features[r] = feats0[q].to(dev)
         eng.input_masks[:n] = 0
         sc = eng.sampling_cfg(greedy=True)
-        out_ids, out_logits = [], []
+        out_ids, out_logits, in_ids, in_feats = [], [], [], []
         for f in range(frames):
             L = kv0 + 1 + f
+            in_ids.append(eng.input_ids[:n].cpu().clone()), in_feats.append(eng.input_features[:n].cpu().clone())
             eng.upload_plan(pos=[L] * n, kvlen=[L] * n, page=list(range(n)), slot=[L - 1] * n, indptr=list(range(n + 1)), indices=list(range(n)))
             eng.frame(n, L, sc, feedback=True)
             torch.cuda.synchronize()
             out_ids.append(eng.out_ids[:n].cpu().clone())
             out_logits.append(eng.out_logits[:n].float().cpu().clone())
-        del eng
-        return torch.stack(out_ids), torch.stack(out_logits)
+        eng.close()
+        return torch.stack(out_ids), torch.stack(out_logits), in_ids, in_feats
 
     ident = list(range(B))
-    ids_a, lg_a = run(ident, B)
-    ids_b, lg_b = run(ident, B)
+    ids_a, lg_a, in_ids, in_feats = run(ident, B)
+    ids_b, lg_b, _, _ = run(ident, B)
     assert torch.equal(ids_a, ids_b) and torch.equal(lg_a, lg_b)                      # (1)
     perm = torch.randperm(B, generator=g).tolist()
-    ids_p, lg_p = run(perm, B)
+    ids_p, lg_p, _, _ = run(perm, B)
     inv = [perm.index(q) for q in range(B)]                                            # row of request q in the permuted batch
     assert torch.equal(ids_p[:, inv], ids_a) and torch.equal(lg_p[:, inv], lg_a)      # (2)
-    for q in (0, 13, 31):                                                              # (3) frame 0: same inputs on both paths
-        ids_1, lg_1 = run([q], 1)
-        a, e = lg_a[0, q].double(), lg_1[0, 0].double()
-        assert float(((a - e) ** 2).mean().sqrt() / (e ** 2).mean().sqrt()) <= 2e-2
-
-
-def test_full_size_b32_free_running_bit_exact_vs_oracle(dev):
-    """BASELINE config 2 at the 1.7B layer shapes, 32 concurrent requests: every linear of the frame runs on the matrix cores (full-K
-    GEMMs on fragment-major weights, 64-row depth step 1, 4-wave GEMM for codec_head and the text projection).  One whole frame from an
-    injected 40-token KV state: hidden states, masked logits, all 15 depth logits, all 16 codebook ids, the fed-back next-frame features
-    and the K/V cache equal the oracle's bit for bit.  The stacks are cut to 6 of the 28 talker layers
-    and 2 of the 5 depth layers (the 15-step depth loop is kept): kernel selection depends on the layer shapes and the row count, not on the
-    number of layers, and the oracle's restatement of the matrix cores' arithmetic costs minutes of host time per full-depth frame on
-    the GPU box's 16-CPU share.  The full 28 + 5 stack is pinned by the one-request test above (12-row MFMA prefill through all
-    layers) and, at 32 requests, by the property test above; the 100-frame free run at 32 requests is the tiny-config test."""
-    from vox_serve_amd.engine import Qwen3Engine
-    cfg = QR.Qwen3Cfg(text_vocab=4096, tts_pad_id=4095, max_pos=1024)
-    cfg.talker, cfg.depth = dataclasses.replace(cfg.talker, layers=6), dataclasses.replace(cfg.depth, layers=2)
-    W = QR.random_weights(cfg, 0, 0.02)
-    B, ps, kv0, frames = 32, 128, 40, 1
-    rng = np.random.default_rng(11)
-    t = cfg.talker
-    ref = QR.Qwen3Ref(cfg, W, page_size=ps, max_pages=B, max_batch=B)
-    eng = Qwen3Engine(to_engine_cfg(cfg), {k: vr.to_torch(v).to(dev) for k, v in W.items()}, max_batch=B, page_size=ps,
-                      max_pages=B, max_seq_len=512, max_prefill_rows=32, keep_depth_logits=True, device=dev)
-    kv0_bits = vr.f2bf((0.5 * rng.standard_normal((t.layers, B, 2, kv0, t.kv_heads, t.head_dim))).astype(np.float32))
-    for l in range(t.layers):
-        ref.kv[l][:, :, :kv0] = kv0_bits[l]
-    eng.kv[:, :, :, :kv0] = vr.to_torch(kv0_bits).to(dev)
-    ids0 = np.zeros((B, cfg.n_groups + 1), np.int32)
-    ids0[:, 0] = rng.integers(0, cfg.vocab - 1024, B)
-    ids0[:, -1] = cfg.tts_pad_id
-    feats0 = vr.f2bf((0.05 * rng.standard_normal((B, t.hidden))).astype(np.float32))
-    reqs = []
-    for b in range(B):
-        ref.free_pages.remove(b)
-        reqs.append(QR.RefRequest(kv_pages=[b], kv_token_len=kv0, kv_last_page_len=kv0, next_position_id=kv0 + 1,
-                                  input_ids=ids0[b:b + 1].copy(), input_mask=True, input_features=feats0[b:b + 1].copy()))
-    eng.input_ids[:B] = torch.from_numpy(ids0).to(dev)
-    eng.input_masks[:B] = 1
-    eng.input_features[:B] = vr.to_torch(feats0).to(dev)
+    # (3) one 1-row engine, re-used for every request
+    eng = Qwen3Engine(cfg, W, max_batch=1, page_size=ps, max_pages=8, max_seq_len=512, max_prefill_rows=16)
+    eng.keep_hidden = False
     sc = eng.sampling_cfg(greedy=True)
-    for f in range(frames):
-        lg, hid = ref.decode(reqs)
-        out, masked, _, dl = ref.frame(reqs, lg, hid, None)
-        eng.upload_plan(pos=[q.next_position_id - 1 for q in reqs], kvlen=[q.kv_token_len for q in reqs],
-                        page=[q.kv_pages[-1] for q in reqs], slot=[q.kv_last_page_len - 1 for q in reqs],
-                        indptr=list(range(B + 1)), indices=list(range(B)))
-        eng.frame(B, max(q.kv_token_len for q in reqs), sc, feedback=True)
+    live = torch.isfinite(lg_a[0, 0])
+    worst = 0.0
+    for q in range(B):
+        eng.kv[:, 0].zero_()
+        eng.kv[:, 0, :, :kv0] = kv_req[q].to(dev)
+        for f in range(frames):
+            L = kv0 + 1 + f
+            eng.input_ids[0], eng.input_features[0] = in_ids[f][q].to(dev), in_feats[f][q].to(dev)
+            eng.input_masks[:1] = 0 if f == 0 else 1
+            eng.upload_plan(pos=[L], kvlen=[L], page=[0], slot=[L - 1], indptr=[0, 1], indices=[0])
+            eng.frame(1, L, sc, feedback=False)
+            torch.cuda.synchronize()
+            a, e = lg_a[f, q][live].double(), eng.out_logits[0].float().cpu()[live].double()
+            worst = max(worst, float(((a - e) ** 2).mean().sqrt() / (e ** 2).mean().sqrt()))
+    eng.close()
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        json.dump({"max_rel_rms_32row_vs_1row_logits": worst, "rows": B, "frames": frames, "bar": B32_VS_B1_REL_RMS_BAR},
+                  open(os.path.join(out_dir, "b32_vs_b1_logit_rms.json"), "w"))
+    assert worst <= B32_VS_B1_REL_RMS_BAR, worst
+
+
+def rel_rms(a_bits, b_bits):
+    a, b = vr.bf2f(a_bits).astype(np.float64), vr.bf2f(b_bits).astype(np.float64)
+    return float(np.sqrt(((a - b) ** 2).mean() / (b ** 2).mean()))
+
+
+def test_b12_batched_path_against_reference_worker_logits(dev, golden):
+    """The independent check of the matrix-core paths: 12 concurrent requests on the tiny config against what the REFERENCE's own
+    modules produced through its ModelWorker (g18, tests/golden/make_goldens.py) — hidden states, codec logits, all depth logits
+    within bf16 rounding of the reference's (the tolerances of the oracle's own pin to this fixture, tests/test_oracle_goldens.py:
+    relative RMS of the logits <= 1.2e-2, observed 8.4e-3), teacher-forced with the reference's inputs; greedy ids equal but for near-ties.
+    (The bit-exact tests compare the engine with the oracle's restatement of these kernels; this one cannot be fooled by a wrong
+    K split mirrored on both sides.)"""
+    from vox_serve_amd.engine import Qwen3Engine
+    g = golden("g18_qwen3_lm_b12")
+    cfg = QR.tiny_cfg()
+    W = QR.random_weights(cfg, seed=0, std=0.08)
+    page, P, lens = int(g["page"]), int(g["P"]), g["prompt_lens"].tolist()
+    B = len(lens)
+    eng = Qwen3Engine(to_engine_cfg(cfg), {k: vr.to_torch(v).to(dev) for k, v in W.items()}, max_batch=B, page_size=page,
+                      max_pages=P, max_seq_len=512, max_prefill_rows=128, keep_depth_logits=True, device=dev)
+    sc = eng.sampling_cfg(greedy=True)
+    live = np.ones(cfg.vocab, bool)
+    live[cfg.suppress_ids] = False                      # the engine's out_logits are the masked ones (suppressed ids = -inf)
+    mism = 0
+    for r, n in enumerate(lens):
+        pg = g[f"r{r}_kv_pages"].tolist()
+        eng.row_ids[:n] = torch.from_numpy(g[f"r{r}_ids"]).to(dev)
+        eng.row_masks[:n] = torch.from_numpy(g[f"r{r}_masks"]).to(dev)
+        eng.row_feats[:n] = vr.to_torch(g[f"r{r}_feats"]).to(dev)
+        eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[pg[t // page] for t in range(n)],
+                        slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1], indptr=[0, len(pg)], indices=pg)
+        eng.prefill(n, 1, n, sc, feedback=False)
         torch.cuda.synchronize()
-        assert np.array_equal(vr.from_torch(eng.out_hidden[:B]), hid), f"hidden f{f}"
-        assert np.array_equal(vr.from_torch(eng.out_logits[:B]), masked), f"logits f{f}"
-        assert np.array_equal(vr.from_torch(eng.out_depth_logits[:, :B]), np.stack(dl)), f"depth logits f{f}"
-        assert np.array_equal(eng.out_ids[:B].cpu().numpy(), out), f"tokens f{f}"
-        assert np.array_equal(vr.from_torch(eng.input_features[:B]), np.concatenate([q.input_features for q in reqs])), f"features f{f}"
-    assert np.array_equal(vr.from_torch(eng.kv), np.stack(ref.kv)), "KV cache"
+        assert bf16_close(vr.from_torch(eng.out_hidden[:1]), g[f"r{r}_prefill_hidden"], ulps=4, atol=4e-2).all(), r
+        assert bf16_close(vr.from_torch(eng.out_logits[:1])[:, live], g[f"r{r}_prefill_logits"][:, live], ulps=4, atol=5e-2).all(), r
+        assert rel_rms(vr.from_torch(eng.out_logits[:1])[:, live], g[f"r{r}_prefill_logits"][:, live]) <= 1.2e-2, r
+        mism += int((eng.out_ids[0].cpu().numpy()[: cfg.n_groups] != g[f"r{r}_frame0"][: cfg.n_groups]).sum())
+    for f in range(3):
+        eng.input_ids[:B] = torch.from_numpy(g[f"f{f}_in_ids"]).to(dev)           # teacher forcing with the reference's inputs
+        eng.input_masks[:B] = 1
+        eng.input_features[:B] = vr.to_torch(g[f"f{f}_in_feats"]).to(dev)
+        indptr, indices, last = g[f"f{f}_indptr"], g[f"f{f}_indices"], g[f"f{f}_last"]
+        kvlen = [(int(indptr[r + 1] - indptr[r]) - 1) * page + int(last[r]) for r in range(B)]
+        eng.upload_plan(pos=g[f"f{f}_pos"], kvlen=kvlen, page=[int(indices[indptr[r + 1] - 1]) for r in range(B)],
+                        slot=[int(last[r]) - 1 for r in range(B)], indptr=indptr, indices=indices)
+        eng.frame(B, max(kvlen), sc, feedback=False)
+        torch.cuda.synchronize()
+        assert bf16_close(vr.from_torch(eng.out_hidden[:B]), g[f"f{f}_hidden"], ulps=4, atol=4e-2).all(), f
+        assert bf16_close(vr.from_torch(eng.out_logits[:B])[:, live], g[f"f{f}_logits"][:, live], ulps=4, atol=5e-2).all(), f
+        assert rel_rms(vr.from_torch(eng.out_logits[:B])[:, live], g[f"f{f}_logits"][:, live]) <= 1.2e-2, f
+        got_ids = eng.out_ids[:B].cpu().numpy()[:, : cfg.n_groups]
+        want_ids = g[f"f{f}_tokens"][:, : cfg.n_groups]
+        # depth logits are comparable step by step only while the ids sampled so far agree (step i's input is id i-1)
+        dl, rdl = vr.from_torch(eng.out_depth_logits[:, :B]), g[f"f{f}_dlogits"]
+        for b in range(B):
+            same = np.cumprod(got_ids[b] == want_ids[b])
+            for i in range(cfg.n_groups - 1):
+                if same[i]:
+                    assert bf16_close(dl[i, b], rdl[i, b].reshape(-1), ulps=4, atol=6e-2).all(), (f, b, i)
+        mism += int((got_ids != want_ids).sum())
+    assert mism <= 3 * cfg.n_groups, mism      # a flipped near-tie changes the rest of that frame's depth ids
     eng.close()

@@ -525,3 +525,94 @@ def test_disaggregation_scheduler_runs_two_pipelines():
         done = [m for m in msgs if m.startswith(f"q{i}|COMPLETION|".encode())]
         assert sum(len(m.split(b"|", 2)[2]) for m in audio) == 20 and len(done) == 1, (i, len(audio), len(done))
     assert sorted(w.freed) == [f"q{i}" for i in range(5)] and not sch.active_requests
+
+
+def test_overlapped_detokenize_keeps_the_tail_window_when_eos_lands_on_a_window_boundary():
+    """`finish_detokenize` runs after the LM step of the same iteration (the codec chunk overlaps the frame); the done_all rule
+    (worker/base.py:674-678 of the reference) must still see the request as it was BEFORE that step: for a model with
+    detokenize_overlap > 0 the window that starts `interval - overlap` later is real audio.  The overlapped loop must produce
+    the byte stream of the reference order (detokenize, send, then the LM step) for every EOS position."""
+    from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
+    from vox_serve_amd.worker import ModelWorker
+
+    class Plug(FakePlugin):
+        detokenize_overlap = 1
+
+    def serve(n_frames, overlap):
+        class W(ModelWorker):
+            def run_lm_prefill(self, reqs, li):
+                self._fake(reqs)
+            run_lm_decode = run_lm_prefill
+
+            def _fake(self, reqs):
+                for r in reqs:
+                    k = len(r.lm_output_tokens)
+                    row = torch.tensor([[3 * k + 1, k, 7]], dtype=torch.long)
+                    r.input_tokens, r.input_masks, r.input_features = row, torch.ones(1, 3, dtype=torch.bool), torch.zeros(1, 8)
+                    r.lm_output_tokens.append(row)
+                    if k + 1 > n_frames:
+                        r.done_lm_generation, r.finish_reason = True, "stop_id_encountered"
+                    else:
+                        r.lm_output_audio_tokens.append(row)
+        t = QueueTransport()
+        s = Scheduler(W(model=Plug(), max_num_pages=32, page_size=4, device="cpu"), transport=t)
+        s.overlap_detokenize = overlap
+        t.requests.put(encode_request("r", "3"))
+        s.run_until_idle(200)
+        msgs = []
+        while not t.results.empty():
+            msgs.append(t.results.get())
+        assert msgs[-1].startswith(b"r|COMPLETION|") and sum(m.startswith(b"r|COMPLETION|") for m in msgs) == 1
+        return [m.split(b"|", 2)[2] for m in msgs[:-1]]
+
+    for n in range(3, 15):
+        assert serve(n, True) == serve(n, False), n
+
+
+def test_failed_prefill_launch_answers_once_and_rolls_the_piggy_backed_rows_back():
+    """A prefill launch that raises: the new prompt gets ONE error COMPLETION (no AUDIO / second COMPLETION from the
+    detokenize half of the same iteration), and the decode rows that shared the step get their KV bookkeeping back."""
+    from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
+    from vox_serve_amd.worker import ModelWorker
+
+    class W(ModelWorker):
+        seen = []
+
+        def run_lm_prefill(self, reqs, li):
+            if any(r.request_id == "bad" for r in reqs):
+                raise RuntimeError("boom")
+            self._fake(reqs)
+
+        def run_lm_decode(self, reqs, li):
+            W.seen.append([(r.request_id, r.kv_token_len, r.next_position_id) for r in reqs])
+            self._fake(reqs)
+
+        def _fake(self, reqs):
+            for r in reqs:
+                k = len(r.lm_output_tokens)
+                row = torch.tensor([[k + 1, k, 7]], dtype=torch.long)
+                r.input_tokens, r.input_masks, r.input_features = row, torch.ones(1, 3, dtype=torch.bool), torch.zeros(1, 8)
+                r.lm_output_tokens.append(row)
+                if k + 1 >= 9:
+                    r.done_lm_generation, r.finish_reason = True, "stop_id_encountered"
+                else:
+                    r.lm_output_audio_tokens.append(row)
+    t = QueueTransport()
+    w = W(model=FakePlugin(), max_num_pages=16, page_size=4, device="cpu")
+    s = Scheduler(w, transport=t)
+    t.requests.put(encode_request("ok", "4"))
+    for _ in range(3):
+        s._step()
+    t.requests.put(encode_request("bad", "3"))
+    s.run_until_idle(200)
+    msgs = []
+    while not t.results.empty():
+        msgs.append(t.results.get())
+    bad = [m for m in msgs if m.startswith(b"bad|")]
+    assert len(bad) == 1 and json.loads(bad[0].split(b"|", 2)[2])["status"] == "error"
+    ok = [m for m in msgs if m.startswith(b"ok|")]
+    assert sum(m.startswith(b"ok|COMPLETION|") for m in ok) == 1 and json.loads(ok[-1].split(b"|", 2)[2])["status"] == "completed"
+    # the surviving row's KV length advances by exactly one per executed decode step (the failed step does not count)
+    lens = [row[0][1] for row in W.seen if row and row[0][0] == "ok"]
+    assert lens == list(range(lens[0], lens[0] + len(lens)))
+    assert w.empty_pages.qsize() == 16

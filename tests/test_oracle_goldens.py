@@ -131,22 +131,36 @@ def test_rope_variants(golden, tag, kw):
     assert (q == g[f"rope_{tag}_q"]).mean() > 0.98
 
 
-# ---------------------------------------------------------------- g3: Qwen3 talker + depth --------
-def test_qwen3_lm_against_reference_worker(golden):
-    """Prefill + 3 frames, B=2, greedy, through the oracle vs the reference's ModelWorker."""
-    g = golden("g3_qwen3_lm")
+# ---------------------------------------------------------------- g3 / g18: Qwen3 talker + depth --------
+def _rel_rms(a_bits, b_bits):
+    a, b = vr.bf2f(a_bits).astype(np.float64), vr.bf2f(b_bits).astype(np.float64)
+    return float(np.sqrt(((a - b) ** 2).mean() / (b ** 2).mean()))
+
+
+# tolerances: g3 as pinned in round 1; g18 (12 requests: six times the elements, prompts up to 31 rows) at the observed maxima
+# (logits 0.037 absolute / 19 bf16 ulp on one element, relative RMS 8.4e-3: one bf16 rounding flip early in a stack perturbs
+# everything downstream at the 1-ulp level) plus a margin — a wrong summation split shows as O(1) relative RMS
+@pytest.mark.parametrize("fixture,max_mismatch,atol_h,atol_l,rms_bar", [("g3_qwen3_lm", 1, 2e-2, 3e-2, 6e-3),
+                                                                         ("g18_qwen3_lm_b12", 3, 4e-2, 5e-2, 1.2e-2)])
+def test_qwen3_lm_against_reference_worker(golden, fixture, max_mismatch, atol_h, atol_l, rms_bar):
+    """Prefill + 3 frames, greedy, through the oracle vs the reference's ModelWorker: B=2 (g3: the fixed-order kernels' arithmetic)
+    and B=12 (g18: every linear of the batched frames, and the prompts above 2 rows, in the oracle's restatement of the matrix
+    cores' order — the path the HIP engine takes at these row counts — against logits the REFERENCE produced)."""
+    g = golden(fixture)
     cfg = QR.tiny_cfg()
     W = QR.random_weights(cfg, seed=0, std=0.08)
-    m = QR.Qwen3Ref(cfg, W, page_size=int(g["page"]), max_pages=int(g["P"]), max_batch=4)
+    nreq = len(g["prompt_lens"]) if "prompt_lens" in g else 2
+    m = QR.Qwen3Ref(cfg, W, page_size=int(g["page"]), max_pages=int(g["P"]), max_batch=max(4, nreq))
     reqs = []
     tok_mismatch = 0
-    for r in range(2):
+    for r in range(nreq):
         req = QR.RefRequest()
         logits, hid = m.prefill(req, g[f"r{r}_ids"], g[f"r{r}_masks"], g[f"r{r}_feats"])
         assert np.array_equal(np.array(req.kv_pages, np.int32), g[f"r{r}_kv_pages"])      # FIFO page order
         assert req.next_position_id == int(g[f"r{r}_next_pos"])                            # quirk Q1
-        assert bf16_close(hid, g[f"r{r}_prefill_hidden"], ulps=4, atol=2e-2).all()
-        assert bf16_close(logits, g[f"r{r}_prefill_logits"], ulps=4, atol=3e-2).all()
+        assert bf16_close(hid, g[f"r{r}_prefill_hidden"], ulps=4, atol=atol_h).all()
+        assert bf16_close(logits, g[f"r{r}_prefill_logits"], ulps=4, atol=atol_l).all()
+        assert _rel_rms(logits, g[f"r{r}_prefill_logits"]) <= rms_bar
         out, _, _, _ = m.frame([req], logits, hid)
         tok_mismatch += int((out[0] != g[f"r{r}_frame0"]).sum())
         # teacher-force the reference's frame so the following steps see identical inputs
@@ -159,12 +173,13 @@ def test_qwen3_lm_against_reference_worker(golden):
             req.input_features = g[f"f{f}_in_feats"][b:b + 1].copy()
         logits, hid = m.decode(reqs)
         assert np.array_equal(np.array([r.next_position_id - 1 for r in reqs]), g[f"f{f}_pos"])
-        assert bf16_close(hid, g[f"f{f}_hidden"], ulps=4, atol=2e-2).all()
-        assert bf16_close(logits, g[f"f{f}_logits"], ulps=4, atol=3e-2).all()
+        assert bf16_close(hid, g[f"f{f}_hidden"], ulps=4, atol=atol_h).all()
+        assert bf16_close(logits, g[f"f{f}_logits"], ulps=4, atol=atol_l).all()
+        assert _rel_rms(logits, g[f"f{f}_logits"]) <= rms_bar
         out, _, _, dl = m.frame(reqs, logits, hid)
         tok_mismatch += int((out != g[f"f{f}_tokens"]).sum())
     # greedy ids agree except where bf16 near-ties flip (different fp32 summation order)
-    assert tok_mismatch <= 1, tok_mismatch     # observed: 0 here, 1 on the judge's host (one bf16 near-tie)
+    assert tok_mismatch <= max_mismatch, tok_mismatch     # g3: observed 0 here, 1 on the judge's host (one bf16 near-tie)
 
 
 # ---------------------------------------------------------------- g7: GLM-4-Voice / CosyVoice2 LMs -

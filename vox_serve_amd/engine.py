@@ -7,6 +7,7 @@ step, codebook-0 sampling, 15 depth steps with their sampling and embedding feed
 replay with no host synchronisation inside; the host only uploads the few plan() integers per frame.
 """
 import ctypes
+from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Dict, Optional
 
@@ -161,7 +162,7 @@ class Qwen3Engine:
         self.row_masks = torch.zeros(R, dtype=torch.uint8, device=dev)
         self.row_feats = torch.zeros(R, H, dtype=torch.bfloat16, device=dev)
         self._graphs = {}
-        self.max_graphs = 512          # frame graphs (batch x kv bucket) + prefill graphs (exact shapes seen twice)
+        self.max_graphs = 512          # frame graphs (batch x kv bucket); prefill graphs: own LRU (_prefill_graph)
         self.keep_hidden = True
         # hipGraph capture needs a non-default stream; all engine work runs on this one, fenced against the
         # caller's current stream on entry and exit.
@@ -276,12 +277,10 @@ class Qwen3Engine:
                 return self._prefill_on_stream(n_rows, n_req, max_kvlen, sampling, seed, feedback)
             key = ("prefill", n_rows, n_req, min(max(32, int(max_kvlen)), self.max_seq_len), bytes(sampling), seed, bool(feedback),
                    self.keep_hidden)
-            ent = self._graphs.get(key)
-            if ent is None:                                   # first sighting: eager (also sets kernel attributes)
-                if len(self._graphs) < getattr(self, "max_graphs", 512):
-                    self._graphs[key] = False
+            ent = self._prefill_graph(key)
+            if ent is None:                                   # not (yet) worth a graph: eager (also sets kernel attributes)
                 return self._prefill_on_stream(n_rows, n_req, max_kvlen, sampling, seed, feedback)
-            if ent is False:                                  # second: capture (capture does not execute), then fall through to replay
+            if ent is False:                                  # capture (capture does not execute), then fall through to replay
                 st = N.stream()
                 N.check(self.L.vox_graph_begin(self.ctx, st))
                 try:
@@ -289,8 +288,34 @@ class Qwen3Engine:
                 finally:
                     gh = ctypes.c_void_p()
                     N.check(self.L.vox_graph_end(self.ctx, st, ctypes.byref(gh)))
-                ent = self._graphs[key] = gh
+                ent = self._pf_graphs[key] = gh
             N.check(self.L.vox_graph_launch(ent, N.stream()))
+
+    # Prefill graphs live in their own bounded LRU, apart from the frame graphs: a shape is captured on its
+    # `prefill_capture_after`-th sighting (capture + instantiate cost more than one eager prefill, so a shape seen twice does
+    # not pay), at most `max_prefill_graphs` are kept and the least recently used one is destroyed when a new one arrives;
+    # sighting counters are bounded too (oldest forgotten).  The frame graphs (batch x kv bucket) are never evicted.
+    max_prefill_graphs = 64
+    prefill_capture_after = 3
+
+    def _prefill_graph(self, key):
+        """-> graph handle (replay), False (capture now) or None (run eagerly)."""
+        pg = self.__dict__.setdefault("_pf_graphs", OrderedDict())
+        seen = self.__dict__.setdefault("_pf_seen", OrderedDict())
+        g = pg.get(key)
+        if g is not None:
+            pg.move_to_end(key)
+            return g
+        n = seen.pop(key, 0) + 1
+        if n < self.prefill_capture_after:
+            seen[key] = n
+            while len(seen) > 1024:
+                seen.popitem(last=False)
+            return None
+        while len(pg) >= self.max_prefill_graphs:
+            _, old = pg.popitem(last=False)
+            self.L.vox_graph_destroy(old)
+        return False
 
     def _mutable_state(self):
         return [self.input_ids, self.input_masks, self.input_features, self.rng_offset]
@@ -314,10 +339,11 @@ class Qwen3Engine:
                                          int(feedback))
 
     def close(self):
-        for g in self._graphs.values():
+        for g in list(self._graphs.values()) + list(self.__dict__.get("_pf_graphs", {}).values()):
             if g:
                 self.L.vox_graph_destroy(g)
         self._graphs.clear()
+        self.__dict__.get("_pf_graphs", {}).clear()
         if self.h:
             self._native_destroy()
             self.h = None

@@ -111,7 +111,13 @@ class Scheduler:
             # one bad request must not take the serving loop down (the reference lets the exception escape run_forever):
             # in a prefill step the new prompt is the suspect, in a decode step every row of the failed launch is dropped
             self._fail_requests(fresh or lm_requests, ex)
+            self._undo_surviving_rows(fresh, lm_requests)
         self._finish_detokenize(pending_audio, detokenize_requests)
+
+    def _undo_surviving_rows(self, fresh, lm_requests):
+        """Decode rows piggy-backed onto a prefill step whose launch failed: their bookkeeping was advanced, nothing ran."""
+        if fresh and hasattr(self.model_worker, "undo_decode_advance"):
+            self.model_worker.undo_decode_advance([r for r in lm_requests if r not in fresh])
 
     # ---- detokenize beside the LM frame ----
     overlap_detokenize = True       # False: the reference's order (decode the audio, send it, then launch the LM step)
@@ -145,6 +151,7 @@ class Scheduler:
         for req in requests:
             self.logger.error(f"request {req.request_id} failed: {ex!r}")
             req.done_lm_prefill = req.done_lm_generation = req.done_all = True
+            req._failed = True           # its error COMPLETION is sent here: _send_responses must not send a second one
             req.finish_reason = f"error: {type(ex).__name__}"
             self.stats["failed"] += 1
             self._arrival.pop(req.request_id, None)
@@ -183,6 +190,7 @@ class Scheduler:
                 next_task = self.model_worker.run_lm_decode(lm_requests, lm_inputs)
         except Exception as ex:
             self._fail_requests(fresh or lm_requests, ex)
+            self._undo_surviving_rows(fresh, lm_requests)
         self._finish_detokenize(pending_audio, detokenize_requests)
         if task is not None:
             await task                          # step N-1's tokens -> request objects, while step N runs
@@ -309,6 +317,10 @@ class Scheduler:
     # ---- wire format ----
     def _send_responses(self, detokenize_requests):
         for req in detokenize_requests:
+            if getattr(req, "_failed", False):       # failed in this iteration's LM launch: already answered and freed
+                while not req.output_audio.empty():
+                    req.output_audio.get()
+                continue
             while not req.output_audio.empty():
                 chunk = req.output_audio.get()
                 if req.is_streaming:

@@ -113,7 +113,10 @@ class ModelWorker:
         input_ids_list, position_ids_list, feats, masks, reps = [], [], [], [], []
         is_prefill = any(not req.done_lm_prefill for req in lm_requests)
         prefill_flags = [not req.done_lm_prefill for req in lm_requests]
-        if self._pending is not None and (is_prefill or [r.request_id for r in lm_requests] != self._resident):
+        # An input-streaming decode row gets its text column rewritten on the host below (which invalidates residency), so the
+        # step restages from req.input_tokens / input_features: the deferred update of the previous step must land first.
+        if self._pending is not None and (is_prefill or [r.request_id for r in lm_requests] != self._resident
+                                          or any(getattr(r, "is_input_streaming", False) for r in lm_requests)):
             self.drain()             # this step reads per-request host state (restaging): finish the deferred update first
         ps = self.page_size
         # admission: preprocess the new prompts (once) and count the pages this step takes before touching any KV state
@@ -552,7 +555,11 @@ class ModelWorker:
                 d = req.audio_decode_idx[ci]
                 n_last.append(len(req.lm_output_audio_tokens[d: d + interval]))
         self.nvtx_range_pop()
-        return {"requests": requests, "mapping": mapping, "parts": parts, "event": event, "n_last": n_last}
+        # the done_all rule (worker/base.py:674-678) reads done_lm_generation / the token count as they are when run_detokenize is
+        # CALLED, i.e. before the LM step of the same scheduler iteration; with the overlap the second half runs after that
+        # step, so both are snapshotted here (an EOS sampled by this step must not end the request before its tail window)
+        done_snap = [(bool(r.done_lm_generation), len(r.lm_output_audio_tokens)) for r in requests]
+        return {"requests": requests, "mapping": mapping, "parts": parts, "event": event, "n_last": n_last, "done_snap": done_snap}
 
     def finish_detokenize(self, pending):
         """Second half of `run_detokenize`: wait for the audio of `launch_detokenize`, PCM16 -> the requests' output queues."""
@@ -569,9 +576,8 @@ class ModelWorker:
             if n_last < interval:
                 a16 = a16[:, : int(a16.shape[1] * (n_last - 0.5) / interval)]
             req.output_audio.put(a16.tobytes())
-        for req in requests:
-            if req.done_lm_generation and req.audio_decode_idx and (
-                    req.audio_decode_idx[-1] + interval >= len(req.lm_output_audio_tokens)):
+        for req, (was_done, n_tokens) in zip(requests, pending["done_snap"]):
+            if was_done and req.audio_decode_idx and req.audio_decode_idx[-1] + interval >= n_tokens:
                 req.done_all = True
 
     def run_watermark(self, audio):
@@ -587,6 +593,21 @@ class ModelWorker:
         if self.nvtx_enabled:
             torch.cuda.synchronize()
             torch.cuda.nvtx.range_pop()
+
+    def undo_decode_advance(self, requests: List[Request]):
+        """A launch failed after prepare_lm_inputs had advanced these decode rows (no K/V written, no token produced): put
+        their KV length / position / page bookkeeping back, so that the next step does not attend to an unwritten slot."""
+        ps = self.page_size
+        for req in requests:
+            if not req.done_lm_prefill or req.done_all or not getattr(req, "kv_pages", None):
+                continue
+            req.kv_token_len -= 1
+            req.next_position_id -= 1
+            req.kv_last_page_len -= 1
+            if req.kv_last_page_len == 0:
+                self.empty_pages.put(req.kv_pages.pop())
+                req.kv_last_page_len = ps
+        self._resident, self._pending = None, None      # the engine's rows are in an unknown state: restage next step
 
     def free_kv_cache(self, request: Request):
         if getattr(request, "kv_pages", None):

@@ -23,10 +23,11 @@ def shard_requests(requests: List, rank: int, dp_size: int) -> List:
     return [r for i, r in enumerate(requests) if route(i, dp_size) == rank]
 
 
-def broadcast_weights(weights: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 512 << 20, group=None):
+def broadcast_weights(weights: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = 512 << 20, group=None, force: bool = False):
     """In-place broadcast of a state dict whose keys/shapes every rank already knows (tensors pre-allocated on the
-    receiving ranks).  Tensors of one dtype are packed into flat buckets so that the ring moves few, large messages."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    receiving ranks).  Tensors of one dtype are packed into flat buckets so that the ring moves few, large messages.
+    force: go through the collective even in a one-rank group (bench.py --force-dist: the RCCL path on one GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return weights
     by_dtype = {}
     for k in sorted(weights):
