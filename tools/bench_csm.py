@@ -16,8 +16,8 @@ args = ap.parse_args()
 B, dev = args.batch, torch.device("cuda")
 cfg = CSMCfg()
 W = synth_csm_weights(cfg, dev)
-# algorithmic bytes of one frame: the backbone's weights once, the depth decoder's 31 times (one pass per codebook 1..31), the
-# heads once, K/V of the visible context; activations are negligible
+# algorithmic bytes of one frame: every weight once (backbone, depth decoder, heads) + K/V of the visible context; activations are
+# negligible.  As scheduled, the depth decoder's weights are read 31 times (one pass per codebook 1..31, Infinity-Cache hits)
 nb = lambda pred: sum(v.numel() * v.element_size() for k, v in W.items() if pred(k) and "embed" not in k)
 bytes_backbone = nb(lambda k: k.startswith("backbone_model.") or k == "lm_head.weight")
 bytes_depth = nb(lambda k: k.startswith("depth_decoder.model.layers.") or k.startswith("depth_decoder.model.norm") or "inputs_embeds_projector" in k)
@@ -96,11 +96,15 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 t1 = time.perf_counter(); mimi.decode(ring, code_layout="BTQ"); torch.cuda.synchronize(); t_codec = time.perf_counter() - t1
 frame_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+kv_bytes = B * (n0 + args.warmup + args.steps / 2) * cfg.backbone.layers * 2 * cfg.backbone.kv_heads * cfg.backbone.head_dim * 2
 print(json.dumps({"workload": f"CSM-1B bf16 + Mimi, batch={B}, greedy, 64-token prompt, detokenize_interval 10",
                   "audio_samples_per_s": B * 1920 * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                   "lm_frame_graph_ms": frame_ms, "mimi_chunk_ms": t_codec * 1e3, "realtime_factor_per_request": 1920 * args.steps / dt / 24000,
-                  "roofline": (lambda alg: {"bound": "hbm", "achieved": alg / (frame_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                            "frac": alg / (frame_ms * 1e-3) / 8e12, "traffic": None, "algorithmic_bytes_per_launch": alg,
-                                            "launch": "one hipGraph replay = one frame (backbone + 31 depth passes + samplers)"})(
-                      bytes_backbone + (cfg.n_codebooks - 1) * bytes_depth + bytes_heads
-                      + B * (n0 + args.warmup + args.steps / 2) * cfg.backbone.layers * 2 * cfg.backbone.kv_heads * cfg.backbone.head_dim * 2)}))
+                  "roofline": (lambda alg, sched: {"bound": "hbm", "achieved": alg / (frame_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                                   "frac": alg / (frame_ms * 1e-3) / 8e12, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                                                   "as_scheduled_bytes_per_launch": sched, "as_scheduled_frac": sched / (frame_ms * 1e-3) / 8e12,
+                                                   "launch": "one hipGraph replay = one frame (backbone + 31 depth passes + samplers)"})(
+                      # algorithmic = every weight byte once per frame (unique bytes; the depth decoder's 0.2 GB are re-read
+                      # by each of its 31 passes, served by the Infinity Cache: that figure is reported beside it as `as_scheduled`)
+                      bytes_backbone + bytes_depth + bytes_heads + kv_bytes,
+                      bytes_backbone + (cfg.n_codebooks - 1) * bytes_depth + bytes_heads + kv_bytes)}))

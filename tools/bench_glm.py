@@ -17,8 +17,26 @@ ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=20)
 ap.add_argument("--greedy", action="store_true")
 ap.add_argument("--exact-rows", type=int, default=2)
+ap.add_argument("--gpus", type=int, default=1, help="BASELINE config 5: data-parallel replicas, one process per GPU (8 requests each = 64 "
+                "concurrent requests on 8 GPUs); without a launcher the script starts its ranks itself under torch.distributed.run")
 args = ap.parse_args()
-B, dev = args.batch, torch.device("cuda")
+if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    import socket, subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+                              "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env))
+rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+if world != args.gpus:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+torch.cuda.set_device(local)
+B, dev = args.batch, torch.device("cuda", local)
+if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=dev)       # replicas only: a barrier and a max-reduce of the time, nothing on the token path
 if args.exact_rows != 2:
     from vox_serve_amd import _native as _N
     _N.set_exact_rows(args.exact_rows)
@@ -66,15 +84,27 @@ def step(timed):
 for i in range(max(args.warmup, 80)):
     step(False)
 torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
 t0 = time.perf_counter()
 for i in range(args.steps):
     step(True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+if world > 1:
+    dist.barrier()
+    t_ = torch.tensor([dt, float(samples[0])], device=dev, dtype=torch.float64)
+    tmax, ssum = t_.clone(), t_.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(ssum, op=dist.ReduceOp.SUM)
+    dt, samples[0] = float(tmax[0].item()), float(ssum[1].item())
+    dist.destroy_process_group()
+    if rank != 0:
+        sys.exit(0)
 frame_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 wbytes = sum(t.numel() * 2 for l in layers for t in l.values()) + head.numel() * 2
-print(json.dumps({"workload": f"GLM-4-Voice-9B bf16 LM, batch={B}/GPU, {'greedy' if args.greedy else 'top-p 0.8 T 0.8 over 168960 ids'}, 64-token context",
-                  "lm_tokens_per_s": B * args.steps / dt, "audio_seconds_per_s": B * args.steps / dt / 12.5, "ms_per_step": dt / args.steps * 1e3,
+print(json.dumps({"workload": f"GLM-4-Voice-9B bf16 LM, batch={B}/GPU x {world} GPU(s) (data-parallel replicas), {'greedy' if args.greedy else 'top-p 0.8 T 0.8 over 168960 ids'}, 64-token context",
+                  "n_gpus": world, "concurrent_requests": B * world, "scaling": "weak",
+                  "lm_tokens_per_s": world * B * args.steps / dt, "audio_seconds_per_s": world * B * args.steps / dt / 12.5, "ms_per_step": dt / args.steps * 1e3,
                   "lm_graph_ms": frame_ms, "weight_bytes_streamed": wbytes, "exact_rows": args.exact_rows,
                   "audio_samples_per_s": samples[0] / dt, "detokenizer_window_ms": float(np.mean(chunk_ms)) if chunk_ms else None,
                   "roofline": {"bound": "hbm", "achieved": wbytes / (frame_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
