@@ -317,6 +317,8 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
             if (ablate() & 1) {
             } else if (decode_rows && c.max_kvlen <= 16 && !(ablate() & 512) && vox_attn_short_supported(ac)) {
                 VOX_TRY(vox_launch_attn_short(st, ac));      // one wave per (row, kv head), registers only
+            } else if (decode_rows && !(ablate() & 1024) && vox_attn_decode8_supported(ac)) {
+                VOX_TRY(vox_launch_attn_decode8(st, ac));    // <= 256 visible tokens: every chunk and the merge in one launch
             } else {
                 VOX_TRY(vox_launch_attn_partial(st, ac));
                 if (mc > 1) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc, ac.out_frag));

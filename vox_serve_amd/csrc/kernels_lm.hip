@@ -1622,6 +1622,190 @@ int vox_launch_attn_partial(hipStream_t st, const AttnCall& c) {
 }
 
 // ================================================================================================
+// One-launch decode attention for contexts of up to 8 chunks (<= 256 visible tokens): one 1024-thread block per
+// (kv head, row) runs every chunk of that pair — NG groups of 1024 / NG threads, group q taking chunks q, q + NG, ... — and
+// merges the partials in LDS: the separate merge launch (a whole dependent stage of the frame: 4.7 us + a kernel boundary
+// per talker layer) disappears.  Per chunk the arithmetic is k_attn_partial<D, true>'s, the merge is k_attn_merge's (global
+// max, then L / O accumulated over the chunks in ascending order): bit-identical outputs.  With NG = 8 every chunk has its own
+// group of two waves (all chunks in flight at once); K/V tiles are requested before the q prologue.  The token loops run
+// over the whole zero-padded tile without predicates (p = 0 beyond the chunk's last token: l + 0 and fma(0, v, o) leave the
+// sums bit-unchanged), so that the LDS reads of consecutive tokens overlap.
+// (An earlier one-launch variant gave each chunk ONE wave and lost: a 32-token chunk is too long a serial chain for a wave.)
+template <int D, int GMAX, int NG>
+__global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
+    constexpr int LPT = D / 8, TPW = 64 / LPT, NCH = 8, GT = 1024 / NG, GW = GT / 64, CPG = NCH / NG;
+    constexpr int KVL = (VOX_TC * LPT + GT - 1) / GT;
+    __shared__ __attribute__((aligned(16))) uint4 Ks[NG][VOX_TC * LPT];
+    __shared__ __attribute__((aligned(16))) uint4 Vs[NG][VOX_TC * LPT];
+    __shared__ __attribute__((aligned(16))) uint4 Qs[GMAX * LPT];
+    __shared__ float S[NG][GMAX][VOX_TC];
+    __shared__ float Ms[NG][GMAX];
+    __shared__ float Sh[16 * D];
+    __shared__ __attribute__((aligned(16))) bf16_t Knew[D];
+    __shared__ float Po[NCH][GMAX][D];
+    __shared__ float2 Pml[NCH][GMAX];
+
+    const int hk = blockIdx.x, row = blockIdx.y;
+    const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
+    const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..8
+    const int G = a.Hq / a.Hkv;
+    const int tid = threadIdx.x, lane = tid & 63, wave16 = tid >> 6;
+    const int grp = tid / GT, gt = tid % GT, gw = wave16 % GW;
+    const int* pages = a.identity_pages ? nullptr
+                       : (a.ptab ? a.ptab + (size_t)row * a.pt_stride : a.indices + a.indptr[a.q_req[row]]);
+    const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
+
+    // K/V tiles of this group's chunks (the row's newest token, index L - 1, comes from the projection output instead)
+    uint4 kreg[CPG][KVL], vreg[CPG][KVL];
+#pragma unroll
+    for (int ci = 0; ci < CPG; ++ci) {
+        const int t0 = (grp + NG * ci) * VOX_TC;
+#pragma unroll
+        for (int u = 0; u < KVL; ++u) {
+            const int i = gt + GT * u, t = i / LPT, j = i % LPT;
+            kreg[ci][u] = make_uint4(0, 0, 0, 0);
+            vreg[ci][u] = kreg[ci][u];
+            const int tok = t0 + t;
+            if (i < VOX_TC * LPT && tok < L - 1) {
+                const int pgi = pages ? pages[tok / a.page_size] : row;
+                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
+                kreg[ci][u] = reinterpret_cast<const uint4*>(base)[j];
+                vreg[ci][u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
+            }
+        }
+    }
+    {   // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave
+        const int nqkv = (a.Hq + 2 * a.Hkv) * D;
+        const bf16_t* raw = a.qkv + (size_t)row * nqkv;
+        int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
+        p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
+        const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
+        for (int h = wave16; h < G + 1; h += 16) {
+            const bool isk = h == G;
+            const bf16_t* src = isk ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * G + h) * D;
+            bf16_t* dst = isk ? Knew : reinterpret_cast<bf16_t*>(Qs) + (size_t)h * D;
+            prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, Sh + wave16 * D, dst, lane);
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CPG; ++ci) {
+        const int c = grp + NG * ci, t0 = c * VOX_TC;
+        const bool live = t0 < L;
+        const int nt = live ? ((L - t0) < VOX_TC ? (L - t0) : VOX_TC) : 0;
+        const bool own_last = live && (t0 + nt == L);
+        if (ci > 0) __syncthreads();           // the previous chunk's tile is dead
+#pragma unroll
+        for (int u = 0; u < KVL; ++u) {
+            const int i = gt + GT * u;
+            if (i < VOX_TC * LPT) { Ks[grp][i] = kreg[ci][u]; Vs[grp][i] = vreg[ci][u]; }
+        }
+        __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
+        if (own_last) {
+            // place the new token into the tile and append it to the paged cache (page < 0: graph padding row)
+            const bf16_t* vraw = a.qkv + (size_t)row * (a.Hq + 2 * a.Hkv) * D + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D;
+            const int pg = a.identity_pages ? row : a.page[row];
+            const int sl = a.identity_pages ? (L - 1) : a.slot[row];
+            if (gt < LPT) {
+                const uint4 kx = reinterpret_cast<const uint4*>(Knew)[gt];
+                const uint4 vx = reinterpret_cast<const uint4*>(vraw)[gt];
+                Ks[grp][(nt - 1) * LPT + gt] = kx;
+                Vs[grp][(nt - 1) * LPT + gt] = vx;
+                if (pg >= 0) {
+                    bf16_t* base = a.kv_w + (size_t)pg * ps + ((size_t)sl * a.Hkv + hk) * D;
+                    reinterpret_cast<uint4*>(base)[gt] = kx;
+                    reinterpret_cast<uint4*>(base + (size_t)a.page_size * a.Hkv * D)[gt] = vx;
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {      // scores: LPT lanes per token, butterfly over LPT lanes
+#pragma unroll
+            for (int tb = gw * TPW; tb < VOX_TC; tb += GW * TPW) {
+                const int tt = tb + lane / LPT, j = lane % LPT;
+                const uint4 kx = Ks[grp][tt * LPT + j];
+                for (int g = 0; g < G; ++g) {
+                    float d = dot8(Qs[g * LPT + j], kx, 0.0f);
+                    d = butterfly<LPT>(d);
+                    if (j == 0) S[grp][g][tt] = d * a.scale;
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {      // chunk max + p = exp2((s-m)*log2e): 32 lanes per q head
+            for (int pr = gt; pr < G * VOX_TC; pr += GT) {
+                const int g = pr / VOX_TC, t = pr % VOX_TC;
+                const float s = t < nt ? S[grp][g][t] : -INFINITY;
+                float m = s;
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, VOX_WAVE));
+                const float p = t < nt ? exp2_c((s - m) * VOX_LOG2E) : 0.0f;
+                S[grp][g][t] = p;
+                if (t == 0) Ms[grp][g] = m;
+            }
+        }
+        __syncthreads();
+        if (live) {      // PV: one thread per (q head, d); sequential over the tokens of the (zero-padded) tile
+            const bf16_t* Vb = reinterpret_cast<const bf16_t*>(Vs[grp]);
+            for (int e = gt; e < G * D; e += GT) {
+                const int g = e / D, d = e % D;
+                float o = 0.0f, l = 0.0f;
+#pragma unroll
+                for (int t = 0; t < VOX_TC; ++t) {
+                    const float p = S[grp][g][t];          // 0 for t >= nt
+                    l = l + p;
+                    o = __fmaf_rn(p, bf2f(Vb[t * D + d]), o);
+                }
+                Po[c][g][d] = o;
+                if (d == 0) Pml[c][g] = make_float2(Ms[grp][g], l);
+            }
+        }
+    }
+    __syncthreads();
+    // merge (k_attn_merge): global max, then L and O over the chunks in ascending order
+    for (int e = tid; e < G * D; e += 1024) {
+        const int g = e / D, d = e % D;
+        float M = -INFINITY, Lsum = 0.0f, O = 0.0f;
+        for (int c = 0; c < nc; ++c) M = fmaxf(M, Pml[c][g].x);
+        for (int c = 0; c < nc; ++c) {
+            const float w = exp2_c((Pml[c][g].x - M) * VOX_LOG2E);
+            Lsum = __fmaf_rn(Pml[c][g].y, w, Lsum);
+            O = __fmaf_rn(Po[c][g][d], w, O);
+        }
+        const bf16_t r = f2bf(O / Lsum);
+        const int h = hk * G + g;
+        a.out[((size_t)row * a.Hq + h) * D + d] = r;
+        if (a.out_frag) a.out_frag[frag_off(row, h * D + d, a.Hq * D)] = r;
+    }
+}
+
+// true when the one-launch decode attention covers the call (fused decode rows, <= 8 chunks, a supported head shape)
+bool vox_attn_decode8_supported(const AttnCall& c) {
+    if (!c.qkv || !c.out || c.Nq < 1 || c.Hkv < 1 || c.Hq % c.Hkv) return false;
+    const int nchunk = (c.max_kvlen + VOX_TC - 1) / VOX_TC, G = c.Hq / c.Hkv;
+    if (nchunk < 2 || nchunk > 8) return false;
+    return (c.D == 128 && (G == 2 || G == 16)) || (c.D == 64 && (G == 4 || G == 7));
+}
+int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
+    if (!vox_attn_decode8_supported(c)) return vox_fail(VOX_ERR_INVALID, "attn_decode8: unsupported shape");
+    AttnArgs a{};
+    a.q = (const bf16_t*)c.q; a.kv = (const bf16_t*)c.kv; a.q_req = c.q_req; a.q_kvlen = c.q_kvlen;
+    a.indptr = c.indptr; a.indices = c.indices; a.scale = c.scale;
+    a.Hq = c.Hq; a.Hkv = c.Hkv; a.page_size = c.page_size; a.max_chunks = c.max_chunks;
+    a.qkv = (const bf16_t*)c.qkv; a.kv_w = (bf16_t*)const_cast<void*>(c.kv); a.qn = (const bf16_t*)c.qn;
+    a.kn = (const bf16_t*)c.kn; a.cs = c.cs; a.pos = c.pos; a.page = c.page; a.slot = c.slot; a.eps = c.eps;
+    a.rot = c.rot; a.interleave = c.interleave; a.table_max_pos = c.table_max_pos;
+    a.ptab = c.ptab; a.pt_stride = c.pt_stride; a.fixed_kvlen = c.fixed_kvlen; a.fixed_pos = c.fixed_pos;
+    a.identity_pages = c.identity_pages;
+    a.out = (bf16_t*)c.out; a.out_frag = (bf16_t*)c.out_frag;
+    const dim3 grid(c.Hkv, c.Nq);
+    const int G = c.Hq / c.Hkv;
+#define VOX_AD(D_, G_, NG_) if (c.D == D_ && G == G_) { hipLaunchKernelGGL((k_attn_decode8<D_, G_, NG_>), grid, dim3(1024), 0, st, a); return VOX_OK; }
+    VOX_AD(128, 2, 8) VOX_AD(128, 16, 4) VOX_AD(64, 4, 8) VOX_AD(64, 7, 8)
+#undef VOX_AD
+    return vox_fail(VOX_ERR_INVALID, "attn_decode8: no variant");
+}
+
+// ================================================================================================
 // Short-context decode attention (depth transformer: <= 16 visible tokens, D = 128, two q heads per kv head).
 // One WAVE per (row, kv head), no LDS, no barrier.  Lane = 16*grp + j holds 16-byte chunk j of: q head 0 (grp 0),
 // q head 1 (grp 1), the new k (grp 2), the new v (grp 3) — norm, RoPE (partner chunk = lane ^ 8) and the dot products

@@ -108,6 +108,8 @@ struct AttnCall {
     int pt_stride = 0, fixed_kvlen = 0, fixed_pos = -1, identity_pages = 0;
 };
 int vox_launch_attn_partial(hipStream_t st, const AttnCall& c);
+bool vox_attn_decode8_supported(const AttnCall& c);      // decode rows, 2..8 chunks: every chunk + the merge in one launch
+int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c);
 bool vox_attn_short_supported(const AttnCall& c);
 int vox_launch_attn_short(hipStream_t st, const AttnCall& c);
 bool vox_attn1_linear_supported(const AttnCall& c, const struct LinearCall& l);
