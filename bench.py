@@ -329,6 +329,13 @@ def serving_ttfa(dev, shared, n_requests, load, interval=INTERVAL, seed=0):
     s = Scheduler(w, max_batch_size=mb, transport=t)
     rng = np.random.default_rng(seed)
     counter = [0]
+    first_audio = {}
+
+    def on_send(payload):       # the moment `id|AUDIO|...` is handed to the result transport (a consumer of the queue / socket sees it
+        rid_, kind_, _ = payload.split(b"|", 2)       # then; the scheduler goes on to launch the step's LM frame after the send)
+        if kind_ == b"AUDIO":
+            first_audio.setdefault(rid_.decode(), time.perf_counter())
+    t.on_send = on_send
 
     def submit(tag):
         counter[0] += 1
@@ -361,7 +368,7 @@ def serving_ttfa(dev, shared, n_requests, load, interval=INTERVAL, seed=0):
             s._step()
             if drain(rid):
                 break
-        out.append((time.perf_counter() - t0) * 1e3)
+        out.append((first_audio[rid] - t0) * 1e3)
         if load == 0:
             s.run_until_idle(1000)       # let the probe finish so that the next one runs alone
             drain()
@@ -571,7 +578,7 @@ def main():
             "realtime_factor": head["realtime_factor_per_request"],
             "ttfa_ms_p50": serving.get("ttfa_ms_p50", head.get("ttfa_ms_p50_engine")),
             "ttfa_ms_p50_detokenize_interval_2": serving.get("ttfa_ms_p50_detokenize_interval_2", head.get("ttfa_ms_p50_engine_detokenize_interval_2")),
-            "ttfa_path": ("encode_request -> Scheduler -> ModelWorker -> first id|AUDIO| on the result queue, p50" if serving
+            "ttfa_path": ("encode_request -> Scheduler -> ModelWorker -> first id|AUDIO| handed to the result transport (send time), p50" if serving
                           else "engine lock-step loop (request start -> first PCM chunk on the host), p50"),
             "roofline": head["roofline"],
         }

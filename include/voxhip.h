@@ -120,6 +120,14 @@ int vox_rep_penalty(vox_ctx* ctx, void* stream, void* logits, const uint8_t* cac
 /* Sampler.update_repetition_penalty_cache, codebook-0 form incl. the cross-request leak (sampling.py:150-178) */
 int vox_rep_update(vox_ctx* ctx, void* stream, uint8_t* cache, const int32_t* ids, int B, int W, int C, int V,
                    int window);
+/* The multi-codebook forms of the two (sampling.py:122-178 with logits [B, Cl, V] / output_ids [B, Cl], Cl == C > 1): the
+ * penalty of logits row (b, c) looks at cache codebook c; the update marks, like the reference's advanced-indexing assignment
+ * `repetition_cache[:, w, :, output_ids] = True`, EVERY id of the step in EVERY batch row and EVERY codebook plane (all window
+ * slots for the global window, the newest slot after the shift otherwise). */
+int vox_rep_penalty_mc(vox_ctx* ctx, void* stream, void* logits, const uint8_t* cache, int B, int Cl, int W, int C, int V,
+                       float penalty);
+int vox_rep_update_mc(vox_ctx* ctx, void* stream, uint8_t* cache, const int32_t* ids, int B, int Cl, int W, int C, int V,
+                      int window);
 /* Sampler.run_sampling (sampling.py:85-118): out_ids int32 [B].  Stochastic modes draw from a Philox4x32-10
  * stream keyed by (seed, offset, row) — the contract oracle/voxref.c::vr_sample restates. */
 int vox_sample(vox_ctx* ctx, void* stream, const void* logits, int B, int V, const vox_sampling_config* cfg,

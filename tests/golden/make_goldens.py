@@ -65,6 +65,28 @@ def g1_sampler(ns):
     print("g1 ok", len(out))
 
 
+def g19_sampler_mc(ns):
+    """Sampler.apply_repetition_penalty / update_repetition_penalty_cache in their multi-codebook forms (logits [B, C, V],
+    output_ids [B, C], C > 1: sampling.py:122-178)."""
+    S = ns.sampling
+    out = {}
+    g = torch.Generator().manual_seed(19)
+    B, W, C, V = 3, 2, 4, 320
+    logits = torch.randn(B, C, V, generator=g).to(torch.bfloat16)
+    cache = torch.rand(B, W, C, V, generator=g) < 0.1
+    pen = S.Sampler.apply_repetition_penalty(logits.clone(), cache, 1.3)
+    out["pen_logits"], out["pen_cache"], out["pen_out"] = bits(logits), cache.numpy().astype(np.uint8), bits(pen)
+    for tag, (Wn, window) in {"glob": (1, -1), "win": (3, 3)}.items():
+        c = torch.rand(B, Wn, C, V, generator=g) < 0.02
+        ids = torch.randint(0, V, (B, C), generator=g)
+        c2 = c.clone()
+        S.Sampler.update_repetition_penalty_cache(c2, ids, window)
+        out[f"upd_{tag}_in"], out[f"upd_{tag}_ids"], out[f"upd_{tag}_out"] = (
+            c.numpy().astype(np.uint8), ids.numpy().astype(np.int32), c2.numpy().astype(np.uint8))
+    np.savez_compressed(os.path.join(HERE, "g19_sampler_mc.npz"), **out)
+    print("g19 ok", len(out))
+
+
 # --------------------------------------------------------------------------------------------------
 def g2_wrappers(ns):
     """plan() page/slot arithmetic and set_kv_cache layout (flashinfer_utils.py:60-145,189-244)."""
@@ -1285,7 +1307,7 @@ def g17_flow_evolving(ns):
     np.savez_compressed(os.path.join(HERE, "g17_flow_evolving.npz"), **out)
 
 
-ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g18": g18_qwen3_lm_b12, "g4": g4_qwen3_codec, "g6": g6_host_traces,
+ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g18": g18_qwen3_lm_b12, "g19": g19_sampler_mc, "g4": g4_qwen3_codec, "g6": g6_host_traces,
        "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder, "g17": g17_flow_evolving}
 
 if __name__ == "__main__":

@@ -201,6 +201,34 @@ def test_repetition_penalty_and_update_goldens(dev, golden):
         assert np.array_equal(c.cpu().numpy().astype(np.uint8), g[f"upd_{tag}_out"])
 
 
+def test_multi_codebook_repetition_penalty_and_update(dev, golden):
+    """logits [B, C, V] / output_ids [B, C] with C > 1 (sampling.py:122-178): the native kernels equal the reference's outputs (g19)
+    and the oracle on a second, larger random case; mismatched codebook counts are rejected."""
+    from oracle import sampler_mc_ref as MR
+    from vox_serve_amd.sampling import Sampler
+    g = golden("g19_sampler_mc")
+    out = Sampler.apply_repetition_penalty(T(g["pen_logits"], dev), torch.from_numpy(g["pen_cache"]).to(dev).bool(), 1.3)
+    assert np.array_equal(Bits(out), g["pen_out"])
+    for tag, window in (("glob", -1), ("win", 3)):
+        c = torch.from_numpy(g[f"upd_{tag}_in"]).to(dev).bool()
+        Sampler.update_repetition_penalty_cache(c, torch.from_numpy(g[f"upd_{tag}_ids"]).to(dev), window)
+        assert np.array_equal(c.cpu().numpy().astype(np.uint8), g[f"upd_{tag}_out"]), tag
+    rng = np.random.default_rng(5)
+    B, W, C, V = 5, 3, 8, 2051
+    lg = vr.f2bf(rng.standard_normal((B, C, V)).astype(np.float32) * 2)
+    cache = (rng.random((B, W, C, V)) < 0.05).astype(np.uint8)
+    out = Sampler.apply_repetition_penalty(T(lg, dev), torch.from_numpy(cache).to(dev).bool(), 1.1)
+    assert np.array_equal(Bits(out), MR.rep_penalty_mc(lg, cache, 1.1))
+    ids = rng.integers(0, V, (B, C)).astype(np.int64)
+    for window in (-1, W):
+        ct, want = torch.from_numpy(cache).to(dev).bool(), cache.copy()
+        Sampler.update_repetition_penalty_cache(ct, torch.from_numpy(ids).to(dev), window)
+        MR.rep_update_mc(want, ids, window)
+        assert np.array_equal(ct.cpu().numpy().astype(np.uint8), want), window
+    with pytest.raises(ValueError):
+        Sampler.apply_repetition_penalty(T(lg[:, :3], dev), torch.from_numpy(cache).to(dev).bool(), 1.1)
+
+
 @pytest.mark.parametrize("B,V,k,p,mp,T_", [(4, 3072, 50, 1.0, 0.0, 0.9), (8, 2048, 50, 1.0, 0.0, 0.9),
                                           (3, 2051, 25, 0.8, 0.0, 1.0), (2, 6564, 25, 1.0, 0.1, 0.7),
                                           (5, 512, 200, 0.95, 0.0, 1.3), (2, 300, 256, 1.0, 0.0, 1.0)])

@@ -548,3 +548,16 @@ def test_flow_evolving_cache_mode_pin(golden):
             assert [cache["enc"].shape[3], cache["up"].shape[3], cache["att"].shape[5]] == g["cache_lens"][k].tolist(), k
             assert abs(float(cache["att"].double().sum()) - float(g[f"att_cache_sum_{k}"])) < 1e-3 * (1 + abs(float(g[f"att_cache_sum_{k}"])))
             assert np.sqrt(((speech.numpy() - g[f"speech_cache_{k}"]) ** 2).mean()) < 2e-4
+
+
+# ---------------------------------------------------------------- g19: multi-codebook repetition penalty -
+def test_multi_codebook_repetition_penalty_against_reference(golden):
+    """Sampler.apply_repetition_penalty / update_repetition_penalty_cache with logits [B, C, V] / output_ids [B, C], C > 1
+    (sampling.py:122-178): the numpy restatement equals the reference's outputs bit for bit."""
+    from oracle import sampler_mc_ref as MR
+    g = golden("g19_sampler_mc")
+    assert np.array_equal(MR.rep_penalty_mc(g["pen_logits"], g["pen_cache"], 1.3), g["pen_out"])
+    for tag, window in (("glob", -1), ("win", 3)):
+        c = g[f"upd_{tag}_in"].copy()
+        MR.rep_update_mc(c, g[f"upd_{tag}_ids"], window)
+        assert np.array_equal(c, g[f"upd_{tag}_out"]), tag

@@ -86,6 +86,8 @@ _SIGS = {
     "vox_suppress": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),
     "vox_rep_penalty": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float]),
     "vox_rep_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "vox_rep_penalty_mc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float]),
+    "vox_rep_update_mc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     "vox_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(SamplingCfg), c_uint64, c_uint64,
                            c_void_p]),
     "vox_stack_create": (c_int, [c_void_p, POINTER(StackConfig), POINTER(LayerWeights), c_void_p, c_void_p, c_int,

@@ -190,6 +190,16 @@ int vox_rep_update(vox_ctx* ctx, void* stream, uint8_t* cache, const int32_t* id
     (void)ctx;
     return vox_launch_rep_update((hipStream_t)stream, cache, ids, B, W, C, V, window);
 }
+int vox_rep_penalty_mc(vox_ctx* ctx, void* stream, void* logits, const uint8_t* cache, int B, int Cl, int W, int C, int V,
+                       float penalty) {
+    (void)ctx;
+    return vox_launch_rep_penalty_mc((hipStream_t)stream, logits, cache, B, Cl, W, C, V, penalty);
+}
+int vox_rep_update_mc(vox_ctx* ctx, void* stream, uint8_t* cache, const int32_t* ids, int B, int Cl, int W, int C, int V,
+                      int window) {
+    (void)ctx;
+    return vox_launch_rep_update_mc((hipStream_t)stream, cache, ids, B, Cl, W, C, V, window);
+}
 int vox_sample(vox_ctx* ctx, void* stream, const void* logits, int B, int V, const vox_sampling_config* cfg,
                uint64_t seed, uint64_t offset, int32_t* out_ids) {
     if (!cfg) return vox_fail(VOX_ERR_INVALID, "sample: cfg NULL");

@@ -556,6 +556,36 @@ int vox_launch_rep_penalty(hipStream_t st, void* logits, const uint8_t* cache, i
     return VOX_OK;
 }
 
+// multi-codebook form: logits [B, Cl, V]; row (b, c) is penalised by cache codebook c
+__global__ void k_rep_penalty_mc(bf16_t* lg, const uint8_t* cache, int Cl, int W, int C, int V, float p) {
+    const int b = blockIdx.y / Cl, c = blockIdx.y % Cl;
+    bf16_t* row = lg + ((size_t)b * Cl + c) * V;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+        int m = 0;
+        for (int w = 0; w < W; ++w) m |= cache[(((size_t)b * W + w) * C + c) * V + v];
+        if (m) {
+            const float l = bf2f(row[v]);
+            row[v] = f2bf(l > 0.0f ? l / p : l * p);
+        }
+    }
+}
+int vox_launch_rep_penalty_mc(hipStream_t st, void* logits, const uint8_t* cache, int B, int Cl, int W, int C, int V, float p) {
+    if (B <= 0 || Cl <= 0) return VOX_OK;
+    if (Cl > C) return vox_fail(VOX_ERR_INVALID, "rep_penalty_mc: more logit codebooks than cache codebooks");
+    hipLaunchKernelGGL(k_rep_penalty_mc, dim3((V + 255) / 256, B * Cl), dim3(256), 0, st, (bf16_t*)logits, cache, Cl, W, C, V, p);
+    return VOX_OK;
+}
+// every (row b, slot w, plane c) receives every id of the step: ids [B * Cl]
+__global__ void k_rep_set_mc(uint8_t* cache, const int* ids, int n_ids, int B, int W, int C, int V, int only_last) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * W * C * n_ids;
+    if (i >= total) return;
+    const int j = (int)(i % n_ids), c = (int)((i / n_ids) % C), w = (int)((i / ((size_t)n_ids * C)) % W), b = (int)(i / ((size_t)n_ids * C * W));
+    if (only_last && w != W - 1) return;
+    cache[(((size_t)b * W + w) * C + c) * V + ids[j]] = 1;
+}
+int vox_launch_rep_update_mc(hipStream_t st, uint8_t* cache, const int* ids, int B, int Cl, int W, int C, int V, int window);
+
 // window shift (one block per batch row), then the leak-faithful set: every row gets every request's id
 __global__ void k_rep_shift(uint8_t* cache, int W, int C, int V) {
     uint8_t* cb = cache + (size_t)blockIdx.x * W * C * V;
@@ -579,6 +609,14 @@ int vox_launch_rep_update(hipStream_t st, uint8_t* cache, const int* ids, int B,
     if (window > 1) hipLaunchKernelGGL(k_rep_shift, dim3(B), dim3(256), 0, st, cache, W, C, V);
     const int total = B * W * B;
     hipLaunchKernelGGL(k_rep_set, dim3((total + 255) / 256), dim3(256), 0, st, cache, ids, B, W, C, V,
+                       window > 1 ? 1 : 0);
+    return VOX_OK;
+}
+int vox_launch_rep_update_mc(hipStream_t st, uint8_t* cache, const int* ids, int B, int Cl, int W, int C, int V, int window) {
+    if (B <= 0 || Cl <= 0) return VOX_OK;
+    if (window > 1) hipLaunchKernelGGL(k_rep_shift, dim3(B), dim3(256), 0, st, cache, W, C, V);
+    const size_t total = (size_t)B * W * C * B * Cl;
+    hipLaunchKernelGGL(k_rep_set_mc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cache, ids, B * Cl, B, W, C, V,
                        window > 1 ? 1 : 0);
     return VOX_OK;
 }

@@ -156,3 +156,5 @@ int vox_launch_sample(hipStream_t st, const SampleCall& c);
 int vox_launch_suppress(hipStream_t st, void* logits, int B, int V, const int* ids, int n);
 int vox_launch_rep_penalty(hipStream_t st, void* logits, const uint8_t* cache, int B, int W, int C, int V, float p);
 int vox_launch_rep_update(hipStream_t st, uint8_t* cache, const int* ids, int B, int W, int C, int V, int window);
+int vox_launch_rep_penalty_mc(hipStream_t st, void* logits, const uint8_t* cache, int B, int Cl, int W, int C, int V, float p);
+int vox_launch_rep_update_mc(hipStream_t st, uint8_t* cache, const int* ids, int B, int Cl, int W, int C, int V, int window);

@@ -66,21 +66,30 @@ class Sampler:
 
     @classmethod
     def apply_repetition_penalty(cls, logits: torch.Tensor, repetition_cache: torch.Tensor, penalty: float):
+        """sampling.py:122-146: logits [B, Cl, V], cache [B, W, C, V]; Cl == 1 reads cache codebook 0, Cl == C codebook c per row."""
         b, c1, v = logits.shape
-        if c1 != 1:
-            raise NotImplementedError("multi-codebook logits: only the codebook-0 form used by the hot path is native")
         out = logits.contiguous().clone()
         cache = repetition_cache.contiguous().view(torch.uint8)
         _, w, c, _ = cache.shape
-        N.check(N.lib().vox_rep_penalty(N.ctx(), N.stream(), N.ptr(out), N.ptr(cache), b, w, c, v, float(penalty)))
+        if c1 == 1:
+            N.check(N.lib().vox_rep_penalty(N.ctx(), N.stream(), N.ptr(out), N.ptr(cache), b, w, c, v, float(penalty)))
+        else:
+            if c1 != c:
+                raise ValueError(f"logits cover {c1} codebooks, the repetition cache {c}")       # (torch.where would not broadcast either)
+            N.check(N.lib().vox_rep_penalty_mc(N.ctx(), N.stream(), N.ptr(out), N.ptr(cache), b, c1, w, c, v, float(penalty)))
         return out
 
     @classmethod
     def update_repetition_penalty_cache(cls, repetition_cache: torch.Tensor, output_ids: torch.Tensor, window_size: int):
-        if output_ids.shape[1] != 1:
-            raise NotImplementedError("only the codebook-0 form used by the hot path is native")
+        """sampling.py:150-178, in place.  output_ids [B, 1] with a C-codebook cache: the codebook-0 form (incl. the reference's
+        cross-request leak); output_ids [B, C]: the reference's `cache[:, w, :, output_ids] = True` — every id in every plane."""
         assert repetition_cache.is_contiguous()
         b, w, c, v = repetition_cache.shape
-        ids = output_ids[:, 0].to(torch.int32).contiguous()
-        N.check(N.lib().vox_rep_update(N.ctx(), N.stream(), N.ptr(repetition_cache.view(torch.uint8)), N.ptr(ids), b, w,
-                                       c, v, int(window_size)))
+        cl = output_ids.shape[1]
+        cache8 = repetition_cache.view(torch.uint8)
+        if cl == 1:
+            ids = output_ids[:, 0].to(torch.int32).contiguous()
+            N.check(N.lib().vox_rep_update(N.ctx(), N.stream(), N.ptr(cache8), N.ptr(ids), b, w, c, v, int(window_size)))
+        else:
+            ids = output_ids.to(torch.int32).contiguous()
+            N.check(N.lib().vox_rep_update_mc(N.ctx(), N.stream(), N.ptr(cache8), N.ptr(ids), b, cl, w, c, v, int(window_size)))

@@ -21,6 +21,7 @@ class QueueTransport:
 
     def __init__(self):
         self.requests, self.results = queue.Queue(), queue.Queue()
+        self.on_send = None      # optional callback(payload) at the moment a result is handed to the transport (latency probes)
 
     def recv_request(self) -> Optional[bytes]:
         try:
@@ -30,6 +31,8 @@ class QueueTransport:
 
     def send_result(self, payload: bytes):
         self.results.put(payload)
+        if self.on_send is not None:
+            self.on_send(payload)
 
 
 class ZmqTransport:
