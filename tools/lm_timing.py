@@ -31,6 +31,19 @@ def plan(kvlen):
 for w in range(5):
     plan(kvlen0 + w); eng.frame(B, kvlen0 + w, sc, use_graph=use_graph)
 torch.cuda.synchronize()
+if os.environ.get("LM_ASYNC") == "1":
+    # frames enqueued back to back, no host synchronisation in between (GPU never idles): plans of a fixed kv length
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    plan(kvlen0 + 5)
+    with eng._OnStream(eng):
+        ev0.record()
+    for f in range(frames):
+        eng.frame(B, kvlen0 + 5, sc, use_graph=use_graph)
+    with eng._OnStream(eng):
+        ev1.record()
+    eng.stream.synchronize()
+    print(f"B={B} back-to-back: gpu {ev0.elapsed_time(ev1)/frames:.3f} ms/frame")
+    sys.exit(0)
 t0 = time.perf_counter()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 gpu_ms = 0.0
