@@ -566,6 +566,19 @@ int vox_flow_set_prompt(vox_flow* m, void* stream, const int32_t* prompt_tokens,
 int vox_flow_decode_chunk(vox_flow* m, void* stream, const int32_t* tokens, int n, int T, const float* noise, uint64_t seed,
                           uint32_t noise_stream, float* mel, float* mu);
 
+/* Per-request evolving caches — CosyVoice2Decoder.decode_chunk with shared_prompt_cache_mode=False, i.e. the plugin's
+ * use_detokenizer_cache=True (tokenizer/cosyvoice2.py:1010-1083, model/cosyvoice2.py:514-560, 1104-1117): every request owns a
+ * copy of the five flow caches.  They start as the prompt's (vox_flow_slot_reset = the reference's expanded initial cache), every
+ * chunk is decoded against them, and they then take the chunk's rows under the reference's sliding window (first PREFIX_LEN rows +
+ * the most recent ones, :1016-1046) — held as a ring, so no row is moved.  `slots`: HOST int32 [n]; the requests of one call must
+ * have equal cache states (the reference concatenates their cache tensors, so it needs equal lengths; here the ring offsets must agree
+ * as well).  vox_flow_slot_state -> {encoder, up-encoder, estimator} cache lengths, then their ring offsets. */
+int vox_flow_enable_slots(vox_flow* m, int n_slots);
+int vox_flow_slot_reset(vox_flow* m, void* stream, int slot);
+int vox_flow_slot_state(vox_flow* m, int slot, int32_t out[6]);
+int vox_flow_decode_chunk_slots(vox_flow* m, void* stream, const int32_t* tokens, int n, int T, const int32_t* slots, const float* noise,
+                                uint64_t seed, uint32_t noise_stream, float* mel, float* mu);
+
 /* fade_in_out (tokenizer/cosyvoice2.py:46-54): wav [n][L] (in place): the first `fade` samples of every row become
  * wav * window[:fade] + prev_tail * window[fade:] (prev_tail [n][fade] or NULL = silence; window: device double [2 fade]) */
 int vox_fade_in_out(void* stream, float* wav, int n, int L, const float* prev_tail, const double* window, int fade);

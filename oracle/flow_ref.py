@@ -430,8 +430,8 @@ def decode_chunk_shared(fr: "FlowRef", hr, token, embedding, cache, z, rand_ini,
 
 # ---- CosyVoice2Decoder.decode_chunk, per-request evolving caches (use_detokenizer_cache=True: cosyvoice2.py:1010-1083) ----
 def decode_chunk_evolving(fr: "FlowRef", hr, token, embedding, cache, speech_cache, z, rand_ini, noise, mel_cache_len: int = 6):
-    """One chunk of a request that owns its caches (the reference's non-shared mode; not the plugin default, and not built in HIP yet —
-    this restatement and its fixture g17 are the pinned target).  token [B, T]; cache: dict(enc, up, cnn, att) with batch B (after
+    """One chunk of a request that owns its caches (the reference's non-shared mode; not the plugin default).  Pinned to the reference by
+    fixture g17; the HIP path (vox_flow_decode_chunk_slots) is held to both.  token [B, T]; cache: dict(enc, up, cnn, att) with batch B (after
     init_cache: the prompt's caches); speech_cache [B, mel_cache_len * scale]: the tail of the previous chunk's faded audio (zeros at
     the start).  Returns (audio [B, (2T - mel_cache_len) scale], mel, new cache, new speech_cache): the flow runs against the request's
     own caches, which then grow by this chunk's rows and are cut back to the sliding window (first `prefix` rows + the most recent

@@ -1254,7 +1254,7 @@ def g17_flow_evolving(ns):
     """CosyVoice2Decoder.decode_chunk in the per-request mode (shared_prompt_cache_mode=False, i.e. use_detokenizer_cache=True:
     cosyvoice2.py:1010-1083) through the reference, tiny size, one request, three consecutive 28-token chunks: the caches grow and are
     cut back to the sliding window (the third chunk runs against truncated caches), the fade-in blends against the previous chunk's tail.
-    Not built in HIP yet: this pins the oracle restatement (oracle/flow_ref.py::decode_chunk_evolving) the HIP path will be held to."""
+    Pins the oracle restatement (oracle/flow_ref.py::decode_chunk_evolving); tests/test_gpu_flow.py holds the HIP path to both."""
     from oracle import flow_ref as FR, hift_ref as HR
     import contextlib
     fc, hc, Np = FR.tiny_flow_cfg(), HR.HiftCfg(base_channels=256, f0_channels=64), 9

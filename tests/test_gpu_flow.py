@@ -92,3 +92,66 @@ def test_cosyvoice2_decode_chunk_matches_reference_audio(dev, golden, tag):
     assert rms(audio_s - want) < 2e-4, rms(audio_s - want)
     assert np.abs(audio[:, :8]).max() < 0.02                       # faded in from silence (cosyvoice2.py:1040-1046)
     dec.close()
+
+
+def test_cosyvoice2_per_request_evolving_caches(dev, golden):
+    """use_detokenizer_cache=True (CosyVoice2Decoder with shared_prompt_cache_mode=False, cosyvoice2.py:1010-1083): one request, three
+    consecutive 28-token chunks — the caches grow (40 / 80 / 80 rows), then slide (64 / 128 / 128: the third chunk runs against
+    truncated caches held as a ring), the fade-in blends against the previous chunk's tail.  HIP vs the reference's own output (g17)
+    and vs the oracle (decode_chunk_evolving) chunk by chunk; then two requests that started one chunk apart in ONE call (different
+    cache states: decoded in groups) equal the same requests decoded alone."""
+    from oracle import flow_ref as FR, hift_ref as HR
+    from tests.test_gpu_hift import to_plugin_cfg
+    from vox_serve_amd.tokenizer.base import DecoderCache
+    from vox_serve_amd.tokenizer.cosyvoice2 import CosyVoice2Decoder
+    g = golden("g17_flow_evolving")
+    fc, hc = FR.tiny_flow_cfg(), HR.HiftCfg(base_channels=256, f0_channels=64)
+    Wf, Wh = FR.random_flow_weights(fc, seed=3), HR.random_hift_weights(hc, seed=2)
+    seed, T, K = int(g["noise_seed"]), g["tokens"].shape[2], g["tokens"].shape[0]
+    ptok, pfeat, spk = torch.from_numpy(g["prompt_token"]).long(), torch.from_numpy(g["prompt_feat"]), torch.from_numpy(g["spk"])
+    ref = {"prompt_speech_token": ptok, "prompt_feat": pfeat, "embedding": spk}
+    z0 = FR.cfm_noise(seed, 0, fc.mel, 2 * (ptok.shape[1] + 3))
+
+    def make():
+        d = CosyVoice2Decoder(Wf, Wh, device=dev, flow_config=flow_plugin_cfg(fc), hift_config=to_plugin_cfg(hc), max_batch=2, max_prompt_tokens=48,
+                              seed=seed, shared_prompt_cache_mode=False, max_slots=4)
+        d.init_cache(ref, noise=z0)
+        return d
+    dec = make()
+    fr, hr = FR.FlowRef(fc, Wf), HR.HiftRef(hc, Wh)
+    with torch.no_grad():
+        _, ocache = fr.init_cache(ptok, pfeat, spk, z0)
+    ospeech = torch.zeros(1, 6 * hc.upsample_scale)
+    cache = dec.new_request_cache(1)
+    assert dec.flow.slot_lens(int(cache.slot[0])) == [ptok.shape[1] + 3, 2 * (ptok.shape[1] + 3), 2 * (ptok.shape[1] + 3)]
+    audios = []
+    for k in range(K):
+        tok = torch.from_numpy(g["tokens"][k]).long()
+        ini, nz = HR.make_noise(hc, 1, 2 * T, seed=seed, first_stream=16 + 2 * k)
+        zk = FR.cfm_noise(seed, 1 + k, fc.mel, 2 * T)
+        audio, cache = dec.decode_chunk(tok, T, cache, ref_dict=ref, flow_noise=zk, hift_noise=nz)
+        with torch.no_grad():
+            oa, _, ocache, ospeech = FR.decode_chunk_evolving(fr, hr, tok, spk, ocache, ospeech, zk, ini, nz)
+        a = audio.cpu().numpy()
+        audios.append(a)
+        assert a.shape == g[f"audio_{k}"].shape
+        assert rms(a - g[f"audio_{k}"]) < 2e-4, (k, rms(a - g[f"audio_{k}"]))            # vs the reference
+        assert rms(a - oa.numpy()) < 2e-4, (k, rms(a - oa.numpy()))                       # vs the oracle
+        assert dec.flow.slot_lens(int(cache.slot[0])) == g["cache_lens"][k].tolist(), k
+        assert rms(cache.speech_cache.cpu().numpy() - g[f"speech_cache_{k}"]) < 4e-4, k
+    assert rms(audios[1] - audios[0]) > 1e-2
+    # two requests one chunk apart, decoded together: request A at its chunk k + 1 beside request B at its chunk k
+    ca, cb = dec.new_request_cache(1), dec.new_request_cache(1)
+    toks = [torch.from_numpy(g["tokens"][k]).long() for k in range(K)]
+    nzs = [HR.make_noise(hc, 1, 2 * T, seed=seed, first_stream=16 + 2 * k)[1] for k in range(K)]
+    a0, ca = dec.decode_chunk(toks[0], T, ca, ref_dict=ref, flow_noise=FR.cfm_noise(seed, 1, fc.mel, 2 * T), hift_noise=nzs[0])
+    assert rms(a0.cpu().numpy() - audios[0]) < 1e-6                                      # a fresh slot reproduces the first run
+    both = DecoderCache.cat([ca, cb])
+    zk = FR.cfm_noise(seed, 2, fc.mel, 2 * T)
+    out, both = dec.decode_chunk(torch.cat([toks[1], toks[1]]), T, both, ref_dict=ref, flow_noise=zk, hift_noise=torch.cat([nzs[1], nzs[1]]))
+    assert rms(out[0].cpu().numpy() - audios[1][0]) < 1e-6                               # A: its second chunk, as alone
+    assert dec.flow.slot_lens(int(ca.slot[0])) == g["cache_lens"][1].tolist() and dec.flow.slot_lens(int(cb.slot[0])) == g["cache_lens"][0].tolist()
+    assert rms(out[1].cpu().numpy() - audios[1][0]) > 1e-3                               # B saw the same tokens against a shorter history
+    dec.release_cache(ca), dec.release_cache(cb), dec.release_cache(cache)
+    assert sorted(dec._free_slots) == [0, 1, 2, 3]
+    dec.close()

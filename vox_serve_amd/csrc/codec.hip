@@ -1936,7 +1936,14 @@ struct FlowAttn {
     size_t cache_half_stride;
     float scale;
     int mask_block;                     // > 0: key j is visible to query i iff j <= i or j / mask_block == i / mask_block (glm.py:452-470)
+    // per-request evolving caches (CosyVoice2 use_detokenizer_cache): row n reads cache block cidx[n] (stride cache_half_stride); the
+    // cached keys beyond the first `prefix` rows sit in a ring that starts at ring_head (logical row j -> physical row below)
+    const int* cidx;
+    int prefix, ring_head;
 };
+__device__ __forceinline__ int flow_cache_row(int j, int prefix, int head, int cap) {
+    return (head == 0 || j < prefix) ? j : prefix + (head + j - prefix) % (cap - prefix);
+}
 #define FLOW_MAXKEYS 1024
 __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
     __shared__ float ps[4][FLOW_MAXKEYS];
@@ -1945,7 +1952,8 @@ __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
     const int i = blockIdx.x * 4 + wave, h = blockIdx.y, n = blockIdx.z;
     if (i >= a.T) return;
     const int HD = a.H * a.dk, ld = 3 * HD, S = a.Tc + a.T;
-    const float* cache = a.cache ? a.cache + (a.B > 0 ? (size_t)(n / a.B) * a.cache_half_stride : 0) + (size_t)h * a.Tcap * 2 * a.dk : nullptr;
+    const float* cache = a.cache ? a.cache + (a.cidx ? (size_t)a.cidx[n] * a.cache_half_stride : a.B > 0 ? (size_t)(n / a.B) * a.cache_half_stride : 0) +
+                                       (size_t)h * a.Tcap * 2 * a.dk : nullptr;
     const float* qrow = a.qkv + ((size_t)n * a.T + i) * ld + h * a.dk;
     for (int d = lane; d < a.dk; d += 64) {
         qs[wave][0][d] = qrow[d] + (a.bu ? a.bu[h * a.dk + d] : 0.0f);
@@ -1957,7 +1965,7 @@ __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
     const float4* q4 = reinterpret_cast<const float4*>(qs[wave][0]);
     const float4* v4 = reinterpret_cast<const float4*>(qs[wave][1]);
     for (int j = lane; j < S; j += 64) {
-        const float4* kr = reinterpret_cast<const float4*>(j < a.Tc ? cache + (size_t)j * 2 * a.dk
+        const float4* kr = reinterpret_cast<const float4*>(j < a.Tc ? cache + (size_t)flow_cache_row(j, a.prefix, a.ring_head, a.Tcap) * 2 * a.dk
                                                                     : a.qkv + ((size_t)n * a.T + (j - a.Tc)) * ld + HD + h * a.dk);
         float ac = 0.0f;
 #pragma unroll 4
@@ -2006,7 +2014,9 @@ __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
         for (int u = 0; u < 4; ++u) o[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* vc = cache ? cache + a.dk + c4 : nullptr;
         const float* vn = a.qkv + (size_t)n * a.T * ld + 2 * HD + h * a.dk + c4;
-        auto vrow = [&](int j) { return reinterpret_cast<const float4*>(j < a.Tc ? vc + (size_t)j * 2 * a.dk : vn + (size_t)(j - a.Tc) * ld); };
+        auto vrow = [&](int j) {
+            return reinterpret_cast<const float4*>(j < a.Tc ? vc + (size_t)flow_cache_row(j, a.prefix, a.ring_head, a.Tcap) * 2 * a.dk : vn + (size_t)(j - a.Tc) * ld);
+        };
         int j = g;
         if (on) {
             for (; j + 12 < S; j += 16) {
@@ -2052,13 +2062,32 @@ __global__ __launch_bounds__(256) void k_flow_cache_store(const float* qkv, floa
         cache[(size_t)n * cache_half_stride + ((size_t)h * Tcap + j) * 2 * dk + e] = v;
     }
 }
-// last two rows of every request -> conv state [n][2][C]
-__global__ __launch_bounds__(256) void k_flow_tail2(const float* x, float* st, int N, int T, int C) {
+// evolving caches: the T new K | V rows of request row n are appended to its cache block cidx[n] — logical position len + t; positions
+// below `prefix` are stored in place, the others in the ring of Tcap - prefix rows that starts at `head` (a row past the capacity lands on
+// the oldest ring row: the sliding-window truncation of cosyvoice2.py:1016-1046 without moving the rows that stay)
+__global__ __launch_bounds__(256) void k_flow_cache_append(const float* qkv, float* cache, const int* cidx, size_t stride, int T, int H, int dk,
+                                                            int Tcap, int prefix, int len, int head, int N) {
+    const size_t total = (size_t)N * H * T * 2 * dk;
+    const int HD = H * dk, R = Tcap - prefix;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int e = (int)(i % (2 * dk));
+        size_t r = i / (2 * dk);
+        const int t = (int)(r % T); r /= T;
+        const int h = (int)(r % H), n = (int)(r / H);
+        const int p = len + t;
+        const int row = p < prefix ? p : prefix + (head + p - prefix) % R;
+        const float v = qkv[((size_t)n * T + t) * 3 * HD + (e < dk ? HD : 2 * HD) + h * dk + (e < dk ? e : e - dk)];
+        cache[(size_t)cidx[n] * stride + ((size_t)h * Tcap + row) * 2 * dk + e] = v;
+    }
+}
+// last two rows of every request -> conv state [n][2][C] (slots != NULL: state row slots[n] instead of n)
+__global__ __launch_bounds__(256) void k_flow_tail2(const float* x, float* st, int N, int T, int C, const int* slots = nullptr) {
     const size_t total = (size_t)N * 2 * C;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C), p = (int)((i / C) % 2), n = (int)(i / (2 * C));
         const int t = T - 2 + p;
-        st[i] = t >= 0 ? x[((size_t)n * T + t) * C + c] : 0.0f;
+        const float v = t >= 0 ? x[((size_t)n * T + t) * C + c] : 0.0f;
+        st[slots ? ((size_t)slots[n] * 2 + p) * C + c : i] = v;
     }
 }
 // estimator input [2B * T][4 mel] = x | mu | spk | cond, the second (unconditional) half with mu = spk = cond = 0   (cosyvoice_flow.py:2737-2745)
@@ -2161,6 +2190,13 @@ struct vox_flow {
     float *enc_kv = nullptr, *up_kv = nullptr, *att_kv = nullptr, *cnn1 = nullptr, *cnn2 = nullptr;
     int enc_len = 0, up_len = 0, att_len = 0, cnn1_w = 0;
     bool have_prompt = false;
+    // per-request evolving caches (use_detokenizer_cache=True, cosyvoice2.py:1010-1083): slot-major copies of the five caches, each
+    // slot starting as a copy of the prompt's; the K/V caches keep their first `prefix` rows and run the rest as a ring
+    struct SlotState { int enc_len = 0, enc_head = 0, up_len = 0, up_head = 0, att_len = 0, att_head = 0; bool live = false; };
+    int n_slots = 0;
+    std::vector<SlotState> slot;
+    float *s_enc = nullptr, *s_up = nullptr, *s_att = nullptr, *s_cnn1 = nullptr, *s_cnn2 = nullptr;
+    int *s_eidx = nullptr, *s_cidx = nullptr;      // device: slot of request b [max_batch]; cache block of estimator row n [2 max_batch]
 };
 
 static inline int flow_res_cin(const vox_flow_config& c, int r) { return r == 0 ? 4 * c.mel : (r == 1 + c.est_mid ? 2 * c.est_ch : c.est_ch); }
@@ -2172,6 +2208,8 @@ void vox_flow_destroy(vox_flow* m) {
     for (int i = 0; i < 10; ++i) (void)hipFree(m->buf[i]);
     (void)hipFree(m->tb); (void)hipFree(m->spk); (void)hipFree(m->pe); (void)hipFree(m->pp); (void)hipFree(m->slots);
     (void)hipFree(m->enc_kv); (void)hipFree(m->up_kv); (void)hipFree(m->att_kv); (void)hipFree(m->cnn1); (void)hipFree(m->cnn2);
+    (void)hipFree(m->s_enc); (void)hipFree(m->s_up); (void)hipFree(m->s_att); (void)hipFree(m->s_cnn1); (void)hipFree(m->s_cnn2);
+    (void)hipFree(m->s_eidx); (void)hipFree(m->s_cidx);
     delete m;
 }
 
@@ -2195,17 +2233,24 @@ static int ln_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const fl
     hipLaunchKernelGGL(k_flow_ln, dim3((n * L + 15) / 16), dim3(256), 0, st, x, lw, lb, scratch, w.cin, eps, 1.0f, 0, (const float*)nullptr, 1, n * L);
     return conv_gemm(st, w, scratch, nullptr, nullptr, n, L, 0, FLOW_OFF0, out, nullptr, nullptr, gelu);
 }
+// evolving mode (eidx != NULL): `cache` is layer l of the slot-major cache, request b reads and appends to block eidx[b] (stride
+// slot_stride) whose rows past `prefix` form a ring starting at `head`
 static int flow_conformer(vox_flow* m, hipStream_t st, const vox_flow_conformer_w& w, float* x, int n, int T, const float* cache, int Tc, int Tcap,
-                          float* store_cache, int store_cap, int store_prefix, float** B) {
+                          float* store_cache, int store_cap, int store_prefix, float** B, const int* eidx = nullptr, size_t slot_stride = 0,
+                          int head = 0) {
     const vox_flow_config& c = m->cfg;
     const int D = c.dim, H = c.enc_heads, dk = D / H, S = Tc + T;
     if (S > FLOW_MAXKEYS) return vox_fail(VOX_ERR_INVALID, "flow: %d keys > %d", S, FLOW_MAXKEYS);
     float *nrm = B[0], *qkv = B[1], *att = B[2];
     VOX_TRY(ln_gemm(st, w.qkv, x, w.ln_mha_w, w.ln_mha_b, 1e-12f, nrm, n, T, qkv, 0));
     VOX_TRY(conv_gemm(st, w.pos, m->pe, nullptr, nullptr, 1, 2 * S - 1, 0, FLOW_OFF0, m->pp, nullptr, nullptr, 0));
-    FlowAttn a{qkv, cache, m->pp, w.bias_u, w.bias_v, att, T, H, dk, Tc, Tcap, 0, 0, 1.0f / sqrtf((float)dk)};
+    FlowAttn a{qkv, cache, m->pp, w.bias_u, w.bias_v, att, T, H, dk, Tc, Tcap, 0, eidx ? slot_stride : 0, 1.0f / sqrtf((float)dk)};
+    a.cidx = eidx; a.prefix = store_prefix; a.ring_head = head;
     hipLaunchKernelGGL(k_flow_attn, dim3((T + 3) / 4, H, n), dim3(256), 0, st, a);
-    if (store_cache)
+    if (eidx)
+        hipLaunchKernelGGL(k_flow_cache_append, dim3(ew_grid((size_t)n * H * T * 2 * dk)), dim3(256), 0, st, qkv, const_cast<float*>(cache), eidx,
+                           slot_stride, T, H, dk, Tcap, store_prefix, Tc, head, n);
+    else if (store_cache)
         hipLaunchKernelGGL(k_flow_cache_store, dim3(ew_grid((size_t)H * store_cap * 2 * dk)), dim3(256), 0, st, qkv, store_cache, T, H, dk, store_cap,
                            store_prefix, (size_t)0, 1);
     VOX_TRY(conv_gemm(st, w.out, att, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
@@ -2216,8 +2261,10 @@ static int flow_conformer(vox_flow* m, hipStream_t st, const vox_flow_conformer_
 }
 
 // tokens [B][T] -> mel frames x [B][2T][mel] (time-major, in m->buf[9]); init: B == 1, caches are written instead of read
+// evolve != NULL (decode only): the per-request caches of the given slot state (all requests of the call share one state: equal cache
+// lengths, as the reference's batched caches require) are read through m->s_eidx / m->s_cidx and appended to
 static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, int T, bool init, const float* prompt_feat, int n_feat,
-                    const float* noise, uint64_t seed, uint32_t nstream, float* mu_out) {
+                    const float* noise, uint64_t seed, uint32_t nstream, float* mu_out, const vox_flow::SlotState* evolve = nullptr) {
     const vox_flow_config& c = m->cfg;
     const vox_flow_weights& w = m->w;
     const int D = c.dim, M = c.mel, C = c.est_ch, T2 = 2 * T, H = c.enc_heads, dk = D / H, inner = c.est_heads * c.est_head_dim;
@@ -2234,11 +2281,13 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
     hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)B * T * D)), dim3(256), 0, st, Bf[0], (size_t)B * T * D, 3);
     VOX_TRY(conv_gemm(st, w.pre2, Bf[0], nullptr, nullptr, B, T, 0, FLOW_OFF_C3, x, x, nullptr, 0));
     {
-        const int Tc = init ? 0 : m->enc_len, S = Tc + T, cap = c.max_cache / 2;
+        const int Tc = init ? 0 : (evolve ? evolve->enc_len : m->enc_len), S = Tc + T, cap = c.max_cache / 2;
         hipLaunchKernelGGL(k_flow_relpos, dim3(ew_grid((size_t)(2 * S - 1) * D)), dim3(256), 0, st, m->pe, S, D);
+        const size_t lay = (size_t)H * cap * 2 * dk;
         for (int l = 0; l < c.enc_layers; ++l) {
-            float* kv = m->enc_kv + (size_t)l * H * cap * 2 * dk;
-            VOX_TRY(flow_conformer(m, st, m->enc[l], x, B, T, init ? nullptr : kv, Tc, cap, init ? kv : nullptr, cap, c.prefix / 2, Bf));
+            float* kv = (evolve ? m->s_enc : m->enc_kv) + (size_t)l * lay;
+            VOX_TRY(flow_conformer(m, st, m->enc[l], x, B, T, init ? nullptr : kv, Tc, cap, init ? kv : nullptr, cap, c.prefix / 2, Bf,
+                                   evolve ? m->s_eidx : nullptr, (size_t)c.enc_layers * lay, evolve ? evolve->enc_head : 0));
         }
         if (init) m->enc_len = T < cap ? T : cap;
     }
@@ -2248,11 +2297,13 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
     VOX_TRY(conv_gemm(st, w.up_embed_lin, Bf[1], nullptr, nullptr, B, T2, 0, FLOW_OFF0, Bf[0], nullptr, nullptr, 0));
     hipLaunchKernelGGL(k_flow_ln, dim3((B * T2 + 15) / 16), dim3(256), 0, st, Bf[0], w.up_embed_ln_w, w.up_embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, B * T2);
     {
-        const int Tc = init ? 0 : m->up_len, S = Tc + T2, cap = c.max_cache;
+        const int Tc = init ? 0 : (evolve ? evolve->up_len : m->up_len), S = Tc + T2, cap = c.max_cache;
         hipLaunchKernelGGL(k_flow_relpos, dim3(ew_grid((size_t)(2 * S - 1) * D)), dim3(256), 0, st, m->pe, S, D);
+        const size_t lay = (size_t)H * cap * 2 * dk;
         for (int l = 0; l < c.up_layers; ++l) {
-            float* kv = m->up_kv + (size_t)l * H * cap * 2 * dk;
-            VOX_TRY(flow_conformer(m, st, m->enc[c.enc_layers + l], x, B, T2, init ? nullptr : kv, Tc, cap, init ? kv : nullptr, cap, c.prefix, Bf));
+            float* kv = (evolve ? m->s_up : m->up_kv) + (size_t)l * lay;
+            VOX_TRY(flow_conformer(m, st, m->enc[c.enc_layers + l], x, B, T2, init ? nullptr : kv, Tc, cap, init ? kv : nullptr, cap, c.prefix, Bf,
+                                   evolve ? m->s_eidx : nullptr, (size_t)c.up_layers * lay, evolve ? evolve->up_head : 0));
         }
         if (init) m->up_len = T2 < cap ? T2 : cap;
     }
@@ -2266,9 +2317,12 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
     hipLaunchKernelGGL(k_flow_noise, dim3(ew_grid((size_t)B * T2 * M)), dim3(256), 0, st, noise, seed, nstream, xs, B, T2, M);
     const int N = 2 * B, capA = c.max_cache, hd = c.est_head_dim, HE = c.est_heads;
     const size_t att_layer = (size_t)HE * capA * 2 * hd, att_half = (size_t)c.n_steps * m->n_att * att_layer;
-    const int Tc = init ? 0 : m->att_len;
+    const int Tc = init ? 0 : (evolve ? evolve->att_len : m->att_len);
     if (Tc + T2 > FLOW_MAXKEYS) return vox_fail(VOX_ERR_INVALID, "flow: chunk too long");
     hipLaunchKernelGGL(k_flow_slots, dim3((N + 63) / 64), dim3(64), 0, st, m->slots, N, B);
+    // conv-state row / attention-cache block of estimator row n: the guidance half (shared prompt caches) or 2 slot + half (evolving)
+    const int* crow = evolve ? m->s_cidx : m->slots;
+    const int srows = evolve ? 2 * m->n_slots : 2;             // state rows per (step, resnet) block
     for (int s = 0; s < c.n_steps; ++s) {
         float *hA = Bf[0], *a1 = Bf[1], *a2 = Bf[2], *a3 = Bf[3], *skip = Bf[4], *cat = Bf[5], *hB = Bf[6];
         hipLaunchKernelGGL(k_flow_pack, dim3(ew_grid((size_t)N * T2 * 4 * M)), dim3(256), 0, st, xs, mu, m->spk, init ? cond : nullptr, cat, B, T2, M);
@@ -2283,23 +2337,29 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
                 in = cat;
             }
             h = (in == hA) ? hB : hA;
-            float* st1 = m->cnn1 + ((size_t)s * m->n_res + r) * 4 * m->cnn1_w;
-            float* st2 = m->cnn2 + ((size_t)s * m->n_res + r) * 4 * C;
-            if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * cin)), dim3(256), 0, st, in, st1, N, T2, cin);
+            float* st1 = (evolve ? m->s_cnn1 : m->cnn1) + ((size_t)s * m->n_res + r) * srows * 2 * m->cnn1_w;
+            float* st2 = (evolve ? m->s_cnn2 : m->cnn2) + ((size_t)s * m->n_res + r) * srows * 2 * C;
+            if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * cin)), dim3(256), 0, st, in, st1, N, T2, cin, (const int*)nullptr);
             // block1: (cached) causal conv k3 -> LayerNorm -> Mish, + the time projection; block2 likewise; + res_conv(x)
-            VOX_TRY(conv_gemm(st, rw.conv1, in, init ? nullptr : st1, m->slots, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
+            VOX_TRY(conv_gemm(st, rw.conv1, in, init ? nullptr : st1, crow, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
+            if (evolve) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * cin)), dim3(256), 0, st, in, st1, N, T2, cin, crow);
             hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 15) / 16), dim3(256), 0, st, a1, rw.ln1_w, rw.ln1_b, a2, C, 1e-5f, 1.0f, 1,
                                m->tb + ((size_t)s * m->n_res + r) * C, N * T2, N * T2);
-            if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * C)), dim3(256), 0, st, a2, st2, N, T2, C);
-            VOX_TRY(conv_gemm(st, rw.conv2, a2, init ? nullptr : st2, m->slots, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
+            if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * C)), dim3(256), 0, st, a2, st2, N, T2, C, (const int*)nullptr);
+            VOX_TRY(conv_gemm(st, rw.conv2, a2, init ? nullptr : st2, crow, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
+            if (evolve) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * C)), dim3(256), 0, st, a2, st2, N, T2, C, crow);
             hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 15) / 16), dim3(256), 0, st, a1, rw.ln2_w, rw.ln2_b, a2, C, 1e-5f, 1.0f, 1, nullptr, 1, N * T2);
             VOX_TRY(conv_gemm(st, rw.res, in, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, a2, nullptr, 0));       // h = block2 + res_conv(in)
             for (int j = 0; j < c.est_blocks; ++j, ++li) {
                 const vox_flow_tblock_w& tw = m->tblocks[li];
-                float* kv = m->att_kv + ((size_t)s * m->n_att + li) * att_layer;
+                float* kv = (evolve ? m->s_att : m->att_kv) + ((size_t)s * m->n_att + li) * att_layer;
                 VOX_TRY(ln_gemm(st, tw.qkv, h, tw.ln1_w, tw.ln1_b, 1e-5f, a1, N, T2, a2, 0));
                 FlowAttn a{a2, init ? nullptr : kv, nullptr, nullptr, nullptr, a3, T2, HE, hd, Tc, capA, B, att_half, 1.0f / sqrtf((float)hd)};
+                if (evolve) { a.cidx = m->s_cidx; a.prefix = c.prefix; a.ring_head = evolve->att_head; }
                 hipLaunchKernelGGL(k_flow_attn, dim3((T2 + 3) / 4, HE, N), dim3(256), 0, st, a);
+                if (evolve)
+                    hipLaunchKernelGGL(k_flow_cache_append, dim3(ew_grid((size_t)N * HE * T2 * 2 * hd)), dim3(256), 0, st, a2, kv, m->s_cidx, att_half,
+                                       T2, HE, hd, capA, c.prefix, Tc, evolve->att_head, N);
                 if (init)
                     hipLaunchKernelGGL(k_flow_cache_store, dim3(ew_grid((size_t)N * HE * capA * 2 * hd)), dim3(256), 0, st, a2, kv, T2, HE, hd, capA,
                                        c.prefix, att_half, N);
@@ -2414,6 +2474,108 @@ int vox_flow_decode_chunk(vox_flow* m, void* stream, const int32_t* tokens, int 
     hipStream_t st = (hipStream_t)stream;
     VOX_TRY(flow_run(m, st, tokens, n, T, false, nullptr, 0, noise, seed, noise_stream, mu));
     hipLaunchKernelGGL(k_flow_to_bct, dim3(ew_grid((size_t)n * 2 * T * m->cfg.mel)), dim3(256), 0, st, m->buf[9], mel, n, 2 * T, m->cfg.mel);
+    return VOX_OK;
+}
+
+// ---- per-request evolving caches (CosyVoice2Decoder with shared_prompt_cache_mode=False; cosyvoice2.py:1010-1083) --------------------
+int vox_flow_enable_slots(vox_flow* m, int n_slots) {
+    if (!m || n_slots < 1) return vox_fail(VOX_ERR_INVALID, "flow_enable_slots: bad arguments");
+    if (m->n_slots) return m->n_slots == n_slots ? VOX_OK : vox_fail(VOX_ERR_INVALID, "flow_enable_slots: already enabled with %d slots", m->n_slots);
+    const vox_flow_config& c = m->cfg;
+    const int D = c.dim, C = c.est_ch, dk = D / c.enc_heads;
+    const size_t capE = c.max_cache / 2, capU = c.max_cache;
+    const size_t e = (size_t)c.enc_layers * c.enc_heads * capE * 2 * dk, u = (size_t)c.up_layers * c.enc_heads * capU * 2 * dk;
+    const size_t a = (size_t)2 * c.n_steps * m->n_att * c.est_heads * c.max_cache * 2 * c.est_head_dim;
+    bool ok = true;
+    auto alloc = [&](float** p, size_t n) { ok = ok && hipMalloc((void**)p, n * 4) == hipSuccess; };
+    alloc(&m->s_enc, e * n_slots); alloc(&m->s_up, u * n_slots); alloc(&m->s_att, a * n_slots);
+    alloc(&m->s_cnn1, (size_t)c.n_steps * m->n_res * 2 * n_slots * 2 * m->cnn1_w);
+    alloc(&m->s_cnn2, (size_t)c.n_steps * m->n_res * 2 * n_slots * 2 * C);
+    ok = ok && hipMalloc((void**)&m->s_eidx, (size_t)m->max_batch * 4) == hipSuccess && hipMalloc((void**)&m->s_cidx, (size_t)2 * m->max_batch * 4) == hipSuccess;
+    if (!ok) return vox_fail(VOX_ERR_NOMEM, "flow_enable_slots: hipMalloc failed (%zu MB per slot)", (e + u + a) * 4 >> 20);
+    m->n_slots = n_slots;
+    m->slot.assign(n_slots, vox_flow::SlotState{});
+    return VOX_OK;
+}
+
+// a request takes slot `slot`: its caches start as a copy of the prompt's (model/cosyvoice2.py:514-560: the per-request cache is the
+// expanded initial cache of the default speaker)
+int vox_flow_slot_reset(vox_flow* m, void* stream, int slot) {
+    if (!m || slot < 0 || slot >= m->n_slots) return vox_fail(VOX_ERR_INVALID, "flow_slot_reset: slot %d out of range", slot);
+    if (!m->have_prompt) return vox_fail(VOX_ERR_INVALID, "flow_slot_reset: no prompt set (vox_flow_set_prompt)");
+    hipStream_t st = (hipStream_t)stream;
+    const vox_flow_config& c = m->cfg;
+    const int D = c.dim, C = c.est_ch, dk = D / c.enc_heads;
+    const size_t e = (size_t)c.enc_layers * c.enc_heads * (c.max_cache / 2) * 2 * dk, u = (size_t)c.up_layers * c.enc_heads * c.max_cache * 2 * dk;
+    const size_t a = (size_t)2 * c.n_steps * m->n_att * c.est_heads * c.max_cache * 2 * c.est_head_dim;
+    VOX_HIP(hipMemcpyAsync(m->s_enc + e * slot, m->enc_kv, e * 4, hipMemcpyDeviceToDevice, st));
+    VOX_HIP(hipMemcpyAsync(m->s_up + u * slot, m->up_kv, u * 4, hipMemcpyDeviceToDevice, st));
+    VOX_HIP(hipMemcpyAsync(m->s_att + a * slot, m->att_kv, a * 4, hipMemcpyDeviceToDevice, st));
+    // conv states: per (step, resnet) block [2 halves][2][cin] -> rows 2 slot, 2 slot + 1 of the slot-major block
+    const size_t rows = (size_t)c.n_steps * m->n_res;
+    for (int r = 0; r < m->n_res; ++r) {
+        const int cin = flow_res_cin(c, r);
+        VOX_HIP(hipMemcpy2DAsync(m->s_cnn1 + (size_t)r * 2 * m->n_slots * 2 * m->cnn1_w + (size_t)2 * slot * 2 * cin, (size_t)m->n_res * 2 * m->n_slots * 2 * m->cnn1_w * 4,
+                                 m->cnn1 + (size_t)r * 4 * m->cnn1_w, (size_t)m->n_res * 4 * m->cnn1_w * 4, (size_t)4 * cin * 4, c.n_steps,
+                                 hipMemcpyDeviceToDevice, st));
+        VOX_HIP(hipMemcpy2DAsync(m->s_cnn2 + (size_t)r * 2 * m->n_slots * 2 * C + (size_t)2 * slot * 2 * C, (size_t)m->n_res * 2 * m->n_slots * 2 * C * 4,
+                                 m->cnn2 + (size_t)r * 4 * C, (size_t)m->n_res * 4 * C * 4, (size_t)4 * C * 4, c.n_steps, hipMemcpyDeviceToDevice, st));
+    }
+    (void)rows;
+    vox_flow::SlotState& ss = m->slot[slot];
+    ss = vox_flow::SlotState{};
+    ss.enc_len = m->enc_len; ss.up_len = m->up_len; ss.att_len = m->att_len; ss.live = true;
+    return VOX_OK;
+}
+
+int vox_flow_slot_state(vox_flow* m, int slot, int32_t out[6]) {
+    if (!m || !out || slot < 0 || slot >= m->n_slots) return vox_fail(VOX_ERR_INVALID, "flow_slot_state: bad arguments");
+    const vox_flow::SlotState& x = m->slot[slot];
+    out[0] = x.enc_len; out[1] = x.up_len; out[2] = x.att_len; out[3] = x.enc_head; out[4] = x.up_head; out[5] = x.att_head;
+    return VOX_OK;
+}
+
+// one chunk of n requests that own slots[0..n): the flow runs against their caches, which then take this chunk's rows (sliding
+// window: the first `prefix` rows + the most recent ones).  The requests of one call must share their cache lengths, as the reference's
+// batched cache tensors do (DecoderCache.cat); the caller groups them.
+int vox_flow_decode_chunk_slots(vox_flow* m, void* stream, const int32_t* tokens, int n, int T, const int32_t* slots, const float* noise,
+                                uint64_t seed, uint32_t noise_stream, float* mel, float* mu) {
+    if (!m || !tokens || !mel || !slots) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk_slots: NULL");
+    if (!m->n_slots) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk_slots: vox_flow_enable_slots was not called");
+    if (n < 1 || n > m->max_batch || T < 1 || T > m->max_T) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk_slots: n %d / T %d out of range", n, T);
+    const vox_flow_config& c = m->cfg;
+    std::vector<int> eidx(n), cidx(2 * n);
+    for (int b = 0; b < n; ++b) {
+        const int sl = slots[b];
+        if (sl < 0 || sl >= m->n_slots || !m->slot[sl].live) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk_slots: slot %d not initialised", sl);
+        for (int b2 = 0; b2 < b; ++b2)
+            if (slots[b2] == sl) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk_slots: slot %d twice in one call", sl);
+        const vox_flow::SlotState &x = m->slot[sl], &y = m->slot[slots[0]];
+        if (x.enc_len != y.enc_len || x.enc_head != y.enc_head || x.up_len != y.up_len || x.up_head != y.up_head || x.att_len != y.att_len ||
+            x.att_head != y.att_head)
+            return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk_slots: the requests of a call must have equal cache states (vox_flow_slot_state)");
+        eidx[b] = sl; cidx[b] = 2 * sl; cidx[n + b] = 2 * sl + 1;
+    }
+    const int capE = c.max_cache / 2, capU = c.max_cache;
+    if (T > capE - c.prefix / 2 || 2 * T > capU - c.prefix) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk_slots: chunk longer than the cache ring");
+    hipStream_t st = (hipStream_t)stream;
+    VOX_HIP(hipMemcpyAsync(m->s_eidx, eidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    VOX_HIP(hipMemcpyAsync(m->s_cidx, cidx.data(), (size_t)2 * n * 4, hipMemcpyHostToDevice, st));
+    VOX_HIP(hipStreamSynchronize(st));          // (the index vectors above are stack-owned host memory)
+    const vox_flow::SlotState cur = m->slot[slots[0]];
+    VOX_TRY(flow_run(m, st, tokens, n, T, false, nullptr, 0, noise, seed, noise_stream, mu, &cur));
+    hipLaunchKernelGGL(k_flow_to_bct, dim3(ew_grid((size_t)n * 2 * T * c.mel)), dim3(256), 0, st, m->buf[9], mel, n, 2 * T, c.mel);
+    auto advance = [](int& len, int& head, int add, int cap, int prefix) {
+        const int over = len + add - cap;
+        if (over > 0) head = (head + over) % (cap - prefix);
+        len = len + add < cap ? len + add : cap;
+    };
+    for (int b = 0; b < n; ++b) {
+        vox_flow::SlotState& x = m->slot[slots[b]];
+        advance(x.enc_len, x.enc_head, T, capE, c.prefix / 2);
+        advance(x.up_len, x.up_head, 2 * T, capU, c.prefix);
+        advance(x.att_len, x.att_head, 2 * T, capU, c.prefix);
+    }
     return VOX_OK;
 }
 

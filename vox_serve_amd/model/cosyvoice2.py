@@ -79,9 +79,8 @@ class CosyVoice2Model(SingleStackLM):
         self.stop_token_ids = [self.cv_config.speech_token_size + i for i in range(3)]
         # detokenizer (cosyvoice2.py:377-418): flow + HiFT; the plugin's default is the shared prompt cache — the speaker prompt is run
         # through the flow once here and every chunk of every request is decoded against its caches
-        if use_detokenizer_cache:
-            raise NotImplementedError("CosyVoice2Model: use_detokenizer_cache=True (per-request evolving detokenizer cache) is not built")
-        self.use_detokenizer_cache = False
+        # use_detokenizer_cache=True: every request owns evolving caches (cosyvoice2.py:325-335, 514-560, 1104-1117)
+        self.use_detokenizer_cache = bool(use_detokenizer_cache)
         self.audio_decoder = None
         if codec_weights is not None:
             from ..tokenizer.cosyvoice2 import CosyVoice2Decoder
@@ -93,16 +92,23 @@ class CosyVoice2Model(SingleStackLM):
                                                    flow_config=cc.get("flow"), hift_config=cc.get("hift"),
                                                    max_batch=engine_kw.get("max_batch_size", 8), max_tokens_per_chunk=self.detokenize_interval,
                                                    max_prompt_tokens=max(64, int(self.speaker_ref["prompt_speech_token"].numel()) + 8),
-                                                   seed=codec_seed)
+                                                   seed=codec_seed, shared_prompt_cache_mode=not self.use_detokenizer_cache,
+                                                   max_slots=max(16, 2 * engine_kw.get("max_batch_size", 8)))
             self._shared_prompt_cache = self.audio_decoder.init_cache(self.speaker_ref)
 
     def audio_decoder_initial_cache(self, batch_size: int):
-        return None         # shared prompt cache mode: nothing per request (cosyvoice2.py:521-524)
+        if not self.use_detokenizer_cache:
+            return None     # shared prompt cache mode: nothing per request (cosyvoice2.py:521-524)
+        return self.audio_decoder.new_request_cache(batch_size)      # a copy of the prompt's caches per request (:526-560)
 
     def postprocess(self, token_ids: torch.Tensor, decoder_cache=None, **kwargs) -> torch.Tensor:
         """token_ids [B, 28, 1] -> audio [B, 1, 24000]   (cosyvoice2.py:1093-1103)"""
         if self.audio_decoder is None:
             raise NotImplementedError("CosyVoice2Model: no detokenizer weights were given (codec_weights={'flow': ..., 'hift': ...})")
+        if self.use_detokenizer_cache:      # cosyvoice2.py:1104-1117: the request's caches are used and updated in place
+            audio, _ = self.audio_decoder.decode_chunk(token_ids[:, :, 0], speech_token_lens=self.detokenize_interval,
+                                                       decoder_cache=decoder_cache, ref_dict=self.speaker_ref)
+            return audio[:, None, :]
         audio, _ = self.audio_decoder.decode_chunk(token_ids[:, :, 0], speech_token_lens=self.detokenize_interval,
                                                    decoder_cache=self._shared_prompt_cache, ref_dict=self.speaker_ref)
         return audio[:, None, :]
@@ -136,4 +142,5 @@ class CosyVoice2Model(SingleStackLM):
                            self.llm_embedding[self.task_id][None], self.speech_embedding[speech]], 0)
         masks = torch.ones(ids.shape[0], 1, dtype=torch.bool)
         return PreprocessOutput(input_tokens=ids.view(-1, 1).cpu(), repetition_cache=self._new_repetition_cache(),
-                                input_masks=masks, input_features=feats)
+                                input_masks=masks, input_features=feats,
+                                decoder_cache=self.audio_decoder_initial_cache(1) if self.audio_decoder is not None else None)

@@ -3,7 +3,9 @@
 (model/cosyvoice2.py:325, 1093-1103): `init_cache(ref_dict)` runs the flow over the speaker prompt once and keeps its caches,
 `decode_chunk(speech_tokens, ...)` decodes every 28-token window of every request against them:
     flow (conformer encoder + 10-step CFM)  ->  HiFT vocoder  ->  fade-in over mel_cache_len frames  ->  trailing mel_cache_len frames cut.
-The per-request evolving cache (use_detokenizer_cache=True) is not built.
+With shared_prompt_cache_mode=False (the plugin's use_detokenizer_cache=True, cosyvoice2.py:1010-1083) every request owns evolving caches:
+a native slot that starts as a copy of the prompt's caches, is read and then advanced by each of its chunks (sliding window), plus the tail of
+its previous chunk's audio for the fade-in.
 """
 import ctypes
 from dataclasses import dataclass
@@ -13,15 +15,20 @@ import numpy as np
 import torch
 
 from .. import _native as N
+from .base import DecoderCache
 from .cosyvoice_flow import CosyVoice2Flow, FlowConfig
 from .hifigan import HiFTConfig, HiFTGenerator
 
 
 @dataclass
-class CosyVoice2DecoderCache:
-    """Handle of the static prompt caches (they live inside the native flow object)."""
+class CosyVoice2DecoderCache(DecoderCache):
+    """Shared mode: handle of the static prompt caches (they live inside the native flow object).  Per-request mode: `slot` [B] int32 names
+    the native slots holding each request's evolving flow caches, `speech_cache` [B, mel_cache_len * 480] is the tail of each request's
+    previous chunk (the HiFTGeneratorCache.speech_cache of the reference)."""
     prompt_tokens: int = 0
     prompt_mels: Optional[torch.Tensor] = None
+    slot: Optional[torch.Tensor] = None
+    speech_cache: Optional[torch.Tensor] = None
 
 
 class CosyVoice2Decoder:
@@ -31,11 +38,10 @@ class CosyVoice2Decoder:
 
     def __init__(self, flow_weights: Dict[str, torch.Tensor], hift_weights: Dict[str, torch.Tensor], device="cuda",
                  flow_config: Optional[FlowConfig] = None, hift_config: Optional[HiFTConfig] = None, shared_prompt_cache_mode: bool = True,
-                 max_batch: int = 8, max_tokens_per_chunk: int = 28, max_prompt_tokens: int = 256, seed: int = 0):
-        if not shared_prompt_cache_mode:
-            raise NotImplementedError("CosyVoice2Decoder: only the shared prompt cache mode (the plugin's default) is built")
+                 max_batch: int = 8, max_tokens_per_chunk: int = 28, max_prompt_tokens: int = 256, seed: int = 0, max_slots: int = 16):
         self.device = torch.device(device)
-        self.shared_prompt_cache_mode = True
+        self.shared_prompt_cache_mode = bool(shared_prompt_cache_mode)
+        self.max_slots, self._free_slots = max_slots, list(range(max_slots))
         self.flow = CosyVoice2Flow(flow_weights, flow_config, device=device, max_batch=max_batch, max_T=max_tokens_per_chunk,
                                    max_prompt_T=max_prompt_tokens, seed=seed)
         self.hift = HiFTGenerator(hift_weights, hift_config, device=device, max_batch=max_batch, max_T=2 * max_tokens_per_chunk, seed=seed)
@@ -50,6 +56,30 @@ class CosyVoice2Decoder:
         L.vox_fade_in_out.restype = ctypes.c_int
         L.vox_fade_in_out.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         self.L = L
+        if not self.shared_prompt_cache_mode:
+            self.flow.enable_slots(max_slots)
+
+    # ---- per-request caches (shared_prompt_cache_mode=False) ----
+    def new_request_cache(self, batch_size: int = 1) -> CosyVoice2DecoderCache:
+        """model/cosyvoice2.py:514-560 `audio_decoder_initial_cache`: each new request gets a copy of the prompt's caches (init_cache must
+        have run) and a silent speech tail."""
+        if self.shared_prompt_cache_mode:
+            raise RuntimeError("CosyVoice2Decoder: per-request caches need shared_prompt_cache_mode=False")
+        slots = []
+        for _ in range(batch_size):
+            if not self._free_slots:
+                raise RuntimeError("CosyVoice2Decoder: no free detokenizer cache slot (raise max_slots)")
+            sl = self._free_slots.pop(0)
+            self.flow.slot_reset(sl)
+            slots.append(sl)
+        return CosyVoice2DecoderCache(slot=torch.tensor(slots, dtype=torch.int32),
+                                      speech_cache=torch.zeros(batch_size, self.source_cache_len, dtype=torch.float32, device=self.device))
+
+    def release_cache(self, cache: CosyVoice2DecoderCache):
+        if cache is not None and cache.slot is not None:
+            for sl in cache.slot.tolist():
+                if sl not in self._free_slots:
+                    self._free_slots.append(int(sl))
 
     def init_cache(self, ref_dict: dict, noise: Optional[torch.Tensor] = None) -> CosyVoice2DecoderCache:
         """cosyvoice2.py:862-942: the flow over prompt tokens (+ the first three again) with the prompt mel as condition; the caches
@@ -66,6 +96,8 @@ class CosyVoice2Decoder:
         """speech_tokens [B, T] -> (audio fp32 [B, 2 T * 480 - 2880], the same cache)   (cosyvoice2.py:944-1063, shared mode)"""
         if speech_tokens.dim() == 1:
             speech_tokens = speech_tokens.unsqueeze(0)
+        if not self.shared_prompt_cache_mode:
+            return self._decode_chunk_evolving(speech_tokens, decoder_cache, flow_noise, hift_noise, hift_stream_base, flow_noise_stream)
         if (self.use_graph and flow_noise is None and hift_noise is None and hift_stream_base is None and flow_noise_stream is None
                 and speech_tokens.shape[0] <= self.flow.max_batch):
             return self._decode_chunk_graph(speech_tokens), decoder_cache
@@ -74,6 +106,20 @@ class CosyVoice2Decoder:
         B, Lw = wav.shape
         N.check(self.L.vox_fade_in_out(N.stream(), wav.data_ptr(), B, Lw, None, self.speech_window.data_ptr(), self.source_cache_len))
         return wav[:, : Lw - self.source_cache_len], decoder_cache
+
+    def _decode_chunk_evolving(self, speech_tokens, cache: CosyVoice2DecoderCache, flow_noise, hift_noise, hift_stream_base, flow_noise_stream):
+        """cosyvoice2.py:1010-1083: the flow against each request's own caches (advanced in place by the native call), HiFT, the fade-in
+        against the request's previous tail; the new tail (the trimmed last mel_cache_len frames of the faded audio) is written back into
+        cache.speech_cache in place, like the reference's `decoder_cache.copy_from(new_decoder_cache)` (model/cosyvoice2.py:1114)."""
+        if cache is None or cache.slot is None:
+            raise ValueError("CosyVoice2Decoder: the per-request mode needs the request's decoder_cache (new_request_cache)")
+        mels = self.flow.forward_chunk_slots(speech_tokens, cache.slot.tolist(), noise=flow_noise, noise_stream=flow_noise_stream)
+        wav, _ = self.hift.forward_chunk(mels, noise=hift_noise, stream_base=hift_stream_base)
+        B, Lw = wav.shape
+        prev = cache.speech_cache.to(self.device, torch.float32).contiguous()
+        N.check(self.L.vox_fade_in_out(N.stream(), wav.data_ptr(), B, Lw, prev.data_ptr(), self.speech_window.data_ptr(), self.source_cache_len))
+        cache.speech_cache.copy_(wav[:, Lw - self.source_cache_len:])
+        return wav[:, : Lw - self.source_cache_len], cache
 
     def _decode_chunk_graph(self, speech_tokens: torch.Tensor) -> torch.Tensor:
         """The ~7 000 launches of a chunk (flow: 10 estimator passes of 70 blocks; HiFT) as one hipGraph per (requests, tokens): inputs go

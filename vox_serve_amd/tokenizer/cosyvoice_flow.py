@@ -86,6 +86,11 @@ def _bind(L):
     L.vox_flow_set_prompt.argtypes = [vp, vp, vp, ci, vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32, vp]
     L.vox_flow_decode_chunk.restype = ci
     L.vox_flow_decode_chunk.argtypes = [vp, vp, vp, ci, ci, vp, ctypes.c_uint64, ctypes.c_uint32, vp, vp]
+    L.vox_flow_enable_slots.restype, L.vox_flow_enable_slots.argtypes = ci, [vp, ci]
+    L.vox_flow_slot_reset.restype, L.vox_flow_slot_reset.argtypes = ci, [vp, vp, ci]
+    L.vox_flow_slot_state.restype, L.vox_flow_slot_state.argtypes = ci, [vp, ci, ctypes.POINTER(ctypes.c_int32)]
+    L.vox_flow_decode_chunk_slots.restype = ci
+    L.vox_flow_decode_chunk_slots.argtypes = [vp, vp, vp, ci, ci, ctypes.POINTER(ctypes.c_int32), vp, ctypes.c_uint64, ctypes.c_uint32, vp, vp]
     L._flow_bound = True
 
 
@@ -232,6 +237,49 @@ class CosyVoice2Flow:
                                                  ctypes.c_uint64(self.seed), int(noise_stream or 0), mel[b0:b0 + nb].data_ptr(),
                                                  mu[b0:b0 + nb].data_ptr() if mu is not None else None))
         return (mel, mu) if return_mu else mel
+
+    # ---- per-request evolving caches (CosyVoice2Decoder with shared_prompt_cache_mode=False) ----
+    def enable_slots(self, n_slots: int):
+        N.check(self.L.vox_flow_enable_slots(self.h, int(n_slots)))
+
+    def slot_reset(self, slot: int):
+        """The request that takes `slot` starts from a copy of the prompt's caches (set_prompt must have run)."""
+        N.check(self.L.vox_flow_slot_reset(self.h, N.stream(), int(slot)))
+
+    def slot_state(self, slot: int):
+        """[encoder, up-encoder, estimator cache lengths, then their ring offsets]"""
+        out = (ctypes.c_int32 * 6)()
+        N.check(self.L.vox_flow_slot_state(self.h, int(slot), out))
+        return list(out)
+
+    def slot_lens(self, slot: int):
+        return self.slot_state(slot)[:3]
+
+    def forward_chunk_slots(self, token: torch.Tensor, slots, noise: Optional[torch.Tensor] = None, noise_stream: Optional[int] = None):
+        """token [B, T], slots [B] -> mels fp32 [B, mel, 2T]; the slots' caches are read and then advanced by this chunk.  Requests whose
+        caches are in different states (started in different chunks) are decoded in groups of equal state, each group one native call."""
+        c = self.cfg
+        tok = token.to(self.device, torch.int32).contiguous()
+        B, T = tok.shape
+        slots = [int(s) for s in slots]
+        mel = torch.empty(B, c.mel, 2 * T, dtype=torch.float32, device=self.device)
+        nz = noise.reshape(c.mel, 2 * T).to(self.device, torch.float32).contiguous() if noise is not None else None
+        if noise is None and noise_stream is None:
+            self._chunk += 1
+            noise_stream = self._chunk
+        groups = {}
+        for i, sl in enumerate(slots):
+            groups.setdefault(tuple(self.slot_state(sl)), []).append(i)
+        for rows in groups.values():
+            for g0 in range(0, len(rows), self.max_batch):
+                idx = rows[g0:g0 + self.max_batch]
+                sub = tok[idx].contiguous()
+                out = torch.empty(len(idx), c.mel, 2 * T, dtype=torch.float32, device=self.device)
+                sl = (ctypes.c_int32 * len(idx))(*[slots[i] for i in idx])
+                N.check(self.L.vox_flow_decode_chunk_slots(self.h, N.stream(), sub.data_ptr(), len(idx), T, sl, nz.data_ptr() if nz is not None else None,
+                                                           ctypes.c_uint64(self.seed), int(noise_stream or 0), out.data_ptr(), None))
+                mel[idx] = out
+        return mel
 
     def close(self):
         if self.h:

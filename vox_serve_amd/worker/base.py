@@ -537,6 +537,9 @@ class ModelWorker:
                     self.nvtx_range_push("detokenize_replay")
                     audio = self.model.postprocess(batch, decoder_cache=cache)
                     self.nvtx_range_pop()
+                    if cache is not None:        # tensor-valued state (CosyVoice2's speech tail) goes back to each request's own
+                        for j, i in enumerate(sel):                      # cache (cuda_graph_worker.py:1241)
+                            caches[i].copy_from(cache[j:j + 1])
                     if self.needs_watermarking:
                         audio = self.run_watermark(audio)
                     audio = audio.detach().float()
