@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def build(dev, max_tokens=None, max_prefill_tokens=64):
+def build(dev, max_tokens=None, max_prefill_tokens=64, audio_decoder_device=None):
     from oracle import qwen3_ref as QR, voxref as vr           # weights recipe only (test side)
     from tests.test_gpu_codec import small_cfg
     from oracle import qwen3_codec_ref as CR
@@ -28,7 +28,7 @@ def build(dev, max_tokens=None, max_prefill_tokens=64):
                           codec_language_id={"english": 16}, spk_id={"a": 17})
     m = Qwen3TTSModel("tiny", W, CR.random_codec_weights(cc, 3), config=to_engine_cfg(cfg), codec_config=pc, tokens=toks,
                       device=str(dev), detokenize_interval=4, max_batch_size=4, page_size=16, max_num_pages=64,
-                      max_seq_len=512, max_prefill_tokens=max_prefill_tokens)
+                      max_seq_len=512, max_prefill_tokens=max_prefill_tokens, audio_decoder_device=audio_decoder_device)
     m.default_sampling_config = SamplingConfig(greedy=True, max_tokens=max_tokens, repetition_penalty=1.05, repetition_window=-1)
     return m, cfg
 
@@ -502,3 +502,26 @@ def test_cosyvoice2_served_end_to_end_with_flow_and_hift(evolving):
 
 
 _COSY_SERVED = {}
+
+
+def test_detokenizer_on_its_own_device_gives_the_same_audio():
+    """`audio_decoder_device` (worker/base.py:55-78, 641-644 of the reference: the LM on one GPU, the detokenizer on another): the
+    codec is created, reset and run under its own device's libvoxhip context and stream; the served PCM equals the default
+    placement's byte for byte.  With two GPUs visible the codec really sits on cuda:1; on a one-GPU box the same code path runs with
+    an explicit cuda:0 (the per-device context table, the device guard of every tokenizer call, the worker's stream placement)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vox_serve_amd import _native as N
+    dev = torch.device("cuda:0")
+    dec_dev = "cuda:1" if torch.cuda.device_count() >= 2 else "cuda:0"
+    prompt = [1, 2, 3, 40, 41, 42, 43, 7, 8, 9, 10, 11]
+    m, _ = build(dev, max_tokens=30)
+    want, _ = serve(m, {"r1": prompt, "r2": prompt[:3] + [50, 51] + prompt[-5:]})
+    m.engine.close(); m.audio_decoder.close()
+    m2, _ = build(dev, max_tokens=30, audio_decoder_device=dec_dev)
+    assert str(m2.audio_decoder.device) == dec_dev and torch.device(dec_dev).index in N._ctxs
+    got, w = serve(m2, {"r1": prompt, "r2": prompt[:3] + [50, 51] + prompt[-5:]})
+    assert str(w.detokenizer_device) == dec_dev and w._detok_stream.device == torch.device(dec_dev)
+    assert all(got[r]["pcm"] == want[r]["pcm"] and got[r]["done"] == want[r]["done"] for r in want)
+    assert torch.cuda.current_device() == 0                     # the guards restore the caller's device
+    m2.engine.close(); m2.audio_decoder.close()

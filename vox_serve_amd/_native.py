@@ -107,7 +107,7 @@ _SIGS = {
 _OPTIONAL_SIGS = {}
 
 _lib = None
-_ctx = None
+_ctxs = {}          # one context per HIP device of this process (the LM's GPU; a detokenizer on a second GPU gets its own)
 
 
 def lib():
@@ -133,16 +133,29 @@ def check(status):
 
 
 def ctx():
-    """Process-wide context on the current torch device (one process per GPU)."""
-    global _ctx
-    if _ctx is None:
-        import torch
-        if not torch.cuda.is_available():
-            raise VoxError("no HIP device visible: libvoxhip needs an MI355X (there is no CPU fallback)")
+    """The context of the CURRENT torch device (created on first use).  One process per GPU is the norm; a plugin whose
+    audio_decoder_device differs from its LM device runs its detokenizer calls under `device_guard`, and they land here
+    with that device current — its own context, workspace and streams."""
+    import torch
+    if not torch.cuda.is_available():
+        raise VoxError("no HIP device visible: libvoxhip needs an MI355X (there is no CPU fallback)")
+    d = torch.cuda.current_device()
+    h = _ctxs.get(d)
+    if h is None:
         h = c_void_p()
-        check(lib().vox_ctx_create(torch.cuda.current_device(), ctypes.byref(h)))
-        _ctx = h
-    return _ctx
+        check(lib().vox_ctx_create(d, ctypes.byref(h)))
+        _ctxs[d] = h
+    return h
+
+
+def device_guard(device):
+    """Context manager making `device` the current HIP device (no-op for CPU / index-less devices)."""
+    import contextlib
+    import torch
+    d = torch.device(device)
+    if d.type != "cuda" or d.index is None or not torch.cuda.is_available():
+        return contextlib.nullcontext()
+    return torch.cuda.device(d)
 
 
 def set_exact_rows(rows: int):

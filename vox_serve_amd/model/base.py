@@ -25,13 +25,16 @@ class BaseLM(ABC):
         self.model_name, self.device, self.dtype = model_name, device, dtype
         self.enable_torch_compile = enable_torch_compile
         self.audio_decoder_device = audio_decoder_device or device
-        if torch.device(self.audio_decoder_device) != torch.device(device) and not (
-                torch.device(device).index is None or torch.device(self.audio_decoder_device).index is None):
-            # libvoxhip keeps ONE context per process (one process per GPU): codec state, workspace and streams would be
-            # created on the LM's device while the weights sit on the other one.  The reference's second-GPU detokenizer
-            # (worker/base.py:641-644) maps to a second worker process here, which is not wired up yet.
-            raise NotImplementedError(f"audio_decoder_device {self.audio_decoder_device} != device {device}: a detokenizer on a "
-                                      "second GPU needs its own worker process (one libvoxhip context per process)")
+        if torch.device(self.audio_decoder_device) != torch.device(device) and torch.device(self.audio_decoder_device).type == "cuda" \
+                and torch.cuda.is_available() and (torch.device(self.audio_decoder_device).index or 0) >= torch.cuda.device_count():
+            raise ValueError(f"audio_decoder_device {self.audio_decoder_device}: only {torch.cuda.device_count()} GPU(s) visible")
+
+    def decoder_guard(self):
+        """Detokenizer on its own GPU (worker/base.py:55-78, 641-644 of the reference): every native detokenizer call — creation,
+        cache init / reset, decode — runs with audio_decoder_device current, so it uses that device's libvoxhip context, workspace
+        and streams; the token windows cross with one peer copy per chunk (a few hundred bytes per request)."""
+        from .. import _native as N
+        return N.device_guard(self.audio_decoder_device)
 
     # ---- architecture ----
     @property

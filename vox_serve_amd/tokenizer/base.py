@@ -4,10 +4,41 @@ The reference carries every codec's streaming state as nested tensors inside a d
 concatenates / copies it per request per chunk.  Here the state lives in place inside the native codec
 engine, keyed by a slot id; a DecoderCache is a light handle and the same four operations keep working.
 """
+import functools
+import inspect
 from dataclasses import dataclass, fields
 from typing import Any, List
 
 import torch
+
+
+def device_bound(cls):
+    """Class decorator for the native detokenizers: the constructor and every public method run with the tokenizer's own device
+    current, so that its libvoxhip context (`_native.ctx()` is per device), workspace allocations, streams and graphs belong to
+    that GPU whatever device the caller is on — the reference's `audio_decoder_device` (worker/base.py:55-78): the LM on one
+    GPU, the detokenizer on another.  With one GPU (or an index-less device) the guard is a no-op."""
+    from .. import _native as N
+    init = cls.__init__
+    sig = inspect.signature(init)
+
+    @functools.wraps(init)
+    def __init__(self, *a, **k):
+        bound = sig.bind(self, *a, **k)
+        bound.apply_defaults()
+        with N.device_guard(bound.arguments.get("device", "cuda")):
+            init(self, *a, **k)
+    cls.__init__ = __init__
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def method(self, *a, **k):
+            with N.device_guard(getattr(self, "device", "cuda")):
+                return fn(self, *a, **k)
+        return method
+    for name, fn in list(vars(cls).items()):
+        if inspect.isfunction(fn) and (not name.startswith("_") or name == "__call__"):
+            setattr(cls, name, wrap(fn))
+    return cls
 
 
 @dataclass

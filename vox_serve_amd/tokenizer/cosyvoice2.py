@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
-from .base import DecoderCache
+from .base import DecoderCache, device_bound
 from .cosyvoice_flow import CosyVoice2Flow, FlowConfig
 from .hifigan import HiFTConfig, HiFTGenerator
 
@@ -31,6 +31,7 @@ class CosyVoice2DecoderCache(DecoderCache):
     speech_cache: Optional[torch.Tensor] = None
 
 
+@device_bound
 class CosyVoice2Decoder:
     S3GEN_SR = 24000
     MAX_CACHE_LEN = 128

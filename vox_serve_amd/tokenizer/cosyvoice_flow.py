@@ -17,6 +17,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import _native as N
+from .base import device_bound
 from .qwen3_codec import ConvW
 
 
@@ -115,6 +116,7 @@ def time_schedule(cfg: FlowConfig):
     return torch.cat((e.sin(), e.cos()), dim=-1).contiguous(), torch.stack(dts).contiguous()
 
 
+@device_bound
 class CosyVoice2Flow:
     def __init__(self, weights: Dict[str, torch.Tensor], config: Optional[FlowConfig] = None, device="cuda", max_batch=8, max_T=32,
                  max_prompt_T=256, seed: int = 0):

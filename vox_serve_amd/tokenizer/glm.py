@@ -14,6 +14,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import _native as N
+from .base import device_bound
 from .cosyvoice_flow import ConformerW, FlowConfig, ResnetW, TBlockW, time_schedule
 from .hifigan import HiFTConfig, HiFTGenerator, tconv_taps
 from .qwen3_codec import ConvW
@@ -81,6 +82,7 @@ def _bind(L):
     L._glmflow_bound = True
 
 
+@device_bound
 class GLMFlow:
     def __init__(self, weights: Dict[str, torch.Tensor], config: Optional[GLMFlowConfig] = None, device="cuda", max_batch=8, max_T=32, seed: int = 0):
         self.cfg = c = config or GLMFlowConfig()
@@ -194,6 +196,7 @@ class GLMFlow:
             self.h = None
 
 
+@device_bound
 class GLMAudioDecoder:
     def __init__(self, flow_weights: Dict[str, torch.Tensor], hift_weights: Dict[str, torch.Tensor], device="cuda",
                  flow_config: Optional[GLMFlowConfig] = None, hift_config: Optional[HiFTConfig] = None, max_batch: int = 8, max_tokens: int = 25,

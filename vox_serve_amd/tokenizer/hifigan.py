@@ -21,6 +21,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _native as N
+from .base import device_bound
 from .qwen3_codec import ConvW, SnakeW
 
 
@@ -113,6 +114,7 @@ def tconv_taps(w: torch.Tensor, u: int) -> torch.Tensor:
     return torch.stack(taps, 0)
 
 
+@device_bound
 class HiFTGenerator:
     def __init__(self, weights: Dict[str, torch.Tensor], config: Optional[HiFTConfig] = None, device="cuda", max_batch=8, max_T=64,
                  seed: int = 0):

@@ -14,7 +14,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _native as N
-from .base import DecoderCache
+from .base import DecoderCache, device_bound
 from .qwen3_codec import ConvW
 
 
@@ -118,6 +118,7 @@ class MimiDecoderCache(DecoderCache):
     slot: Optional[torch.Tensor] = None
 
 
+@device_bound
 class MimiDecoder:
     def __init__(self, weights: Dict[str, torch.Tensor], config: Optional[MimiConfig] = None, num_codebooks: Optional[int] = None,
                  device="cuda", max_batch=8, max_frames=10):

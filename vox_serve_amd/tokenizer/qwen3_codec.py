@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _native as N
-from .base import DecoderCache
+from .base import DecoderCache, device_bound
 
 
 @dataclass
@@ -156,6 +156,7 @@ class Qwen3TTSDecoderCache(DecoderCache):
     slot: Optional[torch.Tensor] = None
 
 
+@device_bound
 class Qwen3TTSDecoder:
     """decode_chunk / init_cache surface of the reference's Qwen3TTSDecoder (qwen3_codec.py:1789-1903)."""
 

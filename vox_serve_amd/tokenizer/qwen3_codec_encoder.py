@@ -13,6 +13,7 @@ from typing import Dict, List, Optional
 import torch
 
 from .. import _native as N
+from .base import device_bound
 from .mimi import MimiLayerW
 from .qwen3_codec import ConvW
 
@@ -121,6 +122,7 @@ def _bind(L):
     L._cenc_bound = True
 
 
+@device_bound
 class Qwen3TTSTokenizerV2Encoder:
     def __init__(self, weights: Dict[str, torch.Tensor], config: Optional[Qwen3TTSTokenizerV2EncoderConfig] = None, device="cuda",
                  max_seconds: float = 30.0):

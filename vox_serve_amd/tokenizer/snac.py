@@ -20,6 +20,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from .. import _native as N
+from .base import device_bound
 from .qwen3_codec import ConvW, SnakeW
 
 
@@ -86,6 +87,7 @@ def _folded(W: Dict[str, torch.Tensor], name: str) -> torch.Tensor:
     return g * v / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
 
 
+@device_bound
 class SNACDecoder:
     def __init__(self, weights: Dict[str, torch.Tensor], config: Optional[SNACConfig] = None, device="cuda", max_batch=8, max_T=16,
                  seed: int = 0):

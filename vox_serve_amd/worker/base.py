@@ -57,7 +57,7 @@ class ModelWorker:
             torch.set_num_threads(1)
         self.model = model
         self.device = device
-        self.detokenizer_device = detokenizer_device or device
+        self.detokenizer_device = detokenizer_device or getattr(model, "audio_decoder_device", None) or device
         self.max_batch_size, self.max_num_pages, self.page_size = max_batch_size, max_num_pages, page_size
         self.dp_rank, self.dp_size = dp_rank, dp_size
         base = logging.getLogger(__name__)
@@ -521,9 +521,11 @@ class ModelWorker:
             # from the state its predecessor left (seamless audio).  The reference decodes all of a request's windows from
             # the same starting state and keeps the last one's (worker/base.py:641-656).
             n_rounds = max(ci for _, ci in mapping) + 1 if stateful else 1
-            on_gpu = torch.cuda.is_available() and str(self.device).startswith("cuda")
+            # the chunk runs on a stream of the detokenizer's device (the LM's GPU, or a second one: worker/base.py:55-78, 641-644 of the
+            # reference); entering the stream context makes that device current, so the plugin's native calls use its own context
+            on_gpu = torch.cuda.is_available() and str(self.detokenizer_device).startswith("cuda")
             if on_gpu and self._detok_stream is None:
-                self._detok_stream = torch.cuda.Stream(device=self.device)
+                self._detok_stream = torch.cuda.Stream(device=self.detokenizer_device)
             if on_gpu:
                 self._detok_stream.wait_stream(torch.cuda.current_stream())
             ctx = torch.cuda.stream(self._detok_stream) if on_gpu else contextlib.nullcontext()
