@@ -1,6 +1,7 @@
 """Per-frame HBM traffic of the LM graph from a rocprofv3 --pmc pass (FETCH_SIZE or WRITE_SIZE).
-usage: pmc_summary.py <counter_collection.csv> [COUNTER]
-Counts frames by the number of k_qwen3_feedback dispatches; sums the counter over the LM kernels (everything that is
+usage: pmc_summary.py <counter_collection.csv> [COUNTER] [frame-marker kernel, default k_qwen3_feedback; k_csm_feedback / k_lm_feedback
+for the CSM / single-stack engines]
+Counts frames by the number of frame-marker dispatches; sums the counter over the LM kernels (everything that is
 not a codec / torch kernel) and over the codec kernels separately.  Units: the counter is reported in KiB-like units of
 1024 B by rocprofv3's derived metric; MI355X_MICROARCH.md ('HBM [CDNA4]'): on gfx950 FETCH_SIZE tallies 128-B requests
 at 64 B for wide coalesced streaming reads -> corrected = 2 x raw.  WRITE_SIZE is uncalibrated (reported raw)."""
@@ -8,10 +9,11 @@ import csv, sys, json
 from collections import defaultdict
 path = sys.argv[1]
 counter = sys.argv[2] if len(sys.argv) > 2 else "FETCH_SIZE"
+marker = sys.argv[3] if len(sys.argv) > 3 else "k_qwen3_feedback"
 rows = list(csv.DictReader(open(path)))
 # engine-creation kernels (fragment-major weight copies, depth-loop projection tables) run before the first embedding
 # kernel of the first prefill: they are not part of any frame
-first = min((int(r["Dispatch_Id"]) for r in rows if "k_qwen3_mix" in r["Kernel_Name"] or "k_frame_init" in r["Kernel_Name"]), default=0)
+first = min((int(r["Dispatch_Id"]) for r in rows if any(t in r["Kernel_Name"] for t in ("k_qwen3_mix", "k_frame_init", "k_csm_embed", "k_lm_feedback"))), default=0)
 by = defaultdict(float)
 cnt = defaultdict(int)
 for r in rows:
@@ -20,8 +22,9 @@ for r in rows:
     name = r["Kernel_Name"].split("(")[0].replace("void ", "")
     by[name] += float(r["Counter_Value"])
     cnt[name] += 1
-frames = sum(v for k, v in cnt.items() if "k_qwen3_feedback" in k)
-codec = lambda k: any(t in k for t in ("conv_gemm", "codec", "snake", "dwconv", "rvq", "state_update", "_f32", "final_conv", "pos_advance"))
+frames = sum(v for k, v in cnt.items() if marker in k)
+codec = lambda k: any(t in k for t in ("conv_gemm", "codec", "snake", "dwconv", "rvq", "state_update", "_f32", "final_conv", "pos_advance", "k_mimi", "k_flow",
+                                       "k_hift", "k_glmflow"))
 torchk = lambda k: k.startswith("at::") or "rocclr" in k or "elementwise" in k or "k_swizzle_frag" in k   # (+ engine-creation kernels)
 lm = sum(v for k, v in by.items() if not codec(k) and not torchk(k))
 cd = sum(v for k, v in by.items() if codec(k))

@@ -518,6 +518,9 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         h.x = m->dx; h.x_rows = i == 1 ? m->odd_rows : nullptr; h.norm_w = m->w.depth_norm; h.eps = c.depth.eps;
         h.y = dl; h.B = B; h.N = c.depth_vocab; h.K = Hd; h.pro = VOX_PRO_RMSNORM; h.epi = VOX_EPI_STORE;
         h.keep_weights = m->depth->keep_weights;
+#ifdef VOX_DEV_KNOBS
+        { static int hk = -2; if (hk == -2) { const char* e = getenv("VOX_HEAD_KEEP"); hk = e ? atoi(e) : -1; } if (hk >= 0) h.keep_weights = hk; }
+#endif
         VOX_TRY(vox_launch_linear(m->ctx, st, h));
         SampleCall s;
         s.logits = dl; s.B = B; s.V = c.depth_vocab; s.cfg = *sc; s.cfg.repetition_penalty = 1.0f;
@@ -605,6 +608,9 @@ int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_
     s = vox_stack_create(ctx, &dc, w->depth_layers, w->depth_norm, w->depth_rope, w->depth_rope_max_pos, &m->depth);
     if (s != VOX_OK) { vox_stack_destroy(m->talker); delete m; return s; }
     m->depth->keep_weights = 1;   // 0.16 GB re-read 15 times per frame: Infinity-Cache resident
+#ifdef VOX_DEV_KNOBS
+    if (const char* e = getenv("VOX_DEPTH_KEEP")) m->depth->keep_weights = atoi(e);
+#endif
     const size_t R = tc.max_rows;
     m->dkv_stride = (int64_t)B * 2 * G * dc.kv_heads * dc.head_dim;
     bool ok = hipMalloc(&m->te, R * cfg->text_hidden * 2) == hipSuccess &&
