@@ -616,3 +616,36 @@ def test_failed_prefill_launch_answers_once_and_rolls_the_piggy_backed_rows_back
     lens = [row[0][1] for row in W.seen if row and row[0][0] == "ok"]
     assert lens == list(range(lens[0], lens[0] + len(lens)))
     assert w.empty_pages.qsize() == 16
+
+
+def test_device_bound_tokenizers_and_per_device_contexts():
+    """`audio_decoder_device` plumbing that can be checked without a GPU: the guard is a no-op for CPU / index-less devices, the
+    decorator wraps the constructor and the public methods only (private helpers run inside the caller's guard), and every
+    native tokenizer class carries it."""
+    import contextlib
+    from vox_serve_amd import _native as N
+    from vox_serve_amd.tokenizer.base import device_bound
+    assert isinstance(N.device_guard("cpu"), contextlib.nullcontext) and isinstance(N.device_guard("cuda"), contextlib.nullcontext)
+    calls = []
+
+    @device_bound
+    class T:
+        def __init__(self, x, device="cpu"):
+            self.device, self.x = device, x
+
+        def decode(self, y):
+            calls.append("decode")
+            return self._helper(y)
+
+        def _helper(self, y):
+            return self.x + y
+
+        def __call__(self, y):
+            return self.decode(y)
+    t = T(2, device="cpu")
+    assert t(3) == 5 and t.decode(1) == 3 and calls == ["decode", "decode"]
+    assert T.decode.__wrapped__ is not None and not hasattr(T._helper, "__wrapped__")
+    import vox_serve_amd.tokenizer.cosyvoice2 as c2, vox_serve_amd.tokenizer.glm as gl, vox_serve_amd.tokenizer.mimi as mi
+    import vox_serve_amd.tokenizer.qwen3_codec as qc, vox_serve_amd.tokenizer.snac as sn
+    for cls in (c2.CosyVoice2Decoder, gl.GLMAudioDecoder, mi.MimiDecoder, qc.Qwen3TTSDecoder, sn.SNACDecoder):
+        assert hasattr(cls.__init__, "__wrapped__"), cls

@@ -10,6 +10,13 @@ from vox_serve_amd.engine import StackCfg, _stack_config, rope_table
 
 dev = torch.device("cuda")
 L, ctx = N.lib(), N.ctx()
+if "--with-engine" in sys.argv:      # a whole Qwen3-TTS engine (3.5 GB of weights, KV pages, workspaces) alive in the process, unused
+    from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
+    from vox_serve_amd.synth import synth_qwen3_weights
+    _cfg = Qwen3Cfg()
+    _W = synth_qwen3_weights(_cfg, dev, seed=0)
+    _eng = Qwen3Engine(_cfg, _W, max_batch=1, page_size=128, max_pages=64, max_seq_len=2304, max_prefill_rows=128)
+    sys.argv.remove("--with-engine")
 H, NL, heads, kvh, D, F, G = 1024, 5, 16, 8, 128, 3072, 16
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 4          # distinct weight sets cycled (footprint = reps x 155 MB)
 ec = StackCfg(H, NL, heads, kvh, D, F, 1e-6, 1e6, 1.0, None, False, None, True, False)
