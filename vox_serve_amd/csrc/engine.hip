@@ -490,7 +490,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         s.emb_dst = (bf16_t*)m->depth_x + H; s.emb_dst_stride = 2L * H; s.ws = m->ctx->samp_ws;
         VOX_TRY(vox_launch_sample(st, s));
     }
-    for (int i = 1; i < G && !(ablate() & 2); ++i) {
+    for (int i = (ablate() & 4096) ? 2 : 1; i < G && !(ablate() & 2); ++i) {      // (dev knob 4096: leave out depth step 1)
         const int rows = i == 1 ? 2 * B : B;
         if (i == 1 || !m->proj_tab) {     // (steps >= 2: the previous step's sampler gathered the tabulated projection into dx)
             LinearCall p;  // small_to_mtp_projection
@@ -521,7 +521,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
 #ifdef VOX_DEV_KNOBS
         { static int hk = -2; if (hk == -2) { const char* e = getenv("VOX_HEAD_KEEP"); hk = e ? atoi(e) : -1; } if (hk >= 0) h.keep_weights = hk; }
 #endif
-        VOX_TRY(vox_launch_linear(m->ctx, st, h));
+        if (!(ablate() & 2048)) VOX_TRY(vox_launch_linear(m->ctx, st, h));      // (dev knob 2048: leave out the depth heads)
         SampleCall s;
         s.logits = dl; s.B = B; s.V = c.depth_vocab; s.cfg = *sc; s.cfg.repetition_penalty = 1.0f;
         s.seed = seed; s.offset = (uint64_t)i; s.offset_dev = io->rng_offset; s.offset_mul = (uint64_t)G;
