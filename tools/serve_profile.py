@@ -34,14 +34,23 @@ def main():
     for i in range(load + 1):
         ids = [1, 2, 3] + rng.integers(0, 151000, 64).tolist() + [4, 5, 6, 7, 8]
         t.requests.put(encode_request(f"r{i}", "", model_kwargs={"prompt_token_ids": ids, "language": "english"}))
-    for _ in range(load + 30):       # prefill everything, capture graphs
-        s._step()
+    use_async = len(sys.argv) > 3 and sys.argv[3] == "async"
+    if use_async:
+        import asyncio
+        s.async_scheduling = True
+        asyncio.run(s._run_async_loop(max_steps=load + 30))
+    else:
+        for _ in range(load + 30):       # prefill everything, capture graphs
+            s._step()
     torch.cuda.synchronize()
     pr = cProfile.Profile()
     t0 = time.perf_counter()
     pr.enable()
-    for _ in range(n_steps):
-        s._step()
+    if use_async:
+        asyncio.run(s._run_async_loop(max_steps=n_steps))
+    else:
+        for _ in range(n_steps):
+            s._step()
     torch.cuda.synchronize()
     pr.disable()
     dt = time.perf_counter() - t0

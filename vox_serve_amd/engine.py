@@ -147,9 +147,7 @@ class Qwen3Engine:
             self._plan_layout[name] = (off, n)
             off += n
         self.plan_dev = torch.zeros(off, **i32)
-        self.plan_host = torch.zeros(off, dtype=torch.int32).pin_memory()
-        self._plan_np = self.plan_host.numpy()       # a view: numpy writes land in the pinned block
-        self._ptab_last = {}
+        self._init_plan_host(off)
         self.kv = torch.zeros(t.layers, max_pages, 2, page_size, t.kv_heads, t.head_dim, dtype=torch.bfloat16, device=dev)
         self.out_ids = torch.zeros(max_batch, G1, **i32)
         self.out_logits = torch.zeros(max_batch, cfg.vocab, dtype=torch.bfloat16, device=dev)
@@ -186,15 +184,23 @@ class Qwen3Engine:
         off, n = self._plan_layout[name]
         return self.plan_dev[off:off + n]
 
-    def _ph(self, name):
-        off, n = self._plan_layout[name]
-        return self.plan_host[off:off + n]
+    PLAN_RING = 3
+
+    def _init_plan_host(self, n):
+        """The host side of the plan: one ordinary array that is edited in place (`_plan_np`) and a small ring of pinned
+        blocks it is copied through.  A pinned block is reused only after the H2D copy that read it has run (its event), so
+        an upload never waits for the frame in flight: with async scheduling the host stages frame N + 1 while N runs."""
+        self._plan_np = np.zeros(n, dtype=np.int32)
+        self._plan_pin = [torch.zeros(n, dtype=torch.int32).pin_memory() for _ in range(self.PLAN_RING)]
+        self._plan_pin_np = [t.numpy() for t in self._plan_pin]
+        self._plan_ev = [None] * self.PLAN_RING
+        self._plan_k = 0
+        self._ptab_last = {}
 
     def upload_plan(self, **arrays):
-        """Host int lists/arrays -> the pinned block -> one async H2D copy (no synchronisation).
-        Host cost matters (the GPU idles between frames while this runs): plain numpy writes into views of the pinned
-        block, and the per-row page table is rewritten only for rows whose page list changed since the last upload."""
-        self.stream.synchronize()       # the previous frame may still read the pinned block's last upload
+        """Host int lists/arrays -> a pinned block -> one async H2D copy in stream order (no synchronisation with the frame
+        in flight).  Host cost matters: plain numpy writes, and the per-row page table is rewritten only for rows whose page
+        list changed since the last upload."""
         hv = self._plan_np
         for name, a in arrays.items():
             a = np.asarray(a, dtype=np.int32)
@@ -211,8 +217,16 @@ class Qwen3Engine:
                 if prev is None or prev.size != row.size or not np.array_equal(prev, row):
                     pt[b, : row.size] = row
                     last[b] = row.copy()
+        k = self._plan_k
+        self._plan_k = (k + 1) % self.PLAN_RING
+        if self._plan_ev[k] is not None:
+            self._plan_ev[k].synchronize()          # PLAN_RING uploads ago: long done
+        self._plan_pin_np[k][:] = hv
         with self._OnStream(self):
-            self.plan_dev.copy_(self.plan_host, non_blocking=True)
+            self.plan_dev.copy_(self._plan_pin[k], non_blocking=True)
+            if self._plan_ev[k] is None:
+                self._plan_ev[k] = torch.cuda.Event()
+            self._plan_ev[k].record()
 
     def _io(self):
         return N.Qwen3IO(self.input_ids.data_ptr(), self.input_masks.data_ptr(), self.input_features.data_ptr(),
@@ -428,9 +442,7 @@ class LMEngine(Qwen3Engine):
             self._plan_layout[name] = (off, n)
             off += n
         self.plan_dev = torch.zeros(off, **i32)
-        self.plan_host = torch.zeros(off, dtype=torch.int32).pin_memory()
-        self._plan_np = self.plan_host.numpy()       # a view: numpy writes land in the pinned block
-        self._ptab_last = {}
+        self._init_plan_host(off)
         self.kv = torch.zeros(c.layers, max_pages, 2, page_size, c.kv_heads, c.head_dim, dtype=torch.bfloat16, device=dev)
         self.out_ids = torch.zeros(max_batch, **i32)
         self.out_logits = torch.zeros(max_batch, cfg.vocab_out, dtype=torch.bfloat16, device=dev)
@@ -560,9 +572,7 @@ class CSMEngine(Qwen3Engine):
             self._plan_layout[name] = (off, n)
             off += n
         self.plan_dev = torch.zeros(off, **i32)
-        self.plan_host = torch.zeros(off, dtype=torch.int32).pin_memory()
-        self._plan_np = self.plan_host.numpy()       # a view: numpy writes land in the pinned block
-        self._ptab_last = {}
+        self._init_plan_host(off)
         self.kv = torch.zeros(b.layers, max_pages, 2, page_size, b.kv_heads, b.head_dim, dtype=torch.bfloat16, device=dev)
         self.out_ids = torch.zeros(max_batch, C1, **i32)
         self.out_logits = torch.zeros(max_batch, V, dtype=torch.bfloat16, device=dev)

@@ -75,6 +75,7 @@ class ModelWorker:
         self._pending = None         # the deferred request-state update of the last launched step (async scheduling)
         self._detok_stream = None    # launch_detokenize: the codec chunk + its D2H copy run here, beside the LM frame
         self._snap, self._snap_i = None, 0
+        self._code_pins, self._code_pin_i = [], 0
         self._resident = None        # request ids whose next inputs already sit in the engine's rows (feedback path)
         self._resident_reqs = []     # ... and the requests themselves (their repetition-cache rows live in the engine)
         self._next_feats = None
@@ -545,6 +546,8 @@ class ModelWorker:
                     if not sel:
                         continue
                     batch = torch.stack([token_ids[i] for i in sel], dim=0)
+                    if on_gpu and not batch.is_cuda:
+                        batch = self._pinned_upload(batch)
                     cache = DecoderCache.cat([caches[i] for i in sel]) if stateful else None
                     self.nvtx_range_push("detokenize_replay")
                     audio = self.model.postprocess(batch, decoder_cache=cache)
@@ -575,6 +578,27 @@ class ModelWorker:
         # step, so both are snapshotted here (an EOS sampled by this step must not end the request before its tail window)
         done_snap = [(bool(r.done_lm_generation), len(r.lm_output_audio_tokens)) for r in requests]
         return {"requests": requests, "mapping": mapping, "parts": parts, "event": event, "n_last": n_last, "done_snap": done_snap}
+
+    def _pinned_upload(self, batch: torch.Tensor) -> torch.Tensor:
+        """Token windows -> the detokenizer's device through a pinned staging block, non-blocking on the current (detokenize)
+        stream.  A pageable H2D copy makes the host wait for the LM frame in flight (measured with async scheduling at 32
+        requests: 2.6 ms per chunk); the block is reused only after the copy that read it has run."""
+        ring = self._code_pins
+        if not ring:
+            ring.extend({"buf": None, "event": None} for _ in range(4))
+        ent = ring[self._code_pin_i]
+        self._code_pin_i = (self._code_pin_i + 1) % len(ring)
+        n = batch.numel()
+        if ent["buf"] is None or ent["buf"].numel() < n or ent["buf"].dtype != batch.dtype:
+            ent["buf"] = torch.empty(max(n, 4096), dtype=batch.dtype).pin_memory()
+        elif ent["event"] is not None:
+            ent["event"].synchronize()
+        host = ent["buf"][:n].view(batch.shape)
+        host.copy_(batch)
+        dev = host.to(self.detokenizer_device, non_blocking=True)
+        ent["event"] = ent["event"] or torch.cuda.Event()
+        ent["event"].record()
+        return dev
 
     def finish_detokenize(self, pending):
         """Second half of `run_detokenize`: wait for the audio of `launch_detokenize`, PCM16 -> the requests' output queues."""
