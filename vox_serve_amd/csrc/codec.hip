@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
                 uint4 h, m, l;
                 split3(v0[i], v1[i], h, m, l);
                 *reinterpret_cast<uint4*>(&As[0][o]) = h;
-                *reinterpret_cast<uint4*>(&As[1][o]) = m;
-                *reinterpret_cast<uint4*>(&As[2][o]) = l;
+                if (a.planes > 1) *reinterpret_cast<uint4*>(&As[1][o]) = m;      // (planes is uniform: the unused terms' VALU work and LDS
+                if (a.planes > 2) *reinterpret_cast<uint4*>(&As[2][o]) = l;      //  stores fall away with their consumers)
             }
         }
 #pragma unroll
@@ -701,7 +701,7 @@ int vox_codec_create(vox_ctx* ctx, const vox_codec_config* cfg, const vox_codec_
 }
 
 int vox_codec_set_operand_planes(vox_codec* m, int planes) {
-    if (!m || (planes != 1 && planes != 3)) return vox_fail(VOX_ERR_INVALID, "codec_set_operand_planes: 1 or 3");
+    if (!m || planes < 1 || planes > 3) return vox_fail(VOX_ERR_INVALID, "codec_set_operand_planes: 1, 2 or 3");
     m->planes = planes;
     return VOX_OK;
 }

@@ -766,6 +766,7 @@ static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a) {
 }
 
 __global__ void k_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps);
+__global__ void k_rmsnorm_frag(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps);
 
 // ================================================================================================
 // linear for 17+ rows where the full-K kernel below does not apply (33+ rows: prefill, depth step 1 of > 16 requests; or an
@@ -1112,6 +1113,18 @@ int vox_launch_swizzle_frag(hipStream_t st, const void* src, void* dst, int rows
     return VOX_OK;
 }
 
+// Development probe (VOX_PRENORM2048=1, dev builds only): RMSNorm of the 17..32-row talker linears as its own launch + copy-prologue
+// GEMM ("normalise once").  Measured on MI355X, B = 32: talker 1.95 -> 2.27 ms with a row-major normed operand, 2.08 ms fragment-major:
+// the two extra launches per layer cost more than the per-block prologue they replace.  Not used by the shipped library.
+#ifdef VOX_DEV_KNOBS
+static bool dev_prenorm2048() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("VOX_PRENORM2048"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+#else
+static constexpr bool dev_prenorm2048() { return false; }
+#endif
 static bool fullk_shape_ok(int B, int N, int K, int pro, int epi, int exact_rows = 2) {
     if (B <= exact_rows || B < 2 || B > 128 || K % 256) return false;
     if (N % 16 && (B > 32 || epi == EPI_SILU_MUL)) return false;    // a column tail only for plain outputs of <= 32 rows (row-major weights)
@@ -1119,13 +1132,13 @@ static bool fullk_shape_ok(int B, int N, int K, int pro, int epi, int exact_rows
     const int ks = K / 256;
     if (pro == PRO_RMSNORM && (epi == EPI_STORE || epi == EPI_SILU_MUL)) return ks == 4 || ks == 8;
     if (pro == PRO_COPY && epi == EPI_STORE) return ks == 4 || ks == 8 || ks == 12 || ks == 16 || ks == 24 || ks == 32;
-    if (pro == PRO_COPY && epi == EPI_SILU_MUL) return ks == 16;
+    if (pro == PRO_COPY && epi == EPI_SILU_MUL) return ks == 16 || (ks == 8 && dev_prenorm2048());
     return false;
 }
 // K = 4096 with a norm prologue (GLM-4-Voice width): the operand registers of a whole row slice do not fit next to the weights,
 // so the row is normalised once into the caller's scratch and the copy-prologue kernel runs on that
 static bool fullk_prenorm_ok(const LinearCall& c) {
-    return !c.fixed_order && !c.x_out && !c.x_rows && c.norm_scratch && c.pro == PRO_RMSNORM && c.K == 4096 &&
+    return !c.fixed_order && !c.x_out && !c.x_rows && c.norm_scratch && c.pro == PRO_RMSNORM && (c.K == 4096 || (c.K == 2048 && c.B > 16 && dev_prenorm2048())) &&
            (c.epi == EPI_STORE || c.epi == EPI_SILU_MUL) && fullk_shape_ok(c.B, c.N, c.K, PRO_COPY, c.epi == EPI_SILU_MUL ? EPI_SILU_MUL : EPI_STORE, c.exact_rows);
 }
 template <int MT, int KSTEPS, int PRO, int EPI>
@@ -1156,7 +1169,7 @@ static int launch_gemm_fullk(hipStream_t st, const LinArgs& a) {
 #define VOX_FK(KS) if (ks == KS) return a.B <= 16 ? launch_gemm_fullk_t<1, KS, PRO, EPI>(st, a) : launch_gemm_fullk_t<2, KS, PRO, EPI>(st, a);
     if constexpr (!(PRO == PRO_COPY && EPI == EPI_SILU_MUL)) { VOX_FK(4) VOX_FK(8) }
     if constexpr (PRO == PRO_COPY && EPI == EPI_STORE) { VOX_FK(12) VOX_FK(16) VOX_FK(24) VOX_FK(32) }
-    if constexpr (PRO == PRO_COPY && EPI == EPI_SILU_MUL) { VOX_FK(16) }
+    if constexpr (PRO == PRO_COPY && EPI == EPI_SILU_MUL) { VOX_FK(8) VOX_FK(16) }
 #undef VOX_FK
     return vox_fail(VOX_ERR_INVALID, "linear(full-K): unsupported K");
 }
@@ -1218,6 +1231,16 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& call) {
     if (dev & 8) a.bias = nullptr;
 #endif
     if (fullk_prenorm_ok(c) && pro == PRO_RMSNORM) {
+#ifdef VOX_DEV_KNOBS
+        if (c.K == 2048 && dev_prenorm2048()) {      // timing probe: the normalised rows written fragment-major
+            static bf16_t* nfrag = nullptr;
+            if (!nfrag) (void)hipMalloc((void**)&nfrag, (size_t)128 * 4096 * 2);
+            hipLaunchKernelGGL(k_rmsnorm_frag, dim3((c.B + 3) / 4), dim3(256), 0, st, a.x, a.nw, nfrag, c.B, c.K, c.eps);
+            a.x = (const bf16_t*)c.norm_scratch; a.x_stride = c.K; a.x_frag = nfrag;
+            if (epi == EPI_SILU_MUL) return launch_gemm_fullk<PRO_COPY, EPI_SILU_MUL>(st, a);
+            return launch_gemm_fullk<PRO_COPY, EPI_STORE>(st, a);
+        }
+#endif
         hipLaunchKernelGGL(k_rmsnorm, dim3((c.B + 3) / 4), dim3(256), 0, st, a.x, a.nw, (bf16_t*)c.norm_scratch, c.B, c.K, c.eps);
         a.x = (const bf16_t*)c.norm_scratch; a.x_stride = c.K; a.x_frag = nullptr;
         if (epi == EPI_SILU_MUL) return launch_gemm_fullk<PRO_COPY, EPI_SILU_MUL>(st, a);
@@ -1279,6 +1302,27 @@ __global__ __launch_bounds__(256) void k_rmsnorm(const bf16_t* x, const bf16_t* 
         o.z = (u32)f2bf((bflo(v.z) * rinv) * bflo(g.z)) | ((u32)f2bf((bfhi(v.z) * rinv) * bfhi(g.z)) << 16);
         o.w = (u32)f2bf((bflo(v.w) * rinv) * bflo(g.w)) | ((u32)f2bf((bfhi(v.w) * rinv) * bfhi(g.w)) << 16);
         yr[c] = o;
+    }
+}
+
+// (development probe) the same, output fragment-major
+__global__ __launch_bounds__(256) void k_rmsnorm_frag(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = H >> 3;
+    const uint4* xr = reinterpret_cast<const uint4*>(x) + (size_t)row * nch;
+    const uint4* nw = reinterpret_cast<const uint4*>(w);
+    float s = 0.0f;
+    for (int c = lane; c < nch; c += 64) s = sq8(xr[c], s);
+    s = butterfly<64>(s);
+    const float rinv = 1.0f / sqrtf(s / (float)H + eps);
+    for (int c = lane; c < nch; c += 64) {
+        uint4 v = xr[c], g = nw[c], o;
+        o.x = (u32)f2bf((bflo(v.x) * rinv) * bflo(g.x)) | ((u32)f2bf((bfhi(v.x) * rinv) * bfhi(g.x)) << 16);
+        o.y = (u32)f2bf((bflo(v.y) * rinv) * bflo(g.y)) | ((u32)f2bf((bfhi(v.y) * rinv) * bfhi(g.y)) << 16);
+        o.z = (u32)f2bf((bflo(v.z) * rinv) * bflo(g.z)) | ((u32)f2bf((bfhi(v.z) * rinv) * bfhi(g.z)) << 16);
+        o.w = (u32)f2bf((bflo(v.w) * rinv) * bflo(g.w)) | ((u32)f2bf((bfhi(v.w) * rinv) * bfhi(g.w)) << 16);
+        *reinterpret_cast<uint4*>(y + frag_off(row, c * 8, H)) = o;
     }
 }
 
