@@ -63,7 +63,7 @@ def test_small_codec_streaming_vs_oracle(dev):
     # requests are independent and slots are state: decoding request 1 alone in another slot gives the same audio
     c1 = dec.init_cache(1)
     solo = torch.cat([dec.decode_chunk(codes[1:2, :, t:t + 4], c1)[0].cpu().clone() for t in range(0, 20, 4)], -1).numpy()
-    assert rms(solo - got[1:2]) < 1e-6
+    assert rms(solo - got[1:2]) < 1e-5      # (fp32 summation order of the multi-tap convs depends on the row count: tile kernels differ)
     dec.close()
 
 

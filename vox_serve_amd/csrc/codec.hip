@@ -71,7 +71,23 @@ struct ConvGemmArgs {
     // LayerNorm of the input rows fused into the A-operand staging (few-row kernel, one tap): x <- (x - mean) * rstd * ln_w + ln_b
     const float *ln_w, *ln_b;
     float ln_eps;
+    // "S2" rows: an activation row of Cin values stored as its two leading bf16 terms, [Cin x bf16 h][Cin x bf16 m] (x ~ h + m, 16
+    // significand bits; the same 4 * Cin bytes as the fp32 row, so buffers, history state and k_state_update are format-agnostic).
+    // The producing GEMM's epilogue splits each value ONCE (out2_s2); the consuming GEMM (x_s2, planes = 2) stages plain bf16 — the
+    // per-tap three-way split of fp32 rows made the many-row decoder convs VALU-bound (MFMA 16 % busy; round-3 planes probe).
+    int x_s2, out2_s2;
+    int dev;               // development builds (-DVOX_DEV_KNOBS, VOX_CODEC_DEV): 1 skip the K loop, 2 no out2 stores, 4 no out stores, 8 no residual loads
 };
+#ifdef VOX_DEV_KNOBS
+#define CG_DEV(a, bit) ((a).dev & (bit))
+#else
+#define CG_DEV(a, bit) 0
+#endif
+// the two leading bf16 terms of v
+__device__ __forceinline__ void split2(float v, bf16_t& h, bf16_t& m) {
+    h = f2bf(v);
+    m = f2bf(v - bf2f(h));
+}
 // sin for the fused epilogues: explicit reduction to revolutions + the hardware v_sin_f32 (absolute error ~1e-6 on [-1, 1]:
 // far inside the 1e-4 waveform bar, and sin^2 enters scaled by 1/beta ~ 1).  The libm sinf (argument-reduction table,
 // private array) cannot be inlined into a GEMM epilogue without spilling the accumulators to scratch.
@@ -79,6 +95,73 @@ __device__ __forceinline__ float snake_f(float v, float alpha, float invb) {
     const float r = (v * alpha) * 0.15915494309189535f;
     const float s_ = __builtin_amdgcn_sinf(r - floorf(r));
     return v + invb * (s_ * s_);
+}
+
+// Epilogue of the tiled conv GEMMs (2 x 2 waves, WM x WN 16x16 tiles per wave)
+template <int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, f32x4 (&acc)[WM][WN], int m0, int n0, int wm, int wn, int lane) {
+    // epilogue.  D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg.  The per-column constants are fetched once and
+    // the residual values of a whole row fragment are requested together, ahead of the arithmetic: an epilogue that interleaves loads,
+    // stores and integer divisions element by element serialises on memory latency (the compiler must keep every load behind the
+    // previous store) — the 1-tap conv2 of a residual unit took longer than its 7-tap conv1 (485 vs 365 us at 614 k rows).
+    const int l15 = lane & 15, rg = (lane >> 4) * 4;
+    float cb[WN], cs[WN], ca[WN], ci[WN];
+    int cn[WN], cj[WN], cc[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn + j * 16 + l15, nn = n < a.N ? n : a.N - 1;
+        cn[j] = n;
+        cb[j] = a.bias ? a.bias[nn % a.bias_mod] : 0.0f;
+        cs[j] = a.scale ? a.scale[nn] : 1.0f;
+        ca[j] = ci[j] = 0.0f; cj[j] = cc[j] = 0;
+        if (a.out2) {
+            cj[j] = nn / a.sn_mod; cc[j] = nn - cj[j] * a.sn_mod;      // (a transposed conv's N = r * sn_mod outputs: r consumer rows)
+            ca[j] = a.sn_alpha[cc[j]]; ci[j] = a.sn_invb[cc[j]];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int mb = m0 + wm + i * 16 + rg;
+        float rs[WN][4], rsc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rsc[r] = (a.rscale && mb + r < a.M) ? a.rscale[mb + r] : 1.0f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rs[j][r] = (a.res && !CG_DEV(a, 8) && mb + r < a.M && cn[j] < a.N) ? a.res[(size_t)(mb + r) * a.N + cn[j]] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + r;
+                const bool ok = m < a.M && cn[j] < a.N;
+                float v = acc[i][j][r] + cb[j];
+                if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                if (a.rscale) v = rsc[r] * v;
+                if (a.res) v = rs[j][r] + cs[j] * v;
+                else if (a.scale) v = cs[j] * v;
+                const size_t o = (size_t)m * a.N + cn[j];
+                if (a.out && ok && !CG_DEV(a, 4)) a.out[o] = v;
+                if (a.out2 && !CG_DEV(a, 2)) {
+                    const float sv2 = snake_f(v, ca[j], ci[j]);
+                    if (a.out2_s2) {
+                        // S2 row of the consumer: [sn_mod x h][sn_mod x m]; a lane pair (columns c, c + 1) stores one 32-bit word per
+                        // term (the even lane the h pair, the odd lane the m pair) instead of two 16-bit stores each
+                        bf16_t hb, mbf;
+                        split2(sv2, hb, mbf);
+                        const unsigned hp = __shfl_xor((unsigned)hb, 1, 64), mp = __shfl_xor((unsigned)mbf, 1, 64);
+                        bf16_t* r16 = reinterpret_cast<bf16_t*>(a.out2 + (size_t)m * a.N) + (size_t)cj[j] * 2 * a.sn_mod;
+                        if (ok) {
+                            if (!(l15 & 1)) *reinterpret_cast<unsigned*>(r16 + cc[j]) = (unsigned)hb | (hp << 16);
+                            else *reinterpret_cast<unsigned*>(r16 + a.sn_mod + cc[j] - 1) = mp | ((unsigned)mbf << 16);
+                        }
+                    } else if (ok) {
+                        a.out2[o] = sv2;
+                    }
+                }
+            }
+    }
 }
 
 // WM x WN 16x16 MFMA tiles per wave, 2 x 2 waves: block tile (32 WM) x (32 WN).  Smaller tiles are used when the
@@ -100,7 +183,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nck = a.Cin / BK, nit = a.n_taps * nck;
+    const int nck = a.Cin / BK, nit = CG_DEV(a, 1) ? 0 : a.n_taps * nck;
 
     // staging slots of this thread: (row, segment) pairs of the A and B tiles
     int a_b[NA], a_t[NA];
@@ -128,7 +211,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
                 if (st >= a.L) arow = nullptr;
                 else if (st >= 0) arow = a.x + ((size_t)a_b[i] * a.L + st) * a.Cin;
                 else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[a_b[i]] * a.P + (a.P + st)) * a.Cin;
-                if (arow) {
+                if (arow && a.x_s2) {          // (v0, v1) = the 8 h terms and the 8 m terms
+                    const bf16_t* r16 = reinterpret_cast<const bf16_t*>(arow);
+                    v0[i] = *reinterpret_cast<const float4*>(r16 + c0 + seg * 8);
+                    v1[i] = *reinterpret_cast<const float4*>(r16 + a.Cin + c0 + seg * 8);
+                } else if (arow) {
                     v0[i] = *reinterpret_cast<const float4*>(arow + c0 + seg * 8);
                     v1[i] = *reinterpret_cast<const float4*>(arow + c0 + seg * 8 + 4);
                 }
@@ -150,11 +237,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
             const int idx = tid + 256 * i;
             if (idx < BM * SEG) {
                 const int o = (idx / SEG) * LD + (idx % SEG) * 8;
-                uint4 h, m, l;
-                split3(v0[i], v1[i], h, m, l);
-                *reinterpret_cast<uint4*>(&As[0][o]) = h;
-                if (a.planes > 1) *reinterpret_cast<uint4*>(&As[1][o]) = m;      // (planes is uniform: the unused terms' VALU work and LDS
-                if (a.planes > 2) *reinterpret_cast<uint4*>(&As[2][o]) = l;      //  stores fall away with their consumers)
+                if (a.x_s2) {
+                    *reinterpret_cast<float4*>(&As[0][o]) = v0[i];
+                    *reinterpret_cast<float4*>(&As[1][o]) = v1[i];
+                } else {
+                    uint4 h, m, l;
+                    split3(v0[i], v1[i], h, m, l);
+                    *reinterpret_cast<uint4*>(&As[0][o]) = h;
+                    if (a.planes > 1) *reinterpret_cast<uint4*>(&As[1][o]) = m;
+                    if (a.planes > 2) *reinterpret_cast<uint4*>(&As[2][o]) = l;
+                }
             }
         }
 #pragma unroll
@@ -182,29 +274,106 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
             }
         }
     }
-    // epilogue: D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
+    conv_epilogue<WM, WN>(a, acc, m0, n0, wm, wn, lane);
+}
+
+// Multi-tap convolution over S2 rows, activation tile staged ONCE per 32-channel chunk for all taps: the BM + H rows (H = the largest
+// look-back) a tile's taps read go to LDS together and every tap's MFMAs read them at its own row shift, so the activation staging
+// (global loads, LDS writes, barriers) is paid once per chunk instead of once per tap (7 x for the residual units' dilated convs, whose
+// time was that staging: 365 us for 7 taps against 233 us for the whole 1-tap conv2 at 614 k rows).  Weights: one tap's BN x 32 slice at
+// a time, double-buffered, one barrier per tap.  Accumulation order: chunk-major, taps inside, the m term before the h term.
+// Requires: all offsets in [0, H], L % BM == 0 (a tile lies inside one request).  Dynamic LDS: (2 (BM + H) + 2 BN) x 80 bytes.
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void k_conv_taps(ConvGemmArgs a, int H) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, LD = 40, NBR = (BN * 4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int R = BM + H;
+    bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);          // [2][R][LD]
+    bf16_t* Bs = As + (size_t)2 * R * LD;                       // [2][BN][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wm = (wave >> 1) * 16 * WM, wn = (wave & 1) * 16 * WN;
+    const int rb = m0 / a.L, t0 = m0 - rb * a.L;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    f32x4 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = n0 + wn + j * 16 + (lane & 15);
-            if (n >= a.N) continue;
-            const float bv = a.bias ? a.bias[n % a.bias_mod] : 0.0f;
-            const float sv = a.scale ? a.scale[n] : 1.0f;
+        for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xrows = reinterpret_cast<const bf16_t*>(a.x) + (size_t)rb * a.L * 2 * a.Cin;
+    const bf16_t* srows = a.state ? reinterpret_cast<const bf16_t*>(a.state) + (size_t)a.slots[rb] * a.P * 2 * a.Cin : nullptr;
+    uint4 wv[NBR];
+    auto fetchB = [&](int tap, int c0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm + i * 16 + (lane >> 4) * 4 + r;
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                if (a.rscale) v = a.rscale[m] * v;
-                const size_t o = (size_t)m * a.N + n;
-                if (a.res) v = a.res[o] + sv * v;
-                else if (a.scale) v = sv * v;
-                if (a.out) a.out[o] = v;
-                if (a.out2) a.out2[o] = snake_f(v, a.sn_alpha[n % a.sn_mod], a.sn_invb[n % a.sn_mod]);
-            }
+        for (int i = 0; i < NBR; ++i) {
+            const int idx = tid + 256 * i, bn = n0 + (idx >> 2);
+            wv[i] = make_uint4(0, 0, 0, 0);
+            if (idx < BN * 4 && bn < a.N) wv[i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.N + bn) * a.Cin + c0 + (idx & 3) * 8);
         }
+    };
+    auto storeB = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < NBR; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BN * 4) *reinterpret_cast<uint4*>(Bs + ((size_t)q * BN + (idx >> 2)) * LD + (idx & 3) * 8) = wv[i];
+        }
+    };
+    // the tile's rows of the NEXT chunk travel in registers while this chunk's taps run (all requests issued together, nothing waits
+    // on them until the chunk boundary)
+    constexpr int NAR = ((BM + 64) * 8 + 255) / 256;
+    uint4 av[NAR];
+    auto fetchA = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NAR; ++i) {
+            const int e = tid + 256 * i, j = e >> 3, p = (e >> 2) & 1, seg = e & 3, st = t0 - H + j;
+            av[i] = make_uint4(0, 0, 0, 0);
+            const bf16_t* row = nullptr;
+            if (e < R * 8) {
+                if (st >= 0) row = xrows + (size_t)st * 2 * a.Cin;
+                else if (srows && a.P + st >= 0) row = srows + (size_t)(a.P + st) * 2 * a.Cin;
+            }
+            if (row) av[i] = *reinterpret_cast<const uint4*>(row + p * a.Cin + c0 + seg * 8);
+        }
+    };
+    auto storeA = [&]() {
+#pragma unroll
+        for (int i = 0; i < NAR; ++i) {
+            const int e = tid + 256 * i, j = e >> 3, p = (e >> 2) & 1, seg = e & 3;
+            if (e < R * 8) *reinterpret_cast<uint4*>(As + ((size_t)p * R + j) * LD + seg * 8) = av[i];
+        }
+    };
+    const int nck = CG_DEV(a, 1) ? 0 : a.Cin >> 5;
+    if (nck) { fetchA(0); fetchB(0, 0); }
+    for (int ck = 0; ck < nck; ++ck) {
+        const int c0 = ck * 32;
+        __syncthreads();          // the previous chunk's tile and weight buffers are no longer read
+        storeA();
+        storeB(0);
+        __syncthreads();
+        if (ck + 1 < nck) fetchA(c0 + 32);
+        for (int tap = 0; tap < a.n_taps; ++tap) {
+            if (tap + 1 < a.n_taps) fetchB(tap + 1, c0);
+            else if (ck + 1 < nck) fetchB(0, c0 + 32);
+            const int sh = H - a.off[tap];
+            const bf16_t* Bq = Bs + (size_t)(tap & 1) * BN * LD;
+            uint4 bfr[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(Bq + (wn + j * 16 + fr) * LD + fk);
+#pragma unroll
+            for (int p = 1; p >= 0; --p) {      // smaller term first
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    const uint4 afr = *reinterpret_cast<const uint4*>(As + ((size_t)p * R + wm + i * 16 + fr + sh) * LD + fk);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(afr), as_cbf8(bfr[j]), acc[i][j], 0, 0, 0);
+                }
+            }
+            if (tap + 1 < a.n_taps) storeB((tap + 1) & 1);
+            __syncthreads();      // the next tap's weights are visible; this tap's buffer may be overwritten by the tap after next
+        }
+    }
+    conv_epilogue<WM, WN>(a, acc, m0, n0, wm, wn, lane);
 }
 
 // LayerNorm row statistics by the 16 lanes l16 = 0..15 of a row group (two passes over float4 chunks, butterfly inside the group).
@@ -258,7 +427,14 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
                 if (st >= a.L) arow = nullptr;
                 else if (st >= 0) arow = a.x + ((size_t)ab * a.L + st) * a.Cin;
                 else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[ab] * a.P + (a.P + st)) * a.Cin;
-                if (arow) av[i] = *reinterpret_cast<const float4*>(arow + c0 + seg * 4);
+                if (arow && a.x_s2) {          // (xy, zw) = the 4 h terms and the 4 m terms
+                    const bf16_t* r16 = reinterpret_cast<const bf16_t*>(arow);
+                    const float2 h2 = *reinterpret_cast<const float2*>(r16 + c0 + seg * 4);
+                    const float2 m2 = *reinterpret_cast<const float2*>(r16 + a.Cin + c0 + seg * 4);
+                    av[i] = make_float4(h2.x, h2.y, m2.x, m2.y);
+                } else if (arow) {
+                    av[i] = *reinterpret_cast<const float4*>(arow + c0 + seg * 4);
+                }
             }
         }
 #pragma unroll
@@ -282,7 +458,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < 16 * SEGA) {      // 4 fp32 -> 4 bf16 per plane (8 bytes)
+            if (idx < 16 * SEGA && a.x_s2 && !LN) {
+                const int o = (idx / SEGA) * LD + (idx % SEGA) * 4;
+                *reinterpret_cast<float2*>(&As[0][o]) = make_float2(av[i].x, av[i].y);
+                *reinterpret_cast<float2*>(&As[1][o]) = make_float2(av[i].z, av[i].w);
+            } else if (idx < 16 * SEGA) {      // 4 fp32 -> 4 bf16 per plane (8 bytes)
                 float x4[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
                 if (LN) {
                     const int r = idx / SEGA, c = (it % nck) * BK + (idx % SEGA) * 4;
@@ -337,7 +517,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
         if (a.res) v = a.res[o] + sv * v;
         else if (a.scale) v = sv * v;
         if (a.out) a.out[o] = v;
-        if (a.out2) a.out2[o] = snake_f(v, a.sn_alpha[n % a.sn_mod], a.sn_invb[n % a.sn_mod]);
+        if (a.out2) {
+            const float sv2 = snake_f(v, a.sn_alpha[n % a.sn_mod], a.sn_invb[n % a.sn_mod]);
+            if (a.out2_s2) {
+                const int cw = a.sn_mod, j = n / cw, c = n - j * cw;
+                bf16_t* r16 = reinterpret_cast<bf16_t*>(a.out2 + (size_t)m * a.N) + (size_t)j * 2 * cw;
+                split2(sv2, r16[c], r16[cw + c]);
+            } else {
+                a.out2[o] = sv2;
+            }
+        }
     }
 }
 
@@ -563,6 +752,55 @@ __global__ __launch_bounds__(256) void k_final_conv(const float* x, const float*
     if (lane == 0) out[(size_t)b * L + t] = fminf(1.0f, fmaxf(-1.0f, acc + bias));
 }
 
+// The same conv for many rows: 128 consecutive outputs of one request per block (2 waves, one output per lane).  The 134 input rows the
+// block needs are staged in LDS once (coalesced 16-byte loads; row stride C + 1 words, so the 64 lanes of a wave — 64 consecutive rows,
+// same channel — hit 64 different banks), the weights beside them (read as broadcasts).  The one-wave-per-output form above re-reads
+// every input row 7 times through 4-byte strided loads with an integer division per element: 518 us for 614 k outputs (236 MB of input).
+// Per output: four partial sums over the channel residues mod 4, taps outermost, added ((s0 + s1) + (s2 + s3)) + bias.
+__global__ __launch_bounds__(128) void k_final_conv_rows(const float* x, const float* state, const int* slots, const float* w,
+                                                         float bias, float* out, int L, int C) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];      // [134][C + 1] rows, then [7][C] weights (tap-major)
+    const int b = blockIdx.y, t0 = blockIdx.x * 128, LD = C + 1;
+    float* ws = fsm + 134 * LD;
+    const float* st = state + (size_t)slots[b] * 6 * C;
+    const float* xb = x + (size_t)b * L * C;
+    const int c4n = C >> 2, total = 134 * c4n;
+    for (int e0 = 0; e0 < total; e0 += 128 * 8) {      // eight requests per thread in flight, then their LDS stores
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = e0 + i * 128 + threadIdx.x, j = e / c4n, c4 = e - j * c4n, r = t0 + j;      // r indexes [state(6) ++ x]
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < total) {
+                if (r < 6) v[i] = *reinterpret_cast<const float4*>(st + (size_t)r * C + c4 * 4);
+                else if (r - 6 < L) v[i] = *reinterpret_cast<const float4*>(xb + (size_t)(r - 6) * C + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = e0 + i * 128 + threadIdx.x, j = e / c4n, c4 = e - j * c4n;
+            if (e < total) {
+                float* d = fsm + j * LD + c4 * 4;
+                d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+            }
+        }
+    }
+    for (int e = threadIdx.x; e < 7 * C; e += 128) { const int k = e / C, c = e - k * C; ws[e] = w[c * 7 + k]; }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t >= L) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int k = 0; k < 7; ++k) {
+        const float* xr = fsm + (threadIdx.x + k) * LD;
+        const float* wk = ws + k * C;
+        for (int c = 0; c < C; c += 4) {
+            s0 = __fmaf_rn(wk[c], xr[c], s0); s1 = __fmaf_rn(wk[c + 1], xr[c + 1], s1);
+            s2 = __fmaf_rn(wk[c + 2], xr[c + 2], s2); s3 = __fmaf_rn(wk[c + 3], xr[c + 3], s3);
+        }
+    }
+    out[(size_t)b * L + t] = fminf(1.0f, fmaxf(-1.0f, ((s0 + s1) + (s2 + s3)) + bias));
+}
+
 // ================================================================================================
 // engine
 // ================================================================================================
@@ -573,7 +811,7 @@ struct vox_codec {
     vox_codec_config cfg;
     vox_codec_weights w;
     int max_batch, max_slots, T;
-    int planes = 3;     // operand planes of the conv GEMMs (vox_codec_set_operand_planes)
+    int planes = 2;     // operand planes of the conv GEMMs (vox_codec_set_operand_planes)
     // state (per slot)
     float *st_pre, *st_dw[2], *st_dec0, *st_tc[4], *st_ru[4][3], *st_final;
     bf16_t* ring;   // [layers][slots][Wn][2][HD]
@@ -595,16 +833,27 @@ static bool skinny_wide() {
     static const bool on = [] { const char* e = getenv("VOX_SKINNY_BK256"); return !(e && e[0] == '0'); }();
     return on;
 }
+// VOX_CONV_TAPS=0: the per-tap staging kernel for every multi-tap conv (A/B timing)
+static bool conv_taps_on() {
+    static const bool on = [] { const char* e = getenv("VOX_CONV_TAPS"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const float* state, const int* slots, int n,
                      int L, int P, const int* offs, float* out, const float* res, const float* scale, int gelu,
                      float* out2 = nullptr, const vox_snake_w* sn = nullptr, int sn_mod = 0, const float* rscale = nullptr,
-                     const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 0.0f) {
+                     const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 0.0f, int x_s2 = 0, int out2_s2 = 0) {
     if (w.cin % CG_BK) return vox_fail(VOX_ERR_INVALID, "codec gemm: Cin %d %% %d != 0", w.cin, CG_BK);
     if (w.n_taps > CG_MAXTAPS) return vox_fail(VOX_ERR_INVALID, "codec gemm: too many taps");
     ConvGemmArgs a{};
     a.x = x; a.state = state; a.slots = slots; a.w = (const bf16_t*)w.w; a.bias = w.bias; a.res = res; a.scale = scale;
     a.out = out; a.M = n * L; a.N = w.n; a.Cin = w.cin; a.L = L; a.P = P; a.n_taps = w.n_taps; a.rscale = rscale;
-    a.planes = g_conv_planes;
+    a.planes = x_s2 ? 2 : g_conv_planes;
+    a.x_s2 = x_s2; a.out2_s2 = (out2 && sn) ? out2_s2 : 0;
+#ifdef VOX_DEV_KNOBS
+    { static const int dv = [] { const char* e = getenv("VOX_CODEC_DEV"); return e ? atoi(e) : 0; }(); a.dev = dv; }
+#endif
+    if (x_s2 && ln_w) return vox_fail(VOX_ERR_INVALID, "codec gemm: S2 rows with a fused LayerNorm");
+    if (a.out2_s2 && ((w.n & 1) || ((sn_mod > 0 ? sn_mod : w.n) & 1))) return vox_fail(VOX_ERR_INVALID, "codec gemm: S2 output needs an even channel count");
     a.bias_mod = w.bias_mod > 0 ? w.bias_mod : w.n; a.gelu = gelu;
     if (out2 && sn) { a.out2 = out2; a.sn_alpha = sn->alpha; a.sn_invb = sn->inv_beta; a.sn_mod = sn_mod > 0 ? sn_mod : w.n; }
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
@@ -631,6 +880,24 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     // fragment read then feeds 3-4 MFMAs instead of 2 (the 64 x 64 tile is LDS-read bound with the 3-term split)
     {
         const int wnb = (w.n % 128 == 0 || w.n >= 256) ? 4 : ((w.n > 64 && w.n <= 96) || w.n % 96 == 0) ? 3 : 0;
+        // S2 rows and several taps: the activation tile is staged once per 32-channel chunk for all taps (k_conv_taps); 128-row tiles when
+        // they fill the chip and divide the request length, else 64-row tiles
+        if (wnb && x_s2 && w.n_taps > 1 && conv_taps_on()) {
+            int H = 0, omin = 0;
+            for (int k = 0; k < w.n_taps; ++k) { H = a.off[k] > H ? a.off[k] : H; omin = a.off[k] < omin ? a.off[k] : omin; }
+            const int ncb = (w.n + 32 * wnb - 1) / (32 * wnb);
+            // (below ~256 blocks the per-tap kernels' smaller tiles win: measured at 1 and 4 requests)
+            const int bm = (L % 128 == 0 && ncb * (a.M / 128) >= 256) ? 128 : ((L % 64 == 0 && ncb * (a.M / 64) >= 256) ? 64 : 0);
+            if (bm && omin >= 0 && H <= 64) {
+                const dim3 gt(ncb, a.M / bm);
+                const size_t lds = (size_t)(2 * (bm + H) + 2 * 32 * wnb) * 80;
+                if (bm == 128 && wnb == 4) hipLaunchKernelGGL((k_conv_taps<4, 4>), gt, dim3(256), lds, st, a, H);
+                else if (bm == 128) hipLaunchKernelGGL((k_conv_taps<4, 3>), gt, dim3(256), lds, st, a, H);
+                else if (wnb == 4) hipLaunchKernelGGL((k_conv_taps<2, 4>), gt, dim3(256), lds, st, a, H);
+                else hipLaunchKernelGGL((k_conv_taps<2, 3>), gt, dim3(256), lds, st, a, H);
+                return VOX_OK;
+            }
+        }
         if (wnb && ((w.n + 32 * wnb - 1) / (32 * wnb)) * ((a.M + 127) / 128) >= 256) {
             const dim3 gb((w.n + 32 * wnb - 1) / (32 * wnb), (a.M + 127) / 128);
             if (wnb == 4) hipLaunchKernelGGL((k_conv_gemm<32, 4, 4>), gb, dim3(256), 0, st, a);
@@ -809,6 +1076,10 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
     // SnakeBeta is fused into the epilogue of the conv that produces its input: a conv whose output is only ever consumed
     // through a snake (conv1 of a residual unit) writes just the activated tensor, the others write both (the plain tensor
     // is the residual branch).  t1 always holds the activated input of the next conv.
+    // Two-term mode (planes == 2, the default): the activated tensors t1 / t3 — only ever read as GEMM operands — are kept as S2
+    // rows (ConvGemmArgs), split once where they are produced; the residual stream h stays fp32.  Their history rows (st_tc /
+    // st_ru) are byte copies of those rows, i.e. in the same format: change the mode only on freshly reset slots.
+    const int s2 = m->planes == 2;
     float* h = B;      // current activations
     float* t1 = A;
     float* t2 = C;
@@ -819,7 +1090,8 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
         const int cin = c.decoder_dim >> b, cout = c.decoder_dim >> (b + 1), r = c.rates[b];
         const int offt[2] = {0, 1};
         // t2 [n*L*r, cout] = tconv(t1); t3 = act1 of unit 0 applied to it (t1 is still being read by other blocks)
-        VOX_TRY(conv_gemm(st, bw.tconv, t1, m->st_tc[b], slots, n, L, 1, offt, t2, nullptr, nullptr, 0, t3, &bw.res[0].act1, cout));
+        VOX_TRY(conv_gemm(st, bw.tconv, t1, m->st_tc[b], slots, n, L, 1, offt, t2, nullptr, nullptr, 0, t3, &bw.res[0].act1, cout,
+                          nullptr, nullptr, nullptr, 0.0f, s2 && b > 0, s2));
         state_update(st, m->st_tc[b], slots, t1, n, L, 1, cin);
         L *= r;
         { float* x = h; h = t2; t2 = x; }
@@ -829,16 +1101,22 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
             const int d = u == 0 ? 1 : (u == 1 ? 3 : 9);
             const int offd[7] = {6 * d, 5 * d, 4 * d, 3 * d, 2 * d, d, 0};
             // t3 = act2(conv1(t1))   (the plain conv1 output has no other consumer)
-            VOX_TRY(conv_gemm(st, rw.conv1, t1, m->st_ru[b][u], slots, n, L, 6 * d, offd, nullptr, nullptr, nullptr, 0, t3, &rw.act2, cout));
+            VOX_TRY(conv_gemm(st, rw.conv1, t1, m->st_ru[b][u], slots, n, L, 6 * d, offd, nullptr, nullptr, nullptr, 0, t3, &rw.act2, cout,
+                              nullptr, nullptr, nullptr, 0.0f, s2, s2));
             state_update(st, m->st_ru[b][u], slots, t1, n, L, 6 * d, cout);
             // h += conv2(t3); t1 = the next consumer's activation of the new h
             const vox_snake_w* nx = u < 2 ? &bw.res[u + 1].act1 : (b < 3 ? &w.blocks[b + 1].snake0 : &w.final_snake);
-            VOX_TRY(conv_gemm(st, rw.conv2, t3, nullptr, slots, n, L, 0, off0, h, h, nullptr, 0, t1, nx, cout));
+            VOX_TRY(conv_gemm(st, rw.conv2, t3, nullptr, slots, n, L, 0, off0, h, h, nullptr, 0, t1, nx, cout,
+                              nullptr, nullptr, nullptr, 0.0f, s2, s2 && !(b == 3 && u == 2)));      // (the final conv reads fp32 rows)
         }
     }
     const int cl = c.decoder_dim >> 4;
-    hipLaunchKernelGGL(k_final_conv, dim3((L + 3) / 4, n), dim3(256), 0, st, t1, m->st_final, slots, w.final_w, w.final_b, out,
-                       L, cl);
+    if (L >= 512 && cl % 4 == 0 && (size_t)(134 * (cl + 1) + 7 * cl) * 4 <= 60 * 1024)
+        hipLaunchKernelGGL(k_final_conv_rows, dim3((L + 127) / 128, n), dim3(128), (size_t)(134 * (cl + 1) + 7 * cl) * 4, st, t1, m->st_final,
+                           slots, w.final_w, w.final_b, out, L, cl);
+    else
+        hipLaunchKernelGGL(k_final_conv, dim3((L + 3) / 4, n), dim3(256), 0, st, t1, m->st_final, slots, w.final_w, w.final_b, out,
+                           L, cl);
     state_update(st, m->st_final, slots, t1, n, L, 6, cl);
     return VOX_OK;
 }
