@@ -167,7 +167,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, f32x4 (&acc
 // WM x WN 16x16 MFMA tiles per wave, 2 x 2 waves: block tile (32 WM) x (32 WN).  Smaller tiles are used when the
 // 64 x 64 grid would leave most of the 256 CUs idle (the mid-size decoder stages are MFMA-bound per CU).
 template <int BK, int WM, int WN>
-__global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
+__global__ __launch_bounds__(256, (WM * WN > 12 ? 3 : 4)) void k_conv_gemm(ConvGemmArgs a) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int LD = BK + 8;          // LDS row stride in bf16 elements (+16 B: the 16 rows of a fragment read hit distinct banks)
     constexpr int SEG = BK / 8;         // 8-element segments per row
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvGemmArgs a) {
 // a time, double-buffered, one barrier per tap.  Accumulation order: chunk-major, taps inside, the m term before the h term.
 // Requires: all offsets in [0, H], L % BM == 0 (a tile lies inside one request).  Dynamic LDS: (2 (BM + H) + 2 BN) x 80 bytes.
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void k_conv_taps(ConvGemmArgs a, int H) {
+__global__ __launch_bounds__(256, (WM * WN >= 12 ? 3 : 4)) void k_conv_taps(ConvGemmArgs a, int H) {
     constexpr int BM = 32 * WM, BN = 32 * WN, LD = 40, NBR = (BN * 4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int R = BM + H;
