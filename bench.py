@@ -419,8 +419,8 @@ def serving_throughput(dev, shared, n_req, frames, kind="base"):
             if k == b"AUDIO":
                 n += len(body) // 2
         return n
-    submit("warm", min(2, n_req))          # graph capture for the shapes of this run
-    run()
+    submit("warm", n_req)                  # the same job once untimed: every batch size of the ramp has its frame / codec graph captured
+    run()                                  # (the reference's worker captures all its graph shapes at start-up: cuda_graph_worker.py:383-470)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     submit("r", n_req)

@@ -361,10 +361,12 @@ typedef struct {
     float rms_eps, rope_theta;
 } vox_codec_config;
 
-/* Operand precision of the decoder's conv / linear GEMMs.  3 (default): every product exact — the fp32 activation enters the
- * matrix cores as three bf16 terms (waveform within 1e-4 RMS of the reference module evaluated in fp32).  1: activations rounded
- * to bf16 when staged — the precision the reference itself serves at (it runs the decoder in bf16, qwen3_tts.py:1061-1064), a
- * third of the MFMA issue.  Takes effect from the next decode call (re-capture graphs after changing it). */
+/* Operand precision of the decoder's conv / linear GEMMs = the number of bf16 terms an fp32 activation enters the matrix cores as
+ * (fp32 accumulation).  2 (default): the two leading terms, 16 significand bits — waveform within 1e-4 RMS of the reference module
+ * evaluated in fp32 (measured 1.7e-5 on the full-size fixture); the activated tensors between the decoder convs are then STORED as
+ * those two terms (split once by the producing kernel), as are their history rows in the streaming state.  3: every product exact.
+ * 1: activations rounded to bf16 — the precision the reference itself serves at (it runs the decoder in bf16, qwen3_tts.py:1061-1064).
+ * Takes effect from the next decode call: change it only while every slot is freshly reset, and re-capture graphs. */
 int vox_codec_set_operand_planes(vox_codec* m, int planes);
 int vox_codec_create(vox_ctx* ctx, const vox_codec_config* cfg, const vox_codec_weights* w, int max_batch, int max_slots,
                      int frames_per_chunk, vox_codec** out);
