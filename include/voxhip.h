@@ -421,7 +421,8 @@ int vox_mimi_decode_chunk(vox_mimi* m, void* stream, const int32_t* codes, int c
 /* ---- SNAC decoder (token -> waveform of the Orpheus family) ---------------------------------------------------------
  * Replaces SNAC.decode (/root/reference/vox_serve/tokenizer/snac.py:438-441: ResidualVectorQuantize.from_codes :350-357 +
  * Decoder :119-158 with DecoderBlock :215-241, ResidualUnit :160-176, NoiseBlock :201-212, Snake1d :253-267) as
- * OrpheusModel.postprocess calls it (model/orpheus.py:483-507), for the depthwise / no-local-attention variant (snac_24khz).
+ * OrpheusModel.postprocess calls it (model/orpheus.py:483-507): the depthwise / no-local-attention variant (snac_24khz, what the
+ * reference's Orpheus plugin loads) and the dense-conv / LocalMHA variants of the module (conv0 / res[].dense / attn_*).
  * Stateless per window, fp32 activations, convolutions as implicit GEMMs on the matrix cores with exact products (fp32
  * activations split into three bf16 terms, fp32 weights carried as two bf16 planes = 16 significand bits).
  * Weights: weight-norm already folded (w = g * v / ||v||).  tab[i]: out_proj_i(codebook_i) + bias, tabulated [codebook_size][latent].
@@ -433,6 +434,7 @@ typedef struct {
     vox_snake_w act1, act2;
     const float *dw_w, *dw_b;      /* depthwise conv: [C][7], [C] */
     vox_conv_w pw;                 /* 1x1 conv + bias */
+    vox_conv_w dense;              /* non-depthwise variant: the k7 conv as 7 taps x 2 planes [C][C] + bias (n_taps == 0: depthwise, dw_w) */
 } vox_snac_res_w;
 typedef struct {
     vox_snake_w snake0;
@@ -448,9 +450,14 @@ typedef struct {
     vox_snake_w final_snake;
     const float* final_w;          /* [C_last][7] */
     float final_b;
+    /* variants of the 32 / 44 kHz checkpoints (snac.py:20-90, 119-176) */
+    vox_conv_w conv0;              /* non-depthwise: ONE k7 conv latent -> decoder_dim, 7 taps x 2 planes + bias (n_taps == 0: dw0 + pw0) */
+    const float *attn_ln_w, *attn_ln_b;   /* LocalMHA after the input conv(s): LayerNorm (eps 1e-5) */
+    vox_conv_w attn_qkv, attn_out;        /* to_qkv [3C][C], to_out [C][C], no bias, 1 tap x 2 planes; heads of 64, rotary per window position */
 } vox_snac_weights;
 typedef struct {
     int32_t latent_dim, decoder_dim, codebook_size, n_levels, vq_strides[4], rates[4], noise;
+    int32_t attn_window;           /* 0: no LocalMHA; else T must be a multiple of it (<= 32) */
 } vox_snac_config;
 typedef struct vox_snac vox_snac;
 int vox_snac_create(vox_ctx* ctx, const vox_snac_config* cfg, const vox_snac_weights* w, int max_batch, int max_T, vox_snac** out);

@@ -2,7 +2,9 @@
 
 Restates, in plain torch-CPU fp32 on explicit (weight-norm-folded) tensors:
   ResidualVectorQuantize.from_codes      /root/reference/vox_serve/tokenizer/snac.py:350-357
-  Decoder / DecoderBlock / ResidualUnit  snac.py:119-176, 215-241   (depthwise variant, no local attention: snac_24khz)
+  Decoder / DecoderBlock / ResidualUnit  snac.py:119-176, 215-241   (depthwise or dense convs: `depthwise`)
+  LocalMHA / SinusoidalEmbeddings        snac.py:20-90              (`attn_window_size`: LayerNorm -> qkv -> rotary q, k per window
+                                                                     position -> full softmax inside each window -> out + residual)
   NoiseBlock                             snac.py:201-212            x + noise[b,1,t] * conv1x1(x)
   Snake1d                                snac.py:253-267            x + sin(alpha x)^2 / (alpha + 1e-9)
   SNAC.decode                            snac.py:438-441
@@ -33,6 +35,13 @@ class SnacCfg:
     vq_strides: Sequence[int] = (4, 2, 1)
     noise: bool = True
     sampling_rate: int = 24000
+    depthwise: bool = True                     # snac_24khz; False: the k7 convs are dense (groups = 1), one conv at the decoder input
+    attn_window_size: Optional[int] = None     # LocalMHA after the decoder's input conv(s) (snac_32khz / 44khz: 32)
+
+    @property
+    def first_block(self):
+        """Index of the first DecoderBlock in decoder.model (snac.py:130-146)."""
+        return (2 if self.depthwise else 1) + (1 if self.attn_window_size is not None else 0)
 
     @property
     def hop(self):
@@ -58,13 +67,23 @@ def param_shapes(cfg: SnacCfg) -> Dict[str, tuple]:
         wn(q + "out_proj", (cfg.latent_dim, cfg.codebook_dim, 1), cfg.latent_dim)
         s[q + "out_proj.bias"] = (cfg.latent_dim,)
     d = "decoder.model."
-    wn(d + "0", (cfg.latent_dim, 1, 7), cfg.latent_dim)
-    s[d + "0.bias"] = (cfg.latent_dim,)
-    wn(d + "1", (cfg.decoder_dim, cfg.latent_dim, 1), cfg.decoder_dim)
-    s[d + "1.bias"] = (cfg.decoder_dim,)
+    if cfg.depthwise:
+        wn(d + "0", (cfg.latent_dim, 1, 7), cfg.latent_dim)
+        s[d + "0.bias"] = (cfg.latent_dim,)
+        wn(d + "1", (cfg.decoder_dim, cfg.latent_dim, 1), cfg.decoder_dim)
+        s[d + "1.bias"] = (cfg.decoder_dim,)
+    else:
+        wn(d + "0", (cfg.decoder_dim, cfg.latent_dim, 7), cfg.decoder_dim)
+        s[d + "0.bias"] = (cfg.decoder_dim,)
+    if cfg.attn_window_size is not None:
+        a = f"{d}{cfg.first_block - 1}."
+        s[a + "norm.weight"] = (cfg.decoder_dim,)
+        s[a + "norm.bias"] = (cfg.decoder_dim,)
+        s[a + "to_qkv.weight"] = (3 * cfg.decoder_dim, cfg.decoder_dim)
+        s[a + "to_out.weight"] = (cfg.decoder_dim, cfg.decoder_dim)
     ch = cfg.decoder_dim
     for bi, r in enumerate(cfg.rates):
-        b = f"{d}{2 + bi}.block."
+        b = f"{d}{cfg.first_block + bi}.block."
         cin, cout = ch, ch // 2
         s[b + "0.alpha"] = (1, cin, 1)
         wn(b + "1", (cin, cout, 2 * r), cin)                  # ConvTranspose1d: weight_norm over dim 0 = input channels
@@ -76,20 +95,20 @@ def param_shapes(cfg: SnacCfg) -> Dict[str, tuple]:
         for u in range(3):
             ru = f"{b}{j + u}.block."
             s[ru + "0.alpha"] = (1, cout, 1)
-            wn(ru + "1", (cout, 1, 7), cout)
+            wn(ru + "1", (cout, 1 if cfg.depthwise else cout, 7), cout)
             s[ru + "1.bias"] = (cout,)
             s[ru + "2.alpha"] = (1, cout, 1)
             wn(ru + "3", (cout, cout, 1), cout)
             s[ru + "3.bias"] = (cout,)
         ch = cout
-    n = 2 + len(cfg.rates)
+    n = cfg.first_block + len(cfg.rates)
     s[f"{d}{n}.alpha"] = (1, ch, 1)
     wn(f"{d}{n + 1}", (1, ch, 7), 1)
     s[f"{d}{n + 1}.bias"] = (1,)
     return s
 
 
-def random_snac_weights(cfg: SnacCfg, seed=0) -> Dict[str, torch.Tensor]:
+def random_snac_weights(cfg: SnacCfg, seed=0, final_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """fp32 CPU tensors with bf16-representable values, scaled so that the waveform stays O(0.1)."""
     g = torch.Generator().manual_seed(seed)
     W = {}
@@ -100,6 +119,10 @@ def random_snac_weights(cfg: SnacCfg, seed=0) -> Dict[str, torch.Tensor]:
             t = 0.7 + 0.6 * torch.rand(shp, generator=g)
         elif k.endswith("codebook.weight"):
             t = torch.randn(shp, generator=g)
+        elif k.endswith("norm.weight"):
+            t = 0.8 + 0.4 * torch.rand(shp, generator=g)
+        elif k.endswith("to_qkv.weight") or k.endswith("to_out.weight"):
+            t = torch.randn(shp, generator=g) / math.sqrt(shp[1]) * (1.0 if k.endswith("to_qkv.weight") else 0.5)
         elif k.endswith("bias"):
             t = 0.02 * torch.randn(shp, generator=g)
         else:
@@ -113,7 +136,7 @@ def random_snac_weights(cfg: SnacCfg, seed=0) -> Dict[str, torch.Tensor]:
             elif k.split(".parametrizations")[0].endswith(".3"):
                 W[k] = (W[k] * 0.35).to(torch.bfloat16).float()             # residual-unit output conv
             elif W[k].shape[0] == 1:
-                W[k] = (W[k] * 0.12).to(torch.bfloat16).float()             # final conv: keep tanh out of saturation
+                W[k] = (W[k] * 0.12 * final_gain).to(torch.bfloat16).float()   # final conv: keep tanh out of saturation
     return W
 
 
@@ -188,9 +211,29 @@ class SnacRef:
             z = z + zi.repeat_interleave(st, dim=-1)
         return z
 
+    def local_mha(self, x, p):
+        """LocalMHA.forward (snac.py:33-47), dim_head 64, rotary without xpos: x [B, C, T], T a multiple of the window."""
+        W, ws, dh = self.W, self.cfg.attn_window_size, 64
+        B, C, T = x.shape
+        if T % ws:
+            raise ValueError(f"LocalMHA: {T} frames are not a multiple of the window {ws}")
+        h = C // dh
+        y = F.layer_norm(x.transpose(1, 2), (C,), W[p + "norm.weight"], W[p + "norm.bias"], 1e-5)
+        q, k, v = (y @ W[p + "to_qkv.weight"].t()).chunk(3, dim=-1)
+        q, k, v = (t.reshape(B, T // ws, ws, h, dh).permute(0, 3, 1, 2, 4) for t in (q, k, v))       # b h w n d
+        inv_freq = 1.0 / (10000 ** (torch.arange(0, dh, 2).float() / dh))
+        fr = torch.einsum("i,j->ij", torch.arange(ws).float(), inv_freq)
+        fr = torch.cat((fr, fr), dim=-1)
+        rot = lambda t: torch.cat((-t[..., dh // 2:], t[..., : dh // 2]), dim=-1)
+        q = q * fr.cos() + rot(q) * fr.sin()
+        k = k * fr.cos() + rot(k) * fr.sin()
+        att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1) @ v
+        out = att.permute(0, 2, 3, 1, 4).reshape(B, T, C) @ W[p + "to_out.weight"].t()
+        return out.transpose(1, 2) + x
+
     def _res_unit(self, x, p, dilation):
         W, w = self.W, self.w
-        C = x.shape[1]
+        C = x.shape[1] if self.cfg.depthwise else 1
         y = snake(x, W[p + "0.alpha"])
         y = F.conv1d(y, w[p + "1"], W[p + "1.bias"], dilation=dilation, padding=3 * dilation, groups=C)
         y = snake(y, W[p + "2.alpha"])
@@ -200,10 +243,15 @@ class SnacRef:
     def decode_latents(self, z: torch.Tensor, noise: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
         cfg, W, w = self.cfg, self.W, self.w
         d = "decoder.model."
-        x = F.conv1d(z, w[d + "0"], W[d + "0.bias"], padding=3, groups=cfg.latent_dim)
-        x = F.conv1d(x, w[d + "1"], W[d + "1.bias"])
+        if cfg.depthwise:
+            x = F.conv1d(z, w[d + "0"], W[d + "0.bias"], padding=3, groups=cfg.latent_dim)
+            x = F.conv1d(x, w[d + "1"], W[d + "1.bias"])
+        else:
+            x = F.conv1d(z, w[d + "0"], W[d + "0.bias"], padding=3)
+        if cfg.attn_window_size is not None:
+            x = self.local_mha(x, f"{d}{cfg.first_block - 1}.")
         for bi, r in enumerate(cfg.rates):
-            b = f"{d}{2 + bi}.block."
+            b = f"{d}{cfg.first_block + bi}.block."
             x = snake(x, W[b + "0.alpha"])
             x = F.conv_transpose1d(x, w[b + "1"], W[b + "1.bias"], stride=r, padding=math.ceil(r / 2), output_padding=r % 2)
             j = 2
@@ -214,7 +262,7 @@ class SnacRef:
                 j = 3
             for u, dil in enumerate((1, 3, 9)):
                 x = self._res_unit(x, f"{b}{j + u}.block.", dil)
-        n = 2 + len(cfg.rates)
+        n = cfg.first_block + len(cfg.rates)
         x = snake(x, W[f"{d}{n}.alpha"])
         x = F.conv1d(x, w[f"{d}{n + 1}"], W[f"{d}{n + 1}.bias"], padding=3)
         return torch.tanh(x)

@@ -880,6 +880,55 @@ def g10_snac(ns):
     np.savez_compressed(os.path.join(HERE, "g10_snac.npz"), **out)
 
 
+def snac_variant_cfgs():
+    """Tiny SNAC decoders of the variants the 32 / 44 kHz checkpoints use: dense k7 convs and / or LocalMHA (window 4 here)."""
+    import dataclasses
+    from oracle import snac_ref as SR
+    base = SR.tiny_snac_cfg()
+    return {"dense_attn": dataclasses.replace(base, depthwise=False, attn_window_size=4),
+            "dw_attn": dataclasses.replace(base, depthwise=True, attn_window_size=4),
+            "dense": dataclasses.replace(base, depthwise=False, attn_window_size=None)}
+
+
+def g20_snac_variants(ns):
+    """SNAC.decode of the reference module for the non-depthwise / local-attention variants (tokenizer/snac.py:20-90, 119-176), tiny
+    size, fp32, seeded NoiseBlock noise as in g10."""
+    import importlib
+    from oracle import snac_ref as SR
+    S = importlib.import_module("vox_serve.tokenizer.snac")
+    out = {}
+    for tag, cfg in snac_variant_cfgs().items():
+        W = SR.random_snac_weights(cfg, seed=2, final_gain=0.3)      # (dense convs / the attention residual: larger activations)
+        m = S.SNAC(sampling_rate=24000, encoder_dim=4, encoder_rates=[2, 2, 2, 2], latent_dim=cfg.latent_dim, decoder_dim=cfg.decoder_dim,
+                   decoder_rates=list(cfg.rates), attn_window_size=cfg.attn_window_size, codebook_size=cfg.codebook_size,
+                   codebook_dim=cfg.codebook_dim, vq_strides=list(cfg.vq_strides), noise=True, depthwise=cfg.depthwise).eval()
+        missing, unexpected = m.load_state_dict(W, strict=False)
+        assert not unexpected and all(k.startswith("encoder.") or "in_proj" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+        B, T = 2, 16
+        g = torch.Generator().manual_seed(5)
+        codes = [torch.randint(0, cfg.codebook_size, (B, T // s), generator=g) for s in cfg.vq_strides]
+        noise = SR.make_noise(cfg, B, T, seed=78)
+        it = iter(noise)
+        real_randn = torch.randn
+
+        def fake_randn(shape, **kwargs):
+            n = next(it)
+            assert tuple(shape) == tuple(n.shape), (shape, n.shape)
+            return n
+        torch.randn = fake_randn
+        try:
+            with torch.no_grad():
+                wav = m.decode(codes)
+        finally:
+            torch.randn = real_randn
+        for i, c in enumerate(codes):
+            out[f"{tag}_codes{i}"] = c.numpy().astype(np.int16)
+        out[f"{tag}_wav"] = wav.numpy().astype(np.float32)
+        print("g20", tag, tuple(wav.shape), "rms", float(wav.pow(2).mean().sqrt()), "max", float(wav.abs().max()))
+    out["noise_seed"] = np.int64(78)
+    np.savez_compressed(os.path.join(HERE, "g20_snac_variants.npz"), **out)
+
+
 def g11_hift(ns):
     """HiFT vocoder through the reference HiFTGenerator.forward_chunk (tokenizer/hifigan.py:641-665), tiny and CosyVoice2 size,
     fp32, with SineGen2's torch.rand / torch.randn_like replaced by the seeded streams of oracle/hift_ref.py (the noise contract);
@@ -1308,7 +1357,7 @@ def g17_flow_evolving(ns):
 
 
 ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g18": g18_qwen3_lm_b12, "g19": g19_sampler_mc, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder, "g17": g17_flow_evolving}
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder, "g17": g17_flow_evolving, "g20": g20_snac_variants}
 
 if __name__ == "__main__":
     ns = H.boot()

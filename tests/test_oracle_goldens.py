@@ -355,6 +355,30 @@ def test_snac_oracle_matches_the_reference_module(golden, tag):
     assert np.abs(ref.decode(codes, None).numpy() - want).max() > 1e-3
 
 
+def snac_variant_cfgs():
+    import dataclasses
+    from oracle import snac_ref as SR
+    base = SR.tiny_snac_cfg()
+    return {"dense_attn": dataclasses.replace(base, depthwise=False, attn_window_size=4),
+            "dw_attn": dataclasses.replace(base, depthwise=True, attn_window_size=4),
+            "dense": dataclasses.replace(base, depthwise=False, attn_window_size=None)}
+
+
+@pytest.mark.parametrize("tag", ["dense_attn", "dw_attn", "dense"])
+def test_snac_variants_oracle_matches_the_reference_module(golden, tag):
+    """The dense-conv / LocalMHA variants (snac.py:20-90, 119-176; the 32 / 44 kHz checkpoints' structure) against the reference module."""
+    import torch
+    from oracle import snac_ref as SR
+    g = golden("g20_snac_variants")
+    cfg = snac_variant_cfgs()[tag]
+    ref = SR.SnacRef(cfg, SR.random_snac_weights(cfg, seed=2, final_gain=0.3))
+    codes = [torch.from_numpy(g[f"{tag}_codes{i}"].astype(np.int64)) for i in range(3)]
+    wav = ref.decode(codes, SR.make_noise(cfg, 2, 16, seed=int(g["noise_seed"]))).numpy()
+    want = g[f"{tag}_wav"]
+    assert wav.shape == want.shape
+    assert np.abs(wav - want).max() < 5e-5 and np.sqrt(np.mean((wav - want) ** 2)) < 1e-5, (np.abs(wav - want).max(), np.sqrt(np.mean((wav - want) ** 2)))
+
+
 def test_orpheus_postprocess_token_layout(golden):
     """7 LM tokens per frame -> SNAC levels (1 + 2 + 4 codes), 4-frame window, samples [2048:4096] (orpheus.py:479-507)."""
     import torch

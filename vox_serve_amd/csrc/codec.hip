@@ -1630,6 +1630,59 @@ __global__ __launch_bounds__(256) void k_snac_final(const float* x, const float*
     if (lane == 0) out[s] = tanhf(acc + bias);
 }
 
+// Snake of the valid rows, zeros elsewhere (same padded geometry): the input of a DENSE k7 conv, whose taps must read zeros
+// outside the sequence                                                                        (ResidualUnit with groups = 1)
+__global__ __launch_bounds__(256) void k_snac_snake_mask(const float* x, const float* alpha, const float* invb, float* y, SnacGeo g) {
+    const size_t total = (size_t)g.B * g.Lb * g.C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % g.C);
+        const int t = (int)((i / g.C) % g.Lb) - g.v0;
+        y[i] = (t >= 0 && t < g.Lv) ? snake_a(x[i], alpha[c], invb[c]) : 0.0f;
+    }
+}
+
+// LocalMHA core (snac.py:33-47, 76-90): one block per (window, head, request).  qkv rows [T][3C] (q | k | v, heads of 64 inside
+// each), window = ws consecutive frames; q and k get the rotary embedding of their position INSIDE the window (no xpos: scale 1),
+// full (non-causal) softmax over the window, scale 1/8.  out rows [T][C].
+__global__ __launch_bounds__(256) void k_snac_local_attn(const float* qkv, float* out, int T, int C, int ws) {
+    constexpr int DH = 64;
+    __shared__ float q[32 * DH], k[32 * DH], v[32 * DH], sc[32 * 65];      // ws <= 32 (vox_snac_create)
+    const int w = blockIdx.x, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const float* base = qkv + ((size_t)b * T + (size_t)w * ws) * 3 * C + h * DH;
+    for (int e = tid; e < ws * DH; e += 256) {
+        const int n = e / DH, d = e % DH, dp = d < DH / 2 ? d + DH / 2 : d - DH / 2;
+        const float* row = base + (size_t)n * 3 * C;
+        const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * (d % (DH / 2))) / (float)DH);
+        const float fr = (float)n * inv_freq, cs = cosf(fr), sn = sinf(fr);
+        const float sgn = d < DH / 2 ? -1.0f : 1.0f;                      // rotate_half: (-x2, x1)
+        q[e] = row[d] * cs + sgn * row[dp] * sn;
+        k[e] = row[C + d] * cs + sgn * row[C + dp] * sn;
+        v[e] = row[2 * C + d];
+    }
+    __syncthreads();
+    for (int e = tid; e < ws * ws; e += 256) {
+        const int i = e / ws, j = e % ws;
+        float s = 0.0f;
+        for (int d = 0; d < DH; ++d) s = fmaf(q[i * DH + d], k[j * DH + d], s);
+        sc[i * 65 + j] = s * 0.125f;
+    }
+    __syncthreads();
+    if (tid < ws) {
+        float mx = -INFINITY, l = 0.0f;
+        for (int j = 0; j < ws; ++j) mx = fmaxf(mx, sc[tid * 65 + j]);
+        for (int j = 0; j < ws; ++j) { const float p = expf(sc[tid * 65 + j] - mx); sc[tid * 65 + j] = p; l += p; }
+        const float il = 1.0f / l;
+        for (int j = 0; j < ws; ++j) sc[tid * 65 + j] *= il;
+    }
+    __syncthreads();
+    for (int e = tid; e < ws * DH; e += 256) {
+        const int i = e / DH, d = e % DH;
+        float o = 0.0f;
+        for (int j = 0; j < ws; ++j) o = fmaf(sc[i * 65 + j], v[j * DH + d], o);
+        out[((size_t)b * T + (size_t)w * ws + i) * C + h * DH + d] = o;
+    }
+}
+
 struct vox_snac {
     vox_ctx* ctx;
     vox_snac_config cfg;
@@ -1653,7 +1706,9 @@ int vox_snac_create(vox_ctx* ctx, const vox_snac_config* cfg, const vox_snac_wei
     m->ctx = ctx; m->cfg = *cfg; m->w = *w; m->max_batch = max_batch; m->max_T = max_T;
     m->n_stages = 0;
     int ch = cfg->decoder_dim;
-    size_t worst = (size_t)max_T * (cfg->latent_dim > cfg->decoder_dim ? cfg->latent_dim : cfg->decoder_dim);
+    if (cfg->attn_window < 0 || cfg->attn_window > 32 || (cfg->attn_window && cfg->decoder_dim % 64))
+        return vox_fail(VOX_ERR_INVALID, "snac_create: attention window 1..32, decoder_dim a multiple of 64");
+    size_t worst = (size_t)max_T * (cfg->latent_dim > cfg->decoder_dim ? cfg->latent_dim : cfg->decoder_dim) * (cfg->attn_window ? 3 : 1);
     size_t T = max_T, rs_rows = 0;
     for (int i = 0; i < 4 && cfg->rates[i] > 0; ++i) {
         const int r = cfg->rates[i];
@@ -1696,11 +1751,25 @@ int vox_snac_decode(vox_snac* m, void* stream, const int32_t* codes, int n, int 
                        w.tab[3], c.n_levels, c.vq_strides[0], c.vq_strides[1] ? c.vq_strides[1] : 1, c.vq_strides[2] ? c.vq_strides[2] : 1,
                        c.vq_strides[3] ? c.vq_strides[3] : 1, c.codebook_size, T, c.latent_dim, x);
     SnacGeo g{n, T, 0, T, c.latent_dim};
-    hipLaunchKernelGGL(k_snac_dw, dim3(ew_grid((size_t)n * T * c.latent_dim)), dim3(256), 0, st, x, w.dw0_w, w.dw0_b, nullptr, nullptr, nullptr,
-                       nullptr, y, g, 1);
     static const int off1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, off2[8] = {0, 1, 0, 1, 0, 0, 0, 0};
-    VOX_TRY(conv_gemm(st, w.pw0, y, nullptr, nullptr, n, T, 0, off1, x, nullptr, nullptr, 0));
+    if (w.conv0.n_taps > 0) {      // non-depthwise: one dense k7 conv ("same" padding: tap j reads row t + j - 3), 2 weight planes
+        static const int off7[14] = {3, 2, 1, 0, -1, -2, -3, 3, 2, 1, 0, -1, -2, -3};
+        VOX_TRY(conv_gemm(st, w.conv0, x, nullptr, nullptr, n, T, 0, off7, y, nullptr, nullptr, 0));
+        float* t = x; x = y; y = t;
+    } else {
+        hipLaunchKernelGGL(k_snac_dw, dim3(ew_grid((size_t)n * T * c.latent_dim)), dim3(256), 0, st, x, w.dw0_w, w.dw0_b, nullptr, nullptr,
+                           nullptr, nullptr, y, g, 1);
+        VOX_TRY(conv_gemm(st, w.pw0, y, nullptr, nullptr, n, T, 0, off1, x, nullptr, nullptr, 0));
+    }
     g.C = c.decoder_dim;
+    if (c.attn_window > 0) {       // LocalMHA: x += to_out(attention(rotary(to_qkv(LayerNorm(x)))))
+        if (T % c.attn_window) return vox_fail(VOX_ERR_INVALID, "snac_decode: %d frames are not a multiple of the attention window %d", T, c.attn_window);
+        hipLaunchKernelGGL(k_layernorm_f32, dim3(n * T), dim3(256), 0, st, x, w.attn_ln_w, w.attn_ln_b, y, g.C, 1e-5f);
+        VOX_TRY(conv_gemm(st, w.attn_qkv, y, nullptr, nullptr, n, T, 0, off1, u, nullptr, nullptr, 0));          // u [nT][3C]
+        hipLaunchKernelGGL(k_snac_local_attn, dim3(T / c.attn_window, g.C / 64, n), dim3(256), 0, st, u, y, T, g.C, c.attn_window);
+        VOX_TRY(conv_gemm(st, w.attn_out, y, nullptr, nullptr, n, T, 0, off1, pk, x, nullptr, 0));                 // pk = x + out
+        float* t = x; x = pk; pk = t;
+    }
     size_t noise_off = 0;
     for (int bi = 0; bi < m->n_stages; ++bi) {
         const vox_snac_block_w& b = w.blocks[bi];
@@ -1719,8 +1788,15 @@ int vox_snac_decode(vox_snac* m, void* stream, const int32_t* codes, int n, int 
         static const int dils[3] = {1, 3, 9};
         for (int k = 0; k < 3; ++k) {
             const vox_snac_res_w& ru = b.res[k];
-            hipLaunchKernelGGL(k_snac_dw, dim3(ew_grid((size_t)n * g.Lb * g.C)), dim3(256), 0, st, x, ru.dw_w, ru.dw_b, ru.act1.alpha, ru.act1.inv_beta,
-                               ru.act2.alpha, ru.act2.inv_beta, u, g, dils[k]);
+            if (ru.dense.n_taps > 0) {      // dense k7 conv: masked Snake -> 7-tap GEMM (taps read zeros outside the valid rows) with act2 fused
+                const int d = dils[k];
+                const int offd[14] = {3 * d, 2 * d, d, 0, -d, -2 * d, -3 * d, 3 * d, 2 * d, d, 0, -d, -2 * d, -3 * d};
+                hipLaunchKernelGGL(k_snac_snake_mask, dim3(ew_grid((size_t)n * g.Lb * g.C)), dim3(256), 0, st, x, ru.act1.alpha, ru.act1.inv_beta, pk, g);
+                VOX_TRY(conv_gemm(st, ru.dense, pk, nullptr, nullptr, n, g.Lb, 0, offd, nullptr, nullptr, nullptr, 0, u, &ru.act2, g.C));
+            } else {
+                hipLaunchKernelGGL(k_snac_dw, dim3(ew_grid((size_t)n * g.Lb * g.C)), dim3(256), 0, st, x, ru.dw_w, ru.dw_b, ru.act1.alpha, ru.act1.inv_beta,
+                                   ru.act2.alpha, ru.act2.inv_beta, u, g, dils[k]);
+            }
             VOX_TRY(conv_gemm(st, ru.pw, u, nullptr, nullptr, n, g.Lb, 0, off1, y, x, nullptr, 0));
             float* t = x; x = y; y = t;
         }

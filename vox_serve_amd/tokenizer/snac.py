@@ -10,7 +10,9 @@ parametrizations original0 = g / original1 = v, or already-folded `.weight`).  P
   * ConvTranspose1d [Cin, Cout, 2r] (stride r, padding r/2) -> two taps writing r*Cout values per input row
   * Snake1d alpha -> (alpha, 1/(alpha + 1e-9))
 NoiseBlock's noise: a seeded Philox stream generated on the device (see include/voxhip.h), or a tensor handed in (tests).
-Only the depthwise / no-local-attention variant (hubertsiuzdak/snac_24khz) is built.
+Variants: depthwise convs without attention (hubertsiuzdak/snac_24khz, what the reference's Orpheus plugin loads) and the module's
+dense-conv / LocalMHA forms (the 32 / 44 kHz checkpoints' structure: `depthwise=False`, `attn_window_size` <= 32 frames, the frame
+count a multiple of the window as in the reference: snac.py:38-40).
 """
 import ctypes
 import math
@@ -44,7 +46,7 @@ class SNACConfig:
 
 
 class SnacResW(ctypes.Structure):
-    _fields_ = [("act1", SnakeW), ("act2", SnakeW), ("dw_w", ctypes.c_void_p), ("dw_b", ctypes.c_void_p), ("pw", ConvW)]
+    _fields_ = [("act1", SnakeW), ("act2", SnakeW), ("dw_w", ctypes.c_void_p), ("dw_b", ctypes.c_void_p), ("pw", ConvW), ("dense", ConvW)]
 
 
 class SnacBlockW(ctypes.Structure):
@@ -53,12 +55,13 @@ class SnacBlockW(ctypes.Structure):
 
 class SnacWeights(ctypes.Structure):
     _fields_ = [("tab", ctypes.c_void_p * 4), ("dw0_w", ctypes.c_void_p), ("dw0_b", ctypes.c_void_p), ("pw0", ConvW),
-                ("blocks", SnacBlockW * 4), ("final_snake", SnakeW), ("final_w", ctypes.c_void_p), ("final_b", ctypes.c_float)]
+                ("blocks", SnacBlockW * 4), ("final_snake", SnakeW), ("final_w", ctypes.c_void_p), ("final_b", ctypes.c_float),
+                ("conv0", ConvW), ("attn_ln_w", ctypes.c_void_p), ("attn_ln_b", ctypes.c_void_p), ("attn_qkv", ConvW), ("attn_out", ConvW)]
 
 
 class SnacConfigC(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("latent_dim", "decoder_dim", "codebook_size", "n_levels")] + \
-               [("vq_strides", ctypes.c_int32 * 4), ("rates", ctypes.c_int32 * 4), ("noise", ctypes.c_int32)]
+               [("vq_strides", ctypes.c_int32 * 4), ("rates", ctypes.c_int32 * 4), ("noise", ctypes.c_int32), ("attn_window", ctypes.c_int32)]
 
 
 def _bind(L):
@@ -92,8 +95,8 @@ class SNACDecoder:
     def __init__(self, weights: Dict[str, torch.Tensor], config: Optional[SNACConfig] = None, device="cuda", max_batch=8, max_T=16,
                  seed: int = 0):
         self.cfg = c = config or SNACConfig()
-        if not c.depthwise or c.attn_window_size is not None:
-            raise NotImplementedError("SNACDecoder: only the depthwise, attention-free variant (snac_24khz) is built")
+        if c.attn_window_size is not None and (not 1 <= c.attn_window_size <= 32 or c.decoder_dim % 64):
+            raise ValueError("SNACDecoder: LocalMHA windows of 1..32 frames, decoder_dim a multiple of the 64-wide heads")
         if len(c.decoder_rates) > 4 or len(c.vq_strides) > 4 or any(r % 2 for r in c.decoder_rates):
             raise ValueError("SNACDecoder: at most 4 even decoder rates / 4 VQ levels")
         self.device = torch.device(device)
@@ -127,11 +130,20 @@ class SNACDecoder:
             tab = W[q + "codebook.weight"].float().cpu() @ proj.t() + W[q + "out_proj.bias"].float().cpu()[None]
             sw.tab[i] = f32(tab)
         d = "decoder.model."
-        sw.dw0_w, sw.dw0_b = f32(_folded(W, d + "0")[:, 0, :]), f32(W[d + "0.bias"])
-        sw.pw0 = conv(_folded(W, d + "1")[:, :, 0][None], W[d + "1.bias"])
+        if c.depthwise:
+            sw.dw0_w, sw.dw0_b = f32(_folded(W, d + "0")[:, 0, :]), f32(W[d + "0.bias"])
+            sw.pw0 = conv(_folded(W, d + "1")[:, :, 0][None], W[d + "1.bias"])
+        else:                                                                            # one dense k7 conv: taps [7][Cout][Cin]
+            sw.conv0 = conv(_folded(W, d + "0").permute(2, 0, 1), W[d + "0.bias"])
+        first = (2 if c.depthwise else 1) + (1 if c.attn_window_size is not None else 0)   # index of the first DecoderBlock (snac.py:130-146)
+        if c.attn_window_size is not None:
+            a = f"{d}{first - 1}."
+            sw.attn_ln_w, sw.attn_ln_b = f32(W[a + "norm.weight"]), f32(W[a + "norm.bias"])
+            sw.attn_qkv = conv(W[a + "to_qkv.weight"].float().cpu()[None])
+            sw.attn_out = conv(W[a + "to_out.weight"].float().cpu()[None])
         ch = c.decoder_dim
         for bi, r in enumerate(c.decoder_rates):
-            b = f"{d}{2 + bi}.block."
+            b = f"{d}{first + bi}.block."
             bw = sw.blocks[bi]
             bw.snake0 = snake(b + "0.alpha")
             wt = _folded(W, b + "1")                                                     # [Cin, Cout, 2r]
@@ -146,17 +158,20 @@ class SNACDecoder:
                 ru = f"{b}{j + u}.block."
                 rw = bw.res[u]
                 rw.act1, rw.act2 = snake(ru + "0.alpha"), snake(ru + "2.alpha")
-                rw.dw_w, rw.dw_b = f32(_folded(W, ru + "1")[:, 0, :]), f32(W[ru + "1.bias"])
+                if c.depthwise:
+                    rw.dw_w, rw.dw_b = f32(_folded(W, ru + "1")[:, 0, :]), f32(W[ru + "1.bias"])
+                else:
+                    rw.dense = conv(_folded(W, ru + "1").permute(2, 0, 1), W[ru + "1.bias"])
                 rw.pw = conv(_folded(W, ru + "3")[:, :, 0][None], W[ru + "3.bias"])
             ch = cout
-        n = 2 + len(c.decoder_rates)
+        n = first + len(c.decoder_rates)
         sw.final_snake = snake(f"{d}{n}.alpha")
         sw.final_w = f32(_folded(W, f"{d}{n + 1}")[0])                                  # [C][7]
         sw.final_b = float(W[f"{d}{n + 1}.bias"].float().item())
         rates = list(c.decoder_rates) + [0] * (4 - len(c.decoder_rates))
         strides = list(c.vq_strides) + [0] * (4 - len(c.vq_strides))
         sc = SnacConfigC(c.latent_dim, c.decoder_dim, c.codebook_size, len(c.vq_strides), (ctypes.c_int32 * 4)(*strides),
-                         (ctypes.c_int32 * 4)(*rates), int(c.noise))
+                         (ctypes.c_int32 * 4)(*rates), int(c.noise), int(c.attn_window_size or 0))
         h = ctypes.c_void_p()
         N.check(self.L.vox_snac_create(N.ctx(), ctypes.byref(sc), ctypes.byref(sw), max_batch, max_T, ctypes.byref(h)))
         self.h, self._sw = h, sw
