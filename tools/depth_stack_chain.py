@@ -17,6 +17,8 @@ if "--with-engine" in sys.argv:      # a whole Qwen3-TTS engine (3.5 GB of weigh
     _W = synth_qwen3_weights(_cfg, dev, seed=0)
     _eng = Qwen3Engine(_cfg, _W, max_batch=1, page_size=128, max_pages=64, max_seq_len=2304, max_prefill_rows=128)
     sys.argv.remove("--with-engine")
+ENGW = "--engine-weights" in sys.argv       # the chain reads the ENGINE's depth-stack weight tensors (needs --with-engine)
+if ENGW: sys.argv.remove("--engine-weights")
 H, NL, heads, kvh, D, F, G = 1024, 5, 16, 8, 128, 3072, 16
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 4          # distinct weight sets cycled (footprint = reps x 155 MB)
 ec = StackCfg(H, NL, heads, kvh, D, F, 1e-6, 1e6, 1.0, None, False, None, True, False)
@@ -34,6 +36,7 @@ for r in range(reps):
             keep.append(v)
             setattr(arr[l], k, v.data_ptr())
     fn = ones(H)
+    if ENGW: arr = _eng.dl
     keep += [arr, fn]
     sc = _stack_config(ec, G, 2, G)
     h = ctypes.c_void_p()

@@ -44,6 +44,9 @@ if os.environ.get("LM_ASYNC") == "1":
     eng.stream.synchronize()
     print(f"B={B} back-to-back: gpu {ev0.elapsed_time(ev1)/frames:.3f} ms/frame")
     sys.exit(0)
+import contextlib
+_one = torch.cuda.stream(eng.stream) if os.environ.get("LM_ONE_STREAM") == "1" else contextlib.nullcontext()
+_one.__enter__()
 t0 = time.perf_counter()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 gpu_ms = 0.0

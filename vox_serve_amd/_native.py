@@ -172,6 +172,56 @@ def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_capture_streams = {}
+
+
+class graph_capture:
+    """`with graph_capture() as cap: <enqueue on N.stream()>` -> `cap.graph` (a vox_graph handle).
+
+    Stream capture needs a non-default stream, so the body runs on a private per-device stream, fenced against the caller's
+    current stream on both sides — a one-time cost per captured shape.  REPLAYS (`vox_graph_launch(g, N.stream())`) and eager
+    calls go on the caller's own current stream: engines and detokenizers own no stream of their own.  That is deliberate and
+    measured: while a graph runs, a barrier packet pending on a SECOND hardware queue (what `other.wait_stream(engine_stream)`
+    leaves behind until the graph finishes) makes the command processor alternate between the queues, and every dependent
+    dispatch of the running graph costs about 1.3 us more on an MI355X — 0.5 ms of a 3.3 ms Qwen3-TTS frame of ~510 dependent
+    kernels (profiles/round3_queue_fence.txt).  Whoever wants two graphs side by side (LM frame + codec chunk) puts them on
+    two streams itself and orders them with events it waits for on the HOST."""
+
+    def __init__(self):
+        import torch
+        self._torch = torch
+        d = torch.cuda.current_device()
+        if d not in _capture_streams:
+            _capture_streams[d] = torch.cuda.Stream(device=d)
+        self.cs = _capture_streams[d]
+        self.graph = None
+
+    def __enter__(self):
+        torch = self._torch
+        self.cur = torch.cuda.current_stream()
+        self.cs.wait_stream(self.cur)
+        self._ctx = torch.cuda.stream(self.cs)
+        self._ctx.__enter__()
+        try:
+            check(lib().vox_graph_begin(ctx(), stream()))
+        except Exception:
+            self._ctx.__exit__(None, None, None)
+            raise
+        return self
+
+    def __exit__(self, et, ev, tb):
+        gh = c_void_p()
+        try:
+            status = lib().vox_graph_end(ctx(), stream(), ctypes.byref(gh))    # capture must end even when the body raised
+        finally:
+            self._ctx.__exit__(None, None, None)
+            self.cur.wait_stream(self.cs)
+        if et is None:
+            check(status)
+            self.graph = gh
+        return False
+
+
 def ptr(t):
     """Device pointer of a torch tensor (None -> NULL).  Tensors must be contiguous."""
     if t is None:

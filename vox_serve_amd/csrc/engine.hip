@@ -71,6 +71,20 @@ int vox_graph_end(vox_ctx* ctx, void* stream, vox_graph** out) {
     (void)ctx;
     hipGraph_t g = nullptr;
     VOX_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+#ifdef VOX_DEV_KNOBS
+    if (getenv("VOX_GRAPH_INFO")) {     // (dev knob: node / edge counts and node types of the captured graph)
+        size_t nn = 0, ne = 0;
+        (void)hipGraphGetNodes(g, nullptr, &nn); (void)hipGraphGetEdges(g, nullptr, nullptr, &ne);
+        std::vector<hipGraphNode_t> nodes(nn);
+        (void)hipGraphGetNodes(g, nodes.data(), &nn);
+        int types[16] = {0};
+        for (auto n : nodes) { hipGraphNodeType t; if (hipGraphNodeGetType(n, &t) == hipSuccess && (int)t < 16) types[(int)t]++; }
+        fprintf(stderr, "[vox graph] %zu nodes, %zu edges; types:", nn, ne);
+        for (int t = 0; t < 16; ++t) if (types[t]) fprintf(stderr, " %d:%d", t, types[t]);
+        fprintf(stderr, "\n");
+        if (const char* dot = getenv("VOX_GRAPH_DOT")) (void)hipGraphDebugDotPrint(g, dot, 0);
+    }
+#endif
     hipGraphExec_t e = nullptr;
     hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
     if (err != hipSuccess) {
@@ -402,6 +416,9 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
             return vox_fail(VOX_ERR_NOMEM, "stack_create: fragment-major weight copies failed");
         }
     }
+#ifdef VOX_DEV_KNOBS
+    if (const char* e = getenv("VOX_STACK_KEEP")) s->keep_weights = atoi(e);
+#endif
     *out = s;
     return VOX_OK;
 }
@@ -490,6 +507,11 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         s.emb_dst = (bf16_t*)m->depth_x + H; s.emb_dst_stride = 2L * H; s.ws = m->ctx->samp_ws;
         VOX_TRY(vox_launch_sample(st, s));
     }
+#ifdef VOX_DEV_KNOBS
+    static int depth_rep = -1;      // (dev knob VOX_DEPTH_REPEAT: the depth loop n times over, timing only)
+    if (depth_rep < 0) { const char* e = getenv("VOX_DEPTH_REPEAT"); depth_rep = e ? atoi(e) : 1; }
+    for (int rep = 0; rep < depth_rep; ++rep)
+#endif
     for (int i = (ablate() & 4096) ? 2 : 1; i < G && !(ablate() & 2); ++i) {      // (dev knob 4096: leave out depth step 1)
         const int rows = i == 1 ? 2 * B : B;
         if (i == 1 || !m->proj_tab) {     // (steps >= 2: the previous step's sampler gathered the tabulated projection into dx)

@@ -50,7 +50,6 @@ class CosyVoice2Decoder:
         self.source_cache_len = int(self.mel_cache_len * 480)
         self.speech_window = torch.from_numpy(np.hamming(2 * self.source_cache_len)).to(self.device)      # float64, like the reference
         self.seed, self.use_graph, self._graphs, self._chunk = seed, True, {}, 0
-        self._stream = torch.cuda.Stream(device=self.device)
         L = N.lib()
         L.vox_flow_fill_noise.restype = ctypes.c_int
         L.vox_flow_fill_noise.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -139,35 +138,28 @@ class CosyVoice2Decoder:
                                        "mel": torch.empty(B, c.mel, 2 * T, dtype=torch.float32, device=self.device),
                                        "wav": torch.empty(B, Lw, dtype=torch.float32, device=self.device), "g": None, "calls": 0}
         self._chunk += 1
-        cur = torch.cuda.current_stream()
-        self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
-            st = N.stream()
-            ent["tok"].copy_(speech_tokens.to(self.device, torch.int32), non_blocking=True)
-            ent["sb"].copy_(((torch.arange(B, dtype=torch.int64) + self._chunk * 65536) * 2).to(torch.int32), non_blocking=True)
-            N.check(L.vox_flow_fill_noise(st, ctypes.c_uint64(self.seed), self._chunk, c.mel, 2 * T, ent["z"].data_ptr()))
+        # on the caller's current stream (N.graph_capture: why the decoder owns none)
+        ent["tok"].copy_(speech_tokens.to(self.device, torch.int32), non_blocking=True)
+        ent["sb"].copy_(((torch.arange(B, dtype=torch.int64) + self._chunk * 65536) * 2).to(torch.int32), non_blocking=True)
+        N.check(L.vox_flow_fill_noise(N.stream(), ctypes.c_uint64(self.seed), self._chunk, c.mel, 2 * T, ent["z"].data_ptr()))
 
-            def body():
-                N.check(self.flow.L.vox_flow_decode_chunk(self.flow.h, st, ent["tok"].data_ptr(), B, T, ent["z"].data_ptr(), ctypes.c_uint64(self.seed), 0,
-                                                          ent["mel"].data_ptr(), None))
-                N.check(self.hift.L.vox_hift_decode(self.hift.h, st, ent["mel"].data_ptr(), B, 2 * T, None, ctypes.c_uint64(self.seed),
-                                                    ent["sb"].data_ptr(), ent["wav"].data_ptr(), None, None))
-                N.check(L.vox_fade_in_out(st, ent["wav"].data_ptr(), B, ent["wav"].shape[1], None, self.speech_window.data_ptr(), self.source_cache_len))
-            ent["calls"] += 1
-            if ent["calls"] == 1:
-                body()
-            else:
-                if ent["g"] is None:
-                    N.check(L.vox_graph_begin(N.ctx(), st))
-                    try:
-                        body()
-                    finally:
-                        gh = ctypes.c_void_p()
-                        N.check(L.vox_graph_end(N.ctx(), st, ctypes.byref(gh)))
-                    ent["g"] = gh
-                N.check(L.vox_graph_launch(ent["g"], st))
-            out = ent["wav"][:, : ent["wav"].shape[1] - self.source_cache_len].clone()
-        cur.wait_stream(self._stream)
+        def body():
+            st = N.stream()
+            N.check(self.flow.L.vox_flow_decode_chunk(self.flow.h, st, ent["tok"].data_ptr(), B, T, ent["z"].data_ptr(), ctypes.c_uint64(self.seed), 0,
+                                                      ent["mel"].data_ptr(), None))
+            N.check(self.hift.L.vox_hift_decode(self.hift.h, st, ent["mel"].data_ptr(), B, 2 * T, None, ctypes.c_uint64(self.seed),
+                                                ent["sb"].data_ptr(), ent["wav"].data_ptr(), None, None))
+            N.check(L.vox_fade_in_out(st, ent["wav"].data_ptr(), B, ent["wav"].shape[1], None, self.speech_window.data_ptr(), self.source_cache_len))
+        ent["calls"] += 1
+        if ent["calls"] == 1:
+            body()
+        else:
+            if ent["g"] is None:
+                with N.graph_capture() as cap:
+                    body()
+                ent["g"] = cap.graph
+            N.check(L.vox_graph_launch(ent["g"], N.stream()))
+        out = ent["wav"][:, : ent["wav"].shape[1] - self.source_cache_len].clone()
         return out
 
     def close(self):

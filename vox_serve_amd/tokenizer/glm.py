@@ -206,7 +206,6 @@ class GLMAudioDecoder:
         self.hift = HiFTGenerator(hift_weights, hift_config or glm_hift_config(), device=device, max_batch=max_batch,
                                   max_T=self.flow.cfg.mel_len(max_tokens) + 2, seed=seed)
         self.seed, self.use_graph, self._graphs, self._call = seed, True, {}, 0
-        self._stream = torch.cuda.Stream(device=self.device)
         L = self.flow.L
         L.vox_flow_fill_noise.restype = ctypes.c_int
         L.vox_flow_fill_noise.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -240,35 +239,28 @@ class GLMAudioDecoder:
                                           "wav": torch.empty(B, Tm * self.hift.upsample_scale, dtype=torch.float32, device=self.device),
                                           "g": None, "calls": 0}
         self._call += 1
-        cur = torch.cuda.current_stream()
-        self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
-            st = N.stream()
-            ent["tok"].copy_(audio_ids.to(self.device, torch.int32), non_blocking=True)
-            ent["sb"].copy_(((torch.arange(B, dtype=torch.int64) + self._call * 65536) * 2).to(torch.int32), non_blocking=True)
-            for b in range(B):
-                N.check(L.vox_flow_fill_noise(st, ctypes.c_uint64(self.seed), self._call * 65536 + b, c.mel, Tm, ent["z"][b].data_ptr()))
+        # on the caller's current stream (N.graph_capture: why the decoder owns none)
+        ent["tok"].copy_(audio_ids.to(self.device, torch.int32), non_blocking=True)
+        ent["sb"].copy_(((torch.arange(B, dtype=torch.int64) + self._call * 65536) * 2).to(torch.int32), non_blocking=True)
+        for b in range(B):
+            N.check(L.vox_flow_fill_noise(N.stream(), ctypes.c_uint64(self.seed), self._call * 65536 + b, c.mel, Tm, ent["z"][b].data_ptr()))
 
-            def body():
-                N.check(L.vox_glmflow_decode(self.flow.h, st, ent["tok"].data_ptr(), B, T, Tm, None, ent["z"].data_ptr(), ctypes.c_uint64(self.seed), 0,
-                                             ent["mel"].data_ptr()))
-                N.check(self.hift.L.vox_hift_decode(self.hift.h, st, ent["mel"].data_ptr(), B, Tm, None, ctypes.c_uint64(self.seed ^ 0x5A5A),
-                                                    ent["sb"].data_ptr(), ent["wav"].data_ptr(), None, None))
-            ent["calls"] += 1
-            if ent["calls"] == 1:
-                body()
-            else:
-                if ent["g"] is None:
-                    N.check(L.vox_graph_begin(N.ctx(), st))
-                    try:
-                        body()
-                    finally:
-                        gh = ctypes.c_void_p()
-                        N.check(L.vox_graph_end(N.ctx(), st, ctypes.byref(gh)))
-                    ent["g"] = gh
-                N.check(L.vox_graph_launch(ent["g"], st))
-            out = ent["wav"].clone()
-        cur.wait_stream(self._stream)
+        def body():
+            st = N.stream()
+            N.check(L.vox_glmflow_decode(self.flow.h, st, ent["tok"].data_ptr(), B, T, Tm, None, ent["z"].data_ptr(), ctypes.c_uint64(self.seed), 0,
+                                         ent["mel"].data_ptr()))
+            N.check(self.hift.L.vox_hift_decode(self.hift.h, st, ent["mel"].data_ptr(), B, Tm, None, ctypes.c_uint64(self.seed ^ 0x5A5A),
+                                                ent["sb"].data_ptr(), ent["wav"].data_ptr(), None, None))
+        ent["calls"] += 1
+        if ent["calls"] == 1:
+            body()
+        else:
+            if ent["g"] is None:
+                with N.graph_capture() as cap:
+                    body()
+                ent["g"] = cap.graph
+            N.check(L.vox_graph_launch(ent["g"], N.stream()))
+        out = ent["wav"].clone()
         return out
 
     def close(self):

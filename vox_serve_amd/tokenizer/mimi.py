@@ -189,7 +189,6 @@ class MimiDecoder:
         N.check(self.L.vox_mimi_create(N.ctx(), ctypes.byref(mc), ctypes.byref(mw), max_batch, max_frames, ctypes.byref(h)))
         self.h, self._mw = h, mw
         self._graphs, self.use_graph = {}, True
-        self._stream = torch.cuda.Stream(device=self.device)
 
     sample_rate = property(lambda self: self.cfg.sample_rate)
     hop = property(lambda self: self.cfg.hop)
@@ -219,27 +218,18 @@ class MimiDecoder:
         if ent is None:
             ent = self._graphs[key] = {"codes": torch.empty(b, t, stride, dtype=torch.int32, device=self.device),
                                        "out": torch.empty(b, 1, t * self.hop, dtype=torch.float32, device=self.device), "g": None, "calls": 0}
-        cur = torch.cuda.current_stream()
-        self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
-            ent["codes"].copy_(codes, non_blocking=True)
-            st = N.stream()
-            args = (self.h, st, ent["codes"].data_ptr(), stride, b, t, ent["out"].data_ptr())
-            ent["calls"] += 1
-            if ent["calls"] == 1:
-                N.check(self.L.vox_mimi_decode(*args))
-            else:
-                if ent["g"] is None:
-                    N.check(self.L.vox_graph_begin(N.ctx(), st))
-                    try:
-                        N.check(self.L.vox_mimi_decode(*args))
-                    finally:
-                        gh = ctypes.c_void_p()
-                        N.check(self.L.vox_graph_end(N.ctx(), st, ctypes.byref(gh)))
-                    ent["g"] = gh
-                N.check(self.L.vox_graph_launch(ent["g"], st))
-        codes.record_stream(self._stream)
-        cur.wait_stream(self._stream)
+        # on the caller's current stream (N.graph_capture: why the decoder owns none)
+        ent["codes"].copy_(codes, non_blocking=True)
+        args = lambda: (self.h, N.stream(), ent["codes"].data_ptr(), stride, b, t, ent["out"].data_ptr())
+        ent["calls"] += 1
+        if ent["calls"] == 1:
+            N.check(self.L.vox_mimi_decode(*args()))
+        else:
+            if ent["g"] is None:
+                with N.graph_capture() as cap:
+                    N.check(self.L.vox_mimi_decode(*args()))
+                ent["g"] = cap.graph
+            N.check(self.L.vox_graph_launch(ent["g"], N.stream()))
         return ent["out"]
 
     # ---- streaming option (not the reference's behaviour: it decodes every chunk from a fresh state, mimi.py:3085-3089) ----

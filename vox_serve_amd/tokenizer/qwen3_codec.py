@@ -270,7 +270,6 @@ class Qwen3TTSDecoder:
         self.hop = c.total_upsample
         self._out = torch.empty(max_batch, detokenize_interval * self.hop, dtype=torch.float32, device=dev)
         self._graphs, self.use_graph = {}, True
-        self._stream = torch.cuda.Stream(device=dev)
 
     @property
     def state_bytes_per_request(self) -> int:
@@ -321,30 +320,20 @@ class Qwen3TTSDecoder:
             ent = self._graphs[key] = {"codes": torch.empty(b, t, stride, dtype=torch.int32, device=self.device),
                                        "slots": torch.empty(b, dtype=torch.int32, device=self.device),
                                        "out": torch.empty(b, t * self.hop, dtype=torch.float32, device=self.device), "g": None, "calls": 0}
-        # capture needs a non-default stream: the chunk runs on the decoder's own stream, fenced against the caller's
-        cur = torch.cuda.current_stream()
-        self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
-            ent["codes"].copy_(codes, non_blocking=True)
-            ent["slots"].copy_(slots, non_blocking=True)
-            st = N.stream()
-            args = (self.h, st, N.ptr(ent["codes"]), stride, N.ptr(ent["slots"]), b, t, N.ptr(ent["out"]))
-            ent["calls"] += 1
-            if ent["calls"] == 1:
-                N.check(self.L.vox_codec_decode_chunk(*args))
-            else:
-                if ent["g"] is None:
-                    N.check(self.L.vox_graph_begin(N.ctx(), st))
-                    try:
-                        N.check(self.L.vox_codec_decode_chunk(*args))
-                    finally:
-                        gh = ctypes.c_void_p()
-                        N.check(self.L.vox_graph_end(N.ctx(), st, ctypes.byref(gh)))
-                    ent["g"] = gh
-                N.check(self.L.vox_graph_launch(ent["g"], st))
-        codes.record_stream(self._stream)
-        slots.record_stream(self._stream)
-        cur.wait_stream(self._stream)
+        # the chunk runs on the caller's current stream (N.graph_capture: why the decoder owns none); a new shape is
+        # captured once on the capture stream
+        ent["codes"].copy_(codes, non_blocking=True)
+        ent["slots"].copy_(slots, non_blocking=True)
+        args = lambda: (self.h, N.stream(), N.ptr(ent["codes"]), stride, N.ptr(ent["slots"]), b, t, N.ptr(ent["out"]))
+        ent["calls"] += 1
+        if ent["calls"] == 1:
+            N.check(self.L.vox_codec_decode_chunk(*args()))
+        else:
+            if ent["g"] is None:
+                with N.graph_capture() as cap:
+                    N.check(self.L.vox_codec_decode_chunk(*args()))
+                ent["g"] = cap.graph
+            N.check(self.L.vox_graph_launch(ent["g"], N.stream()))
         return ent["out"][:, None, :]
 
     def close(self):

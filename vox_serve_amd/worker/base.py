@@ -73,6 +73,7 @@ class ModelWorker:
         self.has_depth_transformer = getattr(model, "has_depth_transformer", False)
         self.async_scheduling = False   # set by a scheduler running the reference's async loop (scheduler/base.py:166-221)
         self._pending = None         # the deferred request-state update of the last launched step (async scheduling)
+        self._detok_fence_needed = True
         self._detok_stream = None    # launch_detokenize: the codec chunk + its D2H copy run here, beside the LM frame
         self._snap, self._snap_i = None, 0
         self._code_pins, self._code_pin_i = [], 0
@@ -208,6 +209,7 @@ class ModelWorker:
             req.repetition_cache = pre.repetition_cache
         if getattr(pre, "decoder_cache", None) is not None:
             req.decoder_cache = pre.decoder_cache
+            self._detok_fence_needed = True      # its slots were reset on this (the LM) stream: the next chunk orders itself behind
         req._preprocessed = True
 
     def _inject_streaming_text_token(self, req: Request) -> None:
@@ -537,8 +539,13 @@ class ModelWorker:
             on_gpu = torch.cuda.is_available() and str(self.detokenizer_device).startswith("cuda")
             if on_gpu and self._detok_stream is None:
                 self._detok_stream = torch.cuda.Stream(device=self.detokenizer_device)
-            if on_gpu:
+            # The chunk's inputs come from the host; the only device state it shares with the LM stream is a decoder cache
+            # that `preprocess` (re)initialised there.  Fence only then: a `wait_stream` leaves a barrier packet pending on the
+            # detokenize queue until the LM frame in flight ends, and a pending barrier on a second hardware queue slows
+            # every dispatch of that frame (N.graph_capture).
+            if on_gpu and (self._detok_fence_needed or any(getattr(t, "is_cuda", False) for t in token_ids)):
                 self._detok_stream.wait_stream(torch.cuda.current_stream())
+                self._detok_fence_needed = False
             ctx = torch.cuda.stream(self._detok_stream) if on_gpu else contextlib.nullcontext()
             with ctx:
                 for rnd in range(n_rounds):
