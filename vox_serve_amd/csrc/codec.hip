@@ -530,6 +530,125 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
     }
 }
 
+// Few-row GEMM with no dependent K steps ("rows" kernel; the flow detokenizers' 56..512-row linears and causal convs: thousands of
+// launches per chunk whose time is exposed memory latency, not arithmetic).  A block owns 16 rows x 16*NT columns; its four waves split
+// the n_taps * Cin reduction into quarters of KB 32-wide k-blocks and each lane requests ALL its operands up front, straight in the
+// layout an MFMA operand register holds (A: 8 consecutive fp32 of row lane % 16; B: 8 consecutive bf16 of weight row lane % 16) — one
+// exposed round trip per launch, no LDS staging, no barrier until the cross-wave sum (fixed order w0 + w1 + w2 + w3).  With the fused
+// LayerNorm the row statistics come from ln_row_stats (the same bits as k_flow_ln) while the operands are in flight.  A row's result
+// depends on that row only, so a request's output does not depend on what else shares its batch.
+template <int KB, int NT, bool LN>
+__global__ __launch_bounds__(256) void k_rows_gemm(ConvGemmArgs a) {
+    __shared__ float red[4][NT][256];
+    __shared__ float ln_stat[LN ? 32 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16 * NT;
+    const int kpt = a.Cin >> 5;                     // k-blocks per tap
+    const int am = m0 + fr;
+    float4 av[KB][2];
+    uint4 bv[NT][KB];
+    float4 lw[LN ? KB : 1][2], lb[LN ? KB : 1][2];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        const int kbi = wave * KB + j, tap = kbi / kpt, c0 = (kbi - tap * kpt) * 32 + kq * 8;
+        const float* arow = nullptr;
+        if (am < a.M) {
+            const int ab = am / a.L, st = am % a.L - a.off[tap];
+            if (st >= a.L) arow = nullptr;
+            else if (st >= 0) arow = a.x + ((size_t)ab * a.L + st) * a.Cin;
+            else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[ab] * a.P + (a.P + st)) * a.Cin;
+        }
+        av[j][0] = av[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (arow) {
+            av[j][0] = *reinterpret_cast<const float4*>(arow + c0);
+            av[j][1] = *reinterpret_cast<const float4*>(arow + c0 + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int bn = n0 + t * 16 + fr;
+            bv[t][j] = make_uint4(0, 0, 0, 0);
+            if (bn < a.N) bv[t][j] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.N + bn) * a.Cin + c0);
+        }
+        if (LN) {
+            lw[j][0] = *reinterpret_cast<const float4*>(a.ln_w + c0); lw[j][1] = *reinterpret_cast<const float4*>(a.ln_w + c0 + 4);
+            lb[j][0] = *reinterpret_cast<const float4*>(a.ln_b + c0); lb[j][1] = *reinterpret_cast<const float4*>(a.ln_b + c0 + 4);
+        }
+    }
+    float mean = 0.0f, rstd = 0.0f;
+    if (LN) {      // wave w: rows 4w..4w+3 of the tile, 16 lanes per row; every wave then reads the statistics of its operand row
+        const int r = wave * 4 + kq, rm = m0 + r;
+        float mu = 0.0f, rs = 0.0f;
+        if (rm < a.M) ln_row_stats(a.x + (size_t)rm * a.Cin, a.Cin, fr, a.ln_eps, mu, rs);
+        if (fr == 0) { ln_stat[2 * r] = mu; ln_stat[2 * r + 1] = rs; }
+        __syncthreads();
+        mean = ln_stat[2 * fr]; rstd = ln_stat[2 * fr + 1];
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+        float x8[8] = {av[j][0].x, av[j][0].y, av[j][0].z, av[j][0].w, av[j][1].x, av[j][1].y, av[j][1].z, av[j][1].w};
+        if (LN) {
+            const float w8[8] = {lw[j][0].x, lw[j][0].y, lw[j][0].z, lw[j][0].w, lw[j][1].x, lw[j][1].y, lw[j][1].z, lw[j][1].w};
+            const float b8[8] = {lb[j][0].x, lb[j][0].y, lb[j][0].z, lb[j][0].w, lb[j][1].x, lb[j][1].y, lb[j][1].z, lb[j][1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x8[e] = (x8[e] - mean) * rstd * w8[e] + b8[e];
+        }
+        unsigned short hb[8], mb[8], lbb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hb[e] = f2bf(x8[e]);
+            const float r1 = x8[e] - bf2f(hb[e]);
+            mb[e] = f2bf(r1);
+            lbb[e] = f2bf(r1 - bf2f(mb[e]));
+        }
+        const uint4 ah = make_uint4(hb[0] | (unsigned)hb[1] << 16, hb[2] | (unsigned)hb[3] << 16, hb[4] | (unsigned)hb[5] << 16, hb[6] | (unsigned)hb[7] << 16);
+        const uint4 amid = make_uint4(mb[0] | (unsigned)mb[1] << 16, mb[2] | (unsigned)mb[3] << 16, mb[4] | (unsigned)mb[5] << 16, mb[6] | (unsigned)mb[7] << 16);
+        const uint4 al = make_uint4(lbb[0] | (unsigned)lbb[1] << 16, lbb[2] | (unsigned)lbb[3] << 16, lbb[4] | (unsigned)lbb[5] << 16, lbb[6] | (unsigned)lbb[7] << 16);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {      // plane order of the staged kernels: low terms first
+            if (a.planes >= 3) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(al), as_cbf8(bv[t][j]), acc[t], 0, 0, 0);
+            if (a.planes >= 2) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(amid), as_cbf8(bv[t][j]), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(ah), as_cbf8(bv[t][j]), acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t][r * 64 + lane] = acc[t][r];
+    __syncthreads();
+    // wave w finishes accumulator component w of every tile: row m0 + 4 * (lane / 16) + w, column n0 + 16 t + lane % 16
+    const int m = m0 + kq * 4 + wave;
+    if (m >= a.M) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + t * 16 + fr;
+        if (n >= a.N) continue;
+        const int e = wave * 64 + lane;
+        float v = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
+        v += a.bias ? a.bias[n % a.bias_mod] : 0.0f;
+        const float sv = a.scale ? a.scale[n] : 1.0f;
+        if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        if (a.rscale) v = a.rscale[m] * v;
+        const size_t o = (size_t)m * a.N + n;
+        if (a.res) v = a.res[o] + sv * v;
+        else if (a.scale) v = sv * v;
+        if (a.out) a.out[o] = v;
+        if (a.out2) {
+            const float sv2 = snake_f(v, a.sn_alpha[n % a.sn_mod], a.sn_invb[n % a.sn_mod]);
+            if (a.out2_s2) {
+                const int cw = a.sn_mod, jj = n / cw, c = n - jj * cw;
+                bf16_t* r16 = reinterpret_cast<bf16_t*>(a.out2 + (size_t)m * a.N) + (size_t)jj * 2 * cw;
+                split2(sv2, r16[c], r16[cw + c]);
+            } else {
+                a.out2[o] = sv2;
+            }
+        }
+    }
+}
+
 // ================================================================================================
 // small kernels
 // ================================================================================================
@@ -827,10 +946,18 @@ static thread_local int g_conv_planes = 3;
 // rows up to which the few-row GEMM variant (16-row tiles, wide K steps) is used: the flow's GEMMs have 56..450 rows and K <= 2048, their
 // time is the number of dependent K steps, not MFMA issue
 static thread_local int g_conv_skinny_rows = 48;
+// k_rows_gemm for eligible shapes: the flows only (their row bound is unbounded, so one kernel serves a shape at every batch size; the
+// codecs' and HiFT's few-row stages become many-row stages as the batch grows and must keep the staged kernels' summation order)
+static thread_local bool g_conv_rows_gemm = false;
 // few-row GEMMs walk K in 256-wide steps where Cin allows (half the dependent steps of the 128-wide walk; same accumulation order, so
 // the results are bit-identical).  VOX_SKINNY_BK256=0 keeps the 128-wide walk (A/B timing).
 static bool skinny_wide() {
     static const bool on = [] { const char* e = getenv("VOX_SKINNY_BK256"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// VOX_ROWS_GEMM=0: the LDS-staged few-row kernel instead of k_rows_gemm (A/B timing)
+static bool rows_gemm_on() {
+    static const bool on = [] { const char* e = getenv("VOX_ROWS_GEMM"); return !(e && e[0] == '0'); }();
     return on;
 }
 // VOX_CONV_TAPS=0: the per-tap staging kernel for every multi-tap conv (A/B timing)
@@ -857,6 +984,25 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     a.bias_mod = w.bias_mod > 0 ? w.bias_mod : w.n; a.gelu = gelu;
     if (out2 && sn) { a.out2 = out2; a.sn_alpha = sn->alpha; a.sn_invb = sn->inv_beta; a.sn_mod = sn_mod > 0 ? sn_mod : w.n; }
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
+    if (g_conv_rows_gemm && rows_gemm_on() && !x_s2 && a.M <= g_conv_skinny_rows && w.cin % 32 == 0 && (w.n_taps * w.cin) % 128 == 0 && (!ln_w || (w.n_taps == 1 && a.off[0] == 0))) {
+        // few rows: every operand requested up front, K split over the block's four waves (k_rows_gemm)
+        const int kb = w.n_taps * w.cin / 128;
+        const int tiles = ((w.n + 15) / 16) * ((a.M + 15) / 16);
+        int nt = tiles > 2048 ? 4 : tiles > 1024 ? 2 : 1;
+        while (nt > 1 && nt * kb > 16) nt >>= 1;
+        if (ln_w) { a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps; }
+        const dim3 g((w.n + 16 * nt - 1) / (16 * nt), (a.M + 15) / 16);
+#define VOX_ROWS(KB_, NT_)                                                                                         \
+        if (kb == KB_ && nt == NT_) {                                                                                  \
+            if (ln_w) hipLaunchKernelGGL((k_rows_gemm<KB_, NT_, true>), g, dim3(256), 0, st, a);                       \
+            else hipLaunchKernelGGL((k_rows_gemm<KB_, NT_, false>), g, dim3(256), 0, st, a);                           \
+            return VOX_OK;                                                                                             \
+        }
+        VOX_ROWS(2, 1) VOX_ROWS(2, 2) VOX_ROWS(2, 4) VOX_ROWS(4, 1) VOX_ROWS(4, 2) VOX_ROWS(4, 4) VOX_ROWS(6, 1) VOX_ROWS(6, 2)
+        VOX_ROWS(8, 1) VOX_ROWS(8, 2) VOX_ROWS(12, 1) VOX_ROWS(16, 1)
+#undef VOX_ROWS
+        a.ln_w = a.ln_b = nullptr;      // no variant for this K: the staged kernels below
+    }
     if (ln_w) {      // fused input LayerNorm: few-row kernel, one plain tap, the row statistics need the whole row in one K walk
         if (a.M > g_conv_skinny_rows || w.n_taps != 1 || a.off[0] != 0)
             return vox_fail(VOX_ERR_INVALID, "codec gemm: fused LayerNorm needs the few-row one-tap path");
@@ -2143,6 +2289,7 @@ int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, c
     const vox_hift_weights& w = m->w;
     hipStream_t st = (hipStream_t)stream;
     g_conv_planes = 3;
+    g_conv_skinny_rows = 48; g_conv_rows_gemm = false;
     const int H1 = c.nb_harmonics + 1, nb2 = c.n_fft + 2;
     const size_t L = (size_t)T * m->scale;
     float** B = m->buf;
@@ -2569,9 +2716,15 @@ void vox_flow_destroy(vox_flow* m) {
 
 }  // extern "C"
 
-#ifndef FLOW_SKINNY_ROWS
-#define FLOW_SKINNY_ROWS 512
-#endif
+// Rows up to which the flows' GEMMs take the few-row kernels (k_rows_gemm where the shape is eligible, the LDS-staged 16-row kernel
+// otherwise) and normalise inside them.  Unbounded by default: the few-row kernels tile any row count, and ONE kernel per shape at
+// every batch size is what keeps a request's mel independent of the batch it shares (k_rows_gemm sums its K quarters in a different
+// order than the staged kernels).  VOX_FLOW_ROWS=<n> restores a row bound (A/B timing).
+static int flow_skinny_rows() {
+    static const int v = [] { const char* e = getenv("VOX_FLOW_ROWS"); return e ? atoi(e) : (1 << 30); }();
+    return v;
+}
+#define FLOW_SKINNY_ROWS flow_skinny_rows()
 static const int FLOW_OFF0[4] = {0, 0, 0, 0};
 static const int FLOW_OFF_C3[3] = {2, 1, 0};            // causal k3
 static const int FLOW_OFF_C5[5] = {4, 3, 2, 1, 0};      // causal k5 (Upsample1D after its left pad of 4)
@@ -2624,7 +2777,8 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
     const int D = c.dim, M = c.mel, C = c.est_ch, T2 = 2 * T, H = c.enc_heads, dk = D / H, inner = c.est_heads * c.est_head_dim;
     float** Bf = m->buf;
     g_conv_planes = 3;
-    g_conv_skinny_rows = FLOW_SKINNY_ROWS;
+    struct RowsGuard { ~RowsGuard() { g_conv_skinny_rows = 48; g_conv_rows_gemm = false; } } rows_guard;      // also on the error returns
+    g_conv_skinny_rows = FLOW_SKINNY_ROWS; g_conv_rows_gemm = true;
     // ---- encoder ----
     float* x = Bf[3];
     hipLaunchKernelGGL(k_flow_embed, dim3(ew_grid((size_t)B * T * D)), dim3(256), 0, st, tokens, w.embedding, Bf[0], (size_t)B * T, D);
@@ -2736,7 +2890,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
         hipLaunchKernelGGL(k_flow_euler, dim3(ew_grid((size_t)B * T2 * M)), dim3(256), 0, st, xs, a2, B, T2, M, m->dt[s], c.cfg_rate);
     }
     if (init) m->att_len = T2 < capA ? T2 : capA;
-    g_conv_skinny_rows = 48;
+    g_conv_skinny_rows = 48; g_conv_rows_gemm = false;
     return VOX_OK;
 }
 
@@ -3108,7 +3262,7 @@ int vox_glmflow_create(vox_ctx* ctx, const vox_glmflow_config* cfg, const vox_gl
     if (!ok) { vox_glmflow_destroy(m); return vox_fail(VOX_ERR_NOMEM, "glmflow_create: hipMalloc failed"); }
     hipStream_t st = nullptr;
     g_conv_planes = 3;
-    g_conv_skinny_rows = 48;
+    g_conv_skinny_rows = 48; g_conv_rows_gemm = false;
     int rc = VOX_OK;
     (void)hipMemcpy(m->buf[0], time_emb, (size_t)c.n_steps * 4 * c.mel * 4, hipMemcpyHostToDevice);
     rc = conv_gemm(st, w->time1, m->buf[0], nullptr, nullptr, 1, c.n_steps, 0, FLOW_OFF0, m->buf[1], nullptr, nullptr, 0);
@@ -3136,7 +3290,8 @@ int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int 
     const int D = c.dim, M = c.mel, MP = c.mel_padded, C = c.est_ch, H = c.enc_heads, dk = D / H, HE = c.est_heads, hd = c.est_head_dim;
     float** Bf = m->buf;
     g_conv_planes = 3;
-    g_conv_skinny_rows = FLOW_SKINNY_ROWS;
+    struct RowsGuard { ~RowsGuard() { g_conv_skinny_rows = 48; g_conv_rows_gemm = false; } } rows_guard;      // also on the error returns
+    g_conv_skinny_rows = FLOW_SKINNY_ROWS; g_conv_rows_gemm = true;
     // speaker vector per request: spk_embed_affine_layer(normalize(embedding)); GLM-4-Voice passes zeros (glm.py:2647)
     hipLaunchKernelGGL(k_flow_l2norm_rows, dim3(n), dim3(256), 0, st, embedding, Bf[0], c.spk_dim);
     VOX_TRY(conv_gemm(st, w.spk, Bf[0], nullptr, nullptr, n, 1, 0, FLOW_OFF0, m->spk, nullptr, nullptr, 0));
@@ -3229,7 +3384,7 @@ int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int 
         VOX_TRY(conv_gemm(st, w.final_proj, a1, nullptr, nullptr, N, Tm, 0, FLOW_OFF0, a2, nullptr, nullptr, 0));
         hipLaunchKernelGGL(k_flow_euler, dim3(ew_grid((size_t)n * Tm * M)), dim3(256), 0, st, xs, a2, n, Tm, M, m->dt[s], c.cfg_rate);
     }
-    g_conv_skinny_rows = 48;
+    g_conv_skinny_rows = 48; g_conv_rows_gemm = false;
     hipLaunchKernelGGL(k_flow_to_bct, dim3(ew_grid((size_t)n * Tm * M)), dim3(256), 0, st, xs, mel, n, Tm, M);
     return VOX_OK;
 }
@@ -3423,7 +3578,7 @@ int vox_spkenc_embed(vox_spkenc* m, void* stream, const float* audio, int n_samp
     if (n_frames) *n_frames = T;
     hipStream_t st = (hipStream_t)stream;
     const int saved_planes = g_conv_planes, saved_skinny = g_conv_skinny_rows;
-    g_conv_planes = 3; g_conv_skinny_rows = 48;
+    g_conv_planes = 3; g_conv_skinny_rows = 48; g_conv_rows_gemm = false;
     const int MP = c.n_mels_padded, C = c.channels, M = c.mfa_channels, cw = C / c.scale;
     int off[CG_MAXTAPS];
     static const int off0[1] = {0};
@@ -3647,7 +3802,7 @@ int vox_codecenc_encode(vox_codecenc* m, void* stream, const float* audio, int n
     const vox_codecenc_weights& w = m->w;
     hipStream_t st = (hipStream_t)stream;
     const int saved_planes = g_conv_planes, saved_skinny = g_conv_skinny_rows;
-    g_conv_planes = 3; g_conv_skinny_rows = 48;
+    g_conv_planes = 3; g_conv_skinny_rows = 48; g_conv_rows_gemm = false;
     static const int off0[1] = {0}, off3[3] = {2, 1, 0}, off2[2] = {1, 0};
     float *x = m->A, *t1 = m->B, *t2 = m->C;
     int L = n_samples, ch = c.num_filters;
