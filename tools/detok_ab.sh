@@ -1,15 +1,17 @@
-# A/B of the few-row GEMM (k_rows_gemm vs the LDS-staged kernel; row bound of the flows) on the detokenizers (run through gpurun)
-cd $GRAFT_REPO_ROOT; O=gpurun_out/d3; mkdir -p $O
-(timeout 900 python -m pytest tests/test_gpu_flow.py tests/test_gpu_glm_decoder.py tests/test_gpu_hift.py tests/test_gpu_codec.py tests/test_gpu_snac.py tests/test_gpu_csm.py tests/test_gpu_spkenc.py tests/test_gpu_codec_encoder.py tests/test_gpu_worker.py -q -x 2>&1 | tail -15) > $O/parity.log
+# detokenizer parity + chunk timing (run through gpurun); env knobs for A/B: VOX_ROWS_GEMM, VOX_FLOW_ROWS, VOX_FLOW_ATTN_TILE
+cd $GRAFT_REPO_ROOT; O=gpurun_out/${DETOK_OUT:-d4}; mkdir -p $O
+(timeout 900 python -m pytest tests/test_gpu_flow.py tests/test_gpu_glm_decoder.py tests/test_gpu_hift.py tests/test_gpu_worker.py -q -x 2>&1 | tail -6) > $O/parity.log
 cat $O/parity.log
-for V in 1000000; do
-  VOX_FLOW_ROWS=$V timeout 600 python tools/bench_cosyvoice2.py --batch 8 > $O/cv_b8_r$V.json 2> $O/cv_b8_r$V.err
-  VOX_FLOW_ROWS=$V timeout 600 python tools/bench_glm.py --batch 8 --greedy --steps 150 > $O/glm_b8_r$V.json 2> $O/glm_b8_r$V.err
+for V in ${DETOK_AB:-0 1}; do
+  for b in 1 8; do
+  VOX_FLOW_ATTN_TILE=$V timeout 600 python tools/bench_cosyvoice2.py --batch $b > $O/cv_b${b}_$V.json 2> $O/cv_b${b}_$V.err
+  VOX_FLOW_ATTN_TILE=$V timeout 600 python tools/bench_glm.py --batch $b --greedy --steps 150 > $O/glm_b${b}_$V.json 2> $O/glm_b${b}_$V.err
+  done
 done
 python - <<PY
-import json
-for f in ["cv_b8_r512","cv_b8_r1000000","glm_b8_r512","glm_b8_r1000000"]:
+import json,glob
+for f in sorted(glob.glob("$O/*.json")):
     try:
-        d=json.loads(open("$O/%s.json"%f).read().strip().splitlines()[-1]); print(f, {k:v for k,v in d.items() if "ms" in k or "samples" in k})
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], {k:round(v,2) for k,v in d.items() if isinstance(v,float) and ("ms" in k or "samples" in k)})
     except Exception as e: print(f,"ERR",e)
 PY

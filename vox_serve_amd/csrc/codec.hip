@@ -2391,18 +2391,25 @@ __global__ __launch_bounds__(256) void k_flow_embed(const int* ids, const float*
 // y = act(LayerNorm(x) * w + b) * post + add[row / rows_per_req]      (act 0 none, 1 Mish)
 __global__ __launch_bounds__(256) void k_flow_ln(const float* x, const float* w, const float* b, float* y, int C, float eps, float post, int act,
                                                   const float* add, int rows_per_req, int rows) {
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;      // 16 rows per block, 16 lanes per row
+    // one wave per row (4 rows per block): each of the wave's four 16-lane groups computes the row statistics (ln_row_stats: the bits the
+    // fused-LayerNorm GEMMs get), then the 64 lanes apply them to one float4 chunk each per pass — a 112-row call is 28 blocks with 4 Mish
+    // evaluations per lane instead of 7 blocks with 16
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * C;
     float mean, rstd;
-    ln_row_stats(xr, C, l16, eps, mean, rstd);
+    ln_row_stats(xr, C, lane & 15, eps, mean, rstd);
     const float* ad = add ? add + (size_t)(row / rows_per_req) * C : nullptr;
-    for (int i = l16; i < C; i += 16) {
-        float o = (xr[i] - mean) * rstd * w[i] + b[i];
-        if (act == 1) o = mish_f(o);
-        o *= post;
-        if (ad) o += ad[i];
-        y[(size_t)row * C + i] = o;
+    for (int i = lane; i < C / 4; i += 64) {
+        const float4 xv = reinterpret_cast<const float4*>(xr)[i], wv = reinterpret_cast<const float4*>(w)[i], bv = reinterpret_cast<const float4*>(b)[i];
+        float o[4] = {(xv.x - mean) * rstd * wv.x + bv.x, (xv.y - mean) * rstd * wv.y + bv.y, (xv.z - mean) * rstd * wv.z + bv.z, (xv.w - mean) * rstd * wv.w + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (act == 1) o[e] = mish_f(o[e]);
+            o[e] *= post;
+        }
+        if (ad) { const float4 av = reinterpret_cast<const float4*>(ad)[i]; o[0] += av.x; o[1] += av.y; o[2] += av.z; o[3] += av.w; }
+        reinterpret_cast<float4*>(y + (size_t)row * C)[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 // in-place activation: 1 Mish, 2 SiLU, 3 leaky_relu(0.01)
@@ -2546,6 +2553,131 @@ __global__ __launch_bounds__(256) void k_flow_attn(FlowAttn a) {
         if (on && g == 0)
             *reinterpret_cast<float4*>(a.out + ((size_t)n * a.T + i) * HD + h * a.dk + c4) = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
     }
+}
+// The same attention for the calls without a relative-position term (the CFM estimators' transformer blocks: thousands of launches per
+// chunk), with the (request, head)'s keys and values staged ONCE per block in LDS: k_flow_attn has every wave stream all S key and value
+// rows from L2 for its one query (94 KB per query at S = 184, dk = 64: 84 MB of L2 reads per call at one request).  A block owns QG
+// consecutive queries, its four waves take them in turn; arithmetic and summation orders are k_flow_attn's, so the two kernels agree
+// bit for bit (which one a call takes may depend on its batch size; a request's output may not).  K rows are padded to DK + 4 floats:
+// lane = key reads of a float4 column then touch every bank once per 16 lanes.
+template <int DK>
+__global__ __launch_bounds__(256) void k_flow_attn_tile(FlowAttn a, int QG) {
+    extern __shared__ __attribute__((aligned(16))) float fa_sm[];
+    constexpr int KS = DK + 4, DK4 = DK / 4;
+    const int S = a.Tc + a.T, S4 = (S + 3) & ~3;
+    float* Ks = fa_sm;
+    float* Vs = Ks + (size_t)S * KS;
+    float* psm = Vs + (size_t)S * DK;
+    float* qsm = psm + 4 * S4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int h = blockIdx.y, n = blockIdx.z, i0 = blockIdx.x * QG;
+    const int HD = a.H * DK, ld = 3 * HD;
+    const float* cache = a.cache ? a.cache + (a.cidx ? (size_t)a.cidx[n] * a.cache_half_stride : a.B > 0 ? (size_t)(n / a.B) * a.cache_half_stride : 0) +
+                                       (size_t)h * a.Tcap * 2 * DK : nullptr;
+    for (int idx = tid; idx < S * DK4; idx += 256) {
+        const int j = idx / DK4, c = idx - j * DK4;
+        const float *kr, *vr;
+        if (j < a.Tc) {
+            kr = cache + (size_t)flow_cache_row(j, a.prefix, a.ring_head, a.Tcap) * 2 * DK;
+            vr = kr + DK;
+        } else {
+            kr = a.qkv + ((size_t)n * a.T + (j - a.Tc)) * ld + HD + h * DK;
+            vr = kr + HD;
+        }
+        *reinterpret_cast<float4*>(Ks + (size_t)j * KS + 4 * c) = reinterpret_cast<const float4*>(kr)[c];
+        *reinterpret_cast<float4*>(Vs + (size_t)j * DK + 4 * c) = reinterpret_cast<const float4*>(vr)[c];
+    }
+    __syncthreads();
+    float* ps = psm + wave * S4;
+    float* qs = qsm + wave * DK;
+    const int iend = (i0 + QG < a.T) ? i0 + QG : a.T;
+    for (int i = i0 + wave; i < iend; i += 4) {
+        const float* qrow = a.qkv + ((size_t)n * a.T + i) * ld + h * DK;
+        for (int d = lane; d < DK; d += 64) qs[d] = qrow[d] + (a.bu ? a.bu[h * DK + d] : 0.0f);
+        __builtin_amdgcn_wave_barrier();
+        float mx = -INFINITY;
+        const float4* q4 = reinterpret_cast<const float4*>(qs);
+        for (int j = lane; j < S; j += 64) {
+            const float4* kr = reinterpret_cast<const float4*>(Ks + (size_t)j * KS);
+            float ac = 0.0f;
+#pragma unroll
+            for (int d = 0; d < DK4; ++d) {
+                const float4 k = kr[d], q = q4[d];
+                ac = fmaf(q.x, k.x, ac); ac = fmaf(q.y, k.y, ac); ac = fmaf(q.z, k.z, ac); ac = fmaf(q.w, k.w, ac);
+            }
+            ac *= a.scale;
+            if (a.mask_block > 0 && j > i && j / a.mask_block != i / a.mask_block) ac = -INFINITY;
+            ps[j] = ac;
+            mx = fmaxf(mx, ac);
+        }
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float sum = 0.0f;
+        for (int j = lane; j < S; j += 64) {
+            const float p = expf(ps[j] - mx);
+            ps[j] = p;
+            sum += p;
+        }
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        __builtin_amdgcn_wave_barrier();
+        const float inv = 1.0f / sum;
+        // PV in k_flow_attn's order: lane = (key group g, float4 chunk c), keys g, g + 4, ... in four interleaved accumulators
+        for (int c4 = (lane & 15) * 4, slab = 0; slab < DK; slab += 64, c4 += 64) {
+            const int g = lane >> 4;
+            const bool on = c4 < DK;
+            float4 o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int j = g;
+            if (on) {
+                for (; j + 12 < S; j += 16) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(Vs + (size_t)(j + 4 * u) * DK + c4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float p = ps[j + 4 * u];
+                        o[u].x = fmaf(p, v[u].x, o[u].x); o[u].y = fmaf(p, v[u].y, o[u].y);
+                        o[u].z = fmaf(p, v[u].z, o[u].z); o[u].w = fmaf(p, v[u].w, o[u].w);
+                    }
+                }
+                for (; j < S; j += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(Vs + (size_t)j * DK + c4);
+                    const float p = ps[j];
+                    o[0].x = fmaf(p, v.x, o[0].x); o[0].y = fmaf(p, v.y, o[0].y); o[0].z = fmaf(p, v.z, o[0].z); o[0].w = fmaf(p, v.w, o[0].w);
+                }
+            }
+            float4 r = make_float4((o[0].x + o[1].x) + (o[2].x + o[3].x), (o[0].y + o[1].y) + (o[2].y + o[3].y),
+                                   (o[0].z + o[1].z) + (o[2].z + o[3].z), (o[0].w + o[1].w) + (o[2].w + o[3].w));
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                r.x += __shfl_xor(r.x, off, 64); r.y += __shfl_xor(r.y, off, 64); r.z += __shfl_xor(r.z, off, 64); r.w += __shfl_xor(r.w, off, 64);
+            }
+            if (on && g == 0)
+                *reinterpret_cast<float4*>(a.out + ((size_t)n * a.T + i) * HD + h * DK + c4) = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
+        }
+        __builtin_amdgcn_wave_barrier();      // ps / qs are rewritten by the wave's next query
+    }
+}
+// VOX_FLOW_ATTN_TILE=0: k_flow_attn for every call (A/B timing)
+static bool flow_attn_tile_on() {
+    static const bool on = [] { const char* e = getenv("VOX_FLOW_ATTN_TILE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+static void launch_flow_attn(hipStream_t st, const FlowAttn& a, int T, int H, int N) {
+    const int S = a.Tc + T;
+    const size_t lds = ((size_t)S * (2 * a.dk + 4) + 4 * ((S + 3) & ~3) + 4 * a.dk) * sizeof(float);
+    if (!a.P && a.dk == 64 && lds <= 150 * 1024 && flow_attn_tile_on()) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_flow_attn_tile<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr = true;
+        }
+        int qg = 4;      // queries per block: one per wave while the grid stays within ~2 blocks per CU, more per wave beyond
+        while ((T + qg - 1) / qg * H * N > 512 && qg < T) qg *= 2;
+        hipLaunchKernelGGL(k_flow_attn_tile<64>, dim3((T + qg - 1) / qg, H, N), dim3(256), lds, st, a, qg);
+        return;
+    }
+    hipLaunchKernelGGL(k_flow_attn, dim3((T + 3) / 4, H, N), dim3(256), 0, st, a);
 }
 // new K | V rows of request n -> cache [half = n][H][Tcap][2 dk], keeping the first `prefix` and the last Tcap - prefix of the T rows
 __global__ __launch_bounds__(256) void k_flow_cache_store(const float* qkv, float* cache, int T, int H, int dk, int Tcap, int prefix,
@@ -2737,7 +2869,7 @@ static int ln_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const fl
                    float* out, int gelu) {
     if (n * L <= g_conv_skinny_rows && w.n_taps == 1)
         return conv_gemm(st, w, x, nullptr, nullptr, n, L, 0, FLOW_OFF0, out, nullptr, nullptr, gelu, nullptr, nullptr, 0, nullptr, lw, lb, eps);
-    hipLaunchKernelGGL(k_flow_ln, dim3((n * L + 15) / 16), dim3(256), 0, st, x, lw, lb, scratch, w.cin, eps, 1.0f, 0, (const float*)nullptr, 1, n * L);
+    hipLaunchKernelGGL(k_flow_ln, dim3((n * L + 3) / 4), dim3(256), 0, st, x, lw, lb, scratch, w.cin, eps, 1.0f, 0, (const float*)nullptr, 1, n * L);
     return conv_gemm(st, w, scratch, nullptr, nullptr, n, L, 0, FLOW_OFF0, out, nullptr, nullptr, gelu);
 }
 // evolving mode (eidx != NULL): `cache` is layer l of the slot-major cache, request b reads and appends to block eidx[b] (stride
@@ -2753,7 +2885,7 @@ static int flow_conformer(vox_flow* m, hipStream_t st, const vox_flow_conformer_
     VOX_TRY(conv_gemm(st, w.pos, m->pe, nullptr, nullptr, 1, 2 * S - 1, 0, FLOW_OFF0, m->pp, nullptr, nullptr, 0));
     FlowAttn a{qkv, cache, m->pp, w.bias_u, w.bias_v, att, T, H, dk, Tc, Tcap, 0, eidx ? slot_stride : 0, 1.0f / sqrtf((float)dk)};
     a.cidx = eidx; a.prefix = store_prefix; a.ring_head = head;
-    hipLaunchKernelGGL(k_flow_attn, dim3((T + 3) / 4, H, n), dim3(256), 0, st, a);
+    launch_flow_attn(st, a, T, H, n);
     if (eidx)
         hipLaunchKernelGGL(k_flow_cache_append, dim3(ew_grid((size_t)n * H * T * 2 * dk)), dim3(256), 0, st, qkv, const_cast<float*>(cache), eidx,
                            slot_stride, T, H, dk, Tcap, store_prefix, Tc, head, n);
@@ -2783,7 +2915,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
     float* x = Bf[3];
     hipLaunchKernelGGL(k_flow_embed, dim3(ew_grid((size_t)B * T * D)), dim3(256), 0, st, tokens, w.embedding, Bf[0], (size_t)B * T, D);
     VOX_TRY(conv_gemm(st, w.embed_lin, Bf[0], nullptr, nullptr, B, T, 0, FLOW_OFF0, Bf[1], nullptr, nullptr, 0));
-    hipLaunchKernelGGL(k_flow_ln, dim3((B * T + 15) / 16), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, B * T);
+    hipLaunchKernelGGL(k_flow_ln, dim3((B * T + 3) / 4), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, B * T);
     // PreLookaheadLayer (empty context): conv k(pre+1) looking ahead, leaky_relu, causal conv k3, residual
     VOX_TRY(conv_gemm(st, w.pre1, x, nullptr, nullptr, B, T, 0, FLOW_OFF_LA, Bf[0], nullptr, nullptr, 0));
     hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)B * T * D)), dim3(256), 0, st, Bf[0], (size_t)B * T * D, 3);
@@ -2803,7 +2935,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
     hipLaunchKernelGGL(k_flow_repeat2, dim3(ew_grid((size_t)B * T2 * D)), dim3(256), 0, st, x, Bf[0], (size_t)B * T, D);
     VOX_TRY(conv_gemm(st, w.up_conv, Bf[0], nullptr, nullptr, B, T2, 0, FLOW_OFF_C5, Bf[1], nullptr, nullptr, 0));
     VOX_TRY(conv_gemm(st, w.up_embed_lin, Bf[1], nullptr, nullptr, B, T2, 0, FLOW_OFF0, Bf[0], nullptr, nullptr, 0));
-    hipLaunchKernelGGL(k_flow_ln, dim3((B * T2 + 15) / 16), dim3(256), 0, st, Bf[0], w.up_embed_ln_w, w.up_embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, B * T2);
+    hipLaunchKernelGGL(k_flow_ln, dim3((B * T2 + 3) / 4), dim3(256), 0, st, Bf[0], w.up_embed_ln_w, w.up_embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, B * T2);
     {
         const int Tc = init ? 0 : (evolve ? evolve->up_len : m->up_len), S = Tc + T2, cap = c.max_cache;
         hipLaunchKernelGGL(k_flow_relpos, dim3(ew_grid((size_t)(2 * S - 1) * D)), dim3(256), 0, st, m->pe, S, D);
@@ -2815,7 +2947,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
         }
         if (init) m->up_len = T2 < cap ? T2 : cap;
     }
-    hipLaunchKernelGGL(k_flow_ln, dim3((B * T2 + 15) / 16), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1, B * T2);
+    hipLaunchKernelGGL(k_flow_ln, dim3((B * T2 + 3) / 4), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1, B * T2);
     float* mu = Bf[8];
     VOX_TRY(conv_gemm(st, w.enc_proj, Bf[0], nullptr, nullptr, B, T2, 0, FLOW_OFF0, mu, nullptr, nullptr, 0));
     if (mu_out) (void)hipMemcpyAsync(mu_out, mu, (size_t)B * T2 * M * 4, hipMemcpyDeviceToDevice, st);
@@ -2851,12 +2983,12 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
             // block1: (cached) causal conv k3 -> LayerNorm -> Mish, + the time projection; block2 likewise; + res_conv(x)
             VOX_TRY(conv_gemm(st, rw.conv1, in, init ? nullptr : st1, crow, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
             if (evolve) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * cin)), dim3(256), 0, st, in, st1, N, T2, cin, crow);
-            hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 15) / 16), dim3(256), 0, st, a1, rw.ln1_w, rw.ln1_b, a2, C, 1e-5f, 1.0f, 1,
+            hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 3) / 4), dim3(256), 0, st, a1, rw.ln1_w, rw.ln1_b, a2, C, 1e-5f, 1.0f, 1,
                                m->tb + ((size_t)s * m->n_res + r) * C, N * T2, N * T2);
             if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * C)), dim3(256), 0, st, a2, st2, N, T2, C, (const int*)nullptr);
             VOX_TRY(conv_gemm(st, rw.conv2, a2, init ? nullptr : st2, crow, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
             if (evolve) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * C)), dim3(256), 0, st, a2, st2, N, T2, C, crow);
-            hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 15) / 16), dim3(256), 0, st, a1, rw.ln2_w, rw.ln2_b, a2, C, 1e-5f, 1.0f, 1, nullptr, 1, N * T2);
+            hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 3) / 4), dim3(256), 0, st, a1, rw.ln2_w, rw.ln2_b, a2, C, 1e-5f, 1.0f, 1, nullptr, 1, N * T2);
             VOX_TRY(conv_gemm(st, rw.res, in, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, a2, nullptr, 0));       // h = block2 + res_conv(in)
             for (int j = 0; j < c.est_blocks; ++j, ++li) {
                 const vox_flow_tblock_w& tw = m->tblocks[li];
@@ -2864,7 +2996,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
                 VOX_TRY(ln_gemm(st, tw.qkv, h, tw.ln1_w, tw.ln1_b, 1e-5f, a1, N, T2, a2, 0));
                 FlowAttn a{a2, init ? nullptr : kv, nullptr, nullptr, nullptr, a3, T2, HE, hd, Tc, capA, B, att_half, 1.0f / sqrtf((float)hd)};
                 if (evolve) { a.cidx = m->s_cidx; a.prefix = c.prefix; a.ring_head = evolve->att_head; }
-                hipLaunchKernelGGL(k_flow_attn, dim3((T2 + 3) / 4, HE, N), dim3(256), 0, st, a);
+                launch_flow_attn(st, a, T2, HE, N);
                 if (evolve)
                     hipLaunchKernelGGL(k_flow_cache_append, dim3(ew_grid((size_t)N * HE * T2 * 2 * hd)), dim3(256), 0, st, a2, kv, m->s_cidx, att_half,
                                        T2, HE, hd, capA, c.prefix, Tc, evolve->att_head, N);
@@ -2885,7 +3017,7 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
         }
         VOX_TRY(conv_gemm(st, w.up_conv2, in, nullptr, nullptr, N, T2, 0, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
         VOX_TRY(conv_gemm(st, w.final_conv, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF_C3, a2, nullptr, nullptr, 0));
-        hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 15) / 16), dim3(256), 0, st, a2, w.final_ln_w, w.final_ln_b, a1, C, 1e-5f, 1.0f, 1, nullptr, 1, N * T2);
+        hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 3) / 4), dim3(256), 0, st, a2, w.final_ln_w, w.final_ln_b, a1, C, 1e-5f, 1.0f, 1, nullptr, 1, N * T2);
         VOX_TRY(conv_gemm(st, w.final_proj, a1, nullptr, nullptr, N, T2, 0, FLOW_OFF0, a2, nullptr, nullptr, 0));
         hipLaunchKernelGGL(k_flow_euler, dim3(ew_grid((size_t)B * T2 * M)), dim3(256), 0, st, xs, a2, B, T2, M, m->dt[s], c.cfg_rate);
     }
@@ -3299,23 +3431,23 @@ int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int 
     float* x = Bf[3];
     hipLaunchKernelGGL(k_flow_embed, dim3(ew_grid((size_t)n * T * D)), dim3(256), 0, st, tokens, w.embedding, Bf[0], (size_t)n * T, D);
     VOX_TRY(conv_gemm(st, w.embed_lin, Bf[0], nullptr, nullptr, n, T, 0, FLOW_OFF0, Bf[1], nullptr, nullptr, 0));
-    hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 15) / 16), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, n * T);
+    hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 3) / 4), dim3(256), 0, st, Bf[1], w.embed_ln_w, w.embed_ln_b, x, D, 1e-5f, sqrtf((float)D), 0, nullptr, 1, n * T);
     hipLaunchKernelGGL(k_flow_relpos, dim3(ew_grid((size_t)(2 * T - 1) * D)), dim3(256), 0, st, m->pe, T, D);
     for (int l = 0; l < c.enc_layers; ++l) {
         const vox_flow_conformer_w& cw = m->enc[l];
         float *nrm = Bf[0], *qkv = Bf[1], *att = Bf[2];
-        hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 15) / 16), dim3(256), 0, st, x, cw.ln_mha_w, cw.ln_mha_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1, n * T);
+        hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 3) / 4), dim3(256), 0, st, x, cw.ln_mha_w, cw.ln_mha_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1, n * T);
         VOX_TRY(conv_gemm(st, cw.qkv, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
         VOX_TRY(conv_gemm(st, cw.pos, m->pe, nullptr, nullptr, 1, 2 * T - 1, 0, FLOW_OFF0, m->pp, nullptr, nullptr, 0));
         FlowAttn a{qkv, nullptr, m->pp, cw.bias_u, cw.bias_v, att, T, H, dk, 0, 0, 0, 0, 1.0f / sqrtf((float)dk), c.block_size};
-        hipLaunchKernelGGL(k_flow_attn, dim3((T + 3) / 4, H, n), dim3(256), 0, st, a);
+        launch_flow_attn(st, a, T, H, n);
         VOX_TRY(conv_gemm(st, cw.out, att, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
-        hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 15) / 16), dim3(256), 0, st, x, cw.ln_ff_w, cw.ln_ff_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1, n * T);
+        hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 3) / 4), dim3(256), 0, st, x, cw.ln_ff_w, cw.ln_ff_b, nrm, D, 1e-12f, 1.0f, 0, nullptr, 1, n * T);
         VOX_TRY(conv_gemm(st, cw.w1, nrm, nullptr, nullptr, n, T, 0, FLOW_OFF0, qkv, nullptr, nullptr, 0));
         hipLaunchKernelGGL(k_flow_act, dim3(ew_grid((size_t)n * T * c.enc_ffn)), dim3(256), 0, st, qkv, (size_t)n * T * c.enc_ffn, 2);
         VOX_TRY(conv_gemm(st, cw.w2, qkv, nullptr, nullptr, n, T, 0, FLOW_OFF0, x, x, nullptr, 0));
     }
-    hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 15) / 16), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1, n * T);
+    hipLaunchKernelGGL(k_flow_ln, dim3((n * T + 3) / 4), dim3(256), 0, st, x, w.after_w, w.after_b, Bf[0], D, 1e-5f, 1.0f, 0, nullptr, 1, n * T);
     VOX_TRY(conv_gemm(st, w.enc_proj, Bf[0], nullptr, nullptr, n, T, 0, FLOW_OFF0, Bf[1], nullptr, nullptr, 0));       // [n*T][MP] (pad columns 0)
     // ---- length regulator: nearest resampling to Tm frames, (conv k3, GroupNorm(1), Mish) x reg_layers, conv k1 ----
     hipLaunchKernelGGL(k_flow_interp, dim3(ew_grid((size_t)n * Tm * MP)), dim3(256), 0, st, Bf[1], Bf[0], n, T, Tm, MP);
@@ -3334,7 +3466,7 @@ int vox_glmflow_decode(vox_glmflow* m, void* stream, const int32_t* tokens, int 
             const vox_flow_tblock_w& tw = m->tblocks[li];
             VOX_TRY(ln_gemm(st, tw.qkv, h, tw.ln1_w, tw.ln1_b, 1e-5f, a1, N, rows_T, a2, 0));
             FlowAttn a{a2, nullptr, nullptr, nullptr, nullptr, a3, rows_T, HE, hd, 0, 0, 0, 0, 1.0f / sqrtf((float)hd), 0};
-            hipLaunchKernelGGL(k_flow_attn, dim3((rows_T + 3) / 4, HE, N), dim3(256), 0, st, a);
+            launch_flow_attn(st, a, rows_T, HE, N);
             VOX_TRY(conv_gemm(st, tw.out, a3, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, h, h, nullptr, 0));
             VOX_TRY(ln_gemm(st, tw.ff1, h, tw.ln3_w, tw.ln3_b, 1e-5f, a1, N, rows_T, a2, 1));
             VOX_TRY(conv_gemm(st, tw.ff2, a2, nullptr, nullptr, N, rows_T, 0, FLOW_OFF0, h, h, nullptr, 0));
