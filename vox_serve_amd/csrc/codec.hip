@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
 template <int KB, int NT, bool LN>
 __global__ __launch_bounds__(256) void k_rows_gemm(ConvGemmArgs a) {
     __shared__ float red[4][NT][256];
-    __shared__ float ln_stat[LN ? 32 : 1];
+    __shared__ float ln_stat[LN ? 128 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16 * NT;
@@ -576,13 +576,29 @@ __global__ __launch_bounds__(256) void k_rows_gemm(ConvGemmArgs a) {
         }
     }
     float mean = 0.0f, rstd = 0.0f;
-    if (LN) {      // wave w: rows 4w..4w+3 of the tile, 16 lanes per row; every wave then reads the statistics of its operand row
-        const int r = wave * 4 + kq, rm = m0 + r;
-        float mu = 0.0f, rs = 0.0f;
-        if (rm < a.M) ln_row_stats(a.x + (size_t)rm * a.Cin, a.Cin, fr, a.ln_eps, mu, rs);
-        if (fr == 0) { ln_stat[2 * r] = mu; ln_stat[2 * r + 1] = rs; }
+    if (LN) {
+        // Row statistics from the operand registers (one tap: the block's 4 KB k-blocks are exactly the row): lane (fr, kq) of wave w
+        // holds 8 KB values of row fr; two passes (mean, then centred squares), each = lane sum -> the row's four k groups by two
+        // butterfly steps -> the four waves in the fixed order w0 + w1 + w2 + w3.  No second trip to memory for the centred pass.
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+            s += ((av[j][0].x + av[j][0].y) + (av[j][0].z + av[j][0].w)) + ((av[j][1].x + av[j][1].y) + (av[j][1].z + av[j][1].w));
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        if (kq == 0) ln_stat[wave * 16 + fr] = s;
         __syncthreads();
-        mean = ln_stat[2 * fr]; rstd = ln_stat[2 * fr + 1];
+        mean = (((ln_stat[fr] + ln_stat[16 + fr]) + ln_stat[32 + fr]) + ln_stat[48 + fr]) / (float)a.Cin;
+        float vs = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const float d0 = av[j][0].x - mean, d1 = av[j][0].y - mean, d2 = av[j][0].z - mean, d3 = av[j][0].w - mean;
+            const float d4 = av[j][1].x - mean, d5 = av[j][1].y - mean, d6 = av[j][1].z - mean, d7 = av[j][1].w - mean;
+            vs += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+        }
+        vs += __shfl_xor(vs, 16, 64); vs += __shfl_xor(vs, 32, 64);
+        if (kq == 0) ln_stat[64 + wave * 16 + fr] = vs;
+        __syncthreads();
+        rstd = rsqrtf((((ln_stat[64 + fr] + ln_stat[80 + fr]) + ln_stat[96 + fr]) + ln_stat[112 + fr]) / (float)a.Cin + a.ln_eps);
     }
     f32x4 acc[NT];
 #pragma unroll
@@ -2658,6 +2674,142 @@ __global__ __launch_bounds__(256) void k_flow_attn_tile(FlowAttn a, int QG) {
         __builtin_amdgcn_wave_barrier();      // ps / qs are rewritten by the wave's next query
     }
 }
+// The estimators' attention on the matrix cores (no relative-position term, dk = 64, at most 256 keys: every CosyVoice2 / GLM estimator
+// call).  A block owns 16 consecutive queries of one (request, head); its four waves take the 16-key tiles w, w + 4, w + 8, w + 12 for
+// BOTH products, so nothing but the row maxima, the row sums and the 16 x 64 partial outputs crosses a wave:
+//   scores  = Q K^T   v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulate), 16 per key tile; every operand is requested up front
+//                     straight in operand layout (lane = (row l % 16, k group l / 16) holds four float4 chunks 16 c + 4 (l / 16) of its
+//                     row: the contraction index is permuted the same way on both sides, which a dot product does not see)
+//   softmax           row maximum by a 16-lane butterfly + one LDS exchange across the waves; p = exp(s - max)
+//   out     = P V     p goes through a wave-private LDS tile to become an A operand; V rows are float4 loads whose four components
+//                     are the four 16-dim output tiles (dim = 4 (l % 16) + tile), so a lane's four accumulators are one float4 of the row
+// and the four partial outputs are summed in the fixed order w0 + w1 + w2 + w3 and scaled by 1 / sum.  A (request, head, query)'s
+// result depends on that request's rows only.
+template <int DK>
+__global__ __launch_bounds__(256) void k_flow_attn_mfma(FlowAttn a) {
+    static_assert(DK == 64, "operand layout below is written for 64-dim heads");
+    constexpr int KT = 4, PS = KT * 16 + 4, OS = DK + 4;
+    __shared__ float red_mx[4][16], red_sum[4][16];
+    __shared__ __attribute__((aligned(16))) float Ps[4][16][PS];
+    __shared__ __attribute__((aligned(16))) float Os[4][16][OS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.x * 16, h = blockIdx.y, n = blockIdx.z;
+    const int HD = a.H * DK, ld = 3 * HD, S = a.Tc + a.T, nt = (S + 15) >> 4;
+    const float* cache = a.cache ? a.cache + (a.cidx ? (size_t)a.cidx[n] * a.cache_half_stride : a.B > 0 ? (size_t)(n / a.B) * a.cache_half_stride : 0) +
+                                       (size_t)h * a.Tcap * 2 * DK : nullptr;
+    auto krow = [&](int j) -> const float* {      // K row of key j (its V row: + DK in the cache, + HD in qkv)
+        return j < a.Tc ? cache + (size_t)flow_cache_row(j, a.prefix, a.ring_head, a.Tcap) * 2 * DK
+                        : a.qkv + ((size_t)n * a.T + (j - a.Tc)) * ld + HD + h * DK;
+    };
+    const int iq = i0 + fr < a.T ? i0 + fr : a.T - 1;
+    const float* qrow = a.qkv + ((size_t)n * a.T + iq) * ld + h * DK + 4 * kq;
+    float4 q[4], k[KT][4], v[KT][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q[c] = *reinterpret_cast<const float4*>(qrow + 16 * c);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int kt = t * 4 + wave;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { k[t][c] = make_float4(0.f, 0.f, 0.f, 0.f); v[t][c] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (kt < nt) {
+            const int j = kt * 16 + fr;
+            if (j < S) {
+                const float* kr = krow(j) + 4 * kq;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) k[t][c] = *reinterpret_cast<const float4*>(kr + 16 * c);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {      // B operand of P V: key 16 kt + 4 s4 + kq, dims 4 fr .. 4 fr + 3
+                const int jv = kt * 16 + 4 * s4 + kq;
+                if (jv < S) v[t][s4] = *reinterpret_cast<const float4*>(krow(jv) + (jv < a.Tc ? DK : HD) + 4 * fr);
+            }
+        }
+    }
+    f32x4 sc[KT];
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int kt = t * 4 + wave;
+        sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kt < nt) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].x, k[t][c].x, sc[t], 0, 0, 0);
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].y, k[t][c].y, sc[t], 0, 0, 0);
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].z, k[t][c].z, sc[t], 0, 0, 0);
+                sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[c].w, k[t][c].w, sc[t], 0, 0, 0);
+            }
+        }
+        const int j = kt * 16 + fr;      // accumulator r: query i0 + 4 kq + r, key j
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * kq + r;
+            float s = sc[t][r] * a.scale;
+            if (kt >= nt || j >= S || (a.mask_block > 0 && j > i && j / a.mask_block != i / a.mask_block)) s = -INFINITY;
+            sc[t][r] = s;
+            mx[r] = fmaxf(mx[r], s);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], off, 64));
+        if (fr == 0) red_mx[wave][4 * kq + r] = mx[r];
+    }
+    __syncthreads();
+    float sum[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = 4 * kq + r;
+        const float gm = fmaxf(fmaxf(red_mx[0][qi], red_mx[1][qi]), fmaxf(red_mx[2][qi], red_mx[3][qi]));
+        float sm = 0.0f;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const float p = sc[t][r] == -INFINITY ? 0.0f : expf(sc[t][r] - gm);
+            Ps[wave][qi][16 * t + fr] = p;
+            sm += p;
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) sm += __shfl_xor(sm, off, 64);
+        sum[r] = sm;
+        if (fr == 0) red_sum[wave][qi] = sm;
+    }
+    __builtin_amdgcn_wave_barrier();      // the wave's own p tile: written in accumulator layout, read back as A operands
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        if (t * 4 + wave < nt) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float pa = Ps[wave][fr][16 * t + 4 * s4 + kq];
+                o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, v[t][s4].x, o[0], 0, 0, 0);
+                o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, v[t][s4].y, o[1], 0, 0, 0);
+                o[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, v[t][s4].z, o[2], 0, 0, 0);
+                o[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, v[t][s4].w, o[3], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)      // o[d][r] = out[query 4 kq + r][dim 4 fr + d]
+        *reinterpret_cast<float4*>(&Os[wave][4 * kq + r][4 * fr]) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+    __syncthreads();
+    const int qi = tid >> 4, c4 = (tid & 15) * 4;
+    if (i0 + qi < a.T) {
+        const float inv = 1.0f / (((red_sum[0][qi] + red_sum[1][qi]) + red_sum[2][qi]) + red_sum[3][qi]);
+        const float4 p0 = *reinterpret_cast<const float4*>(&Os[0][qi][c4]), p1 = *reinterpret_cast<const float4*>(&Os[1][qi][c4]);
+        const float4 p2 = *reinterpret_cast<const float4*>(&Os[2][qi][c4]), p3 = *reinterpret_cast<const float4*>(&Os[3][qi][c4]);
+        *reinterpret_cast<float4*>(a.out + ((size_t)n * a.T + i0 + qi) * HD + h * DK + c4) =
+            make_float4((((p0.x + p1.x) + p2.x) + p3.x) * inv, (((p0.y + p1.y) + p2.y) + p3.y) * inv,
+                        (((p0.z + p1.z) + p2.z) + p3.z) * inv, (((p0.w + p1.w) + p2.w) + p3.w) * inv);
+    }
+}
+// VOX_FLOW_ATTN_MFMA=0: the VALU attention kernels for every call (A/B timing)
+static bool flow_attn_mfma_on() {
+    static const bool on = [] { const char* e = getenv("VOX_FLOW_ATTN_MFMA"); return !(e && e[0] == '0'); }();
+    return on;
+}
 // VOX_FLOW_ATTN_TILE=0: k_flow_attn for every call (A/B timing)
 static bool flow_attn_tile_on() {
     static const bool on = [] { const char* e = getenv("VOX_FLOW_ATTN_TILE"); return !(e && e[0] == '0'); }();
@@ -2666,6 +2818,10 @@ static bool flow_attn_tile_on() {
 static void launch_flow_attn(hipStream_t st, const FlowAttn& a, int T, int H, int N) {
     const int S = a.Tc + T;
     const size_t lds = ((size_t)S * (2 * a.dk + 4) + 4 * ((S + 3) & ~3) + 4 * a.dk) * sizeof(float);
+    if (!a.P && !a.bu && a.dk == 64 && S <= 256 && flow_attn_mfma_on()) {
+        hipLaunchKernelGGL(k_flow_attn_mfma<64>, dim3((T + 15) / 16, H, N), dim3(256), 0, st, a);
+        return;
+    }
     if (!a.P && a.dk == 64 && lds <= 150 * 1024 && flow_attn_tile_on()) {
         static bool attr = false;
         if (!attr) {
