@@ -530,39 +530,44 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
     }
 }
 
-// Few-row GEMM with no dependent K steps ("rows" kernel; the flow detokenizers' 56..512-row linears and causal convs: thousands of
-// launches per chunk whose time is exposed memory latency, not arithmetic).  A block owns 16 rows x 16*NT columns; its four waves split
-// the n_taps * Cin reduction into quarters of KB 32-wide k-blocks and each lane requests ALL its operands up front, straight in the
+// Few-row GEMM with no dependent K steps ("rows" kernel; the flow detokenizers' 56..2752-row linears and causal convs: thousands of
+// launches per chunk whose time is exposed memory latency, not arithmetic).  A block owns 16 MT rows x 16 NT columns; its WV waves split
+// the n_taps * Cin reduction into WV runs of KB 32-wide k-blocks and each lane requests ALL its operands up front, straight in the
 // layout an MFMA operand register holds (A: 8 consecutive fp32 of row lane % 16; B: 8 consecutive bf16 of weight row lane % 16) — one
-// exposed round trip per launch, no LDS staging, no barrier until the cross-wave sum (fixed order w0 + w1 + w2 + w3).  With the fused
-// LayerNorm the row statistics come from ln_row_stats (the same bits as k_flow_ln) while the operands are in flight.  A row's result
-// depends on that row only, so a request's output does not depend on what else shares its batch.
-template <int KB, int NT, bool LN>
-__global__ __launch_bounds__(256) void k_rows_gemm(ConvGemmArgs a) {
-    __shared__ float red[4][NT][256];
-    __shared__ float ln_stat[LN ? 128 : 1];
+// exposed round trip per launch, no LDS staging, no barrier until the cross-wave sum (fixed order w0 + w1 + ... ).  With the fused
+// LayerNorm the row statistics come from the operand registers while the weights are in flight.  A row's result depends on that row only
+// and on (K, WV) — never on MT / NT, which the launcher picks from the row count: more rows per block when the call is large enough
+// that the operand traffic from L2 (12 KB per 16 x 16 output tile at MT = 1, NT = 4, K = 256) is what bounds it.  WV is a function of K
+// alone (8 waves from K = 512 on: half the serial work per wave), so a request's output does not depend on what shares its batch.
+template <int KB, int NT, bool LN, int MT, int WV>
+__global__ __launch_bounds__(64 * WV) void k_rows_gemm(ConvGemmArgs a) {
+    __shared__ float red[WV][MT * NT][256];
+    __shared__ float ln_stat[LN ? 2 * WV * 16 * MT : 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16 * NT;
+    const int m0 = blockIdx.y * 16 * MT, n0 = blockIdx.x * 16 * NT;
     const int kpt = a.Cin >> 5;                     // k-blocks per tap
-    const int am = m0 + fr;
-    float4 av[KB][2];
+    float4 av[MT][KB][2];
     uint4 bv[NT][KB];
     float4 lw[LN ? KB : 1][2], lb[LN ? KB : 1][2];
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
         const int kbi = wave * KB + j, tap = kbi / kpt, c0 = (kbi - tap * kpt) * 32 + kq * 8;
-        const float* arow = nullptr;
-        if (am < a.M) {
-            const int ab = am / a.L, st = am % a.L - a.off[tap];
-            if (st >= a.L) arow = nullptr;
-            else if (st >= 0) arow = a.x + ((size_t)ab * a.L + st) * a.Cin;
-            else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[ab] * a.P + (a.P + st)) * a.Cin;
-        }
-        av[j][0] = av[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (arow) {
-            av[j][0] = *reinterpret_cast<const float4*>(arow + c0);
-            av[j][1] = *reinterpret_cast<const float4*>(arow + c0 + 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int am = m0 + mt * 16 + fr;
+            const float* arow = nullptr;
+            if (am < a.M) {
+                const int ab = am / a.L, st = am % a.L - a.off[tap];
+                if (st >= a.L) arow = nullptr;
+                else if (st >= 0) arow = a.x + ((size_t)ab * a.L + st) * a.Cin;
+                else if (a.state && a.P + st >= 0) arow = a.state + ((size_t)a.slots[ab] * a.P + (a.P + st)) * a.Cin;
+            }
+            av[mt][j][0] = av[mt][j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (arow) {
+                av[mt][j][0] = *reinterpret_cast<const float4*>(arow + c0);
+                av[mt][j][1] = *reinterpret_cast<const float4*>(arow + c0 + 4);
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -575,75 +580,101 @@ __global__ __launch_bounds__(256) void k_rows_gemm(ConvGemmArgs a) {
             lb[j][0] = *reinterpret_cast<const float4*>(a.ln_b + c0); lb[j][1] = *reinterpret_cast<const float4*>(a.ln_b + c0 + 4);
         }
     }
-    float mean = 0.0f, rstd = 0.0f;
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) mean[mt] = rstd[mt] = 0.0f;
     if (LN) {
-        // Row statistics from the operand registers (one tap: the block's 4 KB k-blocks are exactly the row): lane (fr, kq) of wave w
+        // Row statistics from the operand registers (one tap: the block's WV KB k-blocks are exactly the row): lane (fr, kq) of wave w
         // holds 8 KB values of row fr; two passes (mean, then centred squares), each = lane sum -> the row's four k groups by two
-        // butterfly steps -> the four waves in the fixed order w0 + w1 + w2 + w3.  No second trip to memory for the centred pass.
-        float s = 0.0f;
+        // butterfly steps -> the waves in the fixed order w0 + w1 + ...  No second trip to memory for the centred pass.
 #pragma unroll
-        for (int j = 0; j < KB; ++j)
-            s += ((av[j][0].x + av[j][0].y) + (av[j][0].z + av[j][0].w)) + ((av[j][1].x + av[j][1].y) + (av[j][1].z + av[j][1].w));
-        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-        if (kq == 0) ln_stat[wave * 16 + fr] = s;
-        __syncthreads();
-        mean = (((ln_stat[fr] + ln_stat[16 + fr]) + ln_stat[32 + fr]) + ln_stat[48 + fr]) / (float)a.Cin;
-        float vs = 0.0f;
+        for (int mt = 0; mt < MT; ++mt) {
+            float s = 0.0f;
 #pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const float d0 = av[j][0].x - mean, d1 = av[j][0].y - mean, d2 = av[j][0].z - mean, d3 = av[j][0].w - mean;
-            const float d4 = av[j][1].x - mean, d5 = av[j][1].y - mean, d6 = av[j][1].z - mean, d7 = av[j][1].w - mean;
-            vs += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+            for (int j = 0; j < KB; ++j)
+                s += ((av[mt][j][0].x + av[mt][j][0].y) + (av[mt][j][0].z + av[mt][j][0].w)) + ((av[mt][j][1].x + av[mt][j][1].y) + (av[mt][j][1].z + av[mt][j][1].w));
+            s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+            if (kq == 0) ln_stat[(mt * WV + wave) * 16 + fr] = s;
         }
-        vs += __shfl_xor(vs, 16, 64); vs += __shfl_xor(vs, 32, 64);
-        if (kq == 0) ln_stat[64 + wave * 16 + fr] = vs;
         __syncthreads();
-        rstd = rsqrtf((((ln_stat[64 + fr] + ln_stat[80 + fr]) + ln_stat[96 + fr]) + ln_stat[112 + fr]) / (float)a.Cin + a.ln_eps);
-    }
-    f32x4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) {
+            float tot = ln_stat[mt * WV * 16 + fr];
+#pragma unroll
+            for (int w = 1; w < WV; ++w) tot += ln_stat[(mt * WV + w) * 16 + fr];
+            mean[mt] = tot / (float)a.Cin;
+            float vs = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const float d0 = av[mt][j][0].x - mean[mt], d1 = av[mt][j][0].y - mean[mt], d2 = av[mt][j][0].z - mean[mt], d3 = av[mt][j][0].w - mean[mt];
+                const float d4 = av[mt][j][1].x - mean[mt], d5 = av[mt][j][1].y - mean[mt], d6 = av[mt][j][1].z - mean[mt], d7 = av[mt][j][1].w - mean[mt];
+                vs += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+            }
+            vs += __shfl_xor(vs, 16, 64); vs += __shfl_xor(vs, 32, 64);
+            if (kq == 0) ln_stat[(MT * WV + mt * WV + wave) * 16 + fr] = vs;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float tot = ln_stat[(MT * WV + mt * WV) * 16 + fr];
+#pragma unroll
+            for (int w = 1; w < WV; ++w) tot += ln_stat[(MT * WV + mt * WV + w) * 16 + fr];
+            rstd[mt] = rsqrtf(tot / (float)a.Cin + a.ln_eps);
+        }
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
-        float x8[8] = {av[j][0].x, av[j][0].y, av[j][0].z, av[j][0].w, av[j][1].x, av[j][1].y, av[j][1].z, av[j][1].w};
-        if (LN) {
-            const float w8[8] = {lw[j][0].x, lw[j][0].y, lw[j][0].z, lw[j][0].w, lw[j][1].x, lw[j][1].y, lw[j][1].z, lw[j][1].w};
-            const float b8[8] = {lb[j][0].x, lb[j][0].y, lb[j][0].z, lb[j][0].w, lb[j][1].x, lb[j][1].y, lb[j][1].z, lb[j][1].w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) x8[e] = (x8[e] - mean) * rstd * w8[e] + b8[e];
-        }
-        unsigned short hb[8], mb[8], lbb[8];
+        for (int mt = 0; mt < MT; ++mt) {
+            float x8[8] = {av[mt][j][0].x, av[mt][j][0].y, av[mt][j][0].z, av[mt][j][0].w, av[mt][j][1].x, av[mt][j][1].y, av[mt][j][1].z, av[mt][j][1].w};
+            if (LN) {
+                const float w8[8] = {lw[j][0].x, lw[j][0].y, lw[j][0].z, lw[j][0].w, lw[j][1].x, lw[j][1].y, lw[j][1].z, lw[j][1].w};
+                const float b8[8] = {lb[j][0].x, lb[j][0].y, lb[j][0].z, lb[j][0].w, lb[j][1].x, lb[j][1].y, lb[j][1].z, lb[j][1].w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            hb[e] = f2bf(x8[e]);
-            const float r1 = x8[e] - bf2f(hb[e]);
-            mb[e] = f2bf(r1);
-            lbb[e] = f2bf(r1 - bf2f(mb[e]));
-        }
-        const uint4 ah = make_uint4(hb[0] | (unsigned)hb[1] << 16, hb[2] | (unsigned)hb[3] << 16, hb[4] | (unsigned)hb[5] << 16, hb[6] | (unsigned)hb[7] << 16);
-        const uint4 amid = make_uint4(mb[0] | (unsigned)mb[1] << 16, mb[2] | (unsigned)mb[3] << 16, mb[4] | (unsigned)mb[5] << 16, mb[6] | (unsigned)mb[7] << 16);
-        const uint4 al = make_uint4(lbb[0] | (unsigned)lbb[1] << 16, lbb[2] | (unsigned)lbb[3] << 16, lbb[4] | (unsigned)lbb[5] << 16, lbb[6] | (unsigned)lbb[7] << 16);
+                for (int e = 0; e < 8; ++e) x8[e] = (x8[e] - mean[mt]) * rstd[mt] * w8[e] + b8[e];
+            }
+            unsigned short hb[8], mb[8], lbb[8];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {      // plane order of the staged kernels: low terms first
-            if (a.planes >= 3) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(al), as_cbf8(bv[t][j]), acc[t], 0, 0, 0);
-            if (a.planes >= 2) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(amid), as_cbf8(bv[t][j]), acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(ah), as_cbf8(bv[t][j]), acc[t], 0, 0, 0);
+            for (int e = 0; e < 8; ++e) {
+                hb[e] = f2bf(x8[e]);
+                const float r1 = x8[e] - bf2f(hb[e]);
+                mb[e] = f2bf(r1);
+                lbb[e] = f2bf(r1 - bf2f(mb[e]));
+            }
+            const uint4 ah = make_uint4(hb[0] | (unsigned)hb[1] << 16, hb[2] | (unsigned)hb[3] << 16, hb[4] | (unsigned)hb[5] << 16, hb[6] | (unsigned)hb[7] << 16);
+            const uint4 amid = make_uint4(mb[0] | (unsigned)mb[1] << 16, mb[2] | (unsigned)mb[3] << 16, mb[4] | (unsigned)mb[5] << 16, mb[6] | (unsigned)mb[7] << 16);
+            const uint4 al = make_uint4(lbb[0] | (unsigned)lbb[1] << 16, lbb[2] | (unsigned)lbb[3] << 16, lbb[4] | (unsigned)lbb[5] << 16, lbb[6] | (unsigned)lbb[7] << 16);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {      // plane order of the staged kernels: low terms first
+                if (a.planes >= 3) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(al), as_cbf8(bv[t][j]), acc[mt][t], 0, 0, 0);
+                if (a.planes >= 2) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(amid), as_cbf8(bv[t][j]), acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(ah), as_cbf8(bv[t][j]), acc[mt][t], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][t][r * 64 + lane] = acc[t][r];
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][mt * NT + t][r * 64 + lane] = acc[mt][t][r];
     __syncthreads();
-    // wave w finishes accumulator component w of every tile: row m0 + 4 * (lane / 16) + w, column n0 + 16 t + lane % 16
-    const int m = m0 + kq * 4 + wave;
-    if (m >= a.M) return;
+    // work item e = (tile, accumulator component r): row m0 + 16 mt + 4 (lane / 16) + r, column n0 + 16 t + lane % 16; wave w takes
+    // the items w, w + WV, ...
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = n0 + t * 16 + fr;
-        if (n >= a.N) continue;
-        const int e = wave * 64 + lane;
-        float v = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
+    for (int e = wave; e < MT * NT * 4; e += WV) {
+        const int tile = e >> 2, r = e & 3, mt = tile / NT, t = tile - mt * NT;
+        const int m = m0 + mt * 16 + kq * 4 + r, n = n0 + t * 16 + fr;
+        if (m >= a.M || n >= a.N) continue;
+        const int idx = r * 64 + lane;
+        float v = red[0][tile][idx];
+#pragma unroll
+        for (int w = 1; w < WV; ++w) v += red[w][tile][idx];
         v += a.bias ? a.bias[n % a.bias_mod] : 0.0f;
         const float sv = a.scale ? a.scale[n] : 1.0f;
         if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -976,6 +1007,16 @@ static bool rows_gemm_on() {
     static const bool on = [] { const char* e = getenv("VOX_ROWS_GEMM"); return !(e && e[0] == '0'); }();
     return on;
 }
+// VOX_ROWS_WV8=0: four waves per k_rows_gemm block at every K (A/B timing; changes the summation order of the K >= 512 linears)
+static bool rows_wv8_on() {
+    static const bool on = [] { const char* e = getenv("VOX_ROWS_WV8"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// blocks from which k_rows_gemm takes two 16-row tiles per block (VOX_ROWS_MT2=<blocks>; 0 = never)
+static int rows_mt2_blocks() {
+    static const int v = [] { const char* e = getenv("VOX_ROWS_MT2"); const int x = e ? atoi(e) : 1024; return x > 0 ? x : (1 << 30); }();
+    return v;
+}
 // VOX_CONV_TAPS=0: the per-tap staging kernel for every multi-tap conv (A/B timing)
 static bool conv_taps_on() {
     static const bool on = [] { const char* e = getenv("VOX_CONV_TAPS"); return !(e && e[0] == '0'); }();
@@ -1001,22 +1042,27 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     if (out2 && sn) { a.out2 = out2; a.sn_alpha = sn->alpha; a.sn_invb = sn->inv_beta; a.sn_mod = sn_mod > 0 ? sn_mod : w.n; }
     for (int k = 0; k < w.n_taps; ++k) a.off[k] = offs ? offs[k] : 0;
     if (g_conv_rows_gemm && rows_gemm_on() && !x_s2 && a.M <= g_conv_skinny_rows && w.cin % 32 == 0 && (w.n_taps * w.cin) % 128 == 0 && (!ln_w || (w.n_taps == 1 && a.off[0] == 0))) {
-        // few rows: every operand requested up front, K split over the block's four waves (k_rows_gemm)
-        const int kb = w.n_taps * w.cin / 128;
+        // every operand requested up front, K split over the block's waves (k_rows_gemm): 8 waves from K = 512 on
+        const int K = w.n_taps * w.cin, wv = (K >= 512 && K % 256 == 0 && rows_wv8_on()) ? 8 : 4, kb = K / (32 * wv);
         const int tiles = ((w.n + 15) / 16) * ((a.M + 15) / 16);
         int nt = tiles > 2048 ? 4 : tiles > 1024 ? 2 : 1;
         while (nt > 1 && nt * kb > 16) nt >>= 1;
+        const int mt = (tiles / nt >= rows_mt2_blocks() && kb <= 4 && (wv == 4 || nt <= 2)) ? 2 : 1;      // (the 8-wave sum buffer: MT NT <= 4)
         if (ln_w) { a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps; }
-        const dim3 g((w.n + 16 * nt - 1) / (16 * nt), (a.M + 15) / 16);
-#define VOX_ROWS(KB_, NT_)                                                                                         \
-        if (kb == KB_ && nt == NT_) {                                                                                  \
-            if (ln_w) hipLaunchKernelGGL((k_rows_gemm<KB_, NT_, true>), g, dim3(256), 0, st, a);                       \
-            else hipLaunchKernelGGL((k_rows_gemm<KB_, NT_, false>), g, dim3(256), 0, st, a);                           \
+        const dim3 g((w.n + 16 * nt - 1) / (16 * nt), (a.M + 16 * mt - 1) / (16 * mt));
+#define VOX_ROWS1(KB_, NT_, MT_, WV_)                                                                              \
+        if (kb == KB_ && nt == NT_ && mt == MT_ && wv == WV_) {                                                        \
+            if (ln_w) hipLaunchKernelGGL((k_rows_gemm<KB_, NT_, true, MT_, WV_>), g, dim3(64 * WV_), 0, st, a);        \
+            else hipLaunchKernelGGL((k_rows_gemm<KB_, NT_, false, MT_, WV_>), g, dim3(64 * WV_), 0, st, a);            \
             return VOX_OK;                                                                                             \
         }
-        VOX_ROWS(2, 1) VOX_ROWS(2, 2) VOX_ROWS(2, 4) VOX_ROWS(4, 1) VOX_ROWS(4, 2) VOX_ROWS(4, 4) VOX_ROWS(6, 1) VOX_ROWS(6, 2)
-        VOX_ROWS(8, 1) VOX_ROWS(8, 2) VOX_ROWS(12, 1) VOX_ROWS(16, 1)
+#define VOX_ROWS(KB_, WV_) VOX_ROWS1(KB_, 1, 1, WV_) VOX_ROWS1(KB_, 2, 1, WV_) VOX_ROWS1(KB_, 4, 1, WV_) VOX_ROWS1(KB_, 1, 2, WV_) \
+                           VOX_ROWS1(KB_, 2, 2, WV_)
+        VOX_ROWS(2, 4) VOX_ROWS(4, 4) VOX_ROWS(2, 8) VOX_ROWS(3, 8) VOX_ROWS(4, 8) VOX_ROWS1(2, 4, 2, 4) VOX_ROWS1(4, 4, 2, 4)
+        VOX_ROWS1(6, 1, 1, 4) VOX_ROWS1(6, 2, 1, 4) VOX_ROWS1(8, 1, 1, 4) VOX_ROWS1(8, 2, 1, 4) VOX_ROWS1(12, 1, 1, 4) VOX_ROWS1(16, 1, 1, 4)
+        VOX_ROWS1(6, 1, 1, 8) VOX_ROWS1(6, 2, 1, 8) VOX_ROWS1(8, 1, 1, 8) VOX_ROWS1(8, 2, 1, 8)
 #undef VOX_ROWS
+#undef VOX_ROWS1
         a.ln_w = a.ln_b = nullptr;      // no variant for this K: the staged kernels below
     }
     if (ln_w) {      // fused input LayerNorm: few-row kernel, one plain tap, the row statistics need the whole row in one K walk
@@ -2126,8 +2172,11 @@ __global__ __launch_bounds__(256) void k_hift_stft(const float* s, float* S, int
     }
 }
 // source_downs[i]: strided conv over the STFT frames, Cin = 2 nb (hifigan.py:497-510): out[b][t][co]
-__global__ __launch_bounds__(256) void k_hift_sd(const float* S, const float* w, const float* bias, float* out, int n, int F, int Cin,
+__global__ __launch_bounds__(256) void k_hift_sd(const float* S, const float* wt, const float* bias, float* out, int n, int F, int Cin,
                                                   int Lo, int Cout, int k, int stride, int pad) {
+    // wt = the weight transposed to [k][Cin][Cout] at creation: consecutive threads (output channels of one row) read consecutive
+    // floats, the spectrum value is the same address for the whole row (the [Cout][Cin][k] original had every lane 4 k Cin bytes apart);
+    // the accumulation order (tap, then input channel) is the original's
     const size_t total = (size_t)n * Lo * Cout;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int co = (int)(i % Cout);
@@ -2138,9 +2187,19 @@ __global__ __launch_bounds__(256) void k_hift_sd(const float* S, const float* w,
             const int f = t * stride - pad + j;
             if (f < 0 || f >= F) continue;
             const float* sr = S + ((size_t)b * F + f) * Cin;
-            for (int ci = 0; ci < Cin; ++ci) acc = fmaf(sr[ci], w[((size_t)co * Cin + ci) * k + j], acc);
+            const float* wr = wt + (size_t)j * Cin * Cout + co;
+#pragma unroll 6
+            for (int ci = 0; ci < Cin; ++ci) acc = fmaf(sr[ci], wr[(size_t)ci * Cout], acc);
         }
         out[i] = acc;
+    }
+}
+// [Cout][Cin][k] -> [k][Cin][Cout]
+__global__ __launch_bounds__(256) void k_hift_sd_transpose(const float* w, float* wt, int Cout, int Cin, int k) {
+    const size_t total = (size_t)Cout * Cin * k;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), j = (int)(i / ((size_t)Cout * Cin));
+        wt[i] = w[((size_t)co * Cin + ci) * k + j];
     }
 }
 // x = pad(y) + si (ReflectionPad1d((1, 0)) on the last stage: row 0 = row 1 of y) and the first Snake of the three resblocks
@@ -2220,6 +2279,7 @@ struct vox_hift {
     float* buf[9];
     size_t buf_floats;
     float *f0, *ph, *src, *stft, *post, *theta = nullptr;
+    float* sd_wt[4] = {};                  // source_downs weights as [k][n_fft + 2][Cout] (k_hift_sd)
     int sine_v1 = 0;
 };
 
@@ -2245,6 +2305,7 @@ void vox_hift_destroy(vox_hift* m) {
     if (!m) return;
     for (int i = 0; i < 9; ++i) (void)hipFree(m->buf[i]);
     (void)hipFree(m->f0); (void)hipFree(m->ph); (void)hipFree(m->src); (void)hipFree(m->stft); (void)hipFree(m->post); (void)hipFree(m->theta);
+    for (int i = 0; i < 4; ++i) (void)hipFree(m->sd_wt[i]);
     delete m;
 }
 
@@ -2277,6 +2338,17 @@ int vox_hift_create(vox_ctx* ctx, const vox_hift_config* cfg, const vox_hift_wei
          hipMalloc((void**)&m->post, (size_t)max_batch * F * (cfg->n_fft + 2) * 4) == hipSuccess;
     m->sine_v1 = cfg->sine_gen_v1;
     if (m->sine_v1) ok = ok && hipMalloc((void**)&m->theta, (size_t)max_batch * L * (cfg->nb_harmonics + 1) * 4) == hipSuccess;
+    ch = cfg->base_channels;
+    for (int i = 0; i < cfg->n_stages && ok; ++i) {      // transposed source_downs weights
+        int sstride = 1;
+        for (int q = i + 1; q < cfg->n_stages; ++q) sstride *= cfg->upsample_rates[q];
+        const int sk = sstride == 1 ? 1 : 2 * sstride, cin = cfg->n_fft + 2;
+        ch /= 2;
+        const size_t cnt = (size_t)ch * cin * sk;
+        ok = hipMalloc((void**)&m->sd_wt[i], cnt * 4) == hipSuccess;
+        if (ok) hipLaunchKernelGGL(k_hift_sd_transpose, dim3(ew_grid(cnt)), dim3(256), 0, 0, w->sd_w[i], m->sd_wt[i], ch, cin, sk);
+    }
+    ok = ok && hipStreamSynchronize(0) == hipSuccess;
     if (!ok) { vox_hift_destroy(m); return vox_fail(VOX_ERR_NOMEM, "hift_create: hipMalloc failed"); }
     *out = m;
     return VOX_OK;
@@ -2361,7 +2433,7 @@ int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, c
         for (int q = i + 1; q < c.n_stages; ++q) sstride *= c.upsample_rates[q];
         const int sk = sstride == 1 ? 1 : 2 * sstride, spad = sstride == 1 ? 0 : sstride / 2;
         if ((F + 2 * spad - sk) / sstride + 1 != Lx) return vox_fail(VOX_ERR_INVALID, "hift_decode: source / stage length mismatch at stage %d", i);
-        hipLaunchKernelGGL(k_hift_sd, dim3(ew_grid((size_t)n * Lx * cout)), dim3(256), 0, st, m->stft, w.sd_w[i], w.sd_b[i], S, n, F, nb2, Lx, cout,
+        hipLaunchKernelGGL(k_hift_sd, dim3(ew_grid((size_t)n * Lx * cout)), dim3(256), 0, st, m->stft, m->sd_wt[i], w.sd_b[i], S, n, F, nb2, Lx, cout,
                            sk, sstride, spad);
         // source resblock: S <- resblock(S)
         snake(st, S, w.src_rb[i].a1[0], A, (size_t)n * Lx, cout);
