@@ -2093,36 +2093,41 @@ __global__ __launch_bounds__(256) void k_hift_source(const float* f0, const floa
     }
 }
 // SineGen v1 (GLM-4-Voice's vocoder, tokenizer/glm.py:2298-2316): theta[b][l][h] = 2 pi ((cumulative sum over samples of f0 (h+1) / sr) mod 1),
-// the sum accumulated in double like torch.cumsum on the CPU; one thread per (request, harmonic)
-__global__ void k_hift_theta_v1(const float* f0, float* theta, int n, int T, int H1, int scale, float sr) {
+// the sum accumulated in double like torch.cumsum on the CPU.  f0 is constant over the `scale` samples of a frame, so the running sum at
+// sample q of frame t is start[t] + (q + 1) F_t with F_t = fl(fl(f0 (h+1)) / sr): the per-sample additions of the serial form are exact in
+// double whenever F's last bit is above the sum's ulp (24-bit F >= 2^-18 against sums < 2^14: every voiced frame), so the closed form has
+// the serial sum's bits; this kernel walks the T frames per (request, harmonic) — 172 dependent additions instead of 44 032 — and
+// k_hift_source_v1 evaluates the phase of each sample from start[t].
+__global__ void k_hift_theta_v1(const float* f0, double* start, int n, int T, int H1, int scale, float sr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * H1) return;
     const int b = i / H1, h = i % H1;
     double cum = 0.0;
-    const size_t L = (size_t)T * scale;
     for (int t = 0; t < T; ++t) {
         const float F = (f0[(size_t)b * T + t] * (float)(h + 1)) / sr;
-        for (int q = 0; q < scale; ++q) {
-            cum += (double)F;
-            const float v = (float)cum;
-            theta[((size_t)b * L + (size_t)t * scale + q) * H1 + h] = 6.28318548202514648f * (v - floorf(v));
-        }
+        start[((size_t)b * H1 + h) * T + t] = cum;
+        cum += (double)F * (double)scale;
     }
 }
 // merged source for SineGen v1: sin(theta + initial phase), voiced / unvoiced noise, tanh(linear).  Initial phases: -pi + 2 pi u with u
 // given (rand_ini [n][H1], column 0 ignored) or word 0 of the seeded uniform stream stream_base[b] (element h); phase of the fundamental = 0
-__global__ __launch_bounds__(256) void k_hift_source_v1(const float* f0, const float* theta, const float* rand_ini, const float* noise, uint64_t seed,
+__global__ __launch_bounds__(256) void k_hift_source_v1(const float* f0, const double* start, float sr, const float* rand_ini, const float* noise, uint64_t seed,
                                                          const uint32_t* stream_base, const float* lw, float lb, float* s, int n, int T, int H1,
                                                          int scale, float alpha, float sigma, float vth) {
     const size_t L = (size_t)T * scale, total = (size_t)n * L;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int b = (int)(i / L);
         const size_t l = i % L;
-        const float uv = f0[(size_t)b * T + l / scale] > vth ? 1.0f : 0.0f;
+        const int tf = (int)(l / scale), qf = (int)(l - (size_t)tf * scale);
+        const float f0v = f0[(size_t)b * T + tf];
+        const float uv = f0v > vth ? 1.0f : 0.0f;
         const float amp = uv * sigma + (1.0f - uv) * alpha / 3.0f;
         const uint32_t sb = stream_base ? stream_base[b] : (uint32_t)(2 * b);
         float acc = 0.0f;
         for (int h = 0; h < H1; ++h) {
+            const float F = (f0v * (float)(h + 1)) / sr;
+            const float cv = (float)(start[((size_t)b * H1 + h) * T + tf] + (double)F * (double)(qf + 1));
+            const float theta = 6.28318548202514648f * (cv - floorf(cv));
             float ph = 0.0f;
             if (h > 0) {
                 float u;
@@ -2142,7 +2147,7 @@ __global__ __launch_bounds__(256) void k_hift_source_v1(const float* f0, const f
                 const float u1 = ((float)(w0 >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(w1 >> 8) * (1.0f / 16777216.0f);
                 nz = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
             }
-            const float sw = (alpha * sinf(theta[i * H1 + h] + ph)) * uv + amp * nz;
+            const float sw = (alpha * sinf(theta + ph)) * uv + amp * nz;
             acc = fmaf(sw, lw[h], acc);
         }
         s[i] = tanhf(acc + lb);
@@ -2278,7 +2283,8 @@ struct vox_hift {
     int max_batch, max_T, scale;
     float* buf[9];
     size_t buf_floats;
-    float *f0, *ph, *src, *stft, *post, *theta = nullptr;
+    float *f0, *ph, *src, *stft, *post;
+    double* theta = nullptr;               // SineGen v1: running phase sum at the start of every frame [n][H1][T]
     float* sd_wt[4] = {};                  // source_downs weights as [k][n_fft + 2][Cout] (k_hift_sd)
     int sine_v1 = 0;
 };
@@ -2337,7 +2343,7 @@ int vox_hift_create(vox_ctx* ctx, const vox_hift_config* cfg, const vox_hift_wei
          hipMalloc((void**)&m->stft, (size_t)max_batch * F * (cfg->n_fft + 2) * 4) == hipSuccess &&
          hipMalloc((void**)&m->post, (size_t)max_batch * F * (cfg->n_fft + 2) * 4) == hipSuccess;
     m->sine_v1 = cfg->sine_gen_v1;
-    if (m->sine_v1) ok = ok && hipMalloc((void**)&m->theta, (size_t)max_batch * L * (cfg->nb_harmonics + 1) * 4) == hipSuccess;
+    if (m->sine_v1) ok = ok && hipMalloc((void**)&m->theta, (size_t)max_batch * max_T * (cfg->nb_harmonics + 1) * 8) == hipSuccess;
     ch = cfg->base_channels;
     for (int i = 0; i < cfg->n_stages && ok; ++i) {      // transposed source_downs weights
         int sstride = 1;
@@ -2399,7 +2405,7 @@ int vox_hift_decode(vox_hift* m, void* stream, const float* mel, int n, int T, c
     // ---- harmonic source + its STFT ----
     if (m->sine_v1) {
         hipLaunchKernelGGL(k_hift_theta_v1, dim3((n * H1 + 63) / 64), dim3(64), 0, st, m->f0, m->theta, n, T, H1, m->scale, (float)c.sampling_rate);
-        hipLaunchKernelGGL(k_hift_source_v1, dim3(ew_grid((size_t)n * L)), dim3(256), 0, st, m->f0, m->theta, rand_ini, noise, seed, stream_base,
+        hipLaunchKernelGGL(k_hift_source_v1, dim3(ew_grid((size_t)n * L)), dim3(256), 0, st, m->f0, m->theta, (float)c.sampling_rate, rand_ini, noise, seed, stream_base,
                            w.src_lin_w, w.src_lin_b, m->src, n, T, H1, m->scale, c.nsf_alpha, c.nsf_sigma, c.voiced_threshold);
     } else {
         hipLaunchKernelGGL(k_hift_phase, dim3((n * H1 + 63) / 64), dim3(64), 0, st, m->f0, m->ph, n, T, H1, (float)c.sampling_rate, (float)m->scale);

@@ -564,11 +564,11 @@ __device__ __forceinline__ bf16x8_t as_bf8(uint4 v) {
 
 // FULL: K % MF_KS == 0 and N % 16 == 0 — every range guard compiles away (at one wave per SIMD the kernel is
 // instruction-issue bound, each guard is a divergent-branch sequence); padded batch rows re-read the last real row.
-template <int MT, int PRO, int EPI, bool FULL>
+template <int MT, int PRO, int EPI, bool FULL, int KSEG>
 __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BT = 16 * MT;
-    constexpr int LDK = MF_KS + 8;                  // padded row stride (elements)
+    constexpr int LDK = KSEG + 8;                  // padded row stride (elements)
     bf16_t* xs = reinterpret_cast<bf16_t*>(smem);   // [BT][LDK]
     float* rinv = reinterpret_cast<float*>(smem + (size_t)BT * LDK * 2);   // [BT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -585,12 +585,30 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
         const int bt = (a.B - b0) < BT ? (a.B - b0) : BT;
         if (PRO == PRO_RMSNORM) {
             __syncthreads();
-            for (int b = wave; b < bt; b += 4) {
-                const uint4* xr = x_row_ptr(a, b0 + b);
-                float ss = 0.0f;
-                for (int c = lane; c < (a.K >> 3); c += 64) ss = sq8(xr[c], ss);
-                ss = butterfly<64>(ss);
-                if (lane == 0) rinv[b] = 1.0f / sqrtf(ss / (float)a.K + a.eps);
+            {   // the wave's rows together: their chunk loads are in flight at once (a row's sum keeps its order: the lane's chunks
+                // in increasing c, then the butterfly)
+                constexpr int NR = BT / 4;
+                const uint4* xr[NR];
+                float ss[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int b = wave + 4 * r;
+                    xr[r] = x_row_ptr(a, b0 + (b < bt ? b : bt - 1));
+                    ss[r] = 0.0f;
+                }
+                for (int c = lane; c < (a.K >> 3); c += 64) {
+                    uint4 v[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) v[r] = xr[r][c];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) ss[r] = sq8(v[r], ss[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int b = wave + 4 * r;
+                    const float t = butterfly<64>(ss[r]);
+                    if (lane == 0 && b < bt) rinv[b] = 1.0f / sqrtf(t / (float)a.K + a.eps);
+                }
             }
             __syncthreads();
         }
@@ -600,12 +618,12 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
             acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             acc2[m] = acc[m];
         }
-        // Software pipeline over K segments of MF_KS: while segment s is multiplied, the activation chunks of s+1 are
+        // Software pipeline over K segments of KSEG: while segment s is multiplied, the activation chunks of s+1 are
         // already on their way to registers and, queued BEHIND them (vmcnt retires in order), the weight fragments
-        // of s+1.  One group of U = MF_KS/32/4 fragment loads per wave per segment.
-        constexpr int U = MF_KS / 32 / 4;
+        // of s+1.  One group of U = KSEG/32/4 fragment loads per wave per segment.
+        constexpr int U = KSEG / 32 / 4;
         constexpr int RPW = BT / 4;          // activation rows staged per wave
-        constexpr int CPL = MF_KS / 8 / 64;  // 16-byte chunks per lane per row
+        constexpr int CPL = KSEG / 8 / 64;  // 16-byte chunks per lane per row
         uint4 wv[U], wv2[U], xv[RPW][CPL], gv[CPL];
         auto issue_x = [&](int k0, int ks) {
             const int nch = ks >> 3;
@@ -642,12 +660,12 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
             }
         };
         {
-            const int ks0 = a.K < MF_KS ? a.K : MF_KS;
+            const int ks0 = a.K < KSEG ? a.K : KSEG;
             issue_x(0, ks0);
             issue_w(0, ks0);
         }
-        for (int k0 = 0; k0 < a.K; k0 += MF_KS) {
-            const int ks = (a.K - k0) < MF_KS ? (a.K - k0) : MF_KS;
+        for (int k0 = 0; k0 < a.K; k0 += KSEG) {
+            const int ks = (a.K - k0) < KSEG ? (a.K - k0) : KSEG;
             const int nch = ks >> 3;
             __syncthreads();   // the previous segment's MFMAs are done with the LDS tile
 #pragma unroll
@@ -675,10 +693,10 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
                 cw[u] = wv[u];
                 if (EPI == EPI_SILU_MUL) cw2[u] = wv2[u];
             }
-            if (k0 + MF_KS < a.K) {
-                const int nks = (a.K - k0 - MF_KS) < MF_KS ? (a.K - k0 - MF_KS) : MF_KS;
-                issue_x(k0 + MF_KS, nks);
-                issue_w(k0 + MF_KS, nks);
+            if (k0 + KSEG < a.K) {
+                const int nks = (a.K - k0 - KSEG) < KSEG ? (a.K - k0 - KSEG) : KSEG;
+                issue_x(k0 + KSEG, nks);
+                issue_w(k0 + KSEG, nks);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -742,11 +760,11 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
     }
 }
 
-template <int MT, int PRO, int EPI, bool FULL>
+template <int MT, int PRO, int EPI, bool FULL, int KSEG>
 static int launch_linear_mfma_t(hipStream_t st, const LinArgs& a) {
     constexpr int BT = 16 * MT;
-    const size_t smem = (size_t)BT * (MF_KS + 8) * 2 + BT * 4;
-    auto kern = k_linear_mfma<MT, PRO, EPI, FULL>;
+    const size_t smem = (size_t)BT * (KSEG + 8) * 2 + BT * 4;
+    auto kern = k_linear_mfma<MT, PRO, EPI, FULL, KSEG>;
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -758,11 +776,22 @@ static int launch_linear_mfma_t(hipStream_t st, const LinArgs& a) {
     return VOX_OK;
 }
 
+// K segment per LDS stage: 2048 from K = 4096 on (one 16-row tile: twice the weight bytes in flight per block and half the barriers of
+// the 1024-wide walk; which k-steps a wave multiplies, and in which order, does not depend on the segment width, so the results are
+// bit-identical).  VOX_MFMA_KSEG=1024 keeps the narrow walk (A/B timing).
+static bool mfma_wide_seg() {
+    static const bool on = [] { const char* e = getenv("VOX_MFMA_KSEG"); return !(e && atoi(e) == 1024); }();
+    return on;
+}
 template <int PRO, int EPI>
 static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a) {
+    if (a.B <= 16 && a.K >= 4096 && mfma_wide_seg()) {
+        const bool full2 = (a.K % 2048 == 0) && (a.N % 16 == 0);
+        return full2 ? launch_linear_mfma_t<1, PRO, EPI, true, 2048>(st, a) : launch_linear_mfma_t<1, PRO, EPI, false, 2048>(st, a);
+    }
     const bool full = (a.K % MF_KS == 0) && (a.N % 16 == 0);
-    if (a.B <= 16) return full ? launch_linear_mfma_t<1, PRO, EPI, true>(st, a) : launch_linear_mfma_t<1, PRO, EPI, false>(st, a);
-    return full ? launch_linear_mfma_t<2, PRO, EPI, true>(st, a) : launch_linear_mfma_t<2, PRO, EPI, false>(st, a);
+    if (a.B <= 16) return full ? launch_linear_mfma_t<1, PRO, EPI, true, MF_KS>(st, a) : launch_linear_mfma_t<1, PRO, EPI, false, MF_KS>(st, a);
+    return full ? launch_linear_mfma_t<2, PRO, EPI, true, MF_KS>(st, a) : launch_linear_mfma_t<2, PRO, EPI, false, MF_KS>(st, a);
 }
 
 __global__ void k_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* y, int rows, int H, float eps);
