@@ -1,0 +1,16 @@
+cd $GRAFT_REPO_ROOT; O=gpurun_out/${OUT:-q18}; mkdir -p $O
+(timeout 900 python -m pytest tests/test_gpu_lm.py tests/test_gpu_qwen3.py tests/test_gpu_csm.py tests/test_gpu_ops.py tests/test_gpu_icl.py -q -x 2>&1 | tail -4) > $O/parity.log
+cat $O/parity.log
+for V in 0 1; do
+  VOX_ATTN_HEADSPLIT=$V timeout 600 python tools/bench_glm.py --batch 8 --greedy --steps 150 > $O/glm_b8_$V.json 2> $O/glm_b8_$V.err
+  VOX_ATTN_HEADSPLIT=$V timeout 600 python tools/bench_glm.py --batch 1 --greedy --steps 150 > $O/glm_b1_$V.json 2> $O/glm_b1_$V.err
+done
+timeout 600 python tools/bench_cosyvoice2.py --batch 8 > $O/cv_b8.json 2> $O/cv_b8.err
+timeout 600 python tools/bench_csm.py --batch 16 > $O/csm_b16.json 2> $O/csm_b16.err
+python - <<PY
+import json,glob
+for f in sorted(glob.glob("$O/*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], {k:round(v,2) for k,v in d.items() if isinstance(v,float) and ("ms" in k or "samples" in k)})
+    except Exception as e: print(f,"ERR",e)
+PY

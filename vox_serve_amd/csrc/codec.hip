@@ -1118,6 +1118,10 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     const int wm = b64 >= 192 ? 2 : 1, wn = (b64 >= 192 || 2 * b64 >= 192) ? 2 : 1;
     const dim3 grid((w.n + 32 * wn - 1) / (32 * wn), (a.M + 32 * wm - 1) / (32 * wm));
 #define VOX_CG(K_, M_, N_) if (wm == M_ && wn == N_) { hipLaunchKernelGGL((k_conv_gemm<K_, M_, N_>), grid, dim3(256), 0, st, a); return VOX_OK; }
+    // few blocks, long K (HiFT's resblock convs of one request: 112 blocks x 88 K steps of 64): 128-wide K steps halve the dependent
+    // stage-and-barrier rounds; the k order is unchanged, so the results are bit-identical (VOX_CG_BK128=0: 64-wide steps)
+    static const bool bk128 = [] { const char* e = getenv("VOX_CG_BK128"); return !(e && e[0] == '0'); }();
+    if (w.cin % 128 == 0 && bk128) { VOX_CG(128, 1, 1) }
     if (w.cin % 64 == 0) { VOX_CG(64, 2, 2) VOX_CG(64, 1, 2) VOX_CG(64, 1, 1) }
     VOX_CG(32, 2, 2) VOX_CG(32, 1, 2) VOX_CG(32, 1, 1)
 #undef VOX_CG

@@ -583,41 +583,6 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
 
     for (int b0 = 0; b0 < a.B; b0 += BT) {
         const int bt = (a.B - b0) < BT ? (a.B - b0) : BT;
-        if (PRO == PRO_RMSNORM) {
-            __syncthreads();
-            {   // the wave's rows together: their chunk loads are in flight at once (a row's sum keeps its order: the lane's chunks
-                // in increasing c, then the butterfly)
-                constexpr int NR = BT / 4;
-                const uint4* xr[NR];
-                float ss[NR];
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int b = wave + 4 * r;
-                    xr[r] = x_row_ptr(a, b0 + (b < bt ? b : bt - 1));
-                    ss[r] = 0.0f;
-                }
-                for (int c = lane; c < (a.K >> 3); c += 64) {
-                    uint4 v[NR];
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) v[r] = xr[r][c];
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) ss[r] = sq8(v[r], ss[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int b = wave + 4 * r;
-                    const float t = butterfly<64>(ss[r]);
-                    if (lane == 0 && b < bt) rinv[b] = 1.0f / sqrtf(t / (float)a.K + a.eps);
-                }
-            }
-            __syncthreads();
-        }
-        f32x4_t acc[MT], acc2[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            acc2[m] = acc[m];
-        }
         // Software pipeline over K segments of KSEG: while segment s is multiplied, the activation chunks of s+1 are
         // already on their way to registers and, queued BEHIND them (vmcnt retires in order), the weight fragments
         // of s+1.  One group of U = KSEG/32/4 fragment loads per wave per segment.
@@ -659,10 +624,64 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
                 }
             }
         };
+        const int ks_first = a.K < KSEG ? a.K : KSEG;
+        // one segment holds the whole row (K <= KSEG: the depth transformers, CosyVoice2): the row statistics are computed from the very
+        // registers that are staged afterwards (same rows per wave, same chunk -> lane assignment and order as the loop below), with the
+        // weight fragments requested right behind them — no second read of x, and the weights travel during the statistics
+        const bool one_seg = PRO == PRO_RMSNORM && a.K <= KSEG;
+        if (one_seg) {
+            __syncthreads();
+            issue_x(0, ks_first);
+            issue_w(0, ks_first);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int b = wave + 4 * r;
+                float ss = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CPL; ++j)
+                    if (FULL || lane + 64 * j < (ks_first >> 3)) ss = sq8(xv[r][j], ss);
+                ss = butterfly<64>(ss);
+                if (lane == 0 && b < bt) rinv[b] = 1.0f / sqrtf(ss / (float)a.K + a.eps);
+            }
+            __syncthreads();
+        } else if (PRO == PRO_RMSNORM) {
+            __syncthreads();
+            {   // the wave's rows together: their chunk loads are in flight at once (a row's sum keeps its order: the lane's chunks
+                // in increasing c, then the butterfly)
+                constexpr int NR = BT / 4;
+                const uint4* xr[NR];
+                float ss[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int b = wave + 4 * r;
+                    xr[r] = x_row_ptr(a, b0 + (b < bt ? b : bt - 1));
+                    ss[r] = 0.0f;
+                }
+                for (int c = lane; c < (a.K >> 3); c += 64) {
+                    uint4 v[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) v[r] = xr[r][c];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) ss[r] = sq8(v[r], ss[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int b = wave + 4 * r;
+                    const float t = butterfly<64>(ss[r]);
+                    if (lane == 0 && b < bt) rinv[b] = 1.0f / sqrtf(t / (float)a.K + a.eps);
+                }
+            }
+            __syncthreads();
+        }
+        f32x4_t acc[MT], acc2[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            acc2[m] = acc[m];
+        }
         {
             const int ks0 = a.K < KSEG ? a.K : KSEG;
-            issue_x(0, ks0);
-            issue_w(0, ks0);
+            if (!one_seg) { issue_x(0, ks0); issue_w(0, ks0); }
         }
         for (int k0 = 0; k0 < a.K; k0 += KSEG) {
             const int ks = (a.K - k0) < KSEG ? (a.K - k0) : KSEG;
@@ -1321,6 +1340,36 @@ __global__ __launch_bounds__(256) void k_rmsnorm(const bf16_t* x, const bf16_t* 
     const uint4* nw = reinterpret_cast<const uint4*>(w);
     uint4* yr = reinterpret_cast<uint4*>(y) + (size_t)row * nch;
     float s = 0.0f;
+    if (nch <= 512) {
+        // rows of up to 4096 values: the lane's (at most 8) chunks and their weights are requested together and stay in registers for
+        // the scaling pass — one trip to memory instead of a dependent chain of loads per pass (same order of the sum: the lane's chunks
+        // in increasing c, then the butterfly)
+        uint4 v[8], g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = lane + 64 * u;
+            v[u] = make_uint4(0, 0, 0, 0); g[u] = v[u];
+            if (c < nch) { v[u] = xr[c]; g[u] = nw[c]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (lane + 64 * u < nch) s = sq8(v[u], s);
+        s = butterfly<64>(s);
+        const float rinv = 1.0f / sqrtf(s / (float)H + eps);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = lane + 64 * u;
+            if (c < nch) {
+                uint4 o;
+                o.x = (u32)f2bf((bflo(v[u].x) * rinv) * bflo(g[u].x)) | ((u32)f2bf((bfhi(v[u].x) * rinv) * bfhi(g[u].x)) << 16);
+                o.y = (u32)f2bf((bflo(v[u].y) * rinv) * bflo(g[u].y)) | ((u32)f2bf((bfhi(v[u].y) * rinv) * bfhi(g[u].y)) << 16);
+                o.z = (u32)f2bf((bflo(v[u].z) * rinv) * bflo(g[u].z)) | ((u32)f2bf((bfhi(v[u].z) * rinv) * bfhi(g[u].z)) << 16);
+                o.w = (u32)f2bf((bflo(v[u].w) * rinv) * bflo(g[u].w)) | ((u32)f2bf((bfhi(v[u].w) * rinv) * bfhi(g[u].w)) << 16);
+                yr[c] = o;
+            }
+        }
+        return;
+    }
     for (int c = lane; c < nch; c += 64) s = sq8(xr[c], s);
     s = butterfly<64>(s);
     const float rinv = 1.0f / sqrtf(s / (float)H + eps);
@@ -1718,10 +1767,11 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
     __shared__ float Po[NCH][GMAX][D];
     __shared__ float2 Pml[NCH][GMAX];
 
-    const int hk = blockIdx.x, row = blockIdx.y;
+    // head split: gridDim.x = Hkv * HS blocks per row, block (hk, hs) takes q heads hs * G .. hs * G + G - 1 of kv head hk's group
+    const int HS = gridDim.x / a.Hkv, hk = blockIdx.x / HS, hs = blockIdx.x % HS, row = blockIdx.y;
     const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
     const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..8
-    const int G = a.Hq / a.Hkv;
+    const int Gf = a.Hq / a.Hkv, G = Gf / HS, g0 = hs * G;
     const int tid = threadIdx.x, lane = tid & 63, wave16 = tid >> 6;
     const int grp = tid / GT, gt = tid % GT, gw = wave16 % GW;
     const int* pages = a.identity_pages ? nullptr
@@ -1755,7 +1805,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
         const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
         for (int h = wave16; h < G + 1; h += 16) {
             const bool isk = h == G;
-            const bf16_t* src = isk ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * G + h) * D;
+            const bf16_t* src = isk ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * Gf + g0 + h) * D;
             bf16_t* dst = isk ? Knew : reinterpret_cast<bf16_t*>(Qs) + (size_t)h * D;
             prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, Sh + wave16 * D, dst, lane);
         }
@@ -1783,7 +1833,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
                 const uint4 vx = reinterpret_cast<const uint4*>(vraw)[gt];
                 Ks[grp][(nt - 1) * LPT + gt] = kx;
                 Vs[grp][(nt - 1) * LPT + gt] = vx;
-                if (pg >= 0) {
+                if (pg >= 0 && hs == 0) {
                     bf16_t* base = a.kv_w + (size_t)pg * ps + ((size_t)sl * a.Hkv + hk) * D;
                     reinterpret_cast<uint4*>(base)[gt] = kx;
                     reinterpret_cast<uint4*>(base + (size_t)a.page_size * a.Hkv * D)[gt] = vx;
@@ -1845,7 +1895,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             O = __fmaf_rn(Po[c][g][d], w, O);
         }
         const bf16_t r = f2bf(O / Lsum);
-        const int h = hk * G + g;
+        const int h = hk * Gf + g0 + g;
         a.out[((size_t)row * a.Hq + h) * D + d] = r;
         if (a.out_frag) a.out_frag[frag_off(row, h * D + d, a.Hq * D)] = r;
     }
@@ -1870,8 +1920,15 @@ int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
     a.ptab = c.ptab; a.pt_stride = c.pt_stride; a.fixed_kvlen = c.fixed_kvlen; a.fixed_pos = c.fixed_pos;
     a.identity_pages = c.identity_pages;
     a.out = (bf16_t*)c.out; a.out_frag = (bf16_t*)c.out_frag;
-    const dim3 grid(c.Hkv, c.Nq);
     const int G = c.Hq / c.Hkv;
+    // 16-head groups (GLM-4-Voice: 2 kv heads, so 2 blocks per row): eight blocks of two q heads per kv head, each with all 8 chunks in
+    // flight — the per-(row, head) arithmetic does not depend on which heads share a block (VOX_ATTN_HEADSPLIT=0: one block per kv head)
+    static const bool split_on = [] { const char* e = getenv("VOX_ATTN_HEADSPLIT"); return !(e && e[0] == '0'); }();
+    if (c.D == 128 && G == 16 && split_on) {
+        hipLaunchKernelGGL((k_attn_decode8<128, 2, 8>), dim3(c.Hkv * 8, c.Nq), dim3(1024), 0, st, a);
+        return VOX_OK;
+    }
+    const dim3 grid(c.Hkv, c.Nq);
 #define VOX_AD(D_, G_, NG_) if (c.D == D_ && G == G_) { hipLaunchKernelGGL((k_attn_decode8<D_, G_, NG_>), grid, dim3(1024), 0, st, a); return VOX_OK; }
     VOX_AD(128, 2, 8) VOX_AD(128, 16, 4) VOX_AD(64, 4, 8) VOX_AD(64, 7, 8)
 #undef VOX_AD
