@@ -29,6 +29,7 @@ struct LinArgs {
     bf16_t* y_frag;
     int y_rowmajor;
     int row_tiles;       // k_gemv only: > 1 = that many row tiles of BT rows, one block per (column group, row tile)
+    int no_one_seg;      // k_linear_mfma A/B knob (VOX_MFMA_ONESEG=0): row statistics by the separate pass even when K fits one segment
 };
 
 // element offset of (row r, column k) of a [*, K] matrix in fragment-major form
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
         // one segment holds the whole row (K <= KSEG: the depth transformers, CosyVoice2): the row statistics are computed from the very
         // registers that are staged afterwards (same rows per wave, same chunk -> lane assignment and order as the loop below), with the
         // weight fragments requested right behind them — no second read of x, and the weights travel during the statistics
-        const bool one_seg = PRO == PRO_RMSNORM && a.K <= KSEG;
+        const bool one_seg = PRO == PRO_RMSNORM && a.K <= KSEG && !a.no_one_seg;
         if (one_seg) {
             __syncthreads();
             issue_x(0, ks_first);
@@ -803,7 +804,10 @@ static bool mfma_wide_seg() {
     return on;
 }
 template <int PRO, int EPI>
-static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a) {
+static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a_in) {
+    static const bool oneseg_off = [] { const char* e = getenv("VOX_MFMA_ONESEG"); return e && e[0] == '0'; }();
+    LinArgs a = a_in;
+    a.no_one_seg = oneseg_off ? 1 : 0;
     if (a.B <= 16 && a.K >= 4096 && mfma_wide_seg()) {
         const bool full2 = (a.K % 2048 == 0) && (a.N % 16 == 0);
         return full2 ? launch_linear_mfma_t<1, PRO, EPI, true, 2048>(st, a) : launch_linear_mfma_t<1, PRO, EPI, false, 2048>(st, a);
