@@ -24,6 +24,8 @@ for name in ("csm_b1", "csm_b16", "glm_b1", "glm_b8", "cosyvoice2_b1", "cosyvoic
 shutil.copy(os.path.join(S, "kernel_stats_csm_b16.csv"), os.path.join(D, "round3_csm_b16_kernel_stats.csv"))
 shutil.copy(os.path.join(S, "kernel_stats_glm_b8.csv"), os.path.join(D, "round3_glm_b8_kernel_stats.csv"))
 shutil.copy(os.path.join(S, "kernel_stats_cosyvoice2_b1.csv"), os.path.join(D, "round3_cosyvoice2_b1_kernel_stats.csv"))
+if os.path.exists(os.path.join(S, "kernel_stats_cosyvoice2_b8.csv")):
+    shutil.copy(os.path.join(S, "kernel_stats_cosyvoice2_b8.csv"), os.path.join(D, "round3_cosyvoice2_b8_kernel_stats.csv"))
 for src, dst in (("clone.json", "round3_voice_clone_prompt_side.json"), ("kernel_stats_clone.csv", "round3_voice_clone_kernel_stats.csv")):
     if os.path.exists(os.path.join(S, src)):
         shutil.copy(os.path.join(S, src), os.path.join(D, dst))

@@ -25,6 +25,8 @@ for b in 1 8; do timeout 600 python tools/bench_glm.py --batch $b --greedy --ste
 for b in 1 8; do timeout 600 python tools/bench_cosyvoice2.py --batch $b > $O/cosyvoice2_b$b.json 2> $O/cosyvoice2_b$b.err; done
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cv -o cv -- python tools/bench_cosyvoice2.py --batch 1 --steps 50 --warmup 0 > $O/cv_prof.json 2> $O/cv_prof.err
 cp $(find $O/prof_cv -name "*kernel_stats.csv" | head -1) $O/kernel_stats_cosyvoice2_b1.csv; rm -rf $O/prof_cv
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cv8 -o cv -- python tools/bench_cosyvoice2.py --batch 8 --steps 50 --warmup 0 > $O/cv8_prof.json 2> $O/cv8_prof.err
+cp $(find $O/prof_cv8 -name "*kernel_stats.csv" | head -1) $O/kernel_stats_cosyvoice2_b8.csv; rm -rf $O/prof_cv8
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_csm -o csm -- python tools/bench_csm.py --batch 16 --steps 40 --warmup 10 > $O/csm_b16_prof.json 2> $O/csm_b16_prof.err
 cp $(find $O/prof_csm -name "*kernel_stats.csv" | head -1) $O/kernel_stats_csm_b16.csv; rm -rf $O/prof_csm
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_glm -o glm -- python tools/bench_glm.py --batch 8 --greedy --steps 40 --warmup 10 > $O/glm_b8_prof.json 2> $O/glm_b8_prof.err

@@ -117,6 +117,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise VoxError(f"{LIB_PATH} not found: build it with `python -m vox_serve_amd.build` "
                            "(the HIP library is the only compute path; there is no CPU fallback)")
+        # torch first: its wheel carries its own HIP runtime, and the process must have ONE — with libvoxhip (linked against
+        # /opt/rocm's libamdhip64) loaded before torch, the two runtimes coexist and hipGetDeviceCount in ours reports no device
+        # (seen with `python __graft_entry__.py smoke`, whose build() step loaded the library before anything imported torch)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in {**_SIGS, **_OPTIONAL_SIGS}.items():
             fn = getattr(L, name)

@@ -2757,7 +2757,7 @@ __global__ __launch_bounds__(256) void k_flow_attn_tile(FlowAttn a, int QG) {
     }
 }
 // The estimators' attention on the matrix cores (no relative-position term, dk = 64, at most 256 keys: every CosyVoice2 / GLM estimator
-// call).  A block owns 16 consecutive queries of one (request, head); its four waves take the 16-key tiles w, w + 4, w + 8, w + 12 for
+// call).  A block owns 16 consecutive queries of one (request, head); its WV (8) waves take the 16-key tiles w, w + WV for
 // BOTH products, so nothing but the row maxima, the row sums and the 16 x 64 partial outputs crosses a wave:
 //   scores  = Q K^T   v_mfma_f32_16x16x4_f32 (fp32 operands, fp32 accumulate), 16 per key tile; every operand is requested up front
 //                     straight in operand layout (lane = (row l % 16, k group l / 16) holds four float4 chunks 16 c + 4 (l / 16) of its
@@ -2765,15 +2765,15 @@ __global__ __launch_bounds__(256) void k_flow_attn_tile(FlowAttn a, int QG) {
 //   softmax           row maximum by a 16-lane butterfly + one LDS exchange across the waves; p = exp(s - max)
 //   out     = P V     p goes through a wave-private LDS tile to become an A operand; V rows are float4 loads whose four components
 //                     are the four 16-dim output tiles (dim = 4 (l % 16) + tile), so a lane's four accumulators are one float4 of the row
-// and the four partial outputs are summed in the fixed order w0 + w1 + w2 + w3 and scaled by 1 / sum.  A (request, head, query)'s
+// and the partial outputs of the WV waves are summed in the fixed order w0 + w1 + ... and scaled by 1 / sum.  A (request, head, query)'s
 // result depends on that request's rows only.
-template <int DK>
-__global__ __launch_bounds__(256) void k_flow_attn_mfma(FlowAttn a) {
+template <int DK, int WV>
+__global__ __launch_bounds__(64 * WV) void k_flow_attn_mfma(FlowAttn a) {
     static_assert(DK == 64, "operand layout below is written for 64-dim heads");
-    constexpr int KT = 4, PS = KT * 16 + 4, OS = DK + 4;
-    __shared__ float red_mx[4][16], red_sum[4][16];
-    __shared__ __attribute__((aligned(16))) float Ps[4][16][PS];
-    __shared__ __attribute__((aligned(16))) float Os[4][16][OS];
+    constexpr int KT = 16 / WV, PS = KT * 16 + 4, OS = DK + 4;      // WV waves x KT key tiles of 16: at most 256 keys
+    __shared__ float red_mx[WV][16], red_sum[WV][16];
+    __shared__ __attribute__((aligned(16))) float Ps[WV][16][PS];
+    __shared__ __attribute__((aligned(16))) float Os[WV][16][OS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, fr = lane & 15, kq = lane >> 4;
     const int i0 = blockIdx.x * 16, h = blockIdx.y, n = blockIdx.z;
     const int HD = a.H * DK, ld = 3 * HD, S = a.Tc + a.T, nt = (S + 15) >> 4;
@@ -2790,7 +2790,7 @@ __global__ __launch_bounds__(256) void k_flow_attn_mfma(FlowAttn a) {
     for (int c = 0; c < 4; ++c) q[c] = *reinterpret_cast<const float4*>(qrow + 16 * c);
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        const int kt = t * 4 + wave;
+        const int kt = t * WV + wave;
 #pragma unroll
         for (int c = 0; c < 4; ++c) { k[t][c] = make_float4(0.f, 0.f, 0.f, 0.f); v[t][c] = make_float4(0.f, 0.f, 0.f, 0.f); }
         if (kt < nt) {
@@ -2811,7 +2811,7 @@ __global__ __launch_bounds__(256) void k_flow_attn_mfma(FlowAttn a) {
     float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        const int kt = t * 4 + wave;
+        const int kt = t * WV + wave;
         sc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (kt < nt) {
 #pragma unroll
@@ -2843,7 +2843,9 @@ __global__ __launch_bounds__(256) void k_flow_attn_mfma(FlowAttn a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int qi = 4 * kq + r;
-        const float gm = fmaxf(fmaxf(red_mx[0][qi], red_mx[1][qi]), fmaxf(red_mx[2][qi], red_mx[3][qi]));
+        float gm = red_mx[0][qi];
+#pragma unroll
+        for (int w = 1; w < WV; ++w) gm = fmaxf(gm, red_mx[w][qi]);
         float sm = 0.0f;
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
@@ -2862,7 +2864,7 @@ __global__ __launch_bounds__(256) void k_flow_attn_mfma(FlowAttn a) {
     for (int d = 0; d < 4; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-        if (t * 4 + wave < nt) {
+        if (t * WV + wave < nt) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float pa = Ps[wave][fr][16 * t + 4 * s4 + kq];
@@ -2878,13 +2880,17 @@ __global__ __launch_bounds__(256) void k_flow_attn_mfma(FlowAttn a) {
         *reinterpret_cast<float4*>(&Os[wave][4 * kq + r][4 * fr]) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
     __syncthreads();
     const int qi = tid >> 4, c4 = (tid & 15) * 4;
-    if (i0 + qi < a.T) {
-        const float inv = 1.0f / (((red_sum[0][qi] + red_sum[1][qi]) + red_sum[2][qi]) + red_sum[3][qi]);
-        const float4 p0 = *reinterpret_cast<const float4*>(&Os[0][qi][c4]), p1 = *reinterpret_cast<const float4*>(&Os[1][qi][c4]);
-        const float4 p2 = *reinterpret_cast<const float4*>(&Os[2][qi][c4]), p3 = *reinterpret_cast<const float4*>(&Os[3][qi][c4]);
-        *reinterpret_cast<float4*>(a.out + ((size_t)n * a.T + i0 + qi) * HD + h * DK + c4) =
-            make_float4((((p0.x + p1.x) + p2.x) + p3.x) * inv, (((p0.y + p1.y) + p2.y) + p3.y) * inv,
-                        (((p0.z + p1.z) + p2.z) + p3.z) * inv, (((p0.w + p1.w) + p2.w) + p3.w) * inv);
+    if (tid < 256 && i0 + qi < a.T) {
+        float l = red_sum[0][qi];
+        float4 o4 = *reinterpret_cast<const float4*>(&Os[0][qi][c4]);
+#pragma unroll
+        for (int w = 1; w < WV; ++w) {
+            l += red_sum[w][qi];
+            const float4 pw = *reinterpret_cast<const float4*>(&Os[w][qi][c4]);
+            o4.x += pw.x; o4.y += pw.y; o4.z += pw.z; o4.w += pw.w;
+        }
+        const float inv = 1.0f / l;
+        *reinterpret_cast<float4*>(a.out + ((size_t)n * a.T + i0 + qi) * HD + h * DK + c4) = make_float4(o4.x * inv, o4.y * inv, o4.z * inv, o4.w * inv);
     }
 }
 // VOX_FLOW_ATTN_MFMA=0: the VALU attention kernels for every call (A/B timing)
@@ -2901,7 +2907,9 @@ static void launch_flow_attn(hipStream_t st, const FlowAttn& a, int T, int H, in
     const int S = a.Tc + T;
     const size_t lds = ((size_t)S * (2 * a.dk + 4) + 4 * ((S + 3) & ~3) + 4 * a.dk) * sizeof(float);
     if (!a.P && !a.bu && a.dk == 64 && S <= 256 && flow_attn_mfma_on()) {
-        hipLaunchKernelGGL(k_flow_attn_mfma<64>, dim3((T + 15) / 16, H, N), dim3(256), 0, st, a);
+        static const bool wv4 = [] { const char* e = getenv("VOX_FLOW_ATTN_WV"); return e && atoi(e) == 4; }();      // A/B: four waves x four key tiles
+        if (wv4) hipLaunchKernelGGL((k_flow_attn_mfma<64, 4>), dim3((T + 15) / 16, H, N), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_flow_attn_mfma<64, 8>), dim3((T + 15) / 16, H, N), dim3(512), 0, st, a);
         return;
     }
     if (!a.P && a.dk == 64 && lds <= 150 * 1024 && flow_attn_tile_on()) {
