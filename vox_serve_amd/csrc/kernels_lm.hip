@@ -1000,8 +1000,14 @@ static int launch_gemm_splitk(hipStream_t st, const LinArgs& a, float* ws, size_
 // accumulators meet in LDS and are added in wave order; prologue RMSNorm (sum of squares over the block's own
 // operand registers) and the bias / residual / SiLU*up epilogue are fused.  bf16-rounding parity (MFMA order).
 // ================================================================================================
-template <int MT, int KSTEPS, int PRO, int EPI, bool ROWSPLIT>
+// CT = 2 (gate / up of the 17..32-row talker: 384 column tiles, one 8-wave block per CU, i.e. a round and a half): a block owns two
+// consecutive column tiles — 192 blocks, one round — and loads, squares and normalises its activation fragments ONCE for both; the
+// second tile's weight fragments are requested when the first tile's MFMAs have been issued (into the same registers: both tiles'
+// fragments at once do not fit the 256 registers a wave has at two waves per SIMD) and travel during the first tile's sum and
+// epilogue.  Every output keeps its K split and summation order, so the results are bit-identical to CT = 1.
+template <int MT, int KSTEPS, int PRO, int EPI, bool ROWSPLIT, int CT = 1>
 __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
+    static_assert(CT == 1 || (EPI == EPI_SILU_MUL && !ROWSPLIT), "two column tiles per block: the SiLU*up form only");
     constexpr bool SM = (EPI == EPI_SILU_MUL);
     constexpr int NB = SM ? 2 : 1;
     constexpr int G = (PRO == PRO_RMSNORM) ? KSTEPS : (KSTEPS <= 8 ? KSTEPS : 4);   // activation k-steps per group
@@ -1013,7 +1019,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
     // ROWSPLIT: row_tiles blocks per column tile, one per 16*MT-row tile, ids 8 apart so that they land on the same XCD and
     // the later readers of the weight tile hit that XCD's L2 (17..32 rows with few column tiles: 2 x 16 rows on twice the
     // CUs; 33..64 rows: 2 x 32 rows).
-    int ctile = blockIdx.x, r0 = 0;
+    int ctile = blockIdx.x * CT, r0 = 0;
     if (ROWSPLIT) {
         ctile = (blockIdx.x / (8 * a.row_tiles)) * 8 + (blockIdx.x & 7);
         r0 = ((blockIdx.x >> 3) % a.row_tiles) * (16 * MT);
@@ -1023,22 +1029,25 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
     const int bt = a.B - r0;
     uint4 wv[NB][KSTEPS];
     const size_t fbase = (size_t)wave * KSTEPS * 64 + lane;      // uint4 offset of this wave's first fragment inside a tile row
-    {
-        // row-major: lane (fr, g) reads 16 B of weight row n0+fr per k-step (16 rows x 64 B per wave request);
-        // fragment-major: the same register contents from ONE contiguous 1 KiB request
-        const bool wf = a.W_frag != nullptr;
-        const int wstep = wf ? 64 : 4;
-        const uint4* w0 = wf ? reinterpret_cast<const uint4*>(a.W_frag) + (size_t)ctile * (a.K >> 5) * 64 + fbase
-                             : reinterpret_cast<const uint4*>(a.W + (size_t)((n0 + fr) < a.N ? (n0 + fr) : a.N - 1) * a.K + kbase);   // (N % 16 tail: clamped, not stored)
-        const uint4* w1 = !SM ? nullptr
-                          : wf ? reinterpret_cast<const uint4*>(a.W2_frag) + (size_t)ctile * (a.K >> 5) * 64 + fbase
-                               : reinterpret_cast<const uint4*>(a.W2 + (size_t)(n0 + fr) * a.K + kbase);
+    // row-major: lane (fr, g) reads 16 B of weight row n0+fr per k-step (16 rows x 64 B per wave request);
+    // fragment-major: the same register contents from ONE contiguous 1 KiB request
+    const bool wf = a.W_frag != nullptr;
+    const int wstep = wf ? 64 : 4;
+    const uint4* w0 = wf ? reinterpret_cast<const uint4*>(a.W_frag) + (size_t)ctile * (a.K >> 5) * 64 + fbase
+                         : reinterpret_cast<const uint4*>(a.W + (size_t)((n0 + fr) < a.N ? (n0 + fr) : a.N - 1) * a.K + kbase);   // (N % 16 tail: clamped, not stored)
+    const uint4* w1 = !SM ? nullptr
+                      : wf ? reinterpret_cast<const uint4*>(a.W2_frag) + (size_t)ctile * (a.K >> 5) * 64 + fbase
+                           : reinterpret_cast<const uint4*>(a.W2 + (size_t)(n0 + fr) * a.K + kbase);
+    // the next column tile: (K / 32) 1 KiB fragments further in fragment-major form, 16 weight rows further row-major
+    const size_t tstride = wf ? (size_t)(a.K >> 5) * 64 : (size_t)16 * (a.K >> 3);
+    auto load_w = [&](int ct) {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-            wv[0][s] = a.keep ? w0[s * wstep] : ldg_nt(w0 + s * wstep);
-            if (SM) wv[1][s] = a.keep ? w1[s * wstep] : ldg_nt(w1 + s * wstep);
+            wv[0][s] = a.keep ? w0[ct * tstride + s * wstep] : ldg_nt(w0 + ct * tstride + s * wstep);
+            if (SM) wv[1][s] = a.keep ? w1[ct * tstride + s * wstep] : ldg_nt(w1 + ct * tstride + s * wstep);
         }
-    }
+    };
+    load_w(0);
     // residual of the outputs this thread will finish (threads < MT*64), requested with the operands instead of after the reduce
     float res_pre[4] = {0.f, 0.f, 0.f, 0.f};
     if (!SM && a.residual && tid < MT * 64 && n0 + fr < a.N) {
@@ -1056,11 +1065,8 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
         xr[m] = a.x_frag ? reinterpret_cast<const uint4*>(a.x_frag) + (size_t)((r0 >> 4) + m) * (a.K >> 5) * 64 + fbase
                          : x_row_ptr(a, r0 + (row < bt ? row : bt - 1)) + (kbase >> 3);
     }
+    static_assert(CT == 1 || (PRO == PRO_RMSNORM), "two column tiles: every activation fragment resident (norm prologue form)");
     f32x4_t acc[NB][MT];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[nb][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     uint4 xa[NG > 1 ? 2 : 1][MT][G];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -1090,60 +1096,81 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
             for (int w = 0; w < 8; ++w) t += ssq[w][m * 16 + fr];
             rinv[m] = 1.0f / sqrtf(t / (float)a.K + a.eps);
         }
+        if (CT > 1) {      // two column tiles: normalise the fragments in place, once, and let the norm weights' registers go
+#pragma unroll
+            for (int s = 0; s < G; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) xa[0][m][s] = norm_chunk(xa[0][m][s], gv[s], rinv[m]);
+        }
     }
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) {
+    for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int s = 0; s < G; ++s) xa[(g + 1) & 1][m][s] = xr[m][((g + 1) * G + s) * xstep];
+            for (int m = 0; m < MT; ++m) acc[nb][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int s = 0; s < G; ++s) xa[(g + 1) & 1][m][s] = xr[m][((g + 1) * G + s) * xstep];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 0; s < G; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    uint4 ax = xa[g & 1][m][s];
+                    if (PRO == PRO_RMSNORM && CT == 1) ax = norm_chunk(ax, gv[s], rinv[m]);   // normalised right before use: no second copy
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(ax), as_bf8(wv[nb][g * G + s]), acc[nb][m], 0, 0, 0);
+                }
+        }
+        if (ct + 1 < CT) {      // the next tile's weights travel during this tile's sum and epilogue
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(ct + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (ct > 0) __syncthreads();      // the sum buffer is reused by the block's next column tile
 #pragma unroll
-        for (int s = 0; s < G; ++s)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                uint4 ax = xa[g & 1][m][s];
-                if (PRO == PRO_RMSNORM) ax = norm_chunk(ax, gv[s], rinv[m]);   // normalised right before use: no second copy
+            for (int m = 0; m < MT; ++m) red[wave][nb][m][lane] = acc[nb][m];
+        __syncthreads();
+        if (tid < MT * 64) {
+            const int m = tid >> 6;            // thread (m, lane) finishes D fragment m: column n0+fr, rows m*16 + (lane>>4)*4 + r
+            f32x4_t v = red[0][0][m][lane], u = SM ? red[0][NB - 1][m][lane] : v;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(ax), as_bf8(wv[nb][g * G + s]), acc[nb][m], 0, 0, 0);
+            for (int w = 1; w < 8; ++w) {
+                v += red[w][0][m][lane];
+                if (SM) u += red[w][NB - 1][m][lane];
             }
-    }
+            const int n = n0 + 16 * ct + fr;
+            if (n < a.N) {           // (tail columns of an N that is not a multiple of 16: vocabulary heads)
+                const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) red[wave][nb][m][lane] = acc[nb][m];
-    __syncthreads();
-    if (tid >= MT * 64) return;
-    const int m = tid >> 6;            // thread (m, lane) finishes D fragment m: column n0+fr, rows m*16 + (lane>>4)*4 + r
-    f32x4_t v = red[0][0][m][lane], u = SM ? red[0][NB - 1][m][lane] : v;
-#pragma unroll
-    for (int w = 1; w < 8; ++w) {
-        v += red[w][0][m][lane];
-        if (SM) u += red[w][NB - 1][m][lane];
-    }
-    const int n = n0 + fr;
-    if (n >= a.N) return;           // tail columns of an N that is not a multiple of 16 (vocabulary heads)
-    const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b = m * 16 + (lane >> 4) * 4 + r;
-        if (b >= bt) continue;
-        const size_t oi = (size_t)(r0 + b) * a.N + n;
-        bf16_t o;
-        if (SM) {
-            o = f2bf(bfround(silu_c(bfround(v[r]))) * bfround(u[r]));
-        } else {
-            float f = v[r];
-            if (a.bias) f = f + bv;
-            o = f2bf(f);
-            if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
-            if (a.residual) o = f2bf(res_pre[r] + bf2f(o));
+                for (int r = 0; r < 4; ++r) {
+                    const int b = m * 16 + (lane >> 4) * 4 + r;
+                    if (b >= bt) continue;
+                    const size_t oi = (size_t)(r0 + b) * a.N + n;
+                    bf16_t o;
+                    if (SM) {
+                        o = f2bf(bfround(silu_c(bfround(v[r]))) * bfround(u[r]));
+                    } else {
+                        float f = v[r];
+                        if (a.bias) f = f + bv;
+                        o = f2bf(f);
+                        if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
+                        if (a.residual) o = f2bf(res_pre[r] + bf2f(o));
+                    }
+                    if (a.y_rowmajor) a.y[oi] = o;
+                    if (a.y_frag) a.y_frag[frag_off(r0 + b, n, a.N)] = o;
+                }
+            }
         }
-        if (a.y_rowmajor) a.y[oi] = o;
-        if (a.y_frag) a.y_frag[frag_off(r0 + b, n, a.N)] = o;
     }
 }
 
@@ -1210,6 +1237,14 @@ static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a0) {
                 hipLaunchKernelGGL((k_gemm_fullk<1, KSTEPS, PRO, EPI, true>), dim3(a.N / 8), dim3(512), 0, st, a);
                 return VOX_OK;
             }
+        }
+    }
+    if constexpr (MT == 2 && KSTEPS == 8 && PRO == PRO_RMSNORM && EPI == EPI_SILU_MUL) {
+        // more column tiles than one round of 8-wave blocks (one per CU): two tiles per block (VOX_FULLK_CT2=0: one)
+        static const bool ct2 = [] { const char* e = getenv("VOX_FULLK_CT2"); return !(e && e[0] == '0'); }();
+        if (ct2 && a.N % 32 == 0 && a.N / 16 > 256 && a.N / 16 <= 512) {
+            hipLaunchKernelGGL((k_gemm_fullk<MT, KSTEPS, PRO, EPI, false, 2>), dim3(a.N / 32), dim3(512), 0, st, a);
+            return VOX_OK;
         }
     }
     hipLaunchKernelGGL((k_gemm_fullk<MT, KSTEPS, PRO, EPI, false>), dim3((a.N + 15) / 16), dim3(512), 0, st, a);
