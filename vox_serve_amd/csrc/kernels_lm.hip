@@ -1239,7 +1239,7 @@ static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a0) {
             }
         }
     }
-    if constexpr (MT == 2 && KSTEPS == 8 && PRO == PRO_RMSNORM && EPI == EPI_SILU_MUL) {
+    if constexpr (KSTEPS == 8 && PRO == PRO_RMSNORM && EPI == EPI_SILU_MUL) {
         // more column tiles than one round of 8-wave blocks (one per CU): two tiles per block (VOX_FULLK_CT2=0: one)
         static const bool ct2 = [] { const char* e = getenv("VOX_FULLK_CT2"); return !(e && e[0] == '0'); }();
         if (ct2 && a.N % 32 == 0 && a.N / 16 > 256 && a.N / 16 <= 512) {
