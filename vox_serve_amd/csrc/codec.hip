@@ -1017,6 +1017,12 @@ static int rows_mt2_blocks() {
     static const int v = [] { const char* e = getenv("VOX_ROWS_MT2"); const int x = e ? atoi(e) : 1024; return x > 0 ? x : (1 << 30); }();
     return v;
 }
+// 16 x 16 output tiles above which a k_rows_gemm block takes 2 / 4 column tiles (VOX_ROWS_NT2 / VOX_ROWS_NT4)
+static int rows_nt_tiles(int which) {
+    static const int v2 = [] { const char* e = getenv("VOX_ROWS_NT2"); return e ? atoi(e) : 256; }();
+    static const int v4 = [] { const char* e = getenv("VOX_ROWS_NT4"); return e ? atoi(e) : 2048; }();
+    return which ? v4 : v2;
+}
 // VOX_CONV_TAPS=0: the per-tap staging kernel for every multi-tap conv (A/B timing)
 static bool conv_taps_on() {
     static const bool on = [] { const char* e = getenv("VOX_CONV_TAPS"); return !(e && e[0] == '0'); }();
@@ -1045,7 +1051,10 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
         // every operand requested up front, K split over the block's waves (k_rows_gemm): 8 waves from K = 512 on
         const int K = w.n_taps * w.cin, wv = (K >= 512 && K % 256 == 0 && rows_wv8_on()) ? 8 : 4, kb = K / (32 * wv);
         const int tiles = ((w.n + 15) / 16) * ((a.M + 15) / 16);
-        int nt = tiles > 2048 ? 4 : tiles > 1024 ? 2 : 1;
+        // column tiles per block: one while the call is a handful of row tiles (latency: more blocks in flight), two from 256 tiles on
+        // once there are >= 16 row tiles (every block re-loads and re-splits its A rows: at 448+ rows that traffic and VALU work
+        // outweigh the extra blocks — CosyVoice2 chunk 49.7 -> 46.6 ms at B=8, 36.6 -> 35.2 at B=4, unchanged at B=1), four above 2048
+        int nt = tiles > rows_nt_tiles(1) ? 4 : tiles > (a.M >= 256 ? rows_nt_tiles(0) : 1024) ? 2 : 1;
         while (nt > 1 && nt * kb > 16) nt >>= 1;
         const int mt = (tiles / nt >= rows_mt2_blocks() && kb <= 4 && (wv == 4 || nt <= 2)) ? 2 : 1;      // (the 8-wave sum buffer: MT NT <= 4)
         if (ln_w) { a.ln_w = ln_w; a.ln_b = ln_b; a.ln_eps = ln_eps; }
