@@ -3520,6 +3520,48 @@ __global__ __launch_bounds__(256) void k_flow_groupnorm(const float* x, const fl
     const float* xb = x + (size_t)n * T * ld;
     float* yb = y + (size_t)n * T * ld;
     const int cnt = T * cg;
+    if (256 % cg == 0 && T <= 48 * (256 / cg)) {
+        // the group fits the block's registers (GLM: 32 channels x <= 384 frames): element i = tid + 256 k is (frame tid / cg + k * 256 / cg,
+        // channel tid % cg) — the general path's element -> thread assignment and accumulation order without its two integer divisions
+        // per element and per pass, and with ONE read of x instead of three (the kernel is 16-128 blocks of pure latency)
+        constexpr int KM = 48;
+        const int c = g * cg + threadIdx.x % cg, r0 = threadIdx.x / cg, rs = 256 / cg;
+        float xv[KM];
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            const int r = r0 + k * rs;
+            xv[k] = r < T ? xb[(size_t)r * ld + c] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (r0 + k * rs < T) s += xv[k];
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)cnt;
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (r0 + k * rs < T) { const float d = xv[k] - mean; v += d * d; }
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = v;
+        __syncthreads();
+        const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)cnt + eps);
+        const float wc = w[c], bc = b[c], ac = add ? add[c] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            const int r = r0 + k * rs;
+            if (r < T) {
+                float o = mish_f((xv[k] - mean) * rstd * wc + bc);
+                if (add) o += ac;
+                yb[(size_t)r * ld + c] = o;
+            }
+        }
+        if (g == G - 1 && ld > C)
+            for (int i = threadIdx.x; i < T * (ld - C); i += 256) yb[(size_t)(i / (ld - C)) * ld + C + i % (ld - C)] = 0.0f;
+        return;
+    }
     float s = 0.0f;
     for (int i = threadIdx.x; i < cnt; i += 256) s += xb[(size_t)(i / cg) * ld + g * cg + i % cg];
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
