@@ -2504,9 +2504,48 @@ __global__ __launch_bounds__(256) void k_flow_ln(const float* x, const float* w,
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * C;
+    const float* ad = add ? add + (size_t)(row / rows_per_req) * C : nullptr;
+    if (C == 256) {
+        // 256-channel rows (every LayerNorm of the CosyVoice2 estimator): lane (l16 = lane % 16, k = lane / 16) of ln_row_stats' scheme
+        // owns chunks l16, l16 + 16, l16 + 32, l16 + 48 — loaded once, both statistics passes run on the registers (same order: the
+        // lane's chunks ascending, then the 16-lane butterfly), and the chunk this lane writes (index `lane` = l16 + 16 k) is its k-th
+        const int l16 = lane & 15, kq = lane >> 4;
+        const float4* x4 = reinterpret_cast<const float4*>(xr);
+        const float4 c0 = x4[l16], c1 = x4[l16 + 16], c2 = x4[l16 + 32], c3 = x4[l16 + 48];
+        const float4 wv = reinterpret_cast<const float4*>(w)[lane], bv = reinterpret_cast<const float4*>(b)[lane];
+        float sm = 0.0f;
+        sm += (c0.x + c0.y) + (c0.z + c0.w); sm += (c1.x + c1.y) + (c1.z + c1.w);
+        sm += (c2.x + c2.y) + (c2.z + c2.w); sm += (c3.x + c3.y) + (c3.z + c3.w);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) sm += __shfl_xor(sm, off, 64);
+        const float mean = sm / 256.0f;
+        float vs = 0.0f;
+        {
+            float d0 = c0.x - mean, d1 = c0.y - mean, d2 = c0.z - mean, d3 = c0.w - mean;
+            vs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            d0 = c1.x - mean; d1 = c1.y - mean; d2 = c1.z - mean; d3 = c1.w - mean;
+            vs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            d0 = c2.x - mean; d1 = c2.y - mean; d2 = c2.z - mean; d3 = c2.w - mean;
+            vs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            d0 = c3.x - mean; d1 = c3.y - mean; d2 = c3.z - mean; d3 = c3.w - mean;
+            vs += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) vs += __shfl_xor(vs, off, 64);
+        const float rstd = rsqrtf(vs / 256.0f + eps);
+        const float4 xv = kq == 0 ? c0 : kq == 1 ? c1 : kq == 2 ? c2 : c3;
+        float o[4] = {(xv.x - mean) * rstd * wv.x + bv.x, (xv.y - mean) * rstd * wv.y + bv.y, (xv.z - mean) * rstd * wv.z + bv.z, (xv.w - mean) * rstd * wv.w + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (act == 1) o[e] = mish_f(o[e]);
+            o[e] *= post;
+        }
+        if (ad) { const float4 av = reinterpret_cast<const float4*>(ad)[lane]; o[0] += av.x; o[1] += av.y; o[2] += av.z; o[3] += av.w; }
+        reinterpret_cast<float4*>(y + (size_t)row * C)[lane] = make_float4(o[0], o[1], o[2], o[3]);
+        return;
+    }
     float mean, rstd;
     ln_row_stats(xr, C, lane & 15, eps, mean, rstd);
-    const float* ad = add ? add + (size_t)(row / rows_per_req) * C : nullptr;
     for (int i = lane; i < C / 4; i += 64) {
         const float4 xv = reinterpret_cast<const float4*>(xr)[i], wv = reinterpret_cast<const float4*>(w)[i], bv = reinterpret_cast<const float4*>(b)[i];
         float o[4] = {(xv.x - mean) * rstd * wv.x + bv.x, (xv.y - mean) * rstd * wv.y + bv.y, (xv.z - mean) * rstd * wv.z + bv.z, (xv.w - mean) * rstd * wv.w + bv.w};
