@@ -2497,14 +2497,15 @@ __global__ __launch_bounds__(256) void k_flow_embed(const int* ids, const float*
 }
 // y = act(LayerNorm(x) * w + b) * post + add[row / rows_per_req]      (act 0 none, 1 Mish)
 __global__ __launch_bounds__(256) void k_flow_ln(const float* x, const float* w, const float* b, float* y, int C, float eps, float post, int act,
-                                                  const float* add, int rows_per_req, int rows) {
+                                                  const float* add, int rows_per_req, int rows, int ldx = 0, int ld_add = 0) {
+    // ldx / ld_add: row strides of x and of add (0 = C): the ResNet blocks' first conv carries the residual conv as extra columns
     // one wave per row (4 rows per block): each of the wave's four 16-lane groups computes the row statistics (ln_row_stats: the bits the
     // fused-LayerNorm GEMMs get), then the 64 lanes apply them to one float4 chunk each per pass — a 112-row call is 28 blocks with 4 Mish
     // evaluations per lane instead of 7 blocks with 16
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const float* xr = x + (size_t)row * C;
-    const float* ad = add ? add + (size_t)(row / rows_per_req) * C : nullptr;
+    const float* xr = x + (size_t)row * (ldx ? ldx : C);
+    const float* ad = add ? add + (size_t)(row / rows_per_req) * (ld_add ? ld_add : C) : nullptr;
     if (C == 256) {
         // 256-channel rows (every LayerNorm of the CosyVoice2 estimator): lane (l16 = lane % 16, k = lane / 16) of ln_row_stats' scheme
         // owns chunks l16, l16 + 16, l16 + 32, l16 + 48 — loaded once, both statistics passes run on the registers (same order: the
@@ -3113,6 +3114,10 @@ struct vox_flow {
     size_t buf_floats = 0;
     float *spk = nullptr, *pe = nullptr, *pp = nullptr;
     int* slots = nullptr;                   // [2 * max_batch]: conv-state slot (= guidance half) of every estimator request row
+    // ResNet blocks: block1's causal conv with the block's residual 1-tap conv stacked behind it as C more output columns (its weight in
+    // the tap that reads the current row, zeros in the other taps): one launch less per ResNet block, 140 per chunk
+    std::vector<vox_conv_w> conv1x;
+    std::vector<void*> conv1x_mem;
     // static prompt caches
     float *enc_kv = nullptr, *up_kv = nullptr, *att_kv = nullptr, *cnn1 = nullptr, *cnn2 = nullptr;
     int enc_len = 0, up_len = 0, att_len = 0, cnn1_w = 0;
@@ -3137,6 +3142,7 @@ void vox_flow_destroy(vox_flow* m) {
     (void)hipFree(m->enc_kv); (void)hipFree(m->up_kv); (void)hipFree(m->att_kv); (void)hipFree(m->cnn1); (void)hipFree(m->cnn2);
     (void)hipFree(m->s_enc); (void)hipFree(m->s_up); (void)hipFree(m->s_att); (void)hipFree(m->s_cnn1); (void)hipFree(m->s_cnn2);
     (void)hipFree(m->s_eidx); (void)hipFree(m->s_cidx);
+    for (void* p : m->conv1x_mem) (void)hipFree(p);
     delete m;
 }
 
@@ -3275,15 +3281,21 @@ static int flow_run(vox_flow* m, hipStream_t st, const int32_t* tokens, int B, i
             float* st2 = (evolve ? m->s_cnn2 : m->cnn2) + ((size_t)s * m->n_res + r) * srows * 2 * C;
             if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * cin)), dim3(256), 0, st, in, st1, N, T2, cin, (const int*)nullptr);
             // block1: (cached) causal conv k3 -> LayerNorm -> Mish, + the time projection; block2 likewise; + res_conv(x)
-            VOX_TRY(conv_gemm(st, rw.conv1, in, init ? nullptr : st1, crow, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
+            const bool fold = !m->conv1x.empty();      // a1 = [block1 conv | res_conv(in)], 2 C wide
+            VOX_TRY(conv_gemm(st, fold ? m->conv1x[r] : rw.conv1, in, init ? nullptr : st1, crow, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
             if (evolve) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * cin)), dim3(256), 0, st, in, st1, N, T2, cin, crow);
             hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 3) / 4), dim3(256), 0, st, a1, rw.ln1_w, rw.ln1_b, a2, C, 1e-5f, 1.0f, 1,
-                               m->tb + ((size_t)s * m->n_res + r) * C, N * T2, N * T2);
+                               m->tb + ((size_t)s * m->n_res + r) * C, N * T2, N * T2, fold ? 2 * C : 0, 0);
             if (init) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * C)), dim3(256), 0, st, a2, st2, N, T2, C, (const int*)nullptr);
-            VOX_TRY(conv_gemm(st, rw.conv2, a2, init ? nullptr : st2, crow, N, T2, 2, FLOW_OFF_C3, a1, nullptr, nullptr, 0));
+            VOX_TRY(conv_gemm(st, rw.conv2, a2, init ? nullptr : st2, crow, N, T2, 2, FLOW_OFF_C3, fold ? a3 : a1, nullptr, nullptr, 0));
             if (evolve) hipLaunchKernelGGL(k_flow_tail2, dim3(ew_grid((size_t)N * 2 * C)), dim3(256), 0, st, a2, st2, N, T2, C, crow);
-            hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 3) / 4), dim3(256), 0, st, a1, rw.ln2_w, rw.ln2_b, a2, C, 1e-5f, 1.0f, 1, nullptr, 1, N * T2);
-            VOX_TRY(conv_gemm(st, rw.res, in, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, a2, nullptr, 0));       // h = block2 + res_conv(in)
+            if (fold) {      // h = Mish(LayerNorm(block2 conv)) + res_conv(in)
+                hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 3) / 4), dim3(256), 0, st, a3, rw.ln2_w, rw.ln2_b, h, C, 1e-5f, 1.0f, 1, a1 + C, 1, N * T2, 0,
+                                   2 * C);
+            } else {
+                hipLaunchKernelGGL(k_flow_ln, dim3((N * T2 + 3) / 4), dim3(256), 0, st, a1, rw.ln2_w, rw.ln2_b, a2, C, 1e-5f, 1.0f, 1, nullptr, 1, N * T2);
+                VOX_TRY(conv_gemm(st, rw.res, in, nullptr, nullptr, N, T2, 0, FLOW_OFF0, h, a2, nullptr, 0));       // h = block2 + res_conv(in)
+            }
             for (int j = 0; j < c.est_blocks; ++j, ++li) {
                 const vox_flow_tblock_w& tw = m->tblocks[li];
                 float* kv = (evolve ? m->s_att : m->att_kv) + ((size_t)s * m->n_att + li) * att_layer;
@@ -3358,6 +3370,25 @@ int vox_flow_create(vox_ctx* ctx, const vox_flow_config* cfg, const vox_flow_wei
     alloc(&m->cnn1, (size_t)c.n_steps * m->n_res * 4 * m->cnn1_w);
     alloc(&m->cnn2, (size_t)c.n_steps * m->n_res * 4 * C);
     ok = ok && hipMalloc((void**)&m->slots, (size_t)2 * (max_batch > 1 ? max_batch : 1) * 4) == hipSuccess;
+    static const bool resfold = [] { const char* e = getenv("VOX_FLOW_RESFOLD"); return !(e && e[0] == '0'); }();
+    for (int r = 0; r < m->n_res && ok && resfold; ++r) {
+        const vox_flow_resnet_w& rw = m->resnets[r];
+        if (rw.conv1.n_taps != 3 || rw.res.n_taps != 1 || rw.conv1.n != C || rw.res.n != C || rw.conv1.cin != rw.res.cin) { m->conv1x.clear(); break; }
+        const size_t cin = rw.conv1.cin, blk = (size_t)C * cin * 2;      // bytes of one tap's [C][cin] bf16 block
+        char* wx = nullptr; float* bx = nullptr;
+        ok = hipMalloc((void**)&wx, 3 * 2 * blk) == hipSuccess && hipMalloc((void**)&bx, (size_t)2 * C * 4) == hipSuccess;
+        if (wx) m->conv1x_mem.push_back(wx);
+        if (bx) m->conv1x_mem.push_back(bx);
+        if (!ok) break;
+        (void)hipMemset(wx, 0, 3 * 2 * blk); (void)hipMemset(bx, 0, (size_t)2 * C * 4);
+        for (int t = 0; t < 3; ++t) (void)hipMemcpy(wx + (size_t)t * 2 * blk, (const char*)rw.conv1.w + (size_t)t * blk, blk, hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(wx + (size_t)2 * 2 * blk + blk, rw.res.w, blk, hipMemcpyDeviceToDevice);      // FLOW_OFF_C3: tap 2 reads the current row
+        if (rw.conv1.bias) (void)hipMemcpy(bx, rw.conv1.bias, (size_t)C * 4, hipMemcpyDeviceToDevice);
+        if (rw.res.bias) (void)hipMemcpy(bx + C, rw.res.bias, (size_t)C * 4, hipMemcpyDeviceToDevice);
+        vox_conv_w cx = rw.conv1;
+        cx.w = wx; cx.bias = bx; cx.n = 2 * C; cx.bias_mod = 0;
+        m->conv1x.push_back(cx);
+    }
     if (!ok) { vox_flow_destroy(m); return vox_fail(VOX_ERR_NOMEM, "flow_create: hipMalloc failed"); }
     // time projections of every Euler step and resnet, once: tb[s][r] = mlp_r(Mish(linear_2(SiLU(linear_1(emb_s)))))
     hipStream_t st = nullptr;
