@@ -565,7 +565,14 @@ __device__ __forceinline__ bf16x8_t as_bf8(uint4 v) {
 
 // FULL: K % MF_KS == 0 and N % 16 == 0 — every range guard compiles away (at one wave per SIMD the kernel is
 // instruction-issue bound, each guard is a divergent-branch sequence); padded batch rows re-read the last real row.
-template <int MT, int PRO, int EPI, bool FULL, int KSEG>
+// DEPTH > 1: that many weight segments in flight (a ring of DEPTH register buffers, the loop unrolled DEPTH times so that every buffer
+// index is static): iteration s requests the activations of s + 1 and then the weights of s + DEPTH.  vmcnt retires in order, so the
+// wait for x(s + 1) also waits for every weight segment requested before it, i.e. w(j) is complete DEPTH - 1 iterations after its
+// request: with DEPTH = 3 and 1024-wide segments a segment has ~2 iterations (about the HBM latency) to arrive, 96 KB per CU in flight.
+// Measured on the 13 696-wide GLM down projection: slower than one 2048-wide segment in flight (see launch_linear_mfma_pe); opt-in.
+// Which k-steps a wave multiplies and in which order is unchanged: bit-identical.
+template <int B_> struct vox_ic { static constexpr int value = B_; };
+template <int MT, int PRO, int EPI, bool FULL, int KSEG, int DEPTH = 1>
 __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BT = 16 * MT;
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
         constexpr int U = KSEG / 32 / 4;
         constexpr int RPW = BT / 4;          // activation rows staged per wave
         constexpr int CPL = KSEG / 8 / 64;  // 16-byte chunks per lane per row
-        uint4 wv[U], wv2[U], xv[RPW][CPL], gv[CPL];
+        uint4 wv[DEPTH][U], wv2[DEPTH][U], xv[RPW][CPL], gv[CPL];
         auto issue_x = [&](int k0, int ks) {
             const int nch = ks >> 3;
 #pragma unroll
@@ -615,13 +622,14 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
                 }
             }
         };
-        auto issue_w = [&](int k0, int ks) {
+        auto issue_w = [&](auto BUF, int k0, int ks) {
+            constexpr int wb = decltype(BUF)::value;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int kk = 32 * wave + 128 * u;
                 if (FULL || kk < ks) {
-                    wv[u] = ldg_nt(reinterpret_cast<const uint4*>(wrow + k0 + kk + fk));
-                    if (EPI == EPI_SILU_MUL) wv2[u] = ldg_nt(reinterpret_cast<const uint4*>(wrow2 + k0 + kk + fk));
+                    wv[wb][u] = ldg_nt(reinterpret_cast<const uint4*>(wrow + k0 + kk + fk));
+                    if (EPI == EPI_SILU_MUL) wv2[wb][u] = ldg_nt(reinterpret_cast<const uint4*>(wrow2 + k0 + kk + fk));
                 }
             }
         };
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
         if (one_seg) {
             __syncthreads();
             issue_x(0, ks_first);
-            issue_w(0, ks_first);
+            issue_w(vox_ic<0>{}, 0, ks_first);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int b = wave + 4 * r;
@@ -682,9 +690,12 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
         }
         {
             const int ks0 = a.K < KSEG ? a.K : KSEG;
-            if (!one_seg) { issue_x(0, ks0); issue_w(0, ks0); }
+            if (!one_seg) { issue_x(0, ks0); issue_w(vox_ic<0>{}, 0, ks0); }
+            if constexpr (DEPTH > 1) { if (KSEG < a.K) issue_w(vox_ic<1>{}, KSEG, (a.K - KSEG) < KSEG ? (a.K - KSEG) : KSEG); }
+            if constexpr (DEPTH > 2) { if (2 * KSEG < a.K) issue_w(vox_ic<2>{}, 2 * KSEG, (a.K - 2 * KSEG) < KSEG ? (a.K - 2 * KSEG) : KSEG); }
         }
-        for (int k0 = 0; k0 < a.K; k0 += KSEG) {
+        auto body = [&](auto BUF, int k0) {
+            constexpr int wb = decltype(BUF)::value;
             const int ks = (a.K - k0) < KSEG ? (a.K - k0) : KSEG;
             const int nch = ks >> 3;
             __syncthreads();   // the previous segment's MFMAs are done with the LDS tile
@@ -710,13 +721,16 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
             uint4 cw[U], cw2[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                cw[u] = wv[u];
-                if (EPI == EPI_SILU_MUL) cw2[u] = wv2[u];
+                cw[u] = wv[wb][u];
+                if (EPI == EPI_SILU_MUL) cw2[u] = wv2[wb][u];
             }
             if (k0 + KSEG < a.K) {
                 const int nks = (a.K - k0 - KSEG) < KSEG ? (a.K - k0 - KSEG) : KSEG;
                 issue_x(k0 + KSEG, nks);
-                issue_w(k0 + KSEG, nks);
+            }
+            if (k0 + DEPTH * KSEG < a.K) {      // (behind the activations of the next segment: they are needed first)
+                const int kd = k0 + DEPTH * KSEG, nkd = (a.K - kd) < KSEG ? (a.K - kd) : KSEG;
+                issue_w(BUF, kd, nkd);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -731,6 +745,11 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
                     }
                 }
             }
+        };
+        for (int k0 = 0; k0 < a.K;) {
+            body(vox_ic<0>{}, k0); k0 += KSEG;
+            if constexpr (DEPTH > 1) { if (k0 >= a.K) break; body(vox_ic<1>{}, k0); k0 += KSEG; }
+            if constexpr (DEPTH > 2) { if (k0 >= a.K) break; body(vox_ic<2>{}, k0); k0 += KSEG; }
         }
         // cross-wave reduction (fixed order: wave 0 + 1 + 2 + 3), then wave 0 runs the epilogue
         __syncthreads();
@@ -780,11 +799,11 @@ __global__ __launch_bounds__(256) void k_linear_mfma(LinArgs a) {
     }
 }
 
-template <int MT, int PRO, int EPI, bool FULL, int KSEG>
+template <int MT, int PRO, int EPI, bool FULL, int KSEG, int DEPTH = 1>
 static int launch_linear_mfma_t(hipStream_t st, const LinArgs& a) {
     constexpr int BT = 16 * MT;
     const size_t smem = (size_t)BT * (KSEG + 8) * 2 + BT * 4;
-    auto kern = k_linear_mfma<MT, PRO, EPI, FULL, KSEG>;
+    auto kern = k_linear_mfma<MT, PRO, EPI, FULL, KSEG, DEPTH>;
     if (smem > 64 * 1024) {
         static bool done = false;
         if (!done) {
@@ -808,6 +827,16 @@ static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a_in) {
     static const bool oneseg_off = [] { const char* e = getenv("VOX_MFMA_ONESEG"); return e && e[0] == '0'; }();
     LinArgs a = a_in;
     a.no_one_seg = oneseg_off ? 1 : 0;
+    // long K, plain store (GLM's down projection): three 1024-wide weight segments in flight — measured SLOWER than the 2048-wide walk
+    // with one segment in flight (GLM-4-Voice B=8 LM step 5.60 -> 5.71 ms: the per-segment barriers and LDS writes, not the exposed
+    // latency, are what the staged kernel pays); kept behind VOX_MFMA_DEPTH=3 as an A/B form, bit-identical
+    static const bool deep = [] { const char* e = getenv("VOX_MFMA_DEPTH"); return e && atoi(e) == 3; }();
+    if constexpr (PRO == PRO_COPY && EPI == EPI_STORE) {
+        if (a.B <= 16 && a.K >= 4096 && deep) {
+            const bool full1 = (a.K % MF_KS == 0) && (a.N % 16 == 0);
+            return full1 ? launch_linear_mfma_t<1, PRO, EPI, true, MF_KS, 3>(st, a) : launch_linear_mfma_t<1, PRO, EPI, false, MF_KS, 3>(st, a);
+        }
+    }
     if (a.B <= 16 && a.K >= 4096 && mfma_wide_seg()) {
         const bool full2 = (a.K % 2048 == 0) && (a.N % 16 == 0);
         return full2 ? launch_linear_mfma_t<1, PRO, EPI, true, 2048>(st, a) : launch_linear_mfma_t<1, PRO, EPI, false, 2048>(st, a);
