@@ -1996,6 +1996,11 @@ int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
         hipLaunchKernelGGL((k_attn_decode8<128, 2, 8>), dim3(c.Hkv * 8, c.Nq), dim3(1024), 0, st, a);
         return VOX_OK;
     }
+    // CosyVoice2's 7-head groups on 2 kv heads (2 blocks per row): one block per q head
+    if (c.D == 64 && G == 7 && split_on) {
+        hipLaunchKernelGGL((k_attn_decode8<64, 1, 8>), dim3(c.Hkv * 7, c.Nq), dim3(1024), 0, st, a);
+        return VOX_OK;
+    }
     const dim3 grid(c.Hkv, c.Nq);
 #define VOX_AD(D_, G_, NG_) if (c.D == D_ && G == G_) { hipLaunchKernelGGL((k_attn_decode8<D_, G_, NG_>), grid, dim3(1024), 0, st, a); return VOX_OK; }
     VOX_AD(128, 2, 8) VOX_AD(128, 16, 4) VOX_AD(64, 4, 8) VOX_AD(64, 7, 8)
