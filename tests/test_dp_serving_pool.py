@@ -1,0 +1,127 @@
+"""CPU tests of the online data-parallel serving pool (vox_serve_amd/launch.py, scheduler_entry.py, ipc.py) against the
+behaviour of /root/reference/vox_serve/launch.py:183-279, 355-415, 460-474 and scheduler_entry.py:1-105: one daemon per
+rank with the device mask set before torch is imported, request i on rank i % dp_size over per-rank request transports,
+one shared result transport demultiplexed by request id, children terminated on exit; DP-2 PCM == single-process PCM."""
+import json
+import os
+import subprocess
+import sys
+import threading
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ipc_push_pull_frames_and_fan_in(tmp_path):
+    from vox_serve_amd.ipc import PullSocket, PushSocket, TransportBusy
+    path = str(tmp_path / "r.ipc")
+    push = PushSocket(path)
+    with pytest.raises(TransportBusy):          # nobody listening yet: DONTWAIT semantics
+        push.send(b"x")
+    pull = PullSocket(path)
+    msgs = [b"", b"a|AUDIO|" + bytes(range(256)) * 300, b"tail"]
+    for m in msgs:
+        push.send(m)
+    other = PushSocket(path)
+    other.send(b"from-second-peer")
+    got = []
+    t0 = time.time()
+    while len(got) < 4 and time.time() - t0 < 5:
+        m = pull.recv(0.1)
+        if m is not None:
+            got.append(m)
+    assert sorted(got) == sorted(msgs + [b"from-second-peer"])
+    assert [g for g in got if g != b"from-second-peer"] == msgs          # per-peer order kept
+    assert pull.recv(0.0) is None
+    push.close(); other.close(); pull.close()
+    assert not os.path.exists(path)
+
+
+def test_visible_gpu_mapping_respects_a_preset_mask():
+    from vox_serve_amd.launch import visible_gpu_mapping
+    assert visible_gpu_mapping(3, env={}) == [0, 1, 2]
+    assert visible_gpu_mapping(2, env={"HIP_VISIBLE_DEVICES": "4,5,6"}) == [4, 5]
+    assert visible_gpu_mapping(2, env={"CUDA_VISIBLE_DEVICES": "7, 3"}) == [7, 3]
+    with pytest.raises(ValueError):
+        visible_gpu_mapping(4, env={"HIP_VISIBLE_DEVICES": "0,1"})
+
+
+def test_scheduler_entry_does_not_import_torch_at_module_level():
+    code = ("import sys; sys.path.insert(0, %r); import vox_serve_amd.scheduler_entry, vox_serve_amd.launch; "
+            "print('torch' in sys.modules)" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "False", out.stdout + out.stderr
+
+
+def _single_process_pcm(prompts):
+    from tests.dp_fake_worker import make
+    from vox_serve_amd.scheduler import QueueTransport, Scheduler, encode_request
+    t = QueueTransport()
+    s = Scheduler(make(), max_batch_size=8, transport=t)
+    for i, p in enumerate(prompts):
+        t.requests.put(encode_request(f"req{i}", p))
+    s.run_until_idle(2000)
+    pcm = {}
+    while not t.results.empty():
+        rid, kind, data = t.results.get().split(b"|", 2)
+        if kind == b"AUDIO":
+            pcm[rid.decode()] = pcm.get(rid.decode(), b"") + data
+    return pcm
+
+
+@pytest.mark.timeout(300)
+def test_two_daemons_round_robin_demux_and_lifecycle(monkeypatch):
+    from vox_serve_amd.launch import ServingPool
+    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):     # (an empty mask in the build container means "no GPU")
+        monkeypatch.delenv(k, raising=False)
+    prompts = ["hello", "a", "bc", "the quick brown fox", "xyz", "12345", "q"]
+    env = {"VOX_TRANSPORT": "ipc", "PYTHONPATH": ROOT}
+    pool = ServingPool("fake", dp_size=2, max_batch_size=8, page_size=4, max_num_pages=64,
+                       worker_factory="tests.dp_fake_worker:make", extra_env=env, ready_timeout_s=240.0)
+    try:
+        assert sorted(pool.ready) == [0, 1]
+        # every daemon got ONE device in its mask, set before its interpreter started
+        assert [pool.ready[r]["visible_devices"] for r in (0, 1)] == ["0", "1"]
+        pids = [p.pid for p in pool.scheduler_processes]
+        assert sorted(pool.ready[r]["pid"] for r in (0, 1)) == sorted(pids)
+        # submit one at a time so that the router's counter order is the submission order
+        rids = []
+        for i, p in enumerate(prompts):
+            rids.append(pool.start_streaming_request(p, request_id=f"req{i}", block=True))
+            t0 = time.time()
+            while pool.request_info(rids[-1])["rank"] is None and time.time() - t0 < 10:
+                time.sleep(0.002)
+        got = {}
+        lock = threading.Lock()
+
+        def consume(rid):
+            data = b"".join(pool.stream(rid, timeout_s=120))
+            with lock:
+                got[rid] = data
+        ths = [threading.Thread(target=consume, args=(r,)) for r in rids]
+        [t.start() for t in ths]
+        [t.join(150) for t in ths]
+        assert sorted(got) == sorted(rids)
+        assert [pool.request_info(r)["rank"] for r in rids] == [i % 2 for i in range(len(rids))]      # launch.py:471-474
+        for r in rids:
+            assert pool.completion(r) == {"status": "completed", "reason": "stop_id_encountered"}
+        single = _single_process_pcm(prompts)
+        assert got == single                                   # DP-2 PCM == single-process PCM, per request id
+        assert all(len(v) > 0 for v in got.values())
+    finally:
+        procs = list(pool.scheduler_processes)
+        pool.cleanup()
+    assert all(p.poll() is not None for p in procs)            # children terminated (or killed) on exit
+    assert not os.path.exists(pool.result_socket_path)
+
+
+@pytest.mark.timeout(120)
+def test_pool_reports_a_daemon_that_dies_during_startup(monkeypatch):
+    from vox_serve_amd.launch import ServingPool
+    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(RuntimeError):
+        ServingPool("fake", dp_size=1, worker_factory="tests.no_such_module:make", extra_env={"VOX_TRANSPORT": "ipc"},
+                    ready_timeout_s=60.0)

@@ -1572,6 +1572,23 @@ int vox_launch_head_prepare(hipStream_t st, const HeadCall& c) {
     return VOX_OK;
 }
 
+#ifdef VOX_DEV_KNOBS
+// development builds: phase time stamps (s_memrealtime, 100 MHz) of block (0, 0) of the one-launch decode attention;
+// slot 0 of the buffer counts launches, launch i writes stamps [16 * (i + 1) .. ).  Set with vox_dev_set_stamps().
+__device__ unsigned long long* g_vox_stamps = nullptr;
+extern "C" int vox_dev_set_stamps(void* p) {
+    unsigned long long* q = (unsigned long long*)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_vox_stamps), &q, sizeof(q)) == hipSuccess ? 0 : -1;
+}
+#define VOX_STAMP_DECL unsigned long long* stamp_base = nullptr; \
+    if (g_vox_stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { \
+        const unsigned long long li = atomicAdd(g_vox_stamps, 1ull); stamp_base = li < 4000 ? g_vox_stamps + 16 * (li + 1) : nullptr; }
+#define VOX_STAMP(k) if (stamp_base) stamp_base[k] = wall_clock64();
+#else
+#define VOX_STAMP_DECL
+#define VOX_STAMP(k)
+#endif
+
 // ================================================================================================
 // chunked paged attention: one block per (chunk of 32 KV tokens, kv head, query row)
 // ================================================================================================
@@ -1598,6 +1615,7 @@ struct AttnArgs {
     int identity_pages;  // 1: request r owns the single page r and q_req[row] == row (depth loop)
     bf16_t* out;   // single-chunk launches write the final bf16 output here (merge of one chunk == o/l)
     bf16_t* out_frag;   // optional fragment-major copy of the output (see LinearCall)
+    int hoist;          // 1: page ids requested before the row length is known (k_attn_decode8 with a per-row page table)
 };
 
 // norm (optional) + rope of one head held as one 16-byte chunk per lane (lanes < LPT); result as bf16 bits in
@@ -1837,13 +1855,30 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
 
     // head split: gridDim.x = Hkv * HS blocks per row, block (hk, hs) takes q heads hs * G .. hs * G + G - 1 of kv head hk's group
     const int HS = gridDim.x / a.Hkv, hk = blockIdx.x / HS, hs = blockIdx.x % HS, row = blockIdx.y;
-    const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
-    const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..8
-    const int Gf = a.Hq / a.Hkv, G = Gf / HS, g0 = hs * G;
+    VOX_STAMP_DECL
+    VOX_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63, wave16 = tid >> 6;
     const int grp = tid / GT, gt = tid % GT, gw = wave16 % GW;
     const int* pages = a.identity_pages ? nullptr
                        : (a.ptab ? a.ptab + (size_t)row * a.pt_stride : a.indices + a.indptr[a.q_req[row]]);
+    // per-row page table: the page ids of this thread's tokens do not depend on the row's length, so they are requested
+    // together with it (one exposed round trip in front of the K/V loads instead of two); entries past the row's last page are
+    // read (clamped to the table row) and never used
+    int pgi_pre[CPG][KVL];
+    const bool hoist = a.ptab && a.hoist;
+    if (hoist) {
+#pragma unroll
+        for (int ci = 0; ci < CPG; ++ci)
+#pragma unroll
+            for (int u = 0; u < KVL; ++u) {
+                const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT;
+                const int pi = tok / a.page_size;
+                pgi_pre[ci][u] = pages[pi < a.pt_stride ? pi : a.pt_stride - 1];
+            }
+    }
+    const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
+    const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..8
+    const int Gf = a.Hq / a.Hkv, G = Gf / HS, g0 = hs * G;
     const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
 
     // K/V tiles of this group's chunks (the row's newest token, index L - 1, comes from the projection output instead)
@@ -1858,13 +1893,14 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             vreg[ci][u] = kreg[ci][u];
             const int tok = t0 + t;
             if (i < VOX_TC * LPT && tok < L - 1) {
-                const int pgi = pages ? pages[tok / a.page_size] : row;
+                const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[tok / a.page_size] : row);
                 const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
                 kreg[ci][u] = reinterpret_cast<const uint4*>(base)[j];
                 vreg[ci][u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
             }
         }
     }
+    VOX_STAMP(1)
     {   // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave
         const int nqkv = (a.Hq + 2 * a.Hkv) * D;
         const bf16_t* raw = a.qkv + (size_t)row * nqkv;
@@ -1878,6 +1914,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, Sh + wave16 * D, dst, lane);
         }
     }
+    VOX_STAMP(2)
 #pragma unroll
     for (int ci = 0; ci < CPG; ++ci) {
         const int c = grp + NG * ci, t0 = c * VOX_TC;
@@ -1891,6 +1928,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             if (i < VOX_TC * LPT) { Ks[grp][i] = kreg[ci][u]; Vs[grp][i] = vreg[ci][u]; }
         }
         __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
+        VOX_STAMP(3)
         if (own_last) {
             // place the new token into the tile and append it to the paged cache (page < 0: graph padding row)
             const bf16_t* vraw = a.qkv + (size_t)row * (a.Hq + 2 * a.Hkv) * D + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D;
@@ -1909,6 +1947,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             }
         }
         __syncthreads();
+        VOX_STAMP(4)
         if (live) {      // scores: LPT lanes per token, butterfly over LPT lanes
 #pragma unroll
             for (int tb = gw * TPW; tb < VOX_TC; tb += GW * TPW) {
@@ -1922,6 +1961,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             }
         }
         __syncthreads();
+        VOX_STAMP(5)
         if (live) {      // chunk max + p = exp2((s-m)*log2e): 32 lanes per q head
             for (int pr = gt; pr < G * VOX_TC; pr += GT) {
                 const int g = pr / VOX_TC, t = pr % VOX_TC;
@@ -1935,6 +1975,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             }
         }
         __syncthreads();
+        VOX_STAMP(6)
         if (live) {      // PV: one thread per (q head, d); sequential over the tokens of the (zero-padded) tile
             const bf16_t* Vb = reinterpret_cast<const bf16_t*>(Vs[grp]);
             for (int e = gt; e < G * D; e += GT) {
@@ -1952,6 +1993,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
         }
     }
     __syncthreads();
+    VOX_STAMP(7)
     // merge (k_attn_merge): global max, then L and O over the chunks in ascending order
     for (int e = tid; e < G * D; e += 1024) {
         const int g = e / D, d = e % D;
@@ -1967,6 +2009,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
         a.out[((size_t)row * a.Hq + h) * D + d] = r;
         if (a.out_frag) a.out_frag[frag_off(row, h * D + d, a.Hq * D)] = r;
     }
+    VOX_STAMP(8)
 }
 
 // true when the one-launch decode attention covers the call (fused decode rows, <= 8 chunks, a supported head shape)
@@ -1988,6 +2031,8 @@ int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
     a.ptab = c.ptab; a.pt_stride = c.pt_stride; a.fixed_kvlen = c.fixed_kvlen; a.fixed_pos = c.fixed_pos;
     a.identity_pages = c.identity_pages;
     a.out = (bf16_t*)c.out; a.out_frag = (bf16_t*)c.out_frag;
+    static const int hoist_on = [] { const char* e = getenv("VOX_ATTN_HOIST"); return !(e && e[0] == '0'); }();
+    a.hoist = hoist_on;
     const int G = c.Hq / c.Hkv;
     // 16-head groups (GLM-4-Voice: 2 kv heads, so 2 blocks per row): eight blocks of two q heads per kv head, each with all 8 chunks in
     // flight — the per-(row, head) arithmetic does not depend on which heads share a block (VOX_ATTN_HEADSPLIT=0: one block per kv head)
@@ -1999,6 +2044,12 @@ int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
     // CosyVoice2's 7-head groups on 2 kv heads (2 blocks per row): one block per q head
     if (c.D == 64 && G == 7 && split_on) {
         hipLaunchKernelGGL((k_attn_decode8<64, 1, 8>), dim3(c.Hkv * 7, c.Nq), dim3(1024), 0, st, a);
+        return VOX_OK;
+    }
+    // two-head groups (Qwen3-TTS talker, CSM, Orpheus) at few rows: one block per q head (Hq blocks per row instead of Hkv)
+    static const int hs2_rows = [] { const char* e = getenv("VOX_ATTN_HS2_ROWS"); return e ? atoi(e) : 0; }();
+    if (c.D == 128 && G == 2 && c.Nq <= hs2_rows) {
+        hipLaunchKernelGGL((k_attn_decode8<128, 1, 8>), dim3(c.Hkv * 2, c.Nq), dim3(1024), 0, st, a);
         return VOX_OK;
     }
     const dim3 grid(c.Hkv, c.Nq);

@@ -34,6 +34,9 @@ class QueueTransport:
         if self.on_send is not None:
             self.on_send(payload)
 
+    def pending(self) -> bool:
+        return not self.requests.empty()
+
 
 class ZmqTransport:
     def __init__(self, request_socket_path="/tmp/vox_serve_request.ipc", result_socket_path="/tmp/vox_serve_result.ipc"):
@@ -56,6 +59,9 @@ class ZmqTransport:
 
     def send_result(self, payload: bytes):
         self.result_socket.send(payload)
+
+    def pending(self) -> bool:
+        return bool(self.request_socket.poll(0))
 
 
 class Scheduler:
@@ -214,7 +220,7 @@ class Scheduler:
             for _ in range(max_steps):
                 task, lm_requests, detokenize_requests = await self._step_async(task, lm_requests, detokenize_requests)
                 await asyncio.sleep(0)
-                if until_idle and not self.active_requests and self.transport.requests.empty() and not lm_requests:
+                if until_idle and not self.active_requests and not self.transport.pending() and not lm_requests:
                     break
             if task is not None:
                 await task
@@ -223,12 +229,16 @@ class Scheduler:
                 self.model_worker.drain()
             self.model_worker.async_scheduling = False
 
+    idle_sleep_s = 0.0          # > 0: a step that finds nothing to do sleeps this long (the reference spins; the DP daemons set 0.5 ms)
+
     def run_forever(self):
         if self.async_scheduling:
             import asyncio
             asyncio.run(self._run_async_loop())
         while True:
             self._step()
+            if self.idle_sleep_s > 0 and not self.active_requests and not self.transport.pending():
+                time.sleep(self.idle_sleep_s)
 
     def run_until_idle(self, max_steps: int = 100000):
         if self.async_scheduling:
@@ -237,7 +247,7 @@ class Scheduler:
             return
         for _ in range(max_steps):
             self._step()
-            if not self.active_requests and self.transport.requests.empty():
+            if not self.active_requests and not self.transport.pending():
                 return
 
     # ---- selection policies ----

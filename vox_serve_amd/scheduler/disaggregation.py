@@ -152,7 +152,7 @@ class DisaggregationScheduler(Scheduler):
         try:
             while time.time() - t0 < timeout_s and not self._stop.is_set():
                 with self.requests_lock:
-                    idle = not self.active_requests and self.transport.requests.empty()
+                    idle = not self.active_requests and not self.transport.pending()
                 if idle and self.detokenize_queue.empty() and not self.detokenizing_request_ids:
                     return
                 time.sleep(0.002)
