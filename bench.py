@@ -244,13 +244,54 @@ def pmc_traffic(B):
     return None, None
 
 
+class _StubEvent:
+    def __init__(self, t):
+        self.t = t
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class StubLoop:
+    """--dry-run: the launch / barrier / max-over-ranks / JSON path of this file with no GPU behind it (gloo on CPU): a step
+    sleeps 1 ms instead of replaying a frame.  Nothing it prints is a measurement."""
+
+    class _Closable:
+        def close(self):
+            pass
+
+        def release_cache(self, _):
+            pass
+
+    def __init__(self, B, max_frames, dev, W=None, codec_W=None):
+        self.B, self.kvlen, self.samples, self.interval = B, [0] * B, 0, INTERVAL
+        self.eng = self.codec = self._Closable()
+        self.cache = None
+
+    def start_requests(self):
+        self.kvlen = [PROMPT_TOKENS] * self.B
+
+    def step(self, timed_events=None, wait_pcm=False):
+        t0 = time.perf_counter()
+        time.sleep(0.001)
+        self.kvlen = [k + 1 for k in self.kvlen]
+        if timed_events is not None:
+            timed_events.append((_StubEvent(t0), _StubEvent(time.perf_counter())))
+        return None, (np.zeros(1, np.int16) if wait_pcm else None)
+
+    def collect_pcm(self):
+        return None
+
+
 def run_batch(B, args, dev, world, shared, ttfa_requests=0):
     """The timed region for one batch size: W warm-up steps, a barrier, exactly K steps, barrier, max over ranks."""
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
+    dry = getattr(args, "dry_run", False)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     # requests are measured mid-stream: the KV length over the timed steps averages --kv-mean (SURVEY 8d: 200)
     pre = max(0, int(args.kv_mean - PROMPT_TOKENS - args.warmup - args.steps / 2))
-    loop = Loop(B, pre + args.steps + args.warmup + 64, dev, shared["W"], shared["codec_W"])
+    loop = (StubLoop if dry else Loop)(B, pre + args.steps + args.warmup + 64, dev, shared["W"], shared["codec_W"])
     ttfa, ttfa2 = [], []
     if ttfa_requests > 0 and B == 1:
         # engine-level TTFA (request start -> first PCM chunk on the host), lock-step loop, outside the timed steps
@@ -258,7 +299,7 @@ def run_batch(B, args, dev, world, shared, ttfa_requests=0):
             loop.interval = interval
             for _ in range(ttfa_requests + 1):
                 loop.kvlen, loop.samples = [0] * B, 0
-                torch.cuda.synchronize()
+                sync()
                 t0 = time.perf_counter()
                 loop.start_requests()
                 pcm = None
@@ -272,7 +313,7 @@ def run_batch(B, args, dev, world, shared, ttfa_requests=0):
     loop.start_requests()
     for _ in range(pre + args.warmup):
         loop.step()
-    torch.cuda.synchronize()
+    sync()
     if use_dist:
         dist.barrier()
     loop.samples = 0
@@ -282,7 +323,7 @@ def run_batch(B, args, dev, world, shared, ttfa_requests=0):
     for _ in range(args.steps):
         loop.step(events)
     loop.collect_pcm()                     # the last chunk's audio must be on the host inside the timed region
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
@@ -308,6 +349,52 @@ def run_batch(B, args, dev, world, shared, ttfa_requests=0):
     loop.eng.close()
     loop.codec.close()
     return res
+
+
+def kv_sweep(dev, shared, batches=(1, 32), kvs=(100, 200, 325, 1000, 2000), frames=20):
+    """LM frame (one hipGraph replay, HIP events on the engine's stream) at fixed visible lengths, the KV state injected as random
+    pages: kv 100 / 200 sit in the one-launch decode attention (<= 256 visible tokens), 325 is the END of SURVEY 8d's 250-frame
+    request and 1000 / 2000 the long requests `max_tokens` = 2048 allows (qwen3_tts.py:1187-1191) — those run the chunked
+    partial + merge attention.  Per kv: ms per frame and the roofline fraction with that kv's KV bytes."""
+    from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
+    cfg, ps, out = Qwen3Cfg(), 128, {}
+    for B in batches:
+        ppr = (max(kvs) + frames + 8 + ps - 1) // ps + 1
+        eng = Qwen3Engine(cfg, shared["W"], max_batch=B, page_size=ps, max_pages=B * ppr + 1, max_seq_len=2304, max_prefill_rows=128)
+        eng.keep_hidden = False
+        for b0 in range(0, B * ppr, 16):
+            eng.kv[:, b0:b0 + 16].normal_(0, 0.5)
+        sc = eng.sampling_cfg(greedy=True)
+        eng.input_ids.zero_(); eng.input_ids[:, -1] = cfg.tts_pad_id
+        eng.input_masks[:B] = 1
+
+        def plan(kvlen):
+            pages = [[b * ppr + j for j in range((kvlen + ps - 1) // ps)] for b in range(B)]
+            indptr = np.cumsum([0] + [len(p) for p in pages]); indices = sum(pages, [])
+            eng.upload_plan(pos=[kvlen] * B, kvlen=[kvlen] * B, page=[p[-1] for p in pages], slot=[(kvlen - 1) % ps] * B,
+                            indptr=indptr, indices=indices)
+        res = {}
+        for kvl in kvs:
+            for w_ in range(3):
+                plan(kvl + w_); eng.frame(B, kvl + w_, sc, feedback=True, use_graph=True)
+            torch.cuda.synchronize()
+            ms = []
+            for f in range(frames):
+                plan(kvl + 3 + f)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(eng.stream)
+                eng.frame(B, kvl + 3 + f, sc, feedback=True, use_graph=True)
+                ev1.record(eng.stream)
+                eng.out_ids[:B].cpu()
+                ms.append(ev0.elapsed_time(ev1))
+            t = float(np.mean(ms)) * 1e-3
+            alg = algorithmic_bytes_per_frame(B, kvl + 3 + frames / 2)
+            res[f"kv{kvl}"] = {"frame_ms": t * 1e3, "samples_per_s_lm_only": B * 1920 / t, "roofline_frac": alg / t / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_launch": alg}
+        out[f"batch{B}"] = res
+        eng.close()
+    out["note"] = "LM frame alone (no codec chunk beside it), greedy, random KV pages; frame_ms = HIP events around the graph replay"
+    return out
 
 
 def serving_ttfa(dev, shared, n_requests, load, interval=INTERVAL, seed=0):
@@ -422,15 +509,43 @@ def serving_throughput(dev, shared, n_req, frames, kind="base"):
     submit("warm", n_req)                  # the same job once untimed: every batch size of the ramp has its frame / codec graph captured
     run()                                  # (the reference's worker captures all its graph shapes at start-up: cuda_graph_worker.py:383-470)
     torch.cuda.synchronize()
+    sent = []                              # (time, request, kind, samples) of every message handed to the result transport
+
+    def on_send(payload):
+        rid_, kind_, body_ = payload.split(b"|", 2)
+        sent.append((time.perf_counter(), rid_, kind_, len(body_) // 2 if kind_ == b"AUDIO" else 0))
+    t.on_send = on_send
+    hs0 = dict(w.host_stats)
     t0 = time.perf_counter()
     submit("r", n_req)
     samples = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    hs1 = dict(w.host_stats)
     m.engine.close()
     m.audio_decoder.close()
-    return {"value": samples / dt, "unit": "audio samples/s", "requests": n_req, "frames_per_request": frames, "seconds": dt,
-            "scheduler": kind, "ms_per_frame_step_equiv": dt / frames * 1e3}
+    res = {"value": samples / dt, "unit": "audio samples/s", "requests": n_req, "frames_per_request": frames, "seconds": dt,
+           "scheduler": kind, "ms_per_frame_step_equiv": dt / frames * 1e3,
+           "note": "value = the whole job (one prefill per step: an n-step ramp at each end); steady_state = all requests decoding"}
+    # steady state: from the moment the LAST request has produced audio until the FIRST completion — every step in between
+    # decodes n_req rows (continuous batching at n_req concurrent requests, BASELINE config 3)
+    first_audio, t_done = {}, None
+    for ts, rid_, kind_, n_ in sent:
+        if kind_ == b"AUDIO":
+            first_audio.setdefault(rid_, ts)
+        elif kind_ == b"COMPLETION" and t_done is None:
+            t_done = ts
+    if len(first_audio) == n_req and t_done is not None:
+        t_all = max(first_audio.values())
+        if t_done > t_all:
+            n_ss = sum(n_ for ts, _r, kind_, n_ in sent if kind_ == b"AUDIO" and t_all < ts <= t_done)
+            v = n_ss / (t_done - t_all)
+            res["steady_state"] = {"value": v, "unit": "audio samples/s", "window_s": t_done - t_all,
+                                   "ms_per_step": n_req * 1920 / v * 1e3 if v > 0 else None}
+    steps = max(1, hs1["steps"] - hs0["steps"])
+    res["host_us_per_step"] = {"prepare_lm_inputs": (hs1["prepare_s"] - hs0["prepare_s"]) / steps * 1e6,
+                               "update_requests": (hs1["after_s"] - hs0["after_s"]) / steps * 1e6, "steps": steps}
+    return res
 
 
 def other_configs():
@@ -482,6 +597,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the weight broadcast / "
                     "all-reduce / barrier path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs 1, 3, 4 sub-results (CosyVoice2, CSM-1B, GLM-4-Voice)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo on CPU, a stub loop instead of the engine — executes the rank launch, "
+                    "weight broadcast, barrier / max-over-ranks timing and JSON path of `--gpus N` (tests/test_host_logic.py); prints no measurement")
+    ap.add_argument("--no-kv-sweep", action="store_true", help="skip the kv_sweep sub-result (LM frame at kv 100 / 200 / 325 / 1000 / 2000)")
+    ap.add_argument("--serving-frames", type=int, default=250, help="frames per request of the serving-path jobs (SURVEY 8d: 250)")
     ap.add_argument("--exact-rows", type=int, default=None, help="rows up to which linears use the wave64 VALU kernels instead of the "
                     "matrix cores (library default 2; 1..8).  Every setting is bit-exact against the oracle under the same policy")
     args = ap.parse_args()
@@ -493,34 +612,46 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if local >= torch.cuda.device_count():
-        raise SystemExit(f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPU(s) visible")
-    torch.cuda.set_device(local)                                # one process per GPU, bound before any allocation
-    dev = torch.device("cuda", local)
+    dry = args.dry_run
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: local rank {local} but only {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local)                            # one process per GPU, bound before any allocation
+        dev = torch.device("cuda", local)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI; off the token path
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI; off the token path
 
     if args.exact_rows is not None:
         from vox_serve_amd import _native as N
         N.set_exact_rows(args.exact_rows)
-    from vox_serve_amd.engine import Qwen3Cfg
-    from vox_serve_amd.synth import synth_qwen3_codec_weights, synth_qwen3_weights
-    shared = {"W": synth_qwen3_weights(Qwen3Cfg(), dev, seed=0 if rank == 0 else 1 + rank), "codec_W": synth_qwen3_codec_weights(seed=0)}
+    if dry:
+        gen = torch.Generator().manual_seed(0 if rank == 0 else 1 + rank)
+        shared = {"W": {f"w{i}": torch.randn(257, 33, generator=gen).to(torch.bfloat16) for i in range(9)}, "codec_W": None}
+    else:
+        from vox_serve_amd.engine import Qwen3Cfg
+        from vox_serve_amd.synth import synth_qwen3_codec_weights, synth_qwen3_weights
+        shared = {"W": synth_qwen3_weights(Qwen3Cfg(), dev, seed=0 if rank == 0 else 1 + rank), "codec_W": synth_qwen3_codec_weights(seed=0)}
     bcast = None
     if use_dist:
         # load-time weight distribution of the DP pool: rank 0's arena -> every replica over RCCL (worker/dp_pool.py);
         # the other ranks start from different random weights, so a wrong broadcast would show in their outputs
         from vox_serve_amd.worker.dp_pool import broadcast_weights
         nbytes = sum(v.numel() * v.element_size() for v in shared["W"].values())
-        torch.cuda.synchronize(); dist.barrier()
+        sync(); dist.barrier()
         t0 = time.perf_counter()
         broadcast_weights(shared["W"], force=args.force_dist)
-        torch.cuda.synchronize(); dist.barrier()
+        sync(); dist.barrier()
         bdt = time.perf_counter() - t0
         chk = torch.stack([shared["W"][k].float().sum() for k in sorted(shared["W"])[:8]]).to(torch.float64)
         lo, hi = chk.clone(), chk.clone()
@@ -544,9 +675,13 @@ def main():
         sub_res[b] = run_batch(b, args, dev, world, shared)
         _phase(f"batch {b}")
 
+    kv_sweep_res = None
+    if rank == 0 and world == 1 and args.batch is None and not args.no_kv_sweep and not dry:
+        kv_sweep_res = kv_sweep(dev, shared)
+        _phase("kv sweep")
     serving = {}
     modes = {m.strip() for m in args.serving_modes.split(",") if m.strip()}
-    if world == 1 and args.serving_ttfa_requests > 0 and args.batch is None:
+    if world == 1 and args.serving_ttfa_requests > 0 and args.batch is None and not dry:
         n = args.serving_ttfa_requests
         if "ttfa" in modes:
             serving["ttfa_ms_p50"] = serving_ttfa(dev, shared, n, 0)
@@ -560,9 +695,9 @@ def main():
         if "throughput" in modes:
             serving["throughput"] = {}
             for k in ("base", "async", "disaggregation", "offline", "batched_detokenize"):
-                serving["throughput"][k] = serving_throughput(dev, shared, 32, 120, k)
+                serving["throughput"][k] = serving_throughput(dev, shared, 32, args.serving_frames, k)
                 _phase(f"serving throughput {k}")
-            serving["throughput"]["batch1_base"] = serving_throughput(dev, shared, 1, 120, "base")
+            serving["throughput"]["batch1_base"] = serving_throughput(dev, shared, 1, min(args.serving_frames, 120), "base")
             _phase("serving throughput batch 1")
 
     if rank == 0:
@@ -592,12 +727,17 @@ def main():
                 out[k] = head[k]
         for b, r in sub_res.items():
             out[f"batch{b}"] = {k: r[k] for k in ("value", "ms_per_step", "batch_per_gpu", "realtime_factor_per_request", "kv_mean", "roofline")}
+        if kv_sweep_res is not None:
+            out["kv_sweep"] = kv_sweep_res
         if bcast:
             out["weight_broadcast_rccl"] = bcast
-        if world == 1 and args.batch is None and not args.no_other_configs:
+        if dry:
+            out["dry_run"] = True
+            out["data"] = "none (dry run: stub loop, gloo, no GPU) - not a measurement"
+        if world == 1 and args.batch is None and not args.no_other_configs and not dry:
             out["other_configs"] = other_configs()
             _phase("other configs")
-        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 at N=1 only (other ranks would idle in RCCL)
+        if not args.no_cpu_baseline and world == 1 and not dry:      # the CPU leg runs on rank 0 at N=1 only (other ranks would idle in RCCL)
             try:
                 out["cpu_baseline"] = cpu_baseline(shared["W"])
                 _phase("cpu baseline")

@@ -366,7 +366,8 @@ typedef struct {
  * evaluated in fp32 (measured 1.7e-5 on the full-size fixture); the activated tensors between the decoder convs are then STORED as
  * those two terms (split once by the producing kernel), as are their history rows in the streaming state.  3: every product exact.
  * 1: activations rounded to bf16 — the precision the reference itself serves at (it runs the decoder in bf16, qwen3_tts.py:1061-1064).
- * Takes effect from the next decode call: change it only while every slot is freshly reset, and re-capture graphs. */
+ * Set it before the object's first decode call: once a chunk has run the slots hold history in that format, and a CHANGE of the
+ * value is refused with VOX_ERR_INVALID (same value again: no-op). */
 int vox_codec_set_operand_planes(vox_codec* m, int planes);
 int vox_codec_create(vox_ctx* ctx, const vox_codec_config* cfg, const vox_codec_weights* w, int max_batch, int max_slots,
                      int frames_per_chunk, vox_codec** out);

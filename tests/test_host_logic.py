@@ -618,6 +618,39 @@ def test_failed_prefill_launch_answers_once_and_rolls_the_piggy_backed_rows_back
     assert w.empty_pages.qsize() == 16
 
 
+def test_undo_decode_advance_puts_the_streaming_text_state_back_and_keeps_the_step_in_flight():
+    """Roll-back of decode rows after a failed launch: the text token (or EOS) an input-streaming row consumed in that step
+    is handed back in order, and a deferred request-state update still pending from the step before is run, not dropped."""
+    from types import SimpleNamespace
+    from vox_serve_amd.requests import Request
+    from vox_serve_amd.worker import ModelWorker
+    w = ModelWorker(model=FakePlugin(), max_num_pages=16, page_size=4, device="cpu")
+    w.model.tokens = SimpleNamespace(tts_eos=901, tts_pad=902)
+
+    def row(rid, queued, complete=False):
+        r = Request(request_id=rid, prompt="x")
+        r.done_lm_prefill, r.is_input_streaming, r.text_complete = True, True, complete
+        r.input_tokens = torch.zeros(1, 3, dtype=torch.long)
+        r.kv_pages, r.kv_token_len, r.kv_last_page_len, r.next_position_id = [w.empty_pages.get()], 3, 3, 4
+        for t_ in queued:
+            r.pending_text_tokens.put(t_)
+        return r
+    a, b, c = row("a", [11, 12]), row("b", [], complete=True), row("c", [])
+    for r in (a, b, c):
+        w._inject_streaming_text_token(r)
+        r.kv_token_len += 1; r.kv_last_page_len += 1; r.next_position_id += 1       # what prepare_lm_inputs advances
+    assert [int(r.input_tokens[0, -1]) for r in (a, b, c)] == [11, 901, 902] and b.eos_injected and a.text_token_cursor == 1
+    ran = []
+    w._pending = lambda: (ran.append("finish"), setattr(w, "_pending", None))
+    w.undo_decode_advance([a, b, c])
+    assert ran == ["finish"] and w._pending is None and w._resident is None
+    assert list(a.pending_text_tokens.queue) == [11, 12] and a.text_token_cursor == 0      # same token again on the retry
+    assert not b.eos_injected and c.pending_text_tokens.empty()
+    assert all((r.kv_token_len, r.kv_last_page_len, r.next_position_id) == (3, 3, 4) for r in (a, b, c))
+    w._inject_streaming_text_token(a); w._inject_streaming_text_token(b)
+    assert int(a.input_tokens[0, -1]) == 11 and int(b.input_tokens[0, -1]) == 901
+
+
 def test_device_bound_tokenizers_and_per_device_contexts():
     """`audio_decoder_device` plumbing that can be checked without a GPU: the guard is a no-op for CPU / index-less devices, the
     decorator wraps the constructor and the public methods only (private helpers run inside the caller's guard), and every

@@ -107,6 +107,7 @@ _SIGS = {
 _OPTIONAL_SIGS = {}
 
 _lib = None
+_capturing = set()   # devices with a stream capture in progress (graph_capture)
 _ctxs = {}          # one context per HIP device of this process (the LM's GPU; a detokenizer on a second GPU gets its own)
 
 
@@ -202,6 +203,11 @@ class graph_capture:
 
     def __enter__(self):
         torch = self._torch
+        d = torch.cuda.current_device()
+        if d in _capturing:      # the capture stream is one per device and not re-entrant
+            raise VoxError("graph_capture: a capture is already active on this device (nested or concurrent captures are not supported)")
+        _capturing.add(d)
+        self._dev = d
         self.cur = torch.cuda.current_stream()
         self.cs.wait_stream(self.cur)
         self._ctx = torch.cuda.stream(self.cs)
@@ -210,6 +216,7 @@ class graph_capture:
             check(lib().vox_graph_begin(ctx(), stream()))
         except Exception:
             self._ctx.__exit__(None, None, None)
+            _capturing.discard(self._dev)
             raise
         return self
 
@@ -220,9 +227,18 @@ class graph_capture:
         finally:
             self._ctx.__exit__(None, None, None)
             self.cur.wait_stream(self.cs)
+            _capturing.discard(self._dev)
         if et is None:
             check(status)
             self.graph = gh
+        else:
+            # the body raised: its exception propagates; a graph that was instantiated all the same is released, and a failed
+            # end-of-capture is at least reported
+            if gh:
+                lib().vox_graph_destroy(gh)
+            if status != 0:
+                import logging
+                logging.getLogger(__name__).error("graph_capture: vox_graph_end failed (%s) while unwinding %s", status, et.__name__)
         return False
 
 

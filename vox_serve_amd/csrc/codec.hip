@@ -978,6 +978,7 @@ struct vox_codec {
     vox_codec_weights w;
     int max_batch, max_slots, T;
     int planes = 2;     // operand planes of the conv GEMMs (vox_codec_set_operand_planes)
+    bool decoded = false;   // a chunk has run: the slots' streaming history is stored in the format `planes` implies
     // state (per slot)
     float *st_pre, *st_dw[2], *st_dec0, *st_tc[4], *st_ru[4][3], *st_final;
     bf16_t* ring;   // [layers][slots][Wn][2][HD]
@@ -1190,6 +1191,10 @@ int vox_codec_create(vox_ctx* ctx, const vox_codec_config* cfg, const vox_codec_
 
 int vox_codec_set_operand_planes(vox_codec* m, int planes) {
     if (!m || planes < 1 || planes > 3) return vox_fail(VOX_ERR_INVALID, "codec_set_operand_planes: 1, 2 or 3");
+    // the slots' history rows are kept in the operand format (two-term rows vs fp32 rows): switching with history in place would
+    // make the convs misread it, so the mode is fixed once the first chunk has been decoded
+    if (planes != m->planes && m->decoded)
+        return vox_fail(VOX_ERR_INVALID, "codec_set_operand_planes: %d -> %d after a chunk was decoded (set it before the first chunk)", m->planes, planes);
     m->planes = planes;
     return VOX_OK;
 }
@@ -1241,6 +1246,7 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
                            int T, float* out) {
     if (!m || !codes || !slots || !out) return vox_fail(VOX_ERR_INVALID, "codec_decode_chunk: NULL");
     if (n < 1 || n > m->max_batch || T < 1 || T > m->T) return vox_fail(VOX_ERR_INVALID, "codec_decode_chunk: n=%d T=%d out of range", n, T);
+    m->decoded = true;
     hipStream_t st = (hipStream_t)stream;
     struct PlanesGuard { int saved; explicit PlanesGuard(int p) : saved(g_conv_planes) { g_conv_planes = p; } ~PlanesGuard() { g_conv_planes = saved; } } pg(m->planes);
     const vox_codec_config& c = m->cfg;

@@ -1843,6 +1843,210 @@ template <int D, int GMAX, int NG>
 __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
     constexpr int LPT = D / 8, TPW = 64 / LPT, NCH = 8, GT = 1024 / NG, GW = GT / 64, CPG = NCH / NG;
     constexpr int KVL = (VOX_TC * LPT + GT - 1) / GT;
+    constexpr bool QREG = GMAX <= 2;      // q heads held unpacked in registers during the score passes
+    __shared__ __attribute__((aligned(16))) uint4 Ks[NG][VOX_TC * LPT];
+    __shared__ __attribute__((aligned(16))) uint4 Vs[NG][VOX_TC * LPT];
+    __shared__ __attribute__((aligned(16))) uint4 Qs[GMAX * LPT];
+    __shared__ float S[NG][GMAX][VOX_TC];
+    __shared__ float Ms[NG][GMAX];
+    __shared__ float Sh[16 * D];
+    __shared__ __attribute__((aligned(16))) bf16_t Knew[D];
+    __shared__ float Po[NCH][GMAX][D];
+    __shared__ float2 Pml[NCH][GMAX];
+    __shared__ float Wm[NCH][GMAX];
+
+    // head split: gridDim.x = Hkv * HS blocks per row, block (hk, hs) takes q heads hs * G .. hs * G + G - 1 of kv head hk's group
+    const int HS = gridDim.x / a.Hkv, hk = blockIdx.x / HS, hs = blockIdx.x % HS, row = blockIdx.y;
+    VOX_STAMP_DECL
+    VOX_STAMP(0)
+    const int tid = threadIdx.x, lane = tid & 63, wave16 = tid >> 6;
+    const int grp = tid / GT, gt = tid % GT, gw = wave16 % GW;
+    const int* pages = a.identity_pages ? nullptr
+                       : (a.ptab ? a.ptab + (size_t)row * a.pt_stride : a.indices + a.indptr[a.q_req[row]]);
+    // per-row page table: the page ids of this thread's tokens do not depend on the row's length, so they are requested
+    // together with it (one exposed round trip in front of the K/V loads instead of two); entries past the row's last page are
+    // read (clamped to the table row) and never used
+    int pgi_pre[CPG][KVL];
+    const bool hoist = a.ptab && a.hoist;
+    if (hoist) {
+#pragma unroll
+        for (int ci = 0; ci < CPG; ++ci)
+#pragma unroll
+            for (int u = 0; u < KVL; ++u) {
+                const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT;
+                const int pi = tok / a.page_size;
+                pgi_pre[ci][u] = pages[pi < a.pt_stride ? pi : a.pt_stride - 1];
+            }
+    }
+    const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
+    const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..8
+    const int Gf = a.Hq / a.Hkv, G = Gf / HS, g0 = hs * G;
+    const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
+    const int nqkv = (a.Hq + 2 * a.Hkv) * D;
+    const bf16_t* raw = a.qkv + (size_t)row * nqkv;
+
+    // K/V tiles of this group's chunks.  The row's newest token (index L - 1) comes from the projection output: its V row is
+    // loaded into the tile here, its K row (per-head norm + RoPE below) is read from Knew by the score pass.
+    uint4 kreg[CPG][KVL], vreg[CPG][KVL];
+#pragma unroll
+    for (int ci = 0; ci < CPG; ++ci) {
+        const int t0 = (grp + NG * ci) * VOX_TC;
+#pragma unroll
+        for (int u = 0; u < KVL; ++u) {
+            const int i = gt + GT * u, t = i / LPT, j = i % LPT;
+            kreg[ci][u] = make_uint4(0, 0, 0, 0);
+            vreg[ci][u] = kreg[ci][u];
+            const int tok = t0 + t;
+            if (i < VOX_TC * LPT && tok < L - 1) {
+                const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[tok / a.page_size] : row);
+                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
+                kreg[ci][u] = reinterpret_cast<const uint4*>(base)[j];
+                vreg[ci][u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
+            } else if (i < VOX_TC * LPT && tok == L - 1) {
+                vreg[ci][u] = reinterpret_cast<const uint4*>(raw + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D)[j];
+            }
+        }
+    }
+    VOX_STAMP(1)
+    {   // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave
+        int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
+        p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
+        const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
+        for (int h = wave16; h < G + 1; h += 16) {
+            const bool isk = h == G;
+            const bf16_t* src = isk ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * Gf + g0 + h) * D;
+            bf16_t* dst = isk ? Knew : reinterpret_cast<bf16_t*>(Qs) + (size_t)h * D;
+            prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, Sh + wave16 * D, dst, lane);
+        }
+    }
+    VOX_STAMP(2)
+#pragma unroll
+    for (int ci = 0; ci < CPG; ++ci) {
+        const int c = grp + NG * ci, t0 = c * VOX_TC;
+        const bool live = t0 < L;
+        const int nt = live ? ((L - t0) < VOX_TC ? (L - t0) : VOX_TC) : 0;
+        const bool own_last = live && (t0 + nt == L);
+        if (ci > 0) __syncthreads();           // the previous chunk's tile is dead
+#pragma unroll
+        for (int u = 0; u < KVL; ++u) {
+            const int i = gt + GT * u;
+            if (i < VOX_TC * LPT) { Ks[grp][i] = kreg[ci][u]; Vs[grp][i] = vreg[ci][u]; }
+        }
+        __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
+        VOX_STAMP(3)
+        if (own_last && hs == 0 && gt < LPT) {
+            // append the new token to the paged cache (page < 0: graph padding row)
+            const int pg = a.identity_pages ? row : a.page[row];
+            const int sl = a.identity_pages ? (L - 1) : a.slot[row];
+            if (pg >= 0) {
+                bf16_t* base = a.kv_w + (size_t)pg * ps + ((size_t)sl * a.Hkv + hk) * D;
+                reinterpret_cast<uint4*>(base)[gt] = reinterpret_cast<const uint4*>(Knew)[gt];
+                reinterpret_cast<uint4*>(base + (size_t)a.page_size * a.Hkv * D)[gt] = Vs[grp][(nt - 1) * LPT + gt];
+            }
+        }
+        VOX_STAMP(4)
+        if (live) {      // scores: LPT lanes per token, butterfly over LPT lanes; the token's K chunk is unpacked once for all q heads
+            const int j = lane % LPT;
+            float qf[QREG ? GMAX : 1][8];
+            if constexpr (QREG) {
+#pragma unroll
+                for (int g = 0; g < GMAX; ++g) {
+                    const uint4 qx = Qs[(g < G ? g : 0) * LPT + j];
+                    qf[g][0] = bflo(qx.x); qf[g][1] = bfhi(qx.x); qf[g][2] = bflo(qx.y); qf[g][3] = bfhi(qx.y);
+                    qf[g][4] = bflo(qx.z); qf[g][5] = bfhi(qx.z); qf[g][6] = bflo(qx.w); qf[g][7] = bfhi(qx.w);
+                }
+            }
+#pragma unroll
+            for (int tb = gw * TPW; tb < VOX_TC; tb += GW * TPW) {
+                const int tt = tb + lane / LPT;
+                const uint4 kx = (own_last && tt == nt - 1) ? reinterpret_cast<const uint4*>(Knew)[j] : Ks[grp][tt * LPT + j];
+                if constexpr (QREG) {
+                    const float kf[8] = {bflo(kx.x), bfhi(kx.x), bflo(kx.y), bfhi(kx.y), bflo(kx.z), bfhi(kx.z), bflo(kx.w), bfhi(kx.w)};
+#pragma unroll
+                    for (int g = 0; g < GMAX; ++g) {
+                        float d = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d = __fmaf_rn(qf[g][e], kf[e], d);
+                        d = butterfly<LPT>(d);
+                        if (j == 0 && g < G) S[grp][g][tt] = d * a.scale;
+                    }
+                } else {
+                    for (int g = 0; g < G; ++g) {
+                        float d = dot8(Qs[g * LPT + j], kx, 0.0f);
+                        d = butterfly<LPT>(d);
+                        if (j == 0) S[grp][g][tt] = d * a.scale;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        VOX_STAMP(5)
+        if (live) {      // chunk max + p = exp2((s-m)*log2e): 32 lanes per q head
+            for (int pr = gt; pr < G * VOX_TC; pr += GT) {
+                const int g = pr / VOX_TC, t = pr % VOX_TC;
+                const float s = t < nt ? S[grp][g][t] : -INFINITY;
+                float m = s;
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, VOX_WAVE));
+                const float p = t < nt ? exp2_c((s - m) * VOX_LOG2E) : 0.0f;
+                S[grp][g][t] = p;
+                if (t == 0) Ms[grp][g] = m;
+            }
+        }
+        __syncthreads();
+        VOX_STAMP(6)
+        if (live) {      // PV: one thread per (q head, pair of dims); sequential over the tokens of the (zero-padded) tile
+            const u32* Vw = reinterpret_cast<const u32*>(Vs[grp]);
+            for (int e = gt; e < G * (D / 2); e += GT) {
+                const int g = e / (D / 2), dp = e % (D / 2);
+                float o0 = 0.0f, o1 = 0.0f, l = 0.0f;
+#pragma unroll
+                for (int t = 0; t < VOX_TC; ++t) {
+                    const float p = S[grp][g][t];          // 0 for t >= nt
+                    const u32 vw = Vw[t * (D / 2) + dp];
+                    l = l + p;
+                    o0 = __fmaf_rn(p, bflo(vw), o0);
+                    o1 = __fmaf_rn(p, bfhi(vw), o1);
+                }
+                *reinterpret_cast<float2*>(&Po[c][g][2 * dp]) = make_float2(o0, o1);
+                if (dp == 0) Pml[c][g] = make_float2(Ms[grp][g], l);
+            }
+        }
+    }
+    __syncthreads();
+    VOX_STAMP(7)
+    // merge (k_attn_merge): global max, the chunk weights w_c = exp2((m_c - M) log2e) once per (chunk, head), then L and O over
+    // the chunks in ascending order
+    if (tid < NCH * GMAX) {
+        const int c = tid / GMAX, g = tid % GMAX;
+        if (g < G) {
+            float M = -INFINITY;
+            for (int cc = 0; cc < nc; ++cc) M = fmaxf(M, Pml[cc][g].x);
+            Wm[c][g] = c < nc ? exp2_c((Pml[c][g].x - M) * VOX_LOG2E) : 0.0f;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < G * D; e += 1024) {
+        const int g = e / D, d = e % D;
+        float Lsum = 0.0f, O = 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            const float w = Wm[c][g];
+            Lsum = __fmaf_rn(Pml[c][g].y, w, Lsum);
+            O = __fmaf_rn(Po[c][g][d], w, O);
+        }
+        const bf16_t r = f2bf(O / Lsum);
+        const int h = hk * Gf + g0 + g;
+        a.out[((size_t)row * a.Hq + h) * D + d] = r;
+        if (a.out_frag) a.out_frag[frag_off(row, h * D + d, a.Hq * D)] = r;
+    }
+    VOX_STAMP(8)
+}
+
+#ifdef VOX_DEV_KNOBS      // the previous form of the kernel, for A/B timing in development builds (VOX_ATTN_V1=1)
+template <int D, int GMAX, int NG>
+__global__ __launch_bounds__(1024) void k_attn_decode8_v1(AttnArgs a) {
+    constexpr int LPT = D / 8, TPW = 64 / LPT, NCH = 8, GT = 1024 / NG, GW = GT / 64, CPG = NCH / NG;
+    constexpr int KVL = (VOX_TC * LPT + GT - 1) / GT;
     __shared__ __attribute__((aligned(16))) uint4 Ks[NG][VOX_TC * LPT];
     __shared__ __attribute__((aligned(16))) uint4 Vs[NG][VOX_TC * LPT];
     __shared__ __attribute__((aligned(16))) uint4 Qs[GMAX * LPT];
@@ -2012,6 +2216,8 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
     VOX_STAMP(8)
 }
 
+#endif
+
 // true when the one-launch decode attention covers the call (fused decode rows, <= 8 chunks, a supported head shape)
 bool vox_attn_decode8_supported(const AttnCall& c) {
     if (!c.qkv || !c.out || c.Nq < 1 || c.Hkv < 1 || c.Hq % c.Hkv) return false;
@@ -2047,12 +2253,16 @@ int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
         return VOX_OK;
     }
     // two-head groups (Qwen3-TTS talker, CSM, Orpheus) at few rows: one block per q head (Hq blocks per row instead of Hkv)
-    static const int hs2_rows = [] { const char* e = getenv("VOX_ATTN_HS2_ROWS"); return e ? atoi(e) : 0; }();
+    static const int hs2_rows = [] { const char* e = getenv("VOX_ATTN_HS2_ROWS"); return e ? atoi(e) : 4; }();      // measured: -1.2 us per talker layer at 1 row, no gain from 8 rows on, slower at 32
     if (c.D == 128 && G == 2 && c.Nq <= hs2_rows) {
         hipLaunchKernelGGL((k_attn_decode8<128, 1, 8>), dim3(c.Hkv * 2, c.Nq), dim3(1024), 0, st, a);
         return VOX_OK;
     }
     const dim3 grid(c.Hkv, c.Nq);
+#ifdef VOX_DEV_KNOBS
+    static const bool v1 = [] { const char* e = getenv("VOX_ATTN_V1"); return e && e[0] == '1'; }();
+    if (v1 && c.D == 128 && G == 2) { hipLaunchKernelGGL((k_attn_decode8_v1<128, 2, 8>), grid, dim3(1024), 0, st, a); return VOX_OK; }
+#endif
 #define VOX_AD(D_, G_, NG_) if (c.D == D_ && G == G_) { hipLaunchKernelGGL((k_attn_decode8<D_, G_, NG_>), grid, dim3(1024), 0, st, a); return VOX_OK; }
     VOX_AD(128, 2, 8) VOX_AD(128, 16, 4) VOX_AD(64, 4, 8) VOX_AD(64, 7, 8)
 #undef VOX_AD
@@ -2077,6 +2287,7 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
                                                 bool do_append) {
     constexpr int D = 128, LPT = 16, TMAX = NT > 0 ? NT : 16, UMAX = (TMAX + 3) / 4;
     const int grp = lane >> 4, j = lane & 15;
+    const int g = lane >> 5, dq = lane & 31;      // P.V / output layout: lane = (q head g, dims 4 dq .. 4 dq + 3)
     const int nqkv = (at.Hq + 2 * at.Hkv) * D;
     const size_t ps = (size_t)2 * at.page_size * at.Hkv * D;
     const int L = NT > 0 ? NT : (at.fixed_kvlen > 0 ? at.fixed_kvlen : at.q_kvlen[row]);
@@ -2089,6 +2300,8 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
                       : grp == 2 ? raw + (size_t)at.Hq * D + (size_t)hk * D
                                  : raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D;
     const uint4 v = reinterpret_cast<const uint4*>(src)[j];
+    // the new token's V row in the P.V layout (4 dims per lane), straight from the projection output
+    const uint2 vnew = reinterpret_cast<const uint2*>(raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D)[dq];
     const bf16_t* nwp = grp < 2 ? at.qn : (grp == 2 ? at.kn : nullptr);
     uint4 gw4 = make_uint4(0, 0, 0, 0);
     if (nwp) gw4 = reinterpret_cast<const uint4*>(nwp)[j];
@@ -2100,8 +2313,9 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
 #pragma unroll
         for (int k = 0; k < 4; ++k) cs4[k] = cp[k];
     }
-    // cached K (token-major) and V (chunk-major); token nt-1 is the new one
-    uint4 kr[UMAX], vr[TMAX];
+    // cached K (token-major: token 4u + grp, 16-byte chunk j) and V (P.V layout: 4 dims per lane); token nt-1 is the new one
+    uint4 kr[UMAX];
+    uint2 vr[TMAX];
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
         const int t = u * 4 + grp;
@@ -2113,11 +2327,11 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
     }
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
-        vr[t] = make_uint4(0, 0, 0, 0);
+        vr[t] = make_uint2(0, 0);
         if (t < nt - 1) {
             const int pgi = pages ? pages[t / at.page_size] : row;
-            vr[t] = reinterpret_cast<const uint4*>(at.kv + (size_t)pgi * ps + (size_t)at.page_size * at.Hkv * D +
-                                                   ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[j];
+            vr[t] = reinterpret_cast<const uint2*>(at.kv + (size_t)pgi * ps + (size_t)at.page_size * at.Hkv * D +
+                                                   ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[dq];
         }
     }
     // per-head RMSNorm (prep_head: butterfly<64> over a head's 16 non-zero lanes == butterfly<16>)
@@ -2132,7 +2346,8 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
             for (int i = 0; i < 8; ++i) e[i] = bfround((e[i] * rinv) * gw[i]);
         }
     }
-    // NeoX RoPE over the full head: element i < 64 pairs with i + 64, i.e. with the same slot of lane ^ 8
+    // NeoX RoPE over the full head: element i < 64 pairs with i + 64, i.e. with the same slot of lane ^ 8 (a rotation by 8 inside
+    // the 16-lane row: one DPP move)
     uint4 hq;
     {
         const float cc[8] = {cs4[0].x, cs4[0].z, cs4[1].x, cs4[1].z, cs4[2].x, cs4[2].z, cs4[3].x, cs4[3].z};
@@ -2140,14 +2355,18 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
         float r[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+#if VOX_DPP_BUTTERFLY
+            const float o = vox_dpp<0x128, 0xF>(e[i], e[i]);        // row_ror:8
+#else
             const float o = __shfl_xor(e[i], 8, VOX_WAVE);
+#endif
             const float mc = e[i] * cc[i];
             r[i] = (j < 8) ? __fmaf_rn(-o, sn[i], mc) : __fmaf_rn(o, sn[i], mc);
         }
         hq.x = pack_bf2(r[0], r[1]); hq.y = pack_bf2(r[2], r[3]); hq.z = pack_bf2(r[4], r[5]); hq.w = pack_bf2(r[6], r[7]);
         if (grp == 3) hq = v;
     }
-    const uint4 q0c = shfl4(hq, j), q1c = shfl4(hq, 16 + j), knc = shfl4(hq, 32 + j), vnc = shfl4(hq, 48 + j);
+    const uint4 q0c = shfl4(hq, j), q1c = shfl4(hq, 16 + j), knc = shfl4(hq, 32 + j);
     if (do_append) {
         const int pg = at.identity_pages ? row : at.page[row];
         const int sl = at.identity_pages ? (L - 1) : at.slot[row];
@@ -2157,14 +2376,20 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
             reinterpret_cast<uint4*>(base)[j] = hq;
         }
     }
-    // scores of token 4u+grp for both q heads, then the global max
+    // scores of token 4u+grp for both q heads (the q chunks unpacked once, the token's K chunk once per pass), then the global max
+    const float q0f[8] = {bflo(q0c.x), bfhi(q0c.x), bflo(q0c.y), bfhi(q0c.y), bflo(q0c.z), bfhi(q0c.z), bflo(q0c.w), bfhi(q0c.w)};
+    const float q1f[8] = {bflo(q1c.x), bfhi(q1c.x), bflo(q1c.y), bfhi(q1c.y), bflo(q1c.z), bfhi(q1c.z), bflo(q1c.w), bfhi(q1c.w)};
     float sc[2][UMAX], m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
         const int t = u * 4 + grp;
         const uint4 kx = (t == nt - 1) ? knc : kr[u];
-        const float d0 = butterfly<16>(dot8(q0c, kx, 0.0f)) * at.scale;
-        const float d1 = butterfly<16>(dot8(q1c, kx, 0.0f)) * at.scale;
+        const float kf[8] = {bflo(kx.x), bfhi(kx.x), bflo(kx.y), bfhi(kx.y), bflo(kx.z), bfhi(kx.z), bflo(kx.w), bfhi(kx.w)};
+        float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { d0 = __fmaf_rn(q0f[i], kf[i], d0); d1 = __fmaf_rn(q1f[i], kf[i], d1); }
+        d0 = butterfly<16>(d0) * at.scale;
+        d1 = butterfly<16>(d1) * at.scale;
         sc[0][u] = t < nt ? d0 : -INFINITY;
         sc[1][u] = t < nt ? d1 : -INFINITY;
         m0 = fmaxf(m0, sc[0][u]);
@@ -2172,38 +2397,40 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
     }
     m0 = fmaxf(m0, __shfl_xor(m0, 16, VOX_WAVE)); m0 = fmaxf(m0, __shfl_xor(m0, 32, VOX_WAVE));
     m1 = fmaxf(m1, __shfl_xor(m1, 16, VOX_WAVE)); m1 = fmaxf(m1, __shfl_xor(m1, 32, VOX_WAVE));
-    float pp[2][UMAX];
+    // p = exp2((s - m) log2e): the scores of a token are replicated over the 16 lanes of its group, so lane j < 2 UMAX of group
+    // grp evaluates ONE of them — head j / UMAX, token 4 (j % UMAX) + grp — instead of every lane all 2 UMAX
+    float pe;
+    {
+        float ssel = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < UMAX; ++u) {
-        const int t = u * 4 + grp;
-        pp[0][u] = t < nt ? exp2_c((sc[0][u] - m0) * VOX_LOG2E) : 0.0f;
-        pp[1][u] = t < nt ? exp2_c((sc[1][u] - m1) * VOX_LOG2E) : 0.0f;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u) ssel = (j == h * UMAX + u) ? sc[h][u] : ssel;
+        const float msel = j >= UMAX ? m1 : m0;
+        const int tl = (j >= UMAX ? j - UMAX : j) * 4 + grp;
+        pe = (j < 2 * UMAX && tl < nt) ? exp2_c((ssel - msel) * VOX_LOG2E) : 0.0f;
     }
-    // PV: lane (g = grp & 1, chunk j) accumulates its 8 output dims sequentially over the tokens
-    const int g = grp & 1;
-    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l = 0.0f;
+    // P.V: lane (g, dq) accumulates its 4 output dims sequentially over the tokens
+    float o[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.0f;
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
-        // p of token t lives (identically) in the 16 lanes of group t & 3, register t >> 2: a wave-uniform value, fetched with
-        // v_readlane (scalar broadcast) instead of a ds_bpermute round trip per token and head
-        const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pp[0][t >> 2]), (t & 3) * 16));
-        const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pp[1][t >> 2]), (t & 3) * 16));
+        // p of (token t, head h) sits in lane 16 (t & 3) + h UMAX + (t >> 2): fetched with v_readlane (a scalar broadcast)
+        const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pe), (t & 3) * 16 + (t >> 2)));
+        const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pe), (t & 3) * 16 + UMAX + (t >> 2)));
         if (t < nt) {
             const float pt = g ? p1 : p0;
-            const uint4 vx = (t == nt - 1) ? vnc : vr[t];
+            const uint2 vx = (t == nt - 1) ? vnew : vr[t];
             l = l + pt;
             o[0] = __fmaf_rn(pt, bflo(vx.x), o[0]); o[1] = __fmaf_rn(pt, bfhi(vx.x), o[1]);
             o[2] = __fmaf_rn(pt, bflo(vx.y), o[2]); o[3] = __fmaf_rn(pt, bfhi(vx.y), o[3]);
-            o[4] = __fmaf_rn(pt, bflo(vx.z), o[4]); o[5] = __fmaf_rn(pt, bfhi(vx.z), o[5]);
-            o[6] = __fmaf_rn(pt, bflo(vx.w), o[6]); o[7] = __fmaf_rn(pt, bfhi(vx.w), o[7]);
         }
     }
-    if (grp < 2) {
-        uint4 r;
+    {
+        uint2 r;
         r.x = pack_bf2(o[0] / l, o[1] / l); r.y = pack_bf2(o[2] / l, o[3] / l);
-        r.z = pack_bf2(o[4] / l, o[5] / l); r.w = pack_bf2(o[6] / l, o[7] / l);
-        reinterpret_cast<uint4*>(out_row + (size_t)(hk * 2 + g) * D)[j] = r;
-        if (at.out_frag) *reinterpret_cast<uint4*>(at.out_frag + frag_off(row, (hk * 2 + g) * D + j * 8, at.Hq * D)) = r;
+        const int col = (hk * 2 + g) * D + 4 * dq;
+        *reinterpret_cast<uint2*>(out_row + col) = r;
+        if (at.out_frag) *reinterpret_cast<uint2*>(at.out_frag + frag_off(row, col, at.Hq * D)) = r;
     }
 }
 

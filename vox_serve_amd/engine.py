@@ -278,6 +278,10 @@ class Qwen3Engine:
             with N.graph_capture() as cap:
                 self._native_frame(io, N.stream(), batch, bucket, sampling, seed, feedback)
             gh = cap.graph
+            while len(self._graphs) >= self.max_graphs:      # bounded: the oldest captured shape goes (insertion order)
+                old_key = next(iter(self._graphs))
+                torch.cuda.current_stream().synchronize()     # (it may still be running)
+                self.L.vox_graph_destroy(self._graphs.pop(old_key))
             g = self._graphs[key] = gh
         N.check(self.L.vox_graph_launch(g, N.stream()))
 

@@ -15,6 +15,7 @@ import contextlib
 import logging
 import os
 import queue
+import time
 from typing import List, Optional
 
 import numpy as np
@@ -77,6 +78,9 @@ class ModelWorker:
         self._detok_stream = None    # launch_detokenize: the codec chunk + its D2H copy run here, beside the LM frame
         self._snap, self._snap_i = None, 0
         self._code_pins, self._code_pin_i = [], 0
+        # host time of the two per-step bookkeeping halves (plan building; request-state update after the tokens arrived, the
+        # wait for them excluded): bench.py reports them per step next to the serving-path throughput
+        self.host_stats = {"prepare_s": 0.0, "after_s": 0.0, "steps": 0}
         self._resident = None        # request ids whose next inputs already sit in the engine's rows (feedback path)
         self._resident_reqs = []     # ... and the requests themselves (their repetition-cache rows live in the engine)
         self._next_feats = None
@@ -107,6 +111,14 @@ class ModelWorker:
 
     # -------------------------------------------------------------------------------------------------
     def prepare_lm_inputs(self, lm_requests: List[Request], detokenize_requests: List[Request]) -> Optional[LMInputs]:
+        t0 = time.perf_counter()
+        try:
+            return self._prepare_lm_inputs(lm_requests, detokenize_requests)
+        finally:
+            self.host_stats["prepare_s"] += time.perf_counter() - t0
+            self.host_stats["steps"] += 1
+
+    def _prepare_lm_inputs(self, lm_requests: List[Request], detokenize_requests: List[Request]) -> Optional[LMInputs]:
         for req in detokenize_requests:
             req.audio_decode_idx = req.next_audio_decode_idx.copy()
         if len(lm_requests) == 0:
@@ -215,13 +227,17 @@ class ModelWorker:
     def _inject_streaming_text_token(self, req: Request) -> None:
         """worker/base.py:362-394: next queued text token, then tts_eos once, then tts_pad."""
         tk = self.model.tokens
+        req._last_injected = None            # what this step took from the request's text state (undo_decode_advance puts it back)
         try:
-            req.input_tokens[0, -1] = req.pending_text_tokens.get_nowait()
+            tok = req.pending_text_tokens.get_nowait()
+            req.input_tokens[0, -1] = tok
             req.text_token_cursor += 1
+            req._last_injected = ("token", tok)
         except queue.Empty:
             if req.text_complete and not req.eos_injected:
                 req.input_tokens[0, -1] = tk.tts_eos
                 req.eos_injected = True
+                req._last_injected = ("eos", None)
             else:
                 req.input_tokens[0, -1] = tk.tts_pad
         self._resident = None        # the text column changed on the host: restage
@@ -447,6 +463,15 @@ class ModelWorker:
             out = e.out_ids[:B].cpu().to(torch.long)                  # the one synchronisation of the step
             self._resident = [r.request_id for r in requests]
             self._resident_reqs = list(requests)
+        t0 = time.perf_counter()
+        try:
+            self._update_requests(requests, out, feats, positions)
+        finally:
+            self.host_stats["after_s"] += time.perf_counter() - t0
+
+    def _update_requests(self, requests, out, feats, positions):
+        e, m = self.model.engine, self.model
+        B = len(requests)
         # async scheduling launches step N+1 before step N's tokens are seen: a request that finished at N has one surplus
         # row in N+1, whose output is dropped here (the reference's async loop has the same one-step lag)
         if positions is None:
@@ -544,7 +569,16 @@ class ModelWorker:
             # detokenize queue until the LM frame in flight ends, and a pending barrier on a second hardware queue slows
             # every dispatch of that frame (N.graph_capture).
             if on_gpu and (self._detok_fence_needed or any(getattr(t, "is_cuda", False) for t in token_ids)):
-                self._detok_stream.wait_stream(torch.cuda.current_stream())
+                # the slot reset / cache initialisation ran on the CURRENT stream of the detokenizer's device (tokenizer/base.py
+                # device_bound) — with the detokenizer on a second GPU that is not the LM's current stream; device token windows
+                # were produced on their own device's current stream
+                ddev = torch.device(self.detokenizer_device)
+                waits = {torch.cuda.current_stream(ddev)}
+                for t_ in token_ids:
+                    if getattr(t_, "is_cuda", False):
+                        waits.add(torch.cuda.current_stream(t_.device))
+                for st_ in waits:
+                    self._detok_stream.wait_stream(st_)
                 self._detok_fence_needed = False
             ctx = torch.cuda.stream(self._detok_stream) if on_gpu else contextlib.nullcontext()
             with ctx:
@@ -644,6 +678,13 @@ class ModelWorker:
         """A launch failed after prepare_lm_inputs had advanced these decode rows (no K/V written, no token produced): put
         their KV length / position / page bookkeeping back, so that the next step does not attend to an unwritten slot."""
         ps = self.page_size
+        # a step still in flight behind the failed one (async scheduling) produced real tokens: its request-state update must
+        # not be lost with the failed launch
+        try:
+            self.drain()
+        except Exception as ex:              # never mask the launch failure being handled
+            self.logger.error(f"deferred request update failed during roll-back: {ex!r}")
+            self._pending = None
         for req in requests:
             if not req.done_lm_prefill or req.done_all or not getattr(req, "kv_pages", None):
                 continue
@@ -653,7 +694,16 @@ class ModelWorker:
             if req.kv_last_page_len == 0:
                 self.empty_pages.put(req.kv_pages.pop())
                 req.kv_last_page_len = ps
-        self._resident, self._pending = None, None      # the engine's rows are in an unknown state: restage next step
+            inj = getattr(req, "_last_injected", None)      # input streaming: the text token / EOS this step consumed goes back
+            if inj is not None:
+                if inj[0] == "token":
+                    with req.pending_text_tokens.mutex:
+                        req.pending_text_tokens.queue.appendleft(inj[1])
+                    req.text_token_cursor -= 1
+                else:
+                    req.eos_injected = False
+                req._last_injected = None
+        self._resident = None                # the engine's rows are in an unknown state: restage next step
 
     def free_kv_cache(self, request: Request):
         if getattr(request, "kv_pages", None):
