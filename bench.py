@@ -343,6 +343,11 @@ def run_batch(B, args, dev, world, shared, ttfa_requests=0):
                      "launch": "one hipGraph replay = one LM frame (talker + 15 depth steps + sampling)",
                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": frame_gpu_s * 1e3},
     }
+    if not dry and hasattr(loop.eng, "depth_persist_status"):
+        en, err = loop.eng.depth_persist_status()
+        res["depth_persist"] = {"enabled_for_one_request_frames": en, "handoff_timeouts": err}
+        if err:
+            raise SystemExit(f"persistent depth step: a hand-off timed out (code {err:#x}): the measurement is invalid")
     if ttfa:
         res["ttfa_ms_p50_engine"] = float(np.median(ttfa))
         res["ttfa_ms_p50_engine_detokenize_interval_2"] = float(np.median(ttfa2))
@@ -548,6 +553,52 @@ def serving_throughput(dev, shared, n_req, frames, kind="base"):
     return res
 
 
+def serving_pool(n_req, frames, dp_size=1):
+    """The online data-parallel serving pool (vox_serve_amd/launch.py; the reference's `--dp-size N`: launch.py:183-279, 355-415,
+    460-474): `dp_size` scheduler daemons — fresh interpreters pinned to their GPU through HIP_VISIBLE_DEVICES before torch is
+    imported — behind the round-robin router, requests and audio over the AF_UNIX PUSH/PULL transports.  n_req requests per daemon
+    submitted at once; value = PCM samples received by the client / wall time, TTFA = submit -> first AUDIO message at the client."""
+    from vox_serve_amd.launch import ServingPool
+    mb = max(8, n_req)
+    t0 = time.perf_counter()
+    pool = ServingPool("qwen3-tts", dp_size=dp_size, max_batch_size=mb, max_num_pages=4 * mb + 8, page_size=128, synthetic=True, greedy=True,
+                       max_tokens=PROMPT_TOKENS + frames, async_scheduling=True, log_level="WARNING", ready_timeout_s=900.0)
+    startup = time.perf_counter() - t0
+    rng = np.random.default_rng(5)
+    try:
+        def job(tag):
+            rids = []
+            for i in range(n_req * dp_size):
+                ids = [1, 2, 3] + rng.integers(0, 151000, 64).tolist() + [4, 5, 6, 7, 8]
+                rids.append(pool.start_streaming_request("", model_kwargs={"prompt_token_ids": ids, "language": "english"},
+                                                         request_id=f"{tag}{i}", block=True))
+            n = sum(len(c) // 2 for rid in rids for c in pool.stream(rid, timeout_s=600))
+            infos = [pool.request_info(r) for r in rids]
+            for r in rids:
+                pool.release(r)
+            return n, infos
+        job("warm")                          # graph capture of every batch size of the ramp, as in serving_throughput
+        t0 = time.perf_counter()
+        samples, infos = job("r")
+        dt = time.perf_counter() - t0
+        ttfa = sorted((i["first_audio_time"] - i["submit_time"]) * 1e3 for i in infos if i.get("first_audio_time"))
+        ranks = sorted({i["rank"] for i in infos})
+        return {"value": samples / dt, "unit": "audio samples/s", "dp_size": dp_size, "requests": n_req * dp_size, "frames_per_request": frames,
+                "seconds": dt, "ttfa_ms_p50_client": ttfa[len(ttfa) // 2] if ttfa else None, "ranks_used": ranks,
+                "daemon_startup_s": startup, "transport": "AF_UNIX PUSH/PULL (pyzmq absent)" if os.environ.get("VOX_TRANSPORT") == "ipc" or not _has_zmq() else "zmq ipc",
+                "scheduler": "base + async_scheduling, one daemon per GPU (scheduler_entry.py)"}
+    finally:
+        pool.cleanup()
+
+
+def _has_zmq():
+    try:
+        import zmq  # noqa: F401
+        return True
+    except ImportError:
+        return False
+
+
 def other_configs():
     """The other BASELINE.json configs, one GPU each, as sub-results of the same driver-timed command: every tool prints one JSON line
     (LM step + detokenizer in its loop, synthetic weights of the named architecture) and runs in its own process."""
@@ -592,8 +643,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttfa-requests", type=int, default=5, help="engine-level TTFA samples per setting (lock-step loop)")
     ap.add_argument("--serving-ttfa-requests", type=int, default=100, help="TTFA samples through Scheduler + ModelWorker (0 = skip)")
-    ap.add_argument("--serving-modes", type=str, default="ttfa,ttfa2,load,throughput", help="which serving-path measurements run "
-                    "(comma list of ttfa, ttfa2 = detokenize_interval 2, load = TTFA under 32-way load, throughput)")
+    ap.add_argument("--serving-modes", type=str, default="ttfa,ttfa2,load,throughput,pool", help="which serving-path measurements run "
+                    "(comma list of ttfa, ttfa2 = detokenize_interval 2, load = TTFA under 32-way load, throughput, pool = through the "
+                    "DP serving pool's daemon + sockets)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the weight broadcast / "
                     "all-reduce / barrier path even at world size 1 (exercises the multi-GPU code on one GPU)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs 1, 3, 4 sub-results (CosyVoice2, CSM-1B, GLM-4-Voice)")
@@ -699,6 +751,12 @@ def main():
                 _phase(f"serving throughput {k}")
             serving["throughput"]["batch1_base"] = serving_throughput(dev, shared, 1, min(args.serving_frames, 120), "base")
             _phase("serving throughput batch 1")
+        if "pool" in modes:
+            try:
+                serving["pool"] = serving_pool(8, 100)
+            except Exception as ex:          # a sub-result must never hide the headline
+                serving["pool"] = {"error": repr(ex)[:300]}
+            _phase("serving pool")
 
     if rank == 0:
         out = {
@@ -722,7 +780,9 @@ def main():
                 out[k] = serving[k]
         if "throughput" in serving:
             out["serving_path_throughput"] = serving["throughput"]
-        for k in ("ttfa_ms_p50_engine", "ttfa_ms_p50_engine_detokenize_interval_2"):
+        if "pool" in serving:
+            out["serving_pool_dp"] = serving["pool"]
+        for k in ("ttfa_ms_p50_engine", "ttfa_ms_p50_engine_detokenize_interval_2", "depth_persist"):
             if k in head:
                 out[k] = head[k]
         for b, r in sub_res.items():

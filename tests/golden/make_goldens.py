@@ -21,6 +21,7 @@ import _ref_harness as H  # noqa: E402
 
 from oracle import voxref as vr  # noqa: E402  (bf16<->numpy helpers + weight recipe only)
 from oracle import qwen3_ref as QR  # noqa: E402
+from oracle import qwen3_wide as QW  # noqa: E402
 
 
 def bits(t):
@@ -202,12 +203,24 @@ def g18_qwen3_lm_b12(ns):
     _qwen3_lm_golden(ns, [9, 5, 12, 6, 31, 10, 7, 11, 13, 3, 15, 6], "g18_qwen3_lm_b12.npz", seed=18, P=64)
 
 
-def _qwen3_lm_golden(ns, prompt_lens, fname, seed, P=32):
+def g21_qwen3_full_width(ns):
+    """ONE talker layer + ONE depth layer at the widths of Qwen3-TTS-1.7B (hidden 2048 / FFN 6144 / 16+8 heads of 128; depth
+    1024 / 3072; 3072 + 15 x 2048 vocabularies, 16 code groups; oracle/qwen3_wide.py) through the reference's own modules and worker, at
+    1, 12 and 32 concurrent requests (two decode frames each): the K = 2048 / 6144 / 1024 / 3072 reductions and every rounding
+    point of a full-width layer meet numbers the REFERENCE produced — at the row counts that take the fixed-order kernels (1),
+    the staged matrix-core linears (12) and the full-K matrix-core GEMMs (32)."""
+    for tag, lens, seed in (("b1", [12], 211), ("b12", [3, 5, 12, 2, 4, 6, 3, 9, 2, 5, 4, 3], 212),
+                            ("b32", [3, 2, 5, 4, 12, 3, 2, 6, 4, 3, 2, 5, 3, 4, 2, 7, 3, 2, 4, 3, 5, 2, 3, 4, 2, 6, 3, 2, 4, 3, 2, 5], 213)):
+        _qwen3_lm_golden(ns, lens, f"g21_qwen3_full_width_{tag}.npz", seed=seed, P=max(8, len(lens) + 2), cfg=QW.wide_cfg(),
+                         wseed=QW.WEIGHT_SEED, std=QW.WEIGHT_STD, n_frames=2, keep_kv=False, dl_cols=256)
+
+
+def _qwen3_lm_golden(ns, prompt_lens, fname, seed, P=32, cfg=None, wseed=0, std=0.08, n_frames=3, keep_kv=True, dl_cols=None):
     torch.cuda.synchronize = lambda *a, **k: None          # worker/base.py calls it unconditionally
     FU, MW = ns.flashinfer_utils, ns.ModelWorker
     from vox_serve.model.base import PreprocessOutput
-    cfg = QR.tiny_cfg()
-    W = QR.random_weights(cfg, seed=0, std=0.08)
+    cfg = cfg or QR.tiny_cfg()
+    W = QR.random_weights(cfg, seed=wseed, std=std)
     m = _ref_qwen3(ns, cfg, W)
     t, d = cfg.talker, cfg.depth
     page = 16
@@ -270,9 +283,10 @@ def _qwen3_lm_golden(ns, prompt_lens, fname, seed, P=32):
         out[f"r{r}_frame0"] = req.lm_output_tokens[-1].numpy().astype(np.int32)[0]
         out[f"r{r}_next_pos"] = np.int32(req.next_position_id)
         reqs.append(req)
-    out["prefill_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 else x) for x in rec["dlogits"]])
+    dlc = slice(None) if dl_cols is None else slice(0, dl_cols)      # (g21: the first dl_cols columns of every depth head)
+    out["prefill_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 else x)[..., dlc] for x in rec["dlogits"]])
     rec["dlogits"].clear()
-    for f in range(3):
+    for f in range(n_frames):
         li = w.prepare_lm_inputs(reqs, [])
         out[f"f{f}_pos"] = li["position_ids"].numpy().astype(np.int32)
         out[f"f{f}_indptr"] = np.array(li["paged_kv_indptr"], np.int32)
@@ -283,12 +297,14 @@ def _qwen3_lm_golden(ns, prompt_lens, fname, seed, P=32):
         w.run_lm_decode(reqs, li)
         out[f"f{f}_logits"] = bits(rec["logits"][-1][:, 0])
         out[f"f{f}_hidden"] = bits(rec["hidden"][-1])
-        out[f"f{f}_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 * len(reqs) else x) for x in rec["dlogits"]])
+        out[f"f{f}_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 * len(reqs) else x)[..., dlc] for x in rec["dlogits"]])
         rec["dlogits"].clear()
         out[f"f{f}_tokens"] = np.stack([r.lm_output_tokens[-1].numpy().astype(np.int32)[0] for r in reqs])
-    out["kv_final"] = bits(w.kv_cache)
+    if keep_kv:
+        out["kv_final"] = bits(w.kv_cache)
+    out["n_frames"] = np.int32(n_frames)
     np.savez_compressed(os.path.join(HERE, fname), **out)
-    print(fname, "ok; frame tokens", out["f2_tokens"][:, :6])
+    print(fname, "ok; frame tokens", out[f"f{n_frames - 1}_tokens"][:, :6])
 
 
 
@@ -773,7 +789,7 @@ def g9_csm_lm(ns):
         out[f"r{r}_prefill_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 else x) for x in rec["dlogits"]])
         rec["dlogits"].clear()
         reqs.append(req)
-    for f in range(3):
+    for f in range(n_frames):
         li = w.prepare_lm_inputs(reqs, [])
         out[f"f{f}_pos"] = li["position_ids"].numpy().astype(np.int32)
         out[f"f{f}_in_ids"] = li["input_ids"].numpy().astype(np.int32)
@@ -781,7 +797,7 @@ def g9_csm_lm(ns):
         w.run_lm_decode(reqs, li)
         out[f"f{f}_logits"] = bits(rec["logits"][-1][:, 0])
         out[f"f{f}_hidden"] = bits(rec["hidden"][-1])
-        out[f"f{f}_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 * len(reqs) else x) for x in rec["dlogits"]])
+        out[f"f{f}_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 * len(reqs) else x)[..., dlc] for x in rec["dlogits"]])
         rec["dlogits"].clear()
         out[f"f{f}_tokens"] = np.stack([r_.lm_output_tokens[-1].numpy().astype(np.int32)[0] for r_ in reqs])
     out["kv_final"] = bits(w.kv_cache)
@@ -1356,7 +1372,7 @@ def g17_flow_evolving(ns):
     np.savez_compressed(os.path.join(HERE, "g17_flow_evolving.npz"), **out)
 
 
-ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g18": g18_qwen3_lm_b12, "g19": g19_sampler_mc, "g4": g4_qwen3_codec, "g6": g6_host_traces,
+ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g18": g18_qwen3_lm_b12, "g21": g21_qwen3_full_width, "g19": g19_sampler_mc, "g4": g4_qwen3_codec, "g6": g6_host_traces,
        "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder, "g17": g17_flow_evolving, "g20": g20_snac_variants}
 
 if __name__ == "__main__":

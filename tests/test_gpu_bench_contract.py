@@ -26,7 +26,7 @@ def test_bench_line_contract_with_the_rccl_path_exercised_at_world_1():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "2", "--force-dist",
            "--ttfa-requests", "1", "--serving-ttfa-requests", "3", "--serving-modes", "ttfa", "--no-cpu-baseline",
-           "--no-other-configs", "--sub-batches", "8", "--exact-rows", "2"]
+           "--no-other-configs", "--no-kv-sweep", "--sub-batches", "8", "--exact-rows", "2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
@@ -52,3 +52,19 @@ def test_bench_line_contract_with_the_rccl_path_exercised_at_world_1():
     assert d["ranks_seen"] == 1
     b = d["weight_broadcast_rccl"]
     assert b["replicas_identical"] is True and b["bytes"] > 3e9 and b["GBps"] > 0
+
+
+def test_bench_explicit_batch_32_line():
+    """`--batch 32` (BASELINE config 3's batch size as the headline of the line): value = 32 requests x 1920 samples per step over
+    the timed steps, no sub-results, roofline present."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "32", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["batch_per_gpu"] == 32 and "batch8" not in d and "batch32" not in d and "kv_sweep" not in d
+    assert abs(d["value"] - 32 * 1920 * 10 / (d["ms_per_step"] * 10e-3)) / d["value"] < 1e-6
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["algorithmic_bytes_per_launch"] > 3.5e9

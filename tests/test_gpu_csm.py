@@ -203,6 +203,27 @@ def case_csm_full_width_b16(tape, dev):
     run_parity(dev, cfg, W, [(2 + i % 5, i % 3) for i in range(16)], 2, page=128, max_pages=32, tape=tape)
 
 
+def csm_full_depth_cfg():
+    cfg = CR.CSMCfg(max_pos=512)          # all 16 backbone + 4 depth layers of CSM-1B at full width
+    cfg.text_vocab = 4096
+    return cfg
+
+
+@taped("csm_full_depth_b16")
+def case_csm_full_depth_b16(tape, dev):
+    cfg = csm_full_depth_cfg()
+    W = Weights(lambda device=None: CR.random_csm_state_dict(cfg, 9, 0.02, device=device))
+    run_parity(dev, cfg, W, [(2 + i % 4, i % 3) for i in range(16)], 1, page=128, max_pages=32, tape=tape)
+
+
+@pytest.mark.slow
+def test_csm_full_depth_b16(dev):
+    """The whole CSM-1B stack — 16 backbone layers + the 4-layer depth decoder over all 31 depth steps — at BASELINE config 3's
+    batch size (16 requests): prefills and a free-running frame bit-exact against the oracle's recorded run (the 2 + 2-layer cases
+    above pin the layer shapes; this one the depth of the real model: 16 x 4 + 31 x 4 x 4 dependent linears per frame)."""
+    case_csm_full_depth_b16(Tape.open("csm_full_depth_b16"), dev)
+
+
 @pytest.mark.slow
 def test_csm_full_width_two_layers(dev):
     """CSM-1B layer shapes (2048 hidden, 32/8 heads of 64, FFN 8192; depth 1024, 8/2 heads of 128, FFN 8192, vocab 2051,

@@ -384,25 +384,52 @@ def rel_rms(a_bits, b_bits):
     return float(np.sqrt(((a - b) ** 2).mean() / (b ** 2).mean()))
 
 
-def test_b12_batched_path_against_reference_worker_logits(dev, golden):
-    """The independent check of the matrix-core paths: 12 concurrent requests on the tiny config against what the REFERENCE's own
-    modules produced through its ModelWorker (g18, tests/golden/make_goldens.py) — hidden states, codec logits, all depth logits
-    within bf16 rounding of the reference's (the tolerances of the oracle's own pin to this fixture, tests/test_oracle_goldens.py:
-    relative RMS of the logits <= 1.2e-2, observed 8.4e-3), teacher-forced with the reference's inputs; greedy ids equal but for near-ties.
-    (The bit-exact tests compare the engine with the oracle's restatement of these kernels; this one cannot be fooled by a wrong
-    K split mirrored on both sides.)"""
+def _record_parity_count(name, value):
+    """observed counts of the tolerance-based checks, for setting their bars (gpurun_out/ travels back from the GPU box)"""
+    import json, os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        p = os.path.join(d, "parity_counts.json")
+        cur = json.load(open(p)) if os.path.exists(p) else {}
+        cur[name] = value
+        json.dump(cur, open(p, "w"), indent=1, sort_keys=True)
+
+
+# (fixture, id-mismatch bar, atol hidden, atol logits, atol depth logits, relative-RMS bar).  g18: bars of the oracle's own pin to the
+# fixture; its id bar is the count observed on an MI355X (round 4: 0) + the 3 the CPU pin allows.  g21 (full-width layer, reference
+# modules): ids counted on the talker's column only (see tests/test_oracle_goldens.py), bars as on the CPU side.
+@pytest.mark.parametrize("fixture,max_mismatch,atol_h,atol_l,atol_d,rms_bar", [
+    ("g18_qwen3_lm_b12", 3, 4e-2, 5e-2, 6e-2, 1.2e-2),
+    ("g21_qwen3_full_width_b1", 4, 4e-2, 6e-2, 6e-2, 1.0e-2),
+    ("g21_qwen3_full_width_b12", 4, 4e-2, 6e-2, 6e-2, 1.0e-2),
+    ("g21_qwen3_full_width_b32", 4, 4e-2, 6e-2, 6e-2, 1.0e-2)])
+def test_batched_paths_against_reference_worker_logits(dev, golden, fixture, max_mismatch, atol_h, atol_l, atol_d, rms_bar):
+    """The independent check of the engine's numerics: what the REFERENCE's own modules produced through its ModelWorker
+    (tests/golden/make_goldens.py) — hidden states, codec logits, depth logits within bf16 rounding of the reference's, teacher-forced
+    with the reference's inputs; greedy ids equal but for near-ties.  g18: the tiny config at 12 requests.  g21: ONE talker layer + ONE
+    depth layer at the full widths of Qwen3-TTS-1.7B at 1 / 12 / 32 requests — the fixed-order kernels, the staged matrix-core linears
+    and the full-K matrix-core GEMMs with their K = 2048 / 6144 / 1024 / 3072 reductions.  (The bit-exact tests compare the engine with
+    the oracle's restatement of these kernels; this one cannot be fooled by a rounding point or K split mirrored on both sides.)"""
     from vox_serve_amd.engine import Qwen3Engine
-    g = golden("g18_qwen3_lm_b12")
-    cfg = QR.tiny_cfg()
-    W = QR.random_weights(cfg, seed=0, std=0.08)
+    g = golden(fixture)
+    wide = fixture.startswith("g21")
+    if wide:
+        from oracle import qwen3_wide as QW
+        cfg = QW.wide_cfg()
+        W = QR.random_weights(cfg, seed=QW.WEIGHT_SEED, std=QW.WEIGHT_STD)
+    else:
+        cfg = QR.tiny_cfg()
+        W = QR.random_weights(cfg, seed=0, std=0.08)
+    ncol = 1 if wide else cfg.n_groups
     page, P, lens = int(g["page"]), int(g["P"]), g["prompt_lens"].tolist()
+    n_frames = int(g["n_frames"]) if "n_frames" in g else 3
     B = len(lens)
     eng = Qwen3Engine(to_engine_cfg(cfg), {k: vr.to_torch(v).to(dev) for k, v in W.items()}, max_batch=B, page_size=page,
                       max_pages=P, max_seq_len=512, max_prefill_rows=128, keep_depth_logits=True, device=dev)
     sc = eng.sampling_cfg(greedy=True)
     live = np.ones(cfg.vocab, bool)
     live[cfg.suppress_ids] = False                      # the engine's out_logits are the masked ones (suppressed ids = -inf)
-    mism = 0
+    mism, worst = 0, 0.0
     for r, n in enumerate(lens):
         pg = g[f"r{r}_kv_pages"].tolist()
         eng.row_ids[:n] = torch.from_numpy(g[f"r{r}_ids"]).to(dev)
@@ -412,11 +439,11 @@ def test_b12_batched_path_against_reference_worker_logits(dev, golden):
                         slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1], indptr=[0, len(pg)], indices=pg)
         eng.prefill(n, 1, n, sc, feedback=False)
         torch.cuda.synchronize()
-        assert bf16_close(vr.from_torch(eng.out_hidden[:1]), g[f"r{r}_prefill_hidden"], ulps=4, atol=4e-2).all(), r
-        assert bf16_close(vr.from_torch(eng.out_logits[:1])[:, live], g[f"r{r}_prefill_logits"][:, live], ulps=4, atol=5e-2).all(), r
-        assert rel_rms(vr.from_torch(eng.out_logits[:1])[:, live], g[f"r{r}_prefill_logits"][:, live]) <= 1.2e-2, r
-        mism += int((eng.out_ids[0].cpu().numpy()[: cfg.n_groups] != g[f"r{r}_frame0"][: cfg.n_groups]).sum())
-    for f in range(3):
+        assert bf16_close(vr.from_torch(eng.out_hidden[:1]), g[f"r{r}_prefill_hidden"], ulps=4, atol=atol_h).all(), r
+        assert bf16_close(vr.from_torch(eng.out_logits[:1])[:, live], g[f"r{r}_prefill_logits"][:, live], ulps=4, atol=atol_l).all(), r
+        worst = max(worst, rel_rms(vr.from_torch(eng.out_logits[:1])[:, live], g[f"r{r}_prefill_logits"][:, live]))
+        mism += int((eng.out_ids[0].cpu().numpy()[:ncol] != g[f"r{r}_frame0"][:ncol]).sum())
+    for f in range(n_frames):
         eng.input_ids[:B] = torch.from_numpy(g[f"f{f}_in_ids"]).to(dev)           # teacher forcing with the reference's inputs
         eng.input_masks[:B] = 1
         eng.input_features[:B] = vr.to_torch(g[f"f{f}_in_feats"]).to(dev)
@@ -426,18 +453,63 @@ def test_b12_batched_path_against_reference_worker_logits(dev, golden):
                         slot=[int(last[r]) - 1 for r in range(B)], indptr=indptr, indices=indices)
         eng.frame(B, max(kvlen), sc, feedback=False)
         torch.cuda.synchronize()
-        assert bf16_close(vr.from_torch(eng.out_hidden[:B]), g[f"f{f}_hidden"], ulps=4, atol=4e-2).all(), f
-        assert bf16_close(vr.from_torch(eng.out_logits[:B])[:, live], g[f"f{f}_logits"][:, live], ulps=4, atol=5e-2).all(), f
-        assert rel_rms(vr.from_torch(eng.out_logits[:B])[:, live], g[f"f{f}_logits"][:, live]) <= 1.2e-2, f
+        assert bf16_close(vr.from_torch(eng.out_hidden[:B]), g[f"f{f}_hidden"], ulps=4, atol=atol_h).all(), f
+        assert bf16_close(vr.from_torch(eng.out_logits[:B])[:, live], g[f"f{f}_logits"][:, live], ulps=4, atol=atol_l).all(), f
+        worst = max(worst, rel_rms(vr.from_torch(eng.out_logits[:B])[:, live], g[f"f{f}_logits"][:, live]))
         got_ids = eng.out_ids[:B].cpu().numpy()[:, : cfg.n_groups]
         want_ids = g[f"f{f}_tokens"][:, : cfg.n_groups]
         # depth logits are comparable step by step only while the ids sampled so far agree (step i's input is id i-1)
         dl, rdl = vr.from_torch(eng.out_depth_logits[:, :B]), g[f"f{f}_dlogits"]
+        ncmp = 0
         for b in range(B):
             same = np.cumprod(got_ids[b] == want_ids[b])
             for i in range(cfg.n_groups - 1):
                 if same[i]:
-                    assert bf16_close(dl[i, b], rdl[i, b].reshape(-1), ulps=4, atol=6e-2).all(), (f, b, i)
-        mism += int((got_ids != want_ids).sum())
-    assert mism <= 3 * cfg.n_groups, mism      # a flipped near-tie changes the rest of that frame's depth ids
+                    want = rdl[i, b].reshape(-1)                      # (g21 keeps the first 256 columns of every depth head)
+                    assert bf16_close(dl[i, b][: want.shape[0]], want, ulps=4, atol=atol_d).all(), (f, b, i)
+                    ncmp += 1
+        assert ncmp >= B                                              # at least every request's first depth step was compared
+        mism += int((got_ids[:, :ncol] != want_ids[:, :ncol]).sum())
+    _record_parity_count(fixture, {"id_mismatches": mism, "max_rel_rms_logits": worst})
+    assert worst <= rms_bar, worst
+    assert mism <= max_mismatch, mism      # (g18: a flipped near-tie changes the rest of that frame's depth ids)
     eng.close()
+
+
+def test_persistent_depth_step_is_bit_identical_to_the_launch_chain(dev, monkeypatch):
+    """One-request frames at full size: depth steps 2..15 as ONE persistent launch each (k_depth_step: 256 resident blocks, stage outputs
+    handed over as tagged granules) against the 21-launch chain — ids, codec logits, all depth logits, fed-back features and the K/V
+    caches bit-identical over free-running streams (eager + graph replay, greedy + top-k), and no hand-off timed out."""
+    from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ps = 128
+
+    def make(persist):
+        monkeypatch.setenv("VOX_DEPTH_PERSIST", "1" if persist else "0")
+        e = Qwen3Engine(cfg, W, max_batch=1, page_size=ps, max_pages=8, max_seq_len=512, max_prefill_rows=64, keep_depth_logits=True)
+        e.keep_hidden = False
+        g = torch.Generator(device=dev).manual_seed(5)
+        e.kv[:, :3] = (torch.randn(e.kv[:, :3].shape, generator=g, device=dev) * 0.5).to(e.kv.dtype)
+        e.input_ids.zero_(); e.input_ids[:, -1] = cfg.tts_pad_id; e.input_ids[:, 0] = 17
+        e.input_masks[:1] = 1
+        e.input_features.zero_()
+        return e
+    ea, eb = make(False), make(True)
+    assert ea.depth_persist_status() == (False, 0)
+    if not eb.depth_persist_status()[0]:
+        pytest.skip("persistent depth step not available on this part (< 256 CUs)")
+    for use_graph, sc in ((False, ea.sampling_cfg(greedy=False, top_k=50, temperature=0.9)), (True, ea.sampling_cfg(greedy=True))):
+        for f in range(12):
+            for e in (ea, eb):
+                kv = 150 + f
+                pages = list(range((kv + ps - 1) // ps))
+                e.upload_plan(pos=[kv], kvlen=[kv], page=[pages[-1]], slot=[(kv - 1) % ps], indptr=[0, len(pages)], indices=pages)
+                e.frame(1, kv, sc, seed=3, feedback=True, use_graph=use_graph)
+            torch.cuda.synchronize()
+            for name in ("out_ids", "out_logits", "out_depth_logits", "next_features", "input_features", "input_ids"):
+                assert torch.equal(getattr(ea, name), getattr(eb, name)), (use_graph, f, name)
+    assert torch.equal(ea.kv, eb.kv)
+    assert eb.depth_persist_status() == (True, 0)
+    ea.close(); eb.close()

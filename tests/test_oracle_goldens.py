@@ -10,6 +10,7 @@ import pytest
 
 from oracle import voxref as vr
 from oracle import qwen3_ref as QR
+from oracle import qwen3_wide as QW
 from tests.conftest import bf16_close
 
 
@@ -132,6 +133,9 @@ def test_rope_variants(golden, tag, kw):
 
 
 # ---------------------------------------------------------------- g3 / g18: Qwen3 talker + depth --------
+G21_BARS = (4, 4e-2, 6e-2, 1.0e-2)      # (talker-id mismatches, atol hidden, atol logits, relative RMS of the logits)
+
+
 def _rel_rms(a_bits, b_bits):
     a, b = vr.bf2f(a_bits).astype(np.float64), vr.bf2f(b_bits).astype(np.float64)
     return float(np.sqrt(((a - b) ** 2).mean() / (b ** 2).mean()))
@@ -140,16 +144,33 @@ def _rel_rms(a_bits, b_bits):
 # tolerances: g3 as pinned in round 1; g18 (12 requests: six times the elements, prompts up to 31 rows) at the observed maxima
 # (logits 0.037 absolute / 19 bf16 ulp on one element, relative RMS 8.4e-3: one bf16 rounding flip early in a stack perturbs
 # everything downstream at the 1-ulp level) plus a margin — a wrong summation split shows as O(1) relative RMS
+# g21 (round 4): ONE talker + ONE depth layer at the full widths of Qwen3-TTS-1.7B through the reference's modules, at 1 / 12 / 32
+# requests — the K = 2048 / 6144 reductions and every rounding point of a full-width layer against the REFERENCE's numbers (a
+# rounding point misplaced identically in voxref.c and in the kernels would pass every oracle-vs-HIP test; not this one).
+# Observed on this container: relative RMS of the logits 5.5e-3 / 6.3e-3 / 6.1e-3 at 1 / 12 / 32 requests, talker-id mismatches
+# 0 / 0 / 2 (of 3 / 36 / 96): the bars are those with a margin.
 @pytest.mark.parametrize("fixture,max_mismatch,atol_h,atol_l,rms_bar", [("g3_qwen3_lm", 1, 2e-2, 3e-2, 6e-3),
-                                                                         ("g18_qwen3_lm_b12", 3, 4e-2, 5e-2, 1.2e-2)])
+                                                                         ("g18_qwen3_lm_b12", 3, 4e-2, 5e-2, 1.2e-2),
+                                                                         ("g21_qwen3_full_width_b1", G21_BARS[0], *G21_BARS[1:]),
+                                                                         ("g21_qwen3_full_width_b12", G21_BARS[0], *G21_BARS[1:]),
+                                                                         ("g21_qwen3_full_width_b32", G21_BARS[0], *G21_BARS[1:])])
 def test_qwen3_lm_against_reference_worker(golden, fixture, max_mismatch, atol_h, atol_l, rms_bar):
     """Prefill + 3 frames, greedy, through the oracle vs the reference's ModelWorker: B=2 (g3: the fixed-order kernels' arithmetic)
     and B=12 (g18: every linear of the batched frames, and the prompts above 2 rows, in the oracle's restatement of the matrix
     cores' order — the path the HIP engine takes at these row counts — against logits the REFERENCE produced)."""
     g = golden(fixture)
-    cfg = QR.tiny_cfg()
-    W = QR.random_weights(cfg, seed=0, std=0.08)
+    if fixture.startswith("g21"):
+        cfg = QW.wide_cfg()
+        W = QR.random_weights(cfg, seed=QW.WEIGHT_SEED, std=QW.WEIGHT_STD)
+    else:
+        cfg = QR.tiny_cfg()
+        W = QR.random_weights(cfg, seed=0, std=0.08)
     nreq = len(g["prompt_lens"]) if "prompt_lens" in g else 2
+    stats = {"rms": 0.0}
+    # g21's one-layer random model has nearly flat logits: a 1-ulp difference flips an argmax, and a flipped id changes every
+    # later depth id of its frame (the depth loop feeds its own samples).  Its id check therefore counts the talker's id only
+    # (column 0: decided by the teacher-forced inputs alone); the depth path is pinned through its logits on the GPU side.
+    ncol = 1 if fixture.startswith("g21") else None
     m = QR.Qwen3Ref(cfg, W, page_size=int(g["page"]), max_pages=int(g["P"]), max_batch=max(4, nreq))
     reqs = []
     tok_mismatch = 0
@@ -160,13 +181,14 @@ def test_qwen3_lm_against_reference_worker(golden, fixture, max_mismatch, atol_h
         assert req.next_position_id == int(g[f"r{r}_next_pos"])                            # quirk Q1
         assert bf16_close(hid, g[f"r{r}_prefill_hidden"], ulps=4, atol=atol_h).all()
         assert bf16_close(logits, g[f"r{r}_prefill_logits"], ulps=4, atol=atol_l).all()
+        stats["rms"] = max(stats["rms"], _rel_rms(logits, g[f"r{r}_prefill_logits"]))
         assert _rel_rms(logits, g[f"r{r}_prefill_logits"]) <= rms_bar
         out, _, _, _ = m.frame([req], logits, hid)
-        tok_mismatch += int((out[0] != g[f"r{r}_frame0"]).sum())
+        tok_mismatch += int((out[0][:ncol] != g[f"r{r}_frame0"][:ncol]).sum())
         # teacher-force the reference's frame so the following steps see identical inputs
         req.frames[-1] = g[f"r{r}_frame0"].copy()
         reqs.append(req)
-    for f in range(3):
+    for f in range(int(g["n_frames"]) if "n_frames" in g else 3):
         # inputs the reference fed (teacher forcing): ids + accumulated features
         for b, req in enumerate(reqs):
             req.input_ids = g[f"f{f}_in_ids"][b:b + 1].copy()
@@ -175,10 +197,12 @@ def test_qwen3_lm_against_reference_worker(golden, fixture, max_mismatch, atol_h
         assert np.array_equal(np.array([r.next_position_id - 1 for r in reqs]), g[f"f{f}_pos"])
         assert bf16_close(hid, g[f"f{f}_hidden"], ulps=4, atol=atol_h).all()
         assert bf16_close(logits, g[f"f{f}_logits"], ulps=4, atol=atol_l).all()
+        stats["rms"] = max(stats["rms"], _rel_rms(logits, g[f"f{f}_logits"]))
         assert _rel_rms(logits, g[f"f{f}_logits"]) <= rms_bar
         out, _, _, dl = m.frame(reqs, logits, hid)
-        tok_mismatch += int((out != g[f"f{f}_tokens"]).sum())
+        tok_mismatch += int((out[:, :ncol] != g[f"f{f}_tokens"][:, :ncol]).sum())
     # greedy ids agree except where bf16 near-ties flip (different fp32 summation order)
+    print(f"{fixture}: max relative RMS of the logits {stats['rms']:.3e}, token mismatches {tok_mismatch}")
     assert tok_mismatch <= max_mismatch, tok_mismatch     # g3: observed 0 here, 1 on the judge's host (one bf16 near-tie)
 
 

@@ -3506,6 +3506,16 @@ int vox_flow_slot_state(vox_flow* m, int slot, int32_t out[6]) {
     return VOX_OK;
 }
 
+struct FlowSlotIdx {
+    static constexpr int MAXN = 64;
+    int e[MAXN], c[2 * MAXN];
+};
+__global__ void k_flow_slot_idx(FlowSlotIdx ix, int n, int* eidx, int* cidx) {
+    const int t = threadIdx.x;
+    if (t < n) eidx[t] = ix.e[t];
+    else if (t >= FlowSlotIdx::MAXN && t - FlowSlotIdx::MAXN < 2 * n) cidx[t - FlowSlotIdx::MAXN] = ix.c[t - FlowSlotIdx::MAXN];
+}
+
 // one chunk of n requests that own slots[0..n): the flow runs against their caches, which then take this chunk's rows (sliding
 // window: the first `prefix` rows + the most recent ones).  The requests of one call must share their cache lengths, as the reference's
 // batched cache tensors do (DecoderCache.cat); the caller groups them.
@@ -3530,9 +3540,18 @@ int vox_flow_decode_chunk_slots(vox_flow* m, void* stream, const int32_t* tokens
     const int capE = c.max_cache / 2, capU = c.max_cache;
     if (T > capE - c.prefix / 2 || 2 * T > capU - c.prefix) return vox_fail(VOX_ERR_INVALID, "flow_decode_chunk_slots: chunk longer than the cache ring");
     hipStream_t st = (hipStream_t)stream;
-    VOX_HIP(hipMemcpyAsync(m->s_eidx, eidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    VOX_HIP(hipMemcpyAsync(m->s_cidx, cidx.data(), (size_t)2 * n * 4, hipMemcpyHostToDevice, st));
-    VOX_HIP(hipStreamSynchronize(st));          // (the index vectors above are stack-owned host memory)
+    if (n <= FlowSlotIdx::MAXN) {
+        // the slot index vectors travel as kernel arguments (copied at launch): no host buffer whose lifetime the stream depends on,
+        // so the call returns without waiting for the chunks queued before it.  Host-side slot states advance at enqueue time: all
+        // calls on one flow object must go through ONE stream (they are ordered against each other only there).
+        FlowSlotIdx ix{};
+        for (int b = 0; b < n; ++b) { ix.e[b] = eidx[b]; ix.c[b] = cidx[b]; ix.c[n + b] = cidx[n + b]; }
+        hipLaunchKernelGGL(k_flow_slot_idx, dim3(1), dim3(3 * FlowSlotIdx::MAXN), 0, st, ix, n, m->s_eidx, m->s_cidx);
+    } else {
+        VOX_HIP(hipMemcpyAsync(m->s_eidx, eidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        VOX_HIP(hipMemcpyAsync(m->s_cidx, cidx.data(), (size_t)2 * n * 4, hipMemcpyHostToDevice, st));
+        VOX_HIP(hipStreamSynchronize(st));          // (the index vectors above are stack-owned host memory)
+    }
     const vox_flow::SlotState cur = m->slot[slots[0]];
     VOX_TRY(flow_run(m, st, tokens, n, T, false, nullptr, 0, noise, seed, noise_stream, mu, &cur));
     hipLaunchKernelGGL(k_flow_to_bct, dim3(ew_grid((size_t)n * 2 * T * c.mel)), dim3(256), 0, st, m->buf[9], mel, n, 2 * T, c.mel);

@@ -464,6 +464,11 @@ struct vox_qwen3 {
     // depth meta offsets (in int32 elements) for i==1 and per i>=2
     int32_t *d1_pos, *d1_req, *d1_kvlen, *d1_slot, *d_indptr, *odd_rows;
     std::vector<int32_t*> di_pos, di_kvlen;
+    // persistent depth step (one request): device copy of the depth layers' weight pointers, the hand-off granules, the epoch
+    // and error words (kernels_lm.hip: k_depth_step)
+    void *dstep_layers = nullptr, *dstep_gran = nullptr;
+    unsigned* dstep_words = nullptr;      // [0] epoch, [1] error
+    int dstep = 0;                         // 1: depth steps 2.. of a one-request frame run as ONE launch each
 };
 
 __global__ void k_frame_init(int* out_ids, int stride, int col, int val, int B) {
@@ -532,9 +537,24 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         r.n_rows = rows;
         r.max_kvlen = i + 1;
         if (i > 1) { r.fixed_kvlen = i + 1; r.fixed_pos = i; r.identity_pages = 1; }
-        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= m->ctx->exact_rows));
         void* dl = io->out_depth_logits ? (void*)((bf16_t*)io->out_depth_logits + (size_t)(i - 1) * c.max_batch * c.depth_vocab)
                                         : m->dlogits;
+        if (m->dstep && B == 1 && i > 1 && !ablate()) {
+            // one request: the step's 5 layers + head as ONE persistent launch (bit-identical to the chain below)
+            const vox_stack_config& dcfg = m->depth->cfg;
+            DepthStepCall ds;
+            ds.layers_dev = m->dstep_layers; ds.n_layers = dcfg.layers; ds.final_norm = m->w.depth_norm;
+            ds.head_w = (const bf16_t*)m->w.depth_lm_head + (size_t)(i - 1) * c.depth_vocab * Hd;
+            ds.x_in = m->dx; ds.logits = dl; ds.gran = m->dstep_gran; ds.epoch = m->dstep_words; ds.err = m->dstep_words + 1;
+            ds.kv = m->dkv; ds.kv_layer_stride = (long)m->dkv_stride; ds.cs = m->depth->rope; ds.eps = dcfg.eps;
+            ds.scale = 1.0f / sqrtf((float)dcfg.head_dim);
+            ds.hidden = dcfg.hidden; ds.heads = dcfg.heads; ds.kv_heads = dcfg.kv_heads; ds.head_dim = dcfg.head_dim; ds.ffn = dcfg.ffn;
+            ds.vocab = c.depth_vocab; ds.qk_norm = dcfg.qk_norm; ds.qkv_bias = dcfg.qkv_bias; ds.rope_dim = dcfg.rope_dim;
+            ds.rope_interleave = dcfg.rope_interleave; ds.page_size = dcfg.page_size; ds.table_max_pos = m->depth->rope_max_pos;
+            ds.n_tokens = i + 1;
+            VOX_TRY(vox_launch_depth_step(st, ds));
+        } else {
+        VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= m->ctx->exact_rows));
         LinearCall h;  // depth final norm + lm_head[i-1]
         h.W = (const bf16_t*)m->w.depth_lm_head + (size_t)(i - 1) * c.depth_vocab * Hd;
         h.x = m->dx; h.x_rows = i == 1 ? m->odd_rows : nullptr; h.norm_w = m->w.depth_norm; h.eps = c.depth.eps;
@@ -544,6 +564,7 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         { static int hk = -2; if (hk == -2) { const char* e = getenv("VOX_HEAD_KEEP"); hk = e ? atoi(e) : -1; } if (hk >= 0) h.keep_weights = hk; }
 #endif
         if (!(ablate() & 2048)) VOX_TRY(vox_launch_linear(m->ctx, st, h));      // (dev knob 2048: leave out the depth heads)
+        }
         SampleCall s;
         s.logits = dl; s.B = B; s.V = c.depth_vocab; s.cfg = *sc; s.cfg.repetition_penalty = 1.0f;
         s.seed = seed; s.offset = (uint64_t)i; s.offset_dev = io->rng_offset; s.offset_mul = (uint64_t)G;
@@ -689,14 +710,61 @@ int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_
         }
         VOX_HIP(hipDeviceSynchronize());
     }
+    {
+        // persistent depth step (default for one-request frames): available when the depth transformer has the shape the kernel is
+        // written for (Qwen3-TTS: hidden 1024, 16 / 8 heads of 128, FFN 3072, 2048-entry codebook heads) on a part with >= 256 CUs;
+        // VOX_DEPTH_PERSIST=0 keeps the launch chain
+        DepthStepCall probe;
+        const vox_stack_config& dq = m->depth->cfg;       // (as the stack normalised it)
+        probe.hidden = dq.hidden; probe.heads = dq.heads; probe.kv_heads = dq.kv_heads; probe.head_dim = dq.head_dim; probe.ffn = dq.ffn;
+        probe.vocab = cfg->depth_vocab; probe.qk_norm = dq.qk_norm; probe.qkv_bias = dq.qkv_bias; probe.rope_dim = dq.rope_dim;
+        probe.rope_interleave = dq.rope_interleave; probe.page_size = dq.page_size; probe.n_layers = dq.layers; probe.n_tokens = 2;
+        const char* e = getenv("VOX_DEPTH_PERSIST");
+        const bool want = e ? e[0] == '1' : true;
+        int n_cu = 0, dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
+        // 256 blocks of 512 threads must all be resident at once (one per CU): a partitioned or smaller part keeps the launch chain
+        if (want && n_cu >= 256 && vox_depth_step_supported(probe) && w->depth_rope) {
+            std::vector<const void*> ptrs;
+            for (int l = 0; l < dc.layers; ++l) {
+                const vox_layer_weights& lw = w->depth_layers[l];
+                for (const void* q : {lw.wqkv, lw.wo, lw.wgate, lw.wup, lw.wdown, lw.ln1, lw.ln2, lw.qnorm, lw.knorm}) ptrs.push_back(q);
+            }
+            if (hipMalloc(&m->dstep_layers, ptrs.size() * sizeof(void*)) != hipSuccess || hipMalloc(&m->dstep_gran, 4096 * 8) != hipSuccess ||
+                hipMalloc((void**)&m->dstep_words, 8) != hipSuccess)
+                return vox_fail(VOX_ERR_NOMEM, "qwen3_create: hipMalloc");
+            VOX_HIP(hipMemcpy(m->dstep_layers, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice));
+            VOX_HIP(hipMemset(m->dstep_gran, 0, 4096 * 8));
+            const unsigned words[2] = {1u, 0u};
+            VOX_HIP(hipMemcpy(m->dstep_words, words, 8, hipMemcpyHostToDevice));
+            m->dstep = 1;
+        }
+    }
     *out = m;
+    return VOX_OK;
+}
+
+// 0 = every hand-off of the persistent depth steps so far arrived; else the code of the first spin that gave up (results since then
+// are garbage).  *enabled: whether this engine runs them.  Synchronises the device.
+int vox_qwen3_depth_persist_status(vox_qwen3* m, int32_t* enabled, uint32_t* error_code) {
+    if (!m) return vox_fail(VOX_ERR_INVALID, "qwen3_depth_persist_status: NULL");
+    if (enabled) *enabled = m->dstep;
+    if (error_code) {
+        *error_code = 0;
+        if (m->dstep) {
+            unsigned words[2];
+            VOX_HIP(hipMemcpy(words, m->dstep_words, 8, hipMemcpyDeviceToHost));
+            *error_code = words[1];
+        }
+    }
     return VOX_OK;
 }
 
 void vox_qwen3_destroy(vox_qwen3* m) {
     if (!m) return;
     vox_stack_destroy(m->talker); vox_stack_destroy(m->depth);
-    (void)hipFree(m->proj_tab);
+    (void)hipFree(m->proj_tab); (void)hipFree(m->dstep_layers); (void)hipFree(m->dstep_gran); (void)hipFree(m->dstep_words);
     for (void* p : {m->te, m->t1, m->text, m->x, m->depth_x, m->dx, m->dlogits, m->dkv, (void*)m->dmeta}) (void)hipFree(p);
     delete m;
 }

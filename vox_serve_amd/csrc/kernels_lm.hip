@@ -1584,9 +1584,21 @@ extern "C" int vox_dev_set_stamps(void* p) {
     if (g_vox_stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { \
         const unsigned long long li = atomicAdd(g_vox_stamps, 1ull); stamp_base = li < 4000 ? g_vox_stamps + 16 * (li + 1) : nullptr; }
 #define VOX_STAMP(k) if (stamp_base) stamp_base[k] = wall_clock64();
+// the same for the persistent depth step: 32 stamps per launch (block 0, thread 0), buffer set with vox_dev_set_stamps2()
+__device__ unsigned long long* g_vox_stamps2 = nullptr;
+extern "C" int vox_dev_set_stamps2(void* p) {
+    unsigned long long* q = (unsigned long long*)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_vox_stamps2), &q, sizeof(q)) == hipSuccess ? 0 : -1;
+}
+#define VOX_STAMP2_DECL unsigned long long* stamp2_base = nullptr; \
+    if (g_vox_stamps2 && blockIdx.x == 0 && threadIdx.x == 0) { \
+        const unsigned long long li = atomicAdd(g_vox_stamps2, 1ull); stamp2_base = li < 2000 ? g_vox_stamps2 + 32 * (li + 1) : nullptr; }
+#define VOX_STAMP2(k) if (stamp2_base) stamp2_base[k] = wall_clock64();
 #else
 #define VOX_STAMP_DECL
 #define VOX_STAMP(k)
+#define VOX_STAMP2_DECL
+#define VOX_STAMP2(k)
 #endif
 
 // ================================================================================================
@@ -2282,65 +2294,78 @@ __device__ __forceinline__ uint4 shfl4(uint4 v, int src) {
 // NT > 0: the number of visible tokens is a compile-time constant (depth loop: step i sees exactly i + 1 tokens, known when
 // the frame graph is captured): every token loop has its exact trip count and no predicates — at one wave per (row, head)
 // instruction count is time.  NT == 0: read from the plan arrays (<= 16).
+// Operands of the short attention that do NOT depend on the row's fresh q / k / v: the cached K (token-major: token 4u + grp, 16-byte
+// chunk j) and V (P.V layout: 4 dims per lane) of the earlier tokens, the norm weight chunk and the RoPE table entries.  Requested
+// first, so that they are in flight while the projection output arrives (plain loads in the launch-per-stage kernels, a polled
+// hand-off in the persistent depth step).
 template <int NT>
-__device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int hk, int lane, bf16_t* out_row,
-                                                bool do_append) {
-    constexpr int D = 128, LPT = 16, TMAX = NT > 0 ? NT : 16, UMAX = (TMAX + 3) / 4;
-    const int grp = lane >> 4, j = lane & 15;
-    const int g = lane >> 5, dq = lane & 31;      // P.V / output layout: lane = (q head g, dims 4 dq .. 4 dq + 3)
-    const int nqkv = (at.Hq + 2 * at.Hkv) * D;
+struct AttnShortPre {
+    static constexpr int TMAX = NT > 0 ? NT : 16, UMAX = (TMAX + 3) / 4;
+    uint4 kr[UMAX];
+    uint2 vr[TMAX];
+    uint4 gw4;
+    float4 cs4[4];
+    int L, nt;
+};
+template <int NT>
+__device__ __forceinline__ void attn_short_prefetch(const AttnArgs& at, int row, int hk, int lane, AttnShortPre<NT>& pf) {
+    constexpr int D = 128, TMAX = AttnShortPre<NT>::TMAX, UMAX = AttnShortPre<NT>::UMAX;
+    const int grp = lane >> 4, j = lane & 15, dq = lane & 31;
     const size_t ps = (size_t)2 * at.page_size * at.Hkv * D;
-    const int L = NT > 0 ? NT : (at.fixed_kvlen > 0 ? at.fixed_kvlen : at.q_kvlen[row]);
-    const int nt = NT > 0 ? NT : (L < TMAX ? L : TMAX);
+    pf.L = NT > 0 ? NT : (at.fixed_kvlen > 0 ? at.fixed_kvlen : at.q_kvlen[row]);
+    pf.nt = NT > 0 ? NT : (pf.L < TMAX ? pf.L : TMAX);
+    const int nt = pf.nt;
     const int* pages = at.identity_pages ? nullptr
                        : (at.ptab ? at.ptab + (size_t)row * at.pt_stride : at.indices + at.indptr[at.q_req[row]]);
-    const bf16_t* raw = at.qkv + (size_t)row * nqkv;
-    const bf16_t* src = grp == 0 ? raw + (size_t)(hk * 2) * D
-                      : grp == 1 ? raw + (size_t)(hk * 2 + 1) * D
-                      : grp == 2 ? raw + (size_t)at.Hq * D + (size_t)hk * D
-                                 : raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D;
-    const uint4 v = reinterpret_cast<const uint4*>(src)[j];
-    // the new token's V row in the P.V layout (4 dims per lane), straight from the projection output
-    const uint2 vnew = reinterpret_cast<const uint2*>(raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D)[dq];
     const bf16_t* nwp = grp < 2 ? at.qn : (grp == 2 ? at.kn : nullptr);
-    uint4 gw4 = make_uint4(0, 0, 0, 0);
-    if (nwp) gw4 = reinterpret_cast<const uint4*>(nwp)[j];
+    pf.gw4 = make_uint4(0, 0, 0, 0);
+    if (nwp) pf.gw4 = reinterpret_cast<const uint4*>(nwp)[j];
     int p = at.fixed_pos >= 0 ? at.fixed_pos : at.pos[row];
     p = p < 0 ? 0 : (p >= at.table_max_pos ? at.table_max_pos - 1 : p);
-    float4 cs4[4];
     {
         const float4* cp = reinterpret_cast<const float4*>(at.cs + (size_t)p * D) + (j & 7) * 4;   // row = D/2 (c,s) pairs
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cs4[k] = cp[k];
+        for (int k = 0; k < 4; ++k) pf.cs4[k] = cp[k];
     }
-    // cached K (token-major: token 4u + grp, 16-byte chunk j) and V (P.V layout: 4 dims per lane); token nt-1 is the new one
-    uint4 kr[UMAX];
-    uint2 vr[TMAX];
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
         const int t = u * 4 + grp;
-        kr[u] = make_uint4(0, 0, 0, 0);
+        pf.kr[u] = make_uint4(0, 0, 0, 0);
         if (t < nt - 1) {
             const int pgi = pages ? pages[t / at.page_size] : row;
-            kr[u] = reinterpret_cast<const uint4*>(at.kv + (size_t)pgi * ps + ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[j];
+            pf.kr[u] = reinterpret_cast<const uint4*>(at.kv + (size_t)pgi * ps + ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[j];
         }
     }
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
-        vr[t] = make_uint2(0, 0);
+        pf.vr[t] = make_uint2(0, 0);
         if (t < nt - 1) {
             const int pgi = pages ? pages[t / at.page_size] : row;
-            vr[t] = reinterpret_cast<const uint2*>(at.kv + (size_t)pgi * ps + (size_t)at.page_size * at.Hkv * D +
-                                                   ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[dq];
+            pf.vr[t] = reinterpret_cast<const uint2*>(at.kv + (size_t)pgi * ps + (size_t)at.page_size * at.Hkv * D +
+                                                      ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[dq];
         }
     }
+}
+
+// v: this lane's 16-byte chunk of its group's head row (grp 0 / 1: the two q heads, 2: the new k, 3: the new v);
+// vnew: the new token's V row in the P.V layout (dims 4 dq .. 4 dq + 3).
+template <int NT>
+__device__ __forceinline__ void attn_short_compute(const AttnArgs& at, int row, int hk, int lane, const uint4 v, const uint2 vnew,
+                                                   const AttnShortPre<NT>& pf, bf16_t* out_row, bool do_append) {
+    constexpr int D = 128, TMAX = AttnShortPre<NT>::TMAX, UMAX = AttnShortPre<NT>::UMAX;
+    const int grp = lane >> 4, j = lane & 15;
+    const int g = lane >> 5, dq = lane & 31;      // P.V / output layout: lane = (q head g, dims 4 dq .. 4 dq + 3)
+    const size_t ps = (size_t)2 * at.page_size * at.Hkv * D;
+    const int L = pf.L, nt = pf.nt;
+    const bool has_nw = grp < 3 && (grp < 2 ? at.qn : at.kn) != nullptr;
+    const uint4 gw4 = pf.gw4;
     // per-head RMSNorm (prep_head: butterfly<64> over a head's 16 non-zero lanes == butterfly<16>)
     float e[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
     {
         float s = sq8(v, 0.0f);
         s = butterfly<16>(s);
         const float rinv = 1.0f / sqrtf(s / (float)D + at.eps);
-        if (nwp) {
+        if (has_nw) {
             const float gw[8] = {bflo(gw4.x), bfhi(gw4.x), bflo(gw4.y), bfhi(gw4.y), bflo(gw4.z), bfhi(gw4.z), bflo(gw4.w), bfhi(gw4.w)};
 #pragma unroll
             for (int i = 0; i < 8; ++i) e[i] = bfround((e[i] * rinv) * gw[i]);
@@ -2350,8 +2375,8 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
     // the 16-lane row: one DPP move)
     uint4 hq;
     {
-        const float cc[8] = {cs4[0].x, cs4[0].z, cs4[1].x, cs4[1].z, cs4[2].x, cs4[2].z, cs4[3].x, cs4[3].z};
-        const float sn[8] = {cs4[0].y, cs4[0].w, cs4[1].y, cs4[1].w, cs4[2].y, cs4[2].w, cs4[3].y, cs4[3].w};
+        const float cc[8] = {pf.cs4[0].x, pf.cs4[0].z, pf.cs4[1].x, pf.cs4[1].z, pf.cs4[2].x, pf.cs4[2].z, pf.cs4[3].x, pf.cs4[3].z};
+        const float sn[8] = {pf.cs4[0].y, pf.cs4[0].w, pf.cs4[1].y, pf.cs4[1].w, pf.cs4[2].y, pf.cs4[2].w, pf.cs4[3].y, pf.cs4[3].w};
         float r[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -2383,7 +2408,7 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
         const int t = u * 4 + grp;
-        const uint4 kx = (t == nt - 1) ? knc : kr[u];
+        const uint4 kx = (t == nt - 1) ? knc : pf.kr[u];
         const float kf[8] = {bflo(kx.x), bfhi(kx.x), bflo(kx.y), bfhi(kx.y), bflo(kx.z), bfhi(kx.z), bflo(kx.w), bfhi(kx.w)};
         float d0 = 0.0f, d1 = 0.0f;
 #pragma unroll
@@ -2419,7 +2444,7 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
         const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pe), (t & 3) * 16 + UMAX + (t >> 2)));
         if (t < nt) {
             const float pt = g ? p1 : p0;
-            const uint2 vx = (t == nt - 1) ? vnew : vr[t];
+            const uint2 vx = (t == nt - 1) ? vnew : pf.vr[t];
             l = l + pt;
             o[0] = __fmaf_rn(pt, bflo(vx.x), o[0]); o[1] = __fmaf_rn(pt, bfhi(vx.x), o[1]);
             o[2] = __fmaf_rn(pt, bflo(vx.y), o[2]); o[3] = __fmaf_rn(pt, bfhi(vx.y), o[3]);
@@ -2432,6 +2457,27 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
         *reinterpret_cast<uint2*>(out_row + col) = r;
         if (at.out_frag) *reinterpret_cast<uint2*>(at.out_frag + frag_off(row, col, at.Hq * D)) = r;
     }
+}
+
+
+// launch-per-stage form: the row's q / k / v come from the projection output in memory
+template <int NT>
+__device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int hk, int lane, bf16_t* out_row,
+                                                bool do_append) {
+    constexpr int D = 128;
+    const int grp = lane >> 4, j = lane & 15, dq = lane & 31;
+    const int nqkv = (at.Hq + 2 * at.Hkv) * D;
+    const bf16_t* raw = at.qkv + (size_t)row * nqkv;
+    const bf16_t* src = grp == 0 ? raw + (size_t)(hk * 2) * D
+                      : grp == 1 ? raw + (size_t)(hk * 2 + 1) * D
+                      : grp == 2 ? raw + (size_t)at.Hq * D + (size_t)hk * D
+                                 : raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D;
+    const uint4 v = reinterpret_cast<const uint4*>(src)[j];
+    // the new token's V row in the P.V layout (4 dims per lane), straight from the projection output
+    const uint2 vnew = reinterpret_cast<const uint2*>(raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D)[dq];
+    AttnShortPre<NT> pf;
+    attn_short_prefetch<NT>(at, row, hk, lane, pf);
+    attn_short_compute<NT>(at, row, hk, lane, v, vnew, pf, out_row, do_append);
 }
 
 // standalone: one wave per (row, kv head), four pairs per block (NT as in attn_short_wave)
@@ -2496,6 +2542,339 @@ __global__ __launch_bounds__(512) void k_attn1_linear(AttnArgs at, LinArgs a) {
                 a.y[(size_t)b * a.N + n] = r;
             }
         }
+}
+
+// ================================================================================================
+// Persistent depth step (one request): the 5 layers x 4 stages + the codebook head of ONE depth-loop step in a single launch of
+// 256 resident blocks, instead of 21 dependent launches.  A stage's output vector travels between the blocks as 8-byte granules
+// {2 x bf16, tag} written by one relaxed agent-scope store each (sc1 write-through) and polled with relaxed agent-scope loads
+// until every tag matches (MI355X guide, persistent-kernel price list: granule hand-off); the weights of a stage are requested
+// BEFORE its inputs are polled, so they stream while the previous stage finishes — that, and 20 kernel boundaries less per step,
+// is the gain.  Arithmetic: k_gemv<1, KC, ...> / k_attn1_linear<1, 4, 1, NT> stage for stage — the same lane -> chunk assignment,
+// the same sequential dot8 / butterfly<64> order, the same bf16 rounding points — so the step is bit-identical to the launch chain.
+//   stage A  qkv    = Wqkv . rmsnorm(x, ln1)                         2048 column pairs: one per wave of every block
+//   stage B  x     += Wo . attention(qkv, depth KV)                  attention recomputed by every block (8 waves = 8 kv heads)
+//   stage C  h      = silu(Wg . n) * (Wu . n),  n = rmsnorm(x, ln2)  1536 pairs: waves 0..5
+//   stage D  x     += Wd . h                                         512 pairs: waves 0, 1
+//   head     logits = Whead . rmsnorm(x, norm)                       1024 pairs: waves 0..3, plain stores (a kernel boundary follows)
+// Tags: epoch * 64 + stage id; the epoch word is read by every block when it starts and advanced by block 0 when it ends (no block
+// can still be starting then: every block publishes a piece of stage A of layer 0, which block 0's later stages waited for).
+// Every spin is bounded: on a timeout the error word is set and the block goes on (wrong data, never a hang).
+struct DepthLayerW { const bf16_t *wqkv, *wo, *wgate, *wup, *wdown, *ln1, *ln2, *qn, *kn; };
+struct DepthStepArgs {
+    const DepthLayerW* layers;
+    int n_layers;
+    const bf16_t *final_norm, *head_w;
+    const bf16_t* x_in;          // [1024] plain bf16: the step's input row
+    bf16_t* logits;              // [2048] plain bf16
+    unsigned long long *gx, *gqkv, *gh;   // granules: 512, 2048, 1536
+    unsigned* epoch;
+    unsigned* err;
+    AttnArgs at;                 // kv / kv_w = layer 0 of the depth KV cache; fixed_pos, identity_pages, cs, eps, scale ... as in the launch chain
+    long kv_layer_stride;        // elements between the layers' caches
+    float eps;
+};
+#define VOX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// Bound of every poll loop (a pass is a round trip to the memory side, >= ~0.5 us: >= 20 ms).  Legitimate waits are microseconds —
+// up to a fraction of a millisecond when blocks of the launch wait for CUs held by another stream's kernel.  On a timeout the error
+// word is set and every later poll of the launch (and of later launches) gives up after one pass: wrong data, never a hang.
+#ifndef VOX_PERSIST_SPINS
+#define VOX_PERSIST_SPINS 40000u
+#endif
+// Gather of a granule vector into LDS: the block's last VOX_DS_PW waves poll (thread p of them takes granules p, p + 64 PW, ...) until
+// the tags match and park the payload words; the caller's barrier publishes them.  Who polls, and how often, is part of the price:
+// every poll is a round trip to the memory side, and pollers compete with the producers' weight streams and publishes (guide:
+// polling-cost) — idle waves must wait at a barrier, not in a poll loop.
+#ifndef VOX_DS_PW
+#define VOX_DS_PW 8
+#endif
+#ifndef VOX_DS_SLEEP
+#define VOX_DS_SLEEP 0
+#endif
+#ifndef VOX_DS_EXTRA_BARRIERS
+#define VOX_DS_EXTRA_BARRIERS 1
+#endif
+template <int TOTAL>
+__device__ __forceinline__ void gran_gather_lds(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code) {
+    constexpr int NP = 64 * VOX_DS_PW, PER = (TOTAL + NP - 1) / NP;
+    const int p = tid - (512 - NP);
+    if (p < 0) return;
+    unsigned val[PER];
+    for (unsigned spin = 0;; ++spin) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            if (p + NP * q < TOTAL) {
+                const unsigned long long x = __hip_atomic_load(g + p + NP * q, VOX_RLX_AGENT);
+                ok = ok && (unsigned)(x >> 32) == tag;
+                val[q] = (unsigned)x;
+            }
+        }
+        if (ok) break;
+        if (spin > VOX_PERSIST_SPINS) { atomicCAS(err, 0u, code); break; }
+        if ((spin & 63u) == 63u && __hip_atomic_load(err, VOX_RLX_AGENT) != 0u) break;      // somebody already gave up
+        if (VOX_DS_SLEEP) __builtin_amdgcn_s_sleep(VOX_DS_SLEEP);
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (p + NP * q < TOTAL) dst[p + NP * q] = val[q];
+}
+__device__ __forceinline__ void gran_write(unsigned long long* g, unsigned tag, bf16_t lo, bf16_t hi) {
+    __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned)lo | ((unsigned)hi << 16), VOX_RLX_AGENT);
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
+    constexpr int H = 1024, NQKV = 4096, NQ = 2048, F = 3072;
+    __shared__ __attribute__((aligned(16))) uint4 xb[H / 8];           // the residual stream x at the layer's input (bf16 row)
+    __shared__ __attribute__((aligned(16))) uint4 xc[H / 8];           // ... after the attention half (two buffers: two barriers less per layer)
+    __shared__ __attribute__((aligned(16))) uint4 qb[NQKV / 8];        // q | k | v of the step's token
+    __shared__ __attribute__((aligned(16))) uint4 hb[F / 8];           // the FFN's activated row
+    __shared__ __attribute__((aligned(16))) uint4 xs[NQ / 8];          // the attention output row
+    // (wave index made provably uniform: the weight rows' base addresses then live in scalar registers — left as a per-lane value
+    // the compiler hoists some forty 64-bit row pointers out of the layer loop into vector registers and spills them)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
+    const unsigned ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
+    const unsigned tag0 = ep * 64u;
+    auto tagof = [&](int l, int st) { return tag0 + 1u + (unsigned)(l * 4 + st); };
+    VOX_STAMP2_DECL
+    VOX_STAMP2(0)
+    // x of the step: plain row written by the previous kernel
+    reinterpret_cast<unsigned*>(xb)[tid] = reinterpret_cast<const unsigned*>(a.x_in)[tid];
+    for (int l = 0; l < a.n_layers; ++l) {
+        const DepthLayerW w = a.layers[l];
+        // ---------------- stage A: qkv = Wqkv . rmsnorm(x, ln1)  (2048 column pairs: one per wave of every block) ----------------
+        {
+            const int pr = blk * 8 + wave, n0 = 2 * pr;
+            uint4 wq[2][2], nwv[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint4* wr = reinterpret_cast<const uint4*>(w.wqkv + (size_t)(n0 + r) * H);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) wq[r][j] = wr[lane + 64 * j];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) nwv[j] = reinterpret_cast<const uint4*>(w.ln1)[lane + 64 * j];
+            if (l > 0) gran_gather_lds<512>(a.gx, tagof(l - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x100u + l);
+            __syncthreads();                               // x of this layer is in xb
+            uint4 xv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xv[j] = xb[lane + 64 * j];
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s = sq8(xv[j], s);
+            s = butterfly<64>(s);
+            const float rinv = 1.0f / sqrtf(s / (float)H + a.eps);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xv[j] = norm_chunk(xv[j], nwv[j], rinv);
+            float acc[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                float d = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) d = dot8(wq[r][j], xv[j], d);
+                acc[r] = butterfly<64>(d);
+            }
+            if (lane == 0) gran_write(a.gqkv + pr, tagof(l, 0), f2bf(acc[0]), f2bf(acc[1]));
+            VOX_STAMP2(1 + 6 * l)
+        }
+        // ---------------- stage B: x += Wo . attention  (512 pairs: waves 0, 1; the attention by all 8 waves = 8 kv heads) ----------------
+        {
+            const int pr = blk * 2 + wave, n0 = 2 * pr;
+            uint4 wo[2][4];
+            if (wave < 2) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint4* wr = reinterpret_cast<const uint4*>(w.wo + (size_t)(n0 + r) * NQ);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wo[r][j] = wr[lane + 64 * j];
+                }
+            }
+            AttnArgs at = a.at;
+            at.kv = a.at.kv + (size_t)l * a.kv_layer_stride;
+            at.kv_w = a.at.kv_w + (size_t)l * a.kv_layer_stride;
+            at.qn = w.qn; at.kn = w.kn;
+            const int hk = wave;
+            AttnShortPre<NT> pf;
+            attn_short_prefetch<NT>(at, 0, hk, lane, pf);
+            gran_gather_lds<2048>(a.gqkv, tagof(l, 0), reinterpret_cast<unsigned*>(qb), tid, a.err, 0x200u + l);
+            __syncthreads();                               // q | k | v in qb (and: every wave is done with xb's stage-A reads)
+            VOX_STAMP2(2 + 6 * l)
+            {
+                // this lane's chunk of its group's head row (q head 2 hk / 2 hk + 1, new k, new v) and its 4 dims of the new v
+                const int grp = lane >> 4, j16 = lane & 15, dq = lane & 31;
+                const int col = (grp == 0 ? (hk * 2) * 128 : grp == 1 ? (hk * 2 + 1) * 128 : grp == 2 ? NQ + hk * 128 : NQ + 1024 + hk * 128) + 8 * j16;
+                const uint4 v = qb[col >> 3];
+                const uint2 vnew = reinterpret_cast<const uint2*>(qb)[(NQ + 1024 + hk * 128 + 4 * dq) >> 2];
+                attn_short_compute<NT>(at, 0, hk, lane, v, vnew, pf, reinterpret_cast<bf16_t*>(xs), blk == 0);
+            }
+            __syncthreads();                               // the attention row is in xs
+            VOX_STAMP2(3 + 6 * l)
+            if (wave < 2) {
+                const unsigned resw = reinterpret_cast<const unsigned*>(xb)[pr];     // this pair's x (xb still holds the layer's input)
+                float acc[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    float d = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d = dot8(wo[r][j], xs[lane + 64 * j], d);
+                    acc[r] = butterfly<64>(d);
+                }
+                if (lane == 0) {
+                    const bf16_t r0 = f2bf(bflo(resw) + bf2f(f2bf(acc[0]))), r1 = f2bf(bfhi(resw) + bf2f(f2bf(acc[1])));
+                    gran_write(a.gx + pr, tagof(l, 1), r0, r1);
+                }
+            }
+            VOX_STAMP2(4 + 6 * l)
+        }
+        // ---------------- stage C: h = silu(Wg . n) * (Wu . n), n = rmsnorm(x, ln2)  (1536 pairs: waves 0..5) ----------------
+        {
+            const int pr = blk * 6 + wave, f0 = 2 * pr;
+            uint4 wg[2][2], wu[2][2], nwv[2];
+            if (wave < 6) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint4* gr = reinterpret_cast<const uint4*>(w.wgate + (size_t)(f0 + r) * H);
+                    const uint4* ur = reinterpret_cast<const uint4*>(w.wup + (size_t)(f0 + r) * H);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { wg[r][j] = gr[lane + 64 * j]; wu[r][j] = ur[lane + 64 * j]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) nwv[j] = reinterpret_cast<const uint4*>(w.ln2)[lane + 64 * j];
+            }
+            // (xc's last readers, the previous layer's stage-D residual words, were done before this layer's stage-A barrier: the barrier
+            // below is not needed for correctness — it parks the waves that have nothing to do in stage B's o_proj away from the poll loop)
+            if (VOX_DS_EXTRA_BARRIERS) __syncthreads();
+            gran_gather_lds<512>(a.gx, tagof(l, 1), reinterpret_cast<unsigned*>(xc), tid, a.err, 0x400u + l);
+            __syncthreads();
+            if (wave < 6) {
+                uint4 xv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xv[j] = xc[lane + 64 * j];
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) s = sq8(xv[j], s);
+                s = butterfly<64>(s);
+                const float rinv = 1.0f / sqrtf(s / (float)H + a.eps);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xv[j] = norm_chunk(xv[j], nwv[j], rinv);
+                bf16_t hv[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    float dg = 0.0f, du = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) dg = dot8(wg[r][j], xv[j], dg);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) du = dot8(wu[r][j], xv[j], du);
+                    const float gg = bfround(butterfly<64>(dg)), uu = bfround(butterfly<64>(du));
+                    hv[r] = f2bf(bfround(silu_c(gg)) * uu);
+                }
+                if (lane == 0) gran_write(a.gh + pr, tagof(l, 2), hv[0], hv[1]);
+            }
+            VOX_STAMP2(5 + 6 * l)
+        }
+        // ---------------- stage D: x += Wd . h  (512 pairs: waves 0, 1) ----------------
+        {
+            const int pr = blk * 2 + wave, n0 = 2 * pr;
+            uint4 wd[2][6];
+            if (wave < 2) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint4* wr = reinterpret_cast<const uint4*>(w.wdown + (size_t)(n0 + r) * F);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) wd[r][j] = wr[lane + 64 * j];
+                }
+            }
+            gran_gather_lds<1536>(a.gh, tagof(l, 2), reinterpret_cast<unsigned*>(hb), tid, a.err, 0x600u + l);
+            __syncthreads();                               // h in hb (xc = x after attention: the residual of this stage)
+            if (wave < 2) {
+                const unsigned resw = reinterpret_cast<const unsigned*>(xc)[pr];
+                float acc[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    float d = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) d = dot8(wd[r][j], hb[lane + 64 * j], d);
+                    acc[r] = butterfly<64>(d);
+                }
+                if (lane == 0) {
+                    const bf16_t r0 = f2bf(bflo(resw) + bf2f(f2bf(acc[0]))), r1 = f2bf(bfhi(resw) + bf2f(f2bf(acc[1])));
+                    gran_write(a.gx + pr, tagof(l, 3), r0, r1);
+                }
+            }
+            // (the next layer's stage A gathers into xb, whose last readers — stage A's rows and stage B's residual words of THIS layer —
+            // were done before the stage-C barrier, and hb is rewritten only after three more barriers: this barrier, too, only keeps
+            // the six idle waves out of the next poll loop while waves 0, 1 finish the down projection)
+            if (VOX_DS_EXTRA_BARRIERS) __syncthreads();
+            VOX_STAMP2(6 + 6 * l)
+        }
+    }
+    // ---------------- head: logits = Whead . rmsnorm(x, final_norm)  (1024 pairs: waves 0..3; plain stores, a kernel boundary follows) ----------------
+    {
+        const int pr = blk * 4 + wave, n0 = 2 * pr;
+        uint4 wh[2][2], nwv[2];
+        if (wave < 4) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint4* wr = reinterpret_cast<const uint4*>(a.head_w + (size_t)(n0 + r) * H);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) wh[r][j] = wr[lane + 64 * j];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) nwv[j] = reinterpret_cast<const uint4*>(a.final_norm)[lane + 64 * j];
+        }
+        gran_gather_lds<512>(a.gx, tagof(a.n_layers - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x700u);
+        __syncthreads();
+        if (wave < 4) {
+            uint4 xv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xv[j] = xb[lane + 64 * j];
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s = sq8(xv[j], s);
+            s = butterfly<64>(s);
+            const float rinv = 1.0f / sqrtf(s / (float)H + a.eps);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xv[j] = norm_chunk(xv[j], nwv[j], rinv);
+            float acc[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                float d = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) d = dot8(wh[r][j], xv[j], d);
+                acc[r] = butterfly<64>(d);
+            }
+            if (lane == 0) reinterpret_cast<unsigned*>(a.logits)[pr] = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
+        }
+    }
+    VOX_STAMP2(31)
+    if (blk == 0 && tid == 0) __hip_atomic_store(a.epoch, ep + 1u, VOX_RLX_AGENT);
+}
+
+bool vox_depth_step_supported(const DepthStepCall& c) {
+    return c.hidden == 1024 && c.heads == 16 && c.kv_heads == 8 && c.head_dim == 128 && c.ffn == 3072 && c.vocab == 2048 && c.qk_norm &&
+           !c.qkv_bias && c.rope_dim == 128 && !c.rope_interleave && c.n_tokens >= 2 && c.n_tokens <= 16 && c.n_layers >= 1 && c.page_size >= c.n_tokens;
+}
+int vox_launch_depth_step(hipStream_t st, const DepthStepCall& c) {
+    if (!vox_depth_step_supported(c)) return vox_fail(VOX_ERR_INVALID, "depth_step: unsupported shape");
+    DepthStepArgs a{};
+    a.layers = (const DepthLayerW*)c.layers_dev; a.n_layers = c.n_layers; a.final_norm = (const bf16_t*)c.final_norm;
+    a.head_w = (const bf16_t*)c.head_w; a.x_in = (const bf16_t*)c.x_in; a.logits = (bf16_t*)c.logits;
+    a.gx = (unsigned long long*)c.gran; a.gqkv = a.gx + 512; a.gh = a.gqkv + 2048;
+    a.epoch = c.epoch; a.err = c.err; a.kv_layer_stride = c.kv_layer_stride; a.eps = c.eps;
+    AttnArgs& at = a.at;
+    at.kv = (const bf16_t*)c.kv; at.kv_w = (bf16_t*)c.kv; at.cs = c.cs; at.eps = c.eps; at.scale = c.scale;
+    at.Hq = c.heads; at.Hkv = c.kv_heads; at.page_size = c.page_size; at.table_max_pos = c.table_max_pos;
+    at.rot = c.rope_dim; at.interleave = 0; at.fixed_kvlen = c.n_tokens; at.fixed_pos = c.n_tokens - 1; at.identity_pages = 1;
+    at.out = nullptr; at.out_frag = nullptr;
+    switch (c.n_tokens) {
+#define VOX_DS(NT_) case NT_: hipLaunchKernelGGL(k_depth_step<NT_>, dim3(256), dim3(512), 0, st, a); return VOX_OK;
+        VOX_DS(2) VOX_DS(3) VOX_DS(4) VOX_DS(5) VOX_DS(6) VOX_DS(7) VOX_DS(8) VOX_DS(9) VOX_DS(10) VOX_DS(11) VOX_DS(12)
+        VOX_DS(13) VOX_DS(14) VOX_DS(15) VOX_DS(16)
+#undef VOX_DS
+        default: break;
+    }
+    return vox_fail(VOX_ERR_INVALID, "depth_step: n_tokens out of range");
 }
 
 static void fill_attn_args(AttnArgs& a, const AttnCall& c) {

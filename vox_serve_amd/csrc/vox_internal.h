@@ -107,6 +107,24 @@ struct AttnCall {
     const int* ptab = nullptr;
     int pt_stride = 0, fixed_kvlen = 0, fixed_pos = -1, identity_pages = 0;
 };
+// Persistent depth step (one request): 5 layers + the codebook head of one depth-loop step in one launch (kernels_lm.hip).
+struct DepthStepCall {
+    const void* layers_dev = nullptr;      // device array of n_layers x 9 pointers {wqkv, wo, wgate, wup, wdown, ln1, ln2, qnorm, knorm}
+    int n_layers = 0;
+    const void *final_norm = nullptr, *head_w = nullptr, *x_in = nullptr;
+    void* logits = nullptr;
+    void* gran = nullptr;                  // 4096 granules of 8 bytes (x 512, qkv 2048, h 1536), zeroed at creation
+    unsigned *epoch = nullptr, *err = nullptr;
+    void* kv = nullptr;                    // depth KV cache of layer 0; row 0 owns page 0
+    long kv_layer_stride = 0;              // elements
+    const float* cs = nullptr;
+    float eps = 1e-6f, scale = 1.0f;
+    int hidden = 0, heads = 0, kv_heads = 0, head_dim = 0, ffn = 0, vocab = 0, qk_norm = 0, qkv_bias = 0, rope_dim = 0,
+        rope_interleave = 0, page_size = 0, table_max_pos = 0;
+    int n_tokens = 0;                      // visible tokens of the step (position n_tokens - 1)
+};
+bool vox_depth_step_supported(const DepthStepCall& c);
+int vox_launch_depth_step(hipStream_t st, const DepthStepCall& c);
 int vox_launch_attn_partial(hipStream_t st, const AttnCall& c);
 bool vox_attn_decode8_supported(const AttnCall& c);      // decode rows, 2..8 chunks: every chunk + the merge in one launch
 int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c);

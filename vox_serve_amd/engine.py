@@ -160,7 +160,6 @@ class Qwen3Engine:
         self.row_masks = torch.zeros(R, dtype=torch.uint8, device=dev)
         self.row_feats = torch.zeros(R, H, dtype=torch.bfloat16, device=dev)
         self._graphs = {}
-        self.max_graphs = 512          # frame graphs (batch x kv bucket); prefill graphs: own LRU (_prefill_graph)
         self.keep_hidden = True
         # The engine owns no stream: everything is enqueued on the CALLER's current stream, so results are ordered with
         # whatever the caller does next and no stream ever waits for another while a frame graph runs (N.graph_capture
@@ -247,6 +246,8 @@ class Qwen3Engine:
                              float(min_p or 0.0), float(temperature), 1.0)
 
     # ---- one frame ---------------------------------------------------------------------------------
+    max_graphs = 512          # frame graphs kept (batch x kv bucket x sampling); the oldest goes first.  Prefill graphs: own LRU (_prefill_graph)
+
     def frame(self, batch, max_kvlen, sampling=None, seed=0, feedback=True, use_graph=True):
         """Enqueue one frame on the current stream.  plan arrays / inputs must already be on the device."""
         sampling = sampling or self.sampling_cfg()
@@ -264,6 +265,15 @@ class Qwen3Engine:
             return
         key = (batch, bucket, bytes(sampling), seed, bool(feedback), self.keep_hidden)
         g = self._graphs.get(key)
+        # persistent depth steps: their bounded spins turn a stuck hand-off into wrong data + an error word, never a hang; look at
+        # the word now and then (a device synchronisation: every 512th one-request frame) and fail loudly
+        if batch == 1 and hasattr(self.L, "vox_qwen3_depth_persist_status") and type(self) is Qwen3Engine:
+            self._persist_frames = getattr(self, "_persist_frames", 0) + 1
+            if self._persist_frames % 512 == 0:
+                en, err = self.depth_persist_status()
+                if en and err:
+                    raise N.VoxError(f"persistent depth step: a hand-off timed out (code {err:#x}); results since are invalid "
+                                     "(VOX_DEPTH_PERSIST=0 selects the launch chain)")
         if g is None:
             io = self._io()
             st = N.stream()
@@ -352,6 +362,12 @@ class Qwen3Engine:
                                          self._pd("q_req").data_ptr(), n_rows, self._pd("last_rows").data_ptr(), n_req,
                                          min(max(32, max_kvlen), self.max_seq_len), ctypes.byref(sampling), seed,
                                          int(feedback))
+
+    def depth_persist_status(self):
+        """(enabled, error_code) of the persistent depth steps (include/voxhip.h: vox_qwen3_depth_persist_status); synchronises."""
+        en, err = ctypes.c_int32(0), ctypes.c_uint32(0)
+        N.check(self.L.vox_qwen3_depth_persist_status(self.h, ctypes.byref(en), ctypes.byref(err)))
+        return bool(en.value), int(err.value)
 
     def close(self):
         for g in list(self._graphs.values()) + list(self.__dict__.get("_pf_graphs", {}).values()):
