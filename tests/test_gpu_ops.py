@@ -132,6 +132,8 @@ def test_reference_wrappers_golden_on_gpu(dev, golden):
     (14, 2, 64, 8, [9, 130]),
     (4, 2, 16, 4, [3, 40]),
     (16, 8, 128, 128, [200, 33, 256, 97, 129, 64, 255, 161] * 4),      # 32 rows x 8 chunks x 8 kv heads: paired-chunk blocks
+    (16, 8, 128, 128, [2000, 1, 1300, 257]),                            # the long-context merge (k_attn_merge_row: up to 63 chunks)
+    (14, 2, 64, 16, [700, 290]),
 ])
 def test_paged_decode_attention_bit_exact(dev, Hq, Hkv, D, page, lens):
     from vox_serve_amd.flashinfer_utils import FlashInferDecodeWrapper

@@ -2975,10 +2975,69 @@ __global__ __launch_bounds__(256) void k_attn_merge(const float* part_o, const f
     if (out_frag) out_frag[frag_off(row, e % HD, HD)] = f2bf(O / L);
 }
 
+// The same merge for long contexts (more than 8 chunks: the > 256-token buckets), one block of D threads per (row, head): the chunk
+// maxima and sums are fetched once (coalesced), the chunk weights w_c = exp2((m_c - M) log2e) are evaluated once per chunk by thread c
+// instead of once per output element inside a dependent loop, and thread d then runs the two fma chains over the chunks in ascending
+// order with its partial-output loads issued eight at a time.  Same M, same w_c, same fma order: bit-identical to k_attn_merge
+// (which at 64 chunks spent ~25 us per layer in 56 dependent iterations of two loads + one exp each).
+#define VOX_MERGE_MAXC 128
+__global__ __launch_bounds__(128) void k_attn_merge_row(const float* part_o, const float* part_ml, const int* kvlen, bf16_t* out, int Hq, int D,
+                                                        int max_chunks, bf16_t* out_frag) {
+    __shared__ float2 mls[VOX_MERGE_MAXC];
+    __shared__ float ws[VOX_MERGE_MAXC];
+    __shared__ float red[2];
+    const int rh = blockIdx.x, row = rh / Hq, h = rh % Hq, d = threadIdx.x, lane = d & 63, wv = d >> 6;
+    const int nc = (kvlen[row] + VOX_TC - 1) / VOX_TC;
+    const float2* ml = reinterpret_cast<const float2*>(part_ml + (size_t)rh * max_chunks * 2);
+    const float* po = part_o + (size_t)rh * max_chunks * D + d;
+    float m = -INFINITY;
+    for (int c = d; c < nc; c += blockDim.x) {
+        const float2 v = ml[c];
+        mls[c] = v;
+        m = fmaxf(m, v.x);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, VOX_WAVE));
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    const float M = blockDim.x > 64 ? fmaxf(red[0], red[1]) : red[0];
+    for (int c = d; c < nc; c += blockDim.x) ws[c] = exp2_c((mls[c].x - M) * VOX_LOG2E);
+    __syncthreads();
+    float L = 0.0f, O = 0.0f;
+    int c = 0;
+    for (; c + 8 <= nc; c += 8) {
+        float ov[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = po[(size_t)(c + j) * D];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = ws[c + j];
+            L = __fmaf_rn(mls[c + j].y, w, L);
+            O = __fmaf_rn(ov[j], w, O);
+        }
+    }
+    for (; c < nc; ++c) {
+        const float w = ws[c];
+        L = __fmaf_rn(mls[c].y, w, L);
+        O = __fmaf_rn(po[(size_t)c * D], w, O);
+    }
+    if (d < D) {
+        const bf16_t r = f2bf(O / L);
+        out[(size_t)rh * D + d] = r;
+        if (out_frag) out_frag[frag_off(row, h * D + d, Hq * D)] = r;
+    }
+}
+
 int vox_launch_attn_merge(hipStream_t st, const float* part_o, const float* part_ml, const int* kvlen, void* out,
                           int Nq, int Hq, int D, int max_chunks, void* out_frag) {
     const int total = Nq * Hq * D;
     if (total <= 0) return VOX_OK;
+    static const bool row_on = [] { const char* e = getenv("VOX_ATTN_MERGE_ROW"); return !(e && e[0] == '0'); }();
+    if (row_on && max_chunks > 8 && max_chunks <= VOX_MERGE_MAXC && (D == 64 || D == 128)) {
+        hipLaunchKernelGGL(k_attn_merge_row, dim3(Nq * Hq), dim3(D), 0, st, part_o, part_ml, kvlen, (bf16_t*)out, Hq, D, max_chunks,
+                           (bf16_t*)out_frag);
+        return VOX_OK;
+    }
     hipLaunchKernelGGL(k_attn_merge, dim3((total + 255) / 256), dim3(256), 0, st, part_o, part_ml, kvlen,
                        (bf16_t*)out, Hq, D, max_chunks, total, (bf16_t*)out_frag);
     return VOX_OK;
