@@ -216,7 +216,9 @@ void vox_qwen3_destroy(vox_qwen3* m);
  * resident blocks (5 layers x 4 stages + the codebook head; stage outputs handed between the blocks as tagged 8-byte granules)
  * instead of 21 dependent launches — bit-identical results.  Chosen at vox_qwen3_create: on by default for the Qwen3-TTS depth shape on a
  * part with >= 256 CUs, VOX_DEPTH_PERSIST=0 in the environment keeps the launch chain.  All 256 blocks must be resident together: run ONE
- * such frame at a time per GPU (two engines replaying one-request frames concurrently on two streams can starve each other's blocks).  `*enabled`: whether this engine runs them; `*error_code`: 0, or the code of the first hand-off that timed
+ * such frame at a time per GPU (two engines replaying one-request frames concurrently on two streams can starve each other's blocks).
+ * The same mechanism runs the MLP half of every talker layer of a one-request frame (o_proj + residual, gate/up, down + residual in one
+ * launch; VOX_TALKER_PERSIST=0 keeps the three launches).  `*enabled`: bit 0 = depth steps, bit 1 = talker MLP halves.  `*enabled`: whether this engine runs them; `*error_code`: 0, or the code of the first hand-off that timed
  * out (bounded spins: a stuck launch gives up with garbage instead of hanging; everything since is invalid).  Synchronises the device. */
 int vox_qwen3_depth_persist_status(vox_qwen3* m, int32_t* enabled, uint32_t* error_code);
 /* Enqueue one whole frame for `batch` rows.  With feedback != 0 the engine also writes the next step's

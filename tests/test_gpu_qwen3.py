@@ -478,7 +478,7 @@ def test_batched_paths_against_reference_worker_logits(dev, golden, fixture, max
 
 def test_persistent_depth_step_is_bit_identical_to_the_launch_chain(dev, monkeypatch):
     """One-request frames at full size: depth steps 2..15 as ONE persistent launch each (k_depth_step: 256 resident blocks, stage outputs
-    handed over as tagged granules) against the 21-launch chain — ids, codec logits, all depth logits, fed-back features and the K/V
+    handed over as tagged granules) and the MLP half of every talker layer as one launch (k_talker_mlp) against the launch chain — ids, codec logits, all depth logits, fed-back features and the K/V
     caches bit-identical over free-running streams (eager + graph replay, greedy + top-k), and no hand-off timed out."""
     from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
     from vox_serve_amd.synth import synth_qwen3_weights
@@ -488,6 +488,7 @@ def test_persistent_depth_step_is_bit_identical_to_the_launch_chain(dev, monkeyp
 
     def make(persist):
         monkeypatch.setenv("VOX_DEPTH_PERSIST", "1" if persist else "0")
+        monkeypatch.setenv("VOX_TALKER_PERSIST", "1" if persist else "0")
         e = Qwen3Engine(cfg, W, max_batch=1, page_size=ps, max_pages=8, max_seq_len=512, max_prefill_rows=64, keep_depth_logits=True)
         e.keep_hidden = False
         g = torch.Generator(device=dev).manual_seed(5)
@@ -497,8 +498,8 @@ def test_persistent_depth_step_is_bit_identical_to_the_launch_chain(dev, monkeyp
         e.input_features.zero_()
         return e
     ea, eb = make(False), make(True)
-    assert ea.depth_persist_status() == (False, 0)
-    if not eb.depth_persist_status()[0]:
+    assert ea.depth_persist_status() == (0, 0)
+    if eb.depth_persist_status()[0] != 3:
         pytest.skip("persistent depth step not available on this part (< 256 CUs)")
     for use_graph, sc in ((False, ea.sampling_cfg(greedy=False, top_k=50, temperature=0.9)), (True, ea.sampling_cfg(greedy=True))):
         for f in range(12):
@@ -511,5 +512,5 @@ def test_persistent_depth_step_is_bit_identical_to_the_launch_chain(dev, monkeyp
             for name in ("out_ids", "out_logits", "out_depth_logits", "next_features", "input_features", "input_ids"):
                 assert torch.equal(getattr(ea, name), getattr(eb, name)), (use_graph, f, name)
     assert torch.equal(ea.kv, eb.kv)
-    assert eb.depth_persist_status() == (True, 0)
+    assert eb.depth_persist_status() == (3, 0)
     ea.close(); eb.close()

@@ -15,7 +15,8 @@ ps = 128
 
 
 def make(persist):
-    os.environ["VOX_DEPTH_PERSIST"] = "1" if persist else "0"
+    os.environ["VOX_DEPTH_PERSIST"] = "1" if persist & 1 else "0"
+    os.environ["VOX_TALKER_PERSIST"] = "1" if persist & 2 else "0"
     e = Qwen3Engine(cfg, W, max_batch=1, page_size=ps, max_pages=64, max_seq_len=2304, max_prefill_rows=128, keep_depth_logits=True)
     e.keep_hidden = False
     g = torch.Generator(device=dev).manual_seed(5)
@@ -31,9 +32,10 @@ def plan(e, kvlen):
     e.upload_plan(pos=[kvlen], kvlen=[kvlen], page=[pages[0][-1]], slot=[(kvlen - 1) % ps], indptr=[0, len(pages[0])], indices=pages[0])
 
 
-ea, eb = make(False), make(True)
+MODE = int(os.environ.get('PERSIST_MODE', '3'))       # bit 0: depth steps, bit 1: talker MLP halves
+ea, eb = make(0), make(MODE)
 print("persist enabled:", ea.depth_persist_status(), eb.depth_persist_status())
-assert eb.depth_persist_status()[0] and not ea.depth_persist_status()[0]
+assert eb.depth_persist_status()[0] == MODE and not ea.depth_persist_status()[0]
 bad = 0
 for use_graph in (False, True):
     sc = ea.sampling_cfg(greedy=True) if use_graph else ea.sampling_cfg(greedy=False, top_k=50, temperature=0.9)

@@ -246,6 +246,10 @@ struct vox_stack {
     float* attn_ws;
     size_t attn_ws_floats;
     int keep_weights = 0;   // the stack runs many times per frame (depth loop): keep its weights cache-resident
+    // persistent MLP half of a one-row decode layer (k_talker_mlp): hand-off granules, epoch / error words
+    void* mlp_gran = nullptr;
+    unsigned* mlp_words = nullptr;
+    int mlp_persist = 0;
 };
 
 // decode_rows: every row is the newest token of a distinct request (its K/V are not read by any other row), so the
@@ -280,6 +284,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
     const float scale = 1.0f / sqrtf((float)c.head_dim);
     bool xn_ready = false;   // s->xn holds norm(x) for the next norm-prologue linear (written by the producing GEMM's reduce)
     bool xf_ready = false;   // s->xfrag holds x in fragment-major form (written by the producing full-K GEMM's epilogue)
+    bool qkv_done = false;   // s->qkv already holds this layer's projection (fourth stage of the previous layer's k_talker_mlp)
     for (int l = 0; l < c.layers; ++l) {
         const vox_layer_weights& w = s->layers[l];
         void* kvl = (char*)kv + (size_t)l * kv_stride * 2;
@@ -291,7 +296,8 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         const vox_stack::FragW fwl = s->fw.empty() ? vox_stack::FragW{} : s->fw[l];
         a.W_frag = fwl.qkv;
         if (xf_ready && vox_linear_is_fullk(a)) a.x_frag = s->xfrag;
-        if (!(ablate() & 16)) VOX_TRY(vox_launch_linear(s->ctx, st, a));
+        if (qkv_done) qkv_done = false;      // the previous layer's persistent launch already produced this layer's q | k | v
+        else if (!(ablate() & 16)) VOX_TRY(vox_launch_linear(s->ctx, st, a));
         HeadCall hc;  // per-head norm + RoPE + paged append
         hc.q_src = s->qkv; hc.k_src = (bf16_t*)s->qkv + nq; hc.v_src = (bf16_t*)s->qkv + nq + nkv;
         hc.q_stride = hc.k_stride = hc.v_stride = nqkv;
@@ -346,6 +352,20 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
             } else {
                 VOX_TRY(vox_launch_attn_partial(st, ac));
                 if (mc > 1) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc, ac.out_frag));
+            }
+            if (decode_rows && n == 1 && s->mlp_persist && !ablate()) {
+                // one request: o_proj + residual, gate/up, down + residual as ONE persistent launch (bit-identical to the three below)
+                TalkerMlpCall tm;
+                tm.wo = w.wo; tm.wgate = w.wgate; tm.wup = w.wup; tm.wdown = w.wdown; tm.ln2 = w.ln2; tm.attn = s->attn_out; tm.x = x;
+                tm.gran = s->mlp_gran; tm.epoch = s->mlp_words; tm.err = s->mlp_words + 1; tm.eps = c.eps;
+                tm.hidden = c.hidden; tm.nq = nq; tm.ffn = c.ffn;
+                if (l + 1 < c.layers && nqkv == 4096 && !s->layers[l + 1].bqkv) {      // ... and the next layer's q | k | v projection
+                    tm.wqkv_next = s->layers[l + 1].wqkv; tm.ln1_next = s->layers[l + 1].ln1; tm.qkv_out = s->qkv; tm.nqkv = nqkv;
+                    qkv_done = true;
+                }
+                VOX_TRY(vox_launch_talker_mlp(st, tm));
+                xn_ready = xf_ready = false;
+                continue;
             }
             if (!(ablate() & 32)) VOX_TRY(vox_launch_linear(s->ctx, st, o));
         }
@@ -419,11 +439,31 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
 #ifdef VOX_DEV_KNOBS
     if (const char* e = getenv("VOX_STACK_KEEP")) s->keep_weights = atoi(e);
 #endif
+    {
+        // persistent MLP half for one-row decode layers (k_talker_mlp): the Qwen3-TTS talker shape on a part with >= 256 CUs;
+        // VOX_TALKER_PERSIST=0 keeps the three launches
+        TalkerMlpCall probe;
+        probe.hidden = s->cfg.hidden; probe.nq = s->cfg.heads * s->cfg.head_dim; probe.ffn = s->cfg.ffn;
+        const char* e = getenv("VOX_TALKER_PERSIST");
+        const bool want = e ? e[0] == '1' : true;
+        int n_cu = 0, dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
+        if (want && n_cu >= 256 && vox_talker_mlp_supported(probe) && !s->cfg.qkv_bias) {
+            if (hipMalloc(&s->mlp_gran, 4096 * 8) != hipSuccess || hipMalloc((void**)&s->mlp_words, 8) != hipSuccess)
+                return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc");
+            VOX_HIP(hipMemset(s->mlp_gran, 0, 4096 * 8));
+            const unsigned words[2] = {1u, 0u};
+            VOX_HIP(hipMemcpy(s->mlp_words, words, 8, hipMemcpyHostToDevice));
+            s->mlp_persist = 1;
+        }
+    }
     *out = s;
     return VOX_OK;
 }
 void vox_stack_destroy(vox_stack* s) {
     if (!s) return;
+    (void)hipFree(s->mlp_gran); (void)hipFree(s->mlp_words);
     for (auto& f : s->fw) { (void)hipFree(f.qkv); (void)hipFree(f.o); (void)hipFree(f.gate); (void)hipFree(f.up); (void)hipFree(f.down); }
     (void)hipFree(s->xfrag); (void)hipFree(s->hfrag); (void)hipFree(s->afrag);
     (void)hipFree(s->qkv); (void)hipFree(s->q); (void)hipFree(s->h); (void)hipFree(s->attn_out); (void)hipFree(s->xn); (void)hipFree(s->skws); (void)hipFree(s->attn_ws);
@@ -749,12 +789,16 @@ int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_
 // are garbage).  *enabled: whether this engine runs them.  Synchronises the device.
 int vox_qwen3_depth_persist_status(vox_qwen3* m, int32_t* enabled, uint32_t* error_code) {
     if (!m) return vox_fail(VOX_ERR_INVALID, "qwen3_depth_persist_status: NULL");
-    if (enabled) *enabled = m->dstep;
+    if (enabled) *enabled = (m->dstep ? 1 : 0) | (m->talker->mlp_persist ? 2 : 0);     // bit 0: depth steps, bit 1: talker MLP halves
     if (error_code) {
         *error_code = 0;
+        unsigned words[2];
         if (m->dstep) {
-            unsigned words[2];
             VOX_HIP(hipMemcpy(words, m->dstep_words, 8, hipMemcpyDeviceToHost));
+            *error_code = words[1];
+        }
+        if (!*error_code && m->talker->mlp_persist) {
+            VOX_HIP(hipMemcpy(words, m->talker->mlp_words, 8, hipMemcpyDeviceToHost));
             *error_code = words[1];
         }
     }

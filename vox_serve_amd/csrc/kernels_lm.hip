@@ -2851,6 +2851,221 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
     if (blk == 0 && tid == 0) __hip_atomic_store(a.epoch, ep + 1u, VOX_RLX_AGENT);
 }
 
+// ================================================================================================
+// Persistent MLP half of a talker layer (one request): o_proj + residual, gate/up + SiLU*up, down + residual — three dependent
+// weight-streaming stages (8.4 + 50.3 + 25.2 MB at Qwen3-TTS-1.7B) — in ONE launch of 256 resident blocks with the same granule
+// hand-offs as k_depth_step.  What it buys over three launches: the next stage's weights are requested BEFORE the hand-off is
+// polled (waves with no work in the first stage request theirs when the kernel starts), so HBM keeps streaming across the two
+// seams instead of idling for a kernel boundary plus a first-load latency each.  Arithmetic: k_gemv<1, 4 / 12, ...> stage for
+// stage — same lane -> chunk assignment, dot8 / butterfly<64> order and rounding points: bit-identical to the launch chain.
+//   stage O  x'  = x + Wo . attn                                  1024 column pairs: waves 0..3
+//   stage C  h   = silu(Wg . n) * (Wu . n),  n = rmsnorm(x', ln2)  3072 pairs: every wave one, waves 0..3 a second one
+//   stage D  x'' = x' + Wd . h                                    1024 pairs: waves 0..3, plain stores (a kernel boundary follows)
+struct TalkerMlpArgs {
+    const bf16_t *wo, *wgate, *wup, *wdown, *ln2;
+    const bf16_t *wqkv_next, *ln1_next;      // the NEXT layer's input_layernorm + q/k/v projection as a fourth stage (NULL: last layer)
+    bf16_t* qkv_out;                          // plain row [4096] for the attention launch that follows
+    const bf16_t *attn, *x_in;       // plain rows [2048]
+    bf16_t* x_out;                   // plain row [2048] (may alias x_in)
+    unsigned long long *gx, *gh;     // granules: 1024, 3072
+    unsigned *epoch, *err;
+    float eps;
+};
+template <int TOTAL>
+__device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code) {
+    constexpr int PER = (TOTAL + 511) / 512;
+    unsigned val[PER];
+    for (unsigned spin = 0;; ++spin) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            if (tid + 512 * q < TOTAL) {
+                const unsigned long long x = __hip_atomic_load(g + tid + 512 * q, VOX_RLX_AGENT);
+                ok = ok && (unsigned)(x >> 32) == tag;
+                val[q] = (unsigned)x;
+            }
+        }
+        if (ok) break;
+        if (spin > VOX_PERSIST_SPINS) { atomicCAS(err, 0u, code); break; }
+        if ((spin & 63u) == 63u && __hip_atomic_load(err, VOX_RLX_AGENT) != 0u) break;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (tid + 512 * q < TOTAL) dst[tid + 512 * q] = val[q];
+}
+
+__global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
+    constexpr int H = 2048, F = 6144;
+    __shared__ __attribute__((aligned(16))) uint4 xb[H / 8];           // x' (bf16 row)
+    __shared__ __attribute__((aligned(16))) uint4 hb[F / 8];           // h
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
+    const unsigned ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
+    const unsigned tag0 = ep * 64u;
+    // ---- weights of stage C, first pair of every wave: requested at once (waves 4..7 have nothing else to do until x' arrives)
+    const int p1 = blk * 12 + wave;                                     // 3072 pairs: 12 per block
+    uint4 wg1[2][4], wu1[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint4* gr = reinterpret_cast<const uint4*>(a.wgate + (size_t)(2 * p1 + r) * H);
+        const uint4* ur = reinterpret_cast<const uint4*>(a.wup + (size_t)(2 * p1 + r) * H);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wg1[r][j] = ldg_nt(gr + lane + 64 * j); wu1[r][j] = ldg_nt(ur + lane + 64 * j); }
+    }
+    // ---------------- stage O: x' = x + Wo . attn ----------------
+    if (wave < 4) {
+        const int pr = blk * 4 + wave, n0 = 2 * pr;
+        uint4 wo[2][4], av[4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint4* wr = reinterpret_cast<const uint4*>(a.wo + (size_t)(n0 + r) * H);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wo[r][j] = ldg_nt(wr + lane + 64 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[j] = reinterpret_cast<const uint4*>(a.attn)[lane + 64 * j];
+        const unsigned resw = reinterpret_cast<const unsigned*>(a.x_in)[pr];
+        float acc[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float d = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d = dot8(wo[r][j], av[j], d);
+            acc[r] = butterfly<64>(d);
+        }
+        if (lane == 0) {
+            const bf16_t r0 = f2bf(bflo(resw) + bf2f(f2bf(acc[0]))), r1 = f2bf(bfhi(resw) + bf2f(f2bf(acc[1])));
+            gran_write(a.gx + pr, tag0 + 1u, r0, r1);
+        }
+    }
+    // ---------------- stage C: h = silu(Wg . n) * (Wu . n), n = rmsnorm(x', ln2) ----------------
+    uint4 nwv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nwv[j] = reinterpret_cast<const uint4*>(a.ln2)[lane + 64 * j];
+    const int p2 = blk * 12 + 8 + wave;                                 // second pair: waves 0..3
+    uint4 wg2[2][4], wu2[2][4];
+    if (wave < 4) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint4* gr = reinterpret_cast<const uint4*>(a.wgate + (size_t)(2 * p2 + r) * H);
+            const uint4* ur = reinterpret_cast<const uint4*>(a.wup + (size_t)(2 * p2 + r) * H);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wg2[r][j] = ldg_nt(gr + lane + 64 * j); wu2[r][j] = ldg_nt(ur + lane + 64 * j); }
+        }
+    }
+    __syncthreads();                                   // (parks waves 4..7 until waves 0..3 have published their x' pairs)
+    gran_gather_lds_all<1024>(a.gx, tag0 + 1u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1100u);
+    __syncthreads();
+    uint4 xv[4];
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = xb[lane + 64 * j];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = sq8(xv[j], s);
+        s = butterfly<64>(s);
+        const float rinv = 1.0f / sqrtf(s / (float)H + a.eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = norm_chunk(xv[j], nwv[j], rinv);
+    }
+    auto ffn_pair = [&](const uint4 (&wg)[2][4], const uint4 (&wu)[2][4], int pr) {
+        bf16_t hv[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float dg = 0.0f, du = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dg = dot8(wg[r][j], xv[j], dg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) du = dot8(wu[r][j], xv[j], du);
+            const float gg = bfround(butterfly<64>(dg)), uu = bfround(butterfly<64>(du));
+            hv[r] = f2bf(bfround(silu_c(gg)) * uu);
+        }
+        if (lane == 0) gran_write(a.gh + pr, tag0 + 2u, hv[0], hv[1]);
+    };
+    ffn_pair(wg1, wu1, p1);
+    if (wave < 4) ffn_pair(wg2, wu2, p2);
+    // ---------------- stage D: x'' = x' + Wd . h ----------------
+    {
+        const int pr = blk * 4 + wave, n0 = 2 * pr;
+        uint4 wd[2][12];
+        if (wave < 4) {                                 // requested before the hand-off is polled: they stream while h completes
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint4* wr = reinterpret_cast<const uint4*>(a.wdown + (size_t)(n0 + r) * F);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) wd[r][j] = ldg_nt(wr + lane + 64 * j);
+            }
+        }
+        __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish their second pair)
+        gran_gather_lds_all<3072>(a.gh, tag0 + 2u, reinterpret_cast<unsigned*>(hb), tid, a.err, 0x1200u);
+        __syncthreads();
+        if (wave < 4) {
+            const unsigned resw = reinterpret_cast<const unsigned*>(xb)[pr];
+            float acc[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                float d = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) d = dot8(wd[r][j], hb[lane + 64 * j], d);
+                acc[r] = butterfly<64>(d);
+            }
+            if (lane == 0) {
+                const bf16_t r0 = f2bf(bflo(resw) + bf2f(f2bf(acc[0]))), r1 = f2bf(bfhi(resw) + bf2f(f2bf(acc[1])));
+                reinterpret_cast<unsigned*>(a.x_out)[pr] = (unsigned)r0 | ((unsigned)r1 << 16);      // (the next layer's residual reads it)
+                if (a.wqkv_next) gran_write(a.gx + pr, tag0 + 3u, r0, r1);
+            }
+        }
+    }
+    // ---------------- stage A of the next layer: qkv = Wqkv . rmsnorm(x'', ln1)  (2048 pairs: one per wave) ----------------
+    if (a.wqkv_next) {
+        const int pr = blk * 8 + wave, n0 = 2 * pr;
+        uint4 wq[2][4], nw1[4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint4* wr = reinterpret_cast<const uint4*>(a.wqkv_next + (size_t)(n0 + r) * H);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wq[r][j] = ldg_nt(wr + lane + 64 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nw1[j] = reinterpret_cast<const uint4*>(a.ln1_next)[lane + 64 * j];
+        __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish the down projection; xb is free)
+        gran_gather_lds_all<1024>(a.gx, tag0 + 3u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1300u);
+        __syncthreads();
+        uint4 yv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = xb[lane + 64 * j];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s = sq8(yv[j], s);
+        s = butterfly<64>(s);
+        const float rinv = 1.0f / sqrtf(s / (float)H + a.eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = norm_chunk(yv[j], nw1[j], rinv);
+        float acc[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float d = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d = dot8(wq[r][j], yv[j], d);
+            acc[r] = butterfly<64>(d);
+        }
+        if (lane == 0) reinterpret_cast<unsigned*>(a.qkv_out)[pr] = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
+    }
+    if (blk == 0 && tid == 0) __hip_atomic_store(a.epoch, ep + 1u, VOX_RLX_AGENT);
+}
+
+bool vox_talker_mlp_supported(const TalkerMlpCall& c) { return c.hidden == 2048 && c.nq == 2048 && c.ffn == 6144; }
+int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
+    if (!vox_talker_mlp_supported(c)) return vox_fail(VOX_ERR_INVALID, "talker_mlp: unsupported shape");
+    TalkerMlpArgs a{};
+    a.wo = (const bf16_t*)c.wo; a.wgate = (const bf16_t*)c.wgate; a.wup = (const bf16_t*)c.wup; a.wdown = (const bf16_t*)c.wdown;
+    a.ln2 = (const bf16_t*)c.ln2; a.attn = (const bf16_t*)c.attn; a.x_in = (const bf16_t*)c.x; a.x_out = (bf16_t*)c.x;
+    a.gx = (unsigned long long*)c.gran; a.gh = a.gx + 1024; a.epoch = c.epoch; a.err = c.err; a.eps = c.eps;
+    a.wqkv_next = (const bf16_t*)c.wqkv_next; a.ln1_next = (const bf16_t*)c.ln1_next; a.qkv_out = (bf16_t*)c.qkv_out;
+    if (c.wqkv_next && (c.nqkv != 4096 || !c.ln1_next || !c.qkv_out)) return vox_fail(VOX_ERR_INVALID, "talker_mlp: bad next-layer qkv");
+    hipLaunchKernelGGL(k_talker_mlp, dim3(256), dim3(512), 0, st, a);
+    return VOX_OK;
+}
+
 bool vox_depth_step_supported(const DepthStepCall& c) {
     return c.hidden == 1024 && c.heads == 16 && c.kv_heads == 8 && c.head_dim == 128 && c.ffn == 3072 && c.vocab == 2048 && c.qk_norm &&
            !c.qkv_bias && c.rope_dim == 128 && !c.rope_interleave && c.n_tokens >= 2 && c.n_tokens <= 16 && c.n_layers >= 1 && c.page_size >= c.n_tokens;

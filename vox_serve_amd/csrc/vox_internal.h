@@ -123,6 +123,21 @@ struct DepthStepCall {
         rope_interleave = 0, page_size = 0, table_max_pos = 0;
     int n_tokens = 0;                      // visible tokens of the step (position n_tokens - 1)
 };
+// Persistent MLP half of a talker layer at one row (o_proj + residual, gate/up, down + residual in one launch; kernels_lm.hip)
+struct TalkerMlpCall {
+    const void *wo = nullptr, *wgate = nullptr, *wup = nullptr, *wdown = nullptr, *ln2 = nullptr, *attn = nullptr;
+    void* x = nullptr;                     // the residual row, updated in place
+    void* gran = nullptr;                  // 4096 granules of 8 bytes (x' 1024, h 3072), zeroed at creation
+    unsigned *epoch = nullptr, *err = nullptr;
+    float eps = 1e-6f;
+    int hidden = 0, nq = 0, ffn = 0;
+    // optional fourth stage: the NEXT layer's input_layernorm + q/k/v projection (nqkv = 4096 outputs, plain row for the attention launch)
+    const void *wqkv_next = nullptr, *ln1_next = nullptr;
+    void* qkv_out = nullptr;
+    int nqkv = 0;
+};
+bool vox_talker_mlp_supported(const TalkerMlpCall& c);
+int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c);
 bool vox_depth_step_supported(const DepthStepCall& c);
 int vox_launch_depth_step(hipStream_t st, const DepthStepCall& c);
 int vox_launch_attn_partial(hipStream_t st, const AttnCall& c);

@@ -367,7 +367,7 @@ class Qwen3Engine:
         """(enabled, error_code) of the persistent depth steps (include/voxhip.h: vox_qwen3_depth_persist_status); synchronises."""
         en, err = ctypes.c_int32(0), ctypes.c_uint32(0)
         N.check(self.L.vox_qwen3_depth_persist_status(self.h, ctypes.byref(en), ctypes.byref(err)))
-        return bool(en.value), int(err.value)
+        return int(en.value), int(err.value)      # enabled: bit 0 = depth steps, bit 1 = talker MLP halves
 
     def close(self):
         for g in list(self._graphs.values()) + list(self.__dict__.get("_pf_graphs", {}).values()):
