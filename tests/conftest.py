@@ -50,6 +50,25 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=rank)
 
 
+@pytest.fixture(autouse=True)
+def _restore_cpu_threads():
+    """ModelWorker pins torch (and with it the process's OpenMP default) to ONE thread — right for a serving process, but every
+    oracle call of a later test then runs single-threaded (the full-width g21 cases: 40 s -> 270 s).  Put the budget back per test."""
+    n = int(os.environ["OMP_NUM_THREADS"])
+    try:
+        import torch
+        if torch.get_num_threads() != n:
+            torch.set_num_threads(n)
+    except Exception:
+        pass
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(n)
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

@@ -130,7 +130,8 @@ class ServingPool:
                 # ONE mask: with both set, the CUDA_ one would be applied on top of the HIP_ one (an index into what is left)
                 env["HIP_VISIBLE_DEVICES"] = str(gpu_mapping[rank])
                 env.pop("CUDA_VISIBLE_DEVICES", None)
-            proc = subprocess.Popen(self._daemon_cmd(rank), env=env)
+            # the daemons' stdout goes to this process's stderr: the parent's stdout may be a protocol (bench.py prints ONE JSON line)
+            proc = subprocess.Popen(self._daemon_cmd(rank), env=env, stdout=2)
             self.scheduler_processes.append(proc)
             self.logger.info(f"started scheduler daemon rank {rank}/{self.dp_size} pid {proc.pid} on GPU {gpu_mapping[rank]}")
 

@@ -41,7 +41,7 @@ def _build_worker(args, device):
 def _run_scheduler_daemon(args) -> None:
     visible = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "not set"))
     print(f"[DP ENTRY] rank {args.dp_rank}/{args.dp_size}: torch already imported: {'torch' in sys.modules}, "
-          f"visible devices: {visible}", flush=True)
+          f"visible devices: {visible}", file=sys.stderr, flush=True)      # (stderr: a parent's stdout may be a protocol, e.g. bench.py's one JSON line)
     import torch                    # first import in this process: sees the mask the parent set
 
     n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
@@ -62,7 +62,7 @@ def _run_scheduler_daemon(args) -> None:
     ready = {"dp_rank": args.dp_rank, "dp_size": args.dp_size, "pid": os.getpid(), "device": device,
              "visible_devices": visible, "torch_devices": n_dev}
     transport.send_result(f"__rank{args.dp_rank}__".encode() + b"|READY|" + json.dumps(ready).encode())
-    print(f"[DP ENTRY] rank {args.dp_rank}: scheduler '{kind}' serving {args.model_name} on {device}", flush=True)
+    print(f"[DP ENTRY] rank {args.dp_rank}: scheduler '{kind}' serving {args.model_name} on {device}", file=sys.stderr, flush=True)
     scheduler.run_forever()
 
 
