@@ -284,18 +284,15 @@ __global__ __launch_bounds__(256, (WM * WN > 12 ? 3 : 4)) void k_conv_gemm(ConvG
 // a time, double-buffered, one barrier per tap.  Accumulation order: chunk-major, taps inside, the m term before the h term.
 // Requires: all offsets in [0, H], L % BM == 0 (a tile lies inside one request).  Dynamic LDS: (2 (BM + H) + 2 BN) x 80 bytes.
 template <int WM, int WN>
-__global__ __launch_bounds__(256, (WM * WN >= 12 ? 3 : 4)) void k_conv_taps(ConvGemmArgs a, int H) {
+__device__ __forceinline__ void conv_taps_kloop(const ConvGemmArgs& a, int H, unsigned char* smem_raw, f32x4 (&acc)[WM][WN], int m0, int n0) {
     constexpr int BM = 32 * WM, BN = 32 * WN, LD = 40, NBR = (BN * 4 + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int R = BM + H;
     bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);          // [2][R][LD]
     bf16_t* Bs = As + (size_t)2 * R * LD;                       // [2][BN][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wm = (wave >> 1) * 16 * WM, wn = (wave & 1) * 16 * WN;
     const int rb = m0 / a.L, t0 = m0 - rb * a.L;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    f32x4 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -373,7 +370,104 @@ __global__ __launch_bounds__(256, (WM * WN >= 12 ? 3 : 4)) void k_conv_taps(Conv
             __syncthreads();      // the next tap's weights are visible; this tap's buffer may be overwritten by the tap after next
         }
     }
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, (WM * WN >= 12 ? 3 : 4)) void k_conv_taps(ConvGemmArgs a, int H) {
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wm = (wave >> 1) * 16 * WM, wn = (wave & 1) * 16 * WN;
+    f32x4 acc[WM][WN];
+    conv_taps_kloop<WM, WN>(a, H, smem_raw, acc, m0, n0);
     conv_epilogue<WM, WN>(a, acc, m0, n0, wm, wn, lane);
+}
+
+// A whole residual unit of the decoder in ONE kernel:  h += conv2(act2(conv1(x)))  and  out2 = act_next(h)  — conv1 = the dilated 7-tap
+// conv over S2 rows (k_conv_taps' K loop), conv2 = the 1-tap C -> C conv.  The block's tile covers ALL C output channels of conv1, so the
+// activated intermediate (the whole K of conv2) is on chip: it goes from the accumulators through Snake + the two-term split into LDS
+// as the A operand of the second GEMM instead of to HBM and back (per unit at 614 k rows x 96 channels: 236 MB written + 236 MB read).
+// Accumulation orders are those of the two kernels it replaces (conv2: 32-channel chunks in order, the m term before the h term), so the
+// results are bit-identical.  a2.out2 must not alias a1.x: a neighbouring tile still reads its halo rows of x.
+// Dynamic LDS: max((2 (BM + H) + 2 BN) x 80, 2 BM (C + 8) x 2 + 2 BN x 80) bytes.
+template <int WM, int WN>
+__global__ __launch_bounds__(256, (WM * WN >= 12 ? 2 : 3)) void k_res_unit(ConvGemmArgs a1, ConvGemmArgs a2, int H) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, LD = 40, NBR = (BN * 4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM;
+    const int wm = (wave >> 1) * 16 * WM, wn = (wave & 1) * 16 * WN;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    f32x4 acc[WM][WN];
+    conv_taps_kloop<WM, WN>(a1, H, smem_raw, acc, m0, 0);
+    // ---- the activated intermediate as the second GEMM's A operand: [2 terms][BM][C + 8] bf16
+    const int C = a1.N, LD2 = C + 8;
+    bf16_t* A2 = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* B2 = A2 + (size_t)2 * BM * LD2;                     // [2][BN][LD]
+    uint4 wv[NBR];
+    auto fetchB = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NBR; ++i) {
+            const int idx = tid + 256 * i, bn = idx >> 2;
+            wv[i] = make_uint4(0, 0, 0, 0);
+            if (idx < BN * 4 && bn < a2.N) wv[i] = *reinterpret_cast<const uint4*>(a2.w + (size_t)bn * a2.Cin + c0 + (idx & 3) * 8);
+        }
+    };
+    auto storeB = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < NBR; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < BN * 4) *reinterpret_cast<uint4*>(B2 + ((size_t)q * BN + (idx >> 2)) * LD + (idx & 3) * 8) = wv[i];
+        }
+    };
+    fetchB(0);
+    __syncthreads();                                            // every wave is done with the first GEMM's tiles
+    {
+        const int l15 = lane & 15, rg = (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = wn + j * 16 + l15;
+            const float cb = a1.bias ? a1.bias[n % a1.bias_mod] : 0.0f;
+            const int cc = n % a1.sn_mod;
+            const float ca = a1.sn_alpha[cc], ci = a1.sn_invb[cc];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = snake_f(acc[i][j][r] + cb, ca, ci);
+                    bf16_t hb, mb;
+                    split2(sv, hb, mb);
+                    const int row = wm + i * 16 + rg + r;
+                    A2[(size_t)row * LD2 + n] = hb;
+                    A2[((size_t)BM + row) * LD2 + n] = mb;
+                    acc[i][j][r] = 0.0f;
+                }
+        }
+    }
+    storeB(0);
+    __syncthreads();
+    const int nck = C >> 5;
+    for (int ck = 0; ck < nck; ++ck) {
+        if (ck + 1 < nck) fetchB((ck + 1) * 32);
+        const bf16_t* Bq = B2 + (size_t)(ck & 1) * BN * LD;
+        uint4 bfr[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(Bq + (wn + j * 16 + fr) * LD + fk);
+#pragma unroll
+        for (int p = 1; p >= 0; --p) {          // smaller term first
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const uint4 afr = *reinterpret_cast<const uint4*>(A2 + ((size_t)p * BM + wm + i * 16 + fr) * LD2 + ck * 32 + fk);
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(afr), as_cbf8(bfr[j]), acc[i][j], 0, 0, 0);
+            }
+        }
+        if (ck + 1 < nck) storeB((ck + 1) & 1);
+        __syncthreads();
+    }
+    conv_epilogue<WM, WN>(a2, acc, m0, 0, wm, wn, lane);
 }
 
 // LayerNorm row statistics by the 16 lanes l16 = 0..15 of a row group (two passes over float4 chunks, butterfly inside the group).
@@ -1138,6 +1232,54 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     return vox_fail(VOX_ERR_INVALID, "codec gemm: no tile variant");
 }
 
+// A residual unit as ONE launch (k_res_unit) where the tile can cover all channels and the stage has enough rows to fill the chip;
+// *fused = 0 and nothing launched otherwise (the caller then runs the two convs).  x: the S2 activated input rows; h: the fp32
+// residual stream, updated in place; out2: the NEXT consumer's activation of the new h — must not alias x.
+static bool res_unit_on() {
+    static const bool on = [] { const char* e = getenv("VOX_RES_UNIT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// (measured at 614 k / 205 k rows, B = 32: the 96-channel unit 544 -> 390-430 us fused; the 192-channel unit with the 64 x 192 tile it
+// needs 482 -> 500 us — its two launches stay.  VOX_RES_UNIT_192=1 fuses it all the same, for timing.)
+static bool res_unit_192() {
+    static const bool on = [] { const char* e = getenv("VOX_RES_UNIT_192"); return e && e[0] == '1'; }();
+    return on;
+}
+static int conv_unit(hipStream_t st, const vox_conv_w& w1, const vox_conv_w& w2, const float* x, const float* state, const int* slots, int n, int L,
+                     int P, const int* offs, const vox_snake_w& act2, float* h, float* out2, const vox_snake_w* nx, int out2_s2, int* fused) {
+    *fused = 0;
+    const int C = w1.n;
+    if (!res_unit_on() || !conv_taps_on() || g_conv_planes != 2 || w1.n_taps < 2 || w1.n_taps > CG_MAXTAPS || w2.n_taps != 1 || w1.cin != C ||
+        w2.cin != C || w2.n != C || (C != 96 && !(C == 192 && res_unit_192())) || out2 == x || !nx)
+        return VOX_OK;
+    int H = 0, omin = 0;
+    for (int k = 0; k < w1.n_taps; ++k) { H = offs[k] > H ? offs[k] : H; omin = offs[k] < omin ? offs[k] : omin; }
+    const int M = n * L, bm = C == 96 ? 128 : 64;
+    if (omin < 0 || H > 64 || L % bm || M / bm < 256) return VOX_OK;
+    ConvGemmArgs a1{}, a2{};
+    a1.x = x; a1.state = state; a1.slots = slots; a1.w = (const bf16_t*)w1.w; a1.bias = w1.bias; a1.M = M; a1.N = C; a1.Cin = C; a1.L = L; a1.P = P;
+    a1.n_taps = w1.n_taps; a1.planes = 2; a1.x_s2 = 1; a1.bias_mod = w1.bias_mod > 0 ? w1.bias_mod : C;
+    a1.sn_alpha = act2.alpha; a1.sn_invb = act2.inv_beta; a1.sn_mod = C;
+    for (int k = 0; k < w1.n_taps; ++k) a1.off[k] = offs[k];
+    a2.w = (const bf16_t*)w2.w; a2.bias = w2.bias; a2.res = h; a2.out = h; a2.M = M; a2.N = C; a2.Cin = C; a2.L = L; a2.n_taps = 1; a2.planes = 2;
+    a2.x_s2 = 1; a2.bias_mod = w2.bias_mod > 0 ? w2.bias_mod : C; a2.out2 = out2; a2.sn_alpha = nx->alpha; a2.sn_invb = nx->inv_beta; a2.sn_mod = C;
+    a2.out2_s2 = out2_s2;
+    const size_t p1 = (size_t)(2 * (bm + H) + 2 * C) * 80, p3 = (size_t)2 * bm * (C + 8) * 2 + (size_t)2 * C * 80;
+    const size_t lds = p1 > p3 ? p1 : p3;
+    const dim3 g(1, M / bm);
+    if (C == 96) {
+        static bool attr96 = false;
+        if (!attr96 && lds > 64 * 1024) { VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_res_unit<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr96 = true; }
+        hipLaunchKernelGGL((k_res_unit<4, 3>), g, dim3(256), lds, st, a1, a2, H);
+    } else {
+        static bool attr192 = false;
+        if (!attr192 && lds > 64 * 1024) { VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_res_unit<2, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr192 = true; }
+        hipLaunchKernelGGL((k_res_unit<2, 6>), g, dim3(256), lds, st, a1, a2, H);
+    }
+    *fused = 1;
+    return VOX_OK;
+}
+
 static void snake(hipStream_t st, const float* x, const vox_snake_w& s, float* y, size_t rows, int C) {
     const size_t total = rows * C;
     int grid = (int)((total + 255) / 256);
@@ -1327,12 +1469,23 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
             const vox_codec_res_w& rw = bw.res[u];
             const int d = u == 0 ? 1 : (u == 1 ? 3 : 9);
             const int offd[7] = {6 * d, 5 * d, 4 * d, 3 * d, 2 * d, d, 0};
+            const vox_snake_w* nx = u < 2 ? &bw.res[u + 1].act1 : (b < 3 ? &w.blocks[b + 1].snake0 : &w.final_snake);
+            if (s2) {
+                // the whole unit in one launch where the tile covers all channels (k_res_unit): the activated intermediate stays on chip;
+                // the next activation goes to t3 (neighbouring tiles still read their halo rows of t1), then the two swap
+                int fused = 0;
+                VOX_TRY(conv_unit(st, rw.conv1, rw.conv2, t1, m->st_ru[b][u], slots, n, L, 6 * d, offd, rw.act2, h, t3, nx, !(b == 3 && u == 2), &fused));
+                if (fused) {
+                    state_update(st, m->st_ru[b][u], slots, t1, n, L, 6 * d, cout);
+                    { float* x = t1; t1 = t3; t3 = x; }
+                    continue;
+                }
+            }
             // t3 = act2(conv1(t1))   (the plain conv1 output has no other consumer)
             VOX_TRY(conv_gemm(st, rw.conv1, t1, m->st_ru[b][u], slots, n, L, 6 * d, offd, nullptr, nullptr, nullptr, 0, t3, &rw.act2, cout,
                               nullptr, nullptr, nullptr, 0.0f, s2, s2));
             state_update(st, m->st_ru[b][u], slots, t1, n, L, 6 * d, cout);
             // h += conv2(t3); t1 = the next consumer's activation of the new h
-            const vox_snake_w* nx = u < 2 ? &bw.res[u + 1].act1 : (b < 3 ? &w.blocks[b + 1].snake0 : &w.final_snake);
             VOX_TRY(conv_gemm(st, rw.conv2, t3, nullptr, slots, n, L, 0, off0, h, h, nullptr, 0, t1, nx, cout,
                               nullptr, nullptr, nullptr, 0.0f, s2, s2 && !(b == 3 && u == 2)));      // (the final conv reads fp32 rows)
         }
