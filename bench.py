@@ -553,7 +553,7 @@ def serving_throughput(dev, shared, n_req, frames, kind="base"):
     return res
 
 
-def serving_pool(n_req, frames, dp_size=1):
+def serving_pool(n_req, frames, dp_size=1, fake=False):
     """The online data-parallel serving pool (vox_serve_amd/launch.py; the reference's `--dp-size N`: launch.py:183-279, 355-415,
     460-474): `dp_size` scheduler daemons — fresh interpreters pinned to their GPU through HIP_VISIBLE_DEVICES before torch is
     imported — behind the round-robin router, requests and audio over the AF_UNIX PUSH/PULL transports.  n_req requests per daemon
@@ -561,8 +561,12 @@ def serving_pool(n_req, frames, dp_size=1):
     from vox_serve_amd.launch import ServingPool
     mb = max(8, n_req)
     t0 = time.perf_counter()
-    pool = ServingPool("qwen3-tts", dp_size=dp_size, max_batch_size=mb, max_num_pages=4 * mb + 8, page_size=128, synthetic=True, greedy=True,
-                       max_tokens=PROMPT_TOKENS + frames, async_scheduling=True, log_level="WARNING", ready_timeout_s=900.0)
+    if fake:      # --dry-run: CPU daemons over the real worker host logic with a fake LM (tests/dp_fake_worker.py): the N-daemon code path, no GPU
+        pool = ServingPool("fake", dp_size=dp_size, max_batch_size=8, page_size=4, max_num_pages=64, worker_factory="tests.dp_fake_worker:make",
+                           log_level="WARNING", ready_timeout_s=300.0, pin_devices=False)
+    else:
+        pool = ServingPool("qwen3-tts", dp_size=dp_size, max_batch_size=mb, max_num_pages=4 * mb + 8, page_size=128, synthetic=True, greedy=True,
+                           max_tokens=PROMPT_TOKENS + frames, async_scheduling=True, log_level="WARNING", ready_timeout_s=900.0)
     startup = time.perf_counter() - t0
     rng = np.random.default_rng(5)
     try:
@@ -570,7 +574,7 @@ def serving_pool(n_req, frames, dp_size=1):
             rids = []
             for i in range(n_req * dp_size):
                 ids = [1, 2, 3] + rng.integers(0, 151000, 64).tolist() + [4, 5, 6, 7, 8]
-                rids.append(pool.start_streaming_request("", model_kwargs={"prompt_token_ids": ids, "language": "english"},
+                rids.append(pool.start_streaming_request("x" * (1 + i % 7) if fake else "", model_kwargs={} if fake else {"prompt_token_ids": ids, "language": "english"},
                                                          request_id=f"{tag}{i}", block=True))
             n = sum(len(c) // 2 for rid in rids for c in pool.stream(rid, timeout_s=600))
             infos = [pool.request_info(r) for r in rids]
@@ -727,6 +731,14 @@ def main():
         sub_res[b] = run_batch(b, args, dev, world, shared)
         _phase(f"batch {b}")
 
+    if use_dist:
+        # every collective of the run is behind us (weight broadcast, the barriers and max-reduce around each timed region): the group
+        # is torn down by all ranks together, here — what follows (serving-path sub-results, the N-daemon pool) runs on rank 0 alone
+        dist.barrier()
+        dist.destroy_process_group()
+        use_dist = False
+    if rank != 0:
+        return
     kv_sweep_res = None
     if rank == 0 and world == 1 and args.batch is None and not args.no_kv_sweep and not dry:
         kv_sweep_res = kv_sweep(dev, shared)
@@ -757,6 +769,15 @@ def main():
             except Exception as ex:          # a sub-result must never hide the headline
                 serving["pool"] = {"error": repr(ex)[:300]}
             _phase("serving pool")
+    if world > 1 and rank == 0 and "pool" in modes and args.batch is None:
+        # N > 1: the serving mode of the multi-GPU run goes through the online pool — one scheduler daemon per GPU behind the round-robin
+        # router (the replicas of the timed region above are done; their ranks only wait for this rank's line).  Never on the token path
+        # of the headline value; a failure here is reported, not raised.
+        try:
+            serving["pool"] = serving_pool(8, 100, dp_size=world, fake=dry)
+        except Exception as ex:
+            serving["pool"] = {"error": repr(ex)[:300]}
+        _phase(f"serving pool dp{world}")
 
     if rank == 0:
         out = {
@@ -804,8 +825,6 @@ def main():
             except Exception as ex:  # the baseline is a reported extra; never let it hide the GPU number
                 out["cpu_baseline"] = {"value": None, "error": repr(ex)[:200]}
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

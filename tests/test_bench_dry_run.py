@@ -35,6 +35,10 @@ def test_bench_two_ranks_gloo_dry_run_under_the_drivers_launcher():
     assert out["ms_per_step"] >= 1.0                                           # max over ranks of >= 1 ms stub steps
     for k in ("batch8", "batch32", "roofline"):
         assert k in out
+    # the serving mode of an N > 1 run goes through the online pool: two daemons, requests alternate between them
+    pool = out["serving_pool_dp"]
+    assert "error" not in pool, pool
+    assert pool["dp_size"] == 2 and pool["ranks_used"] == [0, 1] and pool["requests"] == 16 and pool["value"] > 0
     # whole-job aggregate: 2 ranks x 1 request x 1920 samples per step
     assert abs(out["value"] - 2 * 1920 / (out["ms_per_step"] * 1e-3)) / out["value"] < 1e-6
 
