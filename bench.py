@@ -566,7 +566,7 @@ def serving_pool(n_req, frames, dp_size=1, fake=False):
                            log_level="WARNING", ready_timeout_s=300.0, pin_devices=False)
     else:
         pool = ServingPool("qwen3-tts", dp_size=dp_size, max_batch_size=mb, max_num_pages=4 * mb + 8, page_size=128, synthetic=True, greedy=True,
-                           max_tokens=PROMPT_TOKENS + frames, async_scheduling=True, log_level="WARNING", ready_timeout_s=900.0)
+                           max_tokens=PROMPT_TOKENS + frames, async_scheduling=True, log_level="WARNING", ready_timeout_s=240.0)
     startup = time.perf_counter() - t0
     rng = np.random.default_rng(5)
     try:
@@ -576,7 +576,7 @@ def serving_pool(n_req, frames, dp_size=1, fake=False):
                 ids = [1, 2, 3] + rng.integers(0, 151000, 64).tolist() + [4, 5, 6, 7, 8]
                 rids.append(pool.start_streaming_request("x" * (1 + i % 7) if fake else "", model_kwargs={} if fake else {"prompt_token_ids": ids, "language": "english"},
                                                          request_id=f"{tag}{i}", block=True))
-            n = sum(len(c) // 2 for rid in rids for c in pool.stream(rid, timeout_s=600))
+            n = sum(len(c) // 2 for rid in rids for c in pool.stream(rid, timeout_s=120))
             infos = [pool.request_info(r) for r in rids]
             for r in rids:
                 pool.release(r)
