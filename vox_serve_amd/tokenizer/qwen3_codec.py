@@ -168,8 +168,11 @@ class Qwen3TTSDecoder:
         fixture, 1.5e-5 with three terms); "exact": three terms, every product exact; "bf16": activations rounded to bf16,
         the precision the reference itself serves at (it runs this decoder in bf16)."""
         self.cfg = c = config or Qwen3CodecConfig()
+        # "two_term" names the default for what it is (round-3 advisory: "fp32" used to mean three terms); "fp32" stays as its alias
+        if operand_precision == "two_term":
+            operand_precision = "fp32"
         if operand_precision not in ("fp32", "exact", "bf16"):
-            raise ValueError("operand_precision must be 'fp32', 'exact' or 'bf16'")
+            raise ValueError("operand_precision must be 'two_term' (= 'fp32', the default), 'exact' or 'bf16'")
         self.operand_precision = operand_precision
         self.device = torch.device(device)
         self.max_batch, self.max_slots, self.interval = max_batch, max_slots, detokenize_interval
