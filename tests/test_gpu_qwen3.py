@@ -514,3 +514,44 @@ def test_persistent_depth_step_is_bit_identical_to_the_launch_chain(dev, monkeyp
     assert torch.equal(ea.kv, eb.kv)
     assert eb.depth_persist_status() == (3, 0)
     ea.close(); eb.close()
+
+
+@pytest.mark.parametrize("B", [1, 6, 32])
+def test_decode_attention_for_257_to_512_tokens_is_bit_identical_to_partial_plus_merge(dev, monkeypatch, B):
+    """Contexts of 257..512 visible tokens: the one-launch decode attention with two chunks per group (k_attn_decode8<.., NCH = 16>, the
+    second tile in flight under the first chunk's arithmetic) against the chunked partial + merge launches it replaces — same chunk
+    arithmetic, same merge order: ids, logits, fed-back features and the K/V cache identical over free-running eager frames that cross
+    page and chunk boundaries (ragged lengths per row)."""
+    from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ps, ppr = 128, 5
+    outs = []
+    for on in ("0", "1"):      # 0: never, 1: from one row on
+        monkeypatch.setenv("VOX_ATTN_DECODE16", on)
+        e = Qwen3Engine(cfg, W, max_batch=B, page_size=ps, max_pages=B * ppr + 1, max_seq_len=640, max_prefill_rows=64)
+        e.keep_hidden = False
+        g = torch.Generator(device=dev).manual_seed(9)
+        e.kv[:] = (torch.randn(e.kv.shape, generator=g, device=dev) * 0.5).to(e.kv.dtype)
+        e.input_ids.zero_(); e.input_ids[:, -1] = cfg.tts_pad_id; e.input_ids[:, 0] = 23
+        e.input_masks[:B] = 1
+        e.input_features.zero_()
+        sc = e.sampling_cfg(greedy=True)
+        rec = []
+        for f in range(6):
+            kv = np.array([260 + 7 * b + f if b % 2 == 0 else 505 - 9 * b + f for b in range(B)])      # 257..512, both ends
+            kv = np.clip(kv, 257, 512)
+            npg = (kv + ps - 1) // ps
+            pages = [[b * ppr + j for j in range(npg[b])] for b in range(B)]
+            e.upload_plan(pos=kv, kvlen=kv, page=[p[-1] for p in pages], slot=(kv - 1) % ps, indptr=np.concatenate([[0], np.cumsum(npg)]),
+                          indices=sum(pages, []))
+            e.frame(B, int(kv.max()), sc, feedback=True, use_graph=False)
+            torch.cuda.synchronize()
+            rec.append((e.out_ids[:B].clone(), e.out_logits[:B].clone(), e.next_features[:B].clone()))
+        outs.append((rec, e.kv.clone()))
+        e.close()
+    for f, (a, b) in enumerate(zip(outs[0][0], outs[1][0])):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), f
+    assert torch.equal(outs[0][1], outs[1][1])

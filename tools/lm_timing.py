@@ -20,7 +20,7 @@ n = 75
 ps = 128
 for b in range(B):
     eng.kv[:, b * 3:(b + 1) * 3].normal_(0, 0.5)
-kvlen0 = 200
+kvlen0 = int(os.environ.get('LM_KV', '200'))
 sc = eng.sampling_cfg(greedy=True)
 eng.input_ids.zero_(); eng.input_ids[:, -1] = cfg.tts_pad_id
 def plan(kvlen):

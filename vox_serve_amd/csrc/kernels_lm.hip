@@ -1851,9 +1851,11 @@ int vox_launch_attn_partial(hipStream_t st, const AttnCall& c) {
 // over the whole zero-padded tile without predicates (p = 0 beyond the chunk's last token: l + 0 and fma(0, v, o) leave the
 // sums bit-unchanged), so that the LDS reads of consecutive tokens overlap.
 // (An earlier one-launch variant gave each chunk ONE wave and lost: a 32-token chunk is too long a serial chain for a wave.)
-template <int D, int GMAX, int NG>
+template <int D, int GMAX, int NG, int NCH = 8>
 __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
-    constexpr int LPT = D / 8, TPW = 64 / LPT, NCH = 8, GT = 1024 / NG, GW = GT / 64, CPG = NCH / NG;
+    // NCH = 16 (CPG = 2 chunks per group): contexts of up to 512 tokens — the second chunk's tile is requested when the first one has been
+    // parked, so its HBM latency runs under the first chunk's scores / softmax / P.V (one tile's registers at a time)
+    constexpr int LPT = D / 8, TPW = 64 / LPT, GT = 1024 / NG, GW = GT / 64, CPG = NCH / NG;
     constexpr int KVL = (VOX_TC * LPT + GT - 1) / GT;
     constexpr bool QREG = GMAX <= 2;      // q heads held unpacked in registers during the score passes
     __shared__ __attribute__((aligned(16))) uint4 Ks[NG][VOX_TC * LPT];
@@ -1891,7 +1893,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             }
     }
     const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
-    const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..8
+    const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..NCH
     const int Gf = a.Hq / a.Hkv, G = Gf / HS, g0 = hs * G;
     const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
     const int nqkv = (a.Hq + 2 * a.Hkv) * D;
@@ -1899,26 +1901,26 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
 
     // K/V tiles of this group's chunks.  The row's newest token (index L - 1) comes from the projection output: its V row is
     // loaded into the tile here, its K row (per-head norm + RoPE below) is read from Knew by the score pass.
-    uint4 kreg[CPG][KVL], vreg[CPG][KVL];
-#pragma unroll
-    for (int ci = 0; ci < CPG; ++ci) {
+    uint4 kreg[KVL], vreg[KVL];
+    auto fetch_tile = [&](int ci) {
         const int t0 = (grp + NG * ci) * VOX_TC;
 #pragma unroll
         for (int u = 0; u < KVL; ++u) {
             const int i = gt + GT * u, t = i / LPT, j = i % LPT;
-            kreg[ci][u] = make_uint4(0, 0, 0, 0);
-            vreg[ci][u] = kreg[ci][u];
+            kreg[u] = make_uint4(0, 0, 0, 0);
+            vreg[u] = kreg[u];
             const int tok = t0 + t;
             if (i < VOX_TC * LPT && tok < L - 1) {
                 const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[tok / a.page_size] : row);
                 const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
-                kreg[ci][u] = reinterpret_cast<const uint4*>(base)[j];
-                vreg[ci][u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
+                kreg[u] = reinterpret_cast<const uint4*>(base)[j];
+                vreg[u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
             } else if (i < VOX_TC * LPT && tok == L - 1) {
-                vreg[ci][u] = reinterpret_cast<const uint4*>(raw + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D)[j];
+                vreg[u] = reinterpret_cast<const uint4*>(raw + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D)[j];
             }
         }
-    }
+    };
+    fetch_tile(0);
     VOX_STAMP(1)
     {   // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave
         int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
@@ -1942,8 +1944,9 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
 #pragma unroll
         for (int u = 0; u < KVL; ++u) {
             const int i = gt + GT * u;
-            if (i < VOX_TC * LPT) { Ks[grp][i] = kreg[ci][u]; Vs[grp][i] = vreg[ci][u]; }
+            if (i < VOX_TC * LPT) { Ks[grp][i] = kreg[u]; Vs[grp][i] = vreg[u]; }
         }
+        if (ci + 1 < CPG) fetch_tile(ci + 1);  // in flight during this chunk's arithmetic
         __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
         VOX_STAMP(3)
         if (own_last && hs == 0 && gt < LPT) {
@@ -2012,7 +2015,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             for (int e = gt; e < G * (D / 2); e += GT) {
                 const int g = e / (D / 2), dp = e % (D / 2);
                 float o0 = 0.0f, o1 = 0.0f, l = 0.0f;
-#pragma unroll
+#pragma unroll(NCH == 8 ? VOX_TC : 8)                      // (beside an in-flight tile the full unroll's operand registers would spill)
                 for (int t = 0; t < VOX_TC; ++t) {
                     const float p = S[grp][g][t];          // 0 for t >= nt
                     const u32 vw = Vw[t * (D / 2) + dp];
@@ -2230,11 +2233,21 @@ __global__ __launch_bounds__(1024) void k_attn_decode8_v1(AttnArgs a) {
 
 #endif
 
+// rows from which contexts of 257..512 tokens take the one-launch form (below: partial + merge — at one row 8 blocks running two
+// rounds lose to 88 chunk blocks: 2.79 vs 2.59 ms per frame; at 32 rows 4.09 vs 4.27).  VOX_ATTN_DECODE16 = 0 never, n = from n rows
+// (read per call — launches are captured into graphs, this is not a hot path — so that a test can A/B it)
+static int decode16_min_rows() {
+    const char* e = getenv("VOX_ATTN_DECODE16");
+    if (!e) return 20;      // measured at kv 330: 4 / 8 / 12 rows slower (+4 .. +2 %), 16 equal, 24 -1.9 %, 32 -4.2 %
+    const int v = atoi(e);
+    return v <= 0 ? (1 << 30) : v;
+}
 // true when the one-launch decode attention covers the call (fused decode rows, <= 8 chunks, a supported head shape)
 bool vox_attn_decode8_supported(const AttnCall& c) {
     if (!c.qkv || !c.out || c.Nq < 1 || c.Hkv < 1 || c.Hq % c.Hkv) return false;
     const int nchunk = (c.max_kvlen + VOX_TC - 1) / VOX_TC, G = c.Hq / c.Hkv;
-    if (nchunk < 2 || nchunk > 8) return false;
+    if (nchunk < 2 || nchunk > 16) return false;
+    if (nchunk > 8) return c.Nq >= decode16_min_rows() && ((c.D == 128 && G == 2) || (c.D == 64 && G == 4));      // 257..512 tokens: two chunks per group
     return (c.D == 128 && (G == 2 || G == 16)) || (c.D == 64 && (G == 4 || G == 7));
 }
 int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
@@ -2252,6 +2265,12 @@ int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
     static const int hoist_on = [] { const char* e = getenv("VOX_ATTN_HOIST"); return !(e && e[0] == '0'); }();
     a.hoist = hoist_on;
     const int G = c.Hq / c.Hkv;
+    if ((c.max_kvlen + VOX_TC - 1) / VOX_TC > 8) {      // 257..512 visible tokens
+        const dim3 grid16(c.Hkv, c.Nq);
+        if (c.D == 128) hipLaunchKernelGGL((k_attn_decode8<128, 2, 8, 16>), grid16, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_attn_decode8<64, 4, 8, 16>), grid16, dim3(1024), 0, st, a);
+        return VOX_OK;
+    }
     // 16-head groups (GLM-4-Voice: 2 kv heads, so 2 blocks per row): eight blocks of two q heads per kv head, each with all 8 chunks in
     // flight — the per-(row, head) arithmetic does not depend on which heads share a block (VOX_ATTN_HEADSPLIT=0: one block per kv head)
     static const bool split_on = [] { const char* e = getenv("VOX_ATTN_HEADSPLIT"); return !(e && e[0] == '0'); }();
