@@ -125,3 +125,32 @@ def test_pool_reports_a_daemon_that_dies_during_startup(monkeypatch):
     with pytest.raises(RuntimeError):
         ServingPool("fake", dp_size=1, worker_factory="tests.no_such_module:make", extra_env={"VOX_TRANSPORT": "ipc"},
                     ready_timeout_s=60.0)
+
+
+@pytest.mark.timeout(180)
+def test_requests_of_a_daemon_that_dies_are_answered_with_an_error(monkeypatch):
+    """A daemon killed mid-flight: the requests routed to its rank get ONE error COMPLETION (their streams end), the other rank's
+    requests are served normally."""
+    from vox_serve_amd.launch import ServingPool
+    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    pool = ServingPool("fake", dp_size=2, max_batch_size=8, page_size=4, max_num_pages=64, worker_factory="tests.dp_fake_worker:make",
+                       extra_env={"VOX_TRANSPORT": "ipc", "PYTHONPATH": ROOT}, ready_timeout_s=120.0)
+    try:
+        pool.scheduler_processes[1].kill()
+        pool.scheduler_processes[1].wait(10)
+        rids = []
+        for i in range(4):
+            rids.append(pool.start_streaming_request("abc", request_id=f"k{i}", block=True))
+            t0 = time.time()
+            while pool.request_info(rids[-1])["rank"] is None and time.time() - t0 < 10:
+                time.sleep(0.002)
+        pcm = {r: b"".join(pool.stream(r, timeout_s=60)) for r in rids}
+        for i, r in enumerate(rids):
+            c = pool.completion(r)
+            if i % 2 == 1:
+                assert c["status"] == "error" and "rank 1" in c["reason"] and pcm[r] == b""
+            else:
+                assert c == {"status": "completed", "reason": "stop_id_encountered"} and len(pcm[r]) > 0
+    finally:
+        pool.cleanup()

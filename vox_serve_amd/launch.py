@@ -199,6 +199,7 @@ class ServingPool:
                     self.logger.error(f"result transport: {e}")
                 continue
             if message is None:
+                self._reap_dead_daemons()
                 continue
             parts = message.split(b"|", 2)
             if len(parts) < 3:
@@ -228,6 +229,24 @@ class ServingPool:
                 elif request_id not in self.recently_completed:
                     self.logger.warning(f"{message_type} for unknown request {request_id}")
 
+    def _reap_dead_daemons(self):
+        """A daemon that exited takes its requests with it (the reference's clients wait for their timeout): answer every request
+        routed to that rank with an error COMPLETION, once."""
+        if not self.ready or len(self.ready) < self.dp_size:
+            return                                          # start-up failures are _wait_ready's to report
+        dead = {r for r, p in enumerate(self.scheduler_processes) if p.poll() is not None}
+        if not dead:
+            return
+        with self.request_lock:
+            now = time.time()
+            for rid, entry in self.pending_requests.items():
+                if entry.get("rank") in dead and entry["completion"] is None:
+                    code = self.scheduler_processes[entry["rank"]].returncode
+                    entry["completion"] = {"status": "error", "reason": f"scheduler daemon of rank {entry['rank']} exited ({code})"}
+                    entry["done_time"] = now
+                    self.recently_completed[rid] = now
+                    entry["event"].set()
+
     # ---- requests: bounded queue -> sender thread -> rank = counter % dp_size ----
     def _enqueue_request(self, payload: bytes, block: bool = False):
         try:
@@ -255,6 +274,8 @@ class ServingPool:
                     self.request_sockets[rank].send(payload)
                     break
                 except TransportBusy:
+                    if rank < len(self.scheduler_processes) and self.scheduler_processes[rank].poll() is not None:
+                        break                              # its daemon is gone: _reap_dead_daemons answers the request; do not block the others
                     time.sleep(backoff)
                     backoff = min(backoff * 2, backoff_max)
                 except Exception as e:
