@@ -1267,13 +1267,16 @@ static int conv_unit(hipStream_t st, const vox_conv_w& w1, const vox_conv_w& w2,
     const size_t p1 = (size_t)(2 * (bm + H) + 2 * C) * 80, p3 = (size_t)2 * bm * (C + 8) * 2 + (size_t)2 * C * 80;
     const size_t lds = p1 > p3 ? p1 : p3;
     const dim3 g(1, M / bm);
+    // (the > 64 KB dynamic-LDS opt-in is a per-device function attribute: the detokenizer may live on a second GPU)
+    static bool attr_done[2][16] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    bool& done = attr_done[C == 96 ? 0 : 1][dev_id & 15];
     if (C == 96) {
-        static bool attr96 = false;
-        if (!attr96 && lds > 64 * 1024) { VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_res_unit<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr96 = true; }
+        if (!done && lds > 64 * 1024) { VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_res_unit<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
         hipLaunchKernelGGL((k_res_unit<4, 3>), g, dim3(256), lds, st, a1, a2, H);
     } else {
-        static bool attr192 = false;
-        if (!attr192 && lds > 64 * 1024) { VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_res_unit<2, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr192 = true; }
+        if (!done && lds > 64 * 1024) { VOX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_res_unit<2, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
         hipLaunchKernelGGL((k_res_unit<2, 6>), g, dim3(256), lds, st, a1, a2, H);
     }
     *fused = 1;
