@@ -42,7 +42,7 @@ if os.environ.get("LM_ASYNC") == "1":
     with eng._OnStream(eng):
         ev1.record()
     eng.stream.synchronize()
-    print(f"B={B} back-to-back: gpu {ev0.elapsed_time(ev1)/frames:.3f} ms/frame")
+    print(f"B={B} back-to-back: gpu {ev0.elapsed_time(ev1)/frames:.3f} ms/frame; persistent kernels (enabled bits, hand-off timeouts): {eng.depth_persist_status()}")
     sys.exit(0)
 import contextlib
 _one = torch.cuda.stream(eng.stream) if os.environ.get("LM_ONE_STREAM") == "1" else contextlib.nullcontext()
