@@ -79,6 +79,13 @@ class Loop:
         self.pcm_host = torch.zeros(B, INTERVAL * 1920, dtype=torch.int16).pin_memory()
         self.pending = None
         self.interval = INTERVAL            # frames per codec chunk (the TTFA-focused measurement lowers it to 2)
+        # pipeline = True (default): the reference's async-scheduling contract (scheduler/base.py:166-221) — frame N+1 is enqueued before the
+        # host has read frame N's tokens (a stream-ordered snapshot in pinned memory, read one step late), so the GPU never idles between
+        # frames; False: lock-step (the host reads every frame's tokens before it enqueues the next)
+        self.pipeline = True
+        self._ids_pin = [torch.zeros(B, self.cfg.n_groups + 1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._ids_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ids_prev = None
 
     def start_requests(self):
         """Prefill every request (one per step, like the scheduler) -> first frame."""
@@ -127,7 +134,17 @@ class Loop:
             ev1.record(e.stream)
             timed_events.append((ev0, ev1))
         self.tok_ring[:, self.nframe % self.interval] = e.out_ids[:B]
-        ids = e.out_ids[:B].cpu()                              # the scheduler needs the tokens (EOS / max_tokens checks)
+        if self.pipeline:
+            k = self.nframe & 1
+            self._ids_pin[k].copy_(e.out_ids[:B], non_blocking=True)          # stream-ordered right behind the frame
+            self._ids_ev[k].record()
+            ids = None
+            if self._ids_prev is not None:                     # the PREVIOUS frame's tokens: the scheduler sees them one step late
+                self._ids_ev[self._ids_prev].synchronize()
+                ids = self._ids_pin[self._ids_prev].clone()
+            self._ids_prev = k
+        else:
+            ids = e.out_ids[:B].cpu()                          # the scheduler needs the tokens (EOS / max_tokens checks)
         self.pos = [p + 1 for p in self.pos]
         self.nframe += 1
         pcm = None
@@ -283,7 +300,7 @@ class StubLoop:
         return None
 
 
-def run_batch(B, args, dev, world, shared, ttfa_requests=0):
+def run_batch(B, args, dev, world, shared, ttfa_requests=0, lockstep=False):
     """The timed region for one batch size: W warm-up steps, a barrier, exactly K steps, barrier, max over ranks."""
     import torch.distributed as dist
     use_dist = world > 1 or args.force_dist
@@ -292,6 +309,7 @@ def run_batch(B, args, dev, world, shared, ttfa_requests=0):
     # requests are measured mid-stream: the KV length over the timed steps averages --kv-mean (200)
     pre = max(0, int(args.kv_mean - PROMPT_TOKENS - args.warmup - args.steps / 2))
     loop = (StubLoop if dry else Loop)(B, pre + args.steps + args.warmup + 64, dev, shared["W"], shared["codec_W"])
+    loop.pipeline = not lockstep
     ttfa, ttfa2 = [], []
     if ttfa_requests > 0 and B == 1:
         # engine-level TTFA (request start -> first PCM chunk on the host), lock-step loop, outside the timed steps
@@ -336,7 +354,7 @@ def run_batch(B, args, dev, world, shared, ttfa_requests=0):
     samples_total = world * B * 1920 * args.steps
     traffic, src = pmc_traffic(B)
     res = {
-        "value": samples_total / dt, "ms_per_step": dt / args.steps * 1e3, "batch_per_gpu": B,
+        "value": samples_total / dt, "ms_per_step": dt / args.steps * 1e3, "batch_per_gpu": B, "loop": "lock-step" if lockstep else "pipelined one frame deep",
         "realtime_factor_per_request": samples_total / dt / 24000.0 / (world * B), "kv_mean": kv_mean,
         "roofline": {"bound": "hbm", "achieved": alg / frame_gpu_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg / frame_gpu_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
@@ -655,6 +673,9 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs 1, 3, 4 sub-results (CosyVoice2, CSM-1B, GLM-4-Voice)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: gloo on CPU, a stub loop instead of the engine — executes the rank launch, "
                     "weight broadcast, barrier / max-over-ranks timing and JSON path of `--gpus N` (tests/test_host_logic.py); prints no measurement")
+    ap.add_argument("--pipelined", action="store_true", help="frames pipelined one deep in the headline loop (the reference's async-scheduling contract: "
+                    "frame N+1 is enqueued before the host reads frame N's tokens); default: lock-step as in rounds 1-3, with the pipelined number of the "
+                    "same run as the `pipelined` sub-result")
     ap.add_argument("--no-kv-sweep", action="store_true", help="skip the kv_sweep sub-result (LM frame at kv 100 / 200 / 325 / 1000 / 2000)")
     ap.add_argument("--serving-frames", type=int, default=250, help="frames per request of the serving-path jobs (SURVEY 8d: 250)")
     ap.add_argument("--exact-rows", type=int, default=None, help="rows up to which linears use the wave64 VALU kernels instead of the "
@@ -724,11 +745,15 @@ def main():
     if args.sub_batches is not None:
         subs = [int(x) for x in args.sub_batches.split(",") if x.strip()]
     _phase("weights")
-    head = run_batch(head_B, args, dev, world, shared, ttfa_requests=args.ttfa_requests if rank == 0 else 0)
+    head = run_batch(head_B, args, dev, world, shared, ttfa_requests=args.ttfa_requests if rank == 0 else 0, lockstep=not args.pipelined)
     _phase(f"batch {head_B}")
+    head_pipe = None
+    if not args.pipelined and world == 1 and not dry:
+        head_pipe = run_batch(head_B, args, dev, world, shared, lockstep=False)      # the same loop with frames pipelined one deep
+        _phase(f"batch {head_B} pipelined")
     sub_res = {}
     for b in subs:
-        sub_res[b] = run_batch(b, args, dev, world, shared)
+        sub_res[b] = run_batch(b, args, dev, world, shared, lockstep=not args.pipelined)
         _phase(f"batch {b}")
 
     if use_dist:
@@ -806,8 +831,12 @@ def main():
         for k in ("ttfa_ms_p50_engine", "ttfa_ms_p50_engine_detokenize_interval_2", "depth_persist"):
             if k in head:
                 out[k] = head[k]
+        out["loop"] = head["loop"]
+        if head_pipe is not None:      # frame N+1 enqueued before the host reads frame N's tokens (stream-ordered pinned snapshot, read one step
+            out["pipelined"] = {k: head_pipe[k] for k in ("value", "ms_per_step", "loop")}      # late: scheduler/base.py:166-221); same work per step
+            out["pipelined"]["roofline_frac"] = head_pipe["roofline"]["frac"]
         for b, r in sub_res.items():
-            out[f"batch{b}"] = {k: r[k] for k in ("value", "ms_per_step", "batch_per_gpu", "realtime_factor_per_request", "kv_mean", "roofline")}
+            out[f"batch{b}"] = {k: r[k] for k in ("value", "ms_per_step", "batch_per_gpu", "realtime_factor_per_request", "kv_mean", "roofline", "loop")}
         if kv_sweep_res is not None:
             out["kv_sweep"] = kv_sweep_res
         if bcast:
