@@ -31,6 +31,34 @@ def plan(kvlen):
 for w in range(5):
     plan(kvlen0 + w); eng.frame(B, kvlen0 + w, sc, use_graph=use_graph)
 torch.cuda.synchronize()
+if os.environ.get("LM_MODE"):
+    # where do the 0.09 ms between back-to-back replays (2.56) and the bench's frames (2.65) go?  a: fixed plan, no host sync;
+    # b: + plan upload (H2D in stream order) per frame; c: b + stream-ordered D2H snapshot of the ids; d: c + host wait per frame (pipelined
+    # one deep); e: lock-step (upload, frame, blocking .cpu()).  Frame time = HIP events around every replay.
+    mode = os.environ["LM_MODE"]
+    pin = [torch.zeros_like(eng.out_ids[:B], device="cpu").pin_memory() for _ in range(2)]
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+    times = []
+    plan(kvlen0 + 5)
+    pairs = []
+    for f in range(frames):
+        if mode in "bcde":
+            plan(kvlen0 + 5 + (f % 40))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(eng.stream)
+        eng.frame(B, kvlen0 + 5 + (f % 40 if mode in "bcde" else 0), sc, use_graph=True)
+        e1.record(eng.stream)
+        pairs.append((e0, e1))
+        if mode in "cd":
+            pin[f & 1].copy_(eng.out_ids[:B], non_blocking=True); evs[f & 1].record(eng.stream)
+            if mode == "d" and f > 0:
+                evs[(f - 1) & 1].synchronize()
+        if mode == "e":
+            eng.out_ids[:B].cpu()
+    torch.cuda.synchronize()
+    ms = np.array([a.elapsed_time(b) for a, b in pairs[20:]])
+    print(f"B={B} LM_MODE={mode}: frame graph mean {ms.mean():.4f} ms, median {np.median(ms):.4f}")
+    sys.exit(0)
 if os.environ.get("LM_ASYNC") == "1":
     # frames enqueued back to back, no host synchronisation in between (GPU never idles): plans of a fixed kv length
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
