@@ -38,7 +38,9 @@ def rnd(rng, *shape, s=1.0):
 @pytest.mark.parametrize("B,N_,K", [(1, 64, 256), (1, 2048, 2048), (2, 1030, 1024), (3, 512, 6144), (4, 4096, 2048),
                                     (5, 96, 512), (8, 3072, 1024), (9, 128, 2048), (19, 256, 768), (1, 7, 64),
                                     (16, 2048, 2048), (32, 4096, 2048), (32, 2048, 6144), (75, 1000, 1024), (33, 64, 96),
-                                    (8, 256, 13696), (7, 64, 13696), (6, 100, 13696), (1, 128, 13696), (2, 256, 13696), (3, 4096, 13696), (12, 2051, 1024), (16, 1000, 2048), (31, 2051, 1024)])
+                                    (8, 256, 13696), (7, 64, 13696), (6, 100, 13696), (1, 128, 13696), (2, 256, 13696), (3, 4096, 13696), (12, 2051, 1024), (16, 1000, 2048), (31, 2051, 1024),
+                                    # <= 16 rows off the full-K shapes: k_linear_mfma_small / _stream (CosyVoice2's 896 / 4864, a ragged K, 1..3 groups)
+                                    (8, 896, 4864), (8, 1152, 896), (16, 896, 896), (9, 6564, 896), (3, 40, 1056), (5, 48, 2080), (4, 64, 3104), (11, 32, 4128), (16, 64, 6176), (7, 128, 96)])
 def test_linear_bit_exact(dev, B, N_, K):
     from vox_serve_amd import _native as N
     rng = np.random.default_rng(B * 1000 + N_ + K)
@@ -57,7 +59,7 @@ def test_linear_bit_exact(dev, B, N_, K):
 
 
 @pytest.mark.parametrize("B,N_,K", [(1, 6144, 2048), (2, 768, 256), (4, 3072, 1024), (8, 520, 512), (11, 64, 128),
-                                    (32, 6144, 2048), (75, 3072, 1024)])
+                                    (32, 6144, 2048), (75, 3072, 1024), (8, 4864, 896), (16, 100, 992)])
 def test_linear_silu_mul_bit_exact(dev, B, N_, K):
     from vox_serve_amd import _native as N
     rng = np.random.default_rng(N_ + K + B)

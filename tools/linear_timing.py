@@ -6,6 +6,8 @@ from vox_serve_amd import _native as N
 dev = torch.device("cuda")
 N.ctx()
 shapes = [(32, 1024, 2048), (32, 1024, 3072), (32, 4096, 1024), (32, 4096, 2048), (32, 2048, 6144), (16, 1024, 2048), (1, 1024, 2048), (8, 1024, 2048), (75, 4096, 2048)]
+if os.environ.get("LT_SHAPES"):          # e.g. LT_SHAPES=8x896x4864,8x4096x13696
+    shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["LT_SHAPES"].split(",")]
 st = torch.cuda.Stream()
 for B, Nn, K in shapes:
     nbuf = max(2, int(600e6 // (Nn * K * 2)))

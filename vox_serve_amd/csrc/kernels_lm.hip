@@ -815,6 +815,212 @@ static int launch_linear_mfma_t(hipStream_t st, const LinArgs& a) {
     return VOX_OK;
 }
 
+// ================================================================================================
+// k_linear_mfma without the LDS tile, for calls of at most 16 rows (one 16-row MFMA tile per block).  With a single row tile the four
+// waves of a block multiply DISJOINT k-steps (wave w owns k = 32 w + 128 t .. + 31, t = 0, 1, ...: MF_KS = 8 x 128, so the 1024-wide
+// segments of the staged kernel collapse into this one sequence), i.e. no activation element is shared between the waves and the LDS
+// tile only adds two barriers and a write + read per segment.  Here a lane reads its A fragment (row lane & 15 of x, 16 bytes,
+// L2-resident) the way it reads its B fragment, normalises it in registers when the call has a norm prologue, and the waves never
+// meet before the sum of the four partial accumulators.  Each wave chains the same k-steps in the same order and the partials are
+// added in wave order: bit-identical to k_linear_mfma (oracle: VR_ORD_MFMA4), which keeps the calls this form does not cover
+// (17+ rows, x_out, a norm prologue with K > 1024).
+//   k_linear_mfma_small   K <= 1024: every operand of the call is requested before anything waits (CosyVoice2's 896-wide linears)
+//   k_linear_mfma_stream  K  > 1024, copy prologue: two register buffers of H k-steps per wave; a buffer is refilled as soon as it has
+//                         been multiplied, the loop body has no conditional load (the in-order vmcnt accounting stays exact), steps
+//                         past the end re-request the last real step (cache hits) and are not multiplied.  CosyVoice2's 4864-wide down
+//                         projection has 56 column tiles: all of a block's 155 KB are in flight after two groups; GLM-4-Voice's
+//                         13 696-wide one keeps 128 KB per CU in flight with no barrier in the walk.
+// ================================================================================================
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void k_linear_mfma_small(LinArgs a) {
+    constexpr bool SM = (EPI == EPI_SILU_MUL);
+    __shared__ float rinv_s[16];
+    __shared__ f32x4_t red[3][SM ? 2 : 1][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16, fr = lane & 15, fk = (lane >> 4) * 8;
+    int nrow = n0 + fr;
+    nrow = nrow < a.N ? nrow : a.N - 1;
+    const int bt = a.B;                                     // <= 16
+    const int T = a.K > 32 * wave ? (a.K - 32 * wave + 127) >> 7 : 0;      // this wave's k-steps (<= 8)
+    // row statistics first (needed first, and loads retire in order): rows wave, wave + 4, ... — the lane's chunks in increasing c,
+    // then the butterfly, as in k_linear_mfma
+    uint4 sv[4][2];
+    if (PRO == PRO_RMSNORM) {
+        const int nch = a.K >> 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = wave + 4 * r;
+            const uint4* xr = x_row_ptr(a, b < bt ? b : bt - 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                sv[r][j] = make_uint4(0, 0, 0, 0);
+                if (lane + 64 * j < nch) sv[r][j] = xr[lane + 64 * j];
+            }
+        }
+    }
+    const uint4* xrow = x_row_ptr(a, fr < bt ? fr : bt - 1) + ((32 * wave + fk) >> 3);
+    const uint4* gvp = reinterpret_cast<const uint4*>(a.nw) + ((32 * wave + fk) >> 3);
+    const uint4* w0 = reinterpret_cast<const uint4*>(a.W + (size_t)nrow * a.K + 32 * wave + fk);
+    const uint4* w1 = SM ? reinterpret_cast<const uint4*>(a.W2 + (size_t)nrow * a.K + 32 * wave + fk) : nullptr;
+    uint4 xa[8], gv[8], wv[8], wv2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < T) {
+            xa[t] = xrow[16 * t];
+            if (PRO == PRO_RMSNORM) gv[t] = gvp[16 * t];
+        }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < T) {
+            wv[t] = ldg_nt(w0 + 16 * t);
+            if (SM) wv2[t] = ldg_nt(w1 + 16 * t);
+        }
+    float ri = 0.0f;
+    if (PRO == PRO_RMSNORM) {
+        const int nch = a.K >> 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = wave + 4 * r;
+            float ss = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (lane + 64 * j < nch) ss = sq8(sv[r][j], ss);
+            ss = butterfly<64>(ss);
+            if (lane == 0 && b < bt) rinv_s[b] = 1.0f / sqrtf(ss / (float)a.K + a.eps);
+        }
+        __syncthreads();
+        ri = rinv_s[fr < bt ? fr : bt - 1];
+    }
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f}, acc2 = acc;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < T) {
+            uint4 ax = xa[t];
+            if (PRO == PRO_RMSNORM) ax = norm_chunk(ax, gv[t], ri);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(ax), as_bf8(wv[t]), acc, 0, 0, 0);
+            if (SM) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(ax), as_bf8(wv2[t]), acc2, 0, 0, 0);
+        }
+    // residual of the outputs wave 0 finishes, requested before the waves meet
+    float res_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n = n0 + fr;
+    if (!SM && a.residual && wave == 0 && n < a.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = (lane >> 4) * 4 + r;
+            if (b < bt) res_pre[r] = bf2f(a.residual[(size_t)b * a.N + n]);
+        }
+    }
+    if (wave > 0) {
+        red[wave - 1][0][lane] = acc;
+        if (SM) red[wave - 1][SM ? 1 : 0][lane] = acc2;
+    }
+    __syncthreads();
+    if (wave != 0 || n >= a.N) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+        acc += red[w][0][lane];
+        if (SM) acc2 += red[w][SM ? 1 : 0][lane];
+    }
+    const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = (lane >> 4) * 4 + r;       // D: column n = lane & 15, rows (lane >> 4) * 4 + r
+        if (b >= bt) continue;
+        const size_t oi = (size_t)b * a.N + n;
+        bf16_t o;
+        if (SM) {
+            const float g = bfround(acc[r]), u = bfround(acc2[r]);
+            o = f2bf(bfround(silu_c(g)) * u);
+        } else {
+            float v = acc[r];
+            if (a.bias) v = v + bv;
+            o = f2bf(v);
+            if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
+            if (a.residual) o = f2bf(res_pre[r] + bf2f(o));
+        }
+        a.y[oi] = o;
+    }
+}
+
+template <int EPI, int H>
+__global__ __launch_bounds__(256) void k_linear_mfma_stream(LinArgs a) {
+    static_assert(EPI == EPI_STORE || EPI == EPI_SILU, "copy prologue, plain epilogues");
+    __shared__ f32x4_t red[3][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16, fr = lane & 15, fk = (lane >> 4) * 8;
+    int nrow = n0 + fr;
+    nrow = nrow < a.N ? nrow : a.N - 1;
+    const int bt = a.B;                                     // <= 16
+    const int T = (a.K - 32 * wave + 127) >> 7;             // this wave's k-steps (K > 1024: at least 8)
+    const int G = (T + H - 1) / H;
+    const uint4* xrow = x_row_ptr(a, fr < bt ? fr : bt - 1) + ((32 * wave + fk) >> 3);     // step t: 16 chunks further
+    const uint4* wrow = reinterpret_cast<const uint4*>(a.W + (size_t)nrow * a.K + 32 * wave + fk);
+    uint4 xb[2][H], wb[2][H];
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    auto issue = [&](auto BUF, int g) {
+        constexpr int b = decltype(BUF)::value;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            int t = g * H + i;
+            t = t < T ? t : T - 1;                  // past the end: the last real step again (a cache hit; never multiplied)
+            xb[b][i] = xrow[16 * t];
+            wb[b][i] = ldg_nt(wrow + 16 * t);
+        }
+    };
+    auto consume = [&](auto BUF, auto GUARD, int g) {      // GUARD: the group may reach past the wave's last step
+        constexpr int b = decltype(BUF)::value;
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+            if (!decltype(GUARD)::value || g * H + i < T)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf8(xb[b][i]), as_bf8(wb[b][i]), acc, 0, 0, 0);
+    };
+    issue(vox_ic<0>{}, 0);
+    issue(vox_ic<1>{}, G > 1 ? 1 : 0);
+    int g = 0;
+    for (; g + 4 <= G; g += 2) {                    // steady state: every group multiplied here is complete, every one requested exists
+        consume(vox_ic<0>{}, vox_ic<0>{}, g);
+        issue(vox_ic<0>{}, g + 2);
+        consume(vox_ic<1>{}, vox_ic<0>{}, g + 1);
+        issue(vox_ic<1>{}, g + 3);
+    }
+    consume(vox_ic<0>{}, vox_ic<1>{}, g);           // one to three groups left; buffer 1 holds g + 1 (if it exists)
+    issue(vox_ic<0>{}, g + 2 < G ? g + 2 : G - 1);
+    consume(vox_ic<1>{}, vox_ic<1>{}, g + 1);
+    consume(vox_ic<0>{}, vox_ic<1>{}, g + 2);
+    float res_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n = n0 + fr;
+    if (a.residual && wave == 0 && n < a.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = (lane >> 4) * 4 + r;
+            if (b < bt) res_pre[r] = bf2f(a.residual[(size_t)b * a.N + n]);
+        }
+    }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave != 0 || n >= a.N) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) acc += red[w][lane];
+    const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = (lane >> 4) * 4 + r;
+        if (b >= bt) continue;
+        const size_t oi = (size_t)b * a.N + n;
+        float v = acc[r];
+        if (a.bias) v = v + bv;
+        bf16_t o = f2bf(v);
+        if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
+        if (a.residual) o = f2bf(res_pre[r] + bf2f(o));
+        a.y[oi] = o;
+    }
+}
+// VOX_MFMA_DIRECT=0: the staged kernel for every call (A/B timing; bit-identical)
+static bool mfma_direct() {
+    static const bool on = [] { const char* e = getenv("VOX_MFMA_DIRECT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 // K segment per LDS stage: 2048 from K = 4096 on (one 16-row tile: twice the weight bytes in flight per block and half the barriers of
 // the 1024-wide walk; which k-steps a wave multiplies, and in which order, does not depend on the segment width, so the results are
 // bit-identical).  VOX_MFMA_KSEG=1024 keeps the narrow walk (A/B timing).
@@ -827,6 +1033,17 @@ static int launch_linear_mfma_pe(hipStream_t st, const LinArgs& a_in) {
     static const bool oneseg_off = [] { const char* e = getenv("VOX_MFMA_ONESEG"); return e && e[0] == '0'; }();
     LinArgs a = a_in;
     a.no_one_seg = oneseg_off ? 1 : 0;
+    if (a.B <= 16 && !a.x_out && mfma_direct()) {      // one row tile: no LDS tile (same k-step chains, same wave-order sum)
+        const dim3 grid((a.N + 15) / 16);
+        if (a.K <= 1024) {
+            hipLaunchKernelGGL((k_linear_mfma_small<PRO, EPI>), grid, dim3(256), 0, st, a);
+            return VOX_OK;
+        }
+        if constexpr (PRO == PRO_COPY && (EPI == EPI_STORE || EPI == EPI_SILU)) {
+            hipLaunchKernelGGL((k_linear_mfma_stream<EPI, 16>), grid, dim3(256), 0, st, a);
+            return VOX_OK;
+        }
+    }
     // long K, plain store (GLM's down projection): three 1024-wide weight segments in flight — measured SLOWER than the 2048-wide walk
     // with one segment in flight (GLM-4-Voice B=8 LM step 5.60 -> 5.71 ms: the per-segment barriers and LDS writes, not the exposed
     // latency, are what the staged kernel pays); kept behind VOX_MFMA_DEPTH=3 as an A/B form, bit-identical
