@@ -417,7 +417,7 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
         // the 1..8 rows GEMV and the 33+ rows split-K GEMM keep reading the caller's row-major tensors)
         auto mk = [&](const void* src, int rows, int K, void** dst) -> bool {
             *dst = nullptr;
-            if (!src || !vox_fullk_weight_ok(rows, K)) return true;
+            if (!src || !(vox_fullk_weight_ok(rows, K) || vox_stream_weight_ok(rows, K))) return true;
             if (hipMalloc(dst, (size_t)rows * K * 2) != hipSuccess) return false;
             return vox_launch_swizzle_frag(nullptr, src, *dst, rows, K) == VOX_OK;
         };

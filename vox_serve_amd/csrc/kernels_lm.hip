@@ -954,7 +954,13 @@ __global__ __launch_bounds__(256) void k_linear_mfma_stream(LinArgs a) {
     const int T = (a.K - 32 * wave + 127) >> 7;             // this wave's k-steps (K > 1024: at least 8)
     const int G = (T + H - 1) / H;
     const uint4* xrow = x_row_ptr(a, fr < bt ? fr : bt - 1) + ((32 * wave + fk) >> 3);     // step t: 16 chunks further
-    const uint4* wrow = reinterpret_cast<const uint4*>(a.W + (size_t)nrow * a.K + 32 * wave + fk);
+    // row-major: lane (fr, g) reads 16 B of weight row n0 + fr per step (16 rows x 64 B per wave request), step t 16 chunks further;
+    // fragment-major (the decoder stack's copy, N % 16 == 0): the same register contents from ONE contiguous 1 KiB request — k-step
+    // wave + 4 t of column tile blockIdx.x, four fragments further per step
+    const bool wf = a.W_frag != nullptr;
+    const int wstep = wf ? 256 : 16;
+    const uint4* wrow = wf ? reinterpret_cast<const uint4*>(a.W_frag) + ((size_t)blockIdx.x * (a.K >> 5) + wave) * 64 + lane
+                           : reinterpret_cast<const uint4*>(a.W + (size_t)nrow * a.K + 32 * wave + fk);
     uint4 xb[2][H], wb[2][H];
     f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     auto issue = [&](auto BUF, int g) {
@@ -964,7 +970,7 @@ __global__ __launch_bounds__(256) void k_linear_mfma_stream(LinArgs a) {
             int t = g * H + i;
             t = t < T ? t : T - 1;                  // past the end: the last real step again (a cache hit; never multiplied)
             xb[b][i] = xrow[16 * t];
-            wb[b][i] = ldg_nt(wrow + 16 * t);
+            wb[b][i] = ldg_nt(wrow + (size_t)wstep * t);
         }
     };
     auto consume = [&](auto BUF, auto GUARD, int g) {      // GUARD: the group may reach past the wave's last step
@@ -1515,6 +1521,8 @@ bool vox_fullk_weight_ok(int N, int K) {
     const int ks = K / 256;
     return N % 16 == 0 && K % 256 == 0 && (ks == 4 || ks == 8 || ks == 12 || ks == 16 || ks == 24 || ks == 32);
 }
+// ... and for k_linear_mfma_stream (<= 16 rows, copy prologue, K > 1024 off the full-K shapes: GLM-4-Voice's / CosyVoice2's down projection)
+bool vox_stream_weight_ok(int N, int K) { return !vox_fullk_weight_ok(N, K) && N % 16 == 0 && K % 32 == 0 && K > 1024; }
 
 static int rows_gemm_min() {
 #ifdef VOX_DEV_KNOBS
@@ -1601,6 +1609,8 @@ int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& call) {
         if (epi == EPI_SILU_MUL) return launch_gemm_splitk<EPI_SILU_MUL>(st, a, (float*)c.splitk_ws, c.splitk_ws_bytes);
     }
     if (c.B > c.exact_rows && !c.fixed_order && c.pro != PRO_ATTN && c.K % 32 == 0) {   // above exact_rows: MFMA path (weights streamed once per 32-row tile)
+        static const bool stream_frag = [] { const char* e = getenv("VOX_STREAM_FRAG"); return !(e && e[0] == '0'); }();     // (=0: row-major weights, A/B timing)
+        if (stream_frag && c.W_frag && c.B <= 16 && c.pro == PRO_COPY && c.epi != EPI_SILU_MUL && vox_stream_weight_ok(c.N, c.K)) a.W_frag = (const bf16_t*)c.W_frag;
 #define VOX_PM(P, E) if (c.pro == P && c.epi == E) return launch_linear_mfma_pe<P, E>(st, a);
         VOX_PM(PRO_COPY, EPI_STORE) VOX_PM(PRO_COPY, EPI_SILU) VOX_PM(PRO_COPY, EPI_SILU_MUL)
         VOX_PM(PRO_RMSNORM, EPI_STORE) VOX_PM(PRO_RMSNORM, EPI_SILU_MUL)

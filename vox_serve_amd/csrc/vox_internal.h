@@ -73,7 +73,8 @@ enum { VOX_PRO_COPY = 0, VOX_PRO_RMSNORM = 1, VOX_PRO_ATTN = 2 };
 enum { VOX_EPI_STORE = 0, VOX_EPI_SILU = 1, VOX_EPI_SILU_MUL = 2 };
 bool vox_linear_is_rows_gemm(const LinearCall& c);
 bool vox_linear_is_fullk(const LinearCall& c);      // true: the call takes the 9..32 rows path that honours *_frag
-bool vox_fullk_weight_ok(int N, int K);             // a weight of this shape can be used fragment-major
+bool vox_fullk_weight_ok(int N, int K);
+bool vox_stream_weight_ok(int N, int K);             // a weight of this shape can be used fragment-major
 int vox_launch_swizzle_frag(hipStream_t st, const void* src, void* dst, int rows, int K);   // rows % 16 == 0, K % 32 == 0
 int vox_launch_linear(vox_ctx* ctx, hipStream_t st, const LinearCall& c);
 int vox_launch_rmsnorm(hipStream_t st, const void* x, const void* w, void* y, int rows, int H, float eps);
