@@ -41,3 +41,11 @@ for k in range(6):
 print(f"  {'head':34s} {d[:, 30].mean():6.2f} us")
 g = np.diff(s[:, 0]); g = g[(g > 0) & (g < 400)]
 print(f"  entry-to-entry of consecutive steps: median {np.median(g):.2f} us")
+# per visible-token count: the frame's 14 persistent launches are steps i = 2 .. 15, NT = i + 1 visible tokens
+if n >= 14 and os.environ.get("DS_PER_NT", "1") != "0":
+    k = np.arange(len(s)) % 14
+    print("  NT : entry->end |  A     B-gather  B-attn  B-pub   C      D      (means over the five layers, us)")
+    for j in range(14):
+        m = k == j
+        row = [d[m][:, [c + 6 * l for l in range(5)]].mean() for c in range(6)]
+        print(f"  {j + 3:2d} : {tot[m].mean():9.2f} | " + "  ".join(f"{v:5.2f}" for v in row))

@@ -2877,6 +2877,9 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 qb[NQKV / 8];        // q | k | v of the step's token
     __shared__ __attribute__((aligned(16))) uint4 hb[F / 8];           // the FFN's activated row
     __shared__ __attribute__((aligned(16))) uint4 xs[NQ / 8];          // the attention output row
+    // o_proj's weight rows of waves 0, 1, requested with stage A's and parked here when stage A is done: held in registers across the
+    // attention (32 of them, next to its cached K / V rows) the step spilled from 7 visible tokens on — 124 bytes of scratch per lane at 16
+    __shared__ __attribute__((aligned(16))) uint4 wos[2][2][4][64];
     // (wave index made provably uniform: the weight rows' base addresses then live in scalar registers — left as a per-lane value
     // the compiler hoists some forty 64-bit row pointers out of the layer loop into vector registers and spills them)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
@@ -2901,6 +2904,12 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) nwv[j] = reinterpret_cast<const uint4*>(w.ln1)[lane + 64 * j];
+            // (every wave requests — waves 2..7 the rows of wave 0 / 1 again, cache hits — and the chunks are named values, not an array: as
+            // an array filled under `wave < 2` they were kept in scratch memory, stored behind a vmcnt(0) each)
+            const uint4* wor0 = reinterpret_cast<const uint4*>(w.wo + (size_t)(2 * (blk * 2 + (wave & 1))) * NQ) + lane;
+            const uint4* wor1 = wor0 + NQ / 8;
+            const uint4 wo00 = wor0[0], wo01 = wor0[64], wo02 = wor0[128], wo03 = wor0[192];
+            const uint4 wo10 = wor1[0], wo11 = wor1[64], wo12 = wor1[128], wo13 = wor1[192];
             if (l > 0) gran_gather_lds<512>(a.gx, tagof(l - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x100u + l);
             __syncthreads();                               // x of this layer is in xb
             uint4 xv[2];
@@ -2922,20 +2931,17 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
                 acc[r] = butterfly<64>(d);
             }
             if (lane == 0) gran_write(a.gqkv + pr, tagof(l, 0), f2bf(acc[0]), f2bf(acc[1]));
+            __builtin_amdgcn_sched_barrier(0);      // (stage B's requests stay below: hoisted above the parking they made the allocator spill these rows)
+            if (wave < 2) {
+                wos[wave][0][0][lane] = wo00; wos[wave][0][1][lane] = wo01; wos[wave][0][2][lane] = wo02; wos[wave][0][3][lane] = wo03;
+                wos[wave][1][0][lane] = wo10; wos[wave][1][1][lane] = wo11; wos[wave][1][2][lane] = wo12; wos[wave][1][3][lane] = wo13;
+            }
+            __builtin_amdgcn_sched_barrier(0);
             VOX_STAMP2(1 + 6 * l)
         }
         // ---------------- stage B: x += Wo . attention  (512 pairs: waves 0, 1; the attention by all 8 waves = 8 kv heads) ----------------
         {
-            const int pr = blk * 2 + wave, n0 = 2 * pr;
-            uint4 wo[2][4];
-            if (wave < 2) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint4* wr = reinterpret_cast<const uint4*>(w.wo + (size_t)(n0 + r) * NQ);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wo[r][j] = wr[lane + 64 * j];
-                }
-            }
+            const int pr = blk * 2 + wave;
             AttnArgs at = a.at;
             at.kv = a.at.kv + (size_t)l * a.kv_layer_stride;
             at.kv_w = a.at.kv_w + (size_t)l * a.kv_layer_stride;
@@ -2963,7 +2969,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
                 for (int r = 0; r < 2; ++r) {
                     float d = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) d = dot8(wo[r][j], xs[lane + 64 * j], d);
+                    for (int j = 0; j < 4; ++j) d = dot8(wos[wave][r][j][lane], xs[lane + 64 * j], d);
                     acc[r] = butterfly<64>(d);
                 }
                 if (lane == 0) {
