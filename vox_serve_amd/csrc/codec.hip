@@ -948,6 +948,118 @@ __global__ __launch_bounds__(256) void k_codec_attn(const float* qkv, const bf16
     }
 }
 
+// k_codec_rope_kv + k_codec_attn as ONE launch per layer, head dim as a compile-time constant: block (head, request) rotates its
+// head's T new q / k rows (q stays in LDS), writes the new K / V rows of its head to the ring and keeps their bf16 values in the LDS
+// tile next to the history rows (16-byte ring loads, one 64-bit modulo per row chunk instead of one per element); the T x Wn scores are
+// spread over all 256 threads as (query, key) pairs — the old form gave a wave one query at a time and left 56 lanes idle in the second
+// key pass — and the per-query softmax + P.V keep their wave-per-query form.  Every output's arithmetic (the fma chain over d of a
+// score, the lane sums and butterfly of the softmax, the fma chain over the keys of P.V, the bf16 rounding of the ring rows) is the
+// chain of the two kernels above: bit-identical.  Measured: 32 -> see profiles/round4_codec_attn_ab.txt.
+template <int D>
+__global__ __launch_bounds__(256) void k_codec_attn2(const float* qkv, bf16_t* ring, const int* slots, const long* pos, float* out, int T,
+                                                     int H, int Wn, const float* inv_freq) {
+    extern __shared__ float sm[];   // K [Wn][D+1], V [Wn][D+1], Q [T][D], P [T][Wn]
+    constexpr int LD = D + 1, half = D / 2, CH = D / 8;
+    float* Ks = sm;
+    float* Vs = Ks + (size_t)Wn * LD;
+    float* Qs = Vs + (size_t)Wn * LD;
+    float* Ps = Qs + (size_t)T * D;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HD = H * D;
+    const int slot = slots[b];
+    const long p0 = pos[slot];
+    const long lo = p0 + T - Wn;   // absolute position of logical slot 0
+    bf16_t* rbase = ring + (size_t)slot * Wn * 2 * HD + (size_t)h * D;
+    // history rows: logical slots 0 .. Wn - T - 1 (absolute positions lo .. p0 - 1; negative = the never-written zero rows)
+    for (int c = tid; c < (Wn - T) * CH; c += 256) {
+        const int j = c / CH, d0 = (c % CH) * 8;
+        const long ap = lo + j;
+        uint4 kq = make_uint4(0, 0, 0, 0), vq = kq;
+        if (ap >= 0) {
+            const bf16_t* r = rbase + (size_t)(ap % Wn) * 2 * HD + d0;
+            kq = *reinterpret_cast<const uint4*>(r);
+            vq = *reinterpret_cast<const uint4*>(r + HD);
+        }
+        float* kd = Ks + j * LD + d0;
+        float* vd = Vs + j * LD + d0;
+        kd[0] = bf2f((bf16_t)(kq.x & 0xffff)); kd[1] = bf2f((bf16_t)(kq.x >> 16)); kd[2] = bf2f((bf16_t)(kq.y & 0xffff)); kd[3] = bf2f((bf16_t)(kq.y >> 16));
+        kd[4] = bf2f((bf16_t)(kq.z & 0xffff)); kd[5] = bf2f((bf16_t)(kq.z >> 16)); kd[6] = bf2f((bf16_t)(kq.w & 0xffff)); kd[7] = bf2f((bf16_t)(kq.w >> 16));
+        vd[0] = bf2f((bf16_t)(vq.x & 0xffff)); vd[1] = bf2f((bf16_t)(vq.x >> 16)); vd[2] = bf2f((bf16_t)(vq.y & 0xffff)); vd[3] = bf2f((bf16_t)(vq.y >> 16));
+        vd[4] = bf2f((bf16_t)(vq.z & 0xffff)); vd[5] = bf2f((bf16_t)(vq.z >> 16)); vd[6] = bf2f((bf16_t)(vq.w & 0xffff)); vd[7] = bf2f((bf16_t)(vq.w >> 16));
+    }
+    // the chunk's T new rows: RoPE (NeoX halves) on q and k, k / v rounded to bf16 for the ring — and for this launch's own tile
+    for (int e = tid; e < T * half; e += 256) {
+        const int t = e / half, i = e % half, j = Wn - T + t;
+        const long p = p0 + t;
+        const float ang = (float)p * inv_freq[i];
+        const float c = cosf(ang), s = sinf(ang);
+        const float* q = qkv + ((size_t)(b * T + t)) * 3 * HD + (size_t)h * D;
+        const float* k = q + HD;
+        const float qa = q[i], qb = q[i + half], ka = k[i], kb = k[i + half];
+        Qs[t * D + i] = qa * c - qb * s;
+        Qs[t * D + i + half] = qb * c + qa * s;
+        const bf16_t k0 = f2bf(ka * c - kb * s), k1 = f2bf(kb * c + ka * s);
+        bf16_t* rk = rbase + (size_t)(p % Wn) * 2 * HD;
+        rk[i] = k0;
+        rk[i + half] = k1;
+        Ks[j * LD + i] = bf2f(k0);
+        Ks[j * LD + i + half] = bf2f(k1);
+    }
+    for (int e = tid; e < T * D; e += 256) {
+        const int t = e / D, d = e % D, j = Wn - T + t;
+        const long p = p0 + t;
+        const bf16_t v16 = f2bf(qkv[((size_t)(b * T + t)) * 3 * HD + 2 * HD + (size_t)h * D + d]);
+        rbase[(size_t)(p % Wn) * 2 * HD + HD + d] = v16;
+        Vs[j * LD + d] = bf2f(v16);
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)D);
+    for (int pr = tid; pr < T * Wn; pr += 256) {
+        const int i = pr / Wn, j = pr % Wn;
+        const int nvis = Wn - T + i + 1;
+        float sc = -INFINITY;
+        if (j < nvis) {
+            const float* q = Qs + (size_t)i * D;
+            const float* kr = Ks + (size_t)j * LD;
+            sc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) sc = fmaf(q[d], kr[d], sc);
+            sc *= scale;
+        }
+        Ps[pr] = sc;
+    }
+    __syncthreads();
+    for (int i = wave; i < T; i += 4) {
+        float* P = Ps + (size_t)i * Wn;
+        const int nvis = Wn - T + i + 1;
+        float mx = -INFINITY;
+        for (int j = lane; j < Wn; j += 64) mx = fmaxf(mx, P[j]);
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        float ls = 0.0f;
+        for (int j = lane; j < Wn; j += 64) {
+            const float pj = j < nvis ? expf(P[j] - mx) : 0.0f;
+            P[j] = pj;
+            ls += pj;
+        }
+        for (int off = 32; off >= 1; off >>= 1) ls += __shfl_xor(ls, off, 64);
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        for (int d = lane; d < D; d += 64) {
+            float o = 0.0f;
+            int j = 0;
+            for (; j + 8 <= nvis; j += 8) {
+                float pv[8], vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { pv[u] = P[j + u]; vv[u] = Vs[(j + u) * LD + d]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o = fmaf(pv[u], vv[u], o);
+            }
+            for (; j < nvis; ++j) o = fmaf(P[j], Vs[j * LD + d], o);
+            out[((size_t)(b * T + i)) * HD + (size_t)h * D + d] = o / ls;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pos_advance(long* pos, const int* slots, int n, int T) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b < n) pos[slots[b]] += T;
@@ -1415,11 +1527,19 @@ int vox_codec_decode_chunk(vox_codec* m, void* stream, const int32_t* codes, int
         bf16_t* ring = m->ring + (size_t)l * m->max_slots * c.window * 2 * HD;
         hipLaunchKernelGGL(k_rmsnorm_f32, dim3(n * L), dim3(256), 0, st, B, lw.ln1, C, H, c.rms_eps);
         VOX_TRY(conv_gemm(st, lw.qkv, C, nullptr, slots, n, L, 0, off0, D, nullptr, nullptr, 0));        // D [nL,3HD]
-        hipLaunchKernelGGL(k_codec_rope_kv, dim3(n * L), dim3(256), 0, st, D, ring, slots, m->pos, L, c.num_heads,
-                           c.head_dim, c.window, w.inv_freq);
-        hipLaunchKernelGGL(k_codec_attn, dim3(c.num_heads, n), dim3(256),
-                           (size_t)(2 * c.window * (c.head_dim + 1) + L * c.head_dim + 4 * c.window) * 4,
-                           st, D, ring, slots, m->pos, C, L, c.num_heads, c.head_dim, c.window);         // C [nL,HD]
+        // (VOX_CODEC_ATTN2=0: RoPE / ring write and the attention as two launches — A/B timing; bit-identical)
+        static const bool attn2 = [] { const char* e = getenv("VOX_CODEC_ATTN2"); return !(e && e[0] == '0'); }();
+        const size_t lds2 = (size_t)(2 * c.window * (c.head_dim + 1) + L * c.head_dim + L * c.window) * 4;
+        if (attn2 && c.head_dim == 64 && L <= c.window && lds2 <= 64 * 1024) {
+            hipLaunchKernelGGL(k_codec_attn2<64>, dim3(c.num_heads, n), dim3(256), lds2,
+                               st, D, ring, slots, m->pos, C, L, c.num_heads, c.window, w.inv_freq);       // C [nL,HD]
+        } else {
+            hipLaunchKernelGGL(k_codec_rope_kv, dim3(n * L), dim3(256), 0, st, D, ring, slots, m->pos, L, c.num_heads,
+                               c.head_dim, c.window, w.inv_freq);
+            hipLaunchKernelGGL(k_codec_attn, dim3(c.num_heads, n), dim3(256),
+                               (size_t)(2 * c.window * (c.head_dim + 1) + L * c.head_dim + 4 * c.window) * 4,
+                               st, D, ring, slots, m->pos, C, L, c.num_heads, c.head_dim, c.window);         // C [nL,HD]
+        }
         VOX_TRY(conv_gemm(st, lw.o, C, nullptr, slots, n, L, 0, off0, B, B, lw.scale1, 0));              // h += s1*o(attn)
         hipLaunchKernelGGL(k_rmsnorm_f32, dim3(n * L), dim3(256), 0, st, B, lw.ln2, C, H, c.rms_eps);
         VOX_TRY(conv_gemm(st, lw.gate_up, C, nullptr, slots, n, L, 0, off0, D, nullptr, nullptr, 0));    // D [nL,2I]
