@@ -954,7 +954,8 @@ __global__ __launch_bounds__(256) void k_codec_attn(const float* qkv, const bf16
 // spread over all 256 threads as (query, key) pairs — the old form gave a wave one query at a time and left 56 lanes idle in the second
 // key pass — and the per-query softmax + P.V keep their wave-per-query form.  Every output's arithmetic (the fma chain over d of a
 // score, the lane sums and butterfly of the softmax, the fma chain over the keys of P.V, the bf16 rounding of the ring rows) is the
-// chain of the two kernels above: bit-identical.  Measured: 32 -> see profiles/round4_codec_attn_ab.txt.
+// chain of the two kernels above: bit-identical (waveform digests equal).  Chunk of 1 / 8 / 32 requests: 1.95 -> 1.76, 3.53 -> 3.34, 7.70 -> 7.47 ms
+// (profiles/round4_codec_attn_ab.txt).
 template <int D>
 __global__ __launch_bounds__(256) void k_codec_attn2(const float* qkv, bf16_t* ring, const int* slots, const long* pos, float* out, int T,
                                                      int H, int Wn, const float* inv_freq) {
