@@ -557,6 +557,13 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
     if (depth_rep < 0) { const char* e = getenv("VOX_DEPTH_REPEAT"); depth_rep = e ? atoi(e) : 1; }
     for (int rep = 0; rep < depth_rep; ++rep)
 #endif
+    // One request, greedy: the pick of codebook i happens at the start of the persistent launch of step i + 1 (every block takes the
+    // argmax itself) instead of in a sampler launch between the two — 14 launches less per frame; VOX_DEPTH_PICK=0 keeps them.
+    static const bool pick_env = [] { const char* e = getenv("VOX_DEPTH_PICK"); return !(e && e[0] == '0'); }();
+    const bool fuse_pick = pick_env && m->dstep && B == 1 && !ablate() && sc->greedy && m->proj_tab && c.depth_vocab % 4 == 0 &&
+                           c.depth_vocab <= 65536 && H % 8 == 0;
+    DepthStepCall pend;         // the deferred pick (pick_* fields only)
+    bool have_pend = false;
     for (int i = (ablate() & 4096) ? 2 : 1; i < G && !(ablate() & 2); ++i) {      // (dev knob 4096: leave out depth step 1)
         const int rows = i == 1 ? 2 * B : B;
         if (i == 1 || !m->proj_tab) {     // (steps >= 2: the previous step's sampler gathered the tabulated projection into dx)
@@ -592,6 +599,11 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
             ds.vocab = c.depth_vocab; ds.qk_norm = dcfg.qk_norm; ds.qkv_bias = dcfg.qkv_bias; ds.rope_dim = dcfg.rope_dim;
             ds.rope_interleave = dcfg.rope_interleave; ds.page_size = dcfg.page_size; ds.table_max_pos = m->depth->rope_max_pos;
             ds.n_tokens = i + 1;
+            if (have_pend) {
+                ds.pick_logits = pend.pick_logits; ds.pick_tab = pend.pick_tab; ds.pick_emb = pend.pick_emb; ds.pick_out = pend.pick_out;
+                ds.pick_feat = pend.pick_feat; ds.pick_vocab = pend.pick_vocab; ds.pick_H = pend.pick_H; ds.pick_init = pend.pick_init;
+                have_pend = false;
+            }
             VOX_TRY(vox_launch_depth_step(st, ds));
         } else {
         VOX_TRY(stack_layers(m->depth, st, m->dx, m->dkv, m->dkv_stride, &r, i > 1, B <= m->ctx->exact_rows));
@@ -617,6 +629,12 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
             s.emb2_dst = m->dx; s.emb2_dst_stride = Hd;
         }
         s.feat_acc = io->next_features; s.feat_init = i == 1; s.ws = m->ctx->samp_ws;
+        if (fuse_pick && i + 1 < G && s.emb2_table && s.feat_acc) {       // (step i + 1 >= 2 of one request is a persistent launch)
+            pend.pick_logits = dl; pend.pick_vocab = c.depth_vocab; pend.pick_tab = s.emb2_table; pend.pick_emb = s.emb_table;
+            pend.pick_out = io->out_ids + i; pend.pick_feat = io->next_features; pend.pick_H = H; pend.pick_init = s.feat_init;
+            have_pend = true;
+            continue;
+        }
         if (!(ablate() & 8)) VOX_TRY(vox_launch_sample(st, s));
     }
     if (feedback) {

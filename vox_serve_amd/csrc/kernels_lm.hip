@@ -2819,6 +2819,11 @@ struct DepthStepArgs {
     AttnArgs at;                 // kv / kv_w = layer 0 of the depth KV cache; fixed_pos, identity_pages, cs, eps, scale ... as in the launch chain
     long kv_layer_stride;        // elements between the layers' caches
     float eps;
+    // the previous step's greedy pick at the start of this launch (DepthStepCall: pick_*)
+    const bf16_t *pick_logits, *pick_tab, *pick_emb;
+    int* pick_out;
+    bf16_t* pick_feat;
+    int pick_vocab, pick_H, pick_init;
 };
 #define VOX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 // Bound of every poll loop (a pass is a round trip to the memory side, >= ~0.5 us: >= 20 ms).  Legitimate waits are microseconds —
@@ -2888,8 +2893,51 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
     auto tagof = [&](int l, int st) { return tag0 + 1u + (unsigned)(l * 4 + st); };
     VOX_STAMP2_DECL
     VOX_STAMP2(0)
-    // x of the step: plain row written by the previous kernel
-    reinterpret_cast<unsigned*>(xb)[tid] = reinterpret_cast<const unsigned*>(a.x_in)[tid];
+    if (a.pick_logits) {
+        // The previous step's codebook, picked here instead of by a sampler launch in between (greedy frames): every block takes the
+        // first maximum of the 2048 logits — order of (value, lowest index), the sampler's — and reads the step's input row of that id
+        // from the tabulated projection; block 0 records the id and adds the id's embedding to the next frame's feature row.
+        __shared__ unsigned pick_red[8];
+        unsigned best = 0;
+        auto take = [&](unsigned h16, int v) {
+            bf16_t b = (bf16_t)h16;
+            if (b == 0x8000) b = 0;                                   // -0 == +0
+            const unsigned key = (b & 0x8000) ? (unsigned)(~b & 0xffff) : (unsigned)(b | 0x8000);
+            const unsigned c = (key << 16) | (0xFFFFu - (unsigned)v);
+            best = c > best ? c : best;
+        };
+        for (int c = tid; c < (a.pick_vocab >> 2); c += 512) {
+            const uint2 q = reinterpret_cast<const uint2*>(a.pick_logits)[c];
+            take(q.x & 0xffff, 4 * c); take(q.x >> 16, 4 * c + 1); take(q.y & 0xffff, 4 * c + 2); take(q.y >> 16, 4 * c + 3);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { const unsigned o = __shfl_xor(best, off, VOX_WAVE); best = o > best ? o : best; }
+        if (lane == 0) pick_red[wave] = best;
+        __syncthreads();
+        unsigned m = pick_red[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = pick_red[w] > m ? pick_red[w] : m;
+        const int picked = (int)(0xFFFFu - (m & 0xFFFFu));
+        reinterpret_cast<unsigned*>(xb)[tid] = reinterpret_cast<const unsigned*>(a.pick_tab + (size_t)picked * H)[tid];
+        if (blk == 0) {
+            if (tid == 0) *a.pick_out = picked;
+            const uint4* src = reinterpret_cast<const uint4*>(a.pick_emb + (size_t)picked * a.pick_H);
+            uint4* fa = reinterpret_cast<uint4*>(a.pick_feat);
+            for (int i = tid; i < (a.pick_H >> 3); i += 512) {
+                const uint4 e = src[i];
+                const uint4 f = a.pick_init ? make_uint4(0, 0, 0, 0) : fa[i];
+                uint4 o;
+                o.x = (u32)f2bf(bflo(f.x) + bflo(e.x)) | ((u32)f2bf(bfhi(f.x) + bfhi(e.x)) << 16);
+                o.y = (u32)f2bf(bflo(f.y) + bflo(e.y)) | ((u32)f2bf(bfhi(f.y) + bfhi(e.y)) << 16);
+                o.z = (u32)f2bf(bflo(f.z) + bflo(e.z)) | ((u32)f2bf(bfhi(f.z) + bfhi(e.z)) << 16);
+                o.w = (u32)f2bf(bflo(f.w) + bflo(e.w)) | ((u32)f2bf(bfhi(f.w) + bfhi(e.w)) << 16);
+                fa[i] = o;
+            }
+        }
+    } else {
+        // x of the step: plain row written by the previous kernel
+        reinterpret_cast<unsigned*>(xb)[tid] = reinterpret_cast<const unsigned*>(a.x_in)[tid];
+    }
     for (int l = 0; l < a.n_layers; ++l) {
         const DepthLayerW w = a.layers[l];
         // ---------------- stage A: qkv = Wqkv . rmsnorm(x, ln1)  (2048 column pairs: one per wave of every block) ----------------
@@ -3329,6 +3377,12 @@ int vox_launch_depth_step(hipStream_t st, const DepthStepCall& c) {
     a.head_w = (const bf16_t*)c.head_w; a.x_in = (const bf16_t*)c.x_in; a.logits = (bf16_t*)c.logits;
     a.gx = (unsigned long long*)c.gran; a.gqkv = a.gx + 512; a.gh = a.gqkv + 2048;
     a.epoch = c.epoch; a.err = c.err; a.kv_layer_stride = c.kv_layer_stride; a.eps = c.eps;
+    if (c.pick_logits) {
+        if (!c.pick_tab || !c.pick_emb || !c.pick_out || !c.pick_feat || c.pick_vocab <= 0 || c.pick_vocab > 65536 || c.pick_vocab % 4 || c.pick_H % 8)
+            return vox_fail(VOX_ERR_INVALID, "depth_step: bad fused-pick arguments");
+        a.pick_logits = (const bf16_t*)c.pick_logits; a.pick_tab = (const bf16_t*)c.pick_tab; a.pick_emb = (const bf16_t*)c.pick_emb;
+        a.pick_out = c.pick_out; a.pick_feat = (bf16_t*)c.pick_feat; a.pick_vocab = c.pick_vocab; a.pick_H = c.pick_H; a.pick_init = c.pick_init;
+    }
     AttnArgs& at = a.at;
     at.kv = (const bf16_t*)c.kv; at.kv_w = (bf16_t*)c.kv; at.cs = c.cs; at.eps = c.eps; at.scale = c.scale;
     at.Hq = c.heads; at.Hkv = c.kv_heads; at.page_size = c.page_size; at.table_max_pos = c.table_max_pos;

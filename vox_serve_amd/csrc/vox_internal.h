@@ -123,6 +123,13 @@ struct DepthStepCall {
     int hidden = 0, heads = 0, kv_heads = 0, head_dim = 0, ffn = 0, vocab = 0, qk_norm = 0, qkv_bias = 0, rope_dim = 0,
         rope_interleave = 0, page_size = 0, table_max_pos = 0;
     int n_tokens = 0;                      // visible tokens of the step (position n_tokens - 1)
+    // Greedy pick of the PREVIOUS step's codebook inside this launch (pick_logits != NULL; instead of a sampler launch in between):
+    // every block takes the first maximum of pick_logits[pick_vocab] and reads its input row pick_tab[id][hidden]; block 0 also
+    // writes the id to *pick_out and adds (pick_init: stores) pick_emb[id][pick_H] to pick_feat — what the sampler launch did.  x_in is unused.
+    const void *pick_logits = nullptr, *pick_tab = nullptr, *pick_emb = nullptr;
+    int* pick_out = nullptr;
+    void* pick_feat = nullptr;
+    int pick_vocab = 0, pick_H = 0, pick_init = 0;
 };
 // Persistent MLP half of a talker layer at one row (o_proj + residual, gate/up, down + residual in one launch; kernels_lm.hip)
 struct TalkerMlpCall {
