@@ -479,7 +479,8 @@ def test_batched_paths_against_reference_worker_logits(dev, golden, fixture, max
 def test_persistent_depth_step_is_bit_identical_to_the_launch_chain(dev, monkeypatch):
     """One-request frames at full size: depth steps 2..15 as ONE persistent launch each (k_depth_step: 256 resident blocks, stage outputs
     handed over as tagged granules) and the MLP half of every talker layer as one launch (k_talker_mlp) against the launch chain — ids, codec logits, all depth logits, fed-back features and the K/V
-    caches bit-identical over free-running streams (eager + graph replay, greedy + top-k), and no hand-off timed out."""
+    caches bit-identical over free-running streams (eager + graph replay, greedy + top-k), and no hand-off timed out.  The greedy half also
+    covers the pick of codebook i taken at the start of the persistent launch of step i + 1 (no sampler launch in between)."""
     from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
     from vox_serve_amd.synth import synth_qwen3_weights
     cfg = Qwen3Cfg()
