@@ -607,18 +607,10 @@ def serving_pool(n_req, frames, dp_size=1, fake=False):
         ranks = sorted({i["rank"] for i in infos})
         return {"value": samples / dt, "unit": "audio samples/s", "dp_size": dp_size, "requests": n_req * dp_size, "frames_per_request": frames,
                 "seconds": dt, "ttfa_ms_p50_client": ttfa[len(ttfa) // 2] if ttfa else None, "ranks_used": ranks,
-                "daemon_startup_s": startup, "transport": "AF_UNIX PUSH/PULL (pyzmq absent)" if os.environ.get("VOX_TRANSPORT") == "ipc" or not _has_zmq() else "zmq ipc",
+                "daemon_startup_s": startup, "transport": "AF_UNIX PUSH/PULL" if pool.transport == "ipc" else "zmq ipc",
                 "scheduler": "base + async_scheduling, one daemon per GPU (scheduler_entry.py)"}
     finally:
         pool.cleanup()
-
-
-def _has_zmq():
-    try:
-        import zmq  # noqa: F401
-        return True
-    except ImportError:
-        return False
 
 
 def other_configs():

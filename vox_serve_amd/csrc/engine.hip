@@ -552,11 +552,6 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         s.emb_dst = (bf16_t*)m->depth_x + H; s.emb_dst_stride = 2L * H; s.ws = m->ctx->samp_ws;
         VOX_TRY(vox_launch_sample(st, s));
     }
-#ifdef VOX_DEV_KNOBS
-    static int depth_rep = -1;      // (dev knob VOX_DEPTH_REPEAT: the depth loop n times over, timing only)
-    if (depth_rep < 0) { const char* e = getenv("VOX_DEPTH_REPEAT"); depth_rep = e ? atoi(e) : 1; }
-    for (int rep = 0; rep < depth_rep; ++rep)
-#endif
     // One request, greedy: the pick of codebook i happens at the start of the persistent launch of step i + 1 (every block takes the
     // argmax itself) instead of in a sampler launch between the two — 14 launches less per frame; VOX_DEPTH_PICK=0 keeps them.
     static const bool pick_env = [] { const char* e = getenv("VOX_DEPTH_PICK"); return !(e && e[0] == '0'); }();
@@ -564,6 +559,11 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
                            c.depth_vocab <= 65536 && H % 8 == 0;
     DepthStepCall pend;         // the deferred pick (pick_* fields only)
     bool have_pend = false;
+#ifdef VOX_DEV_KNOBS
+    static int depth_rep = -1;      // (dev knob VOX_DEPTH_REPEAT: the depth loop n times over, timing only)
+    if (depth_rep < 0) { const char* e = getenv("VOX_DEPTH_REPEAT"); depth_rep = e ? atoi(e) : 1; }
+    for (int rep = 0; rep < depth_rep; ++rep)
+#endif
     for (int i = (ablate() & 4096) ? 2 : 1; i < G && !(ablate() & 2); ++i) {      // (dev knob 4096: leave out depth step 1)
         const int rows = i == 1 ? 2 * B : B;
         if (i == 1 || !m->proj_tab) {     // (steps >= 2: the previous step's sampler gathered the tabulated projection into dx)

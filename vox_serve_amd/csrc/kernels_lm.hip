@@ -32,6 +32,45 @@ struct LinArgs {
     int no_one_seg;      // k_linear_mfma A/B knob (VOX_MFMA_ONESEG=0): row statistics by the separate pass even when K fits one segment
 };
 
+#ifdef VOX_DEV_KNOBS
+// development builds: chain trace.  Thread 0 of block 0 of every instrumented launch keeps up to 8 s_memrealtime stamps (100 MHz)
+// in registers and writes one 16-word record {kind, n, t0..} when it ends (launch order = record order: the chains are
+// dependent); thread 0 of the LAST block writes {entry, exit} into a second stream of records with the same numbering (how long
+// the grid takes to start and to drain).  Word 0 / 1 of the buffer count the records of the two streams.  vox_dev_set_trace().
+__device__ unsigned long long* g_vox_trace = nullptr;
+extern "C" int vox_dev_set_trace(void* p) {
+    unsigned long long* q = (unsigned long long*)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_vox_trace), &q, sizeof(q)) == hipSuccess ? 0 : -1;
+}
+#define VOX_TRACE_CAP 6000
+#define VOX_TR_DECL                                                                                                          \
+    unsigned long long tr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_slot = ~0ull, tr_slot2 = ~0ull;                                \
+    const bool tr_first = g_vox_trace && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0;                             \
+    const bool tr_last = g_vox_trace && threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1;     \
+    if (tr_first || tr_last) tr_t[0] = wall_clock64();                                                                       \
+    if (tr_first) tr_slot = atomicAdd(g_vox_trace, 1ull);                                                                    \
+    if (tr_last) tr_slot2 = atomicAdd(g_vox_trace + 1, 1ull);
+#define VOX_TR(k) if (tr_first) tr_t[k] = wall_clock64();
+#define VOX_TR_END(kind, n)                                                                                                  \
+    if (tr_first || tr_last) {                                                                                               \
+        const unsigned long long tr_e = wall_clock64();                                                                      \
+        if (tr_first && tr_slot < VOX_TRACE_CAP) {                                                                           \
+            unsigned long long* r = g_vox_trace + 16 * (tr_slot + 1);                                                        \
+            r[0] = (unsigned long long)(kind); r[1] = (unsigned long long)(n); r[2] = ((unsigned long long)gridDim.x << 32) | gridDim.y; \
+            for (int i_ = 0; i_ < 8; ++i_) r[3 + i_] = tr_t[i_];                                                              \
+            r[11] = tr_e;                                                                                                    \
+        }                                                                                                                    \
+        if (tr_last && tr_slot2 < VOX_TRACE_CAP) {                                                                           \
+            unsigned long long* r = g_vox_trace + 16 * (VOX_TRACE_CAP + 1) + 2 * tr_slot2;                                    \
+            r[0] = tr_t[0]; r[1] = tr_e;                                                                                     \
+        }                                                                                                                    \
+    }
+#else
+#define VOX_TR_DECL
+#define VOX_TR(k)
+#define VOX_TR_END(kind, n)
+#endif
+
 // element offset of (row r, column k) of a [*, K] matrix in fragment-major form
 __device__ __forceinline__ size_t frag_off(int r, int k, int K) {
     return ((size_t)(r >> 4) * (K >> 5) + (k >> 5)) * 512 + (size_t)(((r & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7));
@@ -1266,6 +1305,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
     constexpr int NG = KSTEPS / G;
     __shared__ f32x4_t red[8][NB][MT][64];
     __shared__ float ssq[8][16 * MT];
+    VOX_TR_DECL
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
     // ROWSPLIT: row_tiles blocks per column tile, one per 16*MT-row tile, ids 8 apart so that they land on the same XCD and
@@ -1325,6 +1365,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
 #pragma unroll
         for (int s = 0; s < G; ++s) xa[0][m][s] = xr[m][s * xstep];
     __builtin_amdgcn_sched_barrier(0);      // every load above is issued before anything below waits on one of them
+    VOX_TR(1)
     uint4 gv[PRO == PRO_RMSNORM ? G : 1];
     float rinv[MT];
     if (PRO == PRO_RMSNORM) {
@@ -1341,6 +1382,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
             if (lane < 16) ssq[wave][m * 16 + fr] = ss;
         }
         __syncthreads();
+        VOX_TR(2)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float t = 0.0f;
@@ -1391,7 +1433,9 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int m = 0; m < MT; ++m) red[wave][nb][m][lane] = acc[nb][m];
+        if (ct == 0) { VOX_TR(3) }
         __syncthreads();
+        if (ct == 0) { VOX_TR(4) }
         if (tid < MT * 64) {
             const int m = tid >> 6;            // thread (m, lane) finishes D fragment m: column n0+fr, rows m*16 + (lane>>4)*4 + r
             f32x4_t v = red[0][0][m][lane], u = SM ? red[0][NB - 1][m][lane] : v;
@@ -1424,6 +1468,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
             }
         }
     }
+    VOX_TR_END(1, (MT << 24) | (KSTEPS << 16) | (PRO << 12) | (EPI << 8) | (ROWSPLIT ? 16 : 0) | CT)
 }
 
 // row-major [rows][K] -> fragment-major (one thread per 16-byte chunk)
@@ -2100,6 +2145,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
     const int HS = gridDim.x / a.Hkv, hk = blockIdx.x / HS, hs = blockIdx.x % HS, row = blockIdx.y;
     VOX_STAMP_DECL
     VOX_STAMP(0)
+    VOX_TR_DECL
     const int tid = threadIdx.x, lane = tid & 63, wave16 = tid >> 6;
     const int grp = tid / GT, gt = tid % GT, gw = wave16 % GW;
     const int* pages = a.identity_pages ? nullptr
@@ -2148,7 +2194,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
         }
     };
     fetch_tile(0);
-    VOX_STAMP(1)
+    VOX_STAMP(1) VOX_TR(1)
     {   // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave
         int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
         p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
@@ -2175,7 +2221,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
         }
         if (ci + 1 < CPG) fetch_tile(ci + 1);  // in flight during this chunk's arithmetic
         __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
-        VOX_STAMP(3)
+        VOX_STAMP(3) VOX_TR(3)
         if (own_last && hs == 0 && gt < LPT) {
             // append the new token to the paged cache (page < 0: graph padding row)
             const int pg = a.identity_pages ? row : a.page[row];
@@ -2222,7 +2268,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             }
         }
         __syncthreads();
-        VOX_STAMP(5)
+        VOX_STAMP(5) VOX_TR(5)
         if (live) {      // chunk max + p = exp2((s-m)*log2e): 32 lanes per q head
             for (int pr = gt; pr < G * VOX_TC; pr += GT) {
                 const int g = pr / VOX_TC, t = pr % VOX_TC;
@@ -2256,7 +2302,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
         }
     }
     __syncthreads();
-    VOX_STAMP(7)
+    VOX_STAMP(7) VOX_TR(7)
     // merge (k_attn_merge): global max, the chunk weights w_c = exp2((m_c - M) log2e) once per (chunk, head), then L and O over
     // the chunks in ascending order
     if (tid < NCH * GMAX) {
@@ -2282,6 +2328,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
         if (a.out_frag) a.out_frag[frag_off(row, h * D + d, a.Hq * D)] = r;
     }
     VOX_STAMP(8)
+    VOX_TR_END(3, (GMAX << 8) | NCH)
 }
 
 #ifdef VOX_DEV_KNOBS      // the previous form of the kernel, for A/B timing in development builds (VOX_ATTN_V1=1)
@@ -2729,10 +2776,12 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
 // standalone: one wave per (row, kv head), four pairs per block (NT as in attn_short_wave)
 template <int NT>
 __global__ __launch_bounds__(256) void k_attn_short(AttnArgs at, int n_pairs) {
+    VOX_TR_DECL
     const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pi >= n_pairs) return;
     const int row = pi / at.Hkv, hk = pi % at.Hkv;
     attn_short_wave<NT>(at, row, hk, threadIdx.x & 63, at.out + (size_t)row * at.Hq * 128, true);
+    VOX_TR_END(2, NT)
 }
 
 // Fused into the o_proj GEMV: every o_proj block recomputes the row's attention (8 waves: one (row, kv head) pair

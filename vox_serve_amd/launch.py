@@ -28,7 +28,7 @@ import time
 import uuid
 from typing import Dict, Iterator, List, Optional
 
-from .ipc import PullSocket, PushSocket, TransportBusy
+from .ipc import TransportBusy, make_router_sockets, transport_kind
 
 
 def visible_gpu_mapping(dp_size: int, env=None) -> List[int]:
@@ -88,10 +88,18 @@ class ServingPool:
         self.ready: Dict[int, dict] = {}
         self._ready_event = threading.Event()
         self.scheduler_processes: List[subprocess.Popen] = []
+        # ONE transport decision for both ends of the wire (ipc.transport_kind: ZeroMQ like the reference when pyzmq is importable
+        # and VOX_TRANSPORT != "ipc"); the daemons get it in VOX_TRANSPORT, so they cannot pick a different framing than the router
+        self.transport = transport_kind({**os.environ, **self.extra_env})
         # the result end binds BEFORE the daemons start (they connect to it and announce READY on it)
-        self.result_socket = PullSocket(self.result_socket_path)
-        self.request_sockets = [PushSocket(f"{self.request_socket_path}_{r}") for r in range(self.dp_size)]
+        self.result_socket, self.request_sockets = make_router_sockets(self.transport, self.request_socket_path,
+                                                                       self.result_socket_path, self.dp_size)
         self.to_scheduler: "queue.Queue[bytes]" = queue.Queue(maxsize=max(1, self.max_batch_size * 2 * self.dp_size))
+        # one bounded queue + sender thread per rank behind the router thread: a rank whose daemon is slow to drain its socket
+        # holds back only the requests pinned to it (the reference's single sender loop retries in place and stalls every rank)
+        self.rank_queues: List["queue.Queue[bytes]"] = [queue.Queue(maxsize=max(2, self.max_batch_size * 2))
+                                                        for _ in range(self.dp_size)]
+        self._last_reap = 0.0
         atexit.register(self.cleanup)
         try:
             self._start_schedulers()
@@ -99,6 +107,10 @@ class ServingPool:
             self.message_thread.start()
             self.sender_thread = threading.Thread(target=self._sender_loop, name="vox-pool-sender", daemon=True)
             self.sender_thread.start()
+            self.rank_threads = [threading.Thread(target=self._rank_sender_loop, args=(r,), name=f"vox-pool-sender-{r}", daemon=True)
+                                 for r in range(self.dp_size)]
+            for t in self.rank_threads:
+                t.start()
             self._wait_ready(ready_timeout_s)
         except BaseException:
             self.cleanup()
@@ -126,6 +138,7 @@ class ServingPool:
             env = os.environ.copy()
             env.update(self.extra_env)
             env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+            env["VOX_TRANSPORT"] = self.transport        # the router's decision, not the child's own probe of pyzmq
             if gpu_mapping[rank] is not None:
                 # ONE mask: with both set, the CUDA_ one would be applied on top of the HIP_ one (an index into what is left)
                 env["HIP_VISIBLE_DEVICES"] = str(gpu_mapping[rank])
@@ -198,8 +211,13 @@ class ServingPool:
                 if self.running:
                     self.logger.error(f"result transport: {e}")
                 continue
-            if message is None:
+            # dead daemons are looked for on a timer, not only when the result socket is idle: under steady traffic from the healthy
+            # ranks the socket never idles and the requests of a dead rank would wait for their clients' timeouts
+            now = time.time()
+            if message is None or now - self._last_reap > 0.25:
+                self._last_reap = now
                 self._reap_dead_daemons()
+            if message is None:
                 continue
             parts = message.split(b"|", 2)
             if len(parts) < 3:
@@ -255,7 +273,6 @@ class ServingPool:
             raise RuntimeError("server busy: request queue full") from None      # the reference answers HTTP 429
 
     def _sender_loop(self):
-        backoff_initial, backoff_max = 0.001, 0.02
         while self.running:
             try:
                 payload = self.to_scheduler.get(timeout=0.1)
@@ -268,18 +285,34 @@ class ServingPool:
             with self.request_lock:
                 if rid in self.pending_requests:
                     self.pending_requests[rid]["rank"] = rank
+            while self.running:
+                try:
+                    self.rank_queues[rank].put(payload, timeout=0.1)
+                    break
+                except queue.Full:
+                    if rank < len(self.scheduler_processes) and self.scheduler_processes[rank].poll() is not None:
+                        break                              # its daemon is gone: _reap_dead_daemons answers the request
+
+    def _rank_sender_loop(self, rank: int):
+        backoff_initial, backoff_max = 0.001, 0.02
+        while self.running:
+            try:
+                payload = self.rank_queues[rank].get(timeout=0.1)
+            except queue.Empty:
+                self.request_sockets[rank].flush()          # finish a frame the socket took only part of
+                continue
             backoff = backoff_initial
             while self.running:
                 try:
-                    self.request_sockets[rank].send(payload)
+                    self.request_sockets[rank].send(payload)      # DONTWAIT: TransportBusy = back-pressure (zmq.Again of launch.py:484)
                     break
                 except TransportBusy:
                     if rank < len(self.scheduler_processes) and self.scheduler_processes[rank].poll() is not None:
-                        break                              # its daemon is gone: _reap_dead_daemons answers the request; do not block the others
+                        break                              # its daemon is gone: _reap_dead_daemons answers the request
                     time.sleep(backoff)
                     backoff = min(backoff * 2, backoff_max)
                 except Exception as e:
-                    self.logger.error(f"sender loop: {e}")
+                    self.logger.error(f"sender loop (rank {rank}): {e}")
                     break
 
     @staticmethod
@@ -326,8 +359,10 @@ class ServingPool:
 
     def generate(self, text: str, model_kwargs: Dict = None, timeout_s: float = 120.0, **kw) -> bytes:
         rid = self.start_streaming_request(text, model_kwargs=model_kwargs, **kw)
-        pcm = b"".join(self.stream(rid, timeout_s))
-        return pcm
+        try:
+            return b"".join(self.stream(rid, timeout_s))
+        finally:
+            self.release(rid)             # (launch.py:593-599: the entry goes away with the response; a long-lived pool must not keep every request's PCM)
 
     def completion(self, request_id: str) -> Optional[dict]:
         with self.request_lock:
