@@ -221,6 +221,27 @@ void vox_qwen3_destroy(vox_qwen3* m);
  * launch; VOX_TALKER_PERSIST=0 keeps the three launches).  `*enabled`: bit 0 = depth steps, bit 1 = talker MLP halves.  `*enabled`: whether this engine runs them; `*error_code`: 0, or the code of the first hand-off that timed
  * out (bounded spins: a stuck launch gives up with garbage instead of hanging; everything since is invalid).  Synchronises the device. */
 int vox_qwen3_depth_persist_status(vox_qwen3* m, int32_t* enabled, uint32_t* error_code);
+/* Fail loud within one frame (round 5).  The reference's graph replay cannot return garbage silently
+ * (worker/cuda_graph_worker.py:946-1056); a persistent kernel whose hand-off times out can, so its error word travels with every frame:
+ *   vox_qwen3_set_status     the LAST kernel of every frame / prefill writes the error code (0 = every hand-off arrived) to `status_dev`
+ *                            (device int32, e.g. the word in front of the out_ids rows the host copies anyway); decode frames also save
+ *                            their inputs (ids / masks / features of their rows, the frame counter) to a two-slot shadow.  Call before
+ *                            the first frame graph is captured.
+ *   vox_qwen3_frame_restore  puts the inputs of the frame `back` frames ago (1 = the last, 2 = the one before: one frame may be in
+ *                            flight behind a failed one) back in place, rows 0..n_rows-1 and the counter (n_rows = 0: the counter only —
+ *                            a prefill's rows are staged by the caller); the status word reads 0 afterwards, 0x7fffffff if no such frame
+ *                            is in the shadow.
+ *   vox_qwen3_persist_reset  waits for the device, clears the error words, re-zeroes the hand-off granules; disable != 0 turns the
+ *                            persistent kernels off: later frames take the bit-identical launch chains (drop graphs captured before).
+ *   vox_qwen3_persist_set_spins   bound of every poll loop in passes (>= ~0.5 us each; default 40000 = >= 20 ms, or VOX_PERSIST_SPINS).
+ *   vox_qwen3_persist_inject      TEST HOOK: in the next `count` launches of persistent kernel `which` (0 depth step, 1 talker MLP half)
+ *                            block 1 withholds its first publish — the effect of a block that never got a CU.
+ * Recovery = restore + reset(disable) + re-run the frame: bit-identical to a healthy run (tests/test_gpu_qwen3.py). */
+int vox_qwen3_set_status(vox_qwen3* m, int32_t* status_dev);
+int vox_qwen3_frame_restore(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int back, int n_rows);
+int vox_qwen3_persist_reset(vox_qwen3* m, int disable);
+int vox_qwen3_persist_set_spins(vox_qwen3* m, uint32_t spins);
+int vox_qwen3_persist_inject(vox_qwen3* m, int which, uint32_t count);
 /* Enqueue one whole frame for `batch` rows.  With feedback != 0 the engine also writes the next step's
  * input_ids / input_masks / input_features in place (qwen3_tts.py:1931-1944), so frames can be replayed
  * back-to-back from one captured graph while the host only advances the plan arrays. */

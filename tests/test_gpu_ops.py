@@ -194,6 +194,33 @@ def test_greedy_goldens(dev, golden, name):
     assert np.array_equal(ids.cpu().numpy().astype(np.int32), g[f"greedy_{name}_ids"])
 
 
+def test_module_level_sampler_helpers(dev, golden):
+    """sampling.py:21-80 of the reference: greedy_sampling / top_k_sampling / top_p_sampling / top_k_top_p_sampling / min_p_sampling as
+    module-level functions with the reference's arguments.  greedy replays the reference's own fixture (first maximum, any leading
+    shape); the stochastic ones equal the oracle's draw for the same (seed, offset) — the contract Sampler.run_sampling is tested on."""
+    from vox_serve_amd import sampling as S
+    g = golden("g1_sampler")
+    for name in ("a", "tie"):
+        lg = T(g[f"greedy_{name}_logits"], dev)
+        ids = S.greedy_sampling(lg)
+        assert ids.dtype == torch.int64 and np.array_equal(ids.cpu().numpy().astype(np.int32), g[f"greedy_{name}_ids"])
+        assert torch.equal(S.greedy_sampling(lg[None]), ids[None])            # argmax(dim=-1) keeps the leading dims
+    rng = np.random.default_rng(11)
+    logits = vr.f2bf(rng.standard_normal((4, 2048)).astype(np.float32) * 3)
+    lt = T(logits, dev)
+    cases = [(lambda: S.top_k_sampling(lt, 50, 0.9), dict(top_k=50, top_p=1.0, min_p=0.0, temperature=0.9)),
+             (lambda: S.top_p_sampling(lt, 0.8, 0.7), dict(top_k=0, top_p=0.8, min_p=0.0, temperature=0.7)),
+             (lambda: S.top_k_top_p_sampling(lt, 25, 0.8, 1.0), dict(top_k=25, top_p=0.8, min_p=0.0, temperature=1.0)),
+             (lambda: S.min_p_sampling(lt, 0.1, 1.0), dict(top_k=0, top_p=1.0, min_p=0.1, temperature=1.0))]
+    S.Sampler.manual_seed(123)
+    for off, (fn, kw) in enumerate(cases):
+        got = fn()
+        assert got.dtype == torch.int32 and got.shape == (4,)
+        assert np.array_equal(got.cpu().numpy(), vr.sample(logits, seed=123, offset=off, **kw)), kw
+    with pytest.raises(NotImplementedError):
+        S.top_k_top_p_sampling(lt, 25, 0.8, 1.0, filter_apply_order="joint")
+
+
 def test_repetition_penalty_and_update_goldens(dev, golden):
     from vox_serve_amd.sampling import Sampler
     g = golden("g1_sampler")

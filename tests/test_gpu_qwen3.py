@@ -16,6 +16,7 @@ import torch
 
 from oracle import qwen3_ref as QR
 from oracle import voxref as vr
+from vox_serve_amd import _native as N
 from tests.oracle_tape import Tape, Weights
 
 pytestmark = pytest.mark.gpu
@@ -517,6 +518,145 @@ def test_persistent_depth_step_is_bit_identical_to_the_launch_chain(dev, monkeyp
                 assert torch.equal(getattr(ea, name), getattr(eb, name)), (use_graph, f, name)
     assert torch.equal(ea.kv, eb.kv)
     assert eb.depth_persist_status() == (3, 0)
+    ea.close(); eb.close()
+
+
+def _persist_pair(dev, monkeypatch, cfg, W, ps=128):
+    from vox_serve_amd.engine import Qwen3Engine
+
+    def make(persist):
+        monkeypatch.setenv("VOX_DEPTH_PERSIST", "1" if persist else "0")
+        monkeypatch.setenv("VOX_TALKER_PERSIST", "1" if persist else "0")
+        e = Qwen3Engine(cfg, W, max_batch=1, page_size=ps, max_pages=8, max_seq_len=512, max_prefill_rows=64, keep_depth_logits=True)
+        e.keep_hidden = False
+        g = torch.Generator(device=dev).manual_seed(5)
+        e.kv[:, :3] = (torch.randn(e.kv[:, :3].shape, generator=g, device=dev) * 0.5).to(e.kv.dtype)
+        e.input_ids.zero_(); e.input_ids[:, -1] = cfg.tts_pad_id; e.input_ids[:, 0] = 17
+        e.input_masks[:1] = 1
+        e.input_features.zero_()
+        return e
+    return make(False), make(True)
+
+
+def _one_frame(e, f, sc, ps=128, use_graph=True):
+    kv = 150 + f
+    pages = list(range((kv + ps - 1) // ps))
+    e.upload_plan(pos=[kv], kvlen=[kv], page=[pages[-1]], slot=[(kv - 1) % ps], indptr=[0, len(pages)], indices=pages)
+    e.frame(1, kv, sc, seed=3, feedback=True, use_graph=use_graph)
+
+
+@pytest.mark.parametrize("which,at_frame", [(0, 3), (1, 5)])       # 0: a depth-step launch, 1: a talker MLP-half launch
+def test_persistent_handoff_timeout_is_seen_in_the_same_frame_and_recovered_bit_identically(dev, monkeypatch, which, at_frame):
+    """Round-4 review P3: a hand-off timeout made every later one-request frame garbage and the host looked at the error word every 512
+    frames.  Now the word travels with every frame's token snapshot.  Here block 1 of one persistent launch withholds its first publish
+    (vox_qwen3_persist_inject; poll bound lowered so the give-up takes a millisecond, not 20): `read_ids` of THAT frame sees the status,
+    replays the frame on the launch chain (persistent kernels off from then on) and returns ids equal to the healthy engine's; every
+    later frame, the K/V caches and the fed-back inputs stay bit-identical; the status row is clean again."""
+    from vox_serve_amd.engine import Qwen3Cfg
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ea, eb = _persist_pair(dev, monkeypatch, cfg, W)
+    if eb.depth_persist_status()[0] != 3:
+        pytest.skip("persistent kernels not available on this part (< 256 CUs)")
+    N.check(eb.L.vox_qwen3_persist_set_spins(eb.h, 2000))
+    sc = ea.sampling_cfg(greedy=True)
+    for f in range(9):
+        if f == at_frame:
+            N.check(eb.L.vox_qwen3_persist_inject(eb.h, which, 1))
+        for e in (ea, eb):
+            _one_frame(e, f, sc)
+        ia, ib = ea.read_ids(1), eb.read_ids(1)                    # the per-frame snapshot: detection + recovery happen inside
+        assert torch.equal(ia, ib), f
+        assert len(eb.persist_failures) == (1 if f >= at_frame else 0), (f, eb.persist_failures)
+        for name in ("out_ids", "out_logits", "out_depth_logits", "next_features", "input_features", "input_ids", "rng_offset"):
+            assert torch.equal(getattr(ea, name), getattr(eb, name)), (f, name)
+        assert int(eb.status_row[0]) == 0
+    assert torch.equal(ea.kv, eb.kv)
+    assert eb.depth_persist_status() == (0, 0)                    # switched off for this engine, error words cleared
+    code = eb.persist_failures[0][1]
+    assert (code >> 8) in ((0x2,) if which == 0 else (0x11,)), hex(code)      # the gather that waits for the withheld publish
+    ea.close(); eb.close()
+
+
+def test_persistent_handoff_timeout_with_one_frame_in_flight_behind_it(dev, monkeypatch):
+    """Async scheduling / the pipelined bench loop: when frame N's status is read, frame N + 1 is already enqueued and started from
+    garbage.  recover(back=2) puts frame N's inputs back from ITS shadow slot (N + 1 wrote the other one), replays N, lets the caller
+    re-read N's outputs, then replays N + 1: both frames' ids and every later frame equal the healthy engine's."""
+    from vox_serve_amd.engine import Qwen3Cfg
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ea, eb = _persist_pair(dev, monkeypatch, cfg, W)
+    if eb.depth_persist_status()[0] != 3:
+        pytest.skip("persistent kernels not available on this part (< 256 CUs)")
+    N.check(eb.L.vox_qwen3_persist_set_spins(eb.h, 2000))
+    sc = ea.sampling_cfg(greedy=True)
+    want = []
+    for f in range(8):
+        _one_frame(ea, f, sc)
+        want.append(ea.read_ids(1).clone())
+    got, pins = [], [torch.zeros(2, cfg.n_groups + 1, dtype=torch.int32).pin_memory() for _ in range(2)]
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def snap(k):
+        pins[k].copy_(eb.snapshot_src(1), non_blocking=True)
+        evs[k].record()
+    for f in range(8):
+        if f == 4:
+            N.check(eb.L.vox_qwen3_persist_inject(eb.h, 0, 1))
+        _one_frame(eb, f, sc)
+        snap(f & 1)
+        if f > 0:                                                   # frame f - 1 is read while frame f is in flight
+            k = (f - 1) & 1
+            evs[k].synchronize()
+            if int(pins[k][0, 0]) != 0:
+                assert f - 1 == 4
+                eb.recover(back=2, code=int(pins[k][0, 0]), on_first_done=lambda k=k: snap(k))
+                snap(f & 1)
+                evs[k].synchronize()
+                assert int(pins[k][0, 0]) == 0
+            got.append(pins[k][1:].to(torch.long).clone())
+    evs[7 & 1].synchronize()
+    got.append(pins[7 & 1][1:].to(torch.long).clone())
+    assert len(eb.persist_failures) == 1
+    for f in range(8):
+        assert torch.equal(got[f], want[f]), f
+    for name in ("out_logits", "next_features", "input_features", "input_ids", "rng_offset"):
+        assert torch.equal(getattr(ea, name), getattr(eb, name)), name
+    assert torch.equal(ea.kv, eb.kv)
+    ea.close(); eb.close()
+
+
+def test_persistent_kernels_with_a_codec_chunk_on_a_second_stream(dev, monkeypatch):
+    """The case the hand-off comment names: the 256 resident blocks of a persistent launch wait for CUs held by another stream's
+    kernels.  One-request frames replay while Qwen3 codec chunks of 8 requests run beside them on a second stream: no hand-off may
+    time out (default 20 ms bound) and the frames must equal the launch-chain engine's, which runs with nothing beside it."""
+    from vox_serve_amd.engine import Qwen3Cfg
+    from vox_serve_amd.synth import synth_qwen3_weights, synth_qwen3_codec_weights
+    from vox_serve_amd.tokenizer.qwen3_codec import Qwen3TTSDecoder
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ea, eb = _persist_pair(dev, monkeypatch, cfg, W)
+    if eb.depth_persist_status()[0] != 3:
+        pytest.skip("persistent kernels not available on this part (< 256 CUs)")
+    codec = Qwen3TTSDecoder(synth_qwen3_codec_weights(seed=1), device=dev, max_batch=8, max_slots=8, detokenize_interval=10)
+    cache = codec.init_cache(8)
+    side = torch.cuda.Stream()
+    toks = torch.randint(0, 2048, (8, 10, cfg.n_groups), device=dev)
+    sc = ea.sampling_cfg(greedy=True)
+    for f in range(40):
+        if f % 4 == 0:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                codec.decode_chunk(toks, cache, code_layout="BTQ")
+        _one_frame(eb, f, sc)
+        ib = eb.read_ids(1)
+        _one_frame(ea, f, sc)
+        assert torch.equal(ea.read_ids(1), ib), f
+    torch.cuda.synchronize()
+    assert eb.persist_failures == [] and eb.depth_persist_status() == (3, 0)
+    assert torch.equal(ea.kv, eb.kv)
     ea.close(); eb.close()
 
 

@@ -102,6 +102,11 @@ _SIGS = {
                                   c_void_p, c_int, c_int, POINTER(SamplingCfg), c_uint64, c_int]),
     "vox_qwen3_prompt_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "vox_qwen3_depth_persist_status": (c_int, [c_void_p, POINTER(c_int32), POINTER(ctypes.c_uint32)]),
+    "vox_qwen3_set_status": (c_int, [c_void_p, c_void_p]),
+    "vox_qwen3_frame_restore": (c_int, [c_void_p, c_void_p, POINTER(Qwen3IO), c_int, c_int]),
+    "vox_qwen3_persist_reset": (c_int, [c_void_p, c_int]),
+    "vox_qwen3_persist_set_spins": (c_int, [c_void_p, ctypes.c_uint32]),
+    "vox_qwen3_persist_inject": (c_int, [c_void_p, c_int, ctypes.c_uint32]),
 }
 
 # symbols added by later translation units (codec); bound if present, listed so the export test sees them

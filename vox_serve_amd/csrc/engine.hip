@@ -267,6 +267,13 @@ static int ablate() {
 static constexpr int ablate() { return 0; }
 #endif
 
+// bound of the persistent kernels' poll loops (passes; a pass is a round trip to the memory side, >= ~0.5 us: >= 20 ms by default);
+// VOX_PERSIST_SPINS in the environment overrides it at engine creation, vox_qwen3_persist_set_spins() later
+static unsigned vox_persist_spins_default() {
+    static const unsigned v = [] { const char* e = getenv("VOX_PERSIST_SPINS"); const long x = e ? atol(e) : 0; return x > 0 ? (unsigned)x : 40000u; }();
+    return v;
+}
+
 static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t kv_stride, const vox_rows* r,
                         bool decode_rows = false, int fixed_order = 0) {
     const vox_stack_config& c = s->cfg;
@@ -450,11 +457,11 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
         (void)hipGetDevice(&dev_id);
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         if (want && n_cu >= 256 && vox_talker_mlp_supported(probe) && !s->cfg.qkv_bias) {
-            if (hipMalloc(&s->mlp_gran, 4096 * 8) != hipSuccess || hipMalloc((void**)&s->mlp_words, 8) != hipSuccess)
+            if (hipMalloc(&s->mlp_gran, 4096 * 8) != hipSuccess || hipMalloc((void**)&s->mlp_words, 16) != hipSuccess)
                 return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc");
             VOX_HIP(hipMemset(s->mlp_gran, 0, 4096 * 8));
-            const unsigned words[2] = {1u, 0u};
-            VOX_HIP(hipMemcpy(s->mlp_words, words, 8, hipMemcpyHostToDevice));
+            const unsigned words[4] = {1u, 0u, vox_persist_spins_default(), 0u};      // epoch, error, poll bound, test hook
+            VOX_HIP(hipMemcpy(s->mlp_words, words, 16, hipMemcpyHostToDevice));
             s->mlp_persist = 1;
         }
     }
@@ -509,14 +516,29 @@ struct vox_qwen3 {
     void *dstep_layers = nullptr, *dstep_gran = nullptr;
     unsigned* dstep_words = nullptr;      // [0] epoch, [1] error
     int dstep = 0;                         // 1: depth steps 2.. of a one-request frame run as ONE launch each
+    // Fail-loud support (vox_qwen3_set_status): the last kernel of every frame / prefill writes the persistent kernels' error word to
+    // the caller's device word, which travels with the token snapshot the host reads anyway; every decode frame saves its inputs
+    // (ids, masks, features of the rows it runs, the frame counter) to one of two shadow slots — the counter's parity picks the slot,
+    // so a frame still in flight behind a failed one does not overwrite it — for vox_qwen3_frame_restore.
+    int32_t* status = nullptr;
+    Qwen3Shadow shadow{};
 };
 
-__global__ void k_frame_init(int* out_ids, int stride, int col, int val, int B) {
+__global__ void k_frame_init(int* out_ids, int stride, int col, int val, int B, const uint64_t* rng, uint64_t* sh_rng) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) out_ids[(size_t)b * stride + col] = val;
+    if (b == 0 && rng && sh_rng) sh_rng[*rng & 1] = *rng;       // shadow of the frame counter (frames and prefills; it is bumped by the frame's last kernel)
+}
+// status word of the frame: the first error code of the persistent kernels (0 = every hand-off arrived)
+__device__ __forceinline__ void frame_status(int32_t* status, const unsigned* e0, const unsigned* e1) {
+    if (!status) return;
+    unsigned v = e0 ? e0[1] : 0u;
+    if (!v && e1) v = e1[1];
+    status[0] = (int32_t)v;
 }
 __global__ void k_qwen3_feedback(const int* out_ids, int* input_ids, uint8_t* masks, const bf16_t* next_feat,
-                                 bf16_t* feat, uint64_t* rng, int G1, int H, int pad_id, int B) {
+                                 bf16_t* feat, uint64_t* rng, int G1, int H, int pad_id, int B, int32_t* status, const unsigned* e0,
+                                 const unsigned* e1) {
     const int b = blockIdx.y;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int j = 0; j < G1; ++j) input_ids[(size_t)b * G1 + j] = 0;
@@ -524,11 +546,33 @@ __global__ void k_qwen3_feedback(const int* out_ids, int* input_ids, uint8_t* ma
         input_ids[(size_t)b * G1 + G1 - 1] = pad_id;
         masks[b] = 1;
         if (b == 0 && rng) *rng += 1;
+        if (b == 0) frame_status(status, e0, e1);
     }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < H; i += gridDim.x * 256)
         feat[(size_t)b * H + i] = next_feat[(size_t)b * H + i];
 }
-__global__ void k_rng_bump(uint64_t* rng) { *rng += 1; }
+__global__ void k_rng_bump(uint64_t* rng, int32_t* status, const unsigned* e0, const unsigned* e1) {
+    if (rng) *rng += 1;
+    frame_status(status, e0, e1);
+}
+// Inputs of the frame `back` frames ago (1 = the last one) back into place: slot = parity of the counter value that frame started
+// from; a slot that does not hold that counter value (no such frame was run) leaves everything alone and reports 0x7fffffff.
+__global__ __launch_bounds__(256) void k_qwen3_restore(Qwen3Shadow sh, int* ids, uint8_t* masks, bf16_t* feat, uint64_t* rng, int back, int n_rows,
+                                                       int32_t* status) {
+    const uint64_t want = *rng - (uint64_t)back;
+    const int slot = (int)(want & 1);
+    __shared__ int ok;
+    if (threadIdx.x == 0) ok = sh.rng[slot] == want;
+    __syncthreads();
+    if (!ok) { if (threadIdx.x == 0 && status) status[0] = 0x7fffffff; return; }
+    for (int b = 0; b < n_rows; ++b) {
+        for (int j = threadIdx.x; j < sh.G1; j += 256) ids[(size_t)b * sh.G1 + j] = sh.ids[((size_t)slot * sh.max_batch + b) * sh.G1 + j];
+        if (threadIdx.x == 0) masks[b] = sh.mask[(size_t)slot * sh.max_batch + b];
+        for (int i = threadIdx.x; i < sh.H; i += 256) feat[(size_t)b * sh.H + i] = sh.feat[((size_t)slot * sh.max_batch + b) * sh.H + i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { *rng = want; if (status) status[0] = 0; }
+}
 __global__ void k_copy_rows(const bf16_t* src, long src_stride, bf16_t* dst, long dst_stride, int H) {
     const int b = blockIdx.y;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < H; i += gridDim.x * 256)
@@ -541,7 +585,8 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
     // codebook-0 sampling, the depth loop, and the feedback of the next step's inputs.
     const vox_qwen3_config& c = m->cfg;
     const int H = c.talker.hidden, Hd = c.depth.hidden, G = c.n_groups, G1 = G + 1;
-    hipLaunchKernelGGL(k_frame_init, dim3((B + 63) / 64), dim3(64), 0, st, io->out_ids, G1, G, c.tts_pad_id, B);
+    hipLaunchKernelGGL(k_frame_init, dim3((B + 63) / 64), dim3(64), 0, st, io->out_ids, G1, G, c.tts_pad_id, B, (const uint64_t*)io->rng_offset,
+                       m->status ? m->shadow.rng : nullptr);
     {
         SampleCall s;
         s.logits = io->out_logits; s.B = B; s.V = c.vocab; s.suppress_ids = m->suppress; s.n_suppress = m->n_suppress;
@@ -637,18 +682,20 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         }
         if (!(ablate() & 8)) VOX_TRY(vox_launch_sample(st, s));
     }
+    const unsigned* e0 = m->dstep_words;                     // (NULL when the engine never had the persistent kernels)
+    const unsigned* e1 = m->talker->mlp_words;
     if (feedback) {
         hipLaunchKernelGGL(k_qwen3_feedback, dim3((H + 255) / 256, B), dim3(256), 0, st, io->out_ids, io->input_ids,
                            io->input_masks, (const bf16_t*)io->next_features, (bf16_t*)io->input_features,
-                           io->rng_offset, G1, H, c.tts_pad_id, B);
-    } else if (io->rng_offset) {
-        hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, io->rng_offset);
+                           io->rng_offset, G1, H, c.tts_pad_id, B, m->status, e0, e1);
+    } else if (io->rng_offset || m->status) {
+        hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, io->rng_offset, m->status, e0, e1);
     }
     return VOX_OK;
 }
 
 static int qwen3_embed(vox_qwen3* m, hipStream_t st, const int32_t* ids, const uint8_t* masks, const void* feats,
-                       int n) {
+                       int n, const uint64_t* shadow_rng = nullptr) {
     const vox_qwen3_config& c = m->cfg;
     const int H = c.talker.hidden, G1 = c.n_groups + 1;
     VOX_TRY(vox_launch_gather(st, m->w.text_embedding, ids, G1, G1 - 1, m->te, c.text_hidden, n, c.text_hidden,
@@ -661,7 +708,9 @@ static int qwen3_embed(vox_qwen3* m, hipStream_t st, const int32_t* ids, const u
     f2.W = m->w.tp_fc2_w; f2.bias = m->w.tp_fc2_b; f2.x = m->t1; f2.y = m->text; f2.B = n; f2.N = H;
     f2.K = c.text_hidden; f2.pro = VOX_PRO_COPY; f2.epi = VOX_EPI_STORE;
     VOX_TRY(vox_launch_linear(m->ctx, st, f2));
-    return vox_launch_qwen3_mix(st, m->text, m->w.codec_embedding, ids, G1, masks, feats, m->x, n, H, c.vocab);
+    // decode frames with a status word: the mix kernel (which reads ids / masks / features anyway) also saves them to the shadow slot
+    return vox_launch_qwen3_mix(st, m->text, m->w.codec_embedding, ids, G1, masks, feats, m->x, n, H, c.vocab,
+                                shadow_rng && m->status ? &m->shadow : nullptr, shadow_rng);
 }
 
 
@@ -776,26 +825,27 @@ int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_
         const vox_stack_config& dq = m->depth->cfg;       // (as the stack normalised it)
         probe.hidden = dq.hidden; probe.heads = dq.heads; probe.kv_heads = dq.kv_heads; probe.head_dim = dq.head_dim; probe.ffn = dq.ffn;
         probe.vocab = cfg->depth_vocab; probe.qk_norm = dq.qk_norm; probe.qkv_bias = dq.qkv_bias; probe.rope_dim = dq.rope_dim;
-        probe.rope_interleave = dq.rope_interleave; probe.page_size = dq.page_size; probe.n_layers = dq.layers; probe.n_tokens = 2;
+        probe.rope_interleave = dq.rope_interleave; probe.page_size = dq.page_size; probe.n_layers = dq.layers;
+        probe.n_tokens = G;      // the LARGEST step (step i sees i + 1 <= G tokens): a config whose later steps the kernel cannot take keeps the chain
         const char* e = getenv("VOX_DEPTH_PERSIST");
         const bool want = e ? e[0] == '1' : true;
         int n_cu = 0, dev_id = 0;
         (void)hipGetDevice(&dev_id);
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         // 256 blocks of 512 threads must all be resident at once (one per CU): a partitioned or smaller part keeps the launch chain
-        if (want && n_cu >= 256 && vox_depth_step_supported(probe) && w->depth_rope) {
+        if (want && n_cu >= 256 && G >= 2 && vox_depth_step_supported(probe) && w->depth_rope) {
             std::vector<const void*> ptrs;
             for (int l = 0; l < dc.layers; ++l) {
                 const vox_layer_weights& lw = w->depth_layers[l];
                 for (const void* q : {lw.wqkv, lw.wo, lw.wgate, lw.wup, lw.wdown, lw.ln1, lw.ln2, lw.qnorm, lw.knorm}) ptrs.push_back(q);
             }
             if (hipMalloc(&m->dstep_layers, ptrs.size() * sizeof(void*)) != hipSuccess || hipMalloc(&m->dstep_gran, 4096 * 8) != hipSuccess ||
-                hipMalloc((void**)&m->dstep_words, 8) != hipSuccess)
+                hipMalloc((void**)&m->dstep_words, 16) != hipSuccess)
                 return vox_fail(VOX_ERR_NOMEM, "qwen3_create: hipMalloc");
             VOX_HIP(hipMemcpy(m->dstep_layers, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice));
             VOX_HIP(hipMemset(m->dstep_gran, 0, 4096 * 8));
-            const unsigned words[2] = {1u, 0u};
-            VOX_HIP(hipMemcpy(m->dstep_words, words, 8, hipMemcpyHostToDevice));
+            const unsigned words[4] = {1u, 0u, vox_persist_spins_default(), 0u};      // epoch, error, poll bound, test hook
+            VOX_HIP(hipMemcpy(m->dstep_words, words, 16, hipMemcpyHostToDevice));
             m->dstep = 1;
         }
     }
@@ -823,10 +873,79 @@ int vox_qwen3_depth_persist_status(vox_qwen3* m, int32_t* enabled, uint32_t* err
     return VOX_OK;
 }
 
+// Per-frame status word (device, int32): written by the LAST kernel of every frame / prefill with the persistent kernels' error code
+// (0 = fine).  The host reads it with the token snapshot of the frame: a hand-off that timed out is seen in the same frame.  Also
+// enables the input shadow that vox_qwen3_frame_restore reads.  Call before any frame graph is captured.
+int vox_qwen3_set_status(vox_qwen3* m, int32_t* status_dev) {
+    if (!m) return vox_fail(VOX_ERR_INVALID, "qwen3_set_status: NULL");
+    if (status_dev && !m->shadow.rng) {
+        const vox_qwen3_config& c = m->cfg;
+        Qwen3Shadow& sh = m->shadow;
+        sh.G1 = c.n_groups + 1; sh.H = c.talker.hidden; sh.max_batch = c.max_batch;
+        const size_t nb = (size_t)2 * c.max_batch;
+        if (hipMalloc((void**)&sh.rng, 16) != hipSuccess || hipMalloc((void**)&sh.ids, nb * sh.G1 * 4) != hipSuccess ||
+            hipMalloc((void**)&sh.mask, nb) != hipSuccess || hipMalloc((void**)&sh.feat, nb * sh.H * 2) != hipSuccess)
+            return vox_fail(VOX_ERR_NOMEM, "qwen3_set_status: hipMalloc");
+        VOX_HIP(hipMemset(sh.rng, 0xff, 16));
+    }
+    m->status = status_dev;
+    return VOX_OK;
+}
+// Put the inputs of the frame `back` frames ago (1: the last frame, 2: the one before) back: input_ids / input_masks / input_features of
+// rows 0..n_rows-1 and the frame counter (io->rng_offset), from the shadow slot of that frame.  n_rows = 0 restores the counter only (a
+// prefill's inputs are staged by the caller).  The status word reads 0 afterwards, 0x7fffffff when no such frame is in the shadow.
+int vox_qwen3_frame_restore(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int back, int n_rows) {
+    if (!m || !io || !m->shadow.rng || !io->rng_offset) return vox_fail(VOX_ERR_INVALID, "qwen3_frame_restore: no shadow (vox_qwen3_set_status) or no frame counter");
+    if (back < 1 || back > 2 || n_rows < 0 || n_rows > m->cfg.max_batch) return vox_fail(VOX_ERR_INVALID, "qwen3_frame_restore: bad arguments");
+    hipLaunchKernelGGL(k_qwen3_restore, dim3(1), dim3(256), 0, (hipStream_t)stream, m->shadow, io->input_ids, io->input_masks,
+                       (bf16_t*)io->input_features, io->rng_offset, back, n_rows, m->status);
+    VOX_HIP(hipGetLastError());
+    return VOX_OK;
+}
+// After a hand-off timeout (or as a precaution): wait for the device, clear the error words, re-zero the granules, move the epochs on;
+// disable != 0 also turns the persistent kernels off for this engine — frames enqueued from now on take the bit-identical launch
+// chains (graphs captured earlier still hold persistent launches: the caller drops them).
+int vox_qwen3_persist_reset(vox_qwen3* m, int disable) {
+    if (!m) return vox_fail(VOX_ERR_INVALID, "qwen3_persist_reset: NULL");
+    VOX_HIP(hipDeviceSynchronize());
+    auto reset = [](unsigned* words, void* gran) -> hipError_t {
+        if (!words) return hipSuccess;
+        unsigned w[4];
+        hipError_t e = hipMemcpy(w, words, 16, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        w[0] += 1u; w[1] = 0u; w[3] = 0u;
+        if ((e = hipMemcpy(words, w, 16, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        return hipMemset(gran, 0, 4096 * 8);
+    };
+    VOX_HIP(reset(m->dstep_words, m->dstep_gran));
+    VOX_HIP(reset(m->talker->mlp_words, m->talker->mlp_gran));
+    if (disable) { m->dstep = 0; m->talker->mlp_persist = 0; }
+    return VOX_OK;
+}
+// bound of the persistent kernels' poll loops, in passes (>= ~0.5 us each; default 40000 or VOX_PERSIST_SPINS); tests lower it
+int vox_qwen3_persist_set_spins(vox_qwen3* m, uint32_t spins) {
+    if (!m || spins < 1) return vox_fail(VOX_ERR_INVALID, "qwen3_persist_set_spins: bad arguments");
+    VOX_HIP(hipDeviceSynchronize());
+    if (m->dstep_words) VOX_HIP(hipMemcpy(m->dstep_words + 2, &spins, 4, hipMemcpyHostToDevice));
+    if (m->talker->mlp_words) VOX_HIP(hipMemcpy(m->talker->mlp_words + 2, &spins, 4, hipMemcpyHostToDevice));
+    return VOX_OK;
+}
+// Test hook: in each of the next `count` launches of the chosen persistent kernel (0: depth step, 1: talker MLP half) block 1 withholds
+// its first publish, so the blocks waiting for it run into the poll bound — the failure a stalled block would cause.
+int vox_qwen3_persist_inject(vox_qwen3* m, int which, uint32_t count) {
+    if (!m || which < 0 || which > 1) return vox_fail(VOX_ERR_INVALID, "qwen3_persist_inject: bad arguments");
+    unsigned* words = which == 0 ? m->dstep_words : m->talker->mlp_words;
+    if (!words) return vox_fail(VOX_ERR_INVALID, "qwen3_persist_inject: that persistent kernel is not enabled");
+    VOX_HIP(hipDeviceSynchronize());
+    VOX_HIP(hipMemcpy(words + 3, &count, 4, hipMemcpyHostToDevice));
+    return VOX_OK;
+}
+
 void vox_qwen3_destroy(vox_qwen3* m) {
     if (!m) return;
     vox_stack_destroy(m->talker); vox_stack_destroy(m->depth);
     (void)hipFree(m->proj_tab); (void)hipFree(m->dstep_layers); (void)hipFree(m->dstep_gran); (void)hipFree(m->dstep_words);
+    (void)hipFree(m->shadow.rng); (void)hipFree(m->shadow.ids); (void)hipFree(m->shadow.mask); (void)hipFree(m->shadow.feat);
     for (void* p : {m->te, m->t1, m->text, m->x, m->depth_x, m->dx, m->dlogits, m->dkv, (void*)m->dmeta}) (void)hipFree(p);
     delete m;
 }
@@ -850,7 +969,7 @@ int vox_qwen3_frame(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int B, i
     if (!m || !io || !sc) return vox_fail(VOX_ERR_INVALID, "qwen3_frame: NULL");
     if (B < 1 || B > m->cfg.max_batch) return vox_fail(VOX_ERR_INVALID, "qwen3_frame: batch %d > max_batch", B);
     hipStream_t st = (hipStream_t)stream;
-    VOX_TRY(qwen3_embed(m, st, io->input_ids, io->input_masks, io->input_features, B));
+    VOX_TRY(qwen3_embed(m, st, io->input_ids, io->input_masks, io->input_features, B, (const uint64_t*)io->rng_offset));
     vox_rows r{};
     r.pos = io->pos; r.q_req = m->iota; r.q_kvlen = io->kvlen; r.page = io->page; r.slot = io->slot;
     r.kv_indptr = io->kv_indptr; r.kv_indices = io->kv_indices; r.n_rows = B; r.max_kvlen = max_kvlen;
@@ -1024,7 +1143,7 @@ static int csm_tail(vox_csm* m, hipStream_t st, const vox_csm_io* io, int B, con
     if (feedback)
         hipLaunchKernelGGL(k_csm_feedback, dim3(B), dim3(64), 0, st, io->out_ids, io->input_ids, io->input_masks, io->rng_offset, C1, B);
     else if (io->rng_offset)
-        hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, io->rng_offset);
+        hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, io->rng_offset, (int32_t*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr);
     return VOX_OK;
 }
 
@@ -1195,7 +1314,7 @@ static int lm_run(vox_lm* m, hipStream_t st, const vox_lm_io* io, const int32_t*
         hipLaunchKernelGGL(k_lm_feedback, dim3((n_req + 63) / 64), dim3(64), 0, st, io->out_ids, io->input_ids, c.ids_stride,
                            c.input_mode == 1 ? io->input_masks : nullptr, io->rng_offset, n_req);
     else if (io->rng_offset)
-        hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, io->rng_offset);
+        hipLaunchKernelGGL(k_rng_bump, dim3(1), dim3(1), 0, st, io->rng_offset, (int32_t*)nullptr, (const unsigned*)nullptr, (const unsigned*)nullptr);
     return VOX_OK;
 }
 

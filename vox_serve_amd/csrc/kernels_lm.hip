@@ -2895,7 +2895,7 @@ struct DepthStepArgs {
 #define VOX_DS_EXTRA_BARRIERS 1
 #endif
 template <int TOTAL>
-__device__ __forceinline__ void gran_gather_lds(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code) {
+__device__ __forceinline__ void gran_gather_lds(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins) {
     constexpr int NP = 64 * VOX_DS_PW, PER = (TOTAL + NP - 1) / NP;
     const int p = tid - (512 - NP);
     if (p < 0) return;
@@ -2911,7 +2911,7 @@ __device__ __forceinline__ void gran_gather_lds(const unsigned long long* g, uns
             }
         }
         if (ok) break;
-        if (spin > VOX_PERSIST_SPINS) { atomicCAS(err, 0u, code); break; }
+        if (spin > max_spins) { atomicCAS(err, 0u, code); break; }
         if ((spin & 63u) == 63u && __hip_atomic_load(err, VOX_RLX_AGENT) != 0u) break;      // somebody already gave up
         if (VOX_DS_SLEEP) __builtin_amdgcn_s_sleep(VOX_DS_SLEEP);
     }
@@ -2938,6 +2938,10 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
     // the compiler hoists some forty 64-bit row pointers out of the layer loop into vector registers and spills them)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
     const unsigned ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
+    // words [2], [3] beside the epoch: the bound of every poll loop (VOX_PERSIST_SPINS unless the host lowered it for a test) and the
+    // test hook "block 1 withholds its first publish of this launch" (vox_qwen3_persist_inject), read once per launch
+    const unsigned max_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);
+    const bool drop_first = blk == 1 && __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT) != 0u;
     const unsigned tag0 = ep * 64u;
     auto tagof = [&](int l, int st) { return tag0 + 1u + (unsigned)(l * 4 + st); };
     VOX_STAMP2_DECL
@@ -3007,7 +3011,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             const uint4* wor1 = wor0 + NQ / 8;
             const uint4 wo00 = wor0[0], wo01 = wor0[64], wo02 = wor0[128], wo03 = wor0[192];
             const uint4 wo10 = wor1[0], wo11 = wor1[64], wo12 = wor1[128], wo13 = wor1[192];
-            if (l > 0) gran_gather_lds<512>(a.gx, tagof(l - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x100u + l);
+            if (l > 0) gran_gather_lds<512>(a.gx, tagof(l - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x100u + l, max_spins);
             __syncthreads();                               // x of this layer is in xb
             uint4 xv[2];
 #pragma unroll
@@ -3027,7 +3031,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
                 for (int j = 0; j < 2; ++j) d = dot8(wq[r][j], xv[j], d);
                 acc[r] = butterfly<64>(d);
             }
-            if (lane == 0) gran_write(a.gqkv + pr, tagof(l, 0), f2bf(acc[0]), f2bf(acc[1]));
+            if (lane == 0 && !(drop_first && l == 0)) gran_write(a.gqkv + pr, tagof(l, 0), f2bf(acc[0]), f2bf(acc[1]));
             __builtin_amdgcn_sched_barrier(0);      // (stage B's requests stay below: hoisted above the parking they made the allocator spill these rows)
             if (wave < 2) {
                 wos[wave][0][0][lane] = wo00; wos[wave][0][1][lane] = wo01; wos[wave][0][2][lane] = wo02; wos[wave][0][3][lane] = wo03;
@@ -3046,7 +3050,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             const int hk = wave;
             AttnShortPre<NT> pf;
             attn_short_prefetch<NT>(at, 0, hk, lane, pf);
-            gran_gather_lds<2048>(a.gqkv, tagof(l, 0), reinterpret_cast<unsigned*>(qb), tid, a.err, 0x200u + l);
+            gran_gather_lds<2048>(a.gqkv, tagof(l, 0), reinterpret_cast<unsigned*>(qb), tid, a.err, 0x200u + l, max_spins);
             __syncthreads();                               // q | k | v in qb (and: every wave is done with xb's stage-A reads)
             VOX_STAMP2(2 + 6 * l)
             {
@@ -3094,7 +3098,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             // (xc's last readers, the previous layer's stage-D residual words, were done before this layer's stage-A barrier: the barrier
             // below is not needed for correctness — it parks the waves that have nothing to do in stage B's o_proj away from the poll loop)
             if (VOX_DS_EXTRA_BARRIERS) __syncthreads();
-            gran_gather_lds<512>(a.gx, tagof(l, 1), reinterpret_cast<unsigned*>(xc), tid, a.err, 0x400u + l);
+            gran_gather_lds<512>(a.gx, tagof(l, 1), reinterpret_cast<unsigned*>(xc), tid, a.err, 0x400u + l, max_spins);
             __syncthreads();
             if (wave < 6) {
                 uint4 xv[2];
@@ -3134,7 +3138,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
                     for (int j = 0; j < 6; ++j) wd[r][j] = wr[lane + 64 * j];
                 }
             }
-            gran_gather_lds<1536>(a.gh, tagof(l, 2), reinterpret_cast<unsigned*>(hb), tid, a.err, 0x600u + l);
+            gran_gather_lds<1536>(a.gh, tagof(l, 2), reinterpret_cast<unsigned*>(hb), tid, a.err, 0x600u + l, max_spins);
             __syncthreads();                               // h in hb (xc = x after attention: the residual of this stage)
             if (wave < 2) {
                 const unsigned resw = reinterpret_cast<const unsigned*>(xc)[pr];
@@ -3172,7 +3176,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) nwv[j] = reinterpret_cast<const uint4*>(a.final_norm)[lane + 64 * j];
         }
-        gran_gather_lds<512>(a.gx, tagof(a.n_layers - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x700u);
+        gran_gather_lds<512>(a.gx, tagof(a.n_layers - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x700u, max_spins);
         __syncthreads();
         if (wave < 4) {
             uint4 xv[2];
@@ -3198,6 +3202,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
     }
     VOX_STAMP2(31)
     if (blk == 0 && tid == 0) __hip_atomic_store(a.epoch, ep + 1u, VOX_RLX_AGENT);
+    if (drop_first && tid == 0) atomicSub(a.epoch + 3, 1u);
 }
 
 // ================================================================================================
@@ -3221,7 +3226,7 @@ struct TalkerMlpArgs {
     float eps;
 };
 template <int TOTAL>
-__device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code) {
+__device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins) {
     constexpr int PER = (TOTAL + 511) / 512;
     unsigned val[PER];
     for (unsigned spin = 0;; ++spin) {
@@ -3235,7 +3240,7 @@ __device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g,
             }
         }
         if (ok) break;
-        if (spin > VOX_PERSIST_SPINS) { atomicCAS(err, 0u, code); break; }
+        if (spin > max_spins) { atomicCAS(err, 0u, code); break; }
         if ((spin & 63u) == 63u && __hip_atomic_load(err, VOX_RLX_AGENT) != 0u) break;
     }
 #pragma unroll
@@ -3249,6 +3254,8 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 hb[F / 8];           // h
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
     const unsigned ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
+    const unsigned max_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);            // (as in k_depth_step)
+    const bool drop_first = blk == 1 && __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT) != 0u;
     const unsigned tag0 = ep * 64u;
     // ---- weights of stage C, first pair of every wave: requested at once (waves 4..7 have nothing else to do until x' arrives)
     const int p1 = blk * 12 + wave;                                     // 3072 pairs: 12 per block
@@ -3283,7 +3290,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         }
         if (lane == 0) {
             const bf16_t r0 = f2bf(bflo(resw) + bf2f(f2bf(acc[0]))), r1 = f2bf(bfhi(resw) + bf2f(f2bf(acc[1])));
-            gran_write(a.gx + pr, tag0 + 1u, r0, r1);
+            if (!drop_first) gran_write(a.gx + pr, tag0 + 1u, r0, r1);
         }
     }
     // ---------------- stage C: h = silu(Wg . n) * (Wu . n), n = rmsnorm(x', ln2) ----------------
@@ -3302,7 +3309,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         }
     }
     __syncthreads();                                   // (parks waves 4..7 until waves 0..3 have published their x' pairs)
-    gran_gather_lds_all<1024>(a.gx, tag0 + 1u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1100u);
+    gran_gather_lds_all<1024>(a.gx, tag0 + 1u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1100u, max_spins);
     __syncthreads();
     uint4 xv[4];
     {
@@ -3345,7 +3352,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
             }
         }
         __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish their second pair)
-        gran_gather_lds_all<3072>(a.gh, tag0 + 2u, reinterpret_cast<unsigned*>(hb), tid, a.err, 0x1200u);
+        gran_gather_lds_all<3072>(a.gh, tag0 + 2u, reinterpret_cast<unsigned*>(hb), tid, a.err, 0x1200u, max_spins);
         __syncthreads();
         if (wave < 4) {
             const unsigned resw = reinterpret_cast<const unsigned*>(xb)[pr];
@@ -3377,7 +3384,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) nw1[j] = reinterpret_cast<const uint4*>(a.ln1_next)[lane + 64 * j];
         __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish the down projection; xb is free)
-        gran_gather_lds_all<1024>(a.gx, tag0 + 3u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1300u);
+        gran_gather_lds_all<1024>(a.gx, tag0 + 3u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1300u, max_spins);
         __syncthreads();
         uint4 yv[4];
 #pragma unroll
@@ -3400,6 +3407,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         if (lane == 0) reinterpret_cast<unsigned*>(a.qkv_out)[pr] = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
     }
     if (blk == 0 && tid == 0) __hip_atomic_store(a.epoch, ep + 1u, VOX_RLX_AGENT);
+    if (drop_first && tid == 0) atomicSub(a.epoch + 3, 1u);
 }
 
 bool vox_talker_mlp_supported(const TalkerMlpCall& c) { return c.hidden == 2048 && c.nq == 2048 && c.ffn == 6144; }
@@ -3637,23 +3645,34 @@ int vox_launch_gather(hipStream_t st, const void* table, const int* ids, int id_
 // Qwen3 input mix (qwen3_tts.py:1836-1852): e = mask ? bf16(text + codec_emb[id0]) : text; y = bf16(e + feat)
 __global__ __launch_bounds__(256) void k_qwen3_mix(const bf16_t* text, const bf16_t* codec_table, const int* ids,
                                                    int id_stride, const uint8_t* mask, const bf16_t* feat, bf16_t* y,
-                                                   int H, int vocab) {
+                                                   int H, int vocab, Qwen3Shadow sh, const uint64_t* rng) {
     const int b = blockIdx.y;
     int id = ids[(size_t)b * id_stride];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const bool m = mask[b] != 0;
+    // decode frames of an engine with a status word: the row's inputs also go to the shadow slot of this frame (counter parity)
+    const size_t srow = sh.rng ? (size_t)(*rng & 1) * sh.max_batch + b : 0;
+    if (sh.rng && blockIdx.x == 0) {
+        for (int j = threadIdx.x; j < sh.G1; j += 256) sh.ids[srow * sh.G1 + j] = ids[(size_t)b * id_stride + j];
+        if (threadIdx.x == 0) sh.mask[srow] = mask[b];
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < H; i += gridDim.x * 256) {
         const size_t j = (size_t)b * H + i;
         bf16_t e = text[j];
         if (m) e = f2bf(bf2f(e) + bf2f(codec_table[(size_t)id * H + i]));
-        y[j] = f2bf(bf2f(e) + bf2f(feat[j]));
+        const bf16_t f = feat[j];
+        if (sh.rng) sh.feat[srow * H + i] = f;
+        y[j] = f2bf(bf2f(e) + bf2f(f));
     }
 }
 int vox_launch_qwen3_mix(hipStream_t st, const void* text, const void* codec_table, const int* ids, int id_stride,
-                         const uint8_t* mask, const void* feat, void* y, int B, int H, int vocab) {
+                         const uint8_t* mask, const void* feat, void* y, int B, int H, int vocab, const Qwen3Shadow* shadow,
+                         const uint64_t* rng) {
     if (B <= 0) return VOX_OK;
+    Qwen3Shadow sh{};
+    if (shadow && rng && shadow->rng && shadow->G1 == id_stride && shadow->H == H && B <= shadow->max_batch) sh = *shadow;
     hipLaunchKernelGGL(k_qwen3_mix, dim3((H + 255) / 256, B), dim3(256), 0, st, (const bf16_t*)text,
-                       (const bf16_t*)codec_table, ids, id_stride, mask, (const bf16_t*)feat, (bf16_t*)y, H, vocab);
+                       (const bf16_t*)codec_table, ids, id_stride, mask, (const bf16_t*)feat, (bf16_t*)y, H, vocab, sh, rng);
     return VOX_OK;
 }
 

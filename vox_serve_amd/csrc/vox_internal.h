@@ -159,8 +159,17 @@ int vox_launch_attn_merge(hipStream_t st, const float* part_o, const float* part
                           int Nq, int Hq, int D, int max_chunks, void* out_frag = nullptr);
 int vox_launch_gather(hipStream_t st, const void* table, const int* ids, int id_stride, int id_off, void* dst,
                       long dst_stride, int B, int H, int vocab);
+// shadow of a decode frame's inputs, two slots (engine.hip: vox_qwen3_set_status / vox_qwen3_frame_restore)
+struct Qwen3Shadow {
+    uint64_t* rng = nullptr;     // [2]
+    int32_t* ids = nullptr;      // [2][max_batch][G1]
+    uint8_t* mask = nullptr;     // [2][max_batch]
+    bf16_t* feat = nullptr;      // [2][max_batch][H]
+    int G1 = 0, H = 0, max_batch = 0;
+};
 int vox_launch_qwen3_mix(hipStream_t st, const void* text, const void* codec_table, const int* ids, int id_stride,
-                         const uint8_t* mask, const void* feat, void* y, int B, int H, int vocab);
+                         const uint8_t* mask, const void* feat, void* y, int B, int H, int vocab,
+                         const Qwen3Shadow* shadow = nullptr, const uint64_t* rng = nullptr);
 int vox_launch_kv_append(hipStream_t st, void* kv, const void* k, const void* v, const int* page, const int* slot,
                          int N, int page_size, int Hkv, int D);
 

@@ -149,7 +149,16 @@ class Qwen3Engine:
         self.plan_dev = torch.zeros(off, **i32)
         self._init_plan_host(off)
         self.kv = torch.zeros(t.layers, max_pages, 2, page_size, t.kv_heads, t.head_dim, dtype=torch.bfloat16, device=dev)
-        self.out_ids = torch.zeros(max_batch, G1, **i32)
+        # row 0 of this block is the frame's STATUS row (word 0: error code of the persistent kernels, written by the frame's last
+        # kernel), rows 1.. are out_ids: the host's one D2H copy per frame (`read_ids` / `snapshot_src`) brings both, so a hand-off
+        # timeout is seen in the same frame (include/voxhip.h: vox_qwen3_set_status)
+        self._out_block = torch.zeros(max_batch + 1, G1, **i32)
+        self.out_ids = self._out_block[1:]
+        self.status_row = self._out_block[0]
+        N.check(self.L.vox_qwen3_set_status(self.h, self.status_row.data_ptr()))
+        self._launch_log = []             # the last two launches (frame / prefill + arguments + plan block): what `recover` replays
+        self.launch_seq = 0
+        self.persist_failures = []        # (launch_seq, error code) of every hand-off timeout seen (and recovered from)
         self.out_logits = torch.zeros(max_batch, cfg.vocab, dtype=torch.bfloat16, device=dev)
         self.out_hidden = torch.zeros(max_batch, H, dtype=torch.bfloat16, device=dev)
         self.out_depth_logits = (torch.zeros(G - 1, max_batch, cfg.depth_vocab, dtype=torch.bfloat16, device=dev)
@@ -222,6 +231,10 @@ class Qwen3Engine:
                     last[b] = row.copy()
         k = self._plan_k
         self._plan_k = (k + 1) % self.PLAN_RING
+        self._plan_gen = getattr(self, "_plan_gen", 0) + 1
+        self._plan_slot_gen = getattr(self, "_plan_slot_gen", [0] * self.PLAN_RING)
+        self._plan_slot_gen[k] = self._plan_gen
+        self._plan_last = (k, self._plan_gen)
         if self._plan_ev[k] is not None:
             self._plan_ev[k].synchronize()          # PLAN_RING uploads ago: long done
         self._plan_pin_np[k][:] = hv
@@ -246,6 +259,7 @@ class Qwen3Engine:
                              float(min_p or 0.0), float(temperature), 1.0)
 
     # ---- one frame ---------------------------------------------------------------------------------
+    launch_seq = 0            # launches enqueued so far (frames + prefills); engines without a status row only count
     max_graphs = 512          # frame graphs kept (batch x kv bucket x sampling); the oldest goes first.  Prefill graphs: own LRU (_prefill_graph)
 
     def frame(self, batch, max_kvlen, sampling=None, seed=0, feedback=True, use_graph=True):
@@ -255,8 +269,90 @@ class Qwen3Engine:
         bucket = min(bucket, self.max_seq_len)
         if max_kvlen > bucket:
             raise N.VoxError(f"kv length {max_kvlen} exceeds max_seq_len {self.max_seq_len}")
+        self._log_launch("frame", (batch, max_kvlen, sampling, seed, feedback, use_graph), batch)
         with self._OnStream(self):
             self._frame_on_stream(batch, bucket, sampling, seed, feedback, use_graph)
+
+    # ---- fail loud within one frame, recover bit-identically -------------------------------------------
+    def _log_launch(self, kind, args, rows):
+        if getattr(self, "_replaying", False):
+            return
+        self.launch_seq += 1
+        if not hasattr(self, "status_row"):
+            return
+        self._launch_log.append({"seq": self.launch_seq, "kind": kind, "args": args, "rows": rows, "plan": getattr(self, "_plan_last", None),
+                                 "restaged": self.__dict__.pop("_restaged", False)})
+        del self._launch_log[:-2]
+
+    def note_restage(self):
+        """The caller rewrote input_ids / input_masks / input_features by hand (batch composition changed): the NEXT launch does
+        not start from the previous launch's feedback, so it cannot be replayed behind it."""
+        self._restaged = True
+
+    def snapshot_src(self, batch):
+        """What the host copies per frame: the status row + out_ids[:batch] — one contiguous D2H."""
+        return self._out_block[: batch + 1]
+
+    def read_ids(self, batch):
+        """out_ids[:batch] on the host (int64) through ONE blocking D2H that also brings the frame's status word; a hand-off timeout
+        of the persistent kernels is recovered from here (the frame re-run on the launch chain, bit-identical) before the ids are returned."""
+        if not hasattr(self, "status_row"):
+            return self.out_ids[:batch].cpu().to(torch.long)
+        blk = self.snapshot_src(batch).cpu()
+        if int(blk[0, 0]) != 0:
+            self.recover(1, code=int(blk[0, 0]))
+            blk = self.snapshot_src(batch).cpu()
+            if int(blk[0, 0]) != 0:
+                raise N.VoxError(f"persistent kernels: status {int(blk[0, 0]):#x} after recovery")
+        return blk[1:].to(torch.long)
+
+    def _drop_graphs(self):
+        torch.cuda.synchronize()
+        for g in list(self._graphs.values()) + [g for g in self.__dict__.get("_pf_graphs", {}).values() if g]:
+            self.L.vox_graph_destroy(g)
+        self._graphs.clear()
+        self.__dict__.get("_pf_graphs", {}).clear()
+
+    def recover(self, back=1, code=0, on_first_done=None):
+        """A hand-off of a persistent kernel timed out in the launch `back` launches ago (1 = the last one; 2 = one more launch was
+        already enqueued behind it — async scheduling): everything since is garbage.  Wait for the device, turn the persistent kernels
+        off for this engine (the launch chains are bit-identical), drop the graphs that hold them, put the failed launch's inputs
+        back from the shadow, re-upload its plan and run it again — then (back = 2) the launch behind it, which starts from the
+        first one's feedback.  `on_first_done()` is called between the two (the caller re-reads the first launch's outputs).
+        Raises when a launch cannot be replayed (its plan block was overwritten, or the caller restaged the inputs in between)."""
+        import logging
+        torch.cuda.synchronize()
+        log = self._launch_log[-back:]
+        if len(log) < back:
+            raise N.VoxError(f"persistent kernels: hand-off timeout (code {code:#x}) and no record of the launch to replay")
+        logging.getLogger(__name__).error("persistent kernels: a hand-off timed out (code %#x) in launch %d; switching this engine to the "
+                                          "launch chains and replaying %d launch(es)", code, log[0]["seq"], back)
+        self.persist_failures.append((log[0]["seq"], code))
+        N.check(self.L.vox_qwen3_persist_reset(self.h, 1))
+        self._drop_graphs()
+        for ent in log[1:]:
+            if ent["restaged"]:
+                raise N.VoxError("persistent kernels: hand-off timeout; the launch behind it had restaged inputs and cannot be replayed")
+        io = self._io()
+        first = log[0]
+        N.check(self.L.vox_qwen3_frame_restore(self.h, N.stream(), ctypes.byref(io), back, first["rows"] if first["kind"] == "frame" else 0))
+        torch.cuda.synchronize()
+        if int(self.status_row[0].item()) != 0:
+            raise N.VoxError("persistent kernels: hand-off timeout and the failed launch's inputs are not in the shadow")
+        self._replaying = True
+        try:
+            for i, ent in enumerate(log):
+                if ent["plan"] is not None:
+                    k, gen = ent["plan"]
+                    if self._plan_slot_gen[k] != gen:
+                        raise N.VoxError("persistent kernels: hand-off timeout; the plan block of the launch to replay was overwritten")
+                    self.plan_dev.copy_(self._plan_pin[k], non_blocking=True)
+                getattr(self, ent["kind"])(*ent["args"])
+                torch.cuda.synchronize()
+                if i == 0 and on_first_done is not None:
+                    on_first_done()
+        finally:
+            self._replaying = False
 
     def _frame_on_stream(self, batch, bucket, sampling, seed, feedback, use_graph):
         if not use_graph:
@@ -265,15 +361,8 @@ class Qwen3Engine:
             return
         key = (batch, bucket, bytes(sampling), seed, bool(feedback), self.keep_hidden)
         g = self._graphs.get(key)
-        # persistent depth steps: their bounded spins turn a stuck hand-off into wrong data + an error word, never a hang; look at
-        # the word now and then (a device synchronisation: every 512th one-request frame) and fail loudly
-        if batch == 1 and hasattr(self.L, "vox_qwen3_depth_persist_status") and type(self) is Qwen3Engine:
-            self._persist_frames = getattr(self, "_persist_frames", 0) + 1
-            if self._persist_frames % 512 == 0:
-                en, err = self.depth_persist_status()
-                if en and err:
-                    raise N.VoxError(f"persistent depth step: a hand-off timed out (code {err:#x}); results since are invalid "
-                                     "(VOX_DEPTH_PERSIST=0 selects the launch chain)")
+        # (persistent kernels: their bounded spins turn a stuck hand-off into wrong data + an error word, never a hang; the word
+        # travels with every frame's token snapshot — read_ids / snapshot_src — and `recover` replays the frame on the launch chain)
         if g is None:
             io = self._io()
             st = N.stream()
@@ -301,6 +390,7 @@ class Qwen3Engine:
         buckets up front, cuda_graph_worker.py:206-352; here every buffer of the call sits at a fixed address, so the exact
         shape can be captured without padding and without changing which kernels — hence which bits — a prompt gets)."""
         sampling = sampling or self.sampling_cfg()
+        self._log_launch("prefill", (n_rows, n_req, max_kvlen, sampling, seed, feedback, use_graph), n_req)
         with self._OnStream(self):
             if not use_graph:
                 return self._prefill_on_stream(n_rows, n_req, max_kvlen, sampling, seed, feedback)

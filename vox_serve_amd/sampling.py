@@ -45,6 +45,47 @@ def native_config(config: SamplingConfig) -> N.SamplingCfg:
                          float(config.temperature if not greedy else 1.0), 1.0)
 
 
+def _sample(logits: torch.Tensor, nc: N.SamplingCfg) -> torch.Tensor:
+    """One on-device sampler call over the rows of `logits` [..., V] (vox_sample); ids shaped like logits.shape[:-1]."""
+    lead, v = logits.shape[:-1], logits.shape[-1]
+    lg = logits.reshape(-1, v).contiguous()
+    if lg.dtype != torch.bfloat16:
+        lg = lg.to(torch.bfloat16)
+    out = torch.empty(lg.shape[0], dtype=torch.int32, device=lg.device)
+    N.check(N.lib().vox_sample(N.ctx(), N.stream(), N.ptr(lg), lg.shape[0], v, nc, Sampler.seed, next(Sampler._offset), N.ptr(out)))
+    return (out.long() if nc.greedy else out).reshape(lead)
+
+
+# Module-level helpers of the reference (sampling.py:21-80: thin wrappers that `Sampler.run_sampling` dispatches to; nothing else in
+# the reference imports them, they are here so that the module is a drop-in symbol for symbol).  Same arguments; the stochastic ones
+# draw from the seeded Philox stream of `Sampler` (manual_seed), their support set and probabilities follow flashinfer's contract.
+def greedy_sampling(logits):
+    """sampling.py:21-27: index of the (first) maximum logit, int64."""
+    return _sample(logits, N.SamplingCfg(1, 0, 1.0, 0.0, 1.0, 1.0))
+
+
+def top_k_sampling(logits, top_k, temperature):
+    """sampling.py:30-40."""
+    return _sample(logits, N.SamplingCfg(0, int(top_k), 1.0, 0.0, float(temperature), 1.0))
+
+
+def top_p_sampling(logits, top_p, temperature):
+    """sampling.py:43-53."""
+    return _sample(logits, N.SamplingCfg(0, 0, float(top_p), 0.0, float(temperature), 1.0))
+
+
+def top_k_top_p_sampling(logits, top_k, top_p, temperature, filter_apply_order="top_k_first"):
+    """sampling.py:56-67 (the reference only ever passes "top_k_first": top-p renormalised inside the top-k set)."""
+    if filter_apply_order != "top_k_first":
+        raise NotImplementedError("filter_apply_order='joint' is not part of the serving path (sampling.py:56 default only)")
+    return _sample(logits, N.SamplingCfg(0, int(top_k), float(top_p), 0.0, float(temperature), 1.0))
+
+
+def min_p_sampling(logits, min_p, temperature):
+    """sampling.py:70-80."""
+    return _sample(logits, N.SamplingCfg(0, 0, 1.0, float(min_p), float(temperature), 1.0))
+
+
 class Sampler:
     seed = 0
     _offset = itertools.count()

@@ -372,6 +372,8 @@ class ModelWorker:
         self.nvtx_range_push(f"lm_decode_bs{B}")
         ids = [r.request_id for r in requests]
         if self._resident != ids:        # batch composition changed: restage the per-request inputs
+            if hasattr(e, "note_restage"):
+                e.note_restage()
             e.input_ids[:B].copy_(lm_inputs["input_ids"].to(torch.int32))
             if lm_inputs["input_masks"] is not None:
                 mk = lm_inputs["input_masks"] if e.input_masks.dim() == 2 else lm_inputs["input_masks"][:, -1]
@@ -403,18 +405,28 @@ class ModelWorker:
             return None
         e, B = self.model.engine, len(requests)
         self.drain()                                   # at most one step in flight behind the one being launched
+        # engines with a status row (Qwen3-TTS: persistent kernels) ship it with the ids: row 0 of the snapshot is the frame's status
+        with_status = hasattr(e, "snapshot_src")
         if self._snap is None:
-            mk = lambda: {"ids": torch.zeros_like(e.out_ids, device="cpu").pin_memory(),
+            mk = lambda: {"ids": torch.zeros(e.out_ids.shape[0] + 1, *e.out_ids.shape[1:], dtype=e.out_ids.dtype).pin_memory(),
                           "feats": torch.zeros_like(e.next_features) if getattr(e, "next_features", None) is not None else None,
                           "event": torch.cuda.Event()}
             self._snap = [mk(), mk()]
         snap = self._snap[self._snap_i]
         self._snap_i ^= 1
-        with e._OnStream(e):
-            snap["ids"][:B].copy_(e.out_ids[:B], non_blocking=True)
-            if snap["feats"] is not None:
-                snap["feats"][:B].copy_(e.next_features[:B])
-            snap["event"].record()
+
+        def take_snapshot():
+            with e._OnStream(e):
+                if with_status:
+                    snap["ids"][:B + 1].copy_(e.snapshot_src(B), non_blocking=True)
+                else:
+                    snap["ids"][0].zero_()
+                    snap["ids"][1:B + 1].copy_(e.out_ids[:B], non_blocking=True)
+                if snap["feats"] is not None:
+                    snap["feats"][:B].copy_(e.next_features[:B])
+                snap["event"].record()
+        take_snapshot()
+        snap_seq = getattr(e, "launch_seq", 0)
         self._resident = [r.request_id for r in requests]
         self._resident_reqs = list(requests)
         positions = [r.next_position_id for r in requests]      # as of this step (the next step's prepare advances them)
@@ -425,7 +437,14 @@ class ModelWorker:
                 return
             state["done"] = True
             snap["event"].synchronize()
-            self._after_frame(requests, out=snap["ids"][:B].to(torch.long), feats=snap["feats"], positions=positions)
+            if int(snap["ids"][0].view(-1)[0]) != 0:
+                # a hand-off of the persistent kernels timed out in THIS step: replay it on the launch chain (and the step already
+                # enqueued behind it, if any), re-reading this step's outputs in between — the stream the clients get is unchanged
+                e.recover(back=e.launch_seq - snap_seq + 1, code=int(snap["ids"][0].view(-1)[0]), on_first_done=take_snapshot)
+                snap["event"].synchronize()
+                if int(snap["ids"][0].view(-1)[0]) != 0:
+                    raise RuntimeError("persistent kernels: status still set after recovery")
+            self._after_frame(requests, out=snap["ids"][1:B + 1].to(torch.long), feats=snap["feats"], positions=positions)
             if self._pending is finish:
                 self._pending = None
         self._pending = finish
@@ -460,7 +479,9 @@ class ModelWorker:
         e, m = self.model.engine, self.model
         B = len(requests)
         if out is None:
-            out = e.out_ids[:B].cpu().to(torch.long)                  # the one synchronisation of the step
+            # the one synchronisation of the step (engines with a status row: it travels with the ids, and a hand-off timeout of the
+            # persistent kernels is recovered from inside read_ids before anything is handed to the requests)
+            out = e.read_ids(B) if hasattr(e, "read_ids") else e.out_ids[:B].cpu().to(torch.long)
             self._resident = [r.request_id for r in requests]
             self._resident_reqs = list(requests)
         t0 = time.perf_counter()
