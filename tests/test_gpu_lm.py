@@ -258,6 +258,19 @@ def case_glm_full_width_b8_er8(tape, dev):
     run_parity(dev, "glm", glm_full_width_cfg(), _GLM_FULL, _GLM_LENS, 2, page=128, max_pages=16, policy=Policy(exact_rows=8), tape=tape)
 
 
+def glm_full_depth_cfg():
+    return LR.glm_cfg(layers=40, max_pos=512)
+
+
+# the WHOLE GLM-4-Voice-9B stack: 40 layers at full width + both 168960 x 4096 tables (9.4 G parameters: 19 GB of bf16 on either side)
+_GLM_DEPTH = Weights(lambda device=None: LR.random_glm_state_dict(glm_full_depth_cfg(), seed=1, std=0.02, device=device))
+
+
+@taped("glm_full_depth_b8")
+def case_glm_full_depth_b8(tape, dev):
+    run_parity(dev, "glm", glm_full_depth_cfg(), _GLM_DEPTH, [1, 2, 1, 2, 1, 2, 1, 2], 1, page=128, max_pages=16, tape=tape)
+
+
 @taped("cosyvoice2_full_size_top_k")
 def case_cosyvoice2_full_size(tape, dev):
     cfg = LR.cosyvoice2_cfg(max_pos=512)
@@ -285,6 +298,18 @@ def test_glm_full_width_b8_both_settings(dev):
         case_glm_full_width_b8_er8(Tape.open("glm_full_width_b8_exact_rows_8"), dev)
     finally:
         N.set_exact_rows(2)
+
+
+@pytest.mark.slow
+def test_glm_full_depth_b8(dev):
+    """Round-4 review, parity tail: GLM-4-Voice-9B at its FULL depth — all 40 layers, 4096 wide, FFN 13696, the 168960-entry tables —
+    at BASELINE config 4's per-GPU share of 8 requests: eight one- and two-token prefills and one 8-row decode frame through the
+    40-layer stack (normalise-once + full-K GEMMs at K = 4096, the streamed K = 13696 down projection, 16-head-group attention),
+    logits / greedy ids / fed-back ids / the K/V cache of all 40 layers bit-exact against the oracle's tape (the 2-of-40-layer
+    cases above cover sampling modes and longer prompts; this one covers depth: error that only accumulates over 40 layers)."""
+    case_glm_full_depth_b8(Tape.open("glm_full_depth_b8"), dev)
+    _GLM_DEPTH.drop_torch()          # (19 GB of weights: not kept for the rest of the session)
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.slow
