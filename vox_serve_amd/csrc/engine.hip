@@ -250,6 +250,7 @@ struct vox_stack {
     void* mlp_gran = nullptr;
     unsigned* mlp_words = nullptr;
     int mlp_persist = 0;
+    int mlp_attn = 0;       // ... and the layer's decode attention inside that launch (VOX_TALKER_ATTN=0: its own launch in front)
 };
 
 // decode_rows: every row is the newest token of a distinct request (its K/V are not read by any other row), so the
@@ -351,7 +352,9 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
         if (decode_rows && c.max_kvlen <= 16 && !(ablate() & 256) && vox_attn1_linear_supported(ac, o)) {
             VOX_TRY(vox_launch_attn1_linear(st, ac, o));     // short context: attention recomputed inside o_proj
         } else {
-            if (ablate() & 1) {
+            // one request, <= 256 visible tokens: the attention runs INSIDE the persistent launch of the layer's MLP half (blocks 0..15)
+            const bool attn_in = decode_rows && n == 1 && s->mlp_persist && s->mlp_attn && !ablate() && vox_talker_attn_supported(ac);
+            if ((ablate() & 1) || attn_in) {
             } else if (decode_rows && c.max_kvlen <= 16 && !(ablate() & 512) && vox_attn_short_supported(ac)) {
                 VOX_TRY(vox_launch_attn_short(st, ac));      // one wave per (row, kv head), registers only
             } else if (decode_rows && !(ablate() & 1024) && vox_attn_decode8_supported(ac)) {
@@ -366,6 +369,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
                 tm.wo = w.wo; tm.wgate = w.wgate; tm.wup = w.wup; tm.wdown = w.wdown; tm.ln2 = w.ln2; tm.attn = s->attn_out; tm.x = x;
                 tm.gran = s->mlp_gran; tm.epoch = s->mlp_words; tm.err = s->mlp_words + 1; tm.eps = c.eps;
                 tm.hidden = c.hidden; tm.nq = nq; tm.ffn = c.ffn;
+                if (attn_in) tm.attn_call = &ac;
                 if (l + 1 < c.layers && nqkv == 4096 && !s->layers[l + 1].bqkv) {      // ... and the next layer's q | k | v projection
                     tm.wqkv_next = s->layers[l + 1].wqkv; tm.ln1_next = s->layers[l + 1].ln1; tm.qkv_out = s->qkv; tm.nqkv = nqkv;
                     qkv_done = true;
@@ -457,12 +461,14 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
         (void)hipGetDevice(&dev_id);
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
         if (want && n_cu >= 256 && vox_talker_mlp_supported(probe) && !s->cfg.qkv_bias) {
-            if (hipMalloc(&s->mlp_gran, 4096 * 8) != hipSuccess || hipMalloc((void**)&s->mlp_words, 16) != hipSuccess)
+            if (hipMalloc(&s->mlp_gran, 5120 * 8) != hipSuccess || hipMalloc((void**)&s->mlp_words, 16) != hipSuccess)
                 return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc");
-            VOX_HIP(hipMemset(s->mlp_gran, 0, 4096 * 8));
+            VOX_HIP(hipMemset(s->mlp_gran, 0, 5120 * 8));
             const unsigned words[4] = {1u, 0u, vox_persist_spins_default(), 0u};      // epoch, error, poll bound, test hook
             VOX_HIP(hipMemcpy(s->mlp_words, words, 16, hipMemcpyHostToDevice));
             s->mlp_persist = 1;
+            const char* ea = getenv("VOX_TALKER_ATTN");
+            s->mlp_attn = !(ea && ea[0] == '0') && s->cfg.heads == 16 && s->cfg.kv_heads == 8 && s->cfg.head_dim == 128;
         }
     }
     *out = s;
@@ -908,17 +914,17 @@ int vox_qwen3_frame_restore(vox_qwen3* m, void* stream, const vox_qwen3_io* io, 
 int vox_qwen3_persist_reset(vox_qwen3* m, int disable) {
     if (!m) return vox_fail(VOX_ERR_INVALID, "qwen3_persist_reset: NULL");
     VOX_HIP(hipDeviceSynchronize());
-    auto reset = [](unsigned* words, void* gran) -> hipError_t {
+    auto reset = [](unsigned* words, void* gran, size_t n_gran) -> hipError_t {
         if (!words) return hipSuccess;
         unsigned w[4];
         hipError_t e = hipMemcpy(w, words, 16, hipMemcpyDeviceToHost);
         if (e != hipSuccess) return e;
         w[0] += 1u; w[1] = 0u; w[3] = 0u;
         if ((e = hipMemcpy(words, w, 16, hipMemcpyHostToDevice)) != hipSuccess) return e;
-        return hipMemset(gran, 0, 4096 * 8);
+        return hipMemset(gran, 0, n_gran * 8);
     };
-    VOX_HIP(reset(m->dstep_words, m->dstep_gran));
-    VOX_HIP(reset(m->talker->mlp_words, m->talker->mlp_gran));
+    VOX_HIP(reset(m->dstep_words, m->dstep_gran, 4096));
+    VOX_HIP(reset(m->talker->mlp_words, m->talker->mlp_gran, 5120));
     if (disable) { m->dstep = 0; m->talker->mlp_persist = 0; }
     return VOX_OK;
 }

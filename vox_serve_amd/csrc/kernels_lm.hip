@@ -3215,6 +3215,211 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
 //   stage O  x'  = x + Wo . attn                                  1024 column pairs: waves 0..3
 //   stage C  h   = silu(Wg . n) * (Wu . n),  n = rmsnorm(x', ln2)  3072 pairs: every wave one, waves 0..3 a second one
 //   stage D  x'' = x' + Wd . h                                    1024 pairs: waves 0..3, plain stores (a kernel boundary follows)
+// ================================================================================================
+// The one-launch decode attention (k_attn_decode8's arithmetic, chunk by chunk and merge, bit for bit) as a device function for a
+// block of NT threads inside a persistent kernel: NG groups of NT / NG threads (512 threads, 8 chunks: one wave per chunk), LDS in
+// the caller's AttnDecodeSmem, the result published as hand-off granules instead of stored.  Per (row, q head) the order of every
+// sum is the launch's own: which threads carry a chunk does not enter the arithmetic.
+// ================================================================================================
+template <int D, int GMAX, int NG, int NCH, int NT>
+struct AttnDecodeSmem {
+    static constexpr int LPT = D / 8;
+    uint4 Ks[NG][VOX_TC * LPT];
+    uint4 Vs[NG][VOX_TC * LPT];
+    uint4 Qs[GMAX * LPT];
+    float S[NG][GMAX][VOX_TC];
+    float Ms[NG][GMAX];
+    float Sh[(NT / 64) * D];
+    bf16_t Knew[D];
+    float Po[NCH][GMAX][D];
+    float2 Pml[NCH][GMAX];
+    float Wm[NCH][GMAX];
+};
+template <int D, int GMAX, int NG, int NCH, int NT, typename AfterPark>
+__device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecodeSmem<D, GMAX, NG, NCH, NT>& sm, int HS, int hk, int hs, int row,
+                                                    unsigned long long* gout, unsigned gtag, bool skip_publish, AfterPark after_park) {
+    constexpr int LPT = D / 8, TPW = 64 / LPT, GT = NT / NG, GW = GT / 64, CPG = NCH / NG;
+    constexpr int KVL = (VOX_TC * LPT + GT - 1) / GT;
+    constexpr bool QREG = GMAX <= 2;
+    static_assert(GT % 64 == 0 && GW >= 1, "a group is whole waves");
+    const int tid = threadIdx.x, lane = tid & 63, wave16 = tid >> 6;
+    const int grp = tid / GT, gt = tid % GT, gw = wave16 % GW;
+    const int* pages = a.identity_pages ? nullptr
+                       : (a.ptab ? a.ptab + (size_t)row * a.pt_stride : a.indices + a.indptr[a.q_req[row]]);
+    // per-row page table: the page ids of this thread's tokens do not depend on the row's length, so they are requested
+    // together with it (one exposed round trip in front of the K/V loads instead of two); entries past the row's last page are
+    // read (clamped to the table row) and never used
+    int pgi_pre[CPG][KVL];
+    const bool hoist = a.ptab && a.hoist;
+    if (hoist) {
+#pragma unroll
+        for (int ci = 0; ci < CPG; ++ci)
+#pragma unroll
+            for (int u = 0; u < KVL; ++u) {
+                const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT;
+                const int pi = tok / a.page_size;
+                pgi_pre[ci][u] = pages[pi < a.pt_stride ? pi : a.pt_stride - 1];
+            }
+    }
+    const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
+    const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..NCH
+    const int Gf = a.Hq / a.Hkv, G = Gf / HS, g0 = hs * G;
+    const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
+    const int nqkv = (a.Hq + 2 * a.Hkv) * D;
+    const bf16_t* raw = a.qkv + (size_t)row * nqkv;
+
+    // K/V tiles of this group's chunks.  The row's newest token (index L - 1) comes from the projection output: its V row is
+    // loaded into the tile here, its K row (per-head norm + RoPE below) is read from Knew by the score pass.
+    uint4 kreg[KVL], vreg[KVL];
+    auto fetch_tile = [&](int ci) {
+        const int t0 = (grp + NG * ci) * VOX_TC;
+#pragma unroll
+        for (int u = 0; u < KVL; ++u) {
+            const int i = gt + GT * u, t = i / LPT, j = i % LPT;
+            kreg[u] = make_uint4(0, 0, 0, 0);
+            vreg[u] = kreg[u];
+            const int tok = t0 + t;
+            if (i < VOX_TC * LPT && tok < L - 1) {
+                const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[tok / a.page_size] : row);
+                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
+                kreg[u] = reinterpret_cast<const uint4*>(base)[j];
+                vreg[u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
+            } else if (i < VOX_TC * LPT && tok == L - 1) {
+                vreg[u] = reinterpret_cast<const uint4*>(raw + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D)[j];
+            }
+        }
+    };
+    fetch_tile(0);
+    {   // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave
+        int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
+        p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
+        const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
+        for (int h = wave16; h < G + 1; h += NT / 64) {
+            const bool isk = h == G;
+            const bf16_t* src = isk ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * Gf + g0 + h) * D;
+            bf16_t* dst = isk ? sm.Knew : reinterpret_cast<bf16_t*>(sm.Qs) + (size_t)h * D;
+            prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, sm.Sh + wave16 * D, dst, lane);
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CPG; ++ci) {
+        const int c = grp + NG * ci, t0 = c * VOX_TC;
+        const bool live = t0 < L;
+        const int nt = live ? ((L - t0) < VOX_TC ? (L - t0) : VOX_TC) : 0;
+        const bool own_last = live && (t0 + nt == L);
+        if (ci > 0) __syncthreads();           // the previous chunk's tile is dead
+#pragma unroll
+        for (int u = 0; u < KVL; ++u) {
+            const int i = gt + GT * u;
+            if (i < VOX_TC * LPT) { sm.Ks[grp][i] = kreg[u]; sm.Vs[grp][i] = vreg[u]; }
+        }
+        if (ci + 1 < CPG) fetch_tile(ci + 1);  // in flight during this chunk's arithmetic
+        __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
+        if (ci == 0) after_park();             // the caller's own loads: nothing of the attention waits behind them any more
+        if (own_last && hs == 0 && gt < LPT) {
+            // append the new token to the paged cache (page < 0: graph padding row)
+            const int pg = a.identity_pages ? row : a.page[row];
+            const int sl = a.identity_pages ? (L - 1) : a.slot[row];
+            if (pg >= 0) {
+                bf16_t* base = a.kv_w + (size_t)pg * ps + ((size_t)sl * a.Hkv + hk) * D;
+                reinterpret_cast<uint4*>(base)[gt] = reinterpret_cast<const uint4*>(sm.Knew)[gt];
+                reinterpret_cast<uint4*>(base + (size_t)a.page_size * a.Hkv * D)[gt] = sm.Vs[grp][(nt - 1) * LPT + gt];
+            }
+        }
+        if (live) {      // scores: LPT lanes per token, butterfly over LPT lanes; the token's K chunk is unpacked once for all q heads
+            const int j = lane % LPT;
+            float qf[QREG ? GMAX : 1][8];
+            if constexpr (QREG) {
+#pragma unroll
+                for (int g = 0; g < GMAX; ++g) {
+                    const uint4 qx = sm.Qs[(g < G ? g : 0) * LPT + j];
+                    qf[g][0] = bflo(qx.x); qf[g][1] = bfhi(qx.x); qf[g][2] = bflo(qx.y); qf[g][3] = bfhi(qx.y);
+                    qf[g][4] = bflo(qx.z); qf[g][5] = bfhi(qx.z); qf[g][6] = bflo(qx.w); qf[g][7] = bfhi(qx.w);
+                }
+            }
+#pragma unroll
+            for (int tb = gw * TPW; tb < VOX_TC; tb += GW * TPW) {
+                const int tt = tb + lane / LPT;
+                const uint4 kx = (own_last && tt == nt - 1) ? reinterpret_cast<const uint4*>(sm.Knew)[j] : sm.Ks[grp][tt * LPT + j];
+                if constexpr (QREG) {
+                    const float kf[8] = {bflo(kx.x), bfhi(kx.x), bflo(kx.y), bfhi(kx.y), bflo(kx.z), bfhi(kx.z), bflo(kx.w), bfhi(kx.w)};
+#pragma unroll
+                    for (int g = 0; g < GMAX; ++g) {
+                        float d = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d = __fmaf_rn(qf[g][e], kf[e], d);
+                        d = butterfly<LPT>(d);
+                        if (j == 0 && g < G) sm.S[grp][g][tt] = d * a.scale;
+                    }
+                } else {
+                    for (int g = 0; g < G; ++g) {
+                        float d = dot8(sm.Qs[g * LPT + j], kx, 0.0f);
+                        d = butterfly<LPT>(d);
+                        if (j == 0) sm.S[grp][g][tt] = d * a.scale;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {      // chunk max + p = exp2((s-m)*log2e): 32 lanes per q head
+            for (int pr = gt; pr < G * VOX_TC; pr += GT) {
+                const int g = pr / VOX_TC, t = pr % VOX_TC;
+                const float s = t < nt ? sm.S[grp][g][t] : -INFINITY;
+                float m = s;
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, VOX_WAVE));
+                const float p = t < nt ? exp2_c((s - m) * VOX_LOG2E) : 0.0f;
+                sm.S[grp][g][t] = p;
+                if (t == 0) sm.Ms[grp][g] = m;
+            }
+        }
+        __syncthreads();
+        if (live) {      // PV: one thread per (q head, pair of dims); sequential over the tokens of the (zero-padded) tile
+            const u32* Vw = reinterpret_cast<const u32*>(sm.Vs[grp]);
+            for (int e = gt; e < G * (D / 2); e += GT) {
+                const int g = e / (D / 2), dp = e % (D / 2);
+                float o0 = 0.0f, o1 = 0.0f, l = 0.0f;
+#pragma unroll(NCH == 8 ? VOX_TC : 8)                      // (beside an in-flight tile the full unroll's operand registers would spill)
+                for (int t = 0; t < VOX_TC; ++t) {
+                    const float p = sm.S[grp][g][t];          // 0 for t >= nt
+                    const u32 vw = Vw[t * (D / 2) + dp];
+                    l = l + p;
+                    o0 = __fmaf_rn(p, bflo(vw), o0);
+                    o1 = __fmaf_rn(p, bfhi(vw), o1);
+                }
+                *reinterpret_cast<float2*>(&sm.Po[c][g][2 * dp]) = make_float2(o0, o1);
+                if (dp == 0) sm.Pml[c][g] = make_float2(sm.Ms[grp][g], l);
+            }
+        }
+    }
+    __syncthreads();
+    // merge (k_attn_merge): global max, the chunk weights w_c = exp2((m_c - M) log2e) once per (chunk, head), then L and O over
+    // the chunks in ascending order
+    if (tid < NCH * GMAX) {
+        const int c = tid / GMAX, g = tid % GMAX;
+        if (g < G) {
+            float M = -INFINITY;
+            for (int cc = 0; cc < nc; ++cc) M = fmaxf(M, sm.Pml[cc][g].x);
+            sm.Wm[c][g] = c < nc ? exp2_c((sm.Pml[c][g].x - M) * VOX_LOG2E) : 0.0f;
+        }
+    }
+    __syncthreads();
+    // output: q head (hk * Gf + g0 + g), two dims per thread -> one granule {bf16 d, bf16 d + 1, tag} (the MLP half of the
+    // layer gathers the 2048-wide attention row from them: no store / re-load through a kernel boundary)
+    for (int e = tid; e < G * (D / 2); e += NT) {
+        const int g = e / (D / 2), dp = e % (D / 2);
+        float Lsum = 0.0f, O0 = 0.0f, O1 = 0.0f;
+        for (int c = 0; c < nc; ++c) {
+            const float w = sm.Wm[c][g];
+            Lsum = __fmaf_rn(sm.Pml[c][g].y, w, Lsum);
+            O0 = __fmaf_rn(sm.Po[c][g][2 * dp], w, O0);
+            O1 = __fmaf_rn(sm.Po[c][g][2 * dp + 1], w, O1);
+        }
+        const int h = hk * Gf + g0 + g;
+        if (!skip_publish) gran_write(gout + ((size_t)row * a.Hq + h) * (D / 2) + dp, gtag, f2bf(O0 / Lsum), f2bf(O1 / Lsum));
+    }
+}
+
 struct TalkerMlpArgs {
     const bf16_t *wo, *wgate, *wup, *wdown, *ln2;
     const bf16_t *wqkv_next, *ln1_next;      // the NEXT layer's input_layernorm + q/k/v projection as a fourth stage (NULL: last layer)
@@ -3224,6 +3429,11 @@ struct TalkerMlpArgs {
     unsigned long long *gx, *gh;     // granules: 1024, 3072
     unsigned *epoch, *err;
     float eps;
+    // ATTN form (k_talker_mlp<true>): the layer's decode attention runs in blocks 0..15 of this launch (one q head each, <= 256 visible
+    // tokens, k_attn_decode8's arithmetic) and reaches stage O as granules; `attn` is unused
+    unsigned long long* gattn;       // granules: 1024 (the 2048-wide attention row)
+    int burst_delay;                 // plain blocks: s_sleep(16) repeats in front of their first weight requests
+    AttnArgs at;
 };
 template <int TOTAL>
 __device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins) {
@@ -3248,38 +3458,105 @@ __device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g,
         if (tid + 512 * q < TOTAL) dst[tid + 512 * q] = val[q];
 }
 
+// ATTN: the whole decoder layer of a one-request frame in ONE launch — blocks 0..15 first run the decode attention of one q head each
+// (their K/V tiles and page ids are requested when the launch starts: no kernel boundary and no second exposed round trip in front
+// of them), while the other 240 blocks already hold their first o_proj / gate / up weight rows in registers: the weight stream of the
+// MLP half runs under the attention's latency chain instead of behind it.
+using TalkerAttnSmem = AttnDecodeSmem<128, 1, 8, 8, 512>;
+#ifdef VOX_DEV_KNOBS
+// development builds: phase stamps of the layer launch from an attention block (0) and a plain block (100): records {kind 4 | 5, ATTN, t0..t7, end}
+#define MLP_TR_DECL unsigned long long mt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mslot = ~0ull;                                      \
+    const bool mtr = g_vox_trace && tid == 0 && (blk == 0 || blk == 100);                                                    \
+    if (mtr) { mt[0] = wall_clock64(); mslot = atomicAdd(g_vox_trace, 1ull); }
+#define MLP_TR(k) if (mtr) mt[k] = wall_clock64();
+#define MLP_TR_END if (mtr && mslot < VOX_TRACE_CAP) { unsigned long long* r = g_vox_trace + 16 * (mslot + 1); r[0] = blk == 0 ? 4 : 5; r[1] = ATTN; r[2] = 0; \
+        for (int i_ = 0; i_ < 8; ++i_) r[3 + i_] = mt[i_]; r[11] = wall_clock64(); }
+#else
+#define MLP_TR_DECL
+#define MLP_TR(k)
+#define MLP_TR_END
+#endif
+template <bool ATTN>
 __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     constexpr int H = 2048, F = 6144;
-    __shared__ __attribute__((aligned(16))) uint4 xb[H / 8];           // x' (bf16 row)
-    __shared__ __attribute__((aligned(16))) uint4 hb[F / 8];           // h
+    // x' (bf16 row) | h | the attention row; ATTN: carved from the attention's LDS (dead by then — barrier below)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ATTN ? sizeof(TalkerAttnSmem) : (H + F) * 2];
+    static_assert(!ATTN || sizeof(TalkerAttnSmem) >= (H + F + H) * 2, "LDS carve");
+    uint4* const xb = reinterpret_cast<uint4*>(smem);
+    uint4* const hb = xb + H / 8;
+    uint4* const ab = hb + F / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
     const unsigned ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
     const unsigned max_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);            // (as in k_depth_step)
     const bool drop_first = blk == 1 && __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT) != 0u;
     const unsigned tag0 = ep * 64u;
-    // ---- weights of stage C, first pair of every wave: requested at once (waves 4..7 have nothing else to do until x' arrives)
+    MLP_TR_DECL
+    const bool attn_blk = ATTN && blk < 16;
+    // The other 240 blocks hold their opening burst back a little (a.burst_delay x ~0.4 us): 41 MB of weight requests issued at launch
+    // queue in front of the attention's K/V tiles (which only leave their blocks after two dependent round trips: arguments, page ids)
+    // and the attention — the critical path of the layer — finished at 15 us instead of 9 (tools/mlp_trace.py).
+    if (ATTN && !attn_blk)
+        for (int d = 0; d < a.burst_delay; ++d) __builtin_amdgcn_s_sleep(16);
+    // ---- stage O's weight rows (waves 0..3).  The attention blocks request them when their K/V tiles are parked in LDS: nothing of
+    // the attention waits behind them (loads return in order), and they land during its arithmetic
+    uint4 wo[2][4];
+    unsigned resw = 0;
+    auto load_o = [&]() {
+        if (wave < 4) {
+            const int n0 = 2 * (blk * 4 + wave);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint4* wr = reinterpret_cast<const uint4*>(a.wo + (size_t)(n0 + r) * H);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wo[r][j] = ldg_nt(wr + lane + 64 * j);
+            }
+            resw = reinterpret_cast<const unsigned*>(a.x_in)[blk * 4 + wave];
+        }
+    };
+    if (!attn_blk) load_o();
+    // ---- weights of stage C, first pair of every wave: requested at once (waves 4..7 have nothing else to do until x' arrives); the
+    // attention blocks request them when the attention is done (its tiles need the registers) — they land during the hand-off
     const int p1 = blk * 12 + wave;                                     // 3072 pairs: 12 per block
     uint4 wg1[2][4], wu1[2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const uint4* gr = reinterpret_cast<const uint4*>(a.wgate + (size_t)(2 * p1 + r) * H);
-        const uint4* ur = reinterpret_cast<const uint4*>(a.wup + (size_t)(2 * p1 + r) * H);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { wg1[r][j] = ldg_nt(gr + lane + 64 * j); wu1[r][j] = ldg_nt(ur + lane + 64 * j); }
-    }
-    // ---------------- stage O: x' = x + Wo . attn ----------------
-    if (wave < 4) {
-        const int pr = blk * 4 + wave, n0 = 2 * pr;
-        uint4 wo[2][4], av[4];
+    auto load_c1 = [&]() {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const uint4* wr = reinterpret_cast<const uint4*>(a.wo + (size_t)(n0 + r) * H);
+            const uint4* gr = reinterpret_cast<const uint4*>(a.wgate + (size_t)(2 * p1 + r) * H);
+            const uint4* ur = reinterpret_cast<const uint4*>(a.wup + (size_t)(2 * p1 + r) * H);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wo[r][j] = ldg_nt(wr + lane + 64 * j);
+            for (int j = 0; j < 4; ++j) { wg1[r][j] = ldg_nt(gr + lane + 64 * j); wu1[r][j] = ldg_nt(ur + lane + 64 * j); }
         }
+    };
+    if (!attn_blk) load_c1();
+    if (attn_blk) {
+        // q head blk: kv head blk / 2, half blk % 2 of its two-head group (the launch form's head split); row 0
+        attn_decode8_block<128, 1, 8, 8, 512>(a.at, *reinterpret_cast<TalkerAttnSmem*>(smem), 2, blk >> 1, blk & 1, 0, a.gattn, tag0 + 4u, false, load_o);
+        load_c1();
+        __syncthreads();                               // the attention's LDS is dead: xb / hb / ab may be written
+    }
+    MLP_TR(1)
+    // ---------------- stage O: x' = x + Wo . attn ----------------
+    if (ATTN) {
+        // The attention row: 1024 granules from blocks 0..15.  The wait is long (the whole attention, ~10 us) and the same for every
+        // block: ONE wave per block watches one sentinel granule with s_sleep between its polls (240 blocks sweeping 1024 granules each
+        // for the whole time take the memory side away from the attention's K/V tiles and from the weight stream: guide, polling-cost);
+        // the others wait at the barrier.  Then the gather proper, by every thread.
+        if (wave == 7 && !attn_blk) {
+            for (unsigned spin = 0; spin <= max_spins; ++spin) {
+                if ((unsigned)(__hip_atomic_load(a.gattn + 1023, VOX_RLX_AGENT) >> 32) == tag0 + 4u) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        gran_gather_lds_all<1024>(a.gattn, tag0 + 4u, reinterpret_cast<unsigned*>(ab), tid, a.err, 0x1400u, max_spins);
+        __syncthreads();
+    }
+    MLP_TR(2)
+    if (wave < 4) {
+        const int pr = blk * 4 + wave;
+        uint4 av[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) av[j] = reinterpret_cast<const uint4*>(a.attn)[lane + 64 * j];
-        const unsigned resw = reinterpret_cast<const unsigned*>(a.x_in)[pr];
+        for (int j = 0; j < 4; ++j) av[j] = ATTN ? ab[lane + 64 * j] : reinterpret_cast<const uint4*>(a.attn)[lane + 64 * j];
         float acc[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -3309,8 +3586,10 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         }
     }
     __syncthreads();                                   // (parks waves 4..7 until waves 0..3 have published their x' pairs)
+    MLP_TR(3)
     gran_gather_lds_all<1024>(a.gx, tag0 + 1u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1100u, max_spins);
     __syncthreads();
+    MLP_TR(4)
     uint4 xv[4];
     {
 #pragma unroll
@@ -3352,8 +3631,10 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
             }
         }
         __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish their second pair)
+        MLP_TR(5)
         gran_gather_lds_all<3072>(a.gh, tag0 + 2u, reinterpret_cast<unsigned*>(hb), tid, a.err, 0x1200u, max_spins);
         __syncthreads();
+        MLP_TR(6)
         if (wave < 4) {
             const unsigned resw = reinterpret_cast<const unsigned*>(xb)[pr];
             float acc[2];
@@ -3386,6 +3667,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish the down projection; xb is free)
         gran_gather_lds_all<1024>(a.gx, tag0 + 3u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1300u, max_spins);
         __syncthreads();
+        MLP_TR(7)
         uint4 yv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) yv[j] = xb[lane + 64 * j];
@@ -3408,9 +3690,15 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     }
     if (blk == 0 && tid == 0) __hip_atomic_store(a.epoch, ep + 1u, VOX_RLX_AGENT);
     if (drop_first && tid == 0) atomicSub(a.epoch + 3, 1u);
+    MLP_TR_END
 }
 
 bool vox_talker_mlp_supported(const TalkerMlpCall& c) { return c.hidden == 2048 && c.nq == 2048 && c.ffn == 6144; }
+// the decode attention inside the launch: one row, 16 q heads of 128 on 8 kv heads, <= 256 visible tokens (8 chunks), fused decode mode
+static void fill_attn_args(AttnArgs& a, const AttnCall& c);
+bool vox_talker_attn_supported(const AttnCall& c) {
+    return c.qkv && c.Nq == 1 && c.D == 128 && c.Hq == 16 && c.Hkv == 8 && c.max_kvlen > VOX_TC && c.max_kvlen <= 8 * VOX_TC;
+}
 int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
     if (!vox_talker_mlp_supported(c)) return vox_fail(VOX_ERR_INVALID, "talker_mlp: unsupported shape");
     TalkerMlpArgs a{};
@@ -3419,7 +3707,19 @@ int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
     a.gx = (unsigned long long*)c.gran; a.gh = a.gx + 1024; a.epoch = c.epoch; a.err = c.err; a.eps = c.eps;
     a.wqkv_next = (const bf16_t*)c.wqkv_next; a.ln1_next = (const bf16_t*)c.ln1_next; a.qkv_out = (bf16_t*)c.qkv_out;
     if (c.wqkv_next && (c.nqkv != 4096 || !c.ln1_next || !c.qkv_out)) return vox_fail(VOX_ERR_INVALID, "talker_mlp: bad next-layer qkv");
-    hipLaunchKernelGGL(k_talker_mlp, dim3(256), dim3(512), 0, st, a);
+    if (c.attn_call) {
+        const AttnCall& ac = *c.attn_call;
+        if (!vox_talker_attn_supported(ac)) return vox_fail(VOX_ERR_INVALID, "talker_mlp: attention shape not supported in the launch");
+        fill_attn_args(a.at, ac);
+        static const int hoist_on = [] { const char* e = getenv("VOX_ATTN_HOIST"); return !(e && e[0] == '0'); }();
+        a.at.hoist = hoist_on;
+        a.gattn = a.gx + 4096;
+        static const int delay = [] { const char* e = getenv("VOX_TALKER_ATTN_DELAY"); return e ? atoi(e) : 4; }();
+        a.burst_delay = delay < 0 ? 0 : (delay > 64 ? 64 : delay);
+        hipLaunchKernelGGL(k_talker_mlp<true>, dim3(256), dim3(512), 0, st, a);
+        return VOX_OK;
+    }
+    hipLaunchKernelGGL(k_talker_mlp<false>, dim3(256), dim3(512), 0, st, a);
     return VOX_OK;
 }
 

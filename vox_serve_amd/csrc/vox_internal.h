@@ -143,8 +143,12 @@ struct TalkerMlpCall {
     const void *wqkv_next = nullptr, *ln1_next = nullptr;
     void* qkv_out = nullptr;
     int nqkv = 0;
+    // optional stage in front: the layer's decode attention inside the launch (blocks 0..15; gran then holds 5120 granules, the last
+    // 1024 for the attention row) — `attn` is unused
+    const struct AttnCall* attn_call = nullptr;
 };
 bool vox_talker_mlp_supported(const TalkerMlpCall& c);
+bool vox_talker_attn_supported(const struct AttnCall& c);
 int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c);
 bool vox_depth_step_supported(const DepthStepCall& c);
 int vox_launch_depth_step(hipStream_t st, const DepthStepCall& c);
