@@ -467,8 +467,11 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
             const unsigned words[4] = {1u, 0u, vox_persist_spins_default(), 0u};      // epoch, error, poll bound, test hook
             VOX_HIP(hipMemcpy(s->mlp_words, words, 16, hipMemcpyHostToDevice));
             s->mlp_persist = 1;
+            // the decode attention INSIDE that launch (blocks 0..15): built, bit-identical, and measured equal to the two-launch form
+            // (2.447 vs 2.442 ms per frame: what the overlapped weight stream saves, the 512-thread attention under that stream
+            // loses — DESIGN.md §3.1); opt-in for A/B
             const char* ea = getenv("VOX_TALKER_ATTN");
-            s->mlp_attn = !(ea && ea[0] == '0') && s->cfg.heads == 16 && s->cfg.kv_heads == 8 && s->cfg.head_dim == 128;
+            s->mlp_attn = (ea && ea[0] == '1') && s->cfg.heads == 16 && s->cfg.kv_heads == 8 && s->cfg.head_dim == 128;
         }
     }
     *out = s;

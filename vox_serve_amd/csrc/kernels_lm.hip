@@ -1882,6 +1882,9 @@ struct AttnArgs {
     float *part_o, *part_ml;
     float scale;
     int Hq, Hkv, page_size, max_chunks;
+    int page_shift;     // log2(page_size) when it is a power of two (set_page_size), else -1: token -> (page, slot) by shift / mask instead of
+                        // an integer division per K/V element (no divide instruction: ~40 VALU each; 8..16 of them per thread stood in
+                        // front of the K/V requests of every decode attention)
     // fused decode mode: q/k/v of each row's own (newest) token come straight from the projection output;
     // per-head norm + RoPE happen here and the block owning the last chunk appends K/V to the cache.
     const bf16_t* qkv;      // [N, (Hq+2Hkv)*D]
@@ -1901,6 +1904,13 @@ struct AttnArgs {
     bf16_t* out_frag;   // optional fragment-major copy of the output (see LinearCall)
     int hoist;          // 1: page ids requested before the row length is known (k_attn_decode8 with a per-row page table)
 };
+static inline void set_page_size(AttnArgs& a, int page_size) {
+    a.page_size = page_size;
+    a.page_shift = -1;
+    if (page_size > 0 && (page_size & (page_size - 1)) == 0) { a.page_shift = 0; while ((1 << a.page_shift) < page_size) ++a.page_shift; }
+}
+__device__ __forceinline__ int page_of(const AttnArgs& a, int tok) { return a.page_shift >= 0 ? tok >> a.page_shift : tok / a.page_size; }
+__device__ __forceinline__ int slot_of(const AttnArgs& a, int tok) { return a.page_shift >= 0 ? tok & (a.page_size - 1) : tok % a.page_size; }
 
 // norm (optional) + rope of one head held as one 16-byte chunk per lane (lanes < LPT); result as bf16 bits in
 // `out` (LDS, D elements).  sh: LDS scratch of D floats.  All 64 lanes of the wave must call this.
@@ -1985,8 +1995,8 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
         vreg[u] = kreg[u];
         if (i < VOX_TC * LPT && t < nt && !(own_last && t == nt - 1)) {
             const int tok = t0 + t;
-            const int pgi = pages ? pages[tok / a.page_size] : row;
-            const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
+            const int pgi = pages ? pages[page_of(a, tok)] : row;
+            const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)slot_of(a, tok) * a.Hkv + hk) * D;
             kreg[u] = reinterpret_cast<const uint4*>(base)[j];
             vreg[u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
         }
@@ -2089,7 +2099,7 @@ int vox_launch_attn_partial(hipStream_t st, const AttnCall& c) {
     AttnArgs a{};
     a.q = (const bf16_t*)c.q; a.kv = (const bf16_t*)c.kv; a.q_req = c.q_req; a.q_kvlen = c.q_kvlen;
     a.indptr = c.indptr; a.indices = c.indices; a.part_o = c.part_o; a.part_ml = c.part_ml; a.scale = c.scale;
-    a.Hq = c.Hq; a.Hkv = c.Hkv; a.page_size = c.page_size; a.max_chunks = c.max_chunks;
+    a.Hq = c.Hq; a.Hkv = c.Hkv; set_page_size(a, c.page_size); a.max_chunks = c.max_chunks;
     a.qkv = (const bf16_t*)c.qkv; a.kv_w = (bf16_t*)const_cast<void*>(c.kv); a.qn = (const bf16_t*)c.qn;
     a.kn = (const bf16_t*)c.kn; a.cs = c.cs; a.pos = c.pos; a.page = c.page; a.slot = c.slot; a.eps = c.eps;
     a.rot = c.rot; a.interleave = c.interleave; a.table_max_pos = c.table_max_pos;
@@ -2161,7 +2171,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
 #pragma unroll
             for (int u = 0; u < KVL; ++u) {
                 const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT;
-                const int pi = tok / a.page_size;
+                const int pi = page_of(a, tok);
                 pgi_pre[ci][u] = pages[pi < a.pt_stride ? pi : a.pt_stride - 1];
             }
     }
@@ -2184,8 +2194,8 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             vreg[u] = kreg[u];
             const int tok = t0 + t;
             if (i < VOX_TC * LPT && tok < L - 1) {
-                const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[tok / a.page_size] : row);
-                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
+                const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[page_of(a, tok)] : row);
+                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)slot_of(a, tok) * a.Hkv + hk) * D;
                 kreg[u] = reinterpret_cast<const uint4*>(base)[j];
                 vreg[u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
             } else if (i < VOX_TC * LPT && tok == L - 1) {
@@ -2365,7 +2375,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8_v1(AttnArgs a) {
 #pragma unroll
             for (int u = 0; u < KVL; ++u) {
                 const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT;
-                const int pi = tok / a.page_size;
+                const int pi = page_of(a, tok);
                 pgi_pre[ci][u] = pages[pi < a.pt_stride ? pi : a.pt_stride - 1];
             }
     }
@@ -2386,8 +2396,8 @@ __global__ __launch_bounds__(1024) void k_attn_decode8_v1(AttnArgs a) {
             vreg[ci][u] = kreg[ci][u];
             const int tok = t0 + t;
             if (i < VOX_TC * LPT && tok < L - 1) {
-                const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[tok / a.page_size] : row);
-                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
+                const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[page_of(a, tok)] : row);
+                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)slot_of(a, tok) * a.Hkv + hk) * D;
                 kreg[ci][u] = reinterpret_cast<const uint4*>(base)[j];
                 vreg[ci][u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
             }
@@ -2529,7 +2539,7 @@ int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
     AttnArgs a{};
     a.q = (const bf16_t*)c.q; a.kv = (const bf16_t*)c.kv; a.q_req = c.q_req; a.q_kvlen = c.q_kvlen;
     a.indptr = c.indptr; a.indices = c.indices; a.scale = c.scale;
-    a.Hq = c.Hq; a.Hkv = c.Hkv; a.page_size = c.page_size; a.max_chunks = c.max_chunks;
+    a.Hq = c.Hq; a.Hkv = c.Hkv; set_page_size(a, c.page_size); a.max_chunks = c.max_chunks;
     a.qkv = (const bf16_t*)c.qkv; a.kv_w = (bf16_t*)const_cast<void*>(c.kv); a.qn = (const bf16_t*)c.qn;
     a.kn = (const bf16_t*)c.kn; a.cs = c.cs; a.pos = c.pos; a.page = c.page; a.slot = c.slot; a.eps = c.eps;
     a.rot = c.rot; a.interleave = c.interleave; a.table_max_pos = c.table_max_pos;
@@ -2625,17 +2635,17 @@ __device__ __forceinline__ void attn_short_prefetch(const AttnArgs& at, int row,
         const int t = u * 4 + grp;
         pf.kr[u] = make_uint4(0, 0, 0, 0);
         if (t < nt - 1) {
-            const int pgi = pages ? pages[t / at.page_size] : row;
-            pf.kr[u] = reinterpret_cast<const uint4*>(at.kv + (size_t)pgi * ps + ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[j];
+            const int pgi = pages ? pages[page_of(at, t)] : row;
+            pf.kr[u] = reinterpret_cast<const uint4*>(at.kv + (size_t)pgi * ps + ((size_t)slot_of(at, t) * at.Hkv + hk) * D)[j];
         }
     }
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
         pf.vr[t] = make_uint2(0, 0);
         if (t < nt - 1) {
-            const int pgi = pages ? pages[t / at.page_size] : row;
+            const int pgi = pages ? pages[page_of(at, t)] : row;
             pf.vr[t] = reinterpret_cast<const uint2*>(at.kv + (size_t)pgi * ps + (size_t)at.page_size * at.Hkv * D +
-                                                      ((size_t)(t % at.page_size) * at.Hkv + hk) * D)[dq];
+                                                      ((size_t)slot_of(at, t) * at.Hkv + hk) * D)[dq];
         }
     }
 }
@@ -3237,11 +3247,27 @@ struct AttnDecodeSmem {
 };
 template <int D, int GMAX, int NG, int NCH, int NT, typename AfterPark>
 __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecodeSmem<D, GMAX, NG, NCH, NT>& sm, int HS, int hk, int hs, int row,
-                                                    unsigned long long* gout, unsigned gtag, bool skip_publish, AfterPark after_park) {
+                                                    unsigned long long* gout, const unsigned* gtag_lds, bool skip_publish, AfterPark after_park,
+                                                    const unsigned* dbg_words = nullptr) {
     constexpr int LPT = D / 8, TPW = 64 / LPT, GT = NT / NG, GW = GT / 64, CPG = NCH / NG;
     constexpr int KVL = (VOX_TC * LPT + GT - 1) / GT;
     constexpr bool QREG = GMAX <= 2;
     static_assert(GT % 64 == 0 && GW >= 1, "a group is whole waves");
+    VOX_STAMP2_DECL
+    VOX_STAMP2(0)
+#ifdef VOX_DEV_KNOBS
+    if (stamp2_base) {      // latency probes at launch start (stamped wave only): a plain load, then an L1-bypassing load of the epoch word
+        const int p0 = a.q_kvlen[row];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp2_base[11] = wall_clock64() + (p0 < -5);
+        const unsigned w0 = __hip_atomic_load(gtag_lds == nullptr ? (const unsigned*)a.pos : dbg_words, VOX_RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp2_base[12] = wall_clock64() + (w0 == 0x7fffffffu);
+        const int p1 = a.ptab ? a.ptab[0] : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp2_base[13] = wall_clock64() + (p1 < -5);
+    }
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave16 = tid >> 6;
     const int grp = tid / GT, gt = tid % GT, gw = wave16 % GW;
     const int* pages = a.identity_pages ? nullptr
@@ -3257,11 +3283,14 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
 #pragma unroll
             for (int u = 0; u < KVL; ++u) {
                 const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT;
-                const int pi = tok / a.page_size;
+                const int pi = page_of(a, tok);
                 pgi_pre[ci][u] = pages[pi < a.pt_stride ? pi : a.pt_stride - 1];
             }
     }
     const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
+#ifdef VOX_DEV_KNOBS
+    if (stamp2_base) { stamp2_base[14] = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp2_base[15] = wall_clock64() + (L < -5); }
+#endif
     const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..NCH
     const int Gf = a.Hq / a.Hkv, G = Gf / HS, g0 = hs * G;
     const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
@@ -3280,8 +3309,8 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
             vreg[u] = kreg[u];
             const int tok = t0 + t;
             if (i < VOX_TC * LPT && tok < L - 1) {
-                const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[tok / a.page_size] : row);
-                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)(tok % a.page_size) * a.Hkv + hk) * D;
+                const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[page_of(a, tok)] : row);
+                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)slot_of(a, tok) * a.Hkv + hk) * D;
                 kreg[u] = reinterpret_cast<const uint4*>(base)[j];
                 vreg[u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
             } else if (i < VOX_TC * LPT && tok == L - 1) {
@@ -3290,6 +3319,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         }
     };
     fetch_tile(0);
+    VOX_STAMP2(1)
     {   // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave
         int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
         p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
@@ -3301,6 +3331,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
             prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, sm.Sh + wave16 * D, dst, lane);
         }
     }
+    VOX_STAMP2(2)
 #pragma unroll
     for (int ci = 0; ci < CPG; ++ci) {
         const int c = grp + NG * ci, t0 = c * VOX_TC;
@@ -3316,6 +3347,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         if (ci + 1 < CPG) fetch_tile(ci + 1);  // in flight during this chunk's arithmetic
         __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
         if (ci == 0) after_park();             // the caller's own loads: nothing of the attention waits behind them any more
+        VOX_STAMP2(3)
         if (own_last && hs == 0 && gt < LPT) {
             // append the new token to the paged cache (page < 0: graph padding row)
             const int pg = a.identity_pages ? row : a.page[row];
@@ -3361,6 +3393,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
             }
         }
         __syncthreads();
+        VOX_STAMP2(4)
         if (live) {      // chunk max + p = exp2((s-m)*log2e): 32 lanes per q head
             for (int pr = gt; pr < G * VOX_TC; pr += GT) {
                 const int g = pr / VOX_TC, t = pr % VOX_TC;
@@ -3374,6 +3407,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
             }
         }
         __syncthreads();
+        VOX_STAMP2(5)
         if (live) {      // PV: one thread per (q head, pair of dims); sequential over the tokens of the (zero-padded) tile
             const u32* Vw = reinterpret_cast<const u32*>(sm.Vs[grp]);
             for (int e = gt; e < G * (D / 2); e += GT) {
@@ -3393,6 +3427,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         }
     }
     __syncthreads();
+    VOX_STAMP2(6)
     // merge (k_attn_merge): global max, the chunk weights w_c = exp2((m_c - M) log2e) once per (chunk, head), then L and O over
     // the chunks in ascending order
     if (tid < NCH * GMAX) {
@@ -3404,8 +3439,10 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         }
     }
     __syncthreads();
+    VOX_STAMP2(7)
     // output: q head (hk * Gf + g0 + g), two dims per thread -> one granule {bf16 d, bf16 d + 1, tag} (the MLP half of the
     // layer gathers the 2048-wide attention row from them: no store / re-load through a kernel boundary)
+    const unsigned gtag = *gtag_lds;             // (written by the caller's after_park, barriers ago)
     for (int e = tid; e < G * (D / 2); e += NT) {
         const int g = e / (D / 2), dp = e % (D / 2);
         float Lsum = 0.0f, O0 = 0.0f, O1 = 0.0f;
@@ -3418,6 +3455,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         const int h = hk * Gf + g0 + g;
         if (!skip_publish) gran_write(gout + ((size_t)row * a.Hq + h) * (D / 2) + dp, gtag, f2bf(O0 / Lsum), f2bf(O1 / Lsum));
     }
+    VOX_STAMP2(8)
 }
 
 struct TalkerMlpArgs {
@@ -3433,6 +3471,7 @@ struct TalkerMlpArgs {
     // tokens, k_attn_decode8's arithmetic) and reaches stage O as granules; `attn` is unused
     unsigned long long* gattn;       // granules: 1024 (the 2048-wide attention row)
     int burst_delay;                 // plain blocks: s_sleep(16) repeats in front of their first weight requests
+    int poll_sleep;                  // s_sleep(8) repeats between two polls of the sentinel granule
     AttnArgs at;
 };
 template <int TOTAL>
@@ -3486,10 +3525,18 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     uint4* const hb = xb + H / 8;
     uint4* const ab = hb + F / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
-    const unsigned ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
-    const unsigned max_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);            // (as in k_depth_step)
-    const bool drop_first = blk == 1 && __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT) != 0u;
-    const unsigned tag0 = ep * 64u;
+    // The launch's state words {epoch, error, poll bound, test hook}: read by ONE thread per block and handed to the others through
+    // LDS.  (Every thread reading them with the L1-bypassing loads such words need put 6144 wave requests per launch on one L2 line:
+    // with loads returning in order, every wave's first real operand waited behind that queue — the attention's page ids arrived 8.7 us
+    // after entry instead of 3.2, tools/attn_in_layer_stamps.py.)
+    __shared__ unsigned wsh[4];
+    unsigned w_ep = 0, w_spins = 0, w_inj = 0;
+    if (tid == 0) {
+        w_ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
+        w_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);
+        w_inj = __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT);
+    }
+    auto park_words = [&]() { if (tid == 0) { wsh[0] = w_ep; wsh[1] = w_ep * 64u + 4u; wsh[2] = w_spins; wsh[3] = w_inj; } };
     MLP_TR_DECL
     const bool attn_blk = ATTN && blk < 16;
     // The other 240 blocks hold their opening burst back a little (a.burst_delay x ~0.4 us): 41 MB of weight requests issued at launch
@@ -3530,10 +3577,16 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     if (!attn_blk) load_c1();
     if (attn_blk) {
         // q head blk: kv head blk / 2, half blk % 2 of its two-head group (the launch form's head split); row 0
-        attn_decode8_block<128, 1, 8, 8, 512>(a.at, *reinterpret_cast<TalkerAttnSmem*>(smem), 2, blk >> 1, blk & 1, 0, a.gattn, tag0 + 4u, false, load_o);
+        attn_decode8_block<128, 1, 8, 8, 512>(a.at, *reinterpret_cast<TalkerAttnSmem*>(smem), 2, blk >> 1, blk & 1, 0, a.gattn, &wsh[1], false,
+                                              [&]() { park_words(); load_o(); }, a.epoch);
         load_c1();
-        __syncthreads();                               // the attention's LDS is dead: xb / hb / ab may be written
+    } else {
+        park_words();
     }
+    __syncthreads();                                   // state words parked; (attention blocks) the attention's LDS is dead: xb / hb / ab may be written
+    const unsigned ep = wsh[0], max_spins = wsh[2];
+    const bool drop_first = blk == 1 && wsh[3] != 0u;
+    const unsigned tag0 = ep * 64u;
     MLP_TR(1)
     // ---------------- stage O: x' = x + Wo . attn ----------------
     if (ATTN) {
@@ -3544,7 +3597,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         if (wave == 7 && !attn_blk) {
             for (unsigned spin = 0; spin <= max_spins; ++spin) {
                 if ((unsigned)(__hip_atomic_load(a.gattn + 1023, VOX_RLX_AGENT) >> 32) == tag0 + 4u) break;
-                __builtin_amdgcn_s_sleep(8);
+                for (int q = 0; q < a.poll_sleep; ++q) __builtin_amdgcn_s_sleep(8);
             }
         }
         __syncthreads();
@@ -3716,6 +3769,8 @@ int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
         a.gattn = a.gx + 4096;
         static const int delay = [] { const char* e = getenv("VOX_TALKER_ATTN_DELAY"); return e ? atoi(e) : 4; }();
         a.burst_delay = delay < 0 ? 0 : (delay > 64 ? 64 : delay);
+        static const int psl = [] { const char* e = getenv("VOX_TALKER_ATTN_POLL"); return e ? atoi(e) : 1; }();
+        a.poll_sleep = psl < 1 ? 1 : (psl > 64 ? 64 : psl);
         hipLaunchKernelGGL(k_talker_mlp<true>, dim3(256), dim3(512), 0, st, a);
         return VOX_OK;
     }
@@ -3742,7 +3797,7 @@ int vox_launch_depth_step(hipStream_t st, const DepthStepCall& c) {
     }
     AttnArgs& at = a.at;
     at.kv = (const bf16_t*)c.kv; at.kv_w = (bf16_t*)c.kv; at.cs = c.cs; at.eps = c.eps; at.scale = c.scale;
-    at.Hq = c.heads; at.Hkv = c.kv_heads; at.page_size = c.page_size; at.table_max_pos = c.table_max_pos;
+    at.Hq = c.heads; at.Hkv = c.kv_heads; set_page_size(at, c.page_size); at.table_max_pos = c.table_max_pos;
     at.rot = c.rope_dim; at.interleave = 0; at.fixed_kvlen = c.n_tokens; at.fixed_pos = c.n_tokens - 1; at.identity_pages = 1;
     at.out = nullptr; at.out_frag = nullptr;
     switch (c.n_tokens) {
@@ -3758,7 +3813,7 @@ int vox_launch_depth_step(hipStream_t st, const DepthStepCall& c) {
 static void fill_attn_args(AttnArgs& a, const AttnCall& c) {
     a.q = (const bf16_t*)c.q; a.kv = (const bf16_t*)c.kv; a.q_req = c.q_req; a.q_kvlen = c.q_kvlen;
     a.indptr = c.indptr; a.indices = c.indices; a.part_o = c.part_o; a.part_ml = c.part_ml; a.scale = c.scale;
-    a.Hq = c.Hq; a.Hkv = c.Hkv; a.page_size = c.page_size; a.max_chunks = c.max_chunks;
+    a.Hq = c.Hq; a.Hkv = c.Hkv; set_page_size(a, c.page_size); a.max_chunks = c.max_chunks;
     a.qkv = (const bf16_t*)c.qkv; a.kv_w = (bf16_t*)const_cast<void*>(c.kv); a.qn = (const bf16_t*)c.qn;
     a.kn = (const bf16_t*)c.kn; a.cs = c.cs; a.pos = c.pos; a.page = c.page; a.slot = c.slot; a.eps = c.eps;
     a.rot = c.rot; a.interleave = c.interleave; a.table_max_pos = c.table_max_pos;
