@@ -433,6 +433,45 @@ def g7_single_stack_lms(ns):
         print("g7", t, [out[f"{t}_f{f}_tokens"].ravel().tolist() for f in range(4)])
 
 
+def g22_glm_full_width(ns):
+    """ONE GLM-4-Voice-9B layer at full width (hidden 4096, 32 q / 2 kv heads of 128, FFN 13696, QKV bias, half-rotary interleaved RoPE;
+    a 4096-entry vocabulary keeps the two 168960 x 4096 tables out of the fixture's way — oracle/lm_wide.py) through the reference's
+    modules and worker (glm_voice.py:85-305) at 1 and at 8 concurrent requests (BASELINE config 4's per-GPU share), two decode steps:
+    the K = 4096 / 13696 reductions and every rounding point of a full-width layer meet numbers the REFERENCE produced — at the row
+    counts that take the fixed-order kernels (1) and the matrix-core linears (8).  The g21 recipe, for the single-stack family."""
+    torch.cuda.synchronize = lambda *a, **k: None
+    from vox_serve.model import glm_voice as GV
+    from oracle import lm_ref as LR, lm_wide as LW
+    cfg = LW.wide_glm_cfg()
+    c = cfg.stack
+    S = LR.random_glm_state_dict(cfg, seed=LW.WEIGHT_SEED, std=LW.WEIGHT_STD)
+    gc = GV.GLMVoiceConfig(ffn_hidden_size=c.ffn, hidden_size=c.hidden, multi_query_group_num=c.kv_heads,
+                           num_attention_heads=c.heads, num_hidden_layers=c.layers, num_layers=c.layers,
+                           padded_vocab_size=cfg.vocab_out, vocab_size=cfg.vocab_out, layernorm_epsilon=c.eps)
+    net = GV.GLMVoiceForCausalLM(gc).to(torch.bfloat16)
+    missing, unexpected = net.load_state_dict({k: vr.to_torch(v) for k, v in S.items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    for tag, lens, seed in (("b1", [9], 221), ("b8", [3, 5, 2, 7, 4, 3, 6, 2], 222)):
+        g = torch.Generator().manual_seed(seed)
+        page, P = 16, max(8, len(lens) + 2)
+        out = {"page": np.int32(page), "P": np.int32(P), "prompt_lens": np.array(lens, np.int32), "n_steps": np.int32(2)}
+        prompts = [{"ids": torch.randint(0, cfg.vocab_in, (n, 1), generator=g)} for n in lens]
+        for i, pp in enumerate(prompts):
+            out[f"glm_r{i}_ids"] = pp["ids"].numpy().astype(np.int32)[:, 0]
+        m = GV.GLMVoiceModel.__new__(GV.GLMVoiceModel)
+        m.model, m.config, m.device, m.dtype = net, gc, "cpu", torch.bfloat16
+        m._num_attention_heads, m._num_key_value_heads = c.heads, c.kv_heads
+        m._num_hidden_layers, m._hidden_size = c.layers, c.hidden
+        m.stop_token_ids, m.audio_offset = [cfg.vocab_out - 3, cfg.vocab_out - 2, cfg.vocab_out - 1], cfg.vocab_out // 2
+        m.default_sampling_config = ns.sampling.SamplingConfig(greedy=True)
+        w = _lm_worker(ns, m, c, page, P)
+        w.max_batch_size = max(4, len(lens))
+        _drive_lm(ns, w, m, prompts, 2, out, "glm")
+        del out["glm_kv_final"]                     # (the logits pin the layer; the K/V bytes would double the fixture)
+        np.savez_compressed(os.path.join(HERE, f"g22_glm_full_width_{tag}.npz"), **out)
+        print("g22", tag, [out[f"glm_f{f}_tokens"].ravel().tolist() for f in range(2)])
+
+
 def _ref_codec(ns, cfg, W, dtype):
     qc = ns.qwen3_codec
     rc = qc.Qwen3TTSTokenizerV2DecoderConfig(
@@ -694,6 +733,21 @@ def g8_scheduler_policies(ns):
 def g9_csm_lm(ns):
     """Tiny CSM (backbone + depth decoder) through the reference modules and the reference worker: prefill of two
     requests (text rows + audio-context rows), then 3 decode frames, greedy (csm.py:55-313, 637-770)."""
+    from oracle import csm_ref as CR
+    _csm_lm_golden(ns, CR.tiny_csm_cfg(), 7, 0.08, "g9_csm_lm.npz", [(7, 5), (10, 0)], 3, None, 16, 24, 21, 64)
+
+
+def g23_csm_full_width(ns):
+    """ONE backbone layer + ONE depth-decoder layer at the widths of CSM-1B (backbone 2048 / 32 q + 8 kv heads of 64 / FFN 8192, depth
+    1024 / 8 + 2 heads of 128 / FFN 8192, 32 codebooks of 2051, llama-3.1 RoPE with the real 8192-token original context; a 1024-entry
+    text vocabulary — oracle/csm_wide.py) through the reference's modules and worker (csm.py:235-255, 637-770) at 16 concurrent
+    requests (BASELINE config 4's batch), two frames of 31 depth steps: the g21 recipe for the CSM family."""
+    from oracle import csm_wide as CW
+    specs = [(3, 2), (4, 0), (2, 1), (5, 0), (3, 0), (2, 2), (4, 1), (3, 0), (2, 0), (6, 0), (3, 1), (2, 0), (4, 0), (3, 2), (2, 1), (5, 0)]
+    _csm_lm_golden(ns, CW.wide_csm_cfg(), CW.WEIGHT_SEED, CW.WEIGHT_STD, "g23_csm_full_width_b16.npz", specs, 2, 256, 32, 20, 231, 8192)
+
+
+def _csm_lm_golden(ns, cfg, wseed, std, fname, specs, n_frames, dl_cols, page, P, seed, orig_ctx):
     import transformers
     from unittest import mock
     torch.cuda.synchronize = lambda *a, **k: None
@@ -701,10 +755,10 @@ def g9_csm_lm(ns):
     from vox_serve.model.base import PreprocessOutput
     from oracle import csm_ref as CR
     FU, MW = ns.flashinfer_utils, ns.ModelWorker
-    cfg = CR.tiny_csm_cfg()
     b, d, C, V = cfg.backbone, cfg.depth, cfg.n_codebooks, cfg.vocab
-    W = CR.random_csm_state_dict(cfg, seed=7, std=0.08)
-    rs = {"factor": 32.0, "high_freq_factor": 4.0, "low_freq_factor": 1.0, "original_max_position_embeddings": 64, "rope_type": "llama3"}
+    W = CR.random_csm_state_dict(cfg, seed=wseed, std=std)
+    rs = {"factor": 32.0, "high_freq_factor": 4.0, "low_freq_factor": 1.0, "original_max_position_embeddings": orig_ctx, "rope_type": "llama3"}
+    dlc = slice(None) if dl_cols is None else slice(0, dl_cols)
     dcfg = transformers.CsmDepthDecoderConfig(num_codebooks=C, backbone_hidden_size=b.hidden, vocab_size=V, hidden_size=d.hidden,
                                               intermediate_size=d.ffn, num_hidden_layers=d.layers, num_attention_heads=d.heads,
                                               num_key_value_heads=d.kv_heads, head_dim=d.head_dim, rms_norm_eps=d.eps,
@@ -735,11 +789,10 @@ def g9_csm_lm(ns):
     m._depth_num_hidden_layers, m._depth_hidden_size = d.layers, d.hidden
     m.stop_token_id = 0
     m.default_sampling_config = ns.sampling.SamplingConfig(greedy=True)
-    page, P = 16, 24
     cpu = torch.device("cpu")
     import logging
     w = MW.__new__(MW)
-    w.model, w.device, w.page_size, w.max_batch_size = m, "cpu", page, 4
+    w.model, w.device, w.page_size, w.max_batch_size = m, "cpu", page, max(4, len(specs))
     w.empty_pages = queue.Queue()
     for i in range(P):
         w.empty_pages.put(i)
@@ -763,10 +816,12 @@ def g9_csm_lm(ns):
         rec["dlogits"].append(lg.clone())
         return lg
     m.forward, m.depth_forward = fwd, dfwd
-    g = torch.Generator().manual_seed(21)
+    g = torch.Generator().manual_seed(seed)
     out = {"page": np.int32(page), "P": np.int32(P)}
+    if dl_cols is not None:                     # (the wide fixtures carry their shape; g9 keeps its round-1 keys, byte for byte)
+        out["n_req"], out["n_frames"] = np.int32(len(specs)), np.int32(n_frames)
     reqs = []
-    for r, (nt, na) in enumerate([(7, 5), (10, 0)]):      # text rows, then audio-context rows (csm.py:473-509)
+    for r, (nt, na) in enumerate(specs):      # text rows, then audio-context rows (csm.py:473-509)
         n = nt + na
         ids = torch.zeros(n, C + 1, dtype=torch.long)
         masks = torch.zeros(n, C + 1, dtype=torch.bool)
@@ -786,7 +841,7 @@ def g9_csm_lm(ns):
         out[f"r{r}_prefill_hidden"] = bits(rec["hidden"][n0][-1:])
         out[f"r{r}_frame0"] = req.lm_output_tokens[-1].numpy().astype(np.int32)[0]
         out[f"r{r}_next_pos"] = np.int32(req.next_position_id)
-        out[f"r{r}_prefill_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 else x) for x in rec["dlogits"]])
+        out[f"r{r}_prefill_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 else x)[..., dlc] for x in rec["dlogits"]])
         rec["dlogits"].clear()
         reqs.append(req)
     for f in range(n_frames):
@@ -800,9 +855,10 @@ def g9_csm_lm(ns):
         out[f"f{f}_dlogits"] = np.stack([bits(x[1::2] if x.shape[0] == 2 * len(reqs) else x)[..., dlc] for x in rec["dlogits"]])
         rec["dlogits"].clear()
         out[f"f{f}_tokens"] = np.stack([r_.lm_output_tokens[-1].numpy().astype(np.int32)[0] for r_ in reqs])
-    out["kv_final"] = bits(w.kv_cache)
-    np.savez_compressed(os.path.join(HERE, "g9_csm_lm.npz"), **out)
-    print("g9 ok; frame tokens", out["f2_tokens"])
+    if dl_cols is None:
+        out["kv_final"] = bits(w.kv_cache)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "ok; frame tokens", out[f"f{n_frames - 1}_tokens"][:, :6])
 
 
 # --------------------------------------------------------------------------------------------------
@@ -1372,8 +1428,8 @@ def g17_flow_evolving(ns):
     np.savez_compressed(os.path.join(HERE, "g17_flow_evolving.npz"), **out)
 
 
-ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g18": g18_qwen3_lm_b12, "g21": g21_qwen3_full_width, "g19": g19_sampler_mc, "g4": g4_qwen3_codec, "g6": g6_host_traces,
-       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder, "g17": g17_flow_evolving, "g20": g20_snac_variants}
+ALL = {"g1": g1_sampler, "g2": g2_wrappers, "g3": g3_qwen3_lm, "g18": g18_qwen3_lm_b12, "g21": g21_qwen3_full_width, "g22": g22_glm_full_width, "g19": g19_sampler_mc, "g4": g4_qwen3_codec, "g6": g6_host_traces,
+       "g7": g7_single_stack_lms, "g8": g8_scheduler_policies, "g9": g9_csm_lm, "g23": g23_csm_full_width, "g5": g5_mimi, "g10": g10_snac, "g11": g11_hift, "g12": g12_flow, "g13": g13_glm_decoder, "g14": g14_qwen3_preprocess, "g15": g15_speaker_encoder, "g16": g16_codec_encoder, "g17": g17_flow_evolving, "g20": g20_snac_variants}
 
 if __name__ == "__main__":
     ns = H.boot()

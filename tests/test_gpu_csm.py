@@ -172,6 +172,57 @@ def test_csm_against_reference_goldens(dev, golden):
     eng.close()
 
 
+def test_csm_full_width_layers_against_reference_fixture(dev, golden):
+    """g23 (round 5): the HIP engine against numbers the REFERENCE's CSM modules produced for ONE backbone layer + ONE depth-decoder
+    layer at the widths of CSM-1B, 16 requests (BASELINE config 4's batch), two teacher-forced frames: backbone logits and the first
+    depth step's logits within relative RMS 1e-2 (bf16 rounding noise), codebook-0 ids equal except near-ties."""
+    from oracle import csm_wide as CW
+    from vox_serve_amd.engine import CSMEngine
+    g = golden("g23_csm_full_width_b16")
+    cfg = CW.wide_csm_cfg()
+    W = CR.random_csm_state_dict(cfg, seed=CW.WEIGHT_SEED, std=CW.WEIGHT_STD, device=dev)
+    page, P, B, NF = int(g["page"]), int(g["P"]), int(g["n_req"]), int(g["n_frames"])
+    eng = CSMEngine(to_engine_cfg(cfg), W, max_batch=B, page_size=page, max_pages=P, max_seq_len=512, max_prefill_rows=64,
+                    keep_depth_logits=True, device=dev)
+    sc = eng.sampling_cfg(greedy=True)
+    f64 = lambda a: vr.bf2f(a).astype(np.float64)
+    rel = lambda a, b: float(np.sqrt(((f64(a) - f64(b)) ** 2).mean() / (f64(b) ** 2).mean()))
+    free, pages, lens, c0_mism, worst, worst_d = list(range(P)), [], [], 0, 0.0, 0.0
+    for r in range(B):
+        ids, masks = g[f"r{r}_ids"], g[f"r{r}_masks"]
+        n = len(ids)
+        pg = [free.pop(0) for _ in range((n + page - 1) // page)]
+        eng.row_ids[:n], eng.row_masks[:n] = torch.from_numpy(ids).to(dev), torch.from_numpy(masks).to(dev)
+        eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[pg[t // page] for t in range(n)],
+                        slot=[t % page for t in range(n)], q_req=np.zeros(n), last_rows=[n - 1], indptr=[0, len(pg)], indices=pg)
+        eng.prefill(n, 1, n, sc, feedback=False)
+        torch.cuda.synchronize()
+        worst = max(worst, rel(vr.from_torch(eng.out_logits[:1]), g[f"r{r}_prefill_logits"]))
+        c0_mism += int(eng.out_ids[0, 0].item() != g[f"r{r}_frame0"][0])
+        pages.append(pg)
+        lens.append(n)
+    for f in range(NF):
+        eng.input_ids[:B] = torch.from_numpy(g[f"f{f}_in_ids"]).to(dev)          # teacher forcing
+        eng.input_masks[:B] = torch.from_numpy(g[f"f{f}_in_masks"]).to(dev)
+        lens = [n + 1 for n in lens]
+        for r in range(B):
+            if lens[r] > len(pages[r]) * page:
+                pages[r].append(free.pop(0))
+        eng.upload_plan(pos=g[f"f{f}_pos"], kvlen=lens, page=[pages[r][(lens[r] - 1) // page] for r in range(B)],
+                        slot=[(lens[r] - 1) % page for r in range(B)], indptr=np.cumsum([0] + [len(p_) for p_ in pages]), indices=sum(pages, []))
+        eng.frame(B, max(lens), sc, feedback=False)
+        torch.cuda.synchronize()
+        worst = max(worst, rel(vr.from_torch(eng.out_logits[:B]), g[f"f{f}_logits"]))
+        got = eng.out_ids[:B].cpu().numpy()
+        ok = got[:, 0] == g[f"f{f}_tokens"][:, 0]
+        c0_mism += int((~ok).sum())
+        d1 = vr.from_torch(eng.out_depth_logits[0, :B])[ok][:, :256]            # depth step 1: a function of the backbone output and codebook 0
+        worst_d = max(worst_d, rel(d1, g[f"f{f}_dlogits"][0][ok]))
+    eng.close()
+    assert worst <= 1.0e-2 and worst_d <= 1.0e-2, (worst, worst_d)
+    assert c0_mism <= 3, c0_mism
+
+
 # ---- heavy cases: the oracle side is recorded ahead of time (tests/oracle_tape.py, tests/golden/make_oracle_tapes.py) ----------
 TAPED = {}
 

@@ -221,6 +221,54 @@ def test_against_reference_goldens(dev, golden):
         eng.close()
 
 
+@pytest.mark.parametrize("tag", ["b1", "b8"])
+def test_glm_full_width_layer_against_reference_fixture(dev, golden, tag):
+    """g22 (round 5): the HIP engine against logits the REFERENCE's GLM-4-Voice modules produced for ONE full-width layer (K = 4096 /
+    13696, 32 q / 2 kv heads, QKV bias, half-rotary interleaved RoPE) at 1 and 8 requests — prefills of 2..9 rows and two
+    teacher-forced decode steps; relative RMS of the logits <= 1e-2 (bf16 rounding noise), greedy ids equal except near-ties."""
+    from oracle import lm_wide as LW
+    g = golden(f"g22_glm_full_width_{tag}")
+    cfg = LW.wide_glm_cfg()
+    S = LR.random_glm_state_dict(cfg, seed=LW.WEIGHT_SEED, std=LW.WEIGHT_STD, device=dev)
+    page, P = int(g["page"]), int(g["P"])
+    lens = g["prompt_lens"].tolist()
+    B = len(lens)
+    eng = build(dev, "glm", cfg, S, B, page, P)
+    sc = eng.sampling_cfg(greedy=True)
+    rel = lambda a, b: float(np.sqrt(((vr.bf2f(a).astype(np.float64) - vr.bf2f(b)) ** 2).mean() / (vr.bf2f(b).astype(np.float64) ** 2).mean()))
+    pages, free, mism, worst = [], list(range(P)), 0, 0.0
+    for r, n in enumerate(lens):
+        ids = g[f"glm_r{r}_ids"]
+        pg = [free.pop(0) for _ in range((n + page - 1) // page)]
+        eng.row_ids[:n, 0] = torch.from_numpy(ids).to(dev)
+        eng.upload_plan(pos=np.arange(n), kvlen=np.arange(1, n + 1), page=[pg[t // page] for t in range(n)], slot=[t % page for t in range(n)],
+                        q_req=np.zeros(n), last_rows=[n - 1], indptr=[0, len(pg)], indices=pg)
+        eng.prefill(n, 1, n, sc, feedback=False)
+        torch.cuda.synchronize()
+        worst = max(worst, rel(vr.from_torch(eng.out_logits[:1]), g[f"glm_r{r}_prefill_logits"]))
+        mism += int(eng.out_ids[0].item() != g[f"glm_r{r}_tok0"][0])
+        pages.append(pg)
+    toks = np.array([g[f"glm_r{r}_tok0"][0] for r in range(B)], np.int32)
+    for f in range(int(g["n_steps"])):
+        eng.input_ids[:B, 0] = torch.from_numpy(toks).to(dev)          # teacher forcing with the reference's tokens
+        eng.input_masks[:B] = 0
+        lens = [n + 1 for n in lens]
+        for r in range(B):
+            if lens[r] > len(pages[r]) * page:
+                pages[r].append(free.pop(0))
+        indptr = np.cumsum([0] + [len(p_) for p_ in pages])
+        eng.upload_plan(pos=g[f"glm_f{f}_pos"], kvlen=lens, page=[pages[r][(lens[r] - 1) // page] for r in range(B)],
+                        slot=[(lens[r] - 1) % page for r in range(B)], indptr=indptr, indices=sum(pages, []))
+        eng.frame(B, max(lens), sc, feedback=False)
+        torch.cuda.synchronize()
+        worst = max(worst, rel(vr.from_torch(eng.out_logits[:B]), g[f"glm_f{f}_logits"]))
+        mism += int((eng.out_ids[:B].cpu().numpy() != g[f"glm_f{f}_tokens"][:, 0]).sum())
+        toks = g[f"glm_f{f}_tokens"][:, 0].astype(np.int32)
+    eng.close()
+    assert worst <= 1.0e-2, worst
+    assert mism <= (1 if tag == "b1" else 3), mism
+
+
 # ---- heavy cases: the oracle side is recorded ahead of time (tests/oracle_tape.py, tests/golden/make_oracle_tapes.py) ----------
 TAPED = {}
 
