@@ -628,6 +628,39 @@ def serving_pool(n_req, frames, dp_size=1, fake=False):
         pool.cleanup()
 
 
+CODEC_GFLOP_PER_REQUEST_CHUNK = 49.6      # useful (one-term) multiply-adds x 2 of one request's 10-frame chunk through the Qwen3 12 Hz decoder
+MFMA_BF16_PEAK_TFLOPS = 2500.0            # dense bf16 matrix-core peak (MI355X_MICROARCH.md)
+
+
+def codec_chunk_stats(dev, codec_W):
+    """The token->waveform half alone: one 10-frame chunk of B requests through the Qwen3 codec decoder (HIP events, nothing beside it),
+    in the default two-term operand mode (waveform within 1e-4 RMS of the reference decoder in fp32) and in the bf16-operand mode (the
+    precision the REFERENCE serves this decoder at; RMS 1.2e-2 from its fp32 evaluation, like the reference's own bf16 run).
+    mfma_frac = useful FLOPs / chunk time / the dense bf16 matrix-core peak."""
+    from vox_serve_amd.tokenizer.qwen3_codec import Qwen3TTSDecoder
+    out = {"unit": "ms per 10-frame chunk", "gflop_per_request_chunk": CODEC_GFLOP_PER_REQUEST_CHUNK, "mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS}
+    for prec, key in (("fp32", "two_term"), ("bf16", "bf16_operands")):
+        for B in (1, 32):
+            dec = Qwen3TTSDecoder(codec_W, device=dev, max_batch=B, max_slots=B, detokenize_interval=INTERVAL, operand_precision=prec)
+            codes = torch.randint(0, 2048, (B, 16, INTERVAL))
+            cache = dec.init_cache(B)
+            for _ in range(3):
+                dec.decode_chunk(codes, cache)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dec.decode_chunk(codes, cache)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            out[f"{key}_b{B}"] = {"ms": ms, "mfma_frac": B * CODEC_GFLOP_PER_REQUEST_CHUNK / ms / MFMA_BF16_PEAK_TFLOPS,
+                                  "samples_per_s": B * INTERVAL * 1920 / ms * 1e3}
+            dec.release_cache(cache)
+            dec.close()
+    return out
+
+
 def other_configs():
     """The other BASELINE.json configs, one GPU each, as sub-results of the same driver-timed command: every tool prints one JSON line
     (LM step + detokenizer in its loop, synthetic weights of the named architecture) and runs in its own process."""
@@ -852,6 +885,11 @@ def main():
             out["dry_run"] = True
             out["data"] = "none (dry run: stub loop, gloo, no GPU) - not a measurement"
         if world == 1 and args.batch is None and not args.no_other_configs and not dry:
+            try:
+                out["codec_chunk"] = codec_chunk_stats(dev, shared["codec_W"])
+            except Exception as ex:          # a sub-result must never hide the headline
+                out["codec_chunk"] = {"error": repr(ex)[:300]}
+            _phase("codec chunk")
             out["other_configs"] = other_configs()
             _phase("other configs")
         if not args.no_cpu_baseline and world == 1 and not dry:      # the CPU leg runs on rank 0 at N=1 only (other ranks would idle in RCCL)

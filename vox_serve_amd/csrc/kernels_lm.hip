@@ -32,6 +32,9 @@ struct LinArgs {
     int no_one_seg;      // k_linear_mfma A/B knob (VOX_MFMA_ONESEG=0): row statistics by the separate pass even when K fits one segment
 };
 
+#ifndef VOX_XFIRST
+#define VOX_XFIRST 2
+#endif
 #ifdef VOX_DEV_KNOBS
 // development builds: chain trace.  Thread 0 of block 0 of every instrumented launch keeps up to 8 s_memrealtime stamps (100 MHz)
 // in registers and writes one 16-word record {kind, n, t0..} when it ends (launch order = record order: the chains are
@@ -1339,16 +1342,11 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
             if (SM) wv[1][s] = a.keep ? w1[ct * tstride + s * wstep] : ldg_nt(w1 + ct * tstride + s * wstep);
         }
     };
-    load_w(0);
-    // residual of the outputs this thread will finish (threads < MT*64), requested with the operands instead of after the reduce
-    float res_pre[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!SM && a.residual && tid < MT * 64 && n0 + fr < a.N) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = (tid >> 6) * 16 + (lane >> 4) * 4 + r;
-            if (b < bt) res_pre[r] = bf2f(a.residual[(size_t)(r0 + b) * a.N + n0 + fr]);
-        }
-    }
+    // Norm-prologue form: the activation fragments are requested BEFORE the weight tile (VOX_XFIRST, default on).  Loads return in order,
+    // and the row statistics (the block's first barrier) need the activations only: asked for last, they arrived behind the whole weight
+    // tile (tools/chain_trace.py: "x arrived" 2.1 us after "all loads issued" in the 32-row talker GEMMs); asked for first, the sum of
+    // squares, the barrier and the normalisation run while the weights are still streaming.  Same loads, same arithmetic.
+    constexpr bool XF = VOX_XFIRST >= 2 || ((PRO == PRO_RMSNORM) && VOX_XFIRST != 0);
     const uint4* xr[MT];
     const int xstep = a.x_frag ? 64 : 4;
 #pragma unroll
@@ -1360,18 +1358,34 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
     static_assert(CT == 1 || (PRO == PRO_RMSNORM), "two column tiles: every activation fragment resident (norm prologue form)");
     f32x4_t acc[NB][MT];
     uint4 xa[NG > 1 ? 2 : 1][MT][G];
+    uint4 gv[PRO == PRO_RMSNORM ? G : 1];
+    auto load_x0 = [&]() {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int s = 0; s < G; ++s) xa[0][m][s] = xr[m][s * xstep];
+            for (int s = 0; s < G; ++s) xa[0][m][s] = xr[m][s * xstep];
+        if (PRO == PRO_RMSNORM) {
+            const uint4* nw = reinterpret_cast<const uint4*>(a.nw) + (kbase >> 3);
+#pragma unroll
+            for (int s = 0; s < G; ++s) gv[s] = nw[s * 4];
+        }
+    };
+    if (XF) load_x0();
+    load_w(0);
+    // residual of the outputs this thread will finish (threads < MT*64), requested with the operands instead of after the reduce
+    float res_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!SM && a.residual && tid < MT * 64 && n0 + fr < a.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = (tid >> 6) * 16 + (lane >> 4) * 4 + r;
+            if (b < bt) res_pre[r] = bf2f(a.residual[(size_t)(r0 + b) * a.N + n0 + fr]);
+        }
+    }
+    if (!XF) load_x0();
     __builtin_amdgcn_sched_barrier(0);      // every load above is issued before anything below waits on one of them
     VOX_TR(1)
-    uint4 gv[PRO == PRO_RMSNORM ? G : 1];
     float rinv[MT];
     if (PRO == PRO_RMSNORM) {
-        const uint4* nw = reinterpret_cast<const uint4*>(a.nw) + (kbase >> 3);
-#pragma unroll
-        for (int s = 0; s < G; ++s) gv[s] = nw[s * 4];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float ss = 0.0f;
@@ -2947,12 +2961,18 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
     // (wave index made provably uniform: the weight rows' base addresses then live in scalar registers — left as a per-lane value
     // the compiler hoists some forty 64-bit row pointers out of the layer loop into vector registers and spills them)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
-    const unsigned ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
-    // words [2], [3] beside the epoch: the bound of every poll loop (VOX_PERSIST_SPINS unless the host lowered it for a test) and the
-    // test hook "block 1 withholds its first publish of this launch" (vox_qwen3_persist_inject), read once per launch
-    const unsigned max_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);
-    const bool drop_first = blk == 1 && __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT) != 0u;
-    const unsigned tag0 = ep * 64u;
+    // The launch's state words beside the epoch — [2] the bound of every poll loop (VOX_PERSIST_SPINS unless the host lowered it for a
+    // test), [3] the test hook "block 1 withholds its first publish of this launch" (vox_qwen3_persist_inject) — are read by ONE thread
+    // per block (L1-bypassing loads: 2048 waves asking for the same line would queue) and reach the others through LDS at the first
+    // barrier of stage A, in front of the launch's first publish.
+    __shared__ unsigned wsh[4];
+    if (tid == 0) {
+        wsh[0] = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
+        wsh[2] = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);
+        wsh[3] = __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT);
+    }
+    unsigned ep = 0, max_spins = 0, tag0 = 0;
+    bool drop_first = false;
     auto tagof = [&](int l, int st) { return tag0 + 1u + (unsigned)(l * 4 + st); };
     VOX_STAMP2_DECL
     VOX_STAMP2(0)
@@ -3022,7 +3042,8 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             const uint4 wo00 = wor0[0], wo01 = wor0[64], wo02 = wor0[128], wo03 = wor0[192];
             const uint4 wo10 = wor1[0], wo11 = wor1[64], wo12 = wor1[128], wo13 = wor1[192];
             if (l > 0) gran_gather_lds<512>(a.gx, tagof(l - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x100u + l, max_spins);
-            __syncthreads();                               // x of this layer is in xb
+            __syncthreads();                               // x of this layer is in xb; (l = 0) the state words are in wsh
+            if (l == 0) { ep = wsh[0]; max_spins = wsh[2]; drop_first = blk == 1 && wsh[3] != 0u; tag0 = ep * 64u; }
             uint4 xv[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) xv[j] = xb[lane + 64 * j];
