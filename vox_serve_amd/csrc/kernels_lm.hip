@@ -29,11 +29,15 @@ struct LinArgs {
     bf16_t* y_frag;
     int y_rowmajor;
     int row_tiles;       // k_gemv only: > 1 = that many row tiles of BT rows, one block per (column group, row tile)
+    int rt_rows;         // k_gemm_fullk<.., ROWSPLIT>: rows per row tile (0 = 16 * MT); 8 or 4: SUB-TILE row split for <= 16 rows (below)
     int no_one_seg;      // k_linear_mfma A/B knob (VOX_MFMA_ONESEG=0): row statistics by the separate pass even when K fits one segment
 };
 
 #ifndef VOX_XFIRST
 #define VOX_XFIRST 2
+#endif
+#ifndef VOX_MLP_C2_LATE
+#define VOX_MLP_C2_LATE 0
 #endif
 #ifdef VOX_DEV_KNOBS
 // development builds: chain trace.  Thread 0 of block 0 of every instrumented launch keeps up to 8 s_memrealtime stamps (100 MHz)
@@ -1317,11 +1321,15 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
     int ctile = blockIdx.x * CT, r0 = 0;
     if (ROWSPLIT) {
         ctile = (blockIdx.x / (8 * a.row_tiles)) * 8 + (blockIdx.x & 7);
-        r0 = ((blockIdx.x >> 3) % a.row_tiles) * (16 * MT);
+        r0 = ((blockIdx.x >> 3) % a.row_tiles) * (a.rt_rows ? a.rt_rows : 16 * MT);
     }
     const int n0 = ctile * 16;
     const int kbase = wave * (KSTEPS * 32) + fk;
-    const int bt = a.B - r0;
+    // Sub-tile row split (rt_rows = 8 | 4, MT = 1): a linear of <= 16 rows with few column tiles (N / 16 <= 128: 64 .. 128 blocks on 256
+    // CUs) runs 2 .. 4 blocks per column tile, each owning rt_rows of the rows — its MFMA row tile is padded with copies of its last row,
+    // whose outputs are dropped.  An output element's K split and summation order do not depend on which rows share its tile, so the
+    // results are bit-identical; per block the activation traffic (as many bytes as the weight tile at 16 rows) shrinks with the rows.
+    const int bt = (ROWSPLIT && a.rt_rows && a.B - r0 > a.rt_rows) ? a.rt_rows : a.B - r0;
     uint4 wv[NB][KSTEPS];
     const size_t fbase = (size_t)wave * KSTEPS * 64 + lane;      // uint4 offset of this wave's first fragment inside a tile row
     // row-major: lane (fr, g) reads 16 B of weight row n0+fr per k-step (16 rows x 64 B per wave request);
@@ -1352,8 +1360,9 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int row = m * 16 + fr;
-        xr[m] = a.x_frag ? reinterpret_cast<const uint4*>(a.x_frag) + (size_t)((r0 >> 4) + m) * (a.K >> 5) * 64 + fbase
-                         : x_row_ptr(a, r0 + (row < bt ? row : bt - 1)) + (kbase >> 3);
+        const int arow = r0 + (row < bt ? row : bt - 1);       // (fragment-major: row arow sits in tile arow / 16 at fragment lane arow % 16 + 16 * (k group))
+        xr[m] = a.x_frag ? reinterpret_cast<const uint4*>(a.x_frag) + (size_t)(arow >> 4) * (a.K >> 5) * 64 + (size_t)wave * KSTEPS * 64 + (arow & 15) + (lane & 48)
+                         : x_row_ptr(a, arow) + (kbase >> 3);
     }
     static_assert(CT == 1 || (PRO == PRO_RMSNORM), "two column tiles: every activation fragment resident (norm prologue form)");
     f32x4_t acc[NB][MT];
@@ -1535,6 +1544,22 @@ template <int MT, int KSTEPS, int PRO, int EPI>
 static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a0) {
     LinArgs a = a0;
     a.row_tiles = 1;
+    a.rt_rows = 0;
+    if constexpr (MT == 1 && PRO == PRO_COPY) {
+        // <= 16 rows, few column tiles: 2 (4) blocks of 8 (4) rows per column tile (k_gemm_fullk: sub-tile row split); VOX_ROWSPLIT_SUB=0: off
+        static const int sub = [] { const char* e = getenv("VOX_ROWSPLIT_SUB"); return e ? atoi(e) : 1; }();
+        const int tiles = a.N / 16;
+        if (sub && a.N % 16 == 0 && tiles % 8 == 0 && tiles <= 128 && a.B > 4) {
+            a.rt_rows = (tiles <= 64 && a.B > 8 && sub != 8) ? 4 : (a.B > 8 ? 8 : 4);
+            if (sub == 4 && a.B > 4) a.rt_rows = 4;
+            a.row_tiles = (a.B + a.rt_rows - 1) / a.rt_rows;
+            if (a.row_tiles > 1) {
+                hipLaunchKernelGGL((k_gemm_fullk<1, KSTEPS, PRO, EPI, true>), dim3(tiles * a.row_tiles), dim3(512), 0, st, a);
+                return VOX_OK;
+            }
+            a.row_tiles = 1; a.rt_rows = 0;
+        }
+    }
     if constexpr (MT == 2) {
         if (a.B > 32) {            // 33..128 rows (short prefills, depth step 1 of 17+ requests): 32-row blocks side by side
             a.row_tiles = (a.B + 31) / 32;
@@ -3552,7 +3577,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     // after entry instead of 3.2, tools/attn_in_layer_stamps.py.)
     __shared__ unsigned wsh[4];
     unsigned w_ep = 0, w_spins = 0, w_inj = 0;
-    if (tid == 0) {
+    if (tid == 0 || !ATTN) {      // (without the attention in front every thread reads them itself: no barrier stands before stage O)
         w_ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
         w_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);
         w_inj = __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT);
@@ -3601,12 +3626,12 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         attn_decode8_block<128, 1, 8, 8, 512>(a.at, *reinterpret_cast<TalkerAttnSmem*>(smem), 2, blk >> 1, blk & 1, 0, a.gattn, &wsh[1], false,
                                               [&]() { park_words(); load_o(); }, a.epoch);
         load_c1();
-    } else {
+    } else if (ATTN) {
         park_words();
     }
-    __syncthreads();                                   // state words parked; (attention blocks) the attention's LDS is dead: xb / hb / ab may be written
-    const unsigned ep = wsh[0], max_spins = wsh[2];
-    const bool drop_first = blk == 1 && wsh[3] != 0u;
+    if (ATTN) __syncthreads();                         // state words parked; (attention blocks) the attention's LDS is dead: xb / hb / ab may be written
+    const unsigned ep = ATTN ? wsh[0] : w_ep, max_spins = ATTN ? wsh[2] : w_spins;
+    const bool drop_first = blk == 1 && (ATTN ? wsh[3] : w_inj) != 0u;
     const unsigned tag0 = ep * 64u;
     MLP_TR(1)
     // ---------------- stage O: x' = x + Wo . attn ----------------
@@ -3650,18 +3675,24 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     for (int j = 0; j < 4; ++j) nwv[j] = reinterpret_cast<const uint4*>(a.ln2)[lane + 64 * j];
     const int p2 = blk * 12 + 8 + wave;                                 // second pair: waves 0..3
     uint4 wg2[2][4], wu2[2][4];
-    if (wave < 4) {
+    auto load_c2 = [&]() {
+        if (wave < 4) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint4* gr = reinterpret_cast<const uint4*>(a.wgate + (size_t)(2 * p2 + r) * H);
-            const uint4* ur = reinterpret_cast<const uint4*>(a.wup + (size_t)(2 * p2 + r) * H);
+            for (int r = 0; r < 2; ++r) {
+                const uint4* gr = reinterpret_cast<const uint4*>(a.wgate + (size_t)(2 * p2 + r) * H);
+                const uint4* ur = reinterpret_cast<const uint4*>(a.wup + (size_t)(2 * p2 + r) * H);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { wg2[r][j] = ldg_nt(gr + lane + 64 * j); wu2[r][j] = ldg_nt(ur + lane + 64 * j); }
+                for (int j = 0; j < 4; ++j) { wg2[r][j] = ldg_nt(gr + lane + 64 * j); wu2[r][j] = ldg_nt(ur + lane + 64 * j); }
+            }
         }
-    }
+    };
+    // VOX_MLP_C2_LATE=1 (measured, no gain: 2.485 vs 2.464 ms per frame): the second pair's rows requested AFTER x' has been
+    // gathered, so that the gather's polls do not come back behind 64 KB of HBM loads per block.
+    if (!VOX_MLP_C2_LATE) load_c2();
     __syncthreads();                                   // (parks waves 4..7 until waves 0..3 have published their x' pairs)
     MLP_TR(3)
     gran_gather_lds_all<1024>(a.gx, tag0 + 1u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1100u, max_spins);
+    if (VOX_MLP_C2_LATE) load_c2();
     __syncthreads();
     MLP_TR(4)
     uint4 xv[4];
