@@ -87,6 +87,19 @@ pend = None
 for i in range(args.warmup):
     step(i, False)
 torch.cuda.synchronize()
+if os.environ.get("VOX_TRACE"):          # development build (VOX_LIB=tools/bin/libvoxhip_dev.so): chain trace of one frame, then exit
+    import ctypes
+    from vox_serve_amd import _native as N
+    from tools.chain_trace import summarize, CAP
+    buf = torch.zeros(16 * (CAP + 1) + 2 * CAP, dtype=torch.int64, device=dev)
+    fn = N.lib().vox_dev_set_trace
+    fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p]
+    for i in range(3):
+        buf.zero_(); torch.cuda.synchronize(); assert fn(buf.data_ptr()) == 0
+        step(1 + i, False); torch.cuda.synchronize()
+    fn(None)
+    summarize(buf.cpu().numpy(), CAP)
+    sys.exit(0)
 t0 = time.perf_counter()
 for i in range(args.steps):
     step(i, True)

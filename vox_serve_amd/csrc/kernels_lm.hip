@@ -1921,6 +1921,7 @@ struct AttnArgs {
     float *part_o, *part_ml;
     float scale;
     int Hq, Hkv, page_size, max_chunks;
+    int hnd_probe;      // development builds only (VOX_ATTN_HND_PROBE=1)
     int page_shift;     // log2(page_size) when it is a power of two (set_page_size), else -1: token -> (page, slot) by shift / mask instead of
                         // an integer division per K/V element (no divide instruction: ~40 VALU each; 8..16 of them per thread stood in
                         // front of the K/V requests of every decode attention)
@@ -2234,7 +2235,11 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             const int tok = t0 + t;
             if (i < VOX_TC * LPT && tok < L - 1) {
                 const int pgi = hoist ? pgi_pre[ci][u] : (pages ? pages[page_of(a, tok)] : row);
+#ifdef VOX_DEV_KNOBS      // timing probe (wrong data): the tile read as if the page were laid out [head][slot][D] — contiguous 32 KB per head
+                const bf16_t* base = a.kv + (size_t)pgi * ps + (a.hnd_probe ? ((size_t)hk * a.page_size + slot_of(a, tok)) * D : ((size_t)slot_of(a, tok) * a.Hkv + hk) * D);
+#else
                 const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)slot_of(a, tok) * a.Hkv + hk) * D;
+#endif
                 kreg[u] = reinterpret_cast<const uint4*>(base)[j];
                 vreg[u] = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D)[j];
             } else if (i < VOX_TC * LPT && tok == L - 1) {
@@ -2587,6 +2592,10 @@ int vox_launch_attn_decode8(hipStream_t st, const AttnCall& c) {
     a.out = (bf16_t*)c.out; a.out_frag = (bf16_t*)c.out_frag;
     static const int hoist_on = [] { const char* e = getenv("VOX_ATTN_HOIST"); return !(e && e[0] == '0'); }();
     a.hoist = hoist_on;
+#ifdef VOX_DEV_KNOBS
+    static const int hnd = [] { const char* e = getenv("VOX_ATTN_HND_PROBE"); return e && e[0] == '1'; }();
+    a.hnd_probe = hnd;
+#endif
     const int G = c.Hq / c.Hkv;
     if ((c.max_kvlen + VOX_TC - 1) / VOX_TC > 8) {      // 257..512 visible tokens
         const dim3 grid16(c.Hkv, c.Nq);
