@@ -36,6 +36,9 @@ struct LinArgs {
 #ifndef VOX_XFIRST
 #define VOX_XFIRST 2
 #endif
+#ifndef VOX_KV_ASM
+#define VOX_KV_ASM 1      // decode attention: K/V tile requests written as asm (see k_attn_decode8)
+#endif
 #ifndef VOX_MLP_C2_LATE
 #define VOX_MLP_C2_LATE 0
 #endif
@@ -1954,20 +1957,31 @@ __device__ __forceinline__ int slot_of(const AttnArgs& a, int tok) { return a.pa
 
 // norm (optional) + rope of one head held as one 16-byte chunk per lane (lanes < LPT); result as bf16 bits in
 // `out` (LDS, D elements).  sh: LDS scratch of D floats.  All 64 lanes of the wave must call this.
+struct PrepOps { u32x4_t v, g; float csx, csy; };
+// the three operands (head row, norm weight, this lane's RoPE table entry) are requested together: one exposed L2 latency instead
+// of three dependent ones.  Branch-free (every lane requests something in range, prep_head_apply selects): a conditional load
+// would be joined with its default by a copy behind a wait, in front of whatever the caller requests next.
 template <int D>
-__device__ __forceinline__ void prep_head(const bf16_t* src, const bf16_t* nw, float eps, const float* cs_row,
-                                          int rot, int interleave, float* sh, bf16_t* out, int lane) {
+__device__ __forceinline__ PrepOps prep_head_load(const bf16_t* src, const bf16_t* nw, const float* cs_row, int rot, int lane) {
     constexpr int LPT = D / 8;
-    // the three operands (head row, norm weight, this lane's RoPE table entry) are requested together: one exposed L2
-    // latency instead of three dependent ones
-    uint4 v = make_uint4(0, 0, 0, 0), g = v;
-    if (lane < LPT) {
-        v = reinterpret_cast<const uint4*>(src)[lane];
-        if (nw) g = reinterpret_cast<const uint4*>(nw)[lane];
-    }
+    PrepOps o;
+    const int l = lane < LPT ? lane : 0;
+    o.v = reinterpret_cast<const u32x4_t*>(src)[l];
+    o.g = reinterpret_cast<const u32x4_t*>(nw ? nw : src)[l];
+    const float2 c = *reinterpret_cast<const float2*>((cs_row ? cs_row : reinterpret_cast<const float*>(src)) + 2 * (lane < (rot >> 1) ? lane : 0));
+    o.csx = c.x; o.csy = c.y;
+    return o;
+}
+// the operands are in registers from here on (the caller's own wait may already have covered them)
+__device__ __forceinline__ void prep_head_arrived(PrepOps& o) { asm volatile("" : "+v"(o.v), "+v"(o.g), "+v"(o.csx), "+v"(o.csy)); }
+template <int D>
+__device__ __forceinline__ void prep_head_apply(const PrepOps& o, const bf16_t* nw, float eps, const float* cs_row,
+                                                int rot, int interleave, float* sh, bf16_t* out, int lane) {
+    constexpr int LPT = D / 8;
     const int half = rot >> 1;
-    float2 cs0 = make_float2(1.0f, 0.0f);
-    if (cs_row && lane < half) cs0 = *reinterpret_cast<const float2*>(cs_row + 2 * lane);
+    const bool own = lane < LPT;
+    const uint4 v = own ? as_uint4(o.v) : make_uint4(0, 0, 0, 0), g = own && nw ? as_uint4(o.g) : make_uint4(0, 0, 0, 0);
+    const float2 cs0 = cs_row && lane < half ? make_float2(o.csx, o.csy) : make_float2(1.0f, 0.0f);
     float e[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
     if (nw) {
         float s = sq8(v, 0.0f);
@@ -1997,6 +2011,12 @@ __device__ __forceinline__ void prep_head(const bf16_t* src, const bf16_t* nw, f
             out[ib] = f2bf(__fmaf_rn(x, sn, yc));
         }
     }
+}
+template <int D>
+__device__ __forceinline__ void prep_head(const bf16_t* src, const bf16_t* nw, float eps, const float* cs_row,
+                                          int rot, int interleave, float* sh, bf16_t* out, int lane) {
+    const PrepOps o = prep_head_load<D>(src, nw, cs_row, rot, lane);
+    prep_head_apply<D>(o, nw, eps, cs_row, rot, interleave, sh, out, lane);
 }
 
 template <int D, bool FUSED>
@@ -2163,6 +2183,73 @@ int vox_launch_attn_partial(hipStream_t st, const AttnCall& c) {
     return vox_fail(VOX_ERR_INVALID, "attention: head_dim must be 16, 64 or 128");
 }
 
+// The tile's requests are written as asm: as plain loads the compiler keeps the zero fill and the conditional load in different
+// registers and joins them with a copy after EACH load (s_waitcnt vmcnt(0) + v_mov per request: one memory round trip per request
+// instead of one per tile).  Here the destination is pre-zeroed and tied ("+v"): lanes without a token are masked out by the
+// branch and keep the zeros, and all requests of the tile go out back to back.  The compiler does not know these registers are in
+// flight (a live-range split between request and wait would copy stale data), so kv_wait() follows the requests DIRECTLY: the
+// first head's q / k operands are requested in front of the tile (they were behind it and returned after it anyway — loads
+// return in order), and only the first tile is fetched this way (a second tile is requested under the first one's arithmetic,
+// off the critical path, as plain loads).
+#define VOX_KV_ASM_FETCH \
+    u32x4_t kreg[KVL], vreg[KVL]; \
+    if (!hoist) { \
+_Pragma("unroll") \
+        for (int ci = 0; ci < CPG; ++ci) \
+_Pragma("unroll") \
+            for (int u = 0; u < KVL; ++u) { \
+                const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT; \
+                pgi_pre[ci][u] = pages ? (tok < L - 1 ? pages[page_of(a, tok)] : 0) : row; \
+            } \
+    } \
+    auto pages_arrived = [&]() { /* the first tile's page ids are in registers (no waits between its requests) */ \
+_Pragma("unroll") \
+        for (int u = 0; u < KVL; ++u) asm volatile("" : "+v"(pgi_pre[0][u])); \
+    }; \
+    auto fetch_tile = [&](int ci) { \
+        const int t0 = (grp + NG * ci) * VOX_TC; \
+_Pragma("unroll") \
+        for (int u = 0; u < KVL; ++u) { \
+            kreg[u] = u32x4_t{0u, 0u, 0u, 0u}; \
+            vreg[u] = u32x4_t{0u, 0u, 0u, 0u}; \
+        } \
+_Pragma("unroll") \
+        for (int u = 0; u < KVL; ++u) { \
+            const int i = gt + GT * u, t = i / LPT, j = i % LPT; \
+            const int tok = t0 + t; \
+            if (i < VOX_TC * LPT && tok < L - 1) { \
+                const int pgi = pgi_pre[ci][u]; \
+                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)slot_of(a, tok) * a.Hkv + hk) * D; \
+                const uint4* kp = reinterpret_cast<const uint4*>(base) + j; \
+                const uint4* vp = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D) + j; \
+                if (ci == 0) { \
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(kreg[u]) : "v"(kp) : "memory"); \
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(vreg[u]) : "v"(vp) : "memory"); \
+                } else { \
+                    kreg[u] = *reinterpret_cast<const u32x4_t*>(kp); \
+                    vreg[u] = *reinterpret_cast<const u32x4_t*>(vp); \
+                } \
+            } else if (i < VOX_TC * LPT && tok == L - 1) { \
+                const uint4* vp = reinterpret_cast<const uint4*>(raw + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D) + j; \
+                if (ci == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(vreg[u]) : "v"(vp) : "memory"); \
+                else vreg[u] = *reinterpret_cast<const u32x4_t*>(vp); \
+            } \
+        } \
+    }; \
+    auto kv_wait = [&]() { \
+        static_assert(KVL == 4 || KVL == 8 || KVL == 2 || KVL == 1, "kv_wait lists the tile registers"); \
+        if constexpr (KVL == 8) \
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(kreg[2]), "+v"(kreg[3]), "+v"(kreg[4]), "+v"(kreg[5]), "+v"(kreg[6]), "+v"(kreg[7]), \
+                         "+v"(vreg[0]), "+v"(vreg[1]), "+v"(vreg[2]), "+v"(vreg[3]), "+v"(vreg[4]), "+v"(vreg[5]), "+v"(vreg[6]), "+v"(vreg[7]) :: "memory"); \
+        else if constexpr (KVL == 4) \
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(kreg[2]), "+v"(kreg[3]), \
+                         "+v"(vreg[0]), "+v"(vreg[1]), "+v"(vreg[2]), "+v"(vreg[3]) :: "memory"); \
+        else if constexpr (KVL == 2) \
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(vreg[0]), "+v"(vreg[1]) :: "memory"); \
+        else \
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(kreg[0]), "+v"(vreg[0]) :: "memory"); \
+    };
+
 // ================================================================================================
 // One-launch decode attention for contexts of up to 8 chunks (<= 256 visible tokens): one 1024-thread block per
 // (kv head, row) runs every chunk of that pair — NG groups of 1024 / NG threads, group q taking chunks q, q + NG, ... — and
@@ -2224,6 +2311,9 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
 
     // K/V tiles of this group's chunks.  The row's newest token (index L - 1) comes from the projection output: its V row is
     // loaded into the tile here, its K row (per-head norm + RoPE below) is read from Knew by the score pass.
+#if VOX_KV_ASM
+    VOX_KV_ASM_FETCH
+#else
     uint4 kreg[KVL], vreg[KVL];
     auto fetch_tile = [&](int ci) {
         const int t0 = (grp + NG * ci) * VOX_TC;
@@ -2247,18 +2337,27 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             }
         }
     };
+    auto kv_wait = [&]() {};
+    auto pages_arrived = [&]() {};
+#endif
+    // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave; the first head's operands are requested in
+    // front of the tile
+    int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
+    p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
+    const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
+    auto head_src = [&](int h) { return h == G ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * Gf + g0 + h) * D; };
+    PrepOps po0;
+    pages_arrived();
+    if (wave16 < G + 1) po0 = prep_head_load<D>(head_src(wave16), wave16 == G ? a.kn : a.qn, cs_row, a.rot, lane);
     fetch_tile(0);
+    kv_wait();
+    if (wave16 < G + 1) prep_head_arrived(po0);
     VOX_STAMP(1) VOX_TR(1)
-    {   // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave
-        int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
-        p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
-        const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
-        for (int h = wave16; h < G + 1; h += 16) {
-            const bool isk = h == G;
-            const bf16_t* src = isk ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * Gf + g0 + h) * D;
-            bf16_t* dst = isk ? Knew : reinterpret_cast<bf16_t*>(Qs) + (size_t)h * D;
-            prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, Sh + wave16 * D, dst, lane);
-        }
+    for (int h = wave16; h < G + 1; h += 16) {
+        const bool isk = h == G;
+        bf16_t* dst = isk ? Knew : reinterpret_cast<bf16_t*>(Qs) + (size_t)h * D;
+        if (h == wave16) prep_head_apply<D>(po0, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, Sh + wave16 * D, dst, lane);
+        else prep_head<D>(head_src(h), isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, Sh + wave16 * D, dst, lane);
     }
     VOX_STAMP(2)
 #pragma unroll
@@ -2271,7 +2370,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
 #pragma unroll
         for (int u = 0; u < KVL; ++u) {
             const int i = gt + GT * u;
-            if (i < VOX_TC * LPT) { Ks[grp][i] = kreg[u]; Vs[grp][i] = vreg[u]; }
+            if (i < VOX_TC * LPT) { Ks[grp][i] = as_uint4(kreg[u]); Vs[grp][i] = as_uint4(vreg[u]); }
         }
         if (ci + 1 < CPG) fetch_tile(ci + 1);  // in flight during this chunk's arithmetic
         __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
@@ -3354,6 +3453,9 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
 
     // K/V tiles of this group's chunks.  The row's newest token (index L - 1) comes from the projection output: its V row is
     // loaded into the tile here, its K row (per-head norm + RoPE below) is read from Knew by the score pass.
+#if VOX_KV_ASM
+    VOX_KV_ASM_FETCH
+#else
     uint4 kreg[KVL], vreg[KVL];
     auto fetch_tile = [&](int ci) {
         const int t0 = (grp + NG * ci) * VOX_TC;
@@ -3373,18 +3475,27 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
             }
         }
     };
+    auto kv_wait = [&]() {};
+    auto pages_arrived = [&]() {};
+#endif
+    // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave; the first head's operands are requested in
+    // front of the tile
+    int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
+    p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
+    const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
+    auto head_src = [&](int h) { return h == G ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * Gf + g0 + h) * D; };
+    PrepOps po0;
+    pages_arrived();
+    if (wave16 < G + 1) po0 = prep_head_load<D>(head_src(wave16), wave16 == G ? a.kn : a.qn, cs_row, a.rot, lane);
     fetch_tile(0);
+    kv_wait();
+    if (wave16 < G + 1) prep_head_arrived(po0);
     VOX_STAMP2(1)
-    {   // q heads of this kv head (per-head norm + RoPE) and the new k: one head per wave
-        int p = a.fixed_pos >= 0 ? a.fixed_pos : a.pos[row];
-        p = p < 0 ? 0 : (p >= a.table_max_pos ? a.table_max_pos - 1 : p);
-        const float* cs_row = a.cs ? a.cs + (size_t)p * (a.rot >> 1) * 2 : nullptr;
-        for (int h = wave16; h < G + 1; h += NT / 64) {
-            const bool isk = h == G;
-            const bf16_t* src = isk ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * Gf + g0 + h) * D;
-            bf16_t* dst = isk ? sm.Knew : reinterpret_cast<bf16_t*>(sm.Qs) + (size_t)h * D;
-            prep_head<D>(src, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, sm.Sh + wave16 * D, dst, lane);
-        }
+    for (int h = wave16; h < G + 1; h += NT / 64) {
+        const bool isk = h == G;
+        bf16_t* dst = isk ? sm.Knew : reinterpret_cast<bf16_t*>(sm.Qs) + (size_t)h * D;
+        if (h == wave16) prep_head_apply<D>(po0, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, sm.Sh + wave16 * D, dst, lane);
+        else prep_head<D>(head_src(h), isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, sm.Sh + wave16 * D, dst, lane);
     }
     VOX_STAMP2(2)
 #pragma unroll
@@ -3397,7 +3508,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
 #pragma unroll
         for (int u = 0; u < KVL; ++u) {
             const int i = gt + GT * u;
-            if (i < VOX_TC * LPT) { sm.Ks[grp][i] = kreg[u]; sm.Vs[grp][i] = vreg[u]; }
+            if (i < VOX_TC * LPT) { sm.Ks[grp][i] = as_uint4(kreg[u]); sm.Vs[grp][i] = as_uint4(vreg[u]); }
         }
         if (ci + 1 < CPG) fetch_tile(ci + 1);  // in flight during this chunk's arithmetic
         __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written

@@ -121,6 +121,8 @@ __device__ __forceinline__ float silu_c(float g) {
 }
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 as_uint4(u32x4_t v) { return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 as_uint4(uint4 v) { return v; }
 // 16-byte non-temporal (streaming) load: weights are read once per step by exactly one wave
 __device__ __forceinline__ uint4 ldg_nt(const uint4* p) {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
