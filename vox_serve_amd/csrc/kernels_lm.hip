@@ -1385,13 +1385,19 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
     if (XF) load_x0();
     load_w(0);
     // residual of the outputs this thread will finish (threads < MT*64), requested with the operands instead of after the reduce
-    float res_pre[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!SM && a.residual && tid < MT * 64 && n0 + fr < a.N) {
+    // (branch-free: rows past the tile's last are clamped and their values dropped — a conditional load is joined with its default by
+    // a copy behind a wait of its own, i.e. the four requests became four dependent round trips in front of this wave's MFMAs)
+    u32 res_raw[4], bias_raw;      // bf16 bits, zero-extended by the load itself (no defaults, nothing to compute on arrival: no wait here)
+    if (!SM && __builtin_amdgcn_readfirstlane(wave) < MT) {       // (a scalar branch: nothing below is predicated)
+        const int nc = n0 + fr < a.N ? n0 + fr : a.N - 1;
+        if (a.residual) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int b = (tid >> 6) * 16 + (lane >> 4) * 4 + r;
-            if (b < bt) res_pre[r] = bf2f(a.residual[(size_t)(r0 + b) * a.N + n0 + fr]);
+            for (int r = 0; r < 4; ++r) {
+                const int b = wave * 16 + (lane >> 4) * 4 + r;
+                res_raw[r] = a.residual[(size_t)(r0 + (b < bt ? b : bt - 1)) * a.N + nc];
+            }
         }
+        if (CT == 1 && a.bias) bias_raw = a.bias[nc];
     }
     if (!XF) load_x0();
     __builtin_amdgcn_sched_barrier(0);      // every load above is issued before anything below waits on one of them
@@ -1472,7 +1478,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
             }
             const int n = n0 + 16 * ct + fr;
             if (n < a.N) {           // (tail columns of an N that is not a multiple of 16: vocabulary heads)
-                const float bv = a.bias ? bf2f(a.bias[n]) : 0.0f;
+                const float bv = a.bias ? bf2f((bf16_t)(CT == 1 && !SM ? bias_raw : (u32)a.bias[n])) : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int b = m * 16 + (lane >> 4) * 4 + r;
@@ -1486,7 +1492,7 @@ __global__ __launch_bounds__(512) void k_gemm_fullk(LinArgs a) {
                         if (a.bias) f = f + bv;
                         o = f2bf(f);
                         if (EPI == EPI_SILU) o = f2bf(silu_c(bf2f(o)));
-                        if (a.residual) o = f2bf(res_pre[r] + bf2f(o));
+                        if (a.residual) o = f2bf(bf2f((bf16_t)res_raw[r]) + bf2f(o));
                     }
                     if (a.y_rowmajor) a.y[oi] = o;
                     if (a.y_frag) a.y_frag[frag_off(r0 + b, n, a.N)] = o;
