@@ -36,6 +36,9 @@ struct LinArgs {
 #ifndef VOX_XFIRST
 #define VOX_XFIRST 2
 #endif
+#ifndef VOX_GRAN_ASM
+#define VOX_GRAN_ASM 2    // persistent kernels: a poll pass's granule requests written as asm (see gran_poll_pass / gran_poll_all); 0: atomic loads
+#endif
 #ifndef VOX_KV_ASM
 #define VOX_KV_ASM 1      // decode attention: K/V tile requests written as asm (see k_attn_decode8)
 #endif
@@ -3057,11 +3060,93 @@ struct DepthStepArgs {
 #ifndef VOX_DS_EXTRA_BARRIERS
 #define VOX_DS_EXTRA_BARRIERS 1
 #endif
+// One poll pass over PER granules of a thread: the requests go out back to back and ONE wait follows.  Written as asm: as atomic loads the
+// compiler interleaves each tag compare (and its wait) with the next request, and a predicated request gets a block of its own — a pass of
+// four granules was three dependent round trips to the memory side, on the critical path of every hand-off.  Same instruction as
+// __hip_atomic_load(relaxed, agent scope): global_load_dwordx2 ... sc1; payload and tag share the 8 bytes, so no ordering is needed.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int PER, int Q0 = 0, int Q1 = PER>
+__device__ __forceinline__ void gran_poll_pass(const unsigned long long* const (&ptr)[PER], u32x2_t (&v)[PER]) {
+    static_assert(PER >= 1 && PER <= 6, "gran_poll_pass lists the payload registers");
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[q]) : "v"(ptr[q]) : "memory");
+    constexpr int N = Q1 - Q0;
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]) :: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]) :: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]), "+v"(v[Q0 + 2]) :: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]), "+v"(v[Q0 + 2]), "+v"(v[Q0 + 3]) :: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]), "+v"(v[Q0 + 2]), "+v"(v[Q0 + 3]), "+v"(v[Q0 + 4]) :: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]), "+v"(v[Q0 + 2]), "+v"(v[Q0 + 3]), "+v"(v[Q0 + 4]), "+v"(v[Q0 + 5]) :: "memory");
+}
+// The gather of a thread's PER granules.  VOX_GRAN_ASM = 2: the thread's FIRST granule is the sentinel — polled alone until its tag matches
+// (a waiting block asks for 1 / PER of the vector per pass: polls travel the same fabric as the producers' weight streams and publishes),
+// then the others in one batch (repeated for stragglers).  = 1: all PER per pass.
+template <int PER, int TOTAL, typename InRange>
+__device__ __forceinline__ void gran_poll_all(const unsigned long long* g, int tid, const unsigned long long* const (&gp)[PER], u32x2_t (&gv)[PER], unsigned tag,
+                                              InRange in_range, unsigned* err, unsigned code, unsigned max_spins) {
+    unsigned spin = 0;
+    auto give_up = [&]() {
+        if (spin > max_spins) { atomicCAS(err, 0u, code); return true; }
+        if ((spin & 63u) == 63u && __hip_atomic_load(err, VOX_RLX_AGENT) != 0u) return true;      // somebody already gave up
+        ++spin;
+        if (VOX_DS_SLEEP) __builtin_amdgcn_s_sleep(VOX_DS_SLEEP);
+        return false;
+    };
+    if constexpr (VOX_GRAN_ASM == 3) {
+        // one wave polls 64 sentinels spread over the vector (every 1 / 64 of it: different producers), the others wait at the barrier
+        if ((tid >> 6) == 7) {
+            const unsigned long long* sp[1] = {g + (size_t)(tid & 63) * (TOTAL / 64)};
+            u32x2_t sv[1];
+            for (;;) {
+                gran_poll_pass<1>(sp, sv);
+                if (sv[0].y == tag || give_up()) break;
+            }
+        }
+        __syncthreads();
+        for (;;) {
+            gran_poll_pass<PER>(gp, gv);
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) ok = ok && (!in_range(q) || gv[q].y == tag);
+            if (ok || give_up()) break;
+        }
+    } else if constexpr (VOX_GRAN_ASM == 2 && PER > 1) {
+        for (;;) {
+            gran_poll_pass<PER, 0, 1>(gp, gv);
+            if (gv[0].y == tag || give_up()) break;
+        }
+        for (;;) {
+            gran_poll_pass<PER, 1, PER>(gp, gv);
+            bool ok = true;
+#pragma unroll
+            for (int q = 1; q < PER; ++q) ok = ok && (!in_range(q) || gv[q].y == tag);
+            if (ok || give_up()) break;
+        }
+    } else {
+        for (;;) {
+            gran_poll_pass<PER>(gp, gv);
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) ok = ok && (!in_range(q) || gv[q].y == tag);
+            if (ok || give_up()) break;
+        }
+    }
+}
 template <int TOTAL>
 __device__ __forceinline__ void gran_gather_lds(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins) {
     constexpr int NP = 64 * VOX_DS_PW, PER = (TOTAL + NP - 1) / NP;
     const int p = tid - (512 - NP);
     if (p < 0) return;
+#if VOX_GRAN_ASM
+    u32x2_t gv[PER];
+    const unsigned long long* gp[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) gp[q] = g + (p + NP * q < TOTAL ? p + NP * q : p);      // (past the vector: the thread's first granule again, ignored)
+    gran_poll_all<PER, TOTAL>(g, tid, gp, gv, tag, [&](int q) { return p + NP * q < TOTAL; }, err, code, max_spins);
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (p + NP * q < TOTAL) dst[p + NP * q] = gv[q].x;
+#else
     unsigned val[PER];
     for (unsigned spin = 0;; ++spin) {
         bool ok = true;
@@ -3081,6 +3166,7 @@ __device__ __forceinline__ void gran_gather_lds(const unsigned long long* g, uns
 #pragma unroll
     for (int q = 0; q < PER; ++q)
         if (p + NP * q < TOTAL) dst[p + NP * q] = val[q];
+#endif
 }
 __device__ __forceinline__ void gran_write(unsigned long long* g, unsigned tag, bf16_t lo, bf16_t hi) {
     __hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned)lo | ((unsigned)hi << 16), VOX_RLX_AGENT);
@@ -3649,6 +3735,16 @@ struct TalkerMlpArgs {
 template <int TOTAL>
 __device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins) {
     constexpr int PER = (TOTAL + 511) / 512;
+#if VOX_GRAN_ASM
+    u32x2_t gv[PER];
+    const unsigned long long* gp[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) gp[q] = g + (tid + 512 * q < TOTAL ? tid + 512 * q : tid);
+    gran_poll_all<PER, TOTAL>(g, tid, gp, gv, tag, [&](int q) { return tid + 512 * q < TOTAL; }, err, code, max_spins);
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (tid + 512 * q < TOTAL) dst[tid + 512 * q] = gv[q].x;
+#else
     unsigned val[PER];
     for (unsigned spin = 0;; ++spin) {
         bool ok = true;
@@ -3667,6 +3763,7 @@ __device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g,
 #pragma unroll
     for (int q = 0; q < PER; ++q)
         if (tid + 512 * q < TOTAL) dst[tid + 512 * q] = val[q];
+#endif
 }
 
 // ATTN: the whole decoder layer of a one-request frame in ONE launch — blocks 0..15 first run the decode attention of one q head each
