@@ -36,6 +36,10 @@ struct LinArgs {
 #ifndef VOX_XFIRST
 #define VOX_XFIRST 2
 #endif
+#define VOX_CONST_AS __attribute__((address_space(4)))
+#ifndef VOX_DS_PICK_LATE
+#define VOX_DS_PICK_LATE 0      // 1: the step input (pick) behind layer 0's first weight requests — measured: no difference, six spilled registers
+#endif
 #ifndef VOX_GRAN_ASM
 #define VOX_GRAN_ASM 2    // persistent kernels: a poll pass's granule requests written as asm (see gran_poll_pass / gran_poll_all); 0: atomic loads
 #endif
@@ -3190,22 +3194,19 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
     // test), [3] the test hook "block 1 withholds its first publish of this launch" (vox_qwen3_persist_inject) — are read by ONE thread
     // per block (L1-bypassing loads: 2048 waves asking for the same line would queue) and reach the others through LDS at the first
     // barrier of stage A, in front of the launch's first publish.
-    __shared__ unsigned wsh[4];
-    if (tid == 0) {
-        wsh[0] = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
-        wsh[2] = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);
-        wsh[3] = __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT);
-    }
     unsigned ep = 0, max_spins = 0, tag0 = 0;
     bool drop_first = false;
     auto tagof = [&](int l, int st) { return tag0 + 1u + (unsigned)(l * 4 + st); };
     VOX_STAMP2_DECL
     VOX_STAMP2(0)
+    __shared__ unsigned pick_red[8];
+    // The step's input row (into xb).  Called in layer 0's stage A when its weight rows have been requested: the pick is a chain of two
+    // dependent round trips (the logits, then the picked id's table row) and the weights travel under it instead of behind it.
+    auto load_step_input = [&]() {
     if (a.pick_logits) {
         // The previous step's codebook, picked here instead of by a sampler launch in between (greedy frames): every block takes the
         // first maximum of the 2048 logits — order of (value, lowest index), the sampler's — and reads the step's input row of that id
         // from the tabulated projection; block 0 records the id and adds the id's embedding to the next frame's feature row.
-        __shared__ unsigned pick_red[8];
         unsigned best = 0;
         auto take = [&](unsigned h16, int v) {
             bf16_t b = (bf16_t)h16;
@@ -3246,8 +3247,21 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
         // x of the step: plain row written by the previous kernel
         reinterpret_cast<unsigned*>(xb)[tid] = reinterpret_cast<const unsigned*>(a.x_in)[tid];
     }
+    };
+#if !VOX_DS_PICK_LATE
+    load_step_input();
+#endif
     for (int l = 0; l < a.n_layers; ++l) {
-        const DepthLayerW w = a.layers[l];
+        // (constant address space: scalar loads straight into scalar registers — as plain loads the table row came through vector registers, a
+        // round trip and nine readfirstlanes in front of the layer's first weight request)
+        DepthLayerW w;
+        {
+            static_assert(sizeof(DepthLayerW) == 9 * sizeof(void*), "DepthLayerW: nine pointers");
+            const VOX_CONST_AS unsigned long long* lp = (const VOX_CONST_AS unsigned long long*)(a.layers + l);
+            const bf16_t** wp = reinterpret_cast<const bf16_t**>(&w);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wp[i] = reinterpret_cast<const bf16_t*>(lp[i]);
+        }
         // ---------------- stage A: qkv = Wqkv . rmsnorm(x, ln1)  (2048 column pairs: one per wave of every block) ----------------
         {
             const int pr = blk * 8 + wave, n0 = 2 * pr;
@@ -3267,8 +3281,18 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             const uint4 wo00 = wor0[0], wo01 = wor0[64], wo02 = wor0[128], wo03 = wor0[192];
             const uint4 wo10 = wor1[0], wo11 = wor1[64], wo12 = wor1[128], wo13 = wor1[192];
             if (l > 0) gran_gather_lds<512>(a.gx, tagof(l - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x100u + l, max_spins);
-            __syncthreads();                               // x of this layer is in xb; (l = 0) the state words are in wsh
-            if (l == 0) { ep = wsh[0]; max_spins = wsh[2]; drop_first = blk == 1 && wsh[3] != 0u; tag0 = ep * 64u; }
+            if (l == 0) {
+#if VOX_DS_PICK_LATE
+                load_step_input();
+#endif
+                // the launch's state words: plain loads of a uniform address (scalar loads: the words were written before this launch started —
+                // the previous launch's block 0, or the host — and a kernel boundary stands in between), BEHIND the step's first weight
+                // requests: as L1-bypassing vector loads at the top of the kernel they were three dependent round trips in front of them
+                asm volatile("" ::: "memory");
+                const VOX_CONST_AS unsigned* wp = (const VOX_CONST_AS unsigned*)a.epoch;      // (constant address space: scalar loads)
+                ep = wp[0]; max_spins = wp[2]; drop_first = blk == 1 && wp[3] != 0u; tag0 = ep * 64u;
+            }
+            __syncthreads();                               // x of this layer is in xb
             uint4 xv[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) xv[j] = xb[lane + 64 * j];
@@ -3800,7 +3824,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     // after entry instead of 3.2, tools/attn_in_layer_stamps.py.)
     __shared__ unsigned wsh[4];
     unsigned w_ep = 0, w_spins = 0, w_inj = 0;
-    if (tid == 0 || !ATTN) {      // (without the attention in front every thread reads them itself: no barrier stands before stage O)
+    if (ATTN && tid == 0) {
         w_ep = __hip_atomic_load(a.epoch, VOX_RLX_AGENT);
         w_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);
         w_inj = __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT);
@@ -3826,7 +3850,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wo[r][j] = ldg_nt(wr + lane + 64 * j);
             }
-            resw = reinterpret_cast<const unsigned*>(a.x_in)[blk * 4 + wave];
+            if (ATTN) resw = reinterpret_cast<const unsigned*>(a.x_in)[blk * 4 + wave];
         }
     };
     if (!attn_blk) load_o();
@@ -3853,6 +3877,22 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         park_words();
     }
     if (ATTN) __syncthreads();                         // state words parked; (attention blocks) the attention's LDS is dead: xb / hb / ab may be written
+    uint4 av[4];
+    if (!ATTN && wave < 4) {       // stage O's operand row (a plain row of the attention launch in front): requested before anything below waits
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[j] = reinterpret_cast<const uint4*>(a.attn)[lane + 64 * j];
+        // (the wave's residual pair: a uniform address, i.e. a scalar load with a wait of its own — behind the opening requests, not between them)
+        asm volatile("" ::: "memory");
+        resw = reinterpret_cast<const unsigned*>(a.x_in)[blk * 4 + wave];
+    }
+    if (!ATTN) {
+        // (without the attention in front: plain loads of a uniform address — scalar loads; the words were written before this launch started
+        // and a kernel boundary stands in between — BEHIND the opening weight requests: as L1-bypassing vector loads at the top of the kernel
+        // they were a round trip in front of every wave's first weight request)
+        asm volatile("" ::: "memory");
+        const VOX_CONST_AS unsigned* wp = (const VOX_CONST_AS unsigned*)a.epoch;      // (constant address space: scalar loads)
+        w_ep = wp[0]; w_spins = wp[2]; w_inj = wp[3];
+    }
     const unsigned ep = ATTN ? wsh[0] : w_ep, max_spins = ATTN ? wsh[2] : w_spins;
     const bool drop_first = blk == 1 && (ATTN ? wsh[3] : w_inj) != 0u;
     const unsigned tag0 = ep * 64u;
@@ -3876,9 +3916,10 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     MLP_TR(2)
     if (wave < 4) {
         const int pr = blk * 4 + wave;
-        uint4 av[4];
+        if (ATTN) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) av[j] = ATTN ? ab[lane + 64 * j] : reinterpret_cast<const uint4*>(a.attn)[lane + 64 * j];
+            for (int j = 0; j < 4; ++j) av[j] = ab[lane + 64 * j];
+        }
         float acc[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
