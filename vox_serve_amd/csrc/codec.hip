@@ -637,7 +637,9 @@ template <int KB, int NT, bool LN, int MT, int WV>
 __global__ __launch_bounds__(64 * WV) void k_rows_gemm(ConvGemmArgs a) {
     __shared__ float red[WV][MT * NT][256];
     __shared__ float ln_stat[LN ? 2 * WV * 16 * MT : 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave index provably uniform: the tap of a k-block, and with it a.off[tap], is then a scalar — read per lane from the argument
+    // block it was a dependent vector load, one round trip in front of every operand row's address)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.y * 16 * MT, n0 = blockIdx.x * 16 * NT;
     const int kpt = a.Cin >> 5;                     // k-blocks per tap
@@ -759,9 +761,29 @@ __global__ __launch_bounds__(64 * WV) void k_rows_gemm(ConvGemmArgs a) {
             for (int r = 0; r < 4; ++r) red[wave][mt * NT + t][r * 64 + lane] = acc[mt][t][r];
     __syncthreads();
     // work item e = (tile, accumulator component r): row m0 + 16 mt + 4 (lane / 16) + r, column n0 + 16 t + lane % 16; wave w takes
-    // the items w, w + WV, ...
+    // the items w, w + WV, ...  Two passes: every operand of every item of this wave (bias, scale, row scale, residual, Snake constants)
+    // is requested first, branch-free (clamped indices), THEN the arithmetic and the stores — item by item the loads of item i + 1 could not
+    // move above the stores of item i (the residual may alias the output), and an item cost up to three dependent round trips: the
+    // epilogue was most of this kernel's time.  Per element the operations and their order are unchanged.
+    constexpr int NE = (MT * NT * 4 + WV - 1) / WV;
+    float e_b[NE], e_s[NE], e_rs[NE], e_res[NE], e_a[NE], e_i[NE];
+    const int Mc = a.M - 1, Nc = a.N - 1;
 #pragma unroll
-    for (int e = wave; e < MT * NT * 4; e += WV) {
+    for (int i = 0; i < NE; ++i) {
+        const int e = wave + i * WV, tile = (e >> 2) < MT * NT ? (e >> 2) : 0, r = e & 3, mt = tile / NT, t = tile - mt * NT;
+        int m = m0 + mt * 16 + kq * 4 + r, n = n0 + t * 16 + fr;
+        m = m < Mc ? m : Mc; n = n < Nc ? n : Nc;
+        e_b[i] = a.bias ? a.bias[n % a.bias_mod] : 0.0f;
+        e_s[i] = a.scale ? a.scale[n] : 1.0f;
+        e_rs[i] = a.rscale ? a.rscale[m] : 1.0f;
+        e_res[i] = a.res ? a.res[(size_t)m * a.N + n] : 0.0f;
+        e_a[i] = a.out2 ? a.sn_alpha[n % a.sn_mod] : 0.0f;
+        e_i[i] = a.out2 ? a.sn_invb[n % a.sn_mod] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = wave + i * WV;
+        if (e >= MT * NT * 4) continue;
         const int tile = e >> 2, r = e & 3, mt = tile / NT, t = tile - mt * NT;
         const int m = m0 + mt * 16 + kq * 4 + r, n = n0 + t * 16 + fr;
         if (m >= a.M || n >= a.N) continue;
@@ -769,16 +791,16 @@ __global__ __launch_bounds__(64 * WV) void k_rows_gemm(ConvGemmArgs a) {
         float v = red[0][tile][idx];
 #pragma unroll
         for (int w = 1; w < WV; ++w) v += red[w][tile][idx];
-        v += a.bias ? a.bias[n % a.bias_mod] : 0.0f;
-        const float sv = a.scale ? a.scale[n] : 1.0f;
+        v += e_b[i];
+        const float sv = e_s[i];
         if (a.gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-        if (a.rscale) v = a.rscale[m] * v;
+        if (a.rscale) v = e_rs[i] * v;
         const size_t o = (size_t)m * a.N + n;
-        if (a.res) v = a.res[o] + sv * v;
+        if (a.res) v = e_res[i] + sv * v;
         else if (a.scale) v = sv * v;
         if (a.out) a.out[o] = v;
         if (a.out2) {
-            const float sv2 = snake_f(v, a.sn_alpha[n % a.sn_mod], a.sn_invb[n % a.sn_mod]);
+            const float sv2 = snake_f(v, e_a[i], e_i[i]);
             if (a.out2_s2) {
                 const int cw = a.sn_mod, jj = n / cw, c = n - jj * cw;
                 bf16_t* r16 = reinterpret_cast<bf16_t*>(a.out2 + (size_t)m * a.N) + (size_t)jj * 2 * cw;
