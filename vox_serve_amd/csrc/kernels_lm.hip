@@ -2047,6 +2047,14 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
 
     const int c = blockIdx.x, hk = blockIdx.y, row = blockIdx.z;
     const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
+    // (fused form) where the row's new token is appended, and its V row: requested with the row length instead of behind the tile's
+    // barrier, where they were three dependent round trips (page, slot, V row) in front of the scores
+    int pg_pre = row, sl_pre = 0;
+    uint4 vx_pre = make_uint4(0, 0, 0, 0);
+    if (FUSED) {
+        if (!a.identity_pages) { pg_pre = a.page[row]; sl_pre = a.slot[row]; }
+        vx_pre = reinterpret_cast<const uint4*>(a.qkv + (size_t)row * (a.Hq + 2 * a.Hkv) * D + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D)[threadIdx.x % LPT];
+    }
     const int t0 = c * VOX_TC;
     if (t0 >= L) return;
     const int nt = (L - t0) < VOX_TC ? (L - t0) : VOX_TC;
@@ -2102,12 +2110,11 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
     __syncthreads();
     if (own_last) {
         // place the new token into the tile and append it to the paged cache (page < 0: graph padding row)
-        const bf16_t* vraw = a.qkv + (size_t)row * (a.Hq + 2 * a.Hkv) * D + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D;
-        const int pg = a.identity_pages ? row : a.page[row];
-        const int sl = a.identity_pages ? (L - 1) : a.slot[row];
+        const int pg = pg_pre;
+        const int sl = a.identity_pages ? (L - 1) : sl_pre;
         if (tid < LPT) {
             const uint4 kx = reinterpret_cast<const uint4*>(Knew)[tid];
-            const uint4 vx = reinterpret_cast<const uint4*>(vraw)[tid];
+            const uint4 vx = vx_pre;
             Ks[(nt - 1) * LPT + tid] = kx;
             Vs[(nt - 1) * LPT + tid] = vx;
             if (pg >= 0) {
