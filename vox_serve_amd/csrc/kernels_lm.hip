@@ -2149,24 +2149,33 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnArgs a) {
         if (t == 0) Ms[g] = m;
     }
     __syncthreads();
-    // PV: one thread per (q head, d); sequential over tokens
-    const bf16_t* Vb = reinterpret_cast<const bf16_t*>(Vs);
-    for (int e = tid; e < G * D; e += 256) {
-        const int g = e / D, d = e % D;
-        float o = 0.0f, l = 0.0f;
-        for (int t = 0; t < nt; ++t) {
+    // PV: one thread per (q head, pair of dims); sequential over the tokens of the zero-padded tile (p = 0 and V = 0 beyond the chunk's last
+    // token: l + 0 and fma(0, 0, o) leave the sums bit-unchanged), so the loop has no trip count to wait for and reads 32-bit words
+    const u32* Vw = reinterpret_cast<const u32*>(Vs);
+    for (int e = tid; e < G * (D / 2); e += 256) {
+        const int g = e / (D / 2), dp = e % (D / 2);
+        float o0 = 0.0f, o1 = 0.0f, l = 0.0f;
+#pragma unroll
+        for (int t = 0; t < VOX_TC; ++t) {
             const float p = S[g][t];
+            const u32 vw = Vw[t * (D / 2) + dp];
             l = l + p;
-            o = __fmaf_rn(p, bf2f(Vb[t * D + d]), o);
+            o0 = __fmaf_rn(p, bflo(vw), o0);
+            o1 = __fmaf_rn(p, bfhi(vw), o1);
         }
         const size_t hi = (size_t)row * a.Hq + hk * G + g;
+        const int d = 2 * dp;
         if (a.out) {   // one chunk: w = exp2(0) = 1, O = fma(o,1,0) = o, L = l
-            a.out[hi * D + d] = f2bf(o / l);
-            if (a.out_frag) a.out_frag[frag_off(row, (hk * G + g) * D + d, a.Hq * D)] = f2bf(o / l);
+            const bf16_t r0 = f2bf(o0 / l), r1 = f2bf(o1 / l);
+            *reinterpret_cast<u32*>(a.out + hi * D + d) = (u32)r0 | ((u32)r1 << 16);
+            if (a.out_frag) {
+                a.out_frag[frag_off(row, (hk * G + g) * D + d, a.Hq * D)] = r0;
+                a.out_frag[frag_off(row, (hk * G + g) * D + d + 1, a.Hq * D)] = r1;
+            }
             continue;
         }
-        a.part_o[(hi * a.max_chunks + c) * D + d] = o;
-        if (d == 0) {
+        *reinterpret_cast<float2*>(a.part_o + (hi * a.max_chunks + c) * D + d) = make_float2(o0, o1);
+        if (dp == 0) {
             a.part_ml[(hi * a.max_chunks + c) * 2 + 0] = Ms[g];
             a.part_ml[(hi * a.max_chunks + c) * 2 + 1] = l;
         }
