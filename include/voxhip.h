@@ -228,9 +228,11 @@ int vox_qwen3_depth_persist_status(vox_qwen3* m, int32_t* enabled, uint32_t* err
  *                            their inputs (ids / masks / features of their rows, the frame counter) to a two-slot shadow.  Call before
  *                            the first frame graph is captured.
  *   vox_qwen3_frame_restore  puts the inputs of the frame `back` frames ago (1 = the last, 2 = the one before: one frame may be in
- *                            flight behind a failed one) back in place, rows 0..n_rows-1 and the counter (n_rows = 0: the counter only —
- *                            a prefill's rows are staged by the caller); the status word reads 0 afterwards, 0x7fffffff if no such frame
- *                            is in the shadow.
+ *                            flight behind a failed one; 0 = the frame that had been started from the counter's CURRENT value, i.e.
+ *                            during a replay the launch behind the failed one, when the caller had staged its inputs by hand) back
+ *                            in place, rows 0..n_rows-1 and the counter (n_rows = 0: the counter only — a prefill's rows are staged
+ *                            by the caller); the status word reads 0 afterwards, 0x7fffffff if no such frame is in the shadow (and
+ *                            nothing was written: callers validate with it BEFORE they reset anything).
  *   vox_qwen3_persist_reset  waits for the device, clears the error words, re-zeroes the hand-off granules; disable != 0 turns the
  *                            persistent kernels off: later frames take the bit-identical launch chains (drop graphs captured before).
  *   vox_qwen3_persist_set_spins   bound of every poll loop in passes (>= ~0.5 us each; default 40000 = >= 20 ms, or VOX_PERSIST_SPINS).

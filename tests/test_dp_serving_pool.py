@@ -152,8 +152,16 @@ def test_requests_of_a_daemon_that_dies_are_answered_with_an_error(monkeypatch):
                 assert c["status"] == "error" and "rank 1" in c["reason"] and pcm[r] == b""
             else:
                 assert c == {"status": "completed", "reason": "stop_id_encountered"} and len(pcm[r]) > 0
+        # generate(): the one-call form must not hand back empty audio for a request that FAILED (round-5 advice): request 4 goes to
+        # the live rank 0, request 5 to the dead rank 1 and raises with the reason; both entries are released
+        assert len(pool.generate("abc", timeout_s=60, request_id="g4", block=True)) > 0
+        with pytest.raises(RuntimeError, match="rank 1"):
+            pool.generate("abc", timeout_s=60, request_id="g5", block=True)
+        assert "g4" not in pool.pending_requests and "g5" not in pool.pending_requests
+        threads = [pool.message_thread, pool.sender_thread] + list(pool.rank_threads)
     finally:
         pool.cleanup()
+    assert not any(t.is_alive() for t in threads)                 # cleanup() joins its threads before it closes their sockets
 
 
 def _serve_one(extra_env, monkeypatch):

@@ -628,6 +628,83 @@ def test_persistent_handoff_timeout_with_one_frame_in_flight_behind_it(dev, monk
     ea.close(); eb.close()
 
 
+def test_persistent_handoff_timeout_behind_which_the_caller_had_restaged_the_inputs(dev, monkeypatch):
+    """Round-5 advice: recover(back=2) used to raise when the launch behind the failed one had hand-staged inputs (`note_restage`: the
+    batch composition changed) — AFTER it had already reset the persistent state and dropped the graphs.  Now the follower's own staged
+    inputs come back from ITS shadow slot (every decode frame saves its inputs on entry) and both launches are replayed: ids, logits,
+    fed-back inputs and K/V equal a healthy engine driven the same way."""
+    from vox_serve_amd.engine import Qwen3Cfg
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ea, eb = _persist_pair(dev, monkeypatch, cfg, W)
+    if eb.depth_persist_status()[0] != 3:
+        pytest.skip("persistent kernels not available on this part (< 256 CUs)")
+    N.check(eb.L.vox_qwen3_persist_set_spins(eb.h, 2000))
+    sc = ea.sampling_cfg(greedy=True)
+    g = torch.Generator(device=dev).manual_seed(11)
+    feat = (torch.randn(1, cfg.talker.hidden, generator=g, device=dev) * 0.3).to(torch.bfloat16)
+
+    def restage(e):                                        # what ModelWorker.run_lm_decode does when the resident rows change
+        e.note_restage()
+        e.input_ids.zero_(); e.input_ids[:, -1] = cfg.tts_pad_id; e.input_ids[:, 0] = 23
+        e.input_masks[:1] = 1
+        e.input_features[:1].copy_(feat)
+    for e in (ea, eb):
+        for f in range(6):
+            if e is eb and f == 3:
+                N.check(eb.L.vox_qwen3_persist_inject(eb.h, 0, 1))
+            if f == 4:
+                restage(e)                                 # frame 4 does not start from frame 3's feedback
+            _one_frame(e, f, sc)
+            if e is eb and f == 4:                         # frame 3's status is read with frame 4 in flight behind it
+                torch.cuda.synchronize()
+                assert int(eb.status_row[0]) != 0
+                seen = []
+                eb.recover(back=2, code=int(eb.status_row[0]), on_first_done=lambda: seen.append(eb.out_ids[:1].clone()))
+                assert len(seen) == 1
+            torch.cuda.synchronize()
+            if e is ea and f == 3:
+                ids3 = ea.out_ids[:1].clone()
+    assert torch.equal(seen[0], ids3)                      # the failed frame's re-read outputs
+    assert len(eb.persist_failures) == 1 and int(eb.status_row[0]) == 0
+    for name in ("out_ids", "out_logits", "out_depth_logits", "next_features", "input_features", "input_ids", "rng_offset"):
+        assert torch.equal(getattr(ea, name), getattr(eb, name)), name
+    assert torch.equal(ea.kv, eb.kv)
+    ea.close(); eb.close()
+
+
+def test_a_handoff_timeout_that_cannot_be_replayed_raises_before_anything_is_reset(dev, monkeypatch):
+    """recover() checks replayability FIRST: with the failed launch's plan block gone from the pinned ring it raises, and the engine
+    is exactly as the failure left it — persistent kernels still enabled, the sticky error word still set (every later frame keeps
+    reporting the failure), graphs kept."""
+    from vox_serve_amd.engine import Qwen3Cfg
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ea, eb = _persist_pair(dev, monkeypatch, cfg, W)
+    ea.close()
+    if eb.depth_persist_status()[0] != 3:
+        pytest.skip("persistent kernels not available on this part (< 256 CUs)")
+    N.check(eb.L.vox_qwen3_persist_set_spins(eb.h, 2000))
+    sc = eb.sampling_cfg(greedy=True)
+    for f in range(3):
+        if f == 2:
+            N.check(eb.L.vox_qwen3_persist_inject(eb.h, 0, 1))
+        _one_frame(eb, f, sc)
+    torch.cuda.synchronize()
+    code = int(eb.status_row[0])
+    assert code != 0
+    n_graphs = len(eb._graphs)
+    for _ in range(eb.PLAN_RING):                          # the ring moves on: the failed launch's plan block is overwritten
+        eb.upload_plan(pos=[1], kvlen=[1], page=[0], slot=[0], indptr=[0, 1], indices=[0])
+    with pytest.raises(N.VoxError, match="plan block"):
+        eb.recover(back=1, code=code)
+    en, err = eb.depth_persist_status()
+    assert en == 3 and err == code and len(eb._graphs) == n_graphs and eb.persist_failures == []
+    eb.close()
+
+
 def test_persistent_kernels_with_a_codec_chunk_on_a_second_stream(dev, monkeypatch):
     """The case the hand-off comment names: the 256 resident blocks of a persistent launch wait for CUs held by another stream's
     kernels.  One-request frames replay while Qwen3 codec chunks of 8 requests run beside them on a second stream: no hand-off may

@@ -682,3 +682,23 @@ def test_device_bound_tokenizers_and_per_device_contexts():
     import vox_serve_amd.tokenizer.qwen3_codec as qc, vox_serve_amd.tokenizer.snac as sn
     for cls in (c2.CosyVoice2Decoder, gl.GLMAudioDecoder, mi.MimiDecoder, qc.Qwen3TTSDecoder, sn.SNACDecoder):
         assert hasattr(cls.__init__, "__wrapped__"), cls
+
+
+def test_status_row_gate_is_on_the_buffer_not_on_the_inherited_method():
+    """Round-5 advice (high): LMEngine / CSMEngine subclass Qwen3Engine without running its __init__, so they HAVE snapshot_src /
+    read_ids but no `_out_block`; the worker's async snapshot gated on the method and crashed for every non-Qwen3 model."""
+    import types
+    from vox_serve_amd import _native as N
+    from vox_serve_amd.engine import CSMEngine, LMEngine, Qwen3Engine
+    from vox_serve_amd.worker.base import engine_has_status_row
+    for cls in (LMEngine, CSMEngine):
+        e = object.__new__(cls)
+        assert hasattr(e, "snapshot_src") and not engine_has_status_row(e)
+        with pytest.raises(N.VoxError, match="no status row"):
+            e.snapshot_src(2)
+    q = object.__new__(Qwen3Engine)
+    assert not engine_has_status_row(q)                       # not constructed: no buffer yet
+    q._out_block = torch.zeros(3, 17, dtype=torch.int32)
+    q.status_row = q._out_block[0]
+    assert engine_has_status_row(q) and q.snapshot_src(1).shape == (2, 17)
+    assert not engine_has_status_row(types.SimpleNamespace(out_ids=torch.zeros(2)))

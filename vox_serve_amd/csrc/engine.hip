@@ -393,6 +393,33 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
 
 extern "C" {
 
+// Persistent MLP half for one-row decode layers (k_talker_mlp): the Qwen3-TTS talker shape on a part with >= 256 CUs;
+// VOX_TALKER_PERSIST=0 keeps the three launches.  Only an owner that ships the launch's error word to the host with every frame
+// (vox_qwen3: the status row, engine.hip k_rng_bump) may turn it on: a bare vox_stack, vox_lm and vox_csm have no status row,
+// so a hand-off timeout there would return garbage silently — they keep the launch chain (bit-identical).
+static int stack_enable_mlp_persist(vox_stack* s) {
+    TalkerMlpCall probe;
+    probe.hidden = s->cfg.hidden; probe.nq = s->cfg.heads * s->cfg.head_dim; probe.ffn = s->cfg.ffn;
+    const char* e = getenv("VOX_TALKER_PERSIST");
+    const bool want = e ? e[0] == '1' : true;
+    int n_cu = 0, dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
+    if (want && n_cu >= 256 && vox_talker_mlp_supported(probe) && !s->cfg.qkv_bias) {
+        if (hipMalloc(&s->mlp_gran, 5120 * 8) != hipSuccess || hipMalloc((void**)&s->mlp_words, 16) != hipSuccess)
+            return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc");
+        VOX_HIP(hipMemset(s->mlp_gran, 0, 5120 * 8));
+        const unsigned words[4] = {1u, 0u, vox_persist_spins_default(), 0u};      // epoch, error, poll bound, test hook
+        VOX_HIP(hipMemcpy(s->mlp_words, words, 16, hipMemcpyHostToDevice));
+        s->mlp_persist = 1;
+        // the decode attention INSIDE that launch (blocks 0..15): built, bit-identical, and measured equal to the two-launch form
+        // (2.447 vs 2.442 ms per frame: what the overlapped weight stream saves, the 512-thread attention under that stream
+        // loses — DESIGN.md §3.1); opt-in for A/B
+        const char* ea = getenv("VOX_TALKER_ATTN");
+        s->mlp_attn = (ea && ea[0] == '1') && s->cfg.heads == 16 && s->cfg.kv_heads == 8 && s->cfg.head_dim == 128;
+    }
+    return VOX_OK;
+}
 int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_weights* layers, const void* final_norm,
                      const float* rope, int rope_max_pos, vox_stack** out) {
     if (!ctx || !cfg || !layers || !out) return vox_fail(VOX_ERR_INVALID, "stack_create: NULL argument");
@@ -450,30 +477,6 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
 #ifdef VOX_DEV_KNOBS
     if (const char* e = getenv("VOX_STACK_KEEP")) s->keep_weights = atoi(e);
 #endif
-    {
-        // persistent MLP half for one-row decode layers (k_talker_mlp): the Qwen3-TTS talker shape on a part with >= 256 CUs;
-        // VOX_TALKER_PERSIST=0 keeps the three launches
-        TalkerMlpCall probe;
-        probe.hidden = s->cfg.hidden; probe.nq = s->cfg.heads * s->cfg.head_dim; probe.ffn = s->cfg.ffn;
-        const char* e = getenv("VOX_TALKER_PERSIST");
-        const bool want = e ? e[0] == '1' : true;
-        int n_cu = 0, dev_id = 0;
-        (void)hipGetDevice(&dev_id);
-        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
-        if (want && n_cu >= 256 && vox_talker_mlp_supported(probe) && !s->cfg.qkv_bias) {
-            if (hipMalloc(&s->mlp_gran, 5120 * 8) != hipSuccess || hipMalloc((void**)&s->mlp_words, 16) != hipSuccess)
-                return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc");
-            VOX_HIP(hipMemset(s->mlp_gran, 0, 5120 * 8));
-            const unsigned words[4] = {1u, 0u, vox_persist_spins_default(), 0u};      // epoch, error, poll bound, test hook
-            VOX_HIP(hipMemcpy(s->mlp_words, words, 16, hipMemcpyHostToDevice));
-            s->mlp_persist = 1;
-            // the decode attention INSIDE that launch (blocks 0..15): built, bit-identical, and measured equal to the two-launch form
-            // (2.447 vs 2.442 ms per frame: what the overlapped weight stream saves, the 512-thread attention under that stream
-            // loses — DESIGN.md §3.1); opt-in for A/B
-            const char* ea = getenv("VOX_TALKER_ATTN");
-            s->mlp_attn = (ea && ea[0] == '1') && s->cfg.heads == 16 && s->cfg.kv_heads == 8 && s->cfg.head_dim == 128;
-        }
-    }
     *out = s;
     return VOX_OK;
 }
@@ -764,6 +767,8 @@ int vox_qwen3_create(vox_ctx* ctx, const vox_qwen3_config* cfg, const vox_qwen3_
     dc.max_kvlen = G;
     int s = vox_stack_create(ctx, &tc, w->talker_layers, w->talker_norm, w->talker_rope, w->talker_rope_max_pos, &m->talker);
     if (s != VOX_OK) { delete m; return s; }
+    s = stack_enable_mlp_persist(m->talker);      // this owner ships the launch's error word with every frame (status row)
+    if (s != VOX_OK) { vox_stack_destroy(m->talker); delete m; return s; }
     s = vox_stack_create(ctx, &dc, w->depth_layers, w->depth_norm, w->depth_rope, w->depth_rope_max_pos, &m->depth);
     if (s != VOX_OK) { vox_stack_destroy(m->talker); delete m; return s; }
     m->depth->keep_weights = 1;   // 0.16 GB re-read 15 times per frame: Infinity-Cache resident
@@ -900,12 +905,13 @@ int vox_qwen3_set_status(vox_qwen3* m, int32_t* status_dev) {
     m->status = status_dev;
     return VOX_OK;
 }
-// Put the inputs of the frame `back` frames ago (1: the last frame, 2: the one before) back: input_ids / input_masks / input_features of
+// Put the inputs of the frame `back` frames ago (1: the last frame, 2: the one before; 0: the frame that was started from the CURRENT
+// counter value — during a replay: the launch that ran behind the failed one with inputs the caller had staged by hand) back: input_ids / input_masks / input_features of
 // rows 0..n_rows-1 and the frame counter (io->rng_offset), from the shadow slot of that frame.  n_rows = 0 restores the counter only (a
 // prefill's inputs are staged by the caller).  The status word reads 0 afterwards, 0x7fffffff when no such frame is in the shadow.
 int vox_qwen3_frame_restore(vox_qwen3* m, void* stream, const vox_qwen3_io* io, int back, int n_rows) {
     if (!m || !io || !m->shadow.rng || !io->rng_offset) return vox_fail(VOX_ERR_INVALID, "qwen3_frame_restore: no shadow (vox_qwen3_set_status) or no frame counter");
-    if (back < 1 || back > 2 || n_rows < 0 || n_rows > m->cfg.max_batch) return vox_fail(VOX_ERR_INVALID, "qwen3_frame_restore: bad arguments");
+    if (back < 0 || back > 2 || n_rows < 0 || n_rows > m->cfg.max_batch) return vox_fail(VOX_ERR_INVALID, "qwen3_frame_restore: bad arguments");
     hipLaunchKernelGGL(k_qwen3_restore, dim3(1), dim3(256), 0, (hipStream_t)stream, m->shadow, io->input_ids, io->input_masks,
                        (bf16_t*)io->input_features, io->rng_offset, back, n_rows, m->status);
     VOX_HIP(hipGetLastError());

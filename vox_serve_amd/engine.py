@@ -290,8 +290,12 @@ class Qwen3Engine:
         self._restaged = True
 
     def snapshot_src(self, batch):
-        """What the host copies per frame: the status row + out_ids[:batch] — one contiguous D2H."""
-        return self._out_block[: batch + 1]
+        """What the host copies per frame: the status row + out_ids[:batch] — one contiguous D2H.  Engines without a status row
+        (LMEngine / CSMEngine inherit this method, not the buffer) say so instead of failing on a missing attribute."""
+        blk = self.__dict__.get("_out_block")
+        if blk is None:
+            raise N.VoxError(f"{type(self).__name__} has no status row: copy out_ids[:batch] (worker/base.py: engine_has_status_row)")
+        return blk[: batch + 1]
 
     def read_ids(self, batch):
         """out_ids[:batch] on the host (int64) through ONE blocking D2H that also brings the frame's status word; a hand-off timeout
@@ -315,38 +319,51 @@ class Qwen3Engine:
 
     def recover(self, back=1, code=0, on_first_done=None):
         """A hand-off of a persistent kernel timed out in the launch `back` launches ago (1 = the last one; 2 = one more launch was
-        already enqueued behind it — async scheduling): everything since is garbage.  Wait for the device, turn the persistent kernels
-        off for this engine (the launch chains are bit-identical), drop the graphs that hold them, put the failed launch's inputs
-        back from the shadow, re-upload its plan and run it again — then (back = 2) the launch behind it, which starts from the
-        first one's feedback.  `on_first_done()` is called between the two (the caller re-reads the first launch's outputs).
-        Raises when a launch cannot be replayed (its plan block was overwritten, or the caller restaged the inputs in between)."""
+        already enqueued behind it — async scheduling): everything since is garbage.  Order of work:
+          1. wait for the device and CHECK that the replay is possible — a record of the launch(es), their plan blocks still in the
+             pinned ring, the failed launch's inputs in the shadow (vox_qwen3_frame_restore leaves everything alone when they are not)
+             — before any device state is changed: a launch that cannot be replayed raises with the engine exactly as the failure left it
+             (error words still set, so every later frame keeps reporting it);
+          2. turn the persistent kernels off for this engine (the launch chains are bit-identical) and drop the graphs that hold them;
+          3. run the failed launch again, call `on_first_done()` (the caller re-reads its outputs), then (back = 2) the launch behind it.
+             That one normally starts from the first one's feedback; if the caller had RESTAGED its inputs by hand (`note_restage`: the
+             batch composition changed), its own staged inputs are put back from ITS shadow slot first (every decode frame saves its
+             inputs on entry, so what the caller had written is still there) — a restaged prefill needs nothing: its row buffers are
+             only ever written by the caller."""
         import logging
         torch.cuda.synchronize()
         log = self._launch_log[-back:]
-        if len(log) < back:
+        if len(log) < back or back < 1:
             raise N.VoxError(f"persistent kernels: hand-off timeout (code {code:#x}) and no record of the launch to replay")
-        logging.getLogger(__name__).error("persistent kernels: a hand-off timed out (code %#x) in launch %d; switching this engine to the "
-                                          "launch chains and replaying %d launch(es)", code, log[0]["seq"], back)
-        self.persist_failures.append((log[0]["seq"], code))
-        N.check(self.L.vox_qwen3_persist_reset(self.h, 1))
-        self._drop_graphs()
-        for ent in log[1:]:
-            if ent["restaged"]:
-                raise N.VoxError("persistent kernels: hand-off timeout; the launch behind it had restaged inputs and cannot be replayed")
+        for ent in log:                                   # (1) host-side checks: nothing touched yet
+            if ent["plan"] is not None:
+                k, gen = ent["plan"]
+                if self._plan_slot_gen[k] != gen:
+                    raise N.VoxError(f"persistent kernels: hand-off timeout (code {code:#x}); the plan block of launch {ent['seq']} was "
+                                     "overwritten and it cannot be replayed")
         io = self._io()
         first = log[0]
+        # (1, device side) the failed launch's inputs + frame counter back from the shadow: a no-op that reports 0x7fffffff when absent
         N.check(self.L.vox_qwen3_frame_restore(self.h, N.stream(), ctypes.byref(io), back, first["rows"] if first["kind"] == "frame" else 0))
         torch.cuda.synchronize()
         if int(self.status_row[0].item()) != 0:
-            raise N.VoxError("persistent kernels: hand-off timeout and the failed launch's inputs are not in the shadow")
+            raise N.VoxError(f"persistent kernels: hand-off timeout (code {code:#x}) and the failed launch's inputs are not in the shadow")
+        logging.getLogger(__name__).error("persistent kernels: a hand-off timed out (code %#x) in launch %d; switching this engine to the "
+                                          "launch chains and replaying %d launch(es)", code, first["seq"], back)
+        self.persist_failures.append((first["seq"], code))
+        N.check(self.L.vox_qwen3_persist_reset(self.h, 1))          # (2)
+        self._drop_graphs()
         self._replaying = True
         try:
-            for i, ent in enumerate(log):
+            for i, ent in enumerate(log):                 # (3)
                 if ent["plan"] is not None:
-                    k, gen = ent["plan"]
-                    if self._plan_slot_gen[k] != gen:
-                        raise N.VoxError("persistent kernels: hand-off timeout; the plan block of the launch to replay was overwritten")
-                    self.plan_dev.copy_(self._plan_pin[k], non_blocking=True)
+                    self.plan_dev.copy_(self._plan_pin[ent["plan"][0]], non_blocking=True)
+                if i > 0 and ent["restaged"] and ent["kind"] == "frame":
+                    # back = 0: the frame that started from the counter value the replay has just reached
+                    N.check(self.L.vox_qwen3_frame_restore(self.h, N.stream(), ctypes.byref(io), 0, ent["rows"]))
+                    torch.cuda.synchronize()
+                    if int(self.status_row[0].item()) != 0:
+                        raise N.VoxError("persistent kernels: the restaged launch behind the failed one is not in the shadow")
                 getattr(self, ent["kind"])(*ent["args"])
                 torch.cuda.synchronize()
                 if i == 0 and on_first_done is not None:

@@ -177,6 +177,15 @@ class ServingPool:
         if not self.running and not self.scheduler_processes:
             return
         self.running = False
+        # The result / sender threads may be inside recv / send on these sockets (pyzmq sockets are not thread-safe, and closing the
+        # PULL socket terminates the shared context, which blocks while any socket of it is open): let every loop see running = False
+        # and leave — their polls are <= 0.1 s — BEFORE the sockets are closed from this thread.
+        me = threading.current_thread()
+        for t in [getattr(self, "message_thread", None), getattr(self, "sender_thread", None)] + list(getattr(self, "rank_threads", [])):
+            if t is not None and t is not me and t.is_alive():
+                t.join(timeout=2.0)
+                if t.is_alive():
+                    self.logger.warning(f"{t.name} did not stop in 2 s; closing its socket under it")
         self._stop_scheduler()
         self.scheduler_processes = []
         for s in self.request_sockets:
@@ -358,9 +367,16 @@ class ServingPool:
                 raise TimeoutError(f"request {request_id} timed out after {timeout_s:.0f} s")
 
     def generate(self, text: str, model_kwargs: Dict = None, timeout_s: float = 120.0, **kw) -> bytes:
+        """One request, start to finish: its PCM16 bytes.  A request that ended with an error COMPLETION (a failed preprocess, a
+        scheduler daemon that exited: `_reap_dead_daemons`) raises with the reason instead of handing back truncated audio — the
+        reference answers such a request with an HTTP error (launch.py:593-640)."""
         rid = self.start_streaming_request(text, model_kwargs=model_kwargs, **kw)
         try:
-            return b"".join(self.stream(rid, timeout_s))
+            pcm = b"".join(self.stream(rid, timeout_s))
+            done = self.completion(rid) or {}
+            if done.get("status") == "error":
+                raise RuntimeError(f"request {rid} failed: {done.get('reason')}" + (f" ({done['detail']})" if done.get("detail") else ""))
+            return pcm
         finally:
             self.release(rid)             # (launch.py:593-599: the entry goes away with the response; a long-lived pool must not keep every request's PCM)
 

@@ -26,6 +26,13 @@ from ..sampling import native_config
 from ..tokenizer.base import DecoderCache
 
 
+def engine_has_status_row(engine) -> bool:
+    """True for engines whose per-frame token snapshot carries a status row in front of out_ids (Qwen3Engine: persistent kernels).
+    LMEngine / CSMEngine subclass Qwen3Engine for its graph / plan machinery WITHOUT running its __init__: they have the
+    `snapshot_src` / `read_ids` methods but no `_out_block`, so the presence of a method says nothing — the buffer does."""
+    return getattr(engine, "status_row", None) is not None and getattr(engine, "_out_block", None) is not None
+
+
 class OutOfPages(queue.Empty):
     """The step needs more KV pages than the free list holds.  Raised by prepare_lm_inputs BEFORE any request state is
     touched, so the scheduler can defer the new prompt and retry (the reference lets `queue.Empty` escape from the
@@ -406,7 +413,8 @@ class ModelWorker:
         e, B = self.model.engine, len(requests)
         self.drain()                                   # at most one step in flight behind the one being launched
         # engines with a status row (Qwen3-TTS: persistent kernels) ship it with the ids: row 0 of the snapshot is the frame's status
-        with_status = hasattr(e, "snapshot_src")
+        # (gate on the DATA: LMEngine / CSMEngine inherit the snapshot_src method from Qwen3Engine but own no status row)
+        with_status = engine_has_status_row(e)
         if self._snap is None:
             mk = lambda: {"ids": torch.zeros(e.out_ids.shape[0] + 1, *e.out_ids.shape[1:], dtype=e.out_ids.dtype).pin_memory(),
                           "feats": torch.zeros_like(e.next_features) if getattr(e, "next_features", None) is not None else None,
@@ -437,7 +445,7 @@ class ModelWorker:
                 return
             state["done"] = True
             snap["event"].synchronize()
-            if int(snap["ids"][0].view(-1)[0]) != 0:
+            if with_status and int(snap["ids"][0].view(-1)[0]) != 0:
                 # a hand-off of the persistent kernels timed out in THIS step: replay it on the launch chain (and the step already
                 # enqueued behind it, if any), re-reading this step's outputs in between — the stream the clients get is unchanged
                 e.recover(back=e.launch_seq - snap_seq + 1, code=int(snap["ids"][0].view(-1)[0]), on_first_done=take_snapshot)
