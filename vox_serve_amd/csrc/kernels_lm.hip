@@ -41,7 +41,7 @@ struct LinArgs {
 #define VOX_DS_PICK_LATE 0      // 1: the step input (pick) behind layer 0's first weight requests — measured: no difference, six spilled registers
 #endif
 #ifndef VOX_GRAN_ASM
-#define VOX_GRAN_ASM 2    // persistent kernels: a poll pass's granule requests written as asm (see gran_poll_pass / gran_poll_all); 0: atomic loads
+#define VOX_GRAN_ASM 4    // persistent kernels: a poll pass's granule requests written as asm (see gran_poll_pass / gran_poll_all); 0: atomic loads
 #endif
 #ifndef VOX_KV_ASM
 #define VOX_KV_ASM 1      // decode attention: K/V tile requests written as asm (see k_attn_decode8)
@@ -2786,11 +2786,43 @@ struct AttnShortPre {
     float4 cs4[4];
     int L, nt;
 };
-template <int NT>
+template <int NT, bool FAST = true>
 __device__ __forceinline__ void attn_short_prefetch(const AttnArgs& at, int row, int hk, int lane, AttnShortPre<NT>& pf) {
     constexpr int D = 128, TMAX = AttnShortPre<NT>::TMAX, UMAX = AttnShortPre<NT>::UMAX;
     const int grp = lane >> 4, j = lane & 15, dq = lane & 31;
     const size_t ps = (size_t)2 * at.page_size * at.Hkv * D;
+    if constexpr (NT > 0 && FAST) {
+        // Depth loop (the launchers pick NT > 0 only with identity pages, a fixed position and page_size >= NT): page = row, slot = token,
+        // position = fixed_pos — no plan array is read, every address is base + constant * stride, and every request of the wave goes out
+        // back to back.  (Through the general path below each token cost a page-table select, a shift / divide select and a conditional
+        // request with a wait of its own: ~95 instructions per token in front of a 300-instruction kernel — at one wave per (row, head)
+        // instruction count is time.)  A lane whose token is not visible reads the LAST cached token instead of nothing (no predicate on
+        // the request); its score is masked to -inf and its K never used, as before.
+        pf.L = NT; pf.nt = NT;
+        const bf16_t* nwp = grp < 2 ? at.qn : at.kn;                    // (grp 3 = the new v takes no norm: its weight chunk is not used)
+        pf.gw4 = make_uint4(0, 0, 0, 0);
+        if (at.qn && at.kn) pf.gw4 = reinterpret_cast<const uint4*>(nwp)[j];      // uniform condition
+        int p = at.fixed_pos;
+        p = p < 0 ? 0 : (p >= at.table_max_pos ? at.table_max_pos - 1 : p);
+        const float4* cp = reinterpret_cast<const float4*>(at.cs + (size_t)p * D) + (j & 7) * 4;   // row = D/2 (c,s) pairs
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pf.cs4[k] = cp[k];
+        const size_t ts = (size_t)at.Hkv * D;                            // elements between two tokens of a page
+        const bf16_t* kb = at.kv + (size_t)row * ps + (size_t)hk * D;
+        const bf16_t* vb = kb + (size_t)at.page_size * at.Hkv * D;
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) {
+            int t = u * 4 + grp;
+            if (u * 4 + 3 >= NT - 1) t = t < NT - 1 ? t : (NT >= 2 ? NT - 2 : 0);      // only the last pass can run past the cached tokens
+            pf.kr[u] = NT >= 2 ? reinterpret_cast<const uint4*>(kb + (size_t)t * ts)[j] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            pf.vr[t] = make_uint2(0, 0);
+            if (t < NT - 1) pf.vr[t] = reinterpret_cast<const uint2*>(vb + (size_t)t * ts)[dq];
+        }
+        return;
+    }
     pf.L = NT > 0 ? NT : (at.fixed_kvlen > 0 ? at.fixed_kvlen : at.q_kvlen[row]);
     pf.nt = NT > 0 ? NT : (pf.L < TMAX ? pf.L : TMAX);
     const int nt = pf.nt;
@@ -2836,7 +2868,10 @@ __device__ __forceinline__ void attn_short_compute(const AttnArgs& at, int row, 
     const int g = lane >> 5, dq = lane & 31;      // P.V / output layout: lane = (q head g, dims 4 dq .. 4 dq + 3)
     const size_t ps = (size_t)2 * at.page_size * at.Hkv * D;
     const int L = pf.L, nt = pf.nt;
-    const bool has_nw = grp < 3 && (grp < 2 ? at.qn : at.kn) != nullptr;
+    // (two uniform conditions selected by lane group: a lane-indexed select of the two POINTERS goes through a scratch array, and
+    // the wait behind that scratch load waits for every K/V request in flight)
+    const bool qn_ok = at.qn != nullptr, kn_ok = at.kn != nullptr;
+    const bool has_nw = grp < 2 ? qn_ok : (grp == 2 && kn_ok);
     const uint4 gw4 = pf.gw4;
     // per-head RMSNorm (prep_head: butterfly<64> over a head's 16 non-zero lanes == butterfly<16>)
     float e[8] = {bflo(v.x), bfhi(v.x), bflo(v.y), bfhi(v.y), bflo(v.z), bfhi(v.z), bflo(v.w), bfhi(v.w)};
@@ -2872,8 +2907,8 @@ __device__ __forceinline__ void attn_short_compute(const AttnArgs& at, int row, 
     }
     const uint4 q0c = shfl4(hq, j), q1c = shfl4(hq, 16 + j), knc = shfl4(hq, 32 + j);
     if (do_append) {
-        const int pg = at.identity_pages ? row : at.page[row];
-        const int sl = at.identity_pages ? (L - 1) : at.slot[row];
+        const int pg = (NT > 0 || at.identity_pages) ? row : at.page[row];
+        const int sl = (NT > 0 || at.identity_pages) ? (L - 1) : at.slot[row];
         if (pg >= 0 && grp >= 2) {
             bf16_t* base = at.kv_w + (size_t)pg * ps + ((size_t)sl * at.Hkv + hk) * D;
             if (grp == 3) base += (size_t)at.page_size * at.Hkv * D;
@@ -3059,6 +3094,7 @@ struct DepthStepArgs {
     int* pick_out;
     bf16_t* pick_feat;
     int pick_vocab, pick_H, pick_init;
+    unsigned poll_delay;         // first-pass hold-back of the four gathers, one byte each (x 128 clocks): [7:0] x (D -> A / head), [15:8] qkv, [23:16] x (B -> C), [31:24] h
 };
 #define VOX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 // Bound of every poll loop (a pass is a round trip to the memory side, >= ~0.5 us: >= 20 ms).  Legitimate waits are microseconds —
@@ -3103,8 +3139,13 @@ __device__ __forceinline__ void gran_poll_pass(const unsigned long long* const (
 // then the others in one batch (repeated for stragglers).  = 1: all PER per pass.
 template <int PER, int TOTAL, typename InRange>
 __device__ __forceinline__ void gran_poll_all(const unsigned long long* g, int tid, const unsigned long long* const (&gp)[PER], u32x2_t (&gv)[PER], unsigned tag,
-                                              InRange in_range, unsigned* err, unsigned code, unsigned max_spins) {
+                                              InRange in_range, unsigned* err, unsigned code, unsigned max_spins, unsigned delay = 0) {
     unsigned spin = 0;
+    // The first pass is held back by `delay` x 128 clocks (uniform count: a scalar loop).  A hand-off takes ~2.5 us from the moment a block
+    // is done with its own stage; every pass before the data can be there is traffic of 512 threads x 256 blocks on the fabric the producers
+    // publish (and stream weights) through — polling EARLIER makes the hand-off LATER (round 6: a depth step whose K/V prefetch got ~1 us
+    // shorter, so that its qkv gather started ~1 us sooner, ran 3 % slower; holding every gather's first pass back ~0.2-0.4 us: -3 %).
+    for (unsigned i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(2);
     auto give_up = [&]() {
         if (spin > max_spins) { atomicCAS(err, 0u, code); return true; }
         if ((spin & 63u) == 63u && __hip_atomic_load(err, VOX_RLX_AGENT) != 0u) return true;      // somebody already gave up
@@ -3130,6 +3171,20 @@ __device__ __forceinline__ void gran_poll_all(const unsigned long long* g, int t
             for (int q = 0; q < PER; ++q) ok = ok && (!in_range(q) || gv[q].y == tag);
             if (ok || give_up()) break;
         }
+    } else if constexpr (VOX_GRAN_ASM == 4 && PER > 1) {
+        // optimistic: behind a hold-back tuned to the hand-off's usual length the vector is normally THERE — ask for all PER granules at
+        // once (one round trip instead of sentinel + batch = two); only when that pass misses fall back to the sentinel form
+        for (;;) {
+            gran_poll_pass<PER>(gp, gv);
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) ok = ok && (!in_range(q) || gv[q].y == tag);
+            if (ok || give_up()) break;
+            for (;;) {
+                gran_poll_pass<PER, 0, 1>(gp, gv);
+                if (gv[0].y == tag || give_up()) break;
+            }
+        }
     } else if constexpr (VOX_GRAN_ASM == 2 && PER > 1) {
         for (;;) {
             gran_poll_pass<PER, 0, 1>(gp, gv);
@@ -3153,7 +3208,7 @@ __device__ __forceinline__ void gran_poll_all(const unsigned long long* g, int t
     }
 }
 template <int TOTAL>
-__device__ __forceinline__ void gran_gather_lds(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins) {
+__device__ __forceinline__ void gran_gather_lds(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins, unsigned delay = 0) {
     constexpr int NP = 64 * VOX_DS_PW, PER = (TOTAL + NP - 1) / NP;
     const int p = tid - (512 - NP);
     if (p < 0) return;
@@ -3162,7 +3217,7 @@ __device__ __forceinline__ void gran_gather_lds(const unsigned long long* g, uns
     const unsigned long long* gp[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) gp[q] = g + (p + NP * q < TOTAL ? p + NP * q : p);      // (past the vector: the thread's first granule again, ignored)
-    gran_poll_all<PER, TOTAL>(g, tid, gp, gv, tag, [&](int q) { return p + NP * q < TOTAL; }, err, code, max_spins);
+    gran_poll_all<PER, TOTAL>(g, tid, gp, gv, tag, [&](int q) { return p + NP * q < TOTAL; }, err, code, max_spins, delay);
 #pragma unroll
     for (int q = 0; q < PER; ++q)
         if (p + NP * q < TOTAL) dst[p + NP * q] = gv[q].x;
@@ -3278,6 +3333,15 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) wp[i] = reinterpret_cast<const bf16_t*>(lp[i]);
         }
+#ifndef VOX_DS_KV_MODE
+#define VOX_DS_KV_MODE 2
+#endif
+        // the layer's attention operands that do not depend on this launch (cached K / V of the earlier tokens, norm weights, RoPE entries)
+        AttnArgs at = a.at;
+        at.kv = a.at.kv + (size_t)l * a.kv_layer_stride;
+        at.kv_w = a.at.kv_w + (size_t)l * a.kv_layer_stride;
+        at.qn = w.qn; at.kn = w.kn;
+        AttnShortPre<NT> pf;
         // ---------------- stage A: qkv = Wqkv . rmsnorm(x, ln1)  (2048 column pairs: one per wave of every block) ----------------
         {
             const int pr = blk * 8 + wave, n0 = 2 * pr;
@@ -3296,7 +3360,12 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             const uint4* wor1 = wor0 + NQ / 8;
             const uint4 wo00 = wor0[0], wo01 = wor0[64], wo02 = wor0[128], wo03 = wor0[192];
             const uint4 wo10 = wor1[0], wo11 = wor1[64], wo12 = wor1[128], wo13 = wor1[192];
-            if (l > 0) gran_gather_lds<512>(a.gx, tagof(l - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x100u + l, max_spins);
+#if VOX_DS_KV_MODE == 5
+            // requested HERE, behind the stage's weight rows and in front of the x gather: between stage A's publish and the qkv gather (where
+            // they used to go out) their return stood in front of the gather's polls — loads return in order — for 0.1 us per visible token
+            attn_short_prefetch<NT, true>(at, 0, wave, lane, pf);
+#endif
+            if (l > 0) gran_gather_lds<512>(a.gx, tagof(l - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x100u + l, max_spins, a.poll_delay & 255u);
             if (l == 0) {
 #if VOX_DS_PICK_LATE
                 load_step_input();
@@ -3339,14 +3408,18 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
         // ---------------- stage B: x += Wo . attention  (512 pairs: waves 0, 1; the attention by all 8 waves = 8 kv heads) ----------------
         {
             const int pr = blk * 2 + wave;
-            AttnArgs at = a.at;
-            at.kv = a.at.kv + (size_t)l * a.kv_layer_stride;
-            at.kv_w = a.at.kv_w + (size_t)l * a.kv_layer_stride;
-            at.qn = w.qn; at.kn = w.kn;
             const int hk = wave;
-            AttnShortPre<NT> pf;
-            attn_short_prefetch<NT>(at, 0, hk, lane, pf);
-            gran_gather_lds<2048>(a.gqkv, tagof(l, 0), reinterpret_cast<unsigned*>(qb), tid, a.err, 0x200u + l, max_spins);
+#if VOX_DS_KV_MODE != 5
+            attn_short_prefetch<NT, VOX_DS_KV_MODE != 0>(at, 0, hk, lane, pf);
+#endif
+#if VOX_DS_KV_MODE == 2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif VOX_DS_KV_MODE == 3
+            __builtin_amdgcn_s_sleep(32);
+#elif VOX_DS_KV_MODE == 4
+            __builtin_amdgcn_s_sleep(64);
+#endif
+            gran_gather_lds<2048>(a.gqkv, tagof(l, 0), reinterpret_cast<unsigned*>(qb), tid, a.err, 0x200u + l, max_spins, (a.poll_delay >> 8) & 255u);
             __syncthreads();                               // q | k | v in qb (and: every wave is done with xb's stage-A reads)
             VOX_STAMP2(2 + 6 * l)
             {
@@ -3394,7 +3467,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             // (xc's last readers, the previous layer's stage-D residual words, were done before this layer's stage-A barrier: the barrier
             // below is not needed for correctness — it parks the waves that have nothing to do in stage B's o_proj away from the poll loop)
             if (VOX_DS_EXTRA_BARRIERS) __syncthreads();
-            gran_gather_lds<512>(a.gx, tagof(l, 1), reinterpret_cast<unsigned*>(xc), tid, a.err, 0x400u + l, max_spins);
+            gran_gather_lds<512>(a.gx, tagof(l, 1), reinterpret_cast<unsigned*>(xc), tid, a.err, 0x400u + l, max_spins, (a.poll_delay >> 16) & 255u);
             __syncthreads();
             if (wave < 6) {
                 uint4 xv[2];
@@ -3434,7 +3507,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
                     for (int j = 0; j < 6; ++j) wd[r][j] = wr[lane + 64 * j];
                 }
             }
-            gran_gather_lds<1536>(a.gh, tagof(l, 2), reinterpret_cast<unsigned*>(hb), tid, a.err, 0x600u + l, max_spins);
+            gran_gather_lds<1536>(a.gh, tagof(l, 2), reinterpret_cast<unsigned*>(hb), tid, a.err, 0x600u + l, max_spins, a.poll_delay >> 24);
             __syncthreads();                               // h in hb (xc = x after attention: the residual of this stage)
             if (wave < 2) {
                 const unsigned resw = reinterpret_cast<const unsigned*>(xc)[pr];
@@ -3472,7 +3545,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) nwv[j] = reinterpret_cast<const uint4*>(a.final_norm)[lane + 64 * j];
         }
-        gran_gather_lds<512>(a.gx, tagof(a.n_layers - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x700u, max_spins);
+        gran_gather_lds<512>(a.gx, tagof(a.n_layers - 1, 3), reinterpret_cast<unsigned*>(xb), tid, a.err, 0x700u, max_spins, a.poll_delay & 255u);
         __syncthreads();
         if (wave < 4) {
             uint4 xv[2];
@@ -3770,17 +3843,18 @@ struct TalkerMlpArgs {
     unsigned long long* gattn;       // granules: 1024 (the 2048-wide attention row)
     int burst_delay;                 // plain blocks: s_sleep(16) repeats in front of their first weight requests
     int poll_sleep;                  // s_sleep(8) repeats between two polls of the sentinel granule
+    unsigned poll_delay;             // first-pass hold-back of the gathers, one byte each (x 128 clocks): [7:0] x' (O -> C), [15:8] h (C -> D), [23:16] x (D -> next qkv), [31:24] the attention row (ATTN form)
     AttnArgs at;
 };
 template <int TOTAL>
-__device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins) {
+__device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins, unsigned delay = 0) {
     constexpr int PER = (TOTAL + 511) / 512;
 #if VOX_GRAN_ASM
     u32x2_t gv[PER];
     const unsigned long long* gp[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) gp[q] = g + (tid + 512 * q < TOTAL ? tid + 512 * q : tid);
-    gran_poll_all<PER, TOTAL>(g, tid, gp, gv, tag, [&](int q) { return tid + 512 * q < TOTAL; }, err, code, max_spins);
+    gran_poll_all<PER, TOTAL>(g, tid, gp, gv, tag, [&](int q) { return tid + 512 * q < TOTAL; }, err, code, max_spins, delay);
 #pragma unroll
     for (int q = 0; q < PER; ++q)
         if (tid + 512 * q < TOTAL) dst[tid + 512 * q] = gv[q].x;
@@ -3926,7 +4000,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
             }
         }
         __syncthreads();
-        gran_gather_lds_all<1024>(a.gattn, tag0 + 4u, reinterpret_cast<unsigned*>(ab), tid, a.err, 0x1400u, max_spins);
+        gran_gather_lds_all<1024>(a.gattn, tag0 + 4u, reinterpret_cast<unsigned*>(ab), tid, a.err, 0x1400u, max_spins, a.poll_delay >> 24);
         __syncthreads();
     }
     MLP_TR(2)
@@ -3971,7 +4045,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     if (!VOX_MLP_C2_LATE) load_c2();
     __syncthreads();                                   // (parks waves 4..7 until waves 0..3 have published their x' pairs)
     MLP_TR(3)
-    gran_gather_lds_all<1024>(a.gx, tag0 + 1u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1100u, max_spins);
+    gran_gather_lds_all<1024>(a.gx, tag0 + 1u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1100u, max_spins, a.poll_delay & 255u);
     if (VOX_MLP_C2_LATE) load_c2();
     __syncthreads();
     MLP_TR(4)
@@ -4017,7 +4091,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         }
         __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish their second pair)
         MLP_TR(5)
-        gran_gather_lds_all<3072>(a.gh, tag0 + 2u, reinterpret_cast<unsigned*>(hb), tid, a.err, 0x1200u, max_spins);
+        gran_gather_lds_all<3072>(a.gh, tag0 + 2u, reinterpret_cast<unsigned*>(hb), tid, a.err, 0x1200u, max_spins, (a.poll_delay >> 8) & 255u);
         __syncthreads();
         MLP_TR(6)
         if (wave < 4) {
@@ -4050,7 +4124,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) nw1[j] = reinterpret_cast<const uint4*>(a.ln1_next)[lane + 64 * j];
         __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish the down projection; xb is free)
-        gran_gather_lds_all<1024>(a.gx, tag0 + 3u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1300u, max_spins);
+        gran_gather_lds_all<1024>(a.gx, tag0 + 3u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1300u, max_spins, (a.poll_delay >> 16) & 255u);
         __syncthreads();
         MLP_TR(7)
         uint4 yv[4];
@@ -4084,6 +4158,19 @@ static void fill_attn_args(AttnArgs& a, const AttnCall& c);
 bool vox_talker_attn_supported(const AttnCall& c) {
     return c.qkv && c.Nq == 1 && c.D == 128 && c.Hq == 16 && c.Hkv == 8 && c.max_kvlen > VOX_TC && c.max_kvlen <= 8 * VOX_TC;
 }
+// First-pass hold-back of the persistent kernels' gathers (gran_poll_all), one byte per gather site in units of 128 clocks.  The defaults
+// are the round-6 sweep's (tools/poll_delay_sweep.sh, profiles/round6_poll_delay_sweep.txt); the environment overrides them for A/B runs
+// (hex or decimal, read when a launch is first built — frame graphs captured afterwards keep the value).
+#ifndef VOX_DS_POLL_DELAY_DEFAULT
+#define VOX_DS_POLL_DELAY_DEFAULT 0x180c0404u
+#endif
+#ifndef VOX_MLP_POLL_DELAY_DEFAULT
+#define VOX_MLP_POLL_DELAY_DEFAULT 0x00082004u
+#endif
+static unsigned vox_poll_delay(const char* name, unsigned dflt) {
+    const char* e = getenv(name);
+    return e ? (unsigned)strtoul(e, nullptr, 0) : dflt;
+}
 int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
     if (!vox_talker_mlp_supported(c)) return vox_fail(VOX_ERR_INVALID, "talker_mlp: unsupported shape");
     TalkerMlpArgs a{};
@@ -4092,6 +4179,7 @@ int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
     a.gx = (unsigned long long*)c.gran; a.gh = a.gx + 1024; a.epoch = c.epoch; a.err = c.err; a.eps = c.eps;
     a.wqkv_next = (const bf16_t*)c.wqkv_next; a.ln1_next = (const bf16_t*)c.ln1_next; a.qkv_out = (bf16_t*)c.qkv_out;
     if (c.wqkv_next && (c.nqkv != 4096 || !c.ln1_next || !c.qkv_out)) return vox_fail(VOX_ERR_INVALID, "talker_mlp: bad next-layer qkv");
+    a.poll_delay = vox_poll_delay("VOX_MLP_POLL_DELAY", VOX_MLP_POLL_DELAY_DEFAULT);
     if (c.attn_call) {
         const AttnCall& ac = *c.attn_call;
         if (!vox_talker_attn_supported(ac)) return vox_fail(VOX_ERR_INVALID, "talker_mlp: attention shape not supported in the launch");
@@ -4099,9 +4187,9 @@ int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
         static const int hoist_on = [] { const char* e = getenv("VOX_ATTN_HOIST"); return !(e && e[0] == '0'); }();
         a.at.hoist = hoist_on;
         a.gattn = a.gx + 4096;
-        static const int delay = [] { const char* e = getenv("VOX_TALKER_ATTN_DELAY"); return e ? atoi(e) : 4; }();
+        const int delay = [] { const char* e = getenv("VOX_TALKER_ATTN_DELAY"); return e ? atoi(e) : 8; }();       // (read per launch built: graphs keep it)
         a.burst_delay = delay < 0 ? 0 : (delay > 64 ? 64 : delay);
-        static const int psl = [] { const char* e = getenv("VOX_TALKER_ATTN_POLL"); return e ? atoi(e) : 1; }();
+        const int psl = [] { const char* e = getenv("VOX_TALKER_ATTN_POLL"); return e ? atoi(e) : 1; }();
         a.poll_sleep = psl < 1 ? 1 : (psl > 64 ? 64 : psl);
         hipLaunchKernelGGL(k_talker_mlp<true>, dim3(256), dim3(512), 0, st, a);
         return VOX_OK;
@@ -4121,6 +4209,7 @@ int vox_launch_depth_step(hipStream_t st, const DepthStepCall& c) {
     a.head_w = (const bf16_t*)c.head_w; a.x_in = (const bf16_t*)c.x_in; a.logits = (bf16_t*)c.logits;
     a.gx = (unsigned long long*)c.gran; a.gqkv = a.gx + 512; a.gh = a.gqkv + 2048;
     a.epoch = c.epoch; a.err = c.err; a.kv_layer_stride = c.kv_layer_stride; a.eps = c.eps;
+    a.poll_delay = vox_poll_delay("VOX_DS_POLL_DELAY", VOX_DS_POLL_DELAY_DEFAULT);
     if (c.pick_logits) {
         if (!c.pick_tab || !c.pick_emb || !c.pick_out || !c.pick_feat || c.pick_vocab <= 0 || c.pick_vocab > 65536 || c.pick_vocab % 4 || c.pick_H % 8)
             return vox_fail(VOX_ERR_INVALID, "depth_step: bad fused-pick arguments");
@@ -4154,6 +4243,11 @@ static void fill_attn_args(AttnArgs& a, const AttnCall& c) {
     a.out = nullptr;
 }
 
+// which compile-time token count a short-attention launch may take: NT > 0 assumes identity pages, a fixed position and a page that
+// holds all NT tokens (attn_short_prefetch); anything else reads the plan arrays (NT = 0)
+static inline int attn_short_nt(const AttnArgs& at) {
+    return (at.identity_pages && at.fixed_pos >= 0 && at.fixed_kvlen >= 2 && at.fixed_kvlen <= 16 && at.page_size >= at.fixed_kvlen) ? at.fixed_kvlen : 0;
+}
 // short-context decode attention: D 128, two q heads per kv head, full-width NeoX RoPE, <= 16 visible tokens
 bool vox_attn_short_supported(const AttnCall& c) {
     return c.qkv && c.D == 128 && c.max_kvlen <= 16 && c.Nq >= 1 && c.Hkv > 0 && c.Hq == 2 * c.Hkv && c.rot == 128 &&
@@ -4166,7 +4260,8 @@ int vox_launch_attn_short(hipStream_t st, const AttnCall& c) {
     at.out = (bf16_t*)c.out;
     at.out_frag = (bf16_t*)c.out_frag;
     const int n_pairs = c.Nq * c.Hkv;
-    switch (at.fixed_kvlen) {      // depth loop: the visible length is part of the captured graph
+    // NT > 0 = the depth-loop form: identity pages, fixed position, the page holds every visible token (attn_short_prefetch)
+    switch (attn_short_nt(at)) {      // depth loop: the visible length is part of the captured graph
 #define VOX_AS(NT_) case NT_: hipLaunchKernelGGL(k_attn_short<NT_>, dim3((n_pairs + 3) / 4), dim3(256), 0, st, at, n_pairs); return VOX_OK;
         VOX_AS(2) VOX_AS(3) VOX_AS(4) VOX_AS(5) VOX_AS(6) VOX_AS(7) VOX_AS(8) VOX_AS(9) VOX_AS(10) VOX_AS(11) VOX_AS(12)
         VOX_AS(13) VOX_AS(14) VOX_AS(15) VOX_AS(16)
@@ -4191,7 +4286,7 @@ int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const LinearCall&
     a.W = (const bf16_t*)l.W; a.bias = (const bf16_t*)l.bias; a.residual = (const bf16_t*)l.residual; a.y = (bf16_t*)l.y;
     a.B = l.B; a.N = l.N; a.K = l.K;
     const dim3 grid((l.N + 7) / 8);
-    switch (at.fixed_kvlen) {      // depth loop: the visible length is part of the captured graph
+    switch (attn_short_nt(at)) {      // depth loop: the visible length is part of the captured graph
 #define VOX_A1(NT_) case NT_: hipLaunchKernelGGL((k_attn1_linear<1, 4, 1, NT_>), grid, dim3(512), 0, st, at, a); return VOX_OK;
         VOX_A1(2) VOX_A1(3) VOX_A1(4) VOX_A1(5) VOX_A1(6) VOX_A1(7) VOX_A1(8) VOX_A1(9) VOX_A1(10) VOX_A1(11) VOX_A1(12)
         VOX_A1(13) VOX_A1(14) VOX_A1(15) VOX_A1(16)
