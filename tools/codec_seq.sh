@@ -2,7 +2,7 @@
 # ordered kernel sequence of one Qwen3 codec chunk at B=32 (two-term operands): name, grid, duration
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/cseq; mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/t -o c -- python tools/codec_chunk_prof.py 32 2 > $O/run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/t -o c -- python tools/codec_chunk_prof.py ${CSEQ_B:-32} 2 > $O/run.log 2>&1
 python - <<'PY'
 import csv, glob
 f=glob.glob('gpurun_out/cseq/t/**/*kernel_trace.csv', recursive=True)[0]

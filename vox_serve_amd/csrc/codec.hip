@@ -166,7 +166,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs& a, f32x4 (&acc
 
 // WM x WN 16x16 MFMA tiles per wave, 2 x 2 waves: block tile (32 WM) x (32 WN).  Smaller tiles are used when the
 // 64 x 64 grid would leave most of the 256 CUs idle (the mid-size decoder stages are MFMA-bound per CU).
-template <int BK, int WM, int WN>
+template <int BK, int WM, int WN, bool UNR = false>
 __global__ __launch_bounds__(256, (WM * WN > 12 ? 3 : 4)) void k_conv_gemm(ConvGemmArgs a) {
     constexpr int BM = 32 * WM, BN = 32 * WN;
     constexpr int LD = BK + 8;          // LDS row stride in bf16 elements (+16 B: the 16 rows of a fragment read hit distinct banks)
@@ -230,6 +230,13 @@ __global__ __launch_bounds__(256, (WM * WN > 12 ? 3 : 4)) void k_conv_gemm(ConvG
         }
     };
     fetch(0);
+    // UNR (few-block launches of the small tiles: one request's chunk): the plane count (1 .. 3 bf16 terms per activation) is a compile-time
+    // constant inside the loop.  As a run-time trip count the term loop is not unrolled and every MFMA sits behind its own ds_read + wait —
+    // 12 dependent LDS round trips per K step of the 32 x 32 tile; unrolled, a k-block's operand reads go out together (one-request chunk
+    // 1.76 -> 1.72 ms).  Many-block launches keep the run-time count: the unrolled reads cost 30 registers, i.e. a wave per SIMD, and
+    // there the other waves hide the round trips (8-request chunk 3.34 -> 3.36 ms unrolled).
+    auto kloop = [&](auto np_tag) {
+    constexpr int NP = decltype(np_tag)::value;
     for (int it = 0; it < nit; ++it) {
         __syncthreads();   // previous tile fully consumed
 #pragma unroll
@@ -244,8 +251,8 @@ __global__ __launch_bounds__(256, (WM * WN > 12 ? 3 : 4)) void k_conv_gemm(ConvG
                     uint4 h, m, l;
                     split3(v0[i], v1[i], h, m, l);
                     *reinterpret_cast<uint4*>(&As[0][o]) = h;
-                    if (a.planes > 1) *reinterpret_cast<uint4*>(&As[1][o]) = m;
-                    if (a.planes > 2) *reinterpret_cast<uint4*>(&As[2][o]) = l;
+                    if ((NP ? NP : a.planes) > 1) *reinterpret_cast<uint4*>(&As[1][o]) = m;
+                    if ((NP ? NP : a.planes) > 2) *reinterpret_cast<uint4*>(&As[2][o]) = l;
                 }
             }
         }
@@ -263,7 +270,9 @@ __global__ __launch_bounds__(256, (WM * WN > 12 ? 3 : 4)) void k_conv_gemm(ConvG
             uint4 bfr[WN];
 #pragma unroll
             for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(&Bs[(wn + j * 16 + fr) * LD + kb + fk]);
-            for (int t = a.planes - 1; t >= 0; --t) {      // smallest term first
+            // (NP = 0: the run-time count — the 128-row tiles run 3 .. 4 blocks per CU on a register budget the unrolled reads do not fit)
+#pragma unroll
+            for (int t = (NP ? NP : a.planes) - 1; t >= 0; --t) {      // smallest term first
 #pragma unroll
                 for (int i = 0; i < WM; ++i) {
                     const uint4 afr = *reinterpret_cast<const uint4*>(&As[t][(wm + i * 16 + fr) * LD + kb + fk]);
@@ -274,6 +283,11 @@ __global__ __launch_bounds__(256, (WM * WN > 12 ? 3 : 4)) void k_conv_gemm(ConvG
             }
         }
     }
+    };
+    if constexpr (!UNR) kloop(std::integral_constant<int, 0>{});
+    else if (a.planes >= 3) kloop(std::integral_constant<int, 3>{});
+    else if (a.planes == 2) kloop(std::integral_constant<int, 2>{});
+    else kloop(std::integral_constant<int, 1>{});
     conv_epilogue<WM, WN>(a, acc, m0, n0, wm, wn, lane);
 }
 
@@ -299,8 +313,12 @@ __device__ __forceinline__ void conv_taps_kloop(const ConvGemmArgs& a, int H, un
         for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bf16_t* xrows = reinterpret_cast<const bf16_t*>(a.x) + (size_t)rb * a.L * 2 * a.Cin;
     const bf16_t* srows = a.state ? reinterpret_cast<const bf16_t*>(a.state) + (size_t)a.slots[rb] * a.P * 2 * a.Cin : nullptr;
-    uint4 wv[NBR];
-    auto fetchB = [&](int tap, int c0) {
+    // Weights: the (chunk, tap) pairs form ONE stream s = chunk * n_taps + tap; the slice of step s + 2 is requested before the MFMAs of
+    // step s and goes to LDS behind the MFMAs of step s + 1 (two register sets, chosen by the parity of s: the stream loop is unrolled by
+    // two so that the choice is static).  One step ahead — the round-3 form — a slice had one tap's MFMAs (24 of them, ~0.16 us) to come
+    // back from L2 (~0.6 us): every tap waited for its weights, the matrix cores were 27 % busy.  LDS buffers: parity of s, as before.
+    uint4 wv0[NBR], wv1[NBR];
+    auto fetchB = [&](uint4 (&wv)[NBR], int tap, int c0) {
 #pragma unroll
         for (int i = 0; i < NBR; ++i) {
             const int idx = tid + 256 * i, bn = n0 + (idx >> 2);
@@ -308,7 +326,7 @@ __device__ __forceinline__ void conv_taps_kloop(const ConvGemmArgs& a, int H, un
             if (idx < BN * 4 && bn < a.N) wv[i] = *reinterpret_cast<const uint4*>(a.w + ((size_t)tap * a.N + bn) * a.Cin + c0 + (idx & 3) * 8);
         }
     };
-    auto storeB = [&](int q) {
+    auto storeB = [&](const uint4 (&wv)[NBR], int q) {
 #pragma unroll
         for (int i = 0; i < NBR; ++i) {
             const int idx = tid + 256 * i;
@@ -340,35 +358,47 @@ __device__ __forceinline__ void conv_taps_kloop(const ConvGemmArgs& a, int H, un
         }
     };
     const int nck = CG_DEV(a, 1) ? 0 : a.Cin >> 5;
-    if (nck) { fetchA(0); fetchB(0, 0); }
-    for (int ck = 0; ck < nck; ++ck) {
-        const int c0 = ck * 32;
-        __syncthreads();          // the previous chunk's tile and weight buffers are no longer read
-        storeA();
-        storeB(0);
-        __syncthreads();
-        if (ck + 1 < nck) fetchA(c0 + 32);
-        for (int tap = 0; tap < a.n_taps; ++tap) {
-            if (tap + 1 < a.n_taps) fetchB(tap + 1, c0);
-            else if (ck + 1 < nck) fetchB(0, c0 + 32);
-            const int sh = H - a.off[tap];
-            const bf16_t* Bq = Bs + (size_t)(tap & 1) * BN * LD;
-            uint4 bfr[WN];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(Bq + (wn + j * 16 + fr) * LD + fk);
-#pragma unroll
-            for (int p = 1; p >= 0; --p) {      // smaller term first
-#pragma unroll
-                for (int i = 0; i < WM; ++i) {
-                    const uint4 afr = *reinterpret_cast<const uint4*>(As + ((size_t)p * R + wm + i * 16 + fr + sh) * LD + fk);
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(afr), as_cbf8(bfr[j]), acc[i][j], 0, 0, 0);
-                }
-            }
-            if (tap + 1 < a.n_taps) storeB((tap + 1) & 1);
-            __syncthreads();      // the next tap's weights are visible; this tap's buffer may be overwritten by the tap after next
+    const int nt = a.n_taps, total = nck * nt;
+    if (total == 0) return;
+    // (tap, chunk offset) of stream index s
+    int f_tap = 0, f_c0 = 0;                       // of the next slice to REQUEST
+    auto advance_f = [&]() { if (++f_tap == nt) { f_tap = 0; f_c0 += 32; } };
+    fetchA(0);
+    fetchB(wv0, 0, 0); advance_f();
+    if (total > 1) { fetchB(wv1, f_tap, f_c0); advance_f(); }
+    __syncthreads();              // (the caller may have used the LDS before)
+    storeB(wv0, 0);
+    int tap = 0, ck = 0;                            // of the step being computed
+    // one step: F = the register set that is free (its slice, step s, is in LDS), S = the set holding step s + 1
+    auto step = [&](int s_, uint4 (&F)[NBR], const uint4 (&S)[NBR]) {
+        if (tap == 0) {           // chunk boundary: the previous step's closing barrier says nobody reads the old tile any more
+            storeA();
+            __syncthreads();
+            if (ck + 1 < nck) fetchA((ck + 1) * 32);
         }
+        if (s_ + 2 < total) { fetchB(F, f_tap, f_c0); advance_f(); }
+        const int sh = H - a.off[tap];
+        const bf16_t* Bq = Bs + (size_t)(s_ & 1) * BN * LD;
+        uint4 bfr[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(Bq + (wn + j * 16 + fr) * LD + fk);
+#pragma unroll
+        for (int p = 1; p >= 0; --p) {      // smaller term first
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const uint4 afr = *reinterpret_cast<const uint4*>(As + ((size_t)p * R + wm + i * 16 + fr + sh) * LD + fk);
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(afr), as_cbf8(bfr[j]), acc[i][j], 0, 0, 0);
+            }
+        }
+        if (s_ + 1 < total) storeB(S, (s_ + 1) & 1);
+        __syncthreads();          // the next step's weights are visible; this step's buffer may be overwritten by the step after next
+        if (++tap == nt) { tap = 0; ++ck; }
+    };
+    for (int s_ = 0; s_ < total; s_ += 2) {
+        step(s_, wv0, wv1);
+        if (s_ + 1 < total) step(s_ + 1, wv1, wv0);
     }
 }
 
@@ -547,6 +577,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
         if (am < a.M) ln_row_stats(a.x + (size_t)am * a.Cin, a.Cin, l16, a.ln_eps, mean, rstd);
         if (l16 == 0) { ln_stat[2 * r] = mean; ln_stat[2 * r + 1] = rstd; }
     }
+    auto kloop = [&](auto np_tag) {       // (the plane count as a compile-time constant: see k_conv_gemm)
+    constexpr int NP = decltype(np_tag)::value;
     for (int it = 0; it < nit; ++it) {
         __syncthreads();
 #pragma unroll
@@ -590,12 +622,17 @@ __global__ __launch_bounds__(256) void k_conv_gemm_skinny(ConvGemmArgs a) {
 #pragma unroll
         for (int kb = 0; kb < BK; kb += 32) {
             const uint4 bfr = *reinterpret_cast<const uint4*>(&Bs[(wave * 16 + fr) * LD + kb + fk]);
-            for (int t = a.planes - 1; t >= 0; --t) {
+#pragma unroll
+            for (int t = NP - 1; t >= 0; --t) {
                 const uint4 afr = *reinterpret_cast<const uint4*>(&As[t][fr * LD + kb + fk]);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_cbf8(afr), as_cbf8(bfr), acc, 0, 0, 0);
             }
         }
     }
+    };
+    if (a.planes >= 3) kloop(std::integral_constant<int, 3>{});
+    else if (a.planes == 2) kloop(std::integral_constant<int, 2>{});
+    else kloop(std::integral_constant<int, 1>{});
     const int n = n0 + wave * 16 + (lane & 15);
     if (n >= a.N) return;
     const float bvv = a.bias ? a.bias[n % a.bias_mod] : 0.0f;
@@ -1356,7 +1393,11 @@ static int conv_gemm(hipStream_t st, const vox_conv_w& w, const float* x, const 
     const int b64 = ((w.n + 63) / 64) * ((a.M + 63) / 64);
     const int wm = b64 >= 192 ? 2 : 1, wn = (b64 >= 192 || 2 * b64 >= 192) ? 2 : 1;
     const dim3 grid((w.n + 32 * wn - 1) / (32 * wn), (a.M + 32 * wm - 1) / (32 * wm));
-#define VOX_CG(K_, M_, N_) if (wm == M_ && wn == N_) { hipLaunchKernelGGL((k_conv_gemm<K_, M_, N_>), grid, dim3(256), 0, st, a); return VOX_OK; }
+    const bool few = grid.x * grid.y <= 512;       // at most two blocks per CU: nothing else hides a block's LDS round trips
+#define VOX_CG(K_, M_, N_) if (wm == M_ && wn == N_) { \
+        if (few && M_ * N_ <= 2) hipLaunchKernelGGL((k_conv_gemm<K_, M_, N_, (M_ * N_ <= 2)>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((k_conv_gemm<K_, M_, N_>), grid, dim3(256), 0, st, a); \
+        return VOX_OK; }
     // few blocks, long K (HiFT's resblock convs of one request: 112 blocks x 88 K steps of 64): 128-wide K steps halve the dependent
     // stage-and-barrier rounds; the k order is unchanged, so the results are bit-identical (VOX_CG_BK128=0: 64-wide steps)
     static const bool bk128 = [] { const char* e = getenv("VOX_CG_BK128"); return !(e && e[0] == '0'); }();

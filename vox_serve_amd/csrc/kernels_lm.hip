@@ -3123,7 +3123,7 @@ struct DepthStepArgs {
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 template <int PER, int Q0 = 0, int Q1 = PER>
 __device__ __forceinline__ void gran_poll_pass(const unsigned long long* const (&ptr)[PER], u32x2_t (&v)[PER]) {
-    static_assert(PER >= 1 && PER <= 6, "gran_poll_pass lists the payload registers");
+    static_assert(PER >= 1 && PER <= 8, "gran_poll_pass lists the payload registers");
 #pragma unroll
     for (int q = Q0; q < Q1; ++q) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[q]) : "v"(ptr[q]) : "memory");
     constexpr int N = Q1 - Q0;
@@ -3133,6 +3133,8 @@ __device__ __forceinline__ void gran_poll_pass(const unsigned long long* const (
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]), "+v"(v[Q0 + 2]), "+v"(v[Q0 + 3]) :: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]), "+v"(v[Q0 + 2]), "+v"(v[Q0 + 3]), "+v"(v[Q0 + 4]) :: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]), "+v"(v[Q0 + 2]), "+v"(v[Q0 + 3]), "+v"(v[Q0 + 4]), "+v"(v[Q0 + 5]) :: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]), "+v"(v[Q0 + 2]), "+v"(v[Q0 + 3]), "+v"(v[Q0 + 4]), "+v"(v[Q0 + 5]), "+v"(v[Q0 + 6]) :: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[Q0]), "+v"(v[Q0 + 1]), "+v"(v[Q0 + 2]), "+v"(v[Q0 + 3]), "+v"(v[Q0 + 4]), "+v"(v[Q0 + 5]), "+v"(v[Q0 + 6]), "+v"(v[Q0 + 7]) :: "memory");
 }
 // The gather of a thread's PER granules.  VOX_GRAN_ASM = 2: the thread's FIRST granule is the sentinel — polled alone until its tag matches
 // (a waiting block asks for 1 / PER of the vector per pass: polls travel the same fabric as the producers' weight streams and publishes),
