@@ -263,7 +263,7 @@ def pmc_traffic(B):
     MI355X_MICROARCH.md prescribes for gfx950; tools/pmc_summary.py).  Hardware counters cannot be read from inside the
     timed run, so the line labels this value `traffic_source: "recorded <file>"`; null when no pass is committed."""
     pdir = os.path.join(ROOT, "profiles")
-    for name in ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+    for name in ("round6_pmc_traffic.json", "round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
         try:
             rec = json.load(open(os.path.join(pdir, name))).get(f"batch_{B}")
             if rec:

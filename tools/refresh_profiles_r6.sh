@@ -1,7 +1,7 @@
-# Round-5 profile refresh (run on the GPU box through gpurun; outputs under gpurun_out/p5, copied into profiles/ by hand).
+# Round-6 profile refresh (run on the GPU box through gpurun; outputs under gpurun_out/p6, copied into profiles/ by hand).
 # Counters are collected in their own rocprofv3 passes (--pmc with --kernel-trace only), one counter per pass.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/p5; mkdir -p $O
+O=gpurun_out/p6; mkdir -p $O
 Q="--no-cpu-baseline --ttfa-requests 0 --serving-ttfa-requests 0 --no-other-configs"
 for b in 1 8 32; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b$b -o b$b -- python bench.py --batch $b --steps 40 --warmup 10 $Q > $O/bench_b${b}_prof.json 2> $O/bench_b${b}_prof.err

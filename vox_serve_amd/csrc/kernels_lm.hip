@@ -2786,11 +2786,24 @@ struct AttnShortPre {
     float4 cs4[4];
     int L, nt;
 };
-template <int NT, bool FAST = true>
+// PART (fast path only): 0 = every operand, 1 = all but the cached V rows, 2 = the cached V rows alone.  The persistent depth step asks for
+// the V rows BEHIND its qkv gather: they are needed a microsecond later than K (after scores + softmax), and in front of the gather their
+// 15 requests per wave stood between the block and its polls (loads return in order: 0.1 us per visible token on every hand-off).
+template <int NT, bool FAST = true, int PART = 0>
 __device__ __forceinline__ void attn_short_prefetch(const AttnArgs& at, int row, int hk, int lane, AttnShortPre<NT>& pf) {
     constexpr int D = 128, TMAX = AttnShortPre<NT>::TMAX, UMAX = AttnShortPre<NT>::UMAX;
     const int grp = lane >> 4, j = lane & 15, dq = lane & 31;
     const size_t ps = (size_t)2 * at.page_size * at.Hkv * D;
+    if constexpr (NT > 0 && FAST && PART == 2) {
+        const bf16_t* vb = at.kv + (size_t)row * ps + (size_t)hk * D + (size_t)at.page_size * at.Hkv * D;
+        const size_t ts = (size_t)at.Hkv * D;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            pf.vr[t] = make_uint2(0, 0);
+            if (t < NT - 1) pf.vr[t] = reinterpret_cast<const uint2*>(vb + (size_t)t * ts)[dq];
+        }
+        return;
+    }
     if constexpr (NT > 0 && FAST) {
         // Depth loop (the launchers pick NT > 0 only with identity pages, a fixed position and page_size >= NT): page = row, slot = token,
         // position = fixed_pos — no plan array is read, every address is base + constant * stride, and every request of the wave goes out
@@ -2816,10 +2829,12 @@ __device__ __forceinline__ void attn_short_prefetch(const AttnArgs& at, int row,
             if (u * 4 + 3 >= NT - 1) t = t < NT - 1 ? t : (NT >= 2 ? NT - 2 : 0);      // only the last pass can run past the cached tokens
             pf.kr[u] = NT >= 2 ? reinterpret_cast<const uint4*>(kb + (size_t)t * ts)[j] : make_uint4(0, 0, 0, 0);
         }
+        if constexpr (PART == 0) {
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            pf.vr[t] = make_uint2(0, 0);
-            if (t < NT - 1) pf.vr[t] = reinterpret_cast<const uint2*>(vb + (size_t)t * ts)[dq];
+            for (int t = 0; t < TMAX; ++t) {
+                pf.vr[t] = make_uint2(0, 0);
+                if (t < NT - 1) pf.vr[t] = reinterpret_cast<const uint2*>(vb + (size_t)t * ts)[dq];
+            }
         }
         return;
     }
@@ -3411,10 +3426,12 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
         {
             const int pr = blk * 2 + wave;
             const int hk = wave;
-#if VOX_DS_KV_MODE != 5
+#if VOX_DS_KV_MODE == 6 || VOX_DS_KV_MODE == 7
+            attn_short_prefetch<NT, true, 1>(at, 0, hk, lane, pf);
+#elif VOX_DS_KV_MODE != 5
             attn_short_prefetch<NT, VOX_DS_KV_MODE != 0>(at, 0, hk, lane, pf);
 #endif
-#if VOX_DS_KV_MODE == 2
+#if VOX_DS_KV_MODE == 2 || VOX_DS_KV_MODE == 7
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #elif VOX_DS_KV_MODE == 3
             __builtin_amdgcn_s_sleep(32);
@@ -3422,6 +3439,9 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             __builtin_amdgcn_s_sleep(64);
 #endif
             gran_gather_lds<2048>(a.gqkv, tagof(l, 0), reinterpret_cast<unsigned*>(qb), tid, a.err, 0x200u + l, max_spins, (a.poll_delay >> 8) & 255u);
+#if VOX_DS_KV_MODE == 6 || VOX_DS_KV_MODE == 7
+            attn_short_prefetch<NT, true, 2>(at, 0, hk, lane, pf);
+#endif
             __syncthreads();                               // q | k | v in qb (and: every wave is done with xb's stage-A reads)
             VOX_STAMP2(2 + 6 * l)
             {
