@@ -1586,7 +1586,12 @@ static int launch_gemm_fullk_t(hipStream_t st, const LinArgs& a0) {
             // few column tiles: per-CU load rate is the limit, so use twice the CUs (two 16-row blocks per column tile)
             if (a.N % 16 == 0 && a.N / 16 <= 128 && (a.N / 16) % 8 == 0) {
                 a.row_tiles = 2;
-                hipLaunchKernelGGL((k_gemm_fullk<1, KSTEPS, PRO, EPI, true>), dim3(a.N / 8), dim3(512), 0, st, a);
+                // <= 64 column tiles (the depth loop's o_proj / down: N = 1024): two 16-row blocks per tile still leave half the CUs idle —
+                // four blocks of 8 rows (the sub-tile split of the <= 16-row case: padded MFMA rows, outputs dropped, bit-identical) put
+                // a block on every CU and halve each block's activation bytes (VOX_ROWSPLIT_SUB32=0: two 16-row blocks)
+                static const bool sub32 = [] { const char* e = getenv("VOX_ROWSPLIT_SUB32"); return !(e && e[0] == '0'); }();
+                if (sub32 && a.N / 16 <= 64 && a.B > 24) { a.rt_rows = 8; a.row_tiles = (a.B + 7) / 8; }
+                hipLaunchKernelGGL((k_gemm_fullk<1, KSTEPS, PRO, EPI, true>), dim3(a.N / 16 * a.row_tiles), dim3(512), 0, st, a);
                 return VOX_OK;
             }
         }
@@ -3350,8 +3355,13 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) wp[i] = reinterpret_cast<const bf16_t*>(lp[i]);
         }
+// Where the depth step asks for the layer's cached K / V rows (all bit-identical; round-6 A/B, one-request frame):  0 the general path in front
+// of the qkv gather (round 5) | 1 the compile-time path there, nothing else: 2.41 ms — the gather's polls start ~1 us sooner and polling early
+// is traffic | 2 ... + a wait for the rows before the first poll: 2.34 | 5 with stage A's weight rows: 66 spilled registers, 2.66 | 6 K in
+// front of the gather, V behind it, no wait: 2.27 | 7 (default) K + wait in front, V behind the gather (needed a microsecond later than K;
+// in front, their 15 requests per wave stood between the block and its polls): -0.6 % against 2 with the qkv delay retuned (4 -> 6).
 #ifndef VOX_DS_KV_MODE
-#define VOX_DS_KV_MODE 2
+#define VOX_DS_KV_MODE 7
 #endif
         // the layer's attention operands that do not depend on this launch (cached K / V of the earlier tokens, norm weights, RoPE entries)
         AttnArgs at = a.at;
@@ -4184,7 +4194,7 @@ bool vox_talker_attn_supported(const AttnCall& c) {
 // are the round-6 sweep's (tools/poll_delay_sweep.sh, profiles/round6_poll_delay_sweep.txt); the environment overrides them for A/B runs
 // (hex or decimal, read when a launch is first built — frame graphs captured afterwards keep the value).
 #ifndef VOX_DS_POLL_DELAY_DEFAULT
-#define VOX_DS_POLL_DELAY_DEFAULT 0x180c0404u
+#define VOX_DS_POLL_DELAY_DEFAULT 0x18100604u
 #endif
 #ifndef VOX_MLP_POLL_DELAY_DEFAULT
 #define VOX_MLP_POLL_DELAY_DEFAULT 0x00082004u
