@@ -355,7 +355,7 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
             // one request, <= 256 visible tokens: the attention runs INSIDE the persistent launch of the layer's MLP half (blocks 0..15)
             const bool attn_in = decode_rows && n == 1 && s->mlp_persist && s->mlp_attn && !ablate() && vox_talker_attn_supported(ac);
             if ((ablate() & 1) || attn_in) {
-            } else if (decode_rows && c.max_kvlen <= 16 && !(ablate() & 512) && vox_attn_short_supported(ac)) {
+            } else if (decode_rows && c.max_kvlen <= 32 && !(ablate() & 512) && vox_attn_short_supported(ac)) {
                 VOX_TRY(vox_launch_attn_short(st, ac));      // one wave per (row, kv head), registers only
             } else if (decode_rows && !(ablate() & 1024) && vox_attn_decode8_supported(ac)) {
                 VOX_TRY(vox_launch_attn_decode8(st, ac));    // <= 256 visible tokens: every chunk and the merge in one launch

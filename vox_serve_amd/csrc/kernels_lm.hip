@@ -2882,7 +2882,8 @@ __device__ __forceinline__ void attn_short_prefetch(const AttnArgs& at, int row,
 // vnew: the new token's V row in the P.V layout (dims 4 dq .. 4 dq + 3).
 template <int NT>
 __device__ __forceinline__ void attn_short_compute(const AttnArgs& at, int row, int hk, int lane, const uint4 v, const uint2 vnew,
-                                                   const AttnShortPre<NT>& pf, bf16_t* out_row, bool do_append) {
+                                                   const AttnShortPre<NT>& pf, bf16_t* out_row, bool do_append, int hq0 = -1) {
+    if (hq0 < 0) hq0 = hk * 2;           // the wave's two q heads: hq0, hq0 + 1 (two q heads per kv head: 2 hk; four: 4 hk + 2 pair)
     constexpr int D = 128, TMAX = AttnShortPre<NT>::TMAX, UMAX = AttnShortPre<NT>::UMAX;
     const int grp = lane >> 4, j = lane & 15;
     const int g = lane >> 5, dq = lane & 31;      // P.V / output layout: lane = (q head g, dims 4 dq .. 4 dq + 3)
@@ -2987,7 +2988,7 @@ __device__ __forceinline__ void attn_short_compute(const AttnArgs& at, int row, 
     {
         uint2 r;
         r.x = pack_bf2(o[0] / l, o[1] / l); r.y = pack_bf2(o[2] / l, o[3] / l);
-        const int col = (hk * 2 + g) * D + 4 * dq;
+        const int col = (hq0 + g) * D + 4 * dq;
         *reinterpret_cast<uint2*>(out_row + col) = r;
         if (at.out_frag) *reinterpret_cast<uint2*>(at.out_frag + frag_off(row, col, at.Hq * D)) = r;
     }
@@ -2997,13 +2998,14 @@ __device__ __forceinline__ void attn_short_compute(const AttnArgs& at, int row, 
 // launch-per-stage form: the row's q / k / v come from the projection output in memory
 template <int NT>
 __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int hk, int lane, bf16_t* out_row,
-                                                bool do_append) {
+                                                bool do_append, int hq0 = -1) {
+    if (hq0 < 0) hq0 = hk * 2;
     constexpr int D = 128;
     const int grp = lane >> 4, j = lane & 15, dq = lane & 31;
     const int nqkv = (at.Hq + 2 * at.Hkv) * D;
     const bf16_t* raw = at.qkv + (size_t)row * nqkv;
-    const bf16_t* src = grp == 0 ? raw + (size_t)(hk * 2) * D
-                      : grp == 1 ? raw + (size_t)(hk * 2 + 1) * D
+    const bf16_t* src = grp == 0 ? raw + (size_t)hq0 * D
+                      : grp == 1 ? raw + (size_t)(hq0 + 1) * D
                       : grp == 2 ? raw + (size_t)at.Hq * D + (size_t)hk * D
                                  : raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D;
     const uint4 v = reinterpret_cast<const uint4*>(src)[j];
@@ -3011,17 +3013,20 @@ __device__ __forceinline__ void attn_short_wave(const AttnArgs& at, int row, int
     const uint2 vnew = reinterpret_cast<const uint2*>(raw + (size_t)(at.Hq + at.Hkv) * D + (size_t)hk * D)[dq];
     AttnShortPre<NT> pf;
     attn_short_prefetch<NT>(at, row, hk, lane, pf);
-    attn_short_compute<NT>(at, row, hk, lane, v, vnew, pf, out_row, do_append);
+    attn_short_compute<NT>(at, row, hk, lane, v, vnew, pf, out_row, do_append, hq0);
 }
 
-// standalone: one wave per (row, kv head), four pairs per block (NT as in attn_short_wave)
+// standalone: one wave per (row, kv head, PAIR of its q heads), four waves per block (NT as in attn_short_wave).  Two q heads per kv head
+// (Qwen3-TTS depth decoder): one pair.  Four (CSM-1B depth decoder, up to 32 visible tokens): two waves per (row, kv head) — each reads the
+// head's cached K / V itself (L2 hits), the first one appends the new token.
 template <int NT>
 __global__ __launch_bounds__(256) void k_attn_short(AttnArgs at, int n_pairs) {
     VOX_TR_DECL
     const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pi >= n_pairs) return;
-    const int row = pi / at.Hkv, hk = pi % at.Hkv;
-    attn_short_wave<NT>(at, row, hk, threadIdx.x & 63, at.out + (size_t)row * at.Hq * 128, true);
+    const int PP = at.Hq / (2 * at.Hkv), per_row = at.Hkv * PP;
+    const int row = pi / per_row, rem = pi - row * per_row, hk = rem / PP, pp = rem - hk * PP;
+    attn_short_wave<NT>(at, row, hk, threadIdx.x & 63, at.out + (size_t)row * at.Hq * 128, pp == 0, hk * 2 * PP + 2 * pp);
     VOX_TR_END(2, NT)
 }
 
@@ -4278,11 +4283,13 @@ static void fill_attn_args(AttnArgs& a, const AttnCall& c) {
 // which compile-time token count a short-attention launch may take: NT > 0 assumes identity pages, a fixed position and a page that
 // holds all NT tokens (attn_short_prefetch); anything else reads the plan arrays (NT = 0)
 static inline int attn_short_nt(const AttnArgs& at) {
-    return (at.identity_pages && at.fixed_pos >= 0 && at.fixed_kvlen >= 2 && at.fixed_kvlen <= 16 && at.page_size >= at.fixed_kvlen) ? at.fixed_kvlen : 0;
+    return (at.identity_pages && at.fixed_pos >= 0 && at.fixed_kvlen >= 2 && at.fixed_kvlen <= 32 && at.page_size >= at.fixed_kvlen) ? at.fixed_kvlen : 0;
 }
 // short-context decode attention: D 128, two q heads per kv head, full-width NeoX RoPE, <= 16 visible tokens
 bool vox_attn_short_supported(const AttnCall& c) {
-    return c.qkv && c.D == 128 && c.max_kvlen <= 16 && c.Nq >= 1 && c.Hkv > 0 && c.Hq == 2 * c.Hkv && c.rot == 128 &&
+    // <= 16 visible tokens: any plan; 17 .. 32: the compile-time form only (identity pages, fixed length and position: the depth loops)
+    const bool len_ok = c.max_kvlen <= 16 || (c.max_kvlen <= 32 && c.identity_pages && c.fixed_pos >= 0 && c.fixed_kvlen == c.max_kvlen && c.page_size >= c.fixed_kvlen);
+    return c.qkv && c.D == 128 && len_ok && c.Nq >= 1 && c.Hkv > 0 && (c.Hq == 2 * c.Hkv || c.Hq == 4 * c.Hkv) && c.rot == 128 &&
            !c.interleave && c.cs;
 }
 int vox_launch_attn_short(hipStream_t st, const AttnCall& c) {
@@ -4291,15 +4298,17 @@ int vox_launch_attn_short(hipStream_t st, const AttnCall& c) {
     fill_attn_args(at, c);
     at.out = (bf16_t*)c.out;
     at.out_frag = (bf16_t*)c.out_frag;
-    const int n_pairs = c.Nq * c.Hkv;
+    const int n_pairs = c.Nq * c.Hkv * (c.Hq / (2 * c.Hkv));
     // NT > 0 = the depth-loop form: identity pages, fixed position, the page holds every visible token (attn_short_prefetch)
     switch (attn_short_nt(at)) {      // depth loop: the visible length is part of the captured graph
 #define VOX_AS(NT_) case NT_: hipLaunchKernelGGL(k_attn_short<NT_>, dim3((n_pairs + 3) / 4), dim3(256), 0, st, at, n_pairs); return VOX_OK;
         VOX_AS(2) VOX_AS(3) VOX_AS(4) VOX_AS(5) VOX_AS(6) VOX_AS(7) VOX_AS(8) VOX_AS(9) VOX_AS(10) VOX_AS(11) VOX_AS(12)
-        VOX_AS(13) VOX_AS(14) VOX_AS(15) VOX_AS(16)
+        VOX_AS(13) VOX_AS(14) VOX_AS(15) VOX_AS(16) VOX_AS(17) VOX_AS(18) VOX_AS(19) VOX_AS(20) VOX_AS(21) VOX_AS(22) VOX_AS(23) VOX_AS(24)
+        VOX_AS(25) VOX_AS(26) VOX_AS(27) VOX_AS(28) VOX_AS(29) VOX_AS(30) VOX_AS(31) VOX_AS(32)
 #undef VOX_AS
         default: break;
     }
+    if (c.max_kvlen > 16) return vox_fail(VOX_ERR_INVALID, "attn_short: 17..32 tokens need the fixed-length form");
     hipLaunchKernelGGL(k_attn_short<0>, dim3((n_pairs + 3) / 4), dim3(256), 0, st, at, n_pairs);
     return VOX_OK;
 }
@@ -4307,7 +4316,7 @@ int vox_launch_attn_short(hipStream_t st, const AttnCall& c) {
 bool vox_attn1_linear_supported(const AttnCall& c, const LinearCall& l) {
     // one row only: with two rows each wave runs two attention passes back to back — the separate one-wave-per-(row, head)
     // kernel + a 2-row GEMV is faster there (B=2 frame 4.30 -> 4.05 ms)
-    return vox_attn_short_supported(c) && c.Nq == 1 && l.K == c.Hq * c.D && l.K == 2048 && l.pro == PRO_COPY &&
+    return vox_attn_short_supported(c) && c.max_kvlen <= 16 && c.Hq == 2 * c.Hkv && c.Nq == 1 && l.K == c.Hq * c.D && l.K == 2048 && l.pro == PRO_COPY &&
            l.epi == EPI_STORE && !l.x_rows && l.B == c.Nq;
 }
 int vox_launch_attn1_linear(hipStream_t st, const AttnCall& c, const LinearCall& l) {
