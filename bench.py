@@ -429,9 +429,29 @@ def kv_sweep(dev, shared, batches=(1, 32), kvs=(100, 200, 325, 1000, 2000), fram
             alg = algorithmic_bytes_per_frame(B, kvl + 3 + frames / 2)
             res[f"kv{kvl}"] = {"frame_ms": t * 1e3, "samples_per_s_lm_only": B * 1920 / t, "roofline_frac": alg / t / 1e9 / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_launch": alg}
+        # the same frame with the REFERENCE'S DEFAULT sampling for Qwen3-TTS (top-k 50 at temperature 0.9, qwen3_tts.py:1088-1096) instead of
+        # greedy: 16 stochastic draws per frame (one-request frames take the 14 inner ones inside the persistent depth-step launches)
+        scs = eng.sampling_cfg(greedy=False, top_k=50, temperature=0.9)
+        kvl = 200
+        for w_ in range(3):
+            plan(kvl + w_); eng.frame(B, kvl + w_, scs, feedback=True, use_graph=True)
+        torch.cuda.synchronize()
+        ms = []
+        for f in range(frames):
+            plan(kvl + 3 + f)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(eng.stream)
+            eng.frame(B, kvl + 3 + f, scs, feedback=True, use_graph=True)
+            ev1.record(eng.stream)
+            eng.out_ids[:B].cpu()
+            ms.append(ev0.elapsed_time(ev1))
+        t = float(np.mean(ms)) * 1e-3
+        res["kv200_top_k50_temperature0.9"] = {"frame_ms": t * 1e3, "samples_per_s_lm_only": B * 1920 / t,
+                                               "vs_greedy": t * 1e3 / res["kv200"]["frame_ms"] if "kv200" in res else None}
         out[f"batch{B}"] = res
         eng.close()
-    out["note"] = "LM frame alone (no codec chunk beside it), greedy, random KV pages; frame_ms = HIP events around the graph replay"
+    out["note"] = ("LM frame alone (no codec chunk beside it), greedy unless named otherwise, random KV pages; frame_ms = HIP events around the "
+                   "graph replay")
     return out
 
 

@@ -521,6 +521,36 @@ def test_persistent_depth_step_is_bit_identical_to_the_launch_chain(dev, monkeyp
     ea.close(); eb.close()
 
 
+@pytest.mark.parametrize("top_k,top_p,min_p,temp", [(50, 1.0, 0.0, 0.9),            # the reference's default for Qwen3-TTS (qwen3_tts.py:1088-1096)
+                                                    (25, 0.8, 0.02, 1.1), (256, 0.95, 0.0, 0.7), (1, 1.0, 0.0, 1.0)])
+def test_sampled_pick_inside_the_persistent_depth_step_equals_the_sampler_launches(dev, monkeypatch, top_k, top_p, min_p, temp):
+    """Round 6: in a one-request SAMPLED frame the top-k / top-p / min-p draw of codebook i is taken at the start of the persistent launch of
+    depth step i + 1 (every block for itself, k_sample_topk's contract) instead of in a sampler launch between the two.  Free-running
+    streams of the launch-chain engine (sampler launches: vox_sample, itself bit-exact vs the oracle in test_gpu_ops) and of the persistent
+    engine must agree in ids, logits, fed-back features and K/V — eager and as graph replays."""
+    from vox_serve_amd.engine import Qwen3Cfg
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ea, eb = _persist_pair(dev, monkeypatch, cfg, W)
+    if eb.depth_persist_status()[0] != 3:
+        pytest.skip("persistent kernels not available on this part (< 256 CUs)")
+    sc = ea.sampling_cfg(greedy=False, top_k=top_k, top_p=top_p, min_p=min_p, temperature=temp)
+    seen = set()
+    for use_graph in (False, True):
+        for f in range(6):
+            for e in (ea, eb):
+                _one_frame(e, f + (6 if use_graph else 0), sc, use_graph=use_graph)
+            torch.cuda.synchronize()
+            for name in ("out_ids", "out_logits", "out_depth_logits", "next_features", "input_features", "input_ids", "rng_offset"):
+                assert torch.equal(getattr(ea, name), getattr(eb, name)), (use_graph, f, name)
+            seen.add(tuple(ea.out_ids[0].tolist()))
+    assert torch.equal(ea.kv, eb.kv)
+    assert eb.depth_persist_status() == (3, 0)
+    assert len(seen) > 1 or top_k == 1                 # (the streams move: the draws are not a constant)
+    ea.close(); eb.close()
+
+
 def _persist_pair(dev, monkeypatch, cfg, W, ps=128):
     from vox_serve_amd.engine import Qwen3Engine
 

@@ -21,7 +21,7 @@ ps = 128
 for b in range(B):
     eng.kv[:, b * 3:(b + 1) * 3].normal_(0, 0.5)
 kvlen0 = int(os.environ.get('LM_KV', '200'))
-sc = eng.sampling_cfg(greedy=True)
+sc = eng.sampling_cfg(greedy=True) if os.environ.get('LM_SAMPLING', 'greedy') == 'greedy' else eng.sampling_cfg(greedy=False, top_k=50, temperature=0.9)      # LM_SAMPLING=topk: the reference's default for Qwen3-TTS
 eng.input_ids.zero_(); eng.input_ids[:, -1] = cfg.tts_pad_id
 def plan(kvlen):
     pages = [[b * 3 + j for j in range((kvlen + ps - 1) // ps)] for b in range(B)]

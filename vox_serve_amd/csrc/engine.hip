@@ -612,7 +612,13 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
     // One request, greedy: the pick of codebook i happens at the start of the persistent launch of step i + 1 (every block takes the
     // argmax itself) instead of in a sampler launch between the two — 14 launches less per frame; VOX_DEPTH_PICK=0 keeps them.
     static const bool pick_env = [] { const char* e = getenv("VOX_DEPTH_PICK"); return !(e && e[0] == '0'); }();
-    const bool fuse_pick = pick_env && m->dstep && B == 1 && !ablate() && sc->greedy && m->proj_tab && c.depth_vocab % 4 == 0 &&
+    // ... and round 6: the SAMPLED pick too (top-k <= 256 over the 2048-entry depth vocabulary: k_sample_topk's contract inside the launch);
+    // VOX_DEPTH_PICK_SAMPLED=0 keeps the sampler launches for sampled frames
+    static const bool pick_sampled_env = [] { const char* e = getenv("VOX_DEPTH_PICK_SAMPLED"); return !(e && e[0] == '0'); }();
+    const bool greedy_cfg = sc->greedy || sc->temperature == 0.0f;
+    const bool sampled_ok = pick_sampled_env && !greedy_cfg && sc->top_k > 0 && sc->top_k <= 256 && c.depth_vocab == 2048 && sc->temperature > 0.0f &&
+                            sc->min_p <= 1.0f;
+    const bool fuse_pick = pick_env && m->dstep && B == 1 && !ablate() && (greedy_cfg || sampled_ok) && m->proj_tab && c.depth_vocab % 4 == 0 &&
                            c.depth_vocab <= 65536 && H % 8 == 0;
     DepthStepCall pend;         // the deferred pick (pick_* fields only)
     bool have_pend = false;
@@ -659,6 +665,8 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
             if (have_pend) {
                 ds.pick_logits = pend.pick_logits; ds.pick_tab = pend.pick_tab; ds.pick_emb = pend.pick_emb; ds.pick_out = pend.pick_out;
                 ds.pick_feat = pend.pick_feat; ds.pick_vocab = pend.pick_vocab; ds.pick_H = pend.pick_H; ds.pick_init = pend.pick_init;
+                ds.pick_top_k = pend.pick_top_k; ds.pick_top_p = pend.pick_top_p; ds.pick_min_p = pend.pick_min_p; ds.pick_temperature = pend.pick_temperature;
+                ds.pick_seed = pend.pick_seed; ds.pick_offset = pend.pick_offset; ds.pick_offset_mul = pend.pick_offset_mul; ds.pick_offset_dev = pend.pick_offset_dev;
                 have_pend = false;
             }
             VOX_TRY(vox_launch_depth_step(st, ds));
@@ -689,6 +697,11 @@ static int qwen3_tail(vox_qwen3* m, hipStream_t st, const vox_qwen3_io* io, int 
         if (fuse_pick && i + 1 < G && s.emb2_table && s.feat_acc) {       // (step i + 1 >= 2 of one request is a persistent launch)
             pend.pick_logits = dl; pend.pick_vocab = c.depth_vocab; pend.pick_tab = s.emb2_table; pend.pick_emb = s.emb_table;
             pend.pick_out = io->out_ids + i; pend.pick_feat = io->next_features; pend.pick_H = H; pend.pick_init = s.feat_init;
+            pend.pick_top_k = 0;
+            if (!greedy_cfg) {      // the sampler call's parameters, as vox_launch_sample would have taken them
+                pend.pick_top_k = s.cfg.top_k; pend.pick_top_p = s.cfg.top_p; pend.pick_min_p = s.cfg.min_p; pend.pick_temperature = s.cfg.temperature;
+                pend.pick_seed = s.seed; pend.pick_offset = s.offset; pend.pick_offset_mul = s.offset_mul; pend.pick_offset_dev = (const uint64_t*)s.offset_dev;
+            }
             have_pend = true;
             continue;
         }

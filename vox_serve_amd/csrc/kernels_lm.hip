@@ -3119,6 +3119,11 @@ struct DepthStepArgs {
     int* pick_out;
     bf16_t* pick_feat;
     int pick_vocab, pick_H, pick_init;
+    // the sampled form of the pick (pick_top_k > 0): DepthStepCall
+    int pick_top_k;
+    float pick_top_p, pick_min_p, pick_temperature;
+    uint64_t pick_seed, pick_offset, pick_offset_mul;
+    const uint64_t* pick_offset_dev;
     unsigned poll_delay;         // first-pass hold-back of the four gathers, one byte each (x 128 clocks): [7:0] x (D -> A / head), [15:8] qkv, [23:16] x (B -> C), [31:24] h
 };
 #define VOX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -3300,8 +3305,140 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
     __shared__ unsigned pick_red[8];
     // The step's input row (into xb).  Called in layer 0's stage A when its weight rows have been requested: the pick is a chain of two
     // dependent round trips (the logits, then the picked id's table row) and the weights travel under it instead of behind it.
+    __shared__ int pk_wsum[2][8];
+    __shared__ int pk_isum[8], pk_pick;
     auto load_step_input = [&]() {
-    if (a.pick_logits) {
+    if (a.pick_logits && a.pick_top_k > 0) {
+        // The previous step's codebook SAMPLED here (the reference's default for Qwen3-TTS is top-k 50 at temperature 0.9, qwen3_tts.py:1088:
+        // through sampler launches between the steps a sampled one-request frame cost 17 % more than a greedy one).  k_sample_topk's contract
+        // and mechanics on 512 threads x 4 entries of the 2048-entry row: keys in registers, bisection on the key value with a block-wide
+        // count per probe, ties in index order through one packed prefix scan,
+        // rank sort of the k candidates, exp2 / sums in order, one Philox draw — every block for itself (same bits everywhere).
+        // LDS: the candidate arrays alias hb (not in use before stage C of layer 0).
+        u32* cand_key = reinterpret_cast<u32*>(hb);                 // [256] each: 5 KiB of hb's 6
+        int* cand_idx = reinterpret_cast<int*>(cand_key + 256);
+        u32* srt_key = reinterpret_cast<u32*>(cand_idx + 256);
+        int* srt_idx = reinterpret_cast<int*>(srt_key + 256);
+        float* pe = reinterpret_cast<float*>(srt_idx + 256);
+        const int k = a.pick_top_k < 2048 ? a.pick_top_k : 2048;
+        u32 key[4];
+        {
+            const uint2 w = reinterpret_cast<const uint2*>(a.pick_logits)[tid];
+            const bf16_t raw[4] = {(bf16_t)(w.x & 0xffff), (bf16_t)(w.x >> 16), (bf16_t)(w.y & 0xffff), (bf16_t)(w.y >> 16)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) key[i] = key_of(f2bf(bf2f(raw[i]) / a.pick_temperature));
+        }
+        int par = 0;
+        auto count_ge = [&](u32 t) {      // (a ballot + popcount per register: scalar arithmetic, no cross-lane moves)
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c += __popcll(__ballot(key[i] >= t));
+            if (lane == 0) pk_wsum[par][wave] = c;
+            __syncthreads();
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) tot += pk_wsum[par][w];
+            par ^= 1;
+            return tot;
+        };
+        u32 lo = 0, hi = 65536;
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (count_ge(mid) >= k) lo = mid; else hi = mid;
+        }
+        const u32 T = lo;
+        int ties = 0, aboves = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ties += key[i] == T ? 1 : 0; aboves += key[i] > T ? 1 : 0; }
+        const int mine = ties | (aboves << 16);
+        int inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off, VOX_WAVE);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) pk_isum[wave] = inc;
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { base += w < wave ? pk_isum[w] : 0; total += pk_isum[w]; }
+        const int excl = base + inc - mine;
+        const int tie_before = excl & 0xffff, above_before = excl >> 16, r = k - (total >> 16);
+        int slot = above_before + (tie_before < r ? tie_before : r), tb = tie_before;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool isT = key[i] == T;
+            if (key[i] > T || (isT && tb < r)) { cand_key[slot] = (key[i] << 16) | (0xFFFFu - (u32)(4 * tid + i)); ++slot; }      // (one word in candidate order: k_sample_topk)
+            tb += isT ? 1 : 0;
+        }
+        __syncthreads();
+        for (int j = tid; j < k; j += 512) {
+            const u32 cj = cand_key[j];
+            int rank = 0;
+            for (int i = 0; i < k; ++i) rank += cand_key[i] > cj ? 1 : 0;
+            srt_key[rank] = cj >> 16;
+            srt_idx[rank] = (int)(0xFFFFu - (cj & 0xFFFFu));
+        }
+        __syncthreads();
+        const float mval = bf2f(bits_of(srt_key[0]));
+        for (int j = tid; j < k; j += 512) pe[j] = exp2_c((bf2f(bits_of(srt_key[j])) - mval) * VOX_LOG2E);
+        __syncthreads();
+        if (tid == 0) {
+            int n = k;
+            float tot = 0.0f;
+            for (int j = 0; j < n; ++j) tot = tot + pe[j];
+            if (a.pick_min_p > 0.0f) {
+                int kk = 0;
+                while (kk < n && pe[kk] >= a.pick_min_p * pe[0]) ++kk;
+                n = kk;
+                tot = 0.0f;
+                for (int j = 0; j < n; ++j) tot = tot + pe[j];
+            }
+            if (a.pick_top_p < 1.0f) {
+                float c = 0.0f;
+                const float thr = a.pick_top_p * tot;
+                int kk = 0;
+                while (kk < n) {
+                    c = c + pe[kk];
+                    ++kk;
+                    if (c >= thr) break;
+                }
+                n = kk;
+                tot = c;
+            }
+            const uint64_t off = a.pick_offset + (a.pick_offset_dev ? (*a.pick_offset_dev) * a.pick_offset_mul : 0ull);
+            const float u = (float)(philox_u32(a.pick_seed, off, 0u) >> 8) * (1.0f / 16777216.0f);
+            const float thr = u * tot;
+            float c = 0.0f;
+            int pick = n - 1;
+            for (int j = 0; j < n; ++j) {
+                c = c + pe[j];
+                if (c > thr) {
+                    pick = j;
+                    break;
+                }
+            }
+            pk_pick = srt_idx[pick];
+        }
+        __syncthreads();
+        const int picked = pk_pick;
+        reinterpret_cast<unsigned*>(xb)[tid] = reinterpret_cast<const unsigned*>(a.pick_tab + (size_t)picked * H)[tid];
+        if (blk == 0) {
+            if (tid == 0) *a.pick_out = picked;
+            const uint4* src = reinterpret_cast<const uint4*>(a.pick_emb + (size_t)picked * a.pick_H);
+            uint4* fa = reinterpret_cast<uint4*>(a.pick_feat);
+            for (int i = tid; i < (a.pick_H >> 3); i += 512) {
+                const uint4 e = src[i];
+                const uint4 f = a.pick_init ? make_uint4(0, 0, 0, 0) : fa[i];
+                uint4 o;
+                o.x = (u32)f2bf(bflo(f.x) + bflo(e.x)) | ((u32)f2bf(bfhi(f.x) + bfhi(e.x)) << 16);
+                o.y = (u32)f2bf(bflo(f.y) + bflo(e.y)) | ((u32)f2bf(bfhi(f.y) + bfhi(e.y)) << 16);
+                o.z = (u32)f2bf(bflo(f.z) + bflo(e.z)) | ((u32)f2bf(bfhi(f.z) + bfhi(e.z)) << 16);
+                o.w = (u32)f2bf(bflo(f.w) + bflo(e.w)) | ((u32)f2bf(bfhi(f.w) + bfhi(e.w)) << 16);
+                fa[i] = o;
+            }
+        }
+    } else if (a.pick_logits) {
         // The previous step's codebook, picked here instead of by a sampler launch in between (greedy frames): every block takes the
         // first maximum of the 2048 logits — order of (value, lowest index), the sampler's — and reads the step's input row of that id
         // from the tabulated projection; block 0 records the id and adds the id's embedding to the next frame's feature row.
@@ -4252,6 +4389,12 @@ int vox_launch_depth_step(hipStream_t st, const DepthStepCall& c) {
             return vox_fail(VOX_ERR_INVALID, "depth_step: bad fused-pick arguments");
         a.pick_logits = (const bf16_t*)c.pick_logits; a.pick_tab = (const bf16_t*)c.pick_tab; a.pick_emb = (const bf16_t*)c.pick_emb;
         a.pick_out = c.pick_out; a.pick_feat = (bf16_t*)c.pick_feat; a.pick_vocab = c.pick_vocab; a.pick_H = c.pick_H; a.pick_init = c.pick_init;
+        if (c.pick_top_k > 0) {
+            if (c.pick_vocab != 2048 || c.pick_top_k > 256 || !(c.pick_temperature > 0.0f) || c.pick_min_p > 1.0f)
+                return vox_fail(VOX_ERR_INVALID, "depth_step: the sampled pick takes a 2048-entry vocabulary, top_k <= 256, temperature > 0");
+            a.pick_top_k = c.pick_top_k; a.pick_top_p = c.pick_top_p; a.pick_min_p = c.pick_min_p; a.pick_temperature = c.pick_temperature;
+            a.pick_seed = c.pick_seed; a.pick_offset = c.pick_offset; a.pick_offset_mul = c.pick_offset_mul; a.pick_offset_dev = c.pick_offset_dev;
+        }
     }
     AttnArgs& at = a.at;
     at.kv = (const bf16_t*)c.kv; at.kv_w = (bf16_t*)c.kv; at.cs = c.cs; at.eps = c.eps; at.scale = c.scale;

@@ -8,26 +8,7 @@
 #define SAMP_KMAX 256
 #define SAMP_LDS_VMAX 32768
 
-__device__ __forceinline__ u32 key_of(bf16_t b) {
-    if (b == 0x8000) b = 0;  // -0 == +0
-    return (b & 0x8000) ? (u32)(~b & 0xffff) : (u32)(b | 0x8000);
-}
-__device__ __forceinline__ bf16_t bits_of(u32 key) { return (key & 0x8000) ? (bf16_t)(key & 0x7fff) : (bf16_t)(~key & 0xffff); }
-
-__device__ __forceinline__ u32 philox_u32(uint64_t seed, uint64_t offset, u32 row) {
-    u32 c0 = (u32)offset, c1 = (u32)(offset >> 32), c2 = row, c3 = 0;
-    u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n1 = (u32)p1;
-        const u32 n2 = (u32)(p0 >> 32) ^ c3 ^ k1, n3 = (u32)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return c0;
-}
+// (key_of / bits_of / philox_u32: vox_device.h — the persistent depth step's fused sampled pick uses them too)
 
 struct SampArgs {
     bf16_t* logits;
@@ -287,6 +268,161 @@ __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
     emit_pick(a, b, picked, tid, 256);
 }
 
+// ---- top-k for vocabularies of <= 4096 entries (every codec vocabulary of the hot path): keys in registers ---------------------------
+// Same contract as k_sample's top-k branch (oracle/voxref.c::vr_sample: the k largest by (value desc, index asc), exp2 / sums in that order,
+// one Philox draw), other mechanics: a thread keeps EPT CONSECUTIVE entries of the row as sortable keys in registers (index order = thread
+// order), the k-th largest key is found by bisection on the key value with a block-wide count per probe (16 probes, no atomics — the two
+// LDS-atomic histogram passes of k_sample serialise on the few exponent bins a row of logits falls into, and thread 0 then walks 2 x 256
+// bins), ties of that key are taken in index order through ONE packed prefix scan (ties | aboves << 16), which also gives every thread the
+// slots of its candidates.  The reference's default for Qwen3-TTS is top-k 50 at temperature 0.9 (qwen3_tts.py:1088-1096): 16 sampler calls
+// per frame, 23 -> ~8 us each.
+template <int EPT>
+__global__ __launch_bounds__(256) void k_sample_topk(SampArgs a) {
+    __shared__ int wsum[2][4];
+    __shared__ int sh_i[8];
+    __shared__ u32 cand_key[SAMP_KMAX], srt_key[SAMP_KMAX];
+    __shared__ int srt_idx[SAMP_KMAX];
+    __shared__ float pe[SAMP_KMAX];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = a.V;
+    bf16_t* lg = a.logits + (size_t)b * V;
+    preprocess_row(a, lg, b, tid, 256);
+    const int k = a.top_k < V ? a.top_k : V;
+    // keys of entries tid * EPT .. + EPT - 1 (0 with valid = false past the row's end)
+    u32 key[EPT];
+    const int v0 = tid * EPT;
+    {
+        const bool vec = (reinterpret_cast<uintptr_t>(lg) & 15u) == 0 && v0 + EPT <= V;
+        bf16_t raw[EPT];
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < EPT / 8; ++q) {
+                const uint4 w = reinterpret_cast<const uint4*>(lg + v0)[q];
+                raw[8 * q + 0] = (bf16_t)(w.x & 0xffff); raw[8 * q + 1] = (bf16_t)(w.x >> 16); raw[8 * q + 2] = (bf16_t)(w.y & 0xffff); raw[8 * q + 3] = (bf16_t)(w.y >> 16);
+                raw[8 * q + 4] = (bf16_t)(w.z & 0xffff); raw[8 * q + 5] = (bf16_t)(w.z >> 16); raw[8 * q + 6] = (bf16_t)(w.w & 0xffff); raw[8 * q + 7] = (bf16_t)(w.w >> 16);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) raw[i] = v0 + i < V ? lg[v0 + i] : (bf16_t)0;
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) key[i] = key_of(f2bf(bf2f(raw[i]) / a.temperature));
+    }
+    const int nvalid = V - v0 < 0 ? 0 : (V - v0 < EPT ? V - v0 : EPT);
+    // block-wide sum of a per-thread count (buffers alternate: one barrier per call)
+    // block-wide count of the entries with key >= t: a ballot + popcount per register (scalar arithmetic — as a per-lane count the wave sum is
+    // six dependent cross-lane moves per probe, 16 probes), one LDS word per wave, buffers alternating by probe: one barrier per probe
+    int par = 0;
+    auto count_ge = [&](u32 t) {
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) c += __popcll(__ballot(i < nvalid && key[i] >= t));
+        if (lane == 0) wsum[par][wave] = c;
+        __syncthreads();
+        const int tot = wsum[par][0] + wsum[par][1] + wsum[par][2] + wsum[par][3];
+        par ^= 1;
+        return tot;
+    };
+    // the largest T with count(key >= T) >= k  (count(key >= 0) = V >= k)
+    u32 lo = 0, hi = 65536;
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (count_ge(mid) >= k) lo = mid; else hi = mid;
+    }
+    const u32 T = lo;
+    // ties (key == T) and aboves (key > T) of this thread; one packed inclusive scan over the block in thread order
+    int ties = 0, aboves = 0;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        ties += (i < nvalid && key[i] == T) ? 1 : 0;
+        aboves += (i < nvalid && key[i] > T) ? 1 : 0;
+    }
+    int inc = ties | (aboves << 16);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, VOX_WAVE);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[par][wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[par][w];
+    const int total = wsum[par][0] + wsum[par][1] + wsum[par][2] + wsum[par][3];
+    par ^= 1;
+    const int excl = base + inc - (ties | (aboves << 16));
+    const int tie_before = excl & 0xffff, above_before = excl >> 16;
+    const int above_total = total >> 16;
+    const int r = k - above_total;                       // ties to take, by ascending index
+    int slot = above_before + (tie_before < r ? tie_before : r);
+    int tb = tie_before;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        if (i < nvalid) {
+            const bool isT = key[i] == T;
+            if (key[i] > T || (isT && tb < r)) {
+                // (key, index) as ONE word whose unsigned order is the candidate order (key descending, index ascending; index < 4096):
+                // the rank loop below is then one compare per candidate on unconditional, vectorisable LDS reads — as two arrays with a
+                // short-circuit `||` every candidate cost two LDS round trips waited for one by one (5 us of the kernel at k = 50)
+                cand_key[slot] = (key[i] << 16) | (0xFFFFu - (u32)(v0 + i));
+                ++slot;
+            }
+            tb += isT ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    const int n0 = k;
+    for (int j = tid; j < n0; j += 256) {
+        const u32 cj = cand_key[j];
+        int rank = 0;
+        for (int i = 0; i < n0; ++i) rank += cand_key[i] > cj ? 1 : 0;
+        srt_key[rank] = cj >> 16;
+        srt_idx[rank] = (int)(0xFFFFu - (cj & 0xFFFFu));
+    }
+    __syncthreads();
+    const float mval = bf2f(bits_of(srt_key[0]));
+    for (int j = tid; j < n0; j += 256) pe[j] = exp2_c((bf2f(bits_of(srt_key[j])) - mval) * VOX_LOG2E);
+    __syncthreads();
+    if (tid == 0) {
+        int n = n0;
+        float tot = 0.0f;
+        for (int j = 0; j < n; ++j) tot = tot + pe[j];
+        if (a.min_p > 0.0f) {
+            int kk = 0;
+            while (kk < n && pe[kk] >= a.min_p * pe[0]) ++kk;
+            n = kk;
+            tot = 0.0f;
+            for (int j = 0; j < n; ++j) tot = tot + pe[j];
+        }
+        if (a.top_p < 1.0f) {
+            float c = 0.0f;
+            const float thr = a.top_p * tot;
+            int kk = 0;
+            while (kk < n) {
+                c = c + pe[kk];
+                ++kk;
+                if (c >= thr) break;
+            }
+            n = kk;
+            tot = c;
+        }
+        const uint64_t off = a.offset + (a.offset_dev ? (*a.offset_dev) * a.offset_mul : 0ull);
+        const float u = (float)(philox_u32(a.seed, off, (u32)b) >> 8) * (1.0f / 16777216.0f);
+        const float thr = u * tot;
+        float c = 0.0f;
+        int pick = n - 1;
+        for (int j = 0; j < n; ++j) {
+            c = c + pe[j];
+            if (c > thr) {
+                pick = j;
+                break;
+            }
+        }
+        sh_i[7] = srt_idx[pick];
+    }
+    __syncthreads();
+    emit_pick(a, b, sh_i[7], tid, 256);
+}
+
 // ---- full-vocabulary ("bucket") mode: top-p-only / min-p-only over any V -------------------------
 // Contract: oracle/voxref.c::sample_bucket / bk_find.  One 1024-thread block per row.  The 65536-bin key
 // histogram lives in a per-context global scratch (L2-resident, 256 KiB per row) that is all-zero between
@@ -541,6 +677,13 @@ int vox_launch_sample(hipStream_t st, const SampleCall& c) {
         if (c.cfg.top_k > SAMP_KMAX)
             return vox_fail(VOX_ERR_INVALID, "sample: top_k %d > %d", c.cfg.top_k, SAMP_KMAX);
         smem = c.V <= SAMP_LDS_VMAX ? (size_t)c.V * 2 : 0;
+        // <= 4096 entries: the register form (VOX_SAMPLE_TOPK_REG=0: the histogram form, A/B)
+        static const bool reg = [] { const char* e = getenv("VOX_SAMPLE_TOPK_REG"); return !(e && e[0] == '0'); }();
+        if (reg && c.V <= 4096) {
+            if (c.V <= 2048) hipLaunchKernelGGL(k_sample_topk<8>, dim3(c.B), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_sample_topk<16>, dim3(c.B), dim3(256), 0, st, a);
+            return VOX_OK;
+        }
     }
     hipLaunchKernelGGL(k_sample, dim3(c.B), dim3(256), smem, st, a);
     return VOX_OK;

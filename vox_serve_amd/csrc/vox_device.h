@@ -128,3 +128,28 @@ __device__ __forceinline__ uint4 ldg_nt(const uint4* p) {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
+
+// ---- sampler pieces shared by sampler.hip and the persistent depth step's fused pick (kernels_lm.hip) ----
+// sortable key of a bf16 value (value order == unsigned key order; -0 == +0) and its inverse; Philox4x32-10 word 0 of (seed, offset, row)
+__device__ __forceinline__ u32 key_of(bf16_t b) {
+    if (b == 0x8000) b = 0;  // -0 == +0
+    return (b & 0x8000) ? (u32)(~b & 0xffff) : (u32)(b | 0x8000);
+}
+__device__ __forceinline__ bf16_t bits_of(u32 key) { return (key & 0x8000) ? (bf16_t)(key & 0x7fff) : (bf16_t)(~key & 0xffff); }
+
+__device__ __forceinline__ u32 philox_u32(uint64_t seed, uint64_t offset, u32 row) {
+    u32 c0 = (u32)offset, c1 = (u32)(offset >> 32), c2 = row, c3 = 0;
+    u32 k0 = (u32)seed, k1 = (u32)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n1 = (u32)p1;
+        const u32 n2 = (u32)(p0 >> 32) ^ c3 ^ k1, n3 = (u32)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+

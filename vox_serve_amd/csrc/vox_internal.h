@@ -130,6 +130,12 @@ struct DepthStepCall {
     int* pick_out = nullptr;
     void* pick_feat = nullptr;
     int pick_vocab = 0, pick_H = 0, pick_init = 0;
+    // ... or the SAMPLED pick (pick_top_k > 0; vocabulary of exactly 2048 entries): top-k / top-p / min-p at a temperature with the draw
+    // philox(seed, pick_offset + *pick_offset_dev * pick_offset_mul, row 0) — k_sample_topk's contract, every block for itself
+    int pick_top_k = 0;
+    float pick_top_p = 1.0f, pick_min_p = 0.0f, pick_temperature = 1.0f;
+    uint64_t pick_seed = 0, pick_offset = 0, pick_offset_mul = 0;
+    const uint64_t* pick_offset_dev = nullptr;
 };
 // Persistent MLP half of a talker layer at one row (o_proj + residual, gate/up, down + residual in one launch; kernels_lm.hip)
 struct TalkerMlpCall {
