@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_sample(SampArgs a) {
     emit_pick(a, b, picked, tid, 256);
 }
 
-// ---- top-k for vocabularies of <= 4096 entries (every codec vocabulary of the hot path): keys in registers ---------------------------
+// ---- top-k for vocabularies of <= 8192 entries (every codec vocabulary of the hot path): keys in registers ---------------------------
 // Same contract as k_sample's top-k branch (oracle/voxref.c::vr_sample: the k largest by (value desc, index asc), exp2 / sums in that order,
 // one Philox draw), other mechanics: a thread keeps EPT CONSECUTIVE entries of the row as sortable keys in registers (index order = thread
 // order), the k-th largest key is found by bisection on the key value with a block-wide count per probe (16 probes, no atomics — the two
@@ -677,11 +677,12 @@ int vox_launch_sample(hipStream_t st, const SampleCall& c) {
         if (c.cfg.top_k > SAMP_KMAX)
             return vox_fail(VOX_ERR_INVALID, "sample: top_k %d > %d", c.cfg.top_k, SAMP_KMAX);
         smem = c.V <= SAMP_LDS_VMAX ? (size_t)c.V * 2 : 0;
-        // <= 4096 entries: the register form (VOX_SAMPLE_TOPK_REG=0: the histogram form, A/B)
+        // <= 8192 entries: the register form (VOX_SAMPLE_TOPK_REG=0: the histogram form, A/B)
         static const bool reg = [] { const char* e = getenv("VOX_SAMPLE_TOPK_REG"); return !(e && e[0] == '0'); }();
-        if (reg && c.V <= 4096) {
+        if (reg && c.V <= 8192) {      // (Qwen3-TTS 3072 / 2048, CSM-1B 2051, CosyVoice2 6564)
             if (c.V <= 2048) hipLaunchKernelGGL(k_sample_topk<8>, dim3(c.B), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(k_sample_topk<16>, dim3(c.B), dim3(256), 0, st, a);
+            else if (c.V <= 4096) hipLaunchKernelGGL(k_sample_topk<16>, dim3(c.B), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_sample_topk<32>, dim3(c.B), dim3(256), 0, st, a);
             return VOX_OK;
         }
     }
