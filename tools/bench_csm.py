@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=20)
+ap.add_argument("--topk", action="store_true", help="the reference's default sampling for CSM-1B (top-k 50 at temperature 0.9, csm.py:355-360) instead of greedy")
 args = ap.parse_args()
 B, dev = args.batch, torch.device("cuda")
 cfg = CSMCfg()
@@ -31,7 +32,7 @@ mimi = MimiDecoder(synth_mimi_weights(MimiConfig(), seed=0), MimiConfig(), devic
 C1, ps, n0 = cfg.n_codebooks + 1, 128, 64
 rng = np.random.default_rng(1)
 pages = [[b * 4 + j for j in range(4)] for b in range(B)]
-sc = eng.sampling_cfg(greedy=True)
+sc = eng.sampling_cfg(greedy=False, top_k=50, temperature=0.9) if args.topk else eng.sampling_cfg(greedy=True)
 for b in range(B):                       # one prefill per request: 64 text rows
     ids = np.zeros((n0, C1), np.int32); ids[:, -1] = rng.integers(0, 128000, n0)
     masks = np.zeros((n0, C1), np.uint8); masks[:, -1] = 1
@@ -110,7 +111,7 @@ dt = time.perf_counter() - t0
 t1 = time.perf_counter(); mimi.decode(ring, code_layout="BTQ"); torch.cuda.synchronize(); t_codec = time.perf_counter() - t1
 frame_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 kv_bytes = B * (n0 + args.warmup + args.steps / 2) * cfg.backbone.layers * 2 * cfg.backbone.kv_heads * cfg.backbone.head_dim * 2
-print(json.dumps({"workload": f"CSM-1B bf16 + Mimi, batch={B}, greedy, 64-token prompt, detokenize_interval 10",
+print(json.dumps({"workload": f"CSM-1B bf16 + Mimi, batch={B}, {'top-k 50 T 0.9' if args.topk else 'greedy'}, 64-token prompt, detokenize_interval 10",
                   "audio_samples_per_s": B * 1920 * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
                   "lm_frame_graph_ms": frame_ms, "mimi_chunk_ms": t_codec * 1e3, "realtime_factor_per_request": 1920 * args.steps / dt / 24000,
                   "roofline": (lambda alg, sched: {"bound": "hbm", "achieved": alg / (frame_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",

@@ -3383,42 +3383,11 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
         const float mval = bf2f(bits_of(srt_key[0]));
         for (int j = tid; j < k; j += 512) pe[j] = exp2_c((bf2f(bits_of(srt_key[j])) - mval) * VOX_LOG2E);
         __syncthreads();
-        if (tid == 0) {
-            int n = k;
-            float tot = 0.0f;
-            for (int j = 0; j < n; ++j) tot = tot + pe[j];
-            if (a.pick_min_p > 0.0f) {
-                int kk = 0;
-                while (kk < n && pe[kk] >= a.pick_min_p * pe[0]) ++kk;
-                n = kk;
-                tot = 0.0f;
-                for (int j = 0; j < n; ++j) tot = tot + pe[j];
-            }
-            if (a.pick_top_p < 1.0f) {
-                float c = 0.0f;
-                const float thr = a.pick_top_p * tot;
-                int kk = 0;
-                while (kk < n) {
-                    c = c + pe[kk];
-                    ++kk;
-                    if (c >= thr) break;
-                }
-                n = kk;
-                tot = c;
-            }
+        if (wave == 0) {
             const uint64_t off = a.pick_offset + (a.pick_offset_dev ? (*a.pick_offset_dev) * a.pick_offset_mul : 0ull);
             const float u = (float)(philox_u32(a.pick_seed, off, 0u) >> 8) * (1.0f / 16777216.0f);
-            const float thr = u * tot;
-            float c = 0.0f;
-            int pick = n - 1;
-            for (int j = 0; j < n; ++j) {
-                c = c + pe[j];
-                if (c > thr) {
-                    pick = j;
-                    break;
-                }
-            }
-            pk_pick = srt_idx[pick];
+            const int pick = sample_tail_wave(pe, k, a.pick_min_p, a.pick_top_p, u, lane);
+            if (lane == 0) pk_pick = srt_idx[pick];
         }
         __syncthreads();
         const int picked = pk_pick;

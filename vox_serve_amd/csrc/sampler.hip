@@ -382,42 +382,11 @@ __global__ __launch_bounds__(256) void k_sample_topk(SampArgs a) {
     const float mval = bf2f(bits_of(srt_key[0]));
     for (int j = tid; j < n0; j += 256) pe[j] = exp2_c((bf2f(bits_of(srt_key[j])) - mval) * VOX_LOG2E);
     __syncthreads();
-    if (tid == 0) {
-        int n = n0;
-        float tot = 0.0f;
-        for (int j = 0; j < n; ++j) tot = tot + pe[j];
-        if (a.min_p > 0.0f) {
-            int kk = 0;
-            while (kk < n && pe[kk] >= a.min_p * pe[0]) ++kk;
-            n = kk;
-            tot = 0.0f;
-            for (int j = 0; j < n; ++j) tot = tot + pe[j];
-        }
-        if (a.top_p < 1.0f) {
-            float c = 0.0f;
-            const float thr = a.top_p * tot;
-            int kk = 0;
-            while (kk < n) {
-                c = c + pe[kk];
-                ++kk;
-                if (c >= thr) break;
-            }
-            n = kk;
-            tot = c;
-        }
+    if (wave == 0) {
         const uint64_t off = a.offset + (a.offset_dev ? (*a.offset_dev) * a.offset_mul : 0ull);
         const float u = (float)(philox_u32(a.seed, off, (u32)b) >> 8) * (1.0f / 16777216.0f);
-        const float thr = u * tot;
-        float c = 0.0f;
-        int pick = n - 1;
-        for (int j = 0; j < n; ++j) {
-            c = c + pe[j];
-            if (c > thr) {
-                pick = j;
-                break;
-            }
-        }
-        sh_i[7] = srt_idx[pick];
+        const int pick = sample_tail_wave(pe, n0, a.min_p, a.top_p, u, lane);
+        if (lane == 0) sh_i[7] = srt_idx[pick];
     }
     __syncthreads();
     emit_pick(a, b, sh_i[7], tid, 256);

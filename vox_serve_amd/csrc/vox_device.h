@@ -152,4 +152,66 @@ __device__ __forceinline__ u32 philox_u32(uint64_t seed, uint64_t offset, u32 ro
     return c0;
 }
 
+// The serial tail of the top-k samplers (oracle/voxref.c::vr_sample: tot = sum of pe[0..n) IN ORDER, the optional min-p / top-p cuts, the
+// first j with pe[0] + .. + pe[j] > u * tot), run by ONE full wave; returns the picked candidate position.  pe: the n0 <= 256 probabilities
+// in candidate order (LDS).  The sums have to be taken sequentially (the contract is their rounding), but every decision is a comparison
+// against a PREFIX of that one chain: so the chain runs once — candidate j's value comes out of lane j % 64 through v_readlane with a
+// compile-time lane, every lane adds (uniform c), lane j keeps c_j — and the cuts and the pick are ballots over the kept prefixes.  (As a
+// thread-0 loop over LDS each of the 2 k dependent adds waited for its own ds_read: ~3.4 of the kernel's ~10 us at k = 50.)
+__device__ __forceinline__ int sample_tail_wave(const float* pe, int n0, float min_p, float top_p, float u, int lane) {
+    float per[4], cpre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) per[q] = (lane + 64 * q) < n0 ? pe[lane + 64 * q] : 0.0f;      // (+ 0.0f leaves a non-negative sum unchanged)
+    float c = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float cm = 0.0f;
+        if (64 * q < n0) {                  // uniform
+#pragma unroll
+            for (int J = 0; J < 64; ++J) {
+                c = c + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, per[q]), J));
+                cm = lane == J ? c : cm;
+            }
+        }
+        cpre[q] = cm;                       // c_j of candidate j = lane + 64 q
+    }
+    // first candidate position < lim for which flag holds, else lim
+    auto first_of = [&](const bool (&f)[4], int lim) {
+        int r = lim;
+#pragma unroll
+        for (int q = 3; q >= 0; --q) {
+            const unsigned long long b = __ballot(f[q] && (lane + 64 * q) < lim);
+            if (b) r = 64 * q + (int)__builtin_ctzll(b);
+        }
+        return r;
+    };
+    auto prefix_at = [&](int j) {           // c_j for a uniform j in [0, n0)
+        const int q = j >> 6, l = j & 63;
+        float v = 0.0f;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cpre[qq]), __builtin_amdgcn_readfirstlane(l)));
+            v = qq == q ? t : v;
+        }
+        return v;
+    };
+    int n = n0;
+    float tot = prefix_at(n - 1);
+    if (min_p > 0.0f) {
+        const float cut = min_p * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, per[0]), 0));
+        const bool f[4] = {!(per[0] >= cut), !(per[1] >= cut), !(per[2] >= cut), !(per[3] >= cut)};
+        n = first_of(f, n);
+        tot = n > 0 ? prefix_at(n - 1) : 0.0f;
+    }
+    if (top_p < 1.0f) {
+        const float thr = top_p * tot;
+        const bool f[4] = {cpre[0] >= thr, cpre[1] >= thr, cpre[2] >= thr, cpre[3] >= thr};
+        const int j = first_of(f, n);
+        if (j < n) { n = j + 1; tot = prefix_at(j); }
+    }
+    const float thr = u * tot;
+    const bool f[4] = {cpre[0] > thr, cpre[1] > thr, cpre[2] > thr, cpre[3] > thr};
+    const int j = first_of(f, n);
+    return j < n ? j : n - 1;
+}
 
