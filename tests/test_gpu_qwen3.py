@@ -568,8 +568,8 @@ def _persist_pair(dev, monkeypatch, cfg, W, ps=128):
     return make(False), make(True)
 
 
-def _one_frame(e, f, sc, ps=128, use_graph=True):
-    kv = 150 + f
+def _one_frame(e, f, sc, ps=128, use_graph=True, kv0=150):
+    kv = kv0 + f
     pages = list(range((kv + ps - 1) // ps))
     e.upload_plan(pos=[kv], kvlen=[kv], page=[pages[-1]], slot=[(kv - 1) % ps], indptr=[0, len(pages)], indices=pages)
     e.frame(1, kv, sc, seed=3, feedback=True, use_graph=use_graph)
@@ -733,6 +733,37 @@ def test_a_handoff_timeout_that_cannot_be_replayed_raises_before_anything_is_res
     en, err = eb.depth_persist_status()
     assert en == 3 and err == code and len(eb._graphs) == n_graphs and eb.persist_failures == []
     eb.close()
+
+
+@pytest.mark.parametrize("kv0,two_chunks", [(250, False), (250, True), (300, True)])      # 250: crosses 256 visible tokens
+def test_attention_inside_the_talker_launch(dev, monkeypatch, kv0, two_chunks):
+    """Round 6: the decode attention of a one-request frame runs inside the persistent talker-layer launch (blocks 0..15) by default, one
+    32-token chunk per wave up to 256 visible tokens (k_talker_mlp<8>); beyond that the layer takes the attention launches again.  The
+    two-chunks-per-wave form up to 512 tokens (k_talker_mlp<16>, VOX_TALKER_ATTN512=1: measured slower, off) is covered too.  Against the
+    launch-chain engine (decode8 / partial + merge): ids, logits, fed-back features and K/V bit-identical."""
+    if two_chunks:
+        pytest.skip("VOX_TALKER_ATTN512 is read once per process: run this case alone with VOX_TALKER_ATTN512=1") if __import__("os").environ.get("VOX_TALKER_ATTN512") != "1" else None
+    from vox_serve_amd.engine import Qwen3Cfg
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ea, eb = _persist_pair(dev, monkeypatch, cfg, W)
+    if eb.depth_persist_status()[0] != 3:
+        pytest.skip("persistent kernels not available on this part (< 256 CUs)")
+    g = torch.Generator(device=dev).manual_seed(9)
+    rnd = (torch.randn(ea.kv[:, 3:6].shape, generator=g, device=dev) * 0.5).to(ea.kv.dtype)
+    for e in (ea, eb):
+        e.kv[:, 3:6] = rnd
+    sc = ea.sampling_cfg(greedy=True)
+    for f in range(12):
+        for e in (ea, eb):
+            _one_frame(e, f, sc, kv0=kv0)
+        torch.cuda.synchronize()
+        for name in ("out_ids", "out_logits", "out_depth_logits", "next_features", "input_features", "input_ids"):
+            assert torch.equal(getattr(ea, name), getattr(eb, name)), (kv0, f, name)
+    assert torch.equal(ea.kv, eb.kv)
+    assert eb.depth_persist_status() == (3, 0)
+    ea.close(); eb.close()
 
 
 def test_persistent_kernels_with_a_codec_chunk_on_a_second_stream(dev, monkeypatch):

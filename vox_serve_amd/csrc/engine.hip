@@ -412,11 +412,13 @@ static int stack_enable_mlp_persist(vox_stack* s) {
         const unsigned words[4] = {1u, 0u, vox_persist_spins_default(), 0u};      // epoch, error, poll bound, test hook
         VOX_HIP(hipMemcpy(s->mlp_words, words, 16, hipMemcpyHostToDevice));
         s->mlp_persist = 1;
-        // the decode attention INSIDE that launch (blocks 0..15): built, bit-identical, and measured equal to the two-launch form
-        // (2.447 vs 2.442 ms per frame: what the overlapped weight stream saves, the 512-thread attention under that stream
-        // loses — DESIGN.md §3.1); opt-in for A/B
+        // the decode attention INSIDE that launch (blocks 0..15, <= 256 visible tokens): bit-identical.  Round 5 measured it equal to the
+        // two-launch form (what the overlapped weight stream saved, the 512-thread attention under that stream lost: its 16 K/V requests
+        // per thread took 8.9 us to issue).  Round 6: with one address computation per tile instead of one per request (a 32-token chunk
+        // lies in one page: VOX_KV_ASM_FETCH) and the tuned polls the frame is 2.2 % shorter with it (2.157 -> 2.110 ms) — default on,
+        // VOX_TALKER_ATTN=0 keeps the attention launch
         const char* ea = getenv("VOX_TALKER_ATTN");
-        s->mlp_attn = (ea && ea[0] == '1') && s->cfg.heads == 16 && s->cfg.kv_heads == 8 && s->cfg.head_dim == 128;
+        s->mlp_attn = !(ea && ea[0] == '0') && s->cfg.heads == 16 && s->cfg.kv_heads == 8 && s->cfg.head_dim == 128;
     }
     return VOX_OK;
 }

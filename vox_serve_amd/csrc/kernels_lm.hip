@@ -2233,6 +2233,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
             for (int u = 0; u < KVL; ++u) { \
                 const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT; \
+                if (one_page && u > 0) { pgi_pre[ci][u] = 0; continue; } \
                 pgi_pre[ci][u] = pages ? (tok < L - 1 ? pages[page_of(a, tok)] : 0) : row; \
             } \
     } \
@@ -2247,13 +2248,22 @@ _Pragma("unroll") \
             kreg[u] = u32x4_t{0u, 0u, 0u, 0u}; \
             vreg[u] = u32x4_t{0u, 0u, 0u, 0u}; \
         } \
+        /* A 32-token chunk lies inside ONE page when the page size is a power of two >= 32 (one_page): the thread's requests are then */ \
+        /* base + u * stride — one 64-bit address computation per tile instead of one per request (page select, shift / mask, two */ \
+        /* 64-bit multiply-adds: ~85 instructions between two requests of a wave that has 8 .. 16 of them to issue) */ \
+        const bf16_t* fast_base = nullptr; \
+        size_t fast_stride = 0; \
+        if (one_page) { \
+            fast_base = a.kv + (size_t)pgi_pre[ci][0] * ps + ((size_t)((t0 & (a.page_size - 1)) + gt / LPT) * a.Hkv + hk) * D; \
+            fast_stride = (size_t)(GT / LPT) * a.Hkv * D; \
+        } \
 _Pragma("unroll") \
         for (int u = 0; u < KVL; ++u) { \
             const int i = gt + GT * u, t = i / LPT, j = i % LPT; \
             const int tok = t0 + t; \
             if (i < VOX_TC * LPT && tok < L - 1) { \
-                const int pgi = pgi_pre[ci][u]; \
-                const bf16_t* base = a.kv + (size_t)pgi * ps + ((size_t)slot_of(a, tok) * a.Hkv + hk) * D; \
+                const int pgi = pgi_pre[ci][one_page ? 0 : u]; \
+                const bf16_t* base = one_page ? fast_base + (size_t)u * fast_stride : a.kv + (size_t)pgi * ps + ((size_t)slot_of(a, tok) * a.Hkv + hk) * D; \
                 const uint4* kp = reinterpret_cast<const uint4*>(base) + j; \
                 const uint4* vp = reinterpret_cast<const uint4*>(base + (size_t)a.page_size * a.Hkv * D) + j; \
                 if (ci == 0) { \
@@ -2326,11 +2336,13 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
     // read (clamped to the table row) and never used
     int pgi_pre[CPG][KVL];
     const bool hoist = a.ptab && a.hoist;
+    const bool one_page = a.page_shift >= 5 && (GT % LPT) == 0;      // (VOX_TC = 32 tokens: a chunk never straddles a page; VOX_KV_ASM_FETCH)
     if (hoist) {
 #pragma unroll
         for (int ci = 0; ci < CPG; ++ci)
 #pragma unroll
             for (int u = 0; u < KVL; ++u) {
+                if (one_page && u > 0) { pgi_pre[ci][u] = 0; continue; }      // one page id per chunk
                 const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT;
                 const int pi = page_of(a, tok);
                 pgi_pre[ci][u] = pages[pi < a.pt_stride ? pi : a.pt_stride - 1];
@@ -3779,11 +3791,13 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
     // read (clamped to the table row) and never used
     int pgi_pre[CPG][KVL];
     const bool hoist = a.ptab && a.hoist;
+    const bool one_page = a.page_shift >= 5 && (GT % LPT) == 0;      // (VOX_TC = 32 tokens: a chunk never straddles a page; VOX_KV_ASM_FETCH)
     if (hoist) {
 #pragma unroll
         for (int ci = 0; ci < CPG; ++ci)
 #pragma unroll
             for (int u = 0; u < KVL; ++u) {
+                if (one_page && u > 0) { pgi_pre[ci][u] = 0; continue; }      // one page id per chunk
                 const int tok = (grp + NG * ci) * VOX_TC + (gt + GT * u) / LPT;
                 const int pi = page_of(a, tok);
                 pgi_pre[ci][u] = pages[pi < a.pt_stride ? pi : a.pt_stride - 1];
@@ -4027,7 +4041,7 @@ __device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g,
 // (their K/V tiles and page ids are requested when the launch starts: no kernel boundary and no second exposed round trip in front
 // of them), while the other 240 blocks already hold their first o_proj / gate / up weight rows in registers: the weight stream of the
 // MLP half runs under the attention's latency chain instead of behind it.
-using TalkerAttnSmem = AttnDecodeSmem<128, 1, 8, 8, 512>;
+template <int NCH> using TalkerAttnSmemT = AttnDecodeSmem<128, 1, 8, (NCH ? NCH : 8), 512>;
 #ifdef VOX_DEV_KNOBS
 // development builds: phase stamps of the layer launch from an attention block (0) and a plain block (100): records {kind 4 | 5, ATTN, t0..t7, end}
 #define MLP_TR_DECL unsigned long long mt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mslot = ~0ull;                                      \
@@ -4041,8 +4055,10 @@ using TalkerAttnSmem = AttnDecodeSmem<128, 1, 8, 8, 512>;
 #define MLP_TR(k)
 #define MLP_TR_END
 #endif
-template <bool ATTN>
+// ATTN = 0: no attention in the launch; 8 / 16: its chunk count (<= 256 / <= 512 visible tokens: one / two 32-token chunks per wave)
+template <int ATTN>
 __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
+    using TalkerAttnSmem = TalkerAttnSmemT<ATTN>;
     constexpr int H = 2048, F = 6144;
     // x' (bf16 row) | h | the attention row; ATTN: carved from the attention's LDS (dead by then — barrier below)
     __shared__ __attribute__((aligned(16))) unsigned char smem[ATTN ? sizeof(TalkerAttnSmem) : (H + F) * 2];
@@ -4103,7 +4119,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     if (!attn_blk) load_c1();
     if (attn_blk) {
         // q head blk: kv head blk / 2, half blk % 2 of its two-head group (the launch form's head split); row 0
-        attn_decode8_block<128, 1, 8, 8, 512>(a.at, *reinterpret_cast<TalkerAttnSmem*>(smem), 2, blk >> 1, blk & 1, 0, a.gattn, &wsh[1], false,
+        attn_decode8_block<128, 1, 8, (ATTN ? ATTN : 8), 512>(a.at, *reinterpret_cast<TalkerAttnSmem*>(smem), 2, blk >> 1, blk & 1, 0, a.gattn, &wsh[1], false,
                                               [&]() { park_words(); load_o(); }, a.epoch);
         load_c1();
     } else if (ATTN) {
@@ -4299,7 +4315,10 @@ bool vox_talker_mlp_supported(const TalkerMlpCall& c) { return c.hidden == 2048 
 // the decode attention inside the launch: one row, 16 q heads of 128 on 8 kv heads, <= 256 visible tokens (8 chunks), fused decode mode
 static void fill_attn_args(AttnArgs& a, const AttnCall& c);
 bool vox_talker_attn_supported(const AttnCall& c) {
-    return c.qkv && c.Nq == 1 && c.D == 128 && c.Hq == 16 && c.Hkv == 8 && c.max_kvlen > VOX_TC && c.max_kvlen <= 8 * VOX_TC;
+    // (<= 256 visible tokens: one chunk per wave.  Two chunks per wave up to 512 — k_talker_mlp<16>, kept compiled and tested — measured
+    // SLOWER than the attention launches there: 2.26 vs 2.17 ms per frame at 325 tokens, 2.26 vs 2.20 at 480; VOX_TALKER_ATTN512=1 for A/B)
+    static const bool a512 = [] { const char* e = getenv("VOX_TALKER_ATTN512"); return e && e[0] == '1'; }();
+    return c.qkv && c.Nq == 1 && c.D == 128 && c.Hq == 16 && c.Hkv == 8 && c.max_kvlen > VOX_TC && c.max_kvlen <= (a512 ? 16 : 8) * VOX_TC;
 }
 // First-pass hold-back of the persistent kernels' gathers (gran_poll_all), one byte per gather site in units of 128 clocks.  The defaults
 // are the round-6 sweep's (tools/poll_delay_sweep.sh, profiles/round6_poll_delay_sweep.txt); the environment overrides them for A/B runs
@@ -4334,10 +4353,11 @@ int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
         a.burst_delay = delay < 0 ? 0 : (delay > 64 ? 64 : delay);
         const int psl = [] { const char* e = getenv("VOX_TALKER_ATTN_POLL"); return e ? atoi(e) : 1; }();
         a.poll_sleep = psl < 1 ? 1 : (psl > 64 ? 64 : psl);
-        hipLaunchKernelGGL(k_talker_mlp<true>, dim3(256), dim3(512), 0, st, a);
+        if (ac.max_kvlen <= 8 * VOX_TC) hipLaunchKernelGGL(k_talker_mlp<8>, dim3(256), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(k_talker_mlp<16>, dim3(256), dim3(512), 0, st, a);
         return VOX_OK;
     }
-    hipLaunchKernelGGL(k_talker_mlp<false>, dim3(256), dim3(512), 0, st, a);
+    hipLaunchKernelGGL(k_talker_mlp<0>, dim3(256), dim3(512), 0, st, a);
     return VOX_OK;
 }
 
