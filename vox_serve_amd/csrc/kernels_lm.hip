@@ -2711,7 +2711,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8_v1(AttnArgs a) {
 // (read per call — launches are captured into graphs, this is not a hot path — so that a test can A/B it)
 static int decode16_min_rows() {
     const char* e = getenv("VOX_ATTN_DECODE16");
-    if (!e) return 20;      // measured at kv 330: 4 / 8 / 12 rows slower (+4 .. +2 %), 16 equal, 24 -1.9 %, 32 -4.2 %
+    if (!e) return 16;      // measured at kv 330: 4 / 8 / 12 rows slower (+4 .. +2 %), 16 equal (round 6, one address computation per tile: -1.8 %), 24 -1.9 %, 32 -4.2 %
     const int v = atoi(e);
     return v <= 0 ? (1 << 30) : v;
 }
