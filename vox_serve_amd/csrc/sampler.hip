@@ -496,7 +496,9 @@ __device__ void bk_find_blk(const BK& c, float thr, int strict, BKShared& S, int
 }
 
 __global__ __launch_bounds__(1024) void k_sample_bucket(SampArgs a) {
-    __shared__ u32 tile[256][33];
+    // pass 1's histogram of one sign's 32768 keys (128 KiB); the coarse pass's staging tile reuses its head afterwards
+    __shared__ __attribute__((aligned(16))) u32 lhist[32768];
+    u32 (*tile)[33] = reinterpret_cast<u32 (*)[33]>(lhist);
     __shared__ BKShared S;
     __shared__ u32 wred[16];
     __shared__ int sh_pick;
@@ -508,13 +510,66 @@ __global__ __launch_bounds__(1024) void k_sample_bucket(SampArgs a) {
 
     preprocess_row(a, lg, b, tid, 1024);
 
-    // pass 1: keys, histogram, largest key
+    // pass 1: keys, histogram, largest key.  Large vocabularies: the histogram is built in LDS, one sign of the values at a time (32768 keys
+    // each), and written to the global 65536-bin table with plain stores of the non-zero bins — as 168960 global atomics per row it was 160
+    // of the kernel's 300 us (a row of logits falls into a few thousand bins, and same-address atomics serialise in L2); the second half
+    // is counted from the keys the first one stored (no second division).  300 -> 207 us per call at 168960 entries.  Small vocabularies
+    // keep the global atomics (the two 128 KiB LDS sweeps per half would cost more than they save).
+    // (Measured and rejected: the coarse masses summed straight from the LDS histogram — 64-way bank conflicts on 2 of 16 waves: +30 us.)
     u32 kmx = 0;
-    for (int v = tid; v < V; v += 1024) {
-        const u32 ky = key_of(f2bf(bf2f(lg[v]) / a.temperature));
-        keys[v] = (uint16_t)ky;
-        atomicAdd(hist + ky, 1u);
-        kmx = ky > kmx ? ky : kmx;
+    if (V >= 32768) {
+        for (int half = 1; half >= 0; --half) {
+            for (int i = tid; i < 8192; i += 1024) reinterpret_cast<uint4*>(lhist)[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+            if (half) {
+                // (the row in 16-byte chunks, two in flight per thread)
+                auto take = [&](bf16_t x, int v) {
+                    const u32 ky = key_of(f2bf(bf2f(x) / a.temperature));
+                    keys[v] = (uint16_t)ky;
+                    kmx = ky > kmx ? ky : kmx;
+                    if (ky >> 15) atomicAdd(&lhist[ky & 0x7FFFu], 1u);
+                };
+                auto take8 = [&](const uint4 q, int v0) {
+                    take((bf16_t)(q.x & 0xffff), v0); take((bf16_t)(q.x >> 16), v0 + 1); take((bf16_t)(q.y & 0xffff), v0 + 2); take((bf16_t)(q.y >> 16), v0 + 3);
+                    take((bf16_t)(q.z & 0xffff), v0 + 4); take((bf16_t)(q.z >> 16), v0 + 5); take((bf16_t)(q.w & 0xffff), v0 + 6); take((bf16_t)(q.w >> 16), v0 + 7);
+                };
+                int head = (int)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(lg) & 15u)) & 15u) >> 1);
+                head = head < V ? head : V;
+                for (int v = tid; v < head; v += 1024) take(lg[v], v);
+                const int nvec = (V - head) >> 3;
+                const uint4* lv = reinterpret_cast<const uint4*>(lg + head);
+                int i = tid;
+                for (; i + 1024 < nvec; i += 2048) {
+                    const uint4 q0 = lv[i], q1 = lv[i + 1024];
+                    take8(q0, head + 8 * i);
+                    take8(q1, head + 8 * (i + 1024));
+                }
+                if (i < nvec) take8(lv[i], head + 8 * i);
+                for (int v = head + 8 * nvec + tid; v < V; v += 1024) take(lg[v], v);
+            } else {
+                const int nk = V >> 3;
+                const uint4* kv = reinterpret_cast<const uint4*>(keys);
+                auto cnt = [&](u32 ky) { if (!(ky >> 15)) atomicAdd(&lhist[ky], 1u); };
+                for (int i = tid; i < nk; i += 1024) {
+                    const uint4 q = kv[i];
+                    cnt(q.x & 0xffff); cnt(q.x >> 16); cnt(q.y & 0xffff); cnt(q.y >> 16); cnt(q.z & 0xffff); cnt(q.z >> 16); cnt(q.w & 0xffff); cnt(q.w >> 16);
+                }
+                for (int v = 8 * nk + tid; v < V; v += 1024) cnt(keys[v]);
+            }
+            __syncthreads();
+            for (int i = tid; i < 32768; i += 1024) {
+                const u32 n = lhist[i];
+                if (n) hist[(half << 15) | i] = n;
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int v = tid; v < V; v += 1024) {
+            const u32 ky = key_of(f2bf(bf2f(lg[v]) / a.temperature));
+            keys[v] = (uint16_t)ky;
+            atomicAdd(hist + ky, 1u);
+            kmx = ky > kmx ? ky : kmx;
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -579,6 +634,9 @@ __global__ __launch_bounds__(1024) void k_sample_bucket(SampArgs a) {
     const float u = (float)(philox_u32(a.seed, off, (u32)b) >> 8) * (1.0f / 16777216.0f);
     bk_find_blk(c, u * tot, 1, S, tid);
     const u32 kp = (u32)S.kp, j = S.j;
+#if defined(BK_STOP) && BK_STOP == 3
+    if (kmx != 0x12345u) return;
+#endif
 
     // pass 3: the j-th element (ascending index) whose key is kp; wave w owns a contiguous index range
     const int chunk = ((V + 15) / 16 + 63) & ~63;
