@@ -251,6 +251,7 @@ struct vox_stack {
     unsigned* mlp_words = nullptr;
     int mlp_persist = 0;
     int mlp_attn = 0;       // ... and the layer's decode attention inside that launch (VOX_TALKER_ATTN=0: its own launch in front)
+    void* mlp_tab = nullptr;      // ... and every layer in ONE launch: the device table of the layers' weight pointers (VOX_TALKER_MULTI=0: a launch per layer)
 };
 
 // decode_rows: every row is the newest token of a distinct request (its K/V are not read by any other row), so the
@@ -363,6 +364,15 @@ static int stack_layers(vox_stack* s, hipStream_t st, void* x, void* kv, int64_t
                 VOX_TRY(vox_launch_attn_partial(st, ac));
                 if (mc > 1) VOX_TRY(vox_launch_attn_merge(st, part_o, part_ml, r->q_kvlen, s->attn_out, n, c.heads, c.head_dim, mc, ac.out_frag));
             }
+            if (attn_in && s->mlp_tab && l == 0) {
+                // ... and all layers in that one launch: the next layer's q | k | v reaches its attention blocks as hand-off granules
+                TalkerMlpCall tm;
+                tm.x = x; tm.gran = s->mlp_gran; tm.epoch = s->mlp_words; tm.err = s->mlp_words + 1; tm.eps = c.eps;
+                tm.hidden = c.hidden; tm.nq = nq; tm.ffn = c.ffn; tm.nqkv = nqkv;
+                tm.attn_call = &ac; tm.layer_tab = s->mlp_tab; tm.n_layers = c.layers; tm.kv_layer_stride = (long)kv_stride;      // (elements: the layers lie kv_stride * 2 BYTES apart)
+                VOX_TRY(vox_launch_talker_mlp(st, tm));
+                return VOX_OK;
+            }
             if (decode_rows && n == 1 && s->mlp_persist && !ablate()) {
                 // one request: o_proj + residual, gate/up, down + residual as ONE persistent launch (bit-identical to the three below)
                 TalkerMlpCall tm;
@@ -406,9 +416,9 @@ static int stack_enable_mlp_persist(vox_stack* s) {
     (void)hipGetDevice(&dev_id);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id);
     if (want && n_cu >= 256 && vox_talker_mlp_supported(probe) && !s->cfg.qkv_bias) {
-        if (hipMalloc(&s->mlp_gran, 5120 * 8) != hipSuccess || hipMalloc((void**)&s->mlp_words, 16) != hipSuccess)
+        if (hipMalloc(&s->mlp_gran, 7168 * 8) != hipSuccess || hipMalloc((void**)&s->mlp_words, 16) != hipSuccess)
             return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc");
-        VOX_HIP(hipMemset(s->mlp_gran, 0, 5120 * 8));
+        VOX_HIP(hipMemset(s->mlp_gran, 0, 7168 * 8));
         const unsigned words[4] = {1u, 0u, vox_persist_spins_default(), 0u};      // epoch, error, poll bound, test hook
         VOX_HIP(hipMemcpy(s->mlp_words, words, 16, hipMemcpyHostToDevice));
         s->mlp_persist = 1;
@@ -419,6 +429,17 @@ static int stack_enable_mlp_persist(vox_stack* s) {
         // VOX_TALKER_ATTN=0 keeps the attention launch
         const char* ea = getenv("VOX_TALKER_ATTN");
         s->mlp_attn = !(ea && ea[0] == '0') && s->cfg.heads == 16 && s->cfg.kv_heads == 8 && s->cfg.head_dim == 128;
+        // every layer in one launch (round 6): needs the attention in the launch, head norms, a RoPE table and bias-free projections
+        const char* em = getenv("VOX_TALKER_MULTI");
+        bool multi = s->mlp_attn && !(em && em[0] == '0') && s->cfg.qk_norm && s->rope && s->cfg.layers >= 1;
+        for (const vox_layer_weights& w : s->layers) multi = multi && !w.bqkv && w.qnorm && w.knorm;
+        if (multi) {
+            std::vector<const void*> tab;
+            for (const vox_layer_weights& w : s->layers)
+                for (const void* q : {w.wo, w.wgate, w.wup, w.wdown, w.ln2, w.wqkv, w.ln1, w.qnorm, w.knorm}) tab.push_back(q);
+            if (hipMalloc(&s->mlp_tab, tab.size() * sizeof(void*)) != hipSuccess) return vox_fail(VOX_ERR_NOMEM, "stack_create: hipMalloc");
+            VOX_HIP(hipMemcpy(s->mlp_tab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice));
+        }
     }
     return VOX_OK;
 }
@@ -484,7 +505,7 @@ int vox_stack_create(vox_ctx* ctx, const vox_stack_config* cfg, const vox_layer_
 }
 void vox_stack_destroy(vox_stack* s) {
     if (!s) return;
-    (void)hipFree(s->mlp_gran); (void)hipFree(s->mlp_words);
+    (void)hipFree(s->mlp_gran); (void)hipFree(s->mlp_words); (void)hipFree(s->mlp_tab);
     for (auto& f : s->fw) { (void)hipFree(f.qkv); (void)hipFree(f.o); (void)hipFree(f.gate); (void)hipFree(f.up); (void)hipFree(f.down); }
     (void)hipFree(s->xfrag); (void)hipFree(s->hfrag); (void)hipFree(s->afrag);
     (void)hipFree(s->qkv); (void)hipFree(s->q); (void)hipFree(s->h); (void)hipFree(s->attn_out); (void)hipFree(s->xn); (void)hipFree(s->skws); (void)hipFree(s->attn_ws);
@@ -948,7 +969,7 @@ int vox_qwen3_persist_reset(vox_qwen3* m, int disable) {
         return hipMemset(gran, 0, n_gran * 8);
     };
     VOX_HIP(reset(m->dstep_words, m->dstep_gran, 4096));
-    VOX_HIP(reset(m->talker->mlp_words, m->talker->mlp_gran, 5120));
+    VOX_HIP(reset(m->talker->mlp_words, m->talker->mlp_gran, 7168));
     if (disable) { m->dstep = 0; m->talker->mlp_persist = 0; }
     return VOX_OK;
 }

@@ -1990,6 +1990,19 @@ __device__ __forceinline__ PrepOps prep_head_load(const bf16_t* src, const bf16_
     o.csx = c.x; o.csy = c.y;
     return o;
 }
+// ... the head row staged in LDS by the caller (q | k | v of the new token gathered from hand-off granules: k_talker_layers); norm weight and
+// RoPE table must exist (no pointer selects between LDS and global memory)
+template <int D>
+__device__ __forceinline__ PrepOps prep_head_load_lds(const bf16_t* src_lds, const bf16_t* nw, const float* cs_row, int rot, int lane) {
+    constexpr int LPT = D / 8;
+    PrepOps o;
+    const int l = lane < LPT ? lane : 0;
+    o.v = reinterpret_cast<const u32x4_t*>(src_lds)[l];
+    o.g = *((const VOX_GLOBAL_AS u32x4_t*)nw + l);
+    const VOX_GLOBAL_AS float* cp = (const VOX_GLOBAL_AS float*)cs_row + 2 * (lane < (rot >> 1) ? lane : 0);
+    o.csx = cp[0]; o.csy = cp[1];
+    return o;
+}
 // the operands are in registers from here on (the caller's own wait may already have covered them)
 __device__ __forceinline__ void prep_head_arrived(PrepOps& o) { asm volatile("" : "+v"(o.v), "+v"(o.g), "+v"(o.csx), "+v"(o.csy)); }
 template <int D>
@@ -2273,7 +2286,7 @@ _Pragma("unroll") \
                     kreg[u] = *reinterpret_cast<const u32x4_t*>(kp); \
                     vreg[u] = *reinterpret_cast<const u32x4_t*>(vp); \
                 } \
-            } else if (i < VOX_TC * LPT && tok == L - 1) { \
+            } else if (!kRawLds && i < VOX_TC * LPT && tok == L - 1) { \
                 const uint4* vp = reinterpret_cast<const uint4*>(raw + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D) + j; \
                 if (ci == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(vreg[u]) : "v"(vp) : "memory"); \
                 else vreg[u] = *reinterpret_cast<const u32x4_t*>(vp); \
@@ -2358,6 +2371,7 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
     // K/V tiles of this group's chunks.  The row's newest token (index L - 1) comes from the projection output: its V row is
     // loaded into the tile here, its K row (per-head norm + RoPE below) is read from Knew by the score pass.
 #if VOX_KV_ASM
+    constexpr bool kRawLds = false;
     VOX_KV_ASM_FETCH
 #else
     uint4 kreg[KVL], vreg[KVL];
@@ -2831,7 +2845,7 @@ __device__ __forceinline__ void attn_short_prefetch(const AttnArgs& at, int row,
         pf.L = NT; pf.nt = NT;
         const bf16_t* nwp = grp < 2 ? at.qn : at.kn;                    // (grp 3 = the new v takes no norm: its weight chunk is not used)
         pf.gw4 = make_uint4(0, 0, 0, 0);
-        if (at.qn && at.kn) pf.gw4 = reinterpret_cast<const uint4*>(nwp)[j];      // uniform condition
+        if (at.qn && at.kn) pf.gw4 = ldg(reinterpret_cast<const uint4*>(nwp) + j);      // uniform condition
         int p = at.fixed_pos;
         p = p < 0 ? 0 : (p >= at.table_max_pos ? at.table_max_pos - 1 : p);
         const float4* cp = reinterpret_cast<const float4*>(at.cs + (size_t)p * D) + (j & 7) * 4;   // row = D/2 (c,s) pairs
@@ -3476,7 +3490,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             const VOX_CONST_AS unsigned long long* lp = (const VOX_CONST_AS unsigned long long*)(a.layers + l);
             const bf16_t** wp = reinterpret_cast<const bf16_t**>(&w);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) wp[i] = reinterpret_cast<const bf16_t*>(lp[i]);
+            for (int i = 0; i < 9; ++i) wp[i] = assume_global(reinterpret_cast<const bf16_t*>(lp[i]));
         }
 // Where the depth step asks for the layer's cached K / V rows (all bit-identical; round-6 A/B, one-request frame):  0 the general path in front
 // of the qkv gather (round 5) | 1 the compile-time path there, nothing else: 2.41 ms — the gather's polls start ~1 us sooner and polling early
@@ -3500,16 +3514,16 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
             for (int r = 0; r < 2; ++r) {
                 const uint4* wr = reinterpret_cast<const uint4*>(w.wqkv + (size_t)(n0 + r) * H);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) wq[r][j] = wr[lane + 64 * j];
+                for (int j = 0; j < 2; ++j) wq[r][j] = ldg(wr + lane + 64 * j);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) nwv[j] = reinterpret_cast<const uint4*>(w.ln1)[lane + 64 * j];
+            for (int j = 0; j < 2; ++j) nwv[j] = ldg(reinterpret_cast<const uint4*>(w.ln1) + lane + 64 * j);
             // (every wave requests — waves 2..7 the rows of wave 0 / 1 again, cache hits — and the chunks are named values, not an array: as
             // an array filled under `wave < 2` they were kept in scratch memory, stored behind a vmcnt(0) each)
             const uint4* wor0 = reinterpret_cast<const uint4*>(w.wo + (size_t)(2 * (blk * 2 + (wave & 1))) * NQ) + lane;
             const uint4* wor1 = wor0 + NQ / 8;
-            const uint4 wo00 = wor0[0], wo01 = wor0[64], wo02 = wor0[128], wo03 = wor0[192];
-            const uint4 wo10 = wor1[0], wo11 = wor1[64], wo12 = wor1[128], wo13 = wor1[192];
+            const uint4 wo00 = ldg(wor0), wo01 = ldg(wor0 + 64), wo02 = ldg(wor0 + 128), wo03 = ldg(wor0 + 192);
+            const uint4 wo10 = ldg(wor1), wo11 = ldg(wor1 + 64), wo12 = ldg(wor1 + 128), wo13 = ldg(wor1 + 192);
 #if VOX_DS_KV_MODE == 5
             // requested HERE, behind the stage's weight rows and in front of the x gather: between stage A's publish and the qkv gather (where
             // they used to go out) their return stood in front of the gather's polls — loads return in order — for 0.1 us per visible token
@@ -3614,10 +3628,10 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
                     const uint4* gr = reinterpret_cast<const uint4*>(w.wgate + (size_t)(f0 + r) * H);
                     const uint4* ur = reinterpret_cast<const uint4*>(w.wup + (size_t)(f0 + r) * H);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) { wg[r][j] = gr[lane + 64 * j]; wu[r][j] = ur[lane + 64 * j]; }
+                    for (int j = 0; j < 2; ++j) { wg[r][j] = ldg(gr + lane + 64 * j); wu[r][j] = ldg(ur + lane + 64 * j); }
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) nwv[j] = reinterpret_cast<const uint4*>(w.ln2)[lane + 64 * j];
+                for (int j = 0; j < 2; ++j) nwv[j] = ldg(reinterpret_cast<const uint4*>(w.ln2) + lane + 64 * j);
             }
             // (xc's last readers, the previous layer's stage-D residual words, were done before this layer's stage-A barrier: the barrier
             // below is not needed for correctness — it parks the waves that have nothing to do in stage B's o_proj away from the poll loop)
@@ -3659,7 +3673,7 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
                 for (int r = 0; r < 2; ++r) {
                     const uint4* wr = reinterpret_cast<const uint4*>(w.wdown + (size_t)(n0 + r) * F);
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) wd[r][j] = wr[lane + 64 * j];
+                    for (int j = 0; j < 6; ++j) wd[r][j] = ldg(wr + lane + 64 * j);
                 }
             }
             gran_gather_lds<1536>(a.gh, tagof(l, 2), reinterpret_cast<unsigned*>(hb), tid, a.err, 0x600u + l, max_spins, a.poll_delay >> 24);
@@ -3758,11 +3772,17 @@ struct AttnDecodeSmem {
     float Po[NCH][GMAX][D];
     float2 Pml[NCH][GMAX];
     float Wm[NCH][GMAX];
+    bf16_t Raw[3 * D];          // RAWLDS: q head | k head | v head of the new token, staged by the caller's `stage_raw`
 };
-template <int D, int GMAX, int NG, int NCH, int NT, typename AfterPark>
+// RAWLDS (GMAX = 1): the new token's q / k / v rows are not read from a.qkv but from sm.Raw, which `stage_raw()` fills (it ends with a
+// block barrier) — called BEHIND the first tile's K / V requests, so that the cached rows travel while the caller still waits for q | k | v
+struct NoStage { __device__ void operator()() const {} };
+template <int D, int GMAX, int NG, int NCH, int NT, bool RAWLDS = false, typename AfterPark, typename StageRaw = NoStage>
 __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecodeSmem<D, GMAX, NG, NCH, NT>& sm, int HS, int hk, int hs, int row,
                                                     unsigned long long* gout, const unsigned* gtag_lds, bool skip_publish, AfterPark after_park,
-                                                    const unsigned* dbg_words = nullptr) {
+                                                    const unsigned* dbg_words = nullptr, StageRaw stage_raw = StageRaw()) {
+    constexpr bool kRawLds = RAWLDS;
+    static_assert(!RAWLDS || GMAX == 1, "RAWLDS: one q head per block");
     constexpr int LPT = D / 8, TPW = 64 / LPT, GT = NT / NG, GW = GT / 64, CPG = NCH / NG;
     constexpr int KVL = (VOX_TC * LPT + GT - 1) / GT;
     constexpr bool QREG = GMAX <= 2;
@@ -3782,7 +3802,9 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         stamp2_base[13] = wall_clock64() + (p1 < -5);
     }
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wave16 = tid >> 6;
+    int tid_ = threadIdx.x;
+    if constexpr (RAWLDS) asm volatile("" : "+v"(tid_));      // (called once per layer of a loop: nothing per-thread hoisted out of it)
+    const int tid = tid_, lane = tid & 63, wave16 = tid >> 6;
     const int grp = tid / GT, gt = tid % GT, gw = wave16 % GW;
     const int* pages = a.identity_pages ? nullptr
                        : (a.ptab ? a.ptab + (size_t)row * a.pt_stride : a.indices + a.indptr[a.q_req[row]]);
@@ -3848,6 +3870,19 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
     auto head_src = [&](int h) { return h == G ? raw + (size_t)a.Hq * D + (size_t)hk * D : raw + (size_t)(hk * Gf + g0 + h) * D; };
     PrepOps po0;
     pages_arrived();
+    if constexpr (RAWLDS) {
+        // (the tile is waited for right here: its requests are asm statements — the compiler does not know their destinations are in
+        // flight, and anything it might do with those registers in between, a copy at a loop edge or a spill, would read them too early)
+        fetch_tile(0);
+        kv_wait();
+        stage_raw();                               // q | k | v of the new token -> sm.Raw (ends with a barrier)
+        if (wave16 < 2) po0 = prep_head_load_lds<D>(sm.Raw + (wave16 == 1 ? D : 0), wave16 == 1 ? a.kn : a.qn, cs_row, a.rot, lane);
+        if (wave16 < 2) {
+            prep_head_arrived(po0);
+            prep_head_apply<D>(po0, wave16 == 1 ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, sm.Sh + wave16 * D,
+                               wave16 == 1 ? sm.Knew : reinterpret_cast<bf16_t*>(sm.Qs), lane);
+        }
+    } else {
     if (wave16 < G + 1) po0 = prep_head_load<D>(head_src(wave16), wave16 == G ? a.kn : a.qn, cs_row, a.rot, lane);
     fetch_tile(0);
     kv_wait();
@@ -3858,6 +3893,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         bf16_t* dst = isk ? sm.Knew : reinterpret_cast<bf16_t*>(sm.Qs) + (size_t)h * D;
         if (h == wave16) prep_head_apply<D>(po0, isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, sm.Sh + wave16 * D, dst, lane);
         else prep_head<D>(head_src(h), isk ? a.kn : a.qn, a.eps, cs_row, a.rot, a.interleave, sm.Sh + wave16 * D, dst, lane);
+    }
     }
     VOX_STAMP2(2)
 #pragma unroll
@@ -3870,7 +3906,12 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
 #pragma unroll
         for (int u = 0; u < KVL; ++u) {
             const int i = gt + GT * u;
-            if (i < VOX_TC * LPT) { sm.Ks[grp][i] = as_uint4(kreg[u]); sm.Vs[grp][i] = as_uint4(vreg[u]); }
+            if (i < VOX_TC * LPT) {
+                sm.Ks[grp][i] = as_uint4(kreg[u]);
+                uint4 vv = as_uint4(vreg[u]);
+                if (RAWLDS && own_last && i / LPT == nt - 1) vv = reinterpret_cast<const uint4*>(sm.Raw + 2 * D)[i % LPT];
+                sm.Vs[grp][i] = vv;
+            }
         }
         if (ci + 1 < CPG) fetch_tile(ci + 1);  // in flight during this chunk's arithmetic
         __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
@@ -4002,7 +4043,15 @@ struct TalkerMlpArgs {
     int poll_sleep;                  // s_sleep(8) repeats between two polls of the sentinel granule
     unsigned poll_delay;             // first-pass hold-back of the gathers, one byte each (x 128 clocks): [7:0] x' (O -> C), [15:8] h (C -> D), [23:16] x (D -> next qkv), [31:24] the attention row (ATTN form)
     AttnArgs at;
+    // MULTI form (k_talker_mlp<ATTN, true>): ALL decoder layers in one launch.  Layer l takes its weights from tab[l] (and the next layer's
+    // q/k/v projection from tab[l + 1]), its K / V cache at at.kv + l * kv_layer_stride; stage A hands q | k | v to the next layer's
+    // attention blocks as granules (gq) instead of a plain row behind a kernel boundary.  Layer 0's q | k | v is the plain row at.qkv.
+    const struct TalkerLayerW* tab;
+    int n_layers;
+    long kv_layer_stride;
+    unsigned long long* gq;          // granules: 2048 (the 4096-wide q | k | v row)
 };
+struct TalkerLayerW { const bf16_t *wo, *wgate, *wup, *wdown, *ln2, *wqkv, *ln1, *qn, *kn; };
 template <int TOTAL>
 __device__ __forceinline__ void gran_gather_lds_all(const unsigned long long* g, unsigned tag, unsigned* dst, int tid, unsigned* err, unsigned code, unsigned max_spins, unsigned delay = 0) {
     constexpr int PER = (TOTAL + 511) / 512;
@@ -4056,8 +4105,20 @@ template <int NCH> using TalkerAttnSmemT = AttnDecodeSmem<128, 1, 8, (NCH ? NCH 
 #define MLP_TR_END
 #endif
 // ATTN = 0: no attention in the launch; 8 / 16: its chunk count (<= 256 / <= 512 visible tokens: one / two 32-token chunks per wave)
-template <int ATTN>
+// MULTI: every layer of the stack in this launch (ATTN form only)
+template <int ATTN, bool MULTI = false>
 __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
+    static_assert(!MULTI || ATTN == 8, "MULTI: the attention runs in the launch");
+    // MULTI: register arrays that only some waves fill are (re)defined at their declaration, at no cost: left alone, their value at the
+    // top of the layer loop is "the previous layer's or none" — live across the whole loop, and the allocator keeps them in scratch
+    // memory (every weight row stored behind a wait of its own)
+    auto fresh = [](auto& arr) {
+        if constexpr (MULTI) {
+            uint4* p = reinterpret_cast<uint4*>(&arr);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(arr) / sizeof(uint4)); ++i) asm volatile("" : "=v"(p[i]));
+        }
+    };
     using TalkerAttnSmem = TalkerAttnSmemT<ATTN>;
     constexpr int H = 2048, F = 6144;
     // x' (bf16 row) | h | the attention row; ATTN: carved from the attention's LDS (dead by then — barrier below)
@@ -4066,7 +4127,8 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     uint4* const xb = reinterpret_cast<uint4*>(smem);
     uint4* const hb = xb + H / 8;
     uint4* const ab = hb + F / 8;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), blk = blockIdx.x;
+    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6), blk = blockIdx.x;
+    int tid = tid0, lane = tid0 & 63;
     // The launch's state words {epoch, error, poll bound, test hook}: read by ONE thread per block and handed to the others through
     // LDS.  (Every thread reading them with the L1-bypassing loads such words need put 6144 wave requests per launch on one L2 line:
     // with loads returning in order, every wave's first real operand waited behind that queue — the attention's page ids arrived 8.7 us
@@ -4078,28 +4140,56 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         w_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);
         w_inj = __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT);
     }
-    auto park_words = [&]() { if (tid == 0) { wsh[0] = w_ep; wsh[1] = w_ep * 64u + 4u; wsh[2] = w_spins; wsh[3] = w_inj; } };
     MLP_TR_DECL
     const bool attn_blk = ATTN && blk < 16;
+    const int nl = MULTI ? a.n_layers : 1;
+    unsigned ep = 0, max_spins = 0;
+    bool drop_first = false;
+    unsigned resw_carry = 0;          // MULTI: this wave's pair of x'' (stage D) is its residual pair of the next layer's stage O
+    int l = 0;
+    do {
+    if constexpr (MULTI) {
+        // (the thread index made opaque per layer: left visible, every per-thread address of the body — granule pointers of four gathers,
+        // weight row offsets — is hoisted out of the layer loop and kept in registers across it: 908 bytes of scratch per lane)
+        tid = tid0;
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+    }
+    // the layer's operands: the launch arguments, or (MULTI) row l of the layer table through scalar loads
+    const bf16_t *p_wo = a.wo, *p_wgate = a.wgate, *p_wup = a.wup, *p_wdown = a.wdown, *p_ln2 = a.ln2, *p_wqkv_next = a.wqkv_next, *p_ln1_next = a.ln1_next;
+    AttnArgs at = a.at;
+    if constexpr (MULTI) {
+        static_assert(sizeof(TalkerLayerW) == 9 * sizeof(void*), "TalkerLayerW: nine pointers");
+        const VOX_CONST_AS unsigned long long* lp = (const VOX_CONST_AS unsigned long long*)(a.tab + l);
+        p_wo = assume_global(reinterpret_cast<const bf16_t*>(lp[0])); p_wgate = assume_global(reinterpret_cast<const bf16_t*>(lp[1])); p_wup = assume_global(reinterpret_cast<const bf16_t*>(lp[2]));
+        p_wdown = assume_global(reinterpret_cast<const bf16_t*>(lp[3])); p_ln2 = assume_global(reinterpret_cast<const bf16_t*>(lp[4]));
+        at.qn = assume_global(reinterpret_cast<const bf16_t*>(lp[7])); at.kn = assume_global(reinterpret_cast<const bf16_t*>(lp[8]));
+        p_wqkv_next = l + 1 < nl ? assume_global(reinterpret_cast<const bf16_t*>(lp[9 + 5])) : nullptr;
+        p_ln1_next = l + 1 < nl ? assume_global(reinterpret_cast<const bf16_t*>(lp[9 + 6])) : nullptr;
+        at.kv = a.at.kv + (size_t)l * a.kv_layer_stride;
+        at.kv_w = a.at.kv_w + (size_t)l * a.kv_layer_stride;
+    }
+    auto park_words = [&]() { if (tid == 0) { wsh[0] = w_ep; wsh[1] = (w_ep + (unsigned)l) * 64u + 4u; wsh[2] = w_spins; wsh[3] = w_inj; } };
     // The other 240 blocks hold their opening burst back a little (a.burst_delay x ~0.4 us): 41 MB of weight requests issued at launch
     // queue in front of the attention's K/V tiles (which only leave their blocks after two dependent round trips: arguments, page ids)
     // and the attention — the critical path of the layer — finished at 15 us instead of 9 (tools/mlp_trace.py).
     if (ATTN && !attn_blk)
-        for (int d = 0; d < a.burst_delay; ++d) __builtin_amdgcn_s_sleep(16);
+        for (int d = 0, nd = l == 0 ? (a.burst_delay & 255) : (a.burst_delay >> 8); d < nd; ++d) __builtin_amdgcn_s_sleep(16);
     // ---- stage O's weight rows (waves 0..3).  The attention blocks request them when their K/V tiles are parked in LDS: nothing of
     // the attention waits behind them (loads return in order), and they land during its arithmetic
     uint4 wo[2][4];
+    fresh(wo);
     unsigned resw = 0;
     auto load_o = [&]() {
         if (wave < 4) {
             const int n0 = 2 * (blk * 4 + wave);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const uint4* wr = reinterpret_cast<const uint4*>(a.wo + (size_t)(n0 + r) * H);
+                const uint4* wr = reinterpret_cast<const uint4*>(p_wo + (size_t)(n0 + r) * H);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wo[r][j] = ldg_nt(wr + lane + 64 * j);
             }
-            if (ATTN) resw = reinterpret_cast<const unsigned*>(a.x_in)[blk * 4 + wave];
+            if (ATTN) resw = MULTI && l > 0 ? resw_carry : reinterpret_cast<const unsigned*>(a.x_in)[blk * 4 + wave];
         }
     };
     if (!attn_blk) load_o();
@@ -4107,11 +4197,12 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     // attention blocks request them when the attention is done (its tiles need the registers) — they land during the hand-off
     const int p1 = blk * 12 + wave;                                     // 3072 pairs: 12 per block
     uint4 wg1[2][4], wu1[2][4];
+    fresh(wg1); fresh(wu1);
     auto load_c1 = [&]() {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const uint4* gr = reinterpret_cast<const uint4*>(a.wgate + (size_t)(2 * p1 + r) * H);
-            const uint4* ur = reinterpret_cast<const uint4*>(a.wup + (size_t)(2 * p1 + r) * H);
+            const uint4* gr = reinterpret_cast<const uint4*>(p_wgate + (size_t)(2 * p1 + r) * H);
+            const uint4* ur = reinterpret_cast<const uint4*>(p_wup + (size_t)(2 * p1 + r) * H);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { wg1[r][j] = ldg_nt(gr + lane + 64 * j); wu1[r][j] = ldg_nt(ur + lane + 64 * j); }
         }
@@ -4119,14 +4210,41 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     if (!attn_blk) load_c1();
     if (attn_blk) {
         // q head blk: kv head blk / 2, half blk % 2 of its two-head group (the launch form's head split); row 0
-        attn_decode8_block<128, 1, 8, (ATTN ? ATTN : 8), 512>(a.at, *reinterpret_cast<TalkerAttnSmem*>(smem), 2, blk >> 1, blk & 1, 0, a.gattn, &wsh[1], false,
-                                              [&]() { park_words(); load_o(); }, a.epoch);
+        TalkerAttnSmem& sm = *reinterpret_cast<TalkerAttnSmem*>(smem);
+        // MULTI: q head blk, k / v head blk / 2 of the new token -> sm.Raw: layer 0 from the plain row of the projection launch in front,
+        // later layers from the previous layer's stage-A granules (192 of the 2048: one per thread of waves 0..2)
+        auto stage_raw = [&]() {
+            if constexpr (MULTI) {
+                if (tid < 192) {
+                    const int part = tid >> 6, t = tid & 63;
+                    const int gi = part == 0 ? blk * 64 + t : (part == 1 ? 1024 : 1536) + (blk >> 1) * 64 + t;
+                    unsigned v = 0;
+                    if (l == 0) {
+                        v = reinterpret_cast<const unsigned*>(a.at.qkv)[gi];
+                    } else {
+                        const unsigned want = (wsh[0] + (unsigned)l - 1u) * 64u + 5u, bound = wsh[2];
+                        for (unsigned spin = 0;; ++spin) {
+                            const unsigned long long x = __hip_atomic_load(a.gq + gi, VOX_RLX_AGENT);
+                            if ((unsigned)(x >> 32) == want) { v = (unsigned)x; break; }
+                            if (spin > bound) { atomicCAS(a.err, 0u, 0x1500u); break; }
+                            if ((spin & 63u) == 63u && __hip_atomic_load(a.err, VOX_RLX_AGENT) != 0u) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    reinterpret_cast<unsigned*>(sm.Raw)[tid] = v;
+                }
+                __syncthreads();
+            }
+        };
+        attn_decode8_block<128, 1, 8, (ATTN ? ATTN : 8), 512, MULTI>(at, sm, 2, blk >> 1, blk & 1, 0, a.gattn, &wsh[1], false,
+                                              [&]() { park_words(); load_o(); }, a.epoch, stage_raw);
         load_c1();
-    } else if (ATTN) {
+    } else if (ATTN && l == 0) {
         park_words();
     }
     if (ATTN) __syncthreads();                         // state words parked; (attention blocks) the attention's LDS is dead: xb / hb / ab may be written
     uint4 av[4];
+    fresh(av);
     if (!ATTN && wave < 4) {       // stage O's operand row (a plain row of the attention launch in front): requested before anything below waits
 #pragma unroll
         for (int j = 0; j < 4; ++j) av[j] = reinterpret_cast<const uint4*>(a.attn)[lane + 64 * j];
@@ -4142,9 +4260,11 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         const VOX_CONST_AS unsigned* wp = (const VOX_CONST_AS unsigned*)a.epoch;      // (constant address space: scalar loads)
         w_ep = wp[0]; w_spins = wp[2]; w_inj = wp[3];
     }
-    const unsigned ep = ATTN ? wsh[0] : w_ep, max_spins = ATTN ? wsh[2] : w_spins;
-    const bool drop_first = blk == 1 && (ATTN ? wsh[3] : w_inj) != 0u;
-    const unsigned tag0 = ep * 64u;
+    if (l == 0) {
+        ep = ATTN ? wsh[0] : w_ep; max_spins = ATTN ? wsh[2] : w_spins;
+        drop_first = blk == 1 && (ATTN ? wsh[3] : w_inj) != 0u;
+    }
+    const unsigned tag0 = (ep + (unsigned)l) * 64u;
     MLP_TR(1)
     // ---------------- stage O: x' = x + Wo . attn ----------------
     if (ATTN) {
@@ -4179,21 +4299,22 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         }
         if (lane == 0) {
             const bf16_t r0 = f2bf(bflo(resw) + bf2f(f2bf(acc[0]))), r1 = f2bf(bfhi(resw) + bf2f(f2bf(acc[1])));
-            if (!drop_first) gran_write(a.gx + pr, tag0 + 1u, r0, r1);
+            if (!(drop_first && l == 0)) gran_write(a.gx + pr, tag0 + 1u, r0, r1);
         }
     }
     // ---------------- stage C: h = silu(Wg . n) * (Wu . n), n = rmsnorm(x', ln2) ----------------
     uint4 nwv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) nwv[j] = reinterpret_cast<const uint4*>(a.ln2)[lane + 64 * j];
+    for (int j = 0; j < 4; ++j) nwv[j] = ldg(reinterpret_cast<const uint4*>(p_ln2) + lane + 64 * j);
     const int p2 = blk * 12 + 8 + wave;                                 // second pair: waves 0..3
     uint4 wg2[2][4], wu2[2][4];
+    fresh(wg2); fresh(wu2);
     auto load_c2 = [&]() {
         if (wave < 4) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const uint4* gr = reinterpret_cast<const uint4*>(a.wgate + (size_t)(2 * p2 + r) * H);
-                const uint4* ur = reinterpret_cast<const uint4*>(a.wup + (size_t)(2 * p2 + r) * H);
+                const uint4* gr = reinterpret_cast<const uint4*>(p_wgate + (size_t)(2 * p2 + r) * H);
+                const uint4* ur = reinterpret_cast<const uint4*>(p_wup + (size_t)(2 * p2 + r) * H);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { wg2[r][j] = ldg_nt(gr + lane + 64 * j); wu2[r][j] = ldg_nt(ur + lane + 64 * j); }
             }
@@ -4240,10 +4361,11 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     {
         const int pr = blk * 4 + wave, n0 = 2 * pr;
         uint4 wd[2][12];
+        fresh(wd);
         if (wave < 4) {                                 // requested before the hand-off is polled: they stream while h completes
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const uint4* wr = reinterpret_cast<const uint4*>(a.wdown + (size_t)(n0 + r) * F);
+                const uint4* wr = reinterpret_cast<const uint4*>(p_wdown + (size_t)(n0 + r) * F);
 #pragma unroll
                 for (int j = 0; j < 12; ++j) wd[r][j] = ldg_nt(wr + lane + 64 * j);
             }
@@ -4263,25 +4385,26 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
                 for (int j = 0; j < 12; ++j) d = dot8(wd[r][j], hb[lane + 64 * j], d);
                 acc[r] = butterfly<64>(d);
             }
+            const bf16_t r0 = f2bf(bflo(resw) + bf2f(f2bf(acc[0]))), r1 = f2bf(bfhi(resw) + bf2f(f2bf(acc[1])));
             if (lane == 0) {
-                const bf16_t r0 = f2bf(bflo(resw) + bf2f(f2bf(acc[0]))), r1 = f2bf(bfhi(resw) + bf2f(f2bf(acc[1])));
                 reinterpret_cast<unsigned*>(a.x_out)[pr] = (unsigned)r0 | ((unsigned)r1 << 16);      // (the next layer's residual reads it)
-                if (a.wqkv_next) gran_write(a.gx + pr, tag0 + 3u, r0, r1);
+                if (p_wqkv_next) gran_write(a.gx + pr, tag0 + 3u, r0, r1);
             }
+            if (MULTI) resw_carry = (unsigned)r0 | ((unsigned)r1 << 16);      // (every lane holds the butterfly's sum)
         }
     }
     // ---------------- stage A of the next layer: qkv = Wqkv . rmsnorm(x'', ln1)  (2048 pairs: one per wave) ----------------
-    if (a.wqkv_next) {
+    if (p_wqkv_next) {
         const int pr = blk * 8 + wave, n0 = 2 * pr;
         uint4 wq[2][4], nw1[4];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const uint4* wr = reinterpret_cast<const uint4*>(a.wqkv_next + (size_t)(n0 + r) * H);
+            const uint4* wr = reinterpret_cast<const uint4*>(p_wqkv_next + (size_t)(n0 + r) * H);
 #pragma unroll
             for (int j = 0; j < 4; ++j) wq[r][j] = ldg_nt(wr + lane + 64 * j);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nw1[j] = reinterpret_cast<const uint4*>(a.ln1_next)[lane + 64 * j];
+        for (int j = 0; j < 4; ++j) nw1[j] = ldg(reinterpret_cast<const uint4*>(p_ln1_next) + lane + 64 * j);
         __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish the down projection; xb is free)
         gran_gather_lds_all<1024>(a.gx, tag0 + 3u, reinterpret_cast<unsigned*>(xb), tid, a.err, 0x1300u, max_spins, (a.poll_delay >> 16) & 255u);
         __syncthreads();
@@ -4304,9 +4427,14 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
             for (int j = 0; j < 4; ++j) d = dot8(wq[r][j], yv[j], d);
             acc[r] = butterfly<64>(d);
         }
-        if (lane == 0) reinterpret_cast<unsigned*>(a.qkv_out)[pr] = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
+        if (lane == 0) {
+            if (MULTI) gran_write(a.gq + pr, tag0 + 5u, f2bf(acc[0]), f2bf(acc[1]));      // the next layer's attention blocks gather it
+            else reinterpret_cast<unsigned*>(a.qkv_out)[pr] = (unsigned)f2bf(acc[0]) | ((unsigned)f2bf(acc[1]) << 16);
+        }
     }
-    if (blk == 0 && tid == 0) __hip_atomic_store(a.epoch, ep + 1u, VOX_RLX_AGENT);
+    if (MULTI) __syncthreads();      // stage A's reads of xb are done: the next layer's tiles / gathers may overwrite the buffers
+    } while (MULTI && ++l < nl);      // layers
+    if (blk == 0 && tid == 0) __hip_atomic_store(a.epoch, ep + (unsigned)nl, VOX_RLX_AGENT);
     if (drop_first && tid == 0) atomicSub(a.epoch + 3, 1u);
     MLP_TR_END
 }
@@ -4350,9 +4478,20 @@ int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
         a.at.hoist = hoist_on;
         a.gattn = a.gx + 4096;
         const int delay = [] { const char* e = getenv("VOX_TALKER_ATTN_DELAY"); return e ? atoi(e) : 8; }();       // (read per launch built: graphs keep it)
-        a.burst_delay = delay < 0 ? 0 : (delay > 64 ? 64 : delay);
+        a.burst_delay = delay < 0 ? 0 : (delay > 64 ? 64 : delay);      // ([7:0] the launch's first layer, [15:8] later layers of the all-layer form)
         const int psl = [] { const char* e = getenv("VOX_TALKER_ATTN_POLL"); return e ? atoi(e) : 1; }();
         a.poll_sleep = psl < 1 ? 1 : (psl > 64 ? 64 : psl);
+        if (c.layer_tab) {
+            // every layer in ONE launch (<= 256 visible tokens); granules: x' 1024 | h 3072 | attention row 1024 | q k v 2048
+            if (ac.max_kvlen > 8 * VOX_TC || c.n_layers < 1) return vox_fail(VOX_ERR_INVALID, "talker_mlp: all-layer form needs <= 256 visible tokens");
+            if (!ac.qn || !ac.kn || !ac.cs) return vox_fail(VOX_ERR_INVALID, "talker_mlp: all-layer form needs head norms and a RoPE table");
+            a.tab = (const TalkerLayerW*)c.layer_tab; a.n_layers = c.n_layers; a.kv_layer_stride = c.kv_layer_stride;
+            a.gq = a.gx + 5120;
+            const int d2 = [] { const char* e = getenv("VOX_TALKER_MULTI_DELAY"); return e ? atoi(e) : 8; }();
+            a.burst_delay |= (d2 < 0 ? 0 : (d2 > 64 ? 64 : d2)) << 8;
+            hipLaunchKernelGGL((k_talker_mlp<8, true>), dim3(256), dim3(512), 0, st, a);
+            return VOX_OK;
+        }
         if (ac.max_kvlen <= 8 * VOX_TC) hipLaunchKernelGGL(k_talker_mlp<8>, dim3(256), dim3(512), 0, st, a);
         else hipLaunchKernelGGL(k_talker_mlp<16>, dim3(256), dim3(512), 0, st, a);
         return VOX_OK;

@@ -33,6 +33,13 @@ __device__ __forceinline__ u32 pack_bf2(float lo, float hi) {
 __device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
 
 // 8 sequential fmaf over one 16-byte chunk pair (elements in memory order)
+// A pointer the kernel read from a device-side table (not a kernel argument) has no known address space: every load through it is a
+// FLAT load — counted by vmcnt AND lgkmcnt, so the next LDS wait (every barrier has one) also waits for all weight rows in flight.
+// Round trip through the global address space: the loads become global_load again.
+template <typename T>
+__device__ __forceinline__ const T* assume_global(const T* p) {
+    return (const T*)(const __attribute__((address_space(1))) T*)p;
+}
 __device__ __forceinline__ float dot8(uint4 w, uint4 x, float a) {
     a = __fmaf_rn(bflo(w.x), bflo(x.x), a);
     a = __fmaf_rn(bfhi(w.x), bfhi(x.x), a);
@@ -124,8 +131,16 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 as_uint4(u32x4_t v) { return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint4 as_uint4(uint4 v) { return v; }
 // 16-byte non-temporal (streaming) load: weights are read once per step by exactly one wave
+// (through the global address space explicitly: a pointer read from a device-side table has no known address space, and a load
+// through it is a FLAT load — counted by vmcnt AND lgkmcnt, so the next LDS wait also waits for every weight row in flight)
+#define VOX_GLOBAL_AS __attribute__((address_space(1)))
 __device__ __forceinline__ uint4 ldg_nt(const uint4* p) {
-    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    const u32x4_t v = __builtin_nontemporal_load((const VOX_GLOBAL_AS u32x4_t*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+// plain 16-byte load of global memory (same reason)
+__device__ __forceinline__ uint4 ldg(const uint4* p) {
+    const u32x4_t v = *(const VOX_GLOBAL_AS u32x4_t*)p;
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 

@@ -152,6 +152,12 @@ struct TalkerMlpCall {
     // optional stage in front: the layer's decode attention inside the launch (blocks 0..15; gran then holds 5120 granules, the last
     // 1024 for the attention row) — `attn` is unused
     const struct AttnCall* attn_call = nullptr;
+    // optional (with attn_call): EVERY layer of the stack in this one launch.  layer_tab: device array of n_layers rows of nine pointers
+    // {wo, wgate, wup, wdown, ln2, wqkv, ln1, qnorm, knorm}; the layers' K / V caches lie kv_layer_stride elements apart from
+    // attn_call->kv; attn_call->qkv holds layer 0's projection; gran then holds 7168 granules.  The per-layer weight fields above are unused.
+    const void* layer_tab = nullptr;
+    int n_layers = 0;
+    long kv_layer_stride = 0;
 };
 bool vox_talker_mlp_supported(const TalkerMlpCall& c);
 bool vox_talker_attn_supported(const struct AttnCall& c);
