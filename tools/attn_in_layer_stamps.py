@@ -40,3 +40,6 @@ print(f"kv~{kv0}: {n} launches stamped (persist status {e.depth_persist_status()
 for i, nm in enumerate(names):
     print(f"  {nm:26s} {d[:, i].mean():6.2f} {np.median(d[:, i]):6.2f}")
 print(f"  {'entry -> published':26s} {(s[:, 8] - s[:, 0]).mean():6.2f}")
+if (full[:, 10] > 0).any():      # all-layer launch: the new token's q | k | v gathered from the previous layer's granules (stamp 10), behind the tile (stamp 1)
+    m = full[:, 10] > 0
+    print(f"  all-layer form: tile landed -> q|k|v gathered {np.median(full[m, 10] - full[m, 1]):6.2f} (median, layers 1..)")

@@ -3826,6 +3826,11 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
             }
     }
     const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
+    // where the new token goes in the paged cache: requested HERE, with the row's length.  Read where it is used (behind the caller's
+    // after_park) the two words were vector loads in the own-last-chunk branch, waited for with vmcnt(0) — i.e. behind the o_proj weight
+    // rows after_park had just requested (loads return in order): the score pass of the in-launch attention took 3.3 us instead of 1.1
+    const int pg_new = a.identity_pages ? row : a.page[row];
+    const int sl_new = a.identity_pages ? 0 : a.slot[row];
 #ifdef VOX_DEV_KNOBS
     if (stamp2_base) { stamp2_base[14] = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp2_base[15] = wall_clock64() + (L < -5); }
 #endif
@@ -3875,7 +3880,9 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         // flight, and anything it might do with those registers in between, a copy at a loop edge or a spill, would read them too early)
         fetch_tile(0);
         kv_wait();
+        VOX_STAMP2(1)
         stage_raw();                               // q | k | v of the new token -> sm.Raw (ends with a barrier)
+        VOX_STAMP2(10)
         if (wave16 < 2) po0 = prep_head_load_lds<D>(sm.Raw + (wave16 == 1 ? D : 0), wave16 == 1 ? a.kn : a.qn, cs_row, a.rot, lane);
         if (wave16 < 2) {
             prep_head_arrived(po0);
@@ -3919,8 +3926,8 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         VOX_STAMP2(3)
         if (own_last && hs == 0 && gt < LPT) {
             // append the new token to the paged cache (page < 0: graph padding row)
-            const int pg = a.identity_pages ? row : a.page[row];
-            const int sl = a.identity_pages ? (L - 1) : a.slot[row];
+            const int pg = pg_new;
+            const int sl = a.identity_pages ? (L - 1) : sl_new;
             if (pg >= 0) {
                 bf16_t* base = a.kv_w + (size_t)pg * ps + ((size_t)sl * a.Hkv + hk) * D;
                 reinterpret_cast<uint4*>(base)[gt] = reinterpret_cast<const uint4*>(sm.Knew)[gt];
@@ -4109,14 +4116,15 @@ template <int NCH> using TalkerAttnSmemT = AttnDecodeSmem<128, 1, 8, (NCH ? NCH 
 template <int ATTN, bool MULTI = false>
 __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     static_assert(!MULTI || ATTN == 8, "MULTI: the attention runs in the launch");
-    // MULTI: register arrays that only some waves fill are (re)defined at their declaration, at no cost: left alone, their value at the
-    // top of the layer loop is "the previous layer's or none" — live across the whole loop, and the allocator keeps them in scratch
-    // memory (every weight row stored behind a wait of its own)
+    // MULTI: register arrays that only some waves fill are zeroed at their declaration.  Left undefined inside the layer loop they are
+    // not promoted to registers at all (every weight row stored to scratch memory behind a wait of its own: 908 bytes per lane); an
+    // empty asm definition instead of the zeroes makes the compiler wait for whatever is in flight at that point (behind stage O's
+    // publish: the write-through store of x').  The zeroing folds into the branch that does not load.
     auto fresh = [](auto& arr) {
         if constexpr (MULTI) {
             uint4* p = reinterpret_cast<uint4*>(&arr);
 #pragma unroll
-            for (int i = 0; i < (int)(sizeof(arr) / sizeof(uint4)); ++i) asm volatile("" : "=v"(p[i]));
+            for (int i = 0; i < (int)(sizeof(arr) / sizeof(uint4)); ++i) p[i] = make_uint4(0u, 0u, 0u, 0u);
         }
     };
     using TalkerAttnSmem = TalkerAttnSmemT<ATTN>;
@@ -4140,7 +4148,6 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         w_spins = __hip_atomic_load(a.epoch + 2, VOX_RLX_AGENT);
         w_inj = __hip_atomic_load(a.epoch + 3, VOX_RLX_AGENT);
     }
-    MLP_TR_DECL
     const bool attn_blk = ATTN && blk < 16;
     const int nl = MULTI ? a.n_layers : 1;
     unsigned ep = 0, max_spins = 0;
@@ -4148,6 +4155,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     unsigned resw_carry = 0;          // MULTI: this wave's pair of x'' (stage D) is its residual pair of the next layer's stage O
     int l = 0;
     do {
+    MLP_TR_DECL      // (development builds: one record per layer)
     if constexpr (MULTI) {
         // (the thread index made opaque per layer: left visible, every per-thread address of the body — granule pointers of four gathers,
         // weight row offsets — is hoisted out of the layer loop and kept in registers across it: 908 bytes of scratch per lane)
@@ -4197,7 +4205,6 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     // attention blocks request them when the attention is done (its tiles need the registers) — they land during the hand-off
     const int p1 = blk * 12 + wave;                                     // 3072 pairs: 12 per block
     uint4 wg1[2][4], wu1[2][4];
-    fresh(wg1); fresh(wu1);
     auto load_c1 = [&]() {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -4242,9 +4249,9 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     } else if (ATTN && l == 0) {
         park_words();
     }
-    if (ATTN) __syncthreads();                         // state words parked; (attention blocks) the attention's LDS is dead: xb / hb / ab may be written
     uint4 av[4];
     fresh(av);
+    if (ATTN) __syncthreads();                         // state words parked; (attention blocks) the attention's LDS is dead: xb / hb / ab may be written
     if (!ATTN && wave < 4) {       // stage O's operand row (a plain row of the attention launch in front): requested before anything below waits
 #pragma unroll
         for (int j = 0; j < 4; ++j) av[j] = reinterpret_cast<const uint4*>(a.attn)[lane + 64 * j];
@@ -4283,6 +4290,8 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         __syncthreads();
     }
     MLP_TR(2)
+    uint4 wg2[2][4], wu2[2][4];
+    fresh(wg2); fresh(wu2);      // (in front of stage O's publish: behind it the zeroes wait for the store to have read its registers)
     if (wave < 4) {
         const int pr = blk * 4 + wave;
         if (ATTN) {
@@ -4307,8 +4316,6 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) nwv[j] = ldg(reinterpret_cast<const uint4*>(p_ln2) + lane + 64 * j);
     const int p2 = blk * 12 + 8 + wave;                                 // second pair: waves 0..3
-    uint4 wg2[2][4], wu2[2][4];
-    fresh(wg2); fresh(wu2);
     auto load_c2 = [&]() {
         if (wave < 4) {
 #pragma unroll
@@ -4433,10 +4440,10 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         }
     }
     if (MULTI) __syncthreads();      // stage A's reads of xb are done: the next layer's tiles / gathers may overwrite the buffers
+    MLP_TR_END
     } while (MULTI && ++l < nl);      // layers
     if (blk == 0 && tid == 0) __hip_atomic_store(a.epoch, ep + (unsigned)nl, VOX_RLX_AGENT);
     if (drop_first && tid == 0) atomicSub(a.epoch + 3, 1u);
-    MLP_TR_END
 }
 
 bool vox_talker_mlp_supported(const TalkerMlpCall& c) { return c.hidden == 2048 && c.nq == 2048 && c.ffn == 6144; }
