@@ -46,6 +46,9 @@ struct LinArgs {
 #ifndef VOX_KV_ASM
 #define VOX_KV_ASM 1      // decode attention: K/V tile requests written as asm (see k_attn_decode8)
 #endif
+#ifndef VOX_MLP_D_EARLY
+#define VOX_MLP_D_EARLY 1
+#endif
 #ifndef VOX_MLP_C2_LATE
 #define VOX_MLP_C2_LATE 0
 #endif
@@ -4152,7 +4155,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     const int nl = MULTI ? a.n_layers : 1;
     unsigned ep = 0, max_spins = 0;
     bool drop_first = false;
-    unsigned resw_carry = 0;          // MULTI: this wave's pair of x'' (stage D) is its residual pair of the next layer's stage O
+    __shared__ unsigned xcar[4];      // MULTI: the block's four pairs of x'' (stage D, waves 4..7) are the residual pairs of the next layer's stage O (waves 0..3)
     int l = 0;
     do {
     MLP_TR_DECL      // (development builds: one record per layer)
@@ -4197,7 +4200,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wo[r][j] = ldg_nt(wr + lane + 64 * j);
             }
-            if (ATTN) resw = MULTI && l > 0 ? resw_carry : reinterpret_cast<const unsigned*>(a.x_in)[blk * 4 + wave];
+            if (ATTN) resw = MULTI && l > 0 ? xcar[wave] : reinterpret_cast<const unsigned*>(a.x_in)[blk * 4 + wave];
         }
     };
     if (!attn_blk) load_o();
@@ -4290,8 +4293,10 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
         __syncthreads();
     }
     MLP_TR(2)
-    uint4 wg2[2][4], wu2[2][4];
-    fresh(wg2); fresh(wu2);      // (in front of stage O's publish: behind it the zeroes wait for the store to have read its registers)
+    // U: 24 chunks whose content depends on the wave's role — waves 0..3: the second gate / up pair (gate rows in U[0..7], up rows in
+    // U[8..15]); waves 4..7: their two down-projection rows (U[0..23]).  One array: as separate ones the compiler adds the roles' registers up.
+    uint4 U[24];
+    fresh(U);
     if (wave < 4) {
         const int pr = blk * 4 + wave;
         if (ATTN) {
@@ -4323,7 +4328,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
                 const uint4* gr = reinterpret_cast<const uint4*>(p_wgate + (size_t)(2 * p2 + r) * H);
                 const uint4* ur = reinterpret_cast<const uint4*>(p_wup + (size_t)(2 * p2 + r) * H);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { wg2[r][j] = ldg_nt(gr + lane + 64 * j); wu2[r][j] = ldg_nt(ur + lane + 64 * j); }
+                for (int j = 0; j < 4; ++j) { U[r * 4 + j] = ldg_nt(gr + lane + 64 * j); U[8 + r * 4 + j] = ldg_nt(ur + lane + 64 * j); }
             }
         }
     };
@@ -4336,6 +4341,22 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
     if (VOX_MLP_C2_LATE) load_c2();
     __syncthreads();
     MLP_TR(4)
+    // Stage D's rows belong to waves 4..7 and are requested HERE, a whole stage ahead.  A block's requests are served in the order it made
+    // them (its own queue to the memory side, ~11 bytes per clock per CU when every CU streams): requested when stage C was done (round 5:
+    // by waves 0..3, which had no registers for them earlier) the 96 KB stood in front of the h gather's polls and came back 5 us later —
+    // h was gathered 8.5 us after x' (tools/mlp_trace.py).  From here they travel under stage C's arithmetic.
+    auto load_d = [&]() {
+        if (wave >= 4) {
+            const int n0 = 2 * (blk * 4 + wave - 4);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint4* wr = reinterpret_cast<const uint4*>(p_wdown + (size_t)(n0 + r) * F);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) U[r * 12 + j] = ldg_nt(wr + lane + 64 * j);
+            }
+        }
+    };
+    if (VOX_MLP_D_EARLY) load_d();
     uint4 xv[4];
     {
 #pragma unroll
@@ -4348,48 +4369,39 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) xv[j] = norm_chunk(xv[j], nwv[j], rinv);
     }
-    auto ffn_pair = [&](const uint4 (&wg)[2][4], const uint4 (&wu)[2][4], int pr) {
+    auto ffn_pair = [&](const uint4* wg, const uint4* wu, int pr) {      // (two gate rows, two up rows: four chunks each)
         bf16_t hv[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             float dg = 0.0f, du = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dg = dot8(wg[r][j], xv[j], dg);
+            for (int j = 0; j < 4; ++j) dg = dot8(wg[r * 4 + j], xv[j], dg);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) du = dot8(wu[r][j], xv[j], du);
+            for (int j = 0; j < 4; ++j) du = dot8(wu[r * 4 + j], xv[j], du);
             const float gg = bfround(butterfly<64>(dg)), uu = bfround(butterfly<64>(du));
             hv[r] = f2bf(bfround(silu_c(gg)) * uu);
         }
         if (lane == 0) gran_write(a.gh + pr, tag0 + 2u, hv[0], hv[1]);
     };
-    ffn_pair(wg1, wu1, p1);
-    if (wave < 4) ffn_pair(wg2, wu2, p2);
+    ffn_pair(&wg1[0][0], &wu1[0][0], p1);
+    if (wave < 4) ffn_pair(U, U + 8, p2);
     // ---------------- stage D: x'' = x' + Wd . h ----------------
     {
-        const int pr = blk * 4 + wave, n0 = 2 * pr;
-        uint4 wd[2][12];
-        fresh(wd);
-        if (wave < 4) {                                 // requested before the hand-off is polled: they stream while h completes
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const uint4* wr = reinterpret_cast<const uint4*>(p_wdown + (size_t)(n0 + r) * F);
-#pragma unroll
-                for (int j = 0; j < 12; ++j) wd[r][j] = ldg_nt(wr + lane + 64 * j);
-            }
-        }
+        const int pr = blk * 4 + wave - 4;
+        if (!VOX_MLP_D_EARLY) load_d();
         __syncthreads();                               // (parks waves 4..7 while waves 0..3 finish their second pair)
         MLP_TR(5)
         gran_gather_lds_all<3072>(a.gh, tag0 + 2u, reinterpret_cast<unsigned*>(hb), tid, a.err, 0x1200u, max_spins, (a.poll_delay >> 8) & 255u);
         __syncthreads();
         MLP_TR(6)
-        if (wave < 4) {
+        if (wave >= 4) {
             const unsigned resw = reinterpret_cast<const unsigned*>(xb)[pr];
             float acc[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 float d = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 12; ++j) d = dot8(wd[r][j], hb[lane + 64 * j], d);
+                for (int j = 0; j < 12; ++j) d = dot8(U[r * 12 + j], hb[lane + 64 * j], d);
                 acc[r] = butterfly<64>(d);
             }
             const bf16_t r0 = f2bf(bflo(resw) + bf2f(f2bf(acc[0]))), r1 = f2bf(bfhi(resw) + bf2f(f2bf(acc[1])));
@@ -4397,7 +4409,7 @@ __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
                 reinterpret_cast<unsigned*>(a.x_out)[pr] = (unsigned)r0 | ((unsigned)r1 << 16);      // (the next layer's residual reads it)
                 if (p_wqkv_next) gran_write(a.gx + pr, tag0 + 3u, r0, r1);
             }
-            if (MULTI) resw_carry = (unsigned)r0 | ((unsigned)r1 << 16);      // (every lane holds the butterfly's sum)
+            if (MULTI && lane == 0) xcar[pr & 3] = (unsigned)r0 | ((unsigned)r1 << 16);      // (the next layer's stage O, wave pr & 3, adds its product to it)
         }
     }
     // ---------------- stage A of the next layer: qkv = Wqkv . rmsnorm(x'', ln1)  (2048 pairs: one per wave) ----------------
