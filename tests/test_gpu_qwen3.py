@@ -766,6 +766,42 @@ def test_attention_inside_the_talker_launch(dev, monkeypatch, kv0, two_chunks):
     ea.close(); eb.close()
 
 
+@pytest.mark.parametrize("ps,kv0", [(128, 40), (128, 248), (32, 120)])      # 248: leaves the all-layer form at 257 visible tokens; 32-token pages
+def test_all_talker_layers_in_one_launch(dev, monkeypatch, ps, kv0):
+    """Round 6: with the attention inside the talker-layer launch, EVERY decoder layer of a one-request frame runs in one persistent launch
+    (k_talker_mlp<8, true>): stage A hands the next layer's q | k | v to its attention blocks as granules, the cached K / V tile is
+    requested before they are polled.  Against an engine that keeps a launch per layer (VOX_TALKER_MULTI=0, read at engine creation) and
+    against the launch chain: ids, logits, fed-back features and the K/V caches bit-identical, no hand-off timeout."""
+    from vox_serve_amd.engine import Qwen3Cfg, Qwen3Engine
+    from vox_serve_amd.synth import synth_qwen3_weights
+    cfg = Qwen3Cfg()
+    W = synth_qwen3_weights(cfg, dev, seed=0)
+    ea, eb = _persist_pair(dev, monkeypatch, cfg, W, ps=ps)       # launch chain | persistent kernels (all-layer form where it applies)
+    if eb.depth_persist_status()[0] != 3:
+        pytest.skip("persistent kernels not available on this part (< 256 CUs)")
+    monkeypatch.setenv("VOX_TALKER_MULTI", "0")
+    ec = Qwen3Engine(cfg, W, max_batch=1, page_size=ps, max_pages=32 if ps < 128 else 8, max_seq_len=512, max_prefill_rows=64, keep_depth_logits=True)
+    monkeypatch.delenv("VOX_TALKER_MULTI")
+    ec.keep_hidden = False
+    ec.input_ids.copy_(ea.input_ids); ec.input_masks[:1] = 1; ec.input_features.zero_()
+    npg = (kv0 + 12 + ps - 1) // ps + 1
+    g = torch.Generator(device=dev).manual_seed(11)
+    rnd = (torch.randn(ea.kv[:, :npg].shape, generator=g, device=dev) * 0.5).to(ea.kv.dtype)
+    for e in (ea, eb, ec):
+        e.kv[:, :npg] = rnd
+    sc = ea.sampling_cfg(greedy=True)
+    for f in range(12):
+        for e in (ea, eb, ec):
+            _one_frame(e, f, sc, ps=ps, kv0=kv0)
+        torch.cuda.synchronize()
+        for name in ("out_ids", "out_logits", "out_depth_logits", "next_features", "input_features", "input_ids"):
+            assert torch.equal(getattr(ea, name), getattr(eb, name)), (ps, kv0, f, name, "chain vs all-layer")
+            assert torch.equal(getattr(ec, name), getattr(eb, name)), (ps, kv0, f, name, "per-layer vs all-layer")
+    assert torch.equal(ea.kv[:, :npg], eb.kv[:, :npg]) and torch.equal(ec.kv[:, :npg], eb.kv[:, :npg])
+    assert eb.depth_persist_status() == (3, 0) and ec.depth_persist_status() == (3, 0)
+    ea.close(); eb.close(); ec.close()
+
+
 def test_persistent_kernels_with_a_codec_chunk_on_a_second_stream(dev, monkeypatch):
     """The case the hand-off comment names: the 256 resident blocks of a persistent launch wait for CUs held by another stream's
     kernels.  One-request frames replay while Qwen3 codec chunks of 8 requests run beside them on a second stream: no hand-off may
