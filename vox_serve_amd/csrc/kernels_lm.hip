@@ -2365,6 +2365,9 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
             }
     }
     const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
+    // (the new token's page / slot words with the row length: one exposed round trip less in front of the append — attn_decode8_block)
+    const int pg_new = a.identity_pages ? row : a.page[row];
+    const int sl_new = a.identity_pages ? 0 : a.slot[row];
     const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..NCH
     const int Gf = a.Hq / a.Hkv, G = Gf / HS, g0 = hs * G;
     const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
@@ -2440,8 +2443,8 @@ __global__ __launch_bounds__(1024) void k_attn_decode8(AttnArgs a) {
         VOX_STAMP(3) VOX_TR(3)
         if (own_last && hs == 0 && gt < LPT) {
             // append the new token to the paged cache (page < 0: graph padding row)
-            const int pg = a.identity_pages ? row : a.page[row];
-            const int sl = a.identity_pages ? (L - 1) : a.slot[row];
+            const int pg = pg_new;
+            const int sl = a.identity_pages ? (L - 1) : sl_new;
             if (pg >= 0) {
                 bf16_t* base = a.kv_w + (size_t)pg * ps + ((size_t)sl * a.Hkv + hk) * D;
                 reinterpret_cast<uint4*>(base)[gt] = reinterpret_cast<const uint4*>(Knew)[gt];
@@ -2586,6 +2589,9 @@ __global__ __launch_bounds__(1024) void k_attn_decode8_v1(AttnArgs a) {
             }
     }
     const int L = a.fixed_kvlen > 0 ? a.fixed_kvlen : a.q_kvlen[row];
+    // (the new token's page / slot words with the row length: one exposed round trip less in front of the append — attn_decode8_block)
+    const int pg_new = a.identity_pages ? row : a.page[row];
+    const int sl_new = a.identity_pages ? 0 : a.slot[row];
     const int nc = (L + VOX_TC - 1) / VOX_TC;                 // 1..8
     const int Gf = a.Hq / a.Hkv, G = Gf / HS, g0 = hs * G;
     const size_t ps = (size_t)2 * a.page_size * a.Hkv * D;
@@ -2641,8 +2647,8 @@ __global__ __launch_bounds__(1024) void k_attn_decode8_v1(AttnArgs a) {
         if (own_last) {
             // place the new token into the tile and append it to the paged cache (page < 0: graph padding row)
             const bf16_t* vraw = a.qkv + (size_t)row * (a.Hq + 2 * a.Hkv) * D + (size_t)(a.Hq + a.Hkv) * D + (size_t)hk * D;
-            const int pg = a.identity_pages ? row : a.page[row];
-            const int sl = a.identity_pages ? (L - 1) : a.slot[row];
+            const int pg = pg_new;
+            const int sl = a.identity_pages ? (L - 1) : sl_new;
             if (gt < LPT) {
                 const uint4 kx = reinterpret_cast<const uint4*>(Knew)[gt];
                 const uint4 vx = reinterpret_cast<const uint4*>(vraw)[gt];
@@ -3884,6 +3890,15 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         fetch_tile(0);
         kv_wait();
         VOX_STAMP2(1)
+        if constexpr (CPG == 1) {
+            // one chunk per group: the cached tile is parked HERE, while q | k | v are still on their way (0.64 us of the chain behind
+            // their arrival before); the new token's V row is patched in below, when sm.Raw holds it
+#pragma unroll
+            for (int u = 0; u < KVL; ++u) {
+                const int i = gt + GT * u;
+                if (i < VOX_TC * LPT) { sm.Ks[grp][i] = as_uint4(kreg[u]); sm.Vs[grp][i] = as_uint4(vreg[u]); }
+            }
+        }
         stage_raw();                               // q | k | v of the new token -> sm.Raw (ends with a barrier)
         VOX_STAMP2(10)
         if (wave16 < 2) po0 = prep_head_load_lds<D>(sm.Raw + (wave16 == 1 ? D : 0), wave16 == 1 ? a.kn : a.qn, cs_row, a.rot, lane);
@@ -3913,6 +3928,9 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
         const int nt = live ? ((L - t0) < VOX_TC ? (L - t0) : VOX_TC) : 0;
         const bool own_last = live && (t0 + nt == L);
         if (ci > 0) __syncthreads();           // the previous chunk's tile is dead
+        if constexpr (RAWLDS && CPG == 1) {
+            if (own_last && gt < LPT) sm.Vs[grp][(nt - 1) * LPT + gt] = reinterpret_cast<const uint4*>(sm.Raw + 2 * D)[gt];      // (the tile itself was parked above)
+        } else {
 #pragma unroll
         for (int u = 0; u < KVL; ++u) {
             const int i = gt + GT * u;
@@ -3922,6 +3940,7 @@ __device__ __forceinline__ void attn_decode8_block(const AttnArgs& a, AttnDecode
                 if (RAWLDS && own_last && i / LPT == nt - 1) vv = reinterpret_cast<const uint4*>(sm.Raw + 2 * D)[i % LPT];
                 sm.Vs[grp][i] = vv;
             }
+        }
         }
         if (ci + 1 < CPG) fetch_tile(ci + 1);  // in flight during this chunk's arithmetic
         __syncthreads();                       // tiles parked; (ci = 0) Qs / Knew written
@@ -4474,7 +4493,7 @@ bool vox_talker_attn_supported(const AttnCall& c) {
 #define VOX_DS_POLL_DELAY_DEFAULT 0x18100604u
 #endif
 #ifndef VOX_MLP_POLL_DELAY_DEFAULT
-#define VOX_MLP_POLL_DELAY_DEFAULT 0x00082004u
+#define VOX_MLP_POLL_DELAY_DEFAULT 0x04021004u
 #endif
 static unsigned vox_poll_delay(const char* name, unsigned dflt) {
     const char* e = getenv(name);
