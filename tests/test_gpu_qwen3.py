@@ -766,7 +766,7 @@ def test_attention_inside_the_talker_launch(dev, monkeypatch, kv0, two_chunks):
     ea.close(); eb.close()
 
 
-@pytest.mark.parametrize("ps,kv0", [(128, 40), (128, 248), (32, 120)])      # 248: leaves the all-layer form at 257 visible tokens; 32-token pages
+@pytest.mark.parametrize("ps,kv0", [(128, 40), (128, 248), (32, 120), (128, 300)])      # 248: crosses 256 visible tokens (one / two chunks per wave); 32-token pages
 def test_all_talker_layers_in_one_launch(dev, monkeypatch, ps, kv0):
     """Round 6: with the attention inside the talker-layer launch, EVERY decoder layer of a one-request frame runs in one persistent launch
     (k_talker_mlp<8, true>): stage A hands the next layer's q | k | v to its attention blocks as granules, the cached K / V tile is

@@ -4137,7 +4137,7 @@ template <int NCH> using TalkerAttnSmemT = AttnDecodeSmem<128, 1, 8, (NCH ? NCH 
 // MULTI: every layer of the stack in this launch (ATTN form only)
 template <int ATTN, bool MULTI = false>
 __global__ __launch_bounds__(512) void k_talker_mlp(TalkerMlpArgs a) {
-    static_assert(!MULTI || ATTN == 8, "MULTI: the attention runs in the launch");
+    static_assert(!MULTI || ATTN != 0, "MULTI: the attention runs in the launch");
     // MULTI: register arrays that only some waves fill are zeroed at their declaration.  Left undefined inside the layer loop they are
     // not promoted to registers at all (every weight row stored to scratch memory behind a wait of its own: 908 bytes per lane); an
     // empty asm definition instead of the zeroes makes the compiler wait for whatever is in flight at that point (behind stage O's
@@ -4521,13 +4521,14 @@ int vox_launch_talker_mlp(hipStream_t st, const TalkerMlpCall& c) {
         a.poll_sleep = psl < 1 ? 1 : (psl > 64 ? 64 : psl);
         if (c.layer_tab) {
             // every layer in ONE launch (<= 256 visible tokens); granules: x' 1024 | h 3072 | attention row 1024 | q k v 2048
-            if (ac.max_kvlen > 8 * VOX_TC || c.n_layers < 1) return vox_fail(VOX_ERR_INVALID, "talker_mlp: all-layer form needs <= 256 visible tokens");
+            if (c.n_layers < 1) return vox_fail(VOX_ERR_INVALID, "talker_mlp: all-layer form without layers");
             if (!ac.qn || !ac.kn || !ac.cs) return vox_fail(VOX_ERR_INVALID, "talker_mlp: all-layer form needs head norms and a RoPE table");
             a.tab = (const TalkerLayerW*)c.layer_tab; a.n_layers = c.n_layers; a.kv_layer_stride = c.kv_layer_stride;
             a.gq = a.gx + 5120;
             const int d2 = [] { const char* e = getenv("VOX_TALKER_MULTI_DELAY"); return e ? atoi(e) : 8; }();
             a.burst_delay |= (d2 < 0 ? 0 : (d2 > 64 ? 64 : d2)) << 8;
-            hipLaunchKernelGGL((k_talker_mlp<8, true>), dim3(256), dim3(512), 0, st, a);
+            if (ac.max_kvlen <= 8 * VOX_TC) hipLaunchKernelGGL((k_talker_mlp<8, true>), dim3(256), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((k_talker_mlp<16, true>), dim3(256), dim3(512), 0, st, a);
             return VOX_OK;
         }
         if (ac.max_kvlen <= 8 * VOX_TC) hipLaunchKernelGGL(k_talker_mlp<8>, dim3(256), dim3(512), 0, st, a);
