@@ -3761,7 +3761,10 @@ __global__ __launch_bounds__(512) void k_depth_step(DepthStepArgs a) {
 // stage — same lane -> chunk assignment, dot8 / butterfly<64> order and rounding points: bit-identical to the launch chain.
 //   stage O  x'  = x + Wo . attn                                  1024 column pairs: waves 0..3
 //   stage C  h   = silu(Wg . n) * (Wu . n),  n = rmsnorm(x', ln2)  3072 pairs: every wave one, waves 0..3 a second one
-//   stage D  x'' = x' + Wd . h                                    1024 pairs: waves 0..3, plain stores (a kernel boundary follows)
+//   stage D  x'' = x' + Wd . h                                    1024 pairs: waves 4..7 (round 6: rows requested when x' is gathered)
+//   stage A  qkv = Wqkv' . rmsnorm(x'', ln1')                      the NEXT layer's projection, 2048 pairs: every wave one
+// Round 6: the layer's decode attention in blocks 0..15 of the launch (ATTN, <= 256 visible tokens), and then every layer of the stack
+// in the launch (MULTI: a do-while over the layer table; q | k | v reach the next layer's attention blocks as granules).
 // ================================================================================================
 // The one-launch decode attention (k_attn_decode8's arithmetic, chunk by chunk and merge, bit for bit) as a device function for a
 // block of NT threads inside a persistent kernel: NG groups of NT / NG threads (512 threads, 8 chunks: one wave per chunk), LDS in
